@@ -1,0 +1,104 @@
+"""Pin the CPU oracle against golden vectors produced by the reference itself (tools/gen_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qwen2, vit, vla as ovla, vlm as ovlm
+
+
+def _check(d, prefix, t, rtol=2e-4, atol=2e-5):
+    f = t.detach().float().flatten()
+    assert list(t.shape) == list(d[prefix + '_shape'])
+    got = f[torch.from_numpy(d[prefix + '_idx'])].numpy()
+    np.testing.assert_allclose(got, d[prefix + '_val'], rtol=rtol, atol=atol)
+    st = d[prefix + '_stats']
+    dd = t.detach().double()
+    np.testing.assert_allclose([dd.mean().item(), dd.abs().mean().item(), dd.norm().item()], st, rtol=1e-4, atol=1e-6)
+
+
+@pytest.fixture(scope='module')
+def g56(golden_dir):
+    return np.load(os.path.join(golden_dir, 'g5g6_vlm.npz'))
+
+
+def _inputs(seed, d):
+    g = torch.Generator().manual_seed(seed)
+    pv = torch.randn(1, 3, 448, 448, generator=g)
+    return pv, torch.from_numpy(d['input_ids'])
+
+
+def test_pixel_shuffle_bit_exact(golden_dir):
+    d = np.load(os.path.join(golden_dir, 'g3g4_shuffle_masks.npz'))
+    x = torch.arange(2 * 32 * 32 * 8, dtype=torch.float32).reshape(2, 32, 32, 8)
+    y = vit.pixel_shuffle(x, 0.5, 'v2')
+    assert np.array_equal(y.numpy().astype(np.int32), d['ps_out'])
+    # closed form from SURVEY §8 a5: out[n,i,j,a*2C+b*C+k] = x[n,2i+a,2j+b,k]
+    C = 8
+    for (i, j, a, b, k) in [(0, 0, 0, 0, 0), (3, 5, 1, 0, 2), (15, 15, 1, 1, 7), (7, 0, 0, 1, 4)]:
+        assert y[1, i, j, a * 2 * C + b * C + k] == x[1, 2 * i + a, 2 * j + b, k]
+
+
+def test_vla_masks_bit_exact(golden_dir, golden_model):
+    _, vla, _ = golden_model
+    d = np.load(os.path.join(golden_dir, 'g3g4_shuffle_masks.npz'))
+    for n_valid in (277, 384, 1, 300):
+        am = torch.zeros(2, 384, dtype=torch.long)
+        am[0, :n_valid] = 1
+        am[1, :max(1, n_valid - 17)] = 1
+        m, vp, pp, ap = ovla.build_causal_mask_and_position_ids(am, torch.float32, vla)
+        assert set(m.unique().tolist()) <= {0.0, torch.finfo(torch.float32).min}
+        assert np.array_equal((m == 0).numpy().astype(np.uint8), d[f'mask_{n_valid}_zero'])
+        m1, m2 = ovla.split_full_mask_into_submasks(m, vla)
+        assert list(m1.shape) + list(m2.shape) == list(d[f'mask_{n_valid}_sub_shapes'])
+        assert np.array_equal((m1 == 0).numpy().astype(np.uint8), d[f'mask_{n_valid}_sub1_zero'])
+        assert np.array_equal((m2 == 0).numpy().astype(np.uint8), d[f'mask_{n_valid}_sub2_zero'])
+        assert np.array_equal(vp.numpy(), d[f'pos_{n_valid}_vlm'])
+        assert np.array_equal(pp.numpy(), d[f'pos_{n_valid}_pro'])
+        assert np.array_equal(ap.numpy(), d[f'pos_{n_valid}_act'])
+
+
+def test_vit_and_projector(g56, golden_model):
+    cfg, _, sd = golden_model
+    pv, _ = _inputs(0, g56)
+    emb = vit.embeddings(sd, cfg.vision, pv)
+    _check(g56, 'vit_emb', emb)
+    h, layers = vit.vision_forward(sd, cfg.vision, pv, return_layers=True)
+    for i, l in enumerate(layers):
+        _check(g56, f'vit_l{i}', l)
+    _check(g56, 'vit_feat', vit.extract_feature(sd, cfg, pv))
+
+
+def test_vlm_logits_loss_greedy(g56, golden_model):
+    cfg, _, sd = golden_model
+    pv, ids = _inputs(0, g56)
+    logits = ovlm.forward_logits(sd, cfg, pv, ids)
+    _check(g56, 'logits', logits[:, -4:], rtol=5e-4, atol=5e-5)
+    top = logits[0, -1].topk(8)
+    assert np.array_equal(top.indices.numpy(), g56['last_top_ids'])
+    np.testing.assert_allclose(top.values.numpy(), g56['last_top_vals'], rtol=1e-4, atol=1e-5)
+    labels = torch.full_like(ids, -100)
+    labels[0, -16:] = ids[0, -16:]
+    np.testing.assert_allclose(ovlm.sft_loss(logits, labels).item(), float(g56['sft_loss']), rtol=1e-5)
+    gen, lg = ovlm.generate(sd, cfg, pv, ids, max_new_tokens=8, eos_token_id=None, return_logits=True)
+    assert np.array_equal(gen.numpy(), g56['greedy_ids'])
+    np.testing.assert_allclose(lg[0].topk(4, dim=-1).values.numpy(), g56['greedy_top_vals'], rtol=1e-4, atol=2e-5)
+
+
+def test_infer_action(golden_dir, golden_model):
+    _, vla, sd = golden_model
+    d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))
+    for case in ('a', 'b'):
+        seed = int(d[f'{case}_seed'])
+        g = torch.Generator().manual_seed(seed)
+        pv = torch.randn(1, 3, 448, 448, generator=g)
+        ids = torch.from_numpy(d[f'{case}_input_ids'])
+        am = (ids != vla.base.pad_token_id).long()
+        assert int(am.sum()) == int(d[f'{case}_n_valid'])
+        m, vp, pp, ap = ovla.build_causal_mask_and_position_ids(am, torch.float32, vla)
+        m1, m2 = ovla.split_full_mask_into_submasks(m, vla)
+        act = ovla.infer_action(sd, vla, ids, pv, m1, m2, vp, pp, ap, torch.from_numpy(d[f'{case}_proprio']),
+                                torch.from_numpy(d[f'{case}_noise']))
+        np.testing.assert_allclose(act.numpy(), d[f'{case}_action'], rtol=0, atol=2e-5)

@@ -1,0 +1,347 @@
+"""Generate golden vectors under tests/golden/ by running the REFERENCE's own code (build container only).
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz|json
+
+The reference is imported from /root/reference through tools/ref_import.py (stubs for packages that are not
+installed).  Weights come from vlaser_amd.synth (deterministic integer hash, identical on CPU and GPU) and are
+loaded into the reference modules with strict key matching, which also pins the checkpoint key names.
+Models use the true Vlaser-2B widths with truncated depth so that fixtures stay small and the CPU oracle
+replays them in seconds.  Fixtures hold inputs' seeds and output slices only -- never reference source.
+"""
+import copy
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_import  # noqa: E402
+
+ref_import.install()
+from internvl.model.internvl_chat import InternVLChatModel, InternVLChatConfig  # noqa: E402
+from internvl.conversation import get_conv_template  # noqa: E402
+from internvl.train.dataset import preprocess_internvl2_5, dynamic_preprocess, find_closest_aspect_ratio  # noqa: E402
+from src.model.vla import pizero_internvl as RP  # noqa: E402
+from src.model.vla.joint_model import JointModel  # noqa: E402
+from src.model.vla.modules import ActionEncoder, SinusoidalPosEmb  # noqa: E402
+from src.model.kv_cache import KVCache  # noqa: E402
+from transformers import Qwen2ForCausalLM  # noqa: E402
+
+from vlaser_amd import config as C, synth  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+torch.set_grad_enabled(False)
+
+VIT_L, LLM_L = 2, 2
+
+
+def ref_config(cfg: C.VlaserConfig):
+    raw = json.load(open(ref_import.TOK_DIR + '/config.json'))
+    for k in ('architectures', 'auto_map', 'model_type', '_commit_hash', '_name_or_path',
+              'transformers_version', 'torch_dtype'):
+        raw.pop(k, None)
+    l = raw['llm_config']
+    l.update(hidden_size=cfg.llm.hidden_size, intermediate_size=cfg.llm.intermediate_size,
+             num_hidden_layers=cfg.llm.num_hidden_layers, num_attention_heads=cfg.llm.num_attention_heads,
+             num_key_value_heads=cfg.llm.num_key_value_heads, vocab_size=cfg.llm.vocab_size)
+    raw['vision_config']['drop_path_rate'] = 0.0
+    raw['vision_config']['num_hidden_layers'] = cfg.vision.num_hidden_layers
+    return InternVLChatConfig(**raw)
+
+
+def build_ref_vlm(cfg, sd):
+    rc = ref_config(cfg)
+    m = InternVLChatModel(rc, use_flash_attn=False).eval()
+    m.language_model.config._attn_implementation = 'eager'
+    missing = m.load_state_dict(sd, strict=True)
+    print('ref VLM loaded', missing)
+    return m
+
+
+def subsample(t, n=4096):
+    f = t.detach().float().flatten()
+    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel())).long()
+    return idx.numpy().astype(np.int64), f[idx].numpy()
+
+
+def stats(t):
+    f = t.detach().double()
+    return np.array([f.mean().item(), f.abs().mean().item(), f.norm().item()])
+
+
+def pack(prefix, t, d):
+    idx, val = subsample(t)
+    d[prefix + '_idx'] = idx
+    d[prefix + '_val'] = val
+    d[prefix + '_stats'] = stats(t)
+    d[prefix + '_shape'] = np.array(t.shape)
+
+
+# ----------------------------------------------------------------------------------------------- G1: prompts
+def g1_prompts(tok):
+    out = {}
+    m = types.SimpleNamespace(template='internvl2_5', num_image_token=256)
+    sysmsg = get_conv_template('internvl2_5').system_message
+
+    def chat_query(question, num_patches_list):
+        # the reference's own string assembly: modeling_internvl_chat.py:347-375
+        if '<image>' not in question:
+            question = '<image>\n' + question
+        t = get_conv_template('internvl2_5')
+        t.system_message = sysmsg
+        t.append_message(t.roles[0], question)
+        t.append_message(t.roles[1], None)
+        q = t.get_prompt()
+        for n in num_patches_list:
+            q = q.replace('<image>', '<img>' + '<IMG_CONTEXT>' * 256 * n + '</img>', 1)
+        return q
+    cases = {'chat_1tile': ('What objects are on the table and where should the robot move next?', [1]),
+             'chat_13tiles': ('Point to the red cup.', [13])}
+    for name, (q, npl) in cases.items():
+        s = chat_query(q, npl)
+        ids = tok(s, return_tensors='pt')['input_ids'][0]
+        out[name] = dict(question=q, num_patches_list=npl, prompt_sha=_sha(s), prompt_head=s[:120],
+                         prompt_tail=s[-80:], n_tokens=int(ids.numel()),
+                         ids_nonimg=[int(x) for x in ids[ids != 151667]],
+                         img_first=int((ids == 151667).nonzero()[0]), img_count=int((ids == 151667).sum()),
+                         img_contiguous=bool(((ids == 151667).nonzero().flatten().diff() == 1).all()))
+    # VLA prompt: processing.py:358-363 (system "None", right-padded to 384 with <|endoftext|>)
+    from src.model.vla.processing import InternVLAProcessor
+    os.environ['IMAGE_448'] = '1'
+    proc = InternVLAProcessor(tok, num_image_tokens=256, max_seq_len=384, tokenizer_padding='max_length')
+    tok.padding_side = 'right'
+    img = torch.zeros(1, 1, 3, 448, 448, dtype=torch.uint8)     # [B, n_img, 3, H, W] (processing.py:40)
+    img[0, 0, 0] = 255; img[0, 0, 1] = 128; img[0, 0, 2, :100] = 7
+    for name, text in {'vla_spoon': 'put the spoon on the towel', 'vla_carrot': 'put carrot on plate'}.items():
+        r = proc([text], img)
+        ids = r['input_ids'][0]
+        out[name] = dict(text=text, ids_nonimg=[int(x) for x in ids[ids != 151667]],
+                         n_valid=int(r['attention_mask'][0].sum()), img_first=int((ids == 151667).nonzero()[0]),
+                         img_count=int((ids == 151667).sum()),
+                         pixel_probe=[float(r['pixel_values'][0, c, 0, 0]) for c in range(3)] +
+                                     [float(r['pixel_values'][0, 2, 50, 0])])
+    out['system_message'] = sysmsg
+    out['special'] = {t: int(tok.convert_tokens_to_ids(t)) for t in
+                      ['<IMG_CONTEXT>', '<img>', '</img>', '<|im_end|>', '<|endoftext|>', '<|im_start|>']}
+    out['vocab_len'] = len(tok)
+    # SFT label masking (preprocess_internvl2_5, dataset.py:711-810)
+    src = [[{'from': 'human', 'value': '<image>\nWhat is this?'}, {'from': 'gpt', 'value': 'A cat.'}]]
+    tok.model_max_length = 4096
+    r = preprocess_internvl2_5('internvl2_5', copy.deepcopy(src), tok, [256], group_by_length=True, ds_name='g', num_image=1)
+    ids, lab = r['input_ids'][0], r['labels'][0]
+    out['sft_sample'] = dict(n_tokens=int(ids.numel()), ids_nonimg=[int(x) for x in ids[ids != 151667]],
+                             supervised_pos=[int(i) for i in (lab != -100).nonzero().flatten()],
+                             supervised_ids=[int(x) for x in lab[lab != -100]])
+    json.dump(out, open(os.path.join(OUT, 'g1_prompts.json'), 'w'), ensure_ascii=False, indent=1)
+    print('G1 ok', {k: v.get('n_tokens', v.get('n_valid')) for k, v in out.items() if isinstance(v, dict) and 'ids_nonimg' in v})
+
+
+def _sha(s):
+    import hashlib
+    return hashlib.sha256(s.encode('utf-8')).hexdigest()
+
+
+# ----------------------------------------------------------------------------------------------- G2: tiling
+def g2_tiling():
+    from PIL import Image
+    rows = []
+    for (w, h) in [(640, 480), (1920, 1080), (1000, 300), (448, 448), (300, 1000), (224, 224), (800, 800),
+                   (1280, 720), (720, 1280), (2000, 500), (500, 2000), (449, 448), (1344, 896), (33, 4000)]:
+        for max_num in (6, 12):
+            img = Image.new('RGB', (w, h))
+            tiles = dynamic_preprocess(img, min_num=1, max_num=max_num, image_size=448, use_thumbnail=True)
+            target_ratios = sorted(set((i, j) for n in range(1, max_num + 1) for i in range(1, n + 1)
+                                       for j in range(1, n + 1) if 1 <= i * j <= max_num),
+                                   key=lambda x: x[0] * x[1])
+            grid = find_closest_aspect_ratio(w / h, target_ratios, w, h, 448)
+            rows.append(dict(w=w, h=h, max_num=max_num, n_tiles=len(tiles), grid=list(grid)))
+    json.dump(rows, open(os.path.join(OUT, 'g2_tiling.json'), 'w'), indent=0)
+    print('G2 ok', rows[:3])
+
+
+# ----------------------------------------------------------------------------------------------- G3 / G4
+def g3_g4(ref_vlm):
+    x = torch.arange(2 * 32 * 32 * 8, dtype=torch.float32).reshape(2, 32, 32, 8)
+    y = ref_vlm.pixel_shuffle(x, scale_factor=0.5)
+    d = {'ps_in_shape': np.array(x.shape), 'ps_out': y.numpy().astype(np.int32)}
+    fake = types.SimpleNamespace(max_image_text_tokens=384, num_proprio_tokens=1, num_action_tokens=4,
+                                 debug_causal=False)
+    for n_valid in (277, 384, 1, 300):
+        am = torch.zeros(2, 384, dtype=torch.long)
+        am[0, :n_valid] = 1
+        am[1, :max(1, n_valid - 17)] = 1
+        mask, vp, pp, ap = RP.PiZero.build_causal_mask_and_position_ids(fake, am, torch.float32)
+        m1, m2 = RP.PiZero.split_full_mask_into_submasks(fake, mask)
+        d[f'mask_{n_valid}_zero'] = (mask == 0).numpy().astype(np.uint8)       # structure; values are 0 or finfo.min
+        assert set(mask.unique().tolist()) <= {0.0, torch.finfo(torch.float32).min}
+        d[f'mask_{n_valid}_sub_shapes'] = np.array(list(m1.shape) + list(m2.shape))
+        d[f'mask_{n_valid}_sub1_zero'] = (m1 == 0).numpy().astype(np.uint8)
+        d[f'mask_{n_valid}_sub2_zero'] = (m2 == 0).numpy().astype(np.uint8)
+        d[f'pos_{n_valid}_vlm'] = vp.numpy(); d[f'pos_{n_valid}_pro'] = pp.numpy(); d[f'pos_{n_valid}_act'] = ap.numpy()
+    np.savez_compressed(os.path.join(OUT, 'g3g4_shuffle_masks.npz'), **d)
+    print('G3/G4 ok')
+
+
+# ----------------------------------------------------------------------------------------------- G5 / G6
+def make_inputs(cfg, seed, n_tiles, n_text, tok_specials=True):
+    g = torch.Generator().manual_seed(seed)
+    pv = torch.randn(n_tiles, 3, 448, 448, generator=g)
+    # 48 "template" ids + 256*T image + n_text random text ids (SURVEY §8d synthetic prompt)
+    pre = torch.randint(0, 151643, (41,), generator=g)
+    post = torch.randint(0, 151643, (7 + n_text,), generator=g)
+    ids = torch.cat([pre, torch.full((256 * n_tiles,), 151667), post])[None]
+    return pv, ids
+
+
+def g5_g6(cfg, sd, ref_vlm):
+    d = {}
+    pv, ids = make_inputs(cfg, seed=0, n_tiles=1, n_text=32)
+    d['seed'] = np.array(0); d['input_ids'] = ids.numpy()
+    # G5a: ViT embeddings / per-layer / extract_feature
+    emb = ref_vlm.vision_model.embeddings(pv)
+    pack('vit_emb', emb, d)
+    h = emb
+    for i, layer in enumerate(ref_vlm.vision_model.encoder.layers):
+        h = layer(h)
+        pack(f'vit_l{i}', h, d)
+    feat = ref_vlm.extract_feature(pv)
+    pack('vit_feat', feat, d)
+    # G5b: LLM logits for the full prompt (forward with labels=None path) -- via language_model
+    ref_vlm.img_context_token_id = 151667
+    out = ref_vlm(pixel_values=pv, input_ids=ids, attention_mask=torch.ones_like(ids),
+                  image_flags=torch.ones(1, 1, dtype=torch.long), return_dict=True)
+    logits = out.logits
+    pack('logits', logits[:, -4:], d)
+    top = logits[0, -1].topk(8)
+    d['last_top_vals'] = top.values.numpy(); d['last_top_ids'] = top.indices.numpy()
+    # SFT loss (labels on the last 16 positions)
+    labels = torch.full_like(ids, -100); labels[0, -16:] = ids[0, -16:]
+    out2 = ref_vlm(pixel_values=pv, input_ids=ids, attention_mask=torch.ones_like(ids),
+                   image_flags=torch.ones(1, 1, dtype=torch.long), labels=labels, return_dict=True)
+    d['sft_loss'] = np.array(out2.loss.item())
+    # G6: greedy ids (reference generate -> HF GenerationMixin)
+    gen = ref_vlm.generate(pixel_values=pv, input_ids=ids, attention_mask=torch.ones_like(ids),
+                           max_new_tokens=8, min_new_tokens=8, do_sample=False, eos_token_id=151645,
+                           pad_token_id=151643, output_scores=True, return_dict_in_generate=True)
+    d['greedy_ids'] = gen.sequences.numpy()
+    sc = torch.stack(gen.scores, dim=1)[0]           # [8, V]
+    t2 = sc.topk(2, dim=-1).values
+    d['greedy_margin'] = (t2[:, 0] - t2[:, 1]).numpy()
+    d['greedy_top_vals'] = sc.topk(4, dim=-1).values.numpy()
+    np.savez_compressed(os.path.join(OUT, 'g5g6_vlm.npz'), **d)
+    print('G5/G6 ok greedy', d['greedy_ids'], 'margins', d['greedy_margin'], 'loss', d['sft_loss'])
+
+
+# ----------------------------------------------------------------------------------------------- G7: infer_action
+class _FakeJoint:
+    """Carries exactly the attributes JointModel.forward / build_mixture_caches read (joint_model.py:702-814)."""
+
+    def __init__(self, mixtures, n_layers):
+        self.mixtures = mixtures
+        self.num_hidden_layers = n_layers
+        self.backbone_type = 'INTERNVL'
+        self.use_flash_attention = False
+        self.stop_grad_to_vlm = False
+        self.training = False
+        self.cache_names = ['vlm', 'proprio']
+
+    def build_mixture_caches(self):
+        return JointModel.build_mixture_caches(self)
+
+    def __call__(self, **kw):
+        return JointModel.forward(self, **kw)
+
+
+class _Mix(torch.nn.Module):
+    def __init__(self, layers, norm):
+        super().__init__()
+        self.layers, self.norm = layers, norm
+
+    def forward_norm(self, x, cond=None):
+        return self.norm(x)
+
+
+def g7_vla(vla, sd, ref_vlm):
+    ecfg = copy.deepcopy(ref_vlm.config.llm_config)
+    ecfg.hidden_size = vla.action_hidden_size; ecfg.intermediate_size = vla.action_intermediate_size
+    ecfg.head_dim = 128
+    expert = Qwen2ForCausalLM(ecfg).eval()
+    expert.config._attn_implementation = 'eager'
+    esd = {k[len('action_expert.'):]: v for k, v in sd.items() if k.startswith('action_expert.')}
+    r = expert.load_state_dict(esd, strict=False)
+    assert set(r.missing_keys) <= {'model.embed_tokens.weight', 'lm_head.weight'} and not r.unexpected_keys, r
+    W = vla.action_hidden_size
+    aenc = ActionEncoder(7, W, time_cond=True)
+    aenc.load_state_dict({k[len('action_encoder.'):]: v for k, v in sd.items() if k.startswith('action_encoder.')})
+    pro = torch.nn.Linear(7, W); pro.load_state_dict({'weight': sd['proprio_encoder.weight'], 'bias': sd['proprio_encoder.bias']})
+    dec = torch.nn.Linear(W, 7); dec.load_state_dict({'weight': sd['action_decoder.weight'], 'bias': sd['action_decoder.bias']})
+    vlm_mix = _Mix(ref_vlm.language_model.model.layers, ref_vlm.language_model.model.norm)
+    act_mix = _Mix(expert.model.layers, expert.model.norm)
+    mixtures = torch.nn.ModuleDict({'vlm': vlm_mix, 'proprio': act_mix, 'action': act_mix})
+    fake = types.SimpleNamespace(
+        num_images=1, imgfeat=False, image_448=True, no_img=False, image_token_index=151667, pad_token_id=151643,
+        joint_model=_FakeJoint(mixtures, vla.base.llm.num_hidden_layers),
+        embed_tokens=ref_vlm.language_model.model.embed_tokens,
+        vision_tower=lambda pv: ref_vlm.vision_model(pixel_values=pv, return_dict=True),
+        multi_modal_projector=ref_vlm.mlp1, proprio_encoder=pro,
+        internvl_model=types.SimpleNamespace(language_model=ref_vlm.language_model, action_expert=expert),
+        horizon_steps=vla.num_action_tokens, action_dim=7, num_inference_steps=vla.num_inference_steps,
+        time_embedding=SinusoidalPosEmb(W, vla.time_max_period), action_expert_adaptive_mode=None,
+        action_encoder=aenc, action_decoder=dec, integration_method='euler',
+        final_action_clip_value=vla.final_action_clip_value, cfg=types.SimpleNamespace(horizon_steps=vla.horizon_steps),
+        max_image_text_tokens=384, num_proprio_tokens=1, num_action_tokens=4, debug_causal=False)
+    fake.pixel_shuffle = types.MethodType(RP.PiZero.pixel_shuffle, fake)
+    fake._forward_siglip_and_text_embedding = types.MethodType(RP.PiZero._forward_siglip_and_text_embedding, fake)
+
+    d = {}
+    for case, (seed, n_valid) in {'a': (0, 277), 'b': (1, 300)}.items():
+        g = torch.Generator().manual_seed(seed)
+        pv = torch.randn(1, 3, 448, 448, generator=g)
+        ids = torch.full((1, 384), 151643)
+        n_text = n_valid - 10 - 256
+        ids[0, :10] = torch.randint(0, 151643, (10,), generator=g)
+        ids[0, 10:266] = 151667
+        ids[0, 266:266 + n_text] = torch.randint(0, 151643, (n_text,), generator=g)
+        am = (ids != 151643).long()
+        proprio = torch.rand(1, 1, 7, generator=g) * 2 - 1
+        mask, vp, pp, ap = RP.PiZero.build_causal_mask_and_position_ids(fake, am, torch.float32)
+        m1, m2 = RP.PiZero.split_full_mask_into_submasks(fake, mask)
+        torch.manual_seed(1234 + seed)
+        noise = torch.randn(1, 4, 7)
+        torch.manual_seed(1234 + seed)
+        act = RP.PiZero.infer_action(fake, ids, pv, m1, m2, vp, pp, ap, proprio)
+        d[f'{case}_seed'] = np.array(seed); d[f'{case}_n_valid'] = np.array(n_valid)
+        d[f'{case}_input_ids'] = ids.numpy(); d[f'{case}_proprio'] = proprio.numpy()
+        d[f'{case}_noise'] = noise.numpy(); d[f'{case}_action'] = act.numpy()
+        print('G7', case, act)
+    np.savez_compressed(os.path.join(OUT, 'g7_vla.npz'), **d)
+    return fake
+
+
+def main():
+    tok = ref_import.tokenizer()
+    g1_prompts(tok)
+    g2_tiling()
+    cfg = C.truncated(C.vlaser_2b(), VIT_L, LLM_L)
+    vla = C.VLAConfig(base=cfg)
+    sd = synth.vla_state_dict(vla, with_head=True)
+    vlm_sd = {k: v for k, v in sd.items() if k.startswith(('vision_model.', 'mlp1.', 'language_model.'))}
+    ref_vlm = build_ref_vlm(cfg, vlm_sd)
+    g3_g4(ref_vlm)
+    g5_g6(cfg, sd, ref_vlm)
+    g7_vla(vla, sd, ref_vlm)
+    meta = dict(vit_layers=VIT_L, llm_layers=LLM_L, widths='vlaser-2b', weights='vlaser_amd.synth seed 0',
+                torch=torch.__version__, transformers=__import__('transformers').__version__,
+                generated_by='tools/gen_golden.py (imports /root/reference)')
+    json.dump(meta, open(os.path.join(OUT, 'META.json'), 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()
