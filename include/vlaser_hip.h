@@ -1,0 +1,160 @@
+/*
+ * libvlaser_hip.so -- C ABI of the MI355X-native (gfx950) Vlaser forward hot path.
+ *
+ * The reference (OpenGVLab/Vlaser) is pure Python and has no FFI of its own; its operator seams
+ * are Python duck-typing.  This header is the C-ABI the seams bind to through ctypes
+ * (vlaser_amd/_lib.py; INTEGRATION.md shows the reference-side stubs).  Each entry point cites the reference
+ * function it replaces.
+ *
+ * Conventions: every pointer is a DEVICE pointer owned by the caller (PyTorch allocates); bf16 tensors are raw
+ * uint16 bits; kernels are asynchronous on `stream`, never allocate, never synchronise; return 0 on success,
+ * negative on error (vlaser_last_error() gives the message).  Thread-safe w.r.t. distinct streams.
+ */
+#ifndef VLASER_HIP_H
+#define VLASER_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vl_stream_t; /* hipStream_t */
+
+const char* vlaser_last_error(void);
+int vlaser_abi_version(void);
+
+/* ---- GEMM: out = epilogue(A[M,K] @ W[N,K]^T), bf16 in, fp32 accumulate on MFMA ------------------------------
+ * replaces nn.Linear / F.linear call sites: modeling_intern_vit.py:196,208,256-257 (qkv, proj, fc1, fc2),
+ * modeling_internvl_chat.py:91-93 (mlp1), HF Qwen2Attention q/k/v/o_proj and Qwen2MLP gate/up/down
+ * (joint_model.py:449-450,573-578,694; modeling_internvl_chat.py:194-203). */
+enum {
+  VL_EPI_NONE = 0,       /* out = acc                                              */
+  VL_EPI_BIAS = 1,       /* out = acc + bias[n]                                    */
+  VL_EPI_BIAS_GELU = 2,  /* out = gelu_erf(acc + bias[n])                          */
+  VL_EPI_BIAS_LS_RES = 3,/* out = res[m,n] + ls[n]*(acc + bias[n])   (ViT layer-scale residual, :291-293) */
+  VL_EPI_RES = 4,        /* out = res[m,n] + acc                     (Qwen2 residual) */
+  VL_EPI_SWIGLU = 5,     /* W = gate/up interleaved in 16-row groups; out[m, n/2] = silu(g)*u */
+  VL_EPI_QKV_ROPE = 6,   /* fused q/k/v projection + bias + RoPE + KV-cache write (Qwen2, head_dim 128) */
+  VL_EPI_VIT_QKV = 7,    /* fused ViT qkv + bias, q*scale; writes Q,K [T,H,S,64] and V^T [T,H,64,Spad] */
+  VL_EPI_F32 = 8         /* out (float32) = acc   (full-vocab logits) */
+};
+
+typedef struct {
+  const void* A; const void* W; void* out;
+  int M, N, K;
+  int lda, ldw, ldo;
+  const void* bias;   /* bf16 [N] */
+  const void* res;    /* bf16 [M, ldo] */
+  const void* ls;     /* bf16 [N] */
+  /* VL_EPI_QKV_ROPE */
+  void* q_out;              /* bf16 [M, n_q_heads*128] */
+  void* k_cache;            /* bf16 [B, n_kv, S_max, 128] */
+  void* vt_cache;           /* bf16 [B, n_kv, 128, S_max]  (V transposed) */
+  const float* rope_cos;    /* fp32 [n_pos, 64] */
+  const float* rope_sin;
+  const int32_t* pos_ids;   /* int32 [M] */
+  int n_q_heads, n_kv_heads, s_max, tok_per_batch, slot_base;
+  /* VL_EPI_VIT_QKV */
+  void* vq; void* vk; void* vvt; int vit_heads, vit_seq, vit_seq_pad; float q_scale;
+} VlaserGemmArgs;
+
+int vlaser_gemm(int epi, const VlaserGemmArgs* args, vl_stream_t stream);
+
+/* ---- attention ------------------------------------------------------------------------------------------------
+ * vlaser_attn_prefill replaces FlashAttention.forward / InternAttention._naive_attn (modeling_intern_vit.py:51-96,
+ * 210-227; non-causal, hd 64) and HF eager_attention_forward / flash_attention_2 for Qwen2 prefill (causal GQA,
+ * hd 128; joint_model.py:631-656 with the vlm rows of the block mask).
+ * vlaser_attn_skinny replaces the same call for <=16 query tokens over the KV cache: the proprio row of the joint
+ * prefill, the 4 action tokens of every Euler step (pizero_internvl.py:896-908) and single-token greedy decode.
+ * Masks are passed as descriptors instead of dense [B,1,Sq,Skv] additive tensors (pizero_internvl.py:517-603):
+ * key j is visible to query row i iff  j < lim1(i)  ||  blk_start <= j < kv_len (rows >= blk_start only). */
+enum { VL_ATTN_FULL = 0, VL_ATTN_CAUSAL = 1, VL_ATTN_PREFIX = 2 };
+
+typedef struct {
+  const void* q;   /* bf16, element (b,h,s,d) at q + b*q_bs + h*q_hs + s*q_ss + d */
+  const void* k;   /* bf16 [B, n_kv, S_max, hd]:  b*k_bs + kvh*k_hs + s*hd + d (RoPE already applied) */
+  const void* vt;  /* bf16 [B, n_kv, hd, ld_vt]:  b*vt_bs + kvh*vt_hs + d*ld_vt + s  (V transposed, zero padded) */
+  void* out;       /* bf16: b*o_bs + s*o_ss + h*hd + d */
+  int batch, sq, kv_len, n_q_heads, n_kv_heads, head_dim;
+  long long q_bs, q_hs, q_ss, k_bs, k_hs, vt_bs, vt_hs, o_bs, o_ss;
+  int ld_vt;
+  float scale;
+  int mode;                 /* VL_ATTN_* */
+  int causal_off;           /* CAUSAL: row i sees keys <= i + causal_off */
+  const int32_t* valid_len; /* PREFIX: int32 [B] valid image/text prefix length (device) */
+  int blk_start;            /* PREFIX: first key of the proprio/action block */
+  int q_row_off;            /* PREFIX: global row index of query row 0 */
+} VlaserAttnArgs;
+
+int vlaser_attn_prefill(const VlaserAttnArgs* args, vl_stream_t stream);
+int vlaser_attn_skinny(const VlaserAttnArgs* args, vl_stream_t stream);
+
+/* ---- skinny (M <= 16 rows) weight-streaming GEMV on MFMA, HBM-bound --------------------------------------------
+ * out = epilogue( prologue(x)[M,K] @ W[N,K]^T ).  Replaces the same nn.Linear call sites as vlaser_gemm when the
+ * activation has <= 16 rows: every layer of the 10 Euler steps (joint_model.py:140-232 with only the action
+ * mixture active) and of greedy decode, plus lm_head on the last position (modeling_internvl_chat.py:204).
+ * Prologue VL_PRO_NORM fuses: residual + split-K partial reduction of the producer, bf16 rounding of the residual
+ * stream, Qwen2RMSNorm.  Split-K partials are reduced by the CONSUMER's prologue (deterministic, no atomics). */
+enum { VL_PRO_PLAIN = 0, VL_PRO_NORM = 1 };
+enum {
+  VL_SK_PARTIAL = 0,   /* out_f32[ks, m, n] = partial over this block's K slice */
+  VL_SK_QKV_ROPE = 1,  /* as VL_EPI_QKV_ROPE */
+  VL_SK_SWIGLU = 2,    /* as VL_EPI_SWIGLU */
+  VL_SK_F32 = 3,       /* out_f32[m, n] = acc (+bias)   (logits) */
+  VL_SK_BIAS = 4,      /* out bf16 = acc + bias */
+  VL_SK_BIAS_SILU = 5  /* out bf16 = silu(acc + bias) */
+};
+
+typedef struct {
+  const void* x;          /* PLAIN: bf16 [M,K]; NORM: residual stream h_in bf16 [M,K] */
+  const float* partials;  /* NORM: fp32 [n_partials, M, K] added to h_in (may be null) */
+  int n_partials;
+  const void* norm_w;     /* NORM: bf16 [K] */
+  float eps;
+  void* h_out;            /* NORM: bf16 [M,K] = bf16(h_in + sum partials), written by block 0 (may be null) */
+  const void* W;          /* bf16 [N,K] */
+  int M, N, K, ldw;
+  int k_splits;           /* grid.y; K % (k_splits*128) == 0 */
+  float* out_f32;
+  void* out; int ldo;
+  const void* bias;       /* bf16 [N] */
+  /* VL_SK_QKV_ROPE (same meaning as in VlaserGemmArgs) */
+  void* q_out; void* k_cache; void* vt_cache;
+  const float* rope_cos; const float* rope_sin; const int32_t* pos_ids;
+  int n_q_heads, n_kv_heads, s_max, tok_per_batch, slot_base;
+} VlaserSkinnyArgs;
+
+int vlaser_skinny(int prologue, int epi, const VlaserSkinnyArgs* args, vl_stream_t stream);
+
+/* ---- memory-bound helpers -------------------------------------------------------------------------------------- */
+/* nn.LayerNorm (NORM2FN['layer_norm'], modeling_intern_vit.py:127-130,275-276) and Qwen2RMSNorm. bf16 [rows, C]. */
+int vlaser_layernorm(const void* x, const void* w, const void* b, void* out, int rows, int C, float eps, vl_stream_t stream);
+int vlaser_rmsnorm(const void* x, const void* w, void* out, int rows, int C, float eps, vl_stream_t stream);
+/* patch embedding as im2col (+ vlaser_gemm) and token assembly: InternVisionEmbeddings.forward
+ * (modeling_intern_vit.py:162-174).  pix bf16 [T,3,img,img] -> A bf16 [T*(img/14)^2, Kpad]. */
+int vlaser_im2col(const void* pix, void* A, int T, int img, int Kpad, vl_stream_t stream);
+int vlaser_vit_assemble(const void* patch, const void* cls, const void* pos, void* h, int T, int P, int C, vl_stream_t stream);
+/* pixel_shuffle (modeling_internvl_chat.py:257-271, drop CLS :284) fused with mlp1[0] LayerNorm (:89-94).
+ * x bf16 [T, G*G+1, C] -> out bf16 [T*(G/2)^2, 4C]. vlaser_pixel_shuffle is the bare permutation. */
+int vlaser_pixel_shuffle_ln(const void* x, const void* w, const void* b, void* out, int T, int G, int C, float eps, int ps_v1, vl_stream_t stream);
+int vlaser_pixel_shuffle(const void* x, void* out, int T, int G, int C, int ps_v1, vl_stream_t stream);
+/* embed_tokens + visual-token scatter (modeling_internvl_chat.py:418-427; VLA variant with zeroed pad rows
+ * pizero_internvl.py:757-791). ids int64 [n]; rank_ws int32 [n] receives the <IMG_CONTEXT> rank (or -1);
+ * count_out (optional, device int32) receives the number of <IMG_CONTEXT> tokens. */
+int vlaser_embed_merge(const int64_t* ids, int n, const void* embed, const void* vit, int n_vit_rows, void* out, int H,
+                       long long img_id, long long pad_id, int zero_pad, int32_t* rank_ws, int32_t* count_out, vl_stream_t stream);
+/* greedy argmax over fp32 logits [M,N] (GenerationMixin greedy step) + optional embedding gather of the winner. */
+int vlaser_argmax(const float* logits, int M, int N, int64_t* out_id, const void* embed, void* next_h, int H, vl_stream_t stream);
+/* pi0 head glue: SinusoidalPosEmb + ActionEncoder.linear_1 (modules.py:9-22,45-50); proprio_encoder
+ * (pizero_internvl.py:823); final norm + action_decoder + Euler update (+clamp) (pizero_internvl.py:911-932). */
+int vlaser_vla_prep(const float* action, const void* w1, const void* b1, void* xcat, int M, int W, int adim, float t, float max_period, vl_stream_t stream);
+int vlaser_small_linear(const float* x, const void* w, const void* b, void* out, int M, int N, int K, vl_stream_t stream);
+int vlaser_vla_euler(const void* h_in, const float* partials, int n_partials, int M, const void* norm_w, float eps, const void* wd,
+                     const void* bd, float* action, int W, int adim, float dt, float clip, int do_clip, float* vel_out, vl_stream_t stream);
+int vlaser_reduce_partials(const void* h_in, const float* partials, int n_partials, int M, int K, void* out, vl_stream_t stream);
+int vlaser_cast_f32_bf16(const float* x, void* y, long long n, vl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

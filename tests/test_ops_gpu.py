@@ -1,0 +1,371 @@
+"""Op-level parity of every C-ABI kernel against a plain PyTorch fp32 reference of the same op (GPU box only)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    from vlaser_amd import ops as o
+    return o
+
+
+def rnd(*shape, std=1.0, seed=0, dtype=BF):
+    g = torch.Generator(device='cpu').manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * std).to(dtype).cuda()
+
+
+def close(got, ref, rtol=1.6e-2, atol=None, name=''):
+    got, ref = got.float(), ref.float()
+    if atol is None:
+        atol = 1e-2 * ref.abs().max().item() + 1e-6
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    assert torch.isfinite(got).all(), f'{name}: non-finite output'
+    bad = (err > tol)
+    assert not bad.any(), f'{name}: {int(bad.sum())}/{bad.numel()} mismatches, max err {err.max().item():.4g} (ref max {ref.abs().max().item():.4g})'
+
+
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (1025, 1024, 1024), (385, 1536, 1536), (77, 4096, 1024), (300, 1536, 8960)])
+def test_gemm_plain_bias_gelu(ops, M, N, K):
+    from vlaser_amd import _lib as L
+    x, w, b = rnd(M, K), rnd(N, K, std=0.05), rnd(N, std=0.5)
+    ref = x.float() @ w.float().t()
+    close(ops.linear(x, w), ref, name='none')
+    close(ops.linear(x, w, b), ref + b.float(), name='bias')
+    close(ops.linear(x, w, b, epi=L.EPI_BIAS_GELU), F.gelu(ref + b.float()), name='gelu')
+    res, ls = rnd(M, N, seed=3), rnd(N, std=0.1, seed=4)
+    close(ops.linear(x, w, b, epi=L.EPI_BIAS_LS_RES, res=res, ls=ls), res.float() + ls.float() * (ref + b.float()), name='ls_res')
+    close(ops.linear(x, w, epi=L.EPI_RES, res=res), res.float() + ref, name='res')
+    out = res.clone()       # in-place residual
+    ops.linear(x, w, epi=L.EPI_RES, res=out, out=out)
+    close(out, res.float() + ref, name='res_inplace')
+
+
+def test_gemm_f32_edge_n(ops):
+    from vlaser_amd import _lib as L
+    M, N, K = 70, 1002, 1536        # N not a multiple of 4/16/128 (vocab-like edge)
+    x, w = rnd(M, K), rnd(N, K, std=0.05)
+    out = ops.linear(x, w, epi=L.EPI_F32)
+    close(out, x.float() @ w.float().t(), rtol=2e-3, atol=2e-3, name='f32')
+    outb = ops.linear(x, w)
+    close(outb, x.float() @ w.float().t(), name='bf16 edge')
+
+
+def test_gemm_transpose_detect(ops):
+    # A = I-like check with asymmetric W (guide: symmetric inputs hide a swapped C layout)
+    M = N = K = 128
+    x = torch.eye(M, dtype=BF).cuda()
+    w = (torch.arange(N * K).reshape(N, K) % 251).to(BF).cuda()
+    out = ops.linear(x, w)
+    assert torch.equal(out.float(), w.float().t())
+
+
+def test_gemm_swiglu(ops):
+    from vlaser_amd import _lib as L
+    M, I, K = 200, 8960, 1536
+    x, g, u = rnd(M, K), rnd(I, K, std=0.03, seed=1), rnd(I, K, std=0.03, seed=2)
+    packed = ops.pack_gate_up(g, u)
+    out = ops.linear(x, packed, epi=L.EPI_SWIGLU)
+    gr = (x.float() @ g.float().t()).to(BF).float()
+    ur = (x.float() @ u.float().t()).to(BF).float()
+    close(out, F.silu(gr).to(BF).float() * ur, name='swiglu')
+
+
+def _rope_ref(x, pos, theta=1e6):
+    # x [M, heads, 128] fp32
+    inv = 1.0 / (theta ** (torch.arange(0, 128, 2).float() / 128))
+    f = pos.float().cpu()[:, None] * inv[None]
+    cos, sin = torch.cat([f, f], -1).cos()[:, None].to(x.device), torch.cat([f, f], -1).sin()[:, None].to(x.device)
+    rot = torch.cat([-x[..., 64:], x[..., :64]], -1)
+    return x * cos + rot * sin
+
+
+def test_gemm_qkv_rope(ops):
+    from vlaser_amd import _lib as L
+    B, S, H, nq, nkv, smax = 2, 100, 1536, 12, 2, 192
+    M = B * S
+    x = rnd(M, H)
+    qw, kw, vw = rnd(nq * 128, H, std=0.03, seed=1), rnd(nkv * 128, H, std=0.03, seed=2), rnd(nkv * 128, H, std=0.03, seed=3)
+    qb, kb, vb = rnd(nq * 128, std=0.3, seed=4), rnd(nkv * 128, std=0.3, seed=5), rnd(nkv * 128, std=0.3, seed=6)
+    W, Bv = ops.pack_qkv(qw, kw, vw, qb, kb, vb)
+    cos, sin = ops.rope_table(512)
+    pos = (torch.arange(S).repeat(B) + 3).int().cuda()
+    q_out = torch.zeros(M, nq * 128, dtype=BF, device='cuda')
+    kc = torch.zeros(B, nkv, smax, 128, dtype=BF, device='cuda')
+    vtc = torch.zeros(B, nkv, 128, smax, dtype=BF, device='cuda')
+    ops.gemm(L.EPI_QKV_ROPE, x, W, bias=Bv, q_out=q_out, k_cache=kc, vt_cache=vtc, rope_cos=cos, rope_sin=sin, pos_ids=pos,
+             n_q_heads=nq, n_kv_heads=nkv, s_max=smax, tok_per_batch=S, slot_base=5)
+    xf = x.float()
+    q = (xf @ qw.float().t() + qb.float()).to(BF).float().view(M, nq, 128)
+    k = (xf @ kw.float().t() + kb.float()).to(BF).float().view(M, nkv, 128)
+    v = (xf @ vw.float().t() + vb.float()).to(BF).float().view(M, nkv, 128)
+    close(q_out.view(M, nq, 128), _rope_ref(q, pos.cpu().cuda()), name='q')
+    kr = _rope_ref(k, pos).view(B, S, nkv, 128).permute(0, 2, 1, 3)
+    close(kc[:, :, 5:5 + S], kr, name='k cache')
+    close(vtc[:, :, :, 5:5 + S], v.view(B, S, nkv, 128).permute(0, 2, 3, 1), name='vT cache')
+    assert kc[:, :, :5].abs().max() == 0 and kc[:, :, 5 + S:].abs().max() == 0
+    assert vtc[:, :, :, :5].abs().max() == 0 and vtc[:, :, :, 5 + S:].abs().max() == 0
+
+
+def test_gemm_vit_qkv(ops):
+    from vlaser_amd import _lib as L
+    T, S, C, Hn, Sp = 2, 130, 1024, 16, 192
+    x, w, b = rnd(T * S, C), rnd(3 * C, C, std=0.03), rnd(3 * C, std=0.3)
+    q = torch.zeros(T, Hn, Sp, 64, dtype=BF, device='cuda'); k = torch.zeros_like(q)
+    vt = torch.zeros(T, Hn, 64, Sp, dtype=BF, device='cuda')
+    ops.gemm(L.EPI_VIT_QKV, x, w, bias=b, vq=q, vk=k, vvt=vt, vit_heads=Hn, vit_seq=S, vit_seq_pad=Sp, q_scale=0.125)
+    ref = (x.float() @ w.float().t() + b.float()).to(BF).float().view(T, S, 3, Hn, 64).permute(2, 0, 3, 1, 4)
+    close(q[:, :, :S], ref[0] * 0.125, name='q'); close(k[:, :, :S], ref[1], name='k')
+    close(vt[:, :, :, :S], ref[2].transpose(-1, -2), name='vT')
+
+
+def _attn_ref(q, k, v, scale, vis):
+    # q [B,Hq,Sq,D], k/v [B,Hkv,Skv,D], vis bool [B,Sq,Skv]
+    rep = q.shape[1] // k.shape[1]
+    k = k.repeat_interleave(rep, 1); v = v.repeat_interleave(rep, 1)
+    s = (q.float() @ k.float().transpose(-1, -2)) * scale
+    s = s.masked_fill(~vis[:, None], float('-inf'))
+    return (s.softmax(-1) @ v.float()).transpose(1, 2).reshape(q.shape[0], q.shape[2], -1)
+
+
+def test_attn_vit_full(ops):
+    from vlaser_amd import _lib as L
+    T, Hn, S, Sp = 2, 16, 1025, 1088
+    q = rnd(T, Hn, Sp, 64, seed=1); k = rnd(T, Hn, Sp, 64, seed=2); v = rnd(T, Hn, Sp, 64, seed=3)
+    v[:, :, S:] = 0
+    vt = v.transpose(-1, -2).contiguous()
+    out = torch.zeros(T, S, Hn * 64, dtype=BF, device='cuda')
+    ops.attn_prefill(q, k, vt, out, T, S, S, Hn, Hn, 64, (Hn * Sp * 64, Sp * 64, 64), (Hn * Sp * 64, Sp * 64),
+                     (Hn * 64 * Sp, 64 * Sp), (S * Hn * 64, Hn * 64), Sp, 1.0, L.ATTN_FULL)
+    vis = torch.ones(T, S, S, dtype=torch.bool, device='cuda')
+    close(out, _attn_ref(q[:, :, :S], k[:, :, :S], v[:, :, :S], 1.0, vis), name='vit attn')
+
+
+@pytest.mark.parametrize('S,off', [(336, 0), (70, 0), (130, 40)])
+def test_attn_causal_gqa(ops, S, off):
+    from vlaser_amd import _lib as L
+    B, nq, nkv, smax = 2, 12, 2, 448
+    kv_len = S + off
+    q = rnd(B * S, nq * 128, seed=1)
+    k = rnd(B, nkv, smax, 128, seed=2); v = rnd(B, nkv, smax, 128, seed=3)
+    vt = v.transpose(-1, -2).contiguous()
+    out = torch.zeros(B, S, nq * 128, dtype=BF, device='cuda')
+    sc = 128 ** -0.5
+    ops.attn_prefill(q, k, vt, out, B, S, kv_len, nq, nkv, 128, (S * nq * 128, 128, nq * 128), (nkv * smax * 128, smax * 128),
+                     (nkv * 128 * smax, 128 * smax), (S * nq * 128, nq * 128), smax, sc, L.ATTN_CAUSAL, causal_off=off)
+    i = torch.arange(S, device='cuda')[:, None]; j = torch.arange(kv_len, device='cuda')[None]
+    vis = (j <= i + off)[None].expand(B, -1, -1)
+    qq = q.view(B, S, nq, 128).permute(0, 2, 1, 3)
+    close(out, _attn_ref(qq, k[:, :, :kv_len], v[:, :, :kv_len], sc, vis), name='causal')
+
+
+def test_attn_prefix_block(ops):
+    from vlaser_amd import _lib as L
+    B, nq, nkv, smax, S = 2, 12, 2, 448, 385
+    valid = torch.tensor([277, 384], dtype=torch.int32, device='cuda')
+    q = rnd(B * S, nq * 128, seed=1)
+    k = rnd(B, nkv, smax, 128, seed=2); v = rnd(B, nkv, smax, 128, seed=3)
+    vt = v.transpose(-1, -2).contiguous()
+    out = torch.zeros(B, S, nq * 128, dtype=BF, device='cuda')
+    sc = 128 ** -0.5
+    ops.attn_prefill(q, k, vt, out, B, S, S, nq, nkv, 128, (S * nq * 128, 128, nq * 128), (nkv * smax * 128, smax * 128),
+                     (nkv * 128 * smax, 128 * smax), (S * nq * 128, nq * 128), smax, sc, L.ATTN_PREFIX, valid_len=valid, blk_start=384)
+    j = torch.arange(S, device='cuda')[None, None]; i = torch.arange(S, device='cuda')[None, :, None]
+    vis = (j < valid[:, None, None]) | ((i >= 384) & (j >= 384))
+    qq = q.view(B, S, nq, 128).permute(0, 2, 1, 3)
+    ref = _attn_ref(qq, k[:, :, :S], v[:, :, :S], sc, vis)
+    for b in range(B):       # rows beyond the valid prefix are "don't care" (reference: uniform softmax over masked row)
+        n = int(valid[b])
+        close(out[b, :n], ref[b, :n], name=f'prefix rows b{b}')
+        close(out[b, 384:], ref[b, 384:], name=f'proprio row b{b}')
+
+
+@pytest.mark.parametrize('nq_tok,kv_len,mode', [(4, 389, 'prefix'), (1, 385, 'prefix'), (1, 337, 'full'), (3, 1500, 'full')])
+def test_attn_skinny(ops, nq_tok, kv_len, mode):
+    from vlaser_amd import _lib as L
+    B, nq, nkv, smax = 2, 12, 2, 1536
+    q = rnd(B * nq_tok, nq * 128, seed=1)
+    k = rnd(B, nkv, smax, 128, seed=2); v = rnd(B, nkv, smax, 128, seed=3)
+    vt = v.transpose(-1, -2).contiguous()
+    out = torch.zeros(B, nq_tok, nq * 128, dtype=BF, device='cuda')
+    sc = 128 ** -0.5
+    valid = torch.tensor([277, 300], dtype=torch.int32, device='cuda')
+    kw = dict(valid_len=valid, blk_start=384) if mode == 'prefix' else {}
+    ops.attn_skinny(q, k, vt, out, B, nq_tok, kv_len, nq, nkv, 128, (nq_tok * nq * 128, 128, nq * 128),
+                    (nkv * smax * 128, smax * 128), (nkv * 128 * smax, 128 * smax), (nq_tok * nq * 128, nq * 128), smax, sc,
+                    L.ATTN_PREFIX if mode == 'prefix' else L.ATTN_FULL, **kw)
+    j = torch.arange(kv_len, device='cuda')[None, None]
+    if mode == 'prefix':
+        vis = ((j < valid[:, None, None]) | (j >= 384)).expand(B, nq_tok, kv_len)
+    else:
+        vis = torch.ones(B, nq_tok, kv_len, dtype=torch.bool, device='cuda')
+    qq = q.view(B, nq_tok, nq, 128).permute(0, 2, 1, 3)
+    close(out, _attn_ref(qq, k[:, :, :kv_len], v[:, :, :kv_len], sc, vis), name='skinny attn')
+
+
+def _rms_ref(h, w, eps=1e-6):
+    hf = h.float()
+    return (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + eps)).to(BF).float() * w.float()
+
+
+@pytest.mark.parametrize('M,N,K,ks', [(4, 768, 1536, 6), (4, 768, 8960, 10), (1, 1536, 8960, 5), (16, 1536, 1536, 1), (5, 3584, 3584, 2)])
+def test_skinny_partial(ops, M, N, K, ks):
+    from vlaser_amd import _lib as L
+    x, w = rnd(M, K), rnd(N, K, std=0.03)
+    part = torch.zeros(ks, M, N, dtype=torch.float32, device='cuda')
+    ops.skinny(L.PRO_PLAIN, L.SK_PARTIAL, x, w, M, k_splits=ks, out_f32=part)
+    close(part.sum(0), x.float() @ w.float().t(), rtol=2e-3, atol=2e-3, name='partial sum')
+    # each slab is the partial over its own K slice
+    kb = K // ks
+    close(part[ks - 1], x[:, -kb:].float() @ w[:, -kb:].float().t(), rtol=2e-3, atol=2e-3, name='last slab')
+
+
+def test_skinny_bias_silu_f32(ops):
+    from vlaser_amd import _lib as L
+    M, N, K = 4, 768, 1536
+    x, w, b = rnd(M, K), rnd(N, K, std=0.03), rnd(N, std=0.3)
+    ref = x.float() @ w.float().t() + b.float()
+    out = torch.zeros(M, N, dtype=BF, device='cuda')
+    ops.skinny(L.PRO_PLAIN, L.SK_BIAS, x, w, M, out=out, ldo=N, bias=b)
+    close(out, ref, name='bias')
+    ops.skinny(L.PRO_PLAIN, L.SK_BIAS_SILU, x, w, M, out=out, ldo=N, bias=b)
+    close(out, F.silu(ref.to(BF).float()), name='bias_silu')
+    N2 = 1002
+    w2 = rnd(N2, K, std=0.03, seed=9)
+    lg = torch.zeros(M, N2, dtype=torch.float32, device='cuda')
+    ops.skinny(L.PRO_PLAIN, L.SK_F32, x, w2, M, out_f32=lg)
+    close(lg, x.float() @ w2.float().t(), rtol=2e-3, atol=2e-3, name='f32 edge N')
+
+
+@pytest.mark.parametrize('M,H,I,npart', [(4, 768, 8960, 10), (1, 1536, 8960, 0), (4, 768, 8960, 3)])
+def test_skinny_norm_swiglu(ops, M, H, I, npart):
+    from vlaser_amd import _lib as L
+    h, nw = rnd(M, H), (1 + 0.1 * rnd(H, seed=5).float()).to(BF)
+    parts = (torch.randn(max(npart, 1), M, H, generator=torch.Generator().manual_seed(7)) * 0.3).cuda()
+    g, u = rnd(I, H, std=0.03, seed=1), rnd(I, H, std=0.03, seed=2)
+    W = ops.pack_gate_up(g, u)
+    out = torch.zeros(M, I, dtype=BF, device='cuda'); h_out = torch.zeros(M, H, dtype=BF, device='cuda')
+    ops.skinny(L.PRO_NORM, L.SK_SWIGLU, h, W, M, partials=parts, n_partials=npart, norm_w=nw, h_out=h_out, out=out, ldo=I)
+    hs = (h.float() + (parts[:npart].sum(0) if npart else 0)).to(BF)
+    assert torch.equal(h_out, hs) or (h_out.float() - hs.float()).abs().max() <= 2 ** -7 * hs.float().abs().max()
+    xn = _rms_ref(h_out, nw).to(BF).float()
+    gr = (xn @ g.float().t()).to(BF).float(); ur = (xn @ u.float().t()).to(BF).float()
+    close(out, F.silu(gr).to(BF).float() * ur, name='norm swiglu')
+
+
+def test_skinny_norm_qkv_rope(ops):
+    from vlaser_amd import _lib as L
+    B, tok, H, nq, nkv, smax = 2, 4, 768, 12, 2, 448
+    M = B * tok
+    h, nw = rnd(M, H), (1 + 0.1 * rnd(H, seed=5).float()).to(BF)
+    qw, kw, vw = rnd(nq * 128, H, std=0.03, seed=1), rnd(nkv * 128, H, std=0.03, seed=2), rnd(nkv * 128, H, std=0.03, seed=3)
+    qb, kb, vb = rnd(nq * 128, std=0.3, seed=4), rnd(nkv * 128, std=0.3, seed=5), rnd(nkv * 128, std=0.3, seed=6)
+    W, Bv = ops.pack_qkv(qw, kw, vw, qb, kb, vb)
+    cos, sin = ops.rope_table(64)
+    pos = (torch.arange(tok).repeat(B) + 2).int().cuda()
+    q_out = torch.zeros(M, nq * 128, dtype=BF, device='cuda')
+    kc = torch.zeros(B, nkv, smax, 128, dtype=BF, device='cuda'); vtc = torch.zeros(B, nkv, 128, smax, dtype=BF, device='cuda')
+    ops.skinny(L.PRO_NORM, L.SK_QKV_ROPE, h, W, M, n_partials=0, norm_w=nw, bias=Bv, q_out=q_out, k_cache=kc, vt_cache=vtc,
+               rope_cos=cos, rope_sin=sin, pos_ids=pos, n_q_heads=nq, n_kv_heads=nkv, s_max=smax, tok_per_batch=tok, slot_base=385)
+    xn = _rms_ref(h, nw).to(BF).float()
+    q = (xn @ qw.float().t() + qb.float()).to(BF).float().view(M, nq, 128)
+    k = (xn @ kw.float().t() + kb.float()).to(BF).float().view(M, nkv, 128)
+    v = (xn @ vw.float().t() + vb.float()).to(BF).float().view(M, nkv, 128)
+    close(q_out.view(M, nq, 128), _rope_ref(q, pos), name='q')
+    close(kc[:, :, 385:389], _rope_ref(k, pos).view(B, tok, nkv, 128).permute(0, 2, 1, 3), name='k')
+    close(vtc[:, :, :, 385:389], v.view(B, tok, nkv, 128).permute(0, 2, 3, 1), name='vT')
+
+
+def test_norms(ops):
+    x = rnd(1025, 1024, std=2.0); w = (1 + 0.1 * rnd(1024, seed=1).float()).to(BF); b = rnd(1024, std=0.1, seed=2)
+    close(ops.layernorm(x, w, b, 1e-6), F.layer_norm(x.float(), (1024,), w.float(), b.float(), 1e-6), name='layernorm')
+    x2 = rnd(385, 1536, std=3.0); w2 = (1 + 0.1 * rnd(1536, seed=1).float()).to(BF)
+    close(ops.rmsnorm(x2, w2, 1e-6), _rms_ref(x2, w2), rtol=8e-3, name='rmsnorm')
+
+
+def test_pixel_shuffle_bit_exact_and_ln(ops):
+    T, G, Cc = 2, 32, 1024
+    x = rnd(T, G * G + 1, Cc)
+    out = torch.zeros(T * 256, 4 * Cc, dtype=BF, device='cuda')
+    ops.pixel_shuffle(x, out, T, G, Cc)
+    xr = x[:, 1:].reshape(T, G, G, Cc)
+    # closed form: out[n,i,j,a*2C+b*C+k] = x[n,2i+a,2j+b,k]
+    ref = xr.view(T, 16, 2, 16, 2, Cc).permute(0, 1, 3, 2, 4, 5).reshape(T * 256, 4 * Cc)
+    assert torch.equal(out, ref)
+    w = (1 + 0.1 * rnd(4 * Cc, seed=1).float()).to(BF); b = rnd(4 * Cc, std=0.1, seed=2)
+    o2 = torch.zeros_like(out)
+    ops.pixel_shuffle_ln(x, w, b, o2, T, G, Cc, 1e-5)
+    close(o2, F.layer_norm(ref.float(), (4 * Cc,), w.float(), b.float(), 1e-5), name='ps+ln')
+
+
+def test_patch_embed(ops):
+    from vlaser_amd import _lib as L
+    T = 2
+    pix = rnd(T, 3, 448, 448)
+    w = rnd(1024, 3, 14, 14, std=0.05, seed=1); b = rnd(1024, std=0.1, seed=2)
+    cls = rnd(1, 1, 1024, seed=3); pos = rnd(1, 1025, 1024, seed=4)
+    A = torch.zeros(T * 1024, 640, dtype=BF, device='cuda')
+    ops.im2col(pix, A, T, 448, 640)
+    patch = ops.linear(A, ops.pack_patch_embed(w), b)
+    h = torch.zeros(T, 1025, 1024, dtype=BF, device='cuda')
+    ops.vit_assemble(patch, cls, pos, h, T, 1024, 1024)
+    ref = F.conv2d(pix.float(), w.float(), b.float(), stride=14).to(BF).float().flatten(2).transpose(1, 2)
+    ref = torch.cat([cls.float().expand(T, 1, -1), ref], 1) + pos.float()
+    close(h, ref, name='patch embed')
+
+
+def test_embed_merge_and_argmax(ops):
+    V, H = 3000, 1536
+    embed = rnd(V, H); vit = rnd(512, H, seed=5)
+    ids = torch.randint(0, 1000, (2, 300))
+    ids[0, 10:266] = 2999; ids[1, 40:296] = 2999; ids[1, 296:] = 1500      # 1500 = pad
+    ids = ids.cuda()
+    out = torch.zeros(2, 300, H, dtype=BF, device='cuda'); rank = torch.zeros(600, dtype=torch.int32, device='cuda')
+    cnt = torch.zeros(1, dtype=torch.int32, device='cuda')
+    ops.embed_merge(ids, embed, vit, out, 2999, 1500, False, rank, cnt)
+    ref = embed[ids].clone(); ref[ids == 2999] = vit
+    assert torch.equal(out, ref) and int(cnt) == 512
+    sel = (ids.flatten() == 2999)
+    assert torch.equal(rank[sel].cpu(), torch.arange(512, dtype=torch.int32))       # visual-token indices bit-exact
+    assert (rank[~sel] == -1).all()
+    ops.embed_merge(ids, embed, vit, out, 2999, 1500, True, rank, cnt)
+    ref[ids == 1500] = 0
+    assert torch.equal(out, ref)
+    logits = torch.randn(3, 151674, device='cuda'); logits[1, 777] = 50; logits[2, 5] = 60; logits[2, 100000] = 60
+    oid = torch.zeros(3, dtype=torch.int64, device='cuda'); nh = torch.zeros(3, H, dtype=BF, device='cuda')
+    big = rnd(151674, 64)
+    nh = torch.zeros(3, 64, dtype=BF, device='cuda')
+    ops.argmax(logits, oid, big, nh)
+    assert torch.equal(oid, logits.argmax(-1)) and oid[2] == 5
+    assert torch.equal(nh, big[oid])
+
+
+def test_vla_glue(ops):
+    W, adim, M = 768, 7, 8
+    act = torch.randn(M, adim).cuda(); w1 = rnd(W, adim, std=0.2); b1 = rnd(W, std=0.1, seed=1)
+    xcat = torch.zeros(M, 2 * W, dtype=BF, device='cuda')
+    t = 0.3
+    ops.vla_prep(act, w1, b1, xcat, M, W, adim, t, 10000.0)
+    half = W // 2
+    e = math.log(10000.0) / (half - 1)
+    ang = t * torch.exp(torch.arange(half).float() * -e)
+    temb = torch.cat([ang.sin(), ang.cos()]).cuda()
+    close(xcat[:, :W], temb[None].expand(M, -1), rtol=1e-2, atol=1e-2, name='time emb')
+    close(xcat[:, W:], act.to(BF).float() @ w1.float().t() + b1.float(), name='linear_1')
+    # euler
+    h = rnd(M, W); parts = (torch.randn(3, M, W) * 0.2).cuda(); nw = (1 + 0.1 * rnd(W, seed=2).float()).to(BF)
+    wd = rnd(adim, W, std=0.02, seed=3); bd = rnd(adim, std=0.05, seed=4)
+    a0 = act.clone(); vel = torch.zeros(M, adim, device='cuda')
+    ops.vla_euler(h, parts, 3, M, nw, 1e-6, wd, bd, act, W, adim, 0.1, 1.0, False, vel)
+    hs = (h.float() + parts.sum(0)).to(BF)
+    y = _rms_ref(hs, nw).to(BF).float()
+    vref = (y @ wd.float().t() + bd.float())
+    close(vel, vref, rtol=1e-2, atol=5e-3, name='vel')
+    close(act, a0 + 0.1 * vel, rtol=1e-5, atol=1e-6, name='euler')

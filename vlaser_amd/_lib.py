@@ -1,0 +1,88 @@
+"""ctypes binding of libvlaser_hip.so (include/vlaser_hip.h).  The product path FAILS LOUDLY when the HIP
+library is missing -- there is no CPU / PyTorch fallback (the CPU oracle lives in oracle/ and is test-only)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libvlaser_hip.so')
+_lib = None
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [('A', vp), ('W', vp), ('out', vp), ('M', i32), ('N', i32), ('K', i32), ('lda', i32), ('ldw', i32),
+                ('ldo', i32), ('bias', vp), ('res', vp), ('ls', vp), ('q_out', vp), ('k_cache', vp), ('vt_cache', vp),
+                ('rope_cos', vp), ('rope_sin', vp), ('pos_ids', vp), ('n_q_heads', i32), ('n_kv_heads', i32),
+                ('s_max', i32), ('tok_per_batch', i32), ('slot_base', i32), ('vq', vp), ('vk', vp), ('vvt', vp),
+                ('vit_heads', i32), ('vit_seq', i32), ('vit_seq_pad', i32), ('q_scale', f32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [('q', vp), ('k', vp), ('vt', vp), ('out', vp), ('batch', i32), ('sq', i32), ('kv_len', i32),
+                ('n_q_heads', i32), ('n_kv_heads', i32), ('head_dim', i32), ('q_bs', i64), ('q_hs', i64), ('q_ss', i64),
+                ('k_bs', i64), ('k_hs', i64), ('vt_bs', i64), ('vt_hs', i64), ('o_bs', i64), ('o_ss', i64),
+                ('ld_vt', i32), ('scale', f32), ('mode', i32), ('causal_off', i32), ('valid_len', vp),
+                ('blk_start', i32), ('q_row_off', i32)]
+
+
+class SkinnyArgs(C.Structure):
+    _fields_ = [('x', vp), ('partials', vp), ('n_partials', i32), ('norm_w', vp), ('eps', f32), ('h_out', vp),
+                ('W', vp), ('M', i32), ('N', i32), ('K', i32), ('ldw', i32), ('k_splits', i32), ('out_f32', vp),
+                ('out', vp), ('ldo', i32), ('bias', vp), ('q_out', vp), ('k_cache', vp), ('vt_cache', vp),
+                ('rope_cos', vp), ('rope_sin', vp), ('pos_ids', vp), ('n_q_heads', i32), ('n_kv_heads', i32),
+                ('s_max', i32), ('tok_per_batch', i32), ('slot_base', i32)]
+
+
+# enums (include/vlaser_hip.h)
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_LS_RES, EPI_RES, EPI_SWIGLU, EPI_QKV_ROPE, EPI_VIT_QKV, EPI_F32 = range(9)
+ATTN_FULL, ATTN_CAUSAL, ATTN_PREFIX = range(3)
+PRO_PLAIN, PRO_NORM = range(2)
+SK_PARTIAL, SK_QKV_ROPE, SK_SWIGLU, SK_F32, SK_BIAS, SK_BIAS_SILU = range(6)
+
+_SIGS = {
+    'vlaser_gemm': [i32, C.POINTER(GemmArgs), vp],
+    'vlaser_attn_prefill': [C.POINTER(AttnArgs), vp],
+    'vlaser_attn_skinny': [C.POINTER(AttnArgs), vp],
+    'vlaser_skinny': [i32, i32, C.POINTER(SkinnyArgs), vp],
+    'vlaser_layernorm': [vp, vp, vp, vp, i32, i32, f32, vp],
+    'vlaser_rmsnorm': [vp, vp, vp, i32, i32, f32, vp],
+    'vlaser_im2col': [vp, vp, i32, i32, i32, vp],
+    'vlaser_vit_assemble': [vp, vp, vp, vp, i32, i32, i32, vp],
+    'vlaser_pixel_shuffle_ln': [vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
+    'vlaser_pixel_shuffle': [vp, vp, i32, i32, i32, i32, vp],
+    'vlaser_embed_merge': [vp, i32, vp, vp, i32, vp, i32, i64, i64, i32, vp, vp, vp],
+    'vlaser_argmax': [vp, i32, i32, vp, vp, vp, i32, vp],
+    'vlaser_vla_prep': [vp, vp, vp, vp, i32, i32, i32, f32, f32, vp],
+    'vlaser_small_linear': [vp, vp, vp, vp, i32, i32, i32, vp],
+    'vlaser_vla_euler': [vp, vp, i32, i32, vp, f32, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp],
+    'vlaser_reduce_partials': [vp, vp, i32, i32, i32, vp, vp],
+    'vlaser_cast_f32_bf16': [vp, vp, i64, vp],
+}
+
+
+class VlaserHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VlaserHipError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                                 f'or `make -C vlaser_amd/csrc` -- there is no CPU fallback')
+        l = C.CDLL(LIB_PATH)
+        l.vlaser_last_error.restype = C.c_char_p
+        l.vlaser_abi_version.restype = i32
+        for name, sig in _SIGS.items():
+            fn = getattr(l, name)
+            fn.argtypes = sig
+            fn.restype = i32
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise VlaserHipError(f'{what} failed ({rc}): {lib().vlaser_last_error().decode()}')

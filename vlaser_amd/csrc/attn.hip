@@ -1,0 +1,381 @@
+// Flash-style attention for gfx950 (bf16 in, fp32 softmax/accumulate), two kernels:
+//
+//  attn_prefill<HD>  : many query rows (ViT S=1025, LLM prefill).  Block = 4 waves x 16 query rows; K tile
+//                      [64 keys][HD] and V^T tile [HD][64 keys] staged through XOR-swizzled LDS.
+//  attn_skinny       : <=16 query tokens per (q-head, batch) over a KV cache (10 Euler steps of the action
+//                      expert, greedy decode).  Block = 16 waves, one 32-key chunk per wave straight from
+//                      global memory (no LDS staging), flash-decoding merge through LDS.
+//
+// Both compute S^T = K Q^T with the K fragment as MFMA-A (rows = keys) and Q as MFMA-B (cols = queries) so that
+// every lane owns ONE query column: softmax statistics are lane-local (2 xor-shuffles per tile for the max).
+// The K rows fed to tile t of a 32-key chunk are permuted (key = (i>>2)*8 + t*4 + (i&3)) so that the two
+// 16-key S^T tiles of a lane concatenate into 8 CONSECUTIVE keys = exactly the MFMA-B fragment of P^T for
+// O^T = V^T P^T.  V is kept TRANSPOSED in memory ([.., HD, S]) so its MFMA-A fragment is one 16-byte load.
+//
+// Visibility of key j for query row i (replaces the dense additive masks of the reference,
+// pizero_internvl.py:517-603 and HF causal masks):   j < lim1(i)  ||  lo2 <= j < hi2
+//   FULL   : lim1 = kv_len                         (ViT, modeling_intern_vit.py:220-224: no mask)
+//   CAUSAL : lim1 = min(kv_len, i + 1 + causal_off)
+//   PREFIX : lim1 = valid_len[b]; rows >= blk_start additionally see [blk_start, kv_len)
+#include "common.h"
+#include "../../include/vlaser_hip.h"
+
+#define NEG_BIG (-1.0e30f)
+
+struct AttnP {
+  VlaserAttnArgs a;
+};
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <int HD>
+__device__ __forceinline__ int k_lds_off(int row, int slot) {
+  if constexpr (HD == 128) return row * 256 + ((slot ^ (row & 15)) << 4);
+  else return row * 128 + ((slot ^ (row & 7)) << 4);
+}
+__device__ __forceinline__ int vt_lds_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnP p) {
+  constexpr int DC = HD / 32;   // d-chunks of 32 for S^T
+  constexpr int DT = HD / 16;   // d-tiles of 16 for O^T
+  constexpr int KCH = HD / 32;  // 16-byte chunks per thread for the K tile (64*HD*2/16/256)
+  constexpr int VCH = HD / 32;  // same for V^T tile
+  __shared__ __attribute__((aligned(16))) char smem[64 * HD * 2 + HD * 128];
+  char* Ks = smem;
+  char* Vs = smem + 64 * HD * 2;
+  const VlaserAttnArgs& a = p.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int kvh = h / (a.n_q_heads / a.n_kv_heads);
+  const int q_row = qb * 64 + wave * 16 + fr;  // this lane's query row (within the batch element)
+
+  const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (size_t)b * a.q_bs + (size_t)h * a.q_hs;
+  const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (size_t)b * a.k_bs + (size_t)kvh * a.k_hs;
+  const bf16_t* VT = reinterpret_cast<const bf16_t*>(a.vt) + (size_t)b * a.vt_bs + (size_t)kvh * a.vt_hs;
+
+  // visibility
+  int lim1, lo2 = 0x7fffffff, hi2 = 0;
+  int blk_lim1, blk_has2 = 0;
+  {
+    const int q_last = min(a.sq, qb * 64 + 64) - 1;
+    if (a.mode == VL_ATTN_FULL) {
+      lim1 = blk_lim1 = a.kv_len;
+    } else if (a.mode == VL_ATTN_CAUSAL) {
+      lim1 = min(a.kv_len, q_row + 1 + a.causal_off);
+      blk_lim1 = min(a.kv_len, q_last + 1 + a.causal_off);
+    } else {
+      const int vl = a.valid_len ? a.valid_len[b] : a.kv_len;
+      lim1 = blk_lim1 = min(vl, a.kv_len);
+      if (q_row + a.q_row_off >= a.blk_start) { lo2 = a.blk_start; hi2 = a.kv_len; }
+      blk_has2 = (q_last + a.q_row_off >= a.blk_start);
+    }
+  }
+
+  // Q fragments (MFMA-B: col = query fr, k = d)
+  bf16x8 qf[DC];
+#pragma unroll
+  for (int dc = 0; dc < DC; ++dc) {
+    u32x4 v = {0, 0, 0, 0};
+    if (q_row < a.sq) v = ld_global_16(Q + (size_t)q_row * a.q_ss + dc * 32 + g * 8);
+    qf[dc] = as_bf16x8(v);
+  }
+
+  f32x4 o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) o[i] = f32x4{0, 0, 0, 0};
+  float m_run = NEG_BIG, l_run = 0.f;
+  const float sc = a.scale * 1.4426950408889634f;  // softmax in base 2
+
+  // key-tile schedule: [0, n1) then tiles overlapping [blk_start, kv_len)
+  const int n1 = (blk_lim1 + 63) >> 6;
+  int t2_lo = 0, t2_hi = 0;
+  if (blk_has2) { t2_lo = max(n1, a.blk_start >> 6); t2_hi = (a.kv_len + 63) >> 6; }
+  const int n_tiles = n1 + max(0, t2_hi - t2_lo);
+
+  u32x4 rk[KCH], rv[VCH];
+  auto tile_key0 = [&](int it) { return (it < n1 ? it : t2_lo + (it - n1)) << 6; };
+  auto load_tile = [&](int it) {
+    const int key0 = tile_key0(it);
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+      const int c = tid + i * 256;              // chunk id: row = c / (HD/8), slot = c % (HD/8)
+      const int row = c / (HD / 8), slot = c % (HD / 8);
+      const int key = key0 + row;
+      rk[i] = (key < a.kv_len) ? ld_global_16(K + (size_t)key * HD + slot * 8) : u32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) {
+      const int c = tid + i * 256;              // row = d = c / 8, slot = c % 8 (8 keys each)
+      const int row = c >> 3, slot = c & 7;
+      rv[i] = ld_global_16(VT + (size_t)row * a.ld_vt + key0 + slot * 8);  // cache is padded to a multiple of 64 keys
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+      const int c = tid + i * 256;
+      *reinterpret_cast<u32x4*>(Ks + k_lds_off<HD>(c / (HD / 8), c % (HD / 8))) = rk[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) {
+      const int c = tid + i * 256;
+      *reinterpret_cast<u32x4*>(Vs + vt_lds_off(c >> 3, c & 7)) = rv[i];
+    }
+  };
+
+  if (n_tiles > 0) load_tile(0);
+  for (int it = 0; it < n_tiles; ++it) {
+    __syncthreads();  // previous tile's LDS reads are done
+    store_tile();
+    __syncthreads();
+    if (it + 1 < n_tiles) load_tile(it + 1);
+    const int key0 = tile_key0(it);
+
+    // S^T tiles: s[c][t], key(c,t,reg) = key0 + c*32 + g*8 + t*4 + reg
+    f32x4 s[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 acc = {0, 0, 0, 0};
+        const int krow = c * 32 + (fr >> 2) * 8 + t * 4 + (fr & 3);
+#pragma unroll
+        for (int dc = 0; dc < DC; ++dc) {
+          bf16x8 kf = as_bf16x8(*reinterpret_cast<const u32x4*>(Ks + k_lds_off<HD>(krow, dc * 4 + g)));
+          acc = mfma16(kf, qf[dc], acc);
+        }
+        s[c][t] = acc;
+      }
+    // mask + online softmax (lane-local per query; max all-reduced over the 4 lane groups)
+    float mx = NEG_BIG;
+    bool vis[2][2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = key0 + c * 32 + g * 8 + t * 4 + r;
+          const bool v = (key < lim1) || (key >= lo2 && key < hi2);
+          vis[c][t][r] = v;
+          const float x = s[c][t][r] * sc;
+          s[c][t][r] = x;
+          if (v) mx = fmaxf(mx, x);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = fast_exp2(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8 pf[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float pv[8];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pe = vis[c][t][r] ? fast_exp2(s[c][t][r] - m_new) : 0.f;
+          psum += pe;
+          pv[t * 4 + r] = pe;
+        }
+      u32x4 pk = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]), pack_bf16x2(pv[4], pv[5]), pack_bf16x2(pv[6], pv[7])};
+      pf[c] = as_bf16x8(pk);
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      f32x4 acc = o[dt];
+      acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        bf16x8 vf = as_bf16x8(*reinterpret_cast<const u32x4*>(Vs + vt_lds_off(dt * 16 + fr, c * 4 + g)));
+        acc = mfma16(vf, pf[c], acc);
+      }
+      o[dt] = acc;
+    }
+  }
+
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  if (q_row < a.sq) {
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    bf16_t* O = reinterpret_cast<bf16_t*>(a.out) + (size_t)b * a.o_bs + (size_t)q_row * a.o_ss + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      u32x2 pk = {pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
+      *reinterpret_cast<u32x2*>(O + dt * 16 + g * 4) = pk;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ skinny
+// grid (n_q_heads, B); block 1024 = 16 waves; wave w handles 32-key chunks w, w+16, ...; HD = 128.
+// Query rows: nq tokens (<=16) of ONE q head.  Visibility is uniform over the rows of a batch element:
+//   keys [0, lim1) U [lo2, hi2)   (lim1 = valid_len[b] or kv_len; causal decode passes lim1 = kv_len).
+__global__ __launch_bounds__(1024) void attn_skinny_kernel(AttnP p) {
+  constexpr int HD = 128, DC = 4, DT = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [16 waves][ m[16] l[16] o[16][128] ] fp32
+  const VlaserAttnArgs& a = p.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int kvh = h / (a.n_q_heads / a.n_kv_heads);
+  const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (size_t)b * a.q_bs + (size_t)h * a.q_hs;
+  const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (size_t)b * a.k_bs + (size_t)kvh * a.k_hs;
+  const bf16_t* VT = reinterpret_cast<const bf16_t*>(a.vt) + (size_t)b * a.vt_bs + (size_t)kvh * a.vt_hs;
+
+  int lim1 = a.kv_len, lo2 = 0x7fffffff, hi2 = 0;
+  if (a.mode == VL_ATTN_PREFIX) {
+    lim1 = min(a.valid_len ? a.valid_len[b] : a.kv_len, a.kv_len);
+    lo2 = a.blk_start; hi2 = a.kv_len;
+  }
+  const int n1 = (lim1 + 31) >> 5;
+  int c2_lo = 0, c2_hi = 0;
+  if (hi2 > lo2) { c2_lo = max(n1, lo2 >> 5); c2_hi = (hi2 + 31) >> 5; }
+  const int n_chunks = n1 + max(0, c2_hi - c2_lo);
+
+  bf16x8 qf[DC];
+#pragma unroll
+  for (int dc = 0; dc < DC; ++dc) {
+    u32x4 v = {0, 0, 0, 0};
+    if (fr < a.sq) v = ld_global_16(Q + (size_t)fr * a.q_ss + dc * 32 + g * 8);
+    qf[dc] = as_bf16x8(v);
+  }
+  f32x4 o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) o[i] = f32x4{0, 0, 0, 0};
+  float m_run = NEG_BIG, l_run = 0.f;
+  const float sc = a.scale * 1.4426950408889634f;
+
+  for (int ci = wave; ci < n_chunks; ci += 16) {
+    const int key0 = (ci < n1 ? ci : c2_lo + (ci - n1)) << 5;
+    // issue all loads of the chunk up front (K: 2 tiles x 4 d-chunks, V^T: 8 d-tiles)
+    u32x4 kf[2][DC], vf[DT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int key = key0 + (fr >> 2) * 8 + t * 4 + (fr & 3);
+#pragma unroll
+      for (int dc = 0; dc < DC; ++dc)
+        kf[t][dc] = (key < a.kv_len) ? ld_global_16(K + (size_t)key * HD + dc * 32 + g * 8) : u32x4{0, 0, 0, 0};
+    }
+    f32x4 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int dc = 0; dc < DC; ++dc) acc = mfma16(as_bf16x8(kf[t][dc]), qf[dc], acc);
+      s[t] = acc;
+    }
+    // V^T loads are issued after the K fragments are consumed (128-VGPR budget at 16 waves/block); their latency
+    // overlaps the softmax VALU work below
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vf[dt] = ld_global_16(VT + (size_t)(dt * 16 + fr) * a.ld_vt + key0 + g * 8);
+    float mx = NEG_BIG;
+    bool vis[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + g * 8 + t * 4 + r;
+        const bool v = (key < lim1) || (key >= lo2 && key < hi2);
+        vis[t][r] = v;
+        s[t][r] *= sc;
+        if (v) mx = fmaxf(mx, s[t][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = fast_exp2(m_run - m_new);
+    m_run = m_new;
+    float pv[8], psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pe = vis[t][r] ? fast_exp2(s[t][r] - m_new) : 0.f;
+        psum += pe;
+        pv[t * 4 + r] = pe;
+      }
+    l_run = l_run * alpha + psum;
+    u32x4 pk = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]), pack_bf16x2(pv[4], pv[5]), pack_bf16x2(pv[6], pv[7])};
+    const bf16x8 pf = as_bf16x8(pk);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      f32x4 acc = o[dt];
+      acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
+      o[dt] = mfma16(as_bf16x8(vf[dt]), pf, acc);
+    }
+  }
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+
+  // flash-decoding merge through LDS
+  float* wm = reinterpret_cast<float*>(smem) + wave * (32 + 16 * 128);
+  float* wl = wm + 16;
+  float* wo = wm + 32;
+  if (g == 0) { wm[fr] = m_run; wl[fr] = l_tot; }
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wo[fr * 128 + dt * 16 + g * 4 + r] = o[dt][r];
+  __syncthreads();
+  // thread -> (row = tid / 64, d pair = (tid % 64) * 2): 16 rows x 128 d = 2048 outputs over 1024 threads
+  {
+    const int row = tid >> 6, d = (tid & 63) * 2;
+    if (row < a.sq) {
+      const float* base = reinterpret_cast<const float*>(smem);
+      float M = NEG_BIG;
+      for (int w = 0; w < 16; ++w) M = fmaxf(M, base[w * (32 + 2048) + row]);
+      float L = 0.f, o0 = 0.f, o1 = 0.f;
+      for (int w = 0; w < 16; ++w) {
+        const float* bw = base + w * (32 + 2048);
+        const float f = fast_exp2(bw[row] - M);
+        L += bw[16 + row] * f;
+        o0 += bw[32 + row * 128 + d] * f;
+        o1 += bw[32 + row * 128 + d + 1] * f;
+      }
+      const float inv = L > 0.f ? 1.0f / L : 0.f;
+      bf16_t* O = reinterpret_cast<bf16_t*>(a.out) + (size_t)b * a.o_bs + (size_t)row * a.o_ss + h * HD + d;
+      *reinterpret_cast<uint32_t*>(O) = pack_bf16x2(o0 * inv, o1 * inv);
+    }
+  }
+}
+
+extern "C" int vlaser_attn_prefill(const VlaserAttnArgs* a, vl_stream_t s) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(s);
+  VL_CHECK(a && a->q && a->k && a->vt && a->out, "vlaser_attn_prefill: null pointer");
+  VL_CHECK(a->head_dim == 64 || a->head_dim == 128, "vlaser_attn_prefill: head_dim %d unsupported", a->head_dim);
+  VL_CHECK(a->n_q_heads % a->n_kv_heads == 0, "vlaser_attn_prefill: GQA group mismatch");
+  VL_CHECK(a->ld_vt % 64 == 0, "vlaser_attn_prefill: V^T row length must be padded to a multiple of 64 keys");
+  VL_CHECK(a->kv_len <= a->ld_vt, "vlaser_attn_prefill: kv_len exceeds cache");
+  VL_CHECK(a->sq > 0 && a->batch > 0, "vlaser_attn_prefill: empty");
+  AttnP p; p.a = *a;
+  dim3 grid((a->sq + 63) / 64, a->n_q_heads, a->batch);
+  if (a->head_dim == 128) hipLaunchKernelGGL(attn_prefill_kernel<128>, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(attn_prefill_kernel<64>, grid, dim3(256), 0, stream, p);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vlaser_attn_skinny(const VlaserAttnArgs* a, vl_stream_t s) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(s);
+  VL_CHECK(a && a->q && a->k && a->vt && a->out, "vlaser_attn_skinny: null pointer");
+  VL_CHECK(a->head_dim == 128, "vlaser_attn_skinny: head_dim must be 128");
+  VL_CHECK(a->sq >= 1 && a->sq <= 16, "vlaser_attn_skinny: 1..16 query tokens, got %d", a->sq);
+  VL_CHECK(a->ld_vt % 32 == 0 && a->kv_len <= a->ld_vt, "vlaser_attn_skinny: bad cache geometry");
+  VL_CHECK(a->mode == VL_ATTN_FULL || a->mode == VL_ATTN_PREFIX, "vlaser_attn_skinny: mode must be FULL or PREFIX");
+  AttnP p; p.a = *a;
+  const int lds = 16 * (32 + 2048) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_skinny_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_skinny_kernel, dim3(a->n_q_heads, a->batch), dim3(1024), lds, stream, p);
+  VL_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,76 @@
+// Shared device helpers for the Vlaser gfx950 (MI355X / CDNA4) kernels.
+// Wave = 64 lanes everywhere; MFMA = v_mfma_f32_16x16x32_bf16 (A: lane l -> row l&15, k (l>>4)*8..+8;
+// B: lane l -> col l&15, same k; C/D: col l&15, rows (l>>4)*4 + reg).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits in memory
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define WAVE 64
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ float bf16lo_to_f32(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// round-to-nearest-even f32 -> bf16 (NaN kept quiet)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) {
+  union { u32x4 u; bf16x8 b; } x;
+  x.u = v;
+  return x.b;
+}
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ u32x4 ld_global_16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st_global_16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+// host-side error plumbing (api.cpp)
+void vlaser_set_error(const char* fmt, ...);
+#define VL_CHECK(cond, ...)            \
+  do {                                 \
+    if (!(cond)) {                     \
+      vlaser_set_error(__VA_ARGS__);   \
+      return -1;                       \
+    }                                  \
+  } while (0)
+#define VL_HIP(expr)                                                        \
+  do {                                                                      \
+    hipError_t _e = (expr);                                                 \
+    if (_e != hipSuccess) {                                                 \
+      vlaser_set_error("%s failed: %s", #expr, hipGetErrorString(_e));      \
+      return -2;                                                            \
+    }                                                                       \
+  } while (0)
+#define VL_LAUNCH_CHECK() VL_HIP(hipGetLastError())

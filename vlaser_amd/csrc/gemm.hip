@@ -1,0 +1,287 @@
+// bf16 MFMA GEMM for gfx950: out = epilogue(A[M,K] @ W[N,K]^T), fp32 accumulate.
+//
+// Tile 128(M) x 128(N) x 64(K), 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile as 4x4 MFMA 16x16x32
+// tiles.  Both operands are K-contiguous (activations [M,K], torch Linear weights [N,K]) so MFMA fragments are
+// 16-byte LDS reads.  Operands are issued "swapped" (W fragment as MFMA-A, activation fragment as MFMA-B) so
+// that each lane ends up with 4 CONSECUTIVE output columns n of one row m -> 8-byte stores and lane-local
+// fused epilogues (bias / GELU / layer-scale residual / SwiGLU / RoPE + KV-cache scatter).
+// LDS: 2 x (A 16 KiB + W 16 KiB), 16-byte slots XOR-swizzled by (row & 7) (guide T2) -> <=2-way conflicts on
+// ds_read_b128.  Global->register prefetch of tile k+1 overlaps the MFMAs of tile k; one barrier per K-step.
+// blockIdx is remapped so each XCD owns a contiguous run of tiles that share the same weight panel (guide T1).
+#include "common.h"
+#include "../../include/vlaser_hip.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+
+struct GemmP {
+  VlaserGemmArgs a;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
+
+template <int EPI>
+__device__ __forceinline__ void epilogue(const VlaserGemmArgs& a, int m, int n0, f32x4 v, f32x4 v2) {
+  // v holds acc for output columns n0..n0+3 of row m. (v2: partner accumulator for SWIGLU / ROPE)
+  if (m >= a.M) return;
+  if constexpr (EPI == VL_EPI_F32) {
+    float* o = reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (n0 + j < a.N) o[j] = v[j];
+    return;
+  }
+  if constexpr (EPI == VL_EPI_NONE || EPI == VL_EPI_BIAS || EPI == VL_EPI_BIAS_GELU || EPI == VL_EPI_BIAS_LS_RES ||
+                EPI == VL_EPI_RES) {
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x = v[j];
+      int n = n0 + j;
+      if (n < a.N) {
+        if constexpr (EPI == VL_EPI_BIAS || EPI == VL_EPI_BIAS_GELU || EPI == VL_EPI_BIAS_LS_RES)
+          x += bf16_to_f32(reinterpret_cast<const bf16_t*>(a.bias)[n]);
+        if constexpr (EPI == VL_EPI_BIAS_GELU) x = gelu_erf(x);
+        if constexpr (EPI == VL_EPI_BIAS_LS_RES)
+          x = bf16_to_f32(reinterpret_cast<const bf16_t*>(a.res)[(size_t)m * a.ldo + n]) +
+              bf16_to_f32(reinterpret_cast<const bf16_t*>(a.ls)[n]) * x;
+        if constexpr (EPI == VL_EPI_RES) x += bf16_to_f32(reinterpret_cast<const bf16_t*>(a.res)[(size_t)m * a.ldo + n]);
+      }
+      r[j] = x;
+    }
+    bf16_t* o = reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n0;
+    if (n0 + 3 < a.N && (a.ldo & 3) == 0) {
+      u32x2 pk = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+      *reinterpret_cast<u32x2*>(o) = pk;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n0 + j < a.N) o[j] = f32_to_bf16(r[j]);
+    }
+    return;
+  }
+  if constexpr (EPI == VL_EPI_SWIGLU) {
+    // n0 indexes the packed [gate16|up16] row space; v = gate rows, v2 = up rows; output column = (n0/32)*16 + n0%16
+    int no = (n0 >> 5) * 16 + (n0 & 15);
+    if (no >= (a.N >> 1)) return;
+    bf16_t* o = reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + no;
+    // HF rounds gate and up to bf16 before the activation (separate Linear outputs)
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = round_bf16(silu(round_bf16(v[j]))) * round_bf16(v2[j]);
+    u32x2 pk = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+    *reinterpret_cast<u32x2*>(o) = pk;
+    return;
+  }
+  if constexpr (EPI == VL_EPI_QKV_ROPE) {
+    // n0 = head*128 + p where p is the packed in-head row: p = 32*j + 16*half + r  <->  d = 16*j + r + 64*half.
+    // v = rows with half 0 (d), v2 = rows with half 1 (d + 64)
+    int head = n0 >> 7;
+    int p = n0 & 127;
+    int d = ((p >> 5) << 4) + (p & 15);  // p&15 is a multiple of 4; j-th element -> d + j
+    int pos = a.pos_ids[m];
+    const bf16_t* bias = reinterpret_cast<const bf16_t*>(a.bias);
+    float x1[4], x2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // q/k/v projections are bf16 Linear outputs in the reference: round once after bias
+      x1[j] = round_bf16(v[j] + bf16_to_f32(bias[n0 + j]));
+      x2[j] = round_bf16(v2[j] + bf16_to_f32(bias[n0 + 16 + j]));
+    }
+    int b = m / a.tok_per_batch;
+    int slot = a.slot_base + (m - b * a.tok_per_batch);
+    const int nq = a.n_q_heads, nkv = a.n_kv_heads;
+    if (head < nq + nkv) {
+      float o1[4], o2[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float c = a.rope_cos[(size_t)pos * 64 + d + j], s = a.rope_sin[(size_t)pos * 64 + d + j];
+        o1[j] = x1[j] * c - x2[j] * s;
+        o2[j] = x2[j] * c + x1[j] * s;
+      }
+      bf16_t* dst;
+      if (head < nq) {
+        dst = reinterpret_cast<bf16_t*>(a.q_out) + (size_t)m * nq * 128 + head * 128;
+      } else {
+        dst = reinterpret_cast<bf16_t*>(a.k_cache) + (((size_t)b * nkv + (head - nq)) * a.s_max + slot) * 128;
+      }
+      u32x2 pk1 = {pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3])};
+      u32x2 pk2 = {pack_bf16x2(o2[0], o2[1]), pack_bf16x2(o2[2], o2[3])};
+      *reinterpret_cast<u32x2*>(dst + d) = pk1;
+      *reinterpret_cast<u32x2*>(dst + d + 64) = pk2;
+    } else {
+      bf16_t* vt = reinterpret_cast<bf16_t*>(a.vt_cache) + ((size_t)b * nkv + (head - nq - nkv)) * 128 * a.s_max + slot;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        vt[(size_t)(d + j) * a.s_max] = f32_to_bf16(x1[j]);
+        vt[(size_t)(d + 64 + j) * a.s_max] = f32_to_bf16(x2[j]);
+      }
+    }
+    return;
+  }
+  if constexpr (EPI == VL_EPI_VIT_QKV) {
+    // columns: [0,C) q, [C,2C) k, [2C,3C) v with C = heads*64 ("three h d", modeling_intern_vit.py:212,231)
+    const int C = a.vit_heads * 64;
+    int which = n0 / C;
+    int c = n0 - which * C;
+    int h = c >> 6, d = c & 63;
+    int t = m / a.vit_seq, s = m - t * a.vit_seq;
+    const bf16_t* bias = reinterpret_cast<const bf16_t*>(a.bias);
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      r[j] = round_bf16(v[j] + bf16_to_f32(bias[n0 + j]));
+      if (which == 0) r[j] *= a.q_scale;
+    }
+    if (which < 2) {
+      bf16_t* dst = reinterpret_cast<bf16_t*>(which == 0 ? a.vq : a.vk) +
+                    (((size_t)t * a.vit_heads + h) * a.vit_seq_pad + s) * 64 + d;
+      u32x2 pk = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+      *reinterpret_cast<u32x2*>(dst) = pk;
+    } else {
+      bf16_t* vt = reinterpret_cast<bf16_t*>(a.vvt) + (((size_t)t * a.vit_heads + h) * 64 + d) * a.vit_seq_pad + s;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) vt[(size_t)j * a.vit_seq_pad] = f32_to_bf16(r[j]);
+    }
+    return;
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 16K | W 16K]
+  const VlaserGemmArgs& a = p.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // XCD-aware remap: block b runs on XCD b%8; give each XCD a contiguous chunk of the tile list (bijective form)
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = bid % p.tiles_m, tile_n = bid / p.tiles_m;  // consecutive tiles share the weight panel
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
+  const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W);
+
+  // staging map: thread -> (row = tid/8 + 32*i, slot = tid%8), i = 0..3
+  const int srow = tid >> 3, sslot = tid & 7;
+  u32x4 ra[4], rw[4];
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * BK + sslot * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int rm = m0 + srow + 32 * i, rn = n0 + srow + 32 * i;
+      ra[i] = (rm < a.M) ? ld_global_16(A + (size_t)rm * a.lda + k0) : u32x4{0, 0, 0, 0};
+      rw[i] = (rn < a.N) ? ld_global_16(W + (size_t)rn * a.ldw + k0) : u32x4{0, 0, 0, 0};
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* base = smem + buf * 32768;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int row = srow + 32 * i;
+      *reinterpret_cast<u32x4*>(base + lds_off(row, sslot)) = ra[i];
+      *reinterpret_cast<u32x4*>(base + 16384 + lds_off(row, sslot)) = rw[i];
+    }
+  };
+
+  f32x4 acc[4][4];  // [nt][mt]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+  const int nk = a.K / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const char* As = smem + buf * 32768;
+    const char* Ws = As + 16384;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fw[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fa[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + lds_off(wr * 64 + t * 16 + fr, ks * 4 + fq)));
+        fw[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ws + lds_off(wc * 64 + t * 16 + fr, ks * 4 + fq)));
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma16(fw[nt], fa[mt], acc[nt][mt]);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane -> m = ... + (lane&15), n = ... + (lane>>4)*4 + reg
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = m0 + wr * 64 + mt * 16 + fr;
+    if constexpr (EPI == VL_EPI_SWIGLU || EPI == VL_EPI_QKV_ROPE) {
+#pragma unroll
+      for (int nt = 0; nt < 4; nt += 2) epilogue<EPI>(a, m, n0 + wc * 64 + nt * 16 + fq * 4, acc[nt][mt], acc[nt + 1][mt]);
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) epilogue<EPI>(a, m, n0 + wc * 64 + nt * 16 + fq * 4, acc[nt][mt], acc[nt][mt]);
+    }
+  }
+}
+
+template <int EPI>
+static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
+  GemmP p;
+  p.a = *args;
+  p.tiles_m = (args->M + BM - 1) / BM;
+  p.tiles_n = (args->N + BN - 1) / BN;
+  static bool attr_set = false;
+  if (!attr_set) {
+    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_kernel<EPI>, dim3(p.tiles_m * p.tiles_n), dim3(256), 65536, stream, p);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(s);
+  VL_CHECK(a && a->A && a->W, "vlaser_gemm: null operand");
+  VL_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "vlaser_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
+  VL_CHECK(a->K % BK == 0, "vlaser_gemm: K=%d must be a multiple of %d", a->K, BK);
+  VL_CHECK(a->lda % 8 == 0 && a->ldw % 8 == 0, "vlaser_gemm: lda/ldw must be multiples of 8 (16-byte rows)");
+  VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm: operands must be 16-byte aligned");
+  switch (epi) {
+    case VL_EPI_NONE: VL_CHECK(a->out, "out null"); return launch<VL_EPI_NONE>(a, stream);
+    case VL_EPI_F32: VL_CHECK(a->out, "out null"); return launch<VL_EPI_F32>(a, stream);
+    case VL_EPI_BIAS: VL_CHECK(a->out && a->bias, "out/bias null"); return launch<VL_EPI_BIAS>(a, stream);
+    case VL_EPI_BIAS_GELU: VL_CHECK(a->out && a->bias, "out/bias null"); return launch<VL_EPI_BIAS_GELU>(a, stream);
+    case VL_EPI_BIAS_LS_RES:
+      VL_CHECK(a->out && a->bias && a->res && a->ls, "out/bias/res/ls null");
+      return launch<VL_EPI_BIAS_LS_RES>(a, stream);
+    case VL_EPI_RES: VL_CHECK(a->out && a->res, "out/res null"); return launch<VL_EPI_RES>(a, stream);
+    case VL_EPI_SWIGLU:
+      VL_CHECK(a->out && a->N % 32 == 0 && a->ldo % 4 == 0, "swiglu: N must be a multiple of 32, ldo of 4");
+      return launch<VL_EPI_SWIGLU>(a, stream);
+    case VL_EPI_QKV_ROPE:
+      VL_CHECK(a->q_out && a->k_cache && a->vt_cache && a->rope_cos && a->rope_sin && a->pos_ids && a->bias, "qkv_rope: null pointer");
+      VL_CHECK(a->N == (a->n_q_heads + 2 * a->n_kv_heads) * 128, "qkv_rope: N mismatch");
+      VL_CHECK(a->tok_per_batch > 0 && a->s_max > 0, "qkv_rope: bad cache geometry");
+      return launch<VL_EPI_QKV_ROPE>(a, stream);
+    case VL_EPI_VIT_QKV:
+      VL_CHECK(a->vq && a->vk && a->vvt && a->bias, "vit_qkv: null pointer");
+      VL_CHECK(a->N == 3 * a->vit_heads * 64 && a->vit_seq > 0 && a->vit_seq_pad >= a->vit_seq, "vit_qkv: bad geometry");
+      return launch<VL_EPI_VIT_QKV>(a, stream);
+    default: vlaser_set_error("vlaser_gemm: unknown epilogue %d", epi); return -1;
+  }
+}

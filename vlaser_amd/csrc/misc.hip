@@ -1,0 +1,434 @@
+// Memory-bound helper kernels of the Vlaser forward path (gfx950): norms, patch-embed im2col, ViT token
+// assembly, pixel-shuffle + LayerNorm gather, embedding / visual-token scatter, argmax, and the tiny pi0 head
+// (time embedding, action encoder input, final norm + action decoder + Euler update).
+// All are one-wave-per-row or one-block kernels with 16-byte vector accesses and fp32 statistics.
+#include "common.h"
+#include "../../include/vlaser_hip.h"
+
+// ---------------------------------------------------------------------------------------------- LayerNorm / RMSNorm
+// one wave per row, 4 rows per block; C % 8 == 0.
+template <bool RMS>
+__global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                   const bf16_t* __restrict__ bias, bf16_t* __restrict__ out, int rows,
+                                                   int C, float eps) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + (size_t)row * C;
+  float s = 0.f, ss = 0.f;
+  for (int c = lane * 8; c < C; c += 512) {
+    const u32x4 v = ld_global_16(xr + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float lo = bf16lo_to_f32(v[j]), hi = bf16hi_to_f32(v[j]);
+      s += lo + hi;
+      ss += lo * lo + hi * hi;
+    }
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  float mean = 0.f, rs;
+  if constexpr (RMS) {
+    rs = rsqrtf(ss / (float)C + eps);
+  } else {
+    mean = s / (float)C;
+    // two-pass variance for accuracy (row is L1/L2 resident)
+    float vs = 0.f;
+    for (int c = lane * 8; c < C; c += 512) {
+      const u32x4 v = ld_global_16(xr + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = bf16lo_to_f32(v[j]) - mean, hi = bf16hi_to_f32(v[j]) - mean;
+        vs += lo * lo + hi * hi;
+      }
+    }
+    vs = wave_sum(vs);
+    rs = rsqrtf(vs / (float)C + eps);
+  }
+  bf16_t* orow = out + (size_t)row * C;
+  for (int c = lane * 8; c < C; c += 512) {
+    const u32x4 v = ld_global_16(xr + c), wv = ld_global_16(w + c);
+    u32x4 bv = {0, 0, 0, 0};
+    if constexpr (!RMS) bv = ld_global_16(bias + c);
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float lo, hi;
+      if constexpr (RMS) {  // Qwen2RMSNorm: w * bf16(x * rs)
+        lo = round_bf16(bf16lo_to_f32(v[j]) * rs) * bf16lo_to_f32(wv[j]);
+        hi = round_bf16(bf16hi_to_f32(v[j]) * rs) * bf16hi_to_f32(wv[j]);
+      } else {
+        lo = (bf16lo_to_f32(v[j]) - mean) * rs * bf16lo_to_f32(wv[j]) + bf16lo_to_f32(bv[j]);
+        hi = (bf16hi_to_f32(v[j]) - mean) * rs * bf16hi_to_f32(wv[j]) + bf16hi_to_f32(bv[j]);
+      }
+      o[j] = pack_bf16x2(lo, hi);
+    }
+    st_global_16(orow + c, o);
+  }
+}
+
+extern "C" int vlaser_layernorm(const void* x, const void* w, const void* b, void* out, int rows, int C, float eps, vl_stream_t s) {
+  VL_CHECK(x && w && b && out && rows > 0 && C % 8 == 0, "vlaser_layernorm: bad args");
+  hipLaunchKernelGGL(norm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)w,
+                     (const bf16_t*)b, (bf16_t*)out, rows, C, eps);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vlaser_rmsnorm(const void* x, const void* w, void* out, int rows, int C, float eps, vl_stream_t s) {
+  VL_CHECK(x && w && out && rows > 0 && C % 8 == 0, "vlaser_rmsnorm: bad args");
+  hipLaunchKernelGGL(norm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)w,
+                     (const bf16_t*)nullptr, (bf16_t*)out, rows, C, eps);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- patch embed
+// im2col for Conv2d(3->C, k=s=14): A[t*G*G + py*G + px][c*196 + ky*14 + kx] = pix[t][c][py*14+ky][px*14+kx],
+// zero padded from 588 to Kpad columns.  One block per patch row group.
+__global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ pix, bf16_t* __restrict__ A, int T, int img,
+                                                     int G, int Kpad) {
+  const int patch = blockIdx.x;  // t*G*G + py*G + px
+  const int t = patch / (G * G), pp = patch - t * G * G, py = pp / G, px = pp - py * G;
+  bf16_t* dst = A + (size_t)patch * Kpad;
+  for (int k = threadIdx.x; k < Kpad; k += 256) {
+    bf16_t v = 0;
+    if (k < 588) {
+      const int c = k / 196, r = k - c * 196, ky = r / 14, kx = r - ky * 14;
+      v = pix[(((size_t)t * 3 + c) * img + py * 14 + ky) * img + px * 14 + kx];
+    }
+    dst[k] = v;
+  }
+}
+extern "C" int vlaser_im2col(const void* pix, void* A, int T, int img, int Kpad, vl_stream_t s) {
+  VL_CHECK(pix && A && T > 0 && img % 14 == 0 && Kpad >= 588, "vlaser_im2col: bad args");
+  const int G = img / 14;
+  hipLaunchKernelGGL(im2col_kernel, dim3(T * G * G), dim3(256), 0, (hipStream_t)s, (const bf16_t*)pix, (bf16_t*)A, T, img, G, Kpad);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// h[t,0,:] = cls + pos[0]; h[t,1+p,:] = patch[t*P+p,:] + pos[1+p]   (modeling_intern_vit.py:166-174)
+__global__ __launch_bounds__(128) void vit_assemble_kernel(const bf16_t* __restrict__ patch, const bf16_t* __restrict__ cls,
+                                                           const bf16_t* __restrict__ pos, bf16_t* __restrict__ h, int P, int C) {
+  const int row = blockIdx.x;  // t*(P+1) + s
+  const int t = row / (P + 1), sidx = row - t * (P + 1);
+  const bf16_t* src = sidx == 0 ? cls : patch + ((size_t)t * P + sidx - 1) * C;
+  for (int c = threadIdx.x * 8; c < C; c += 128 * 8) {
+    const u32x4 a = ld_global_16(src + c), b = ld_global_16(pos + (size_t)sidx * C + c);
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(bf16lo_to_f32(a[j]) + bf16lo_to_f32(b[j]), bf16hi_to_f32(a[j]) + bf16hi_to_f32(b[j]));
+    st_global_16(h + (size_t)row * C + c, o);
+  }
+}
+extern "C" int vlaser_vit_assemble(const void* patch, const void* cls, const void* pos, void* h, int T, int P, int C, vl_stream_t s) {
+  VL_CHECK(patch && cls && pos && h && C % 8 == 0, "vlaser_vit_assemble: bad args");
+  hipLaunchKernelGGL(vit_assemble_kernel, dim3(T * (P + 1)), dim3(128), 0, (hipStream_t)s, (const bf16_t*)patch, (const bf16_t*)cls,
+                     (const bf16_t*)pos, (bf16_t*)h, P, C);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- pixel shuffle + LN
+// out[t, i*G2+j, a*2C + b*C + k] = LN_{4C}( x[t, 1 + (2i+a)*G + (2j+b), k] )   (ps_version v2,
+// modeling_internvl_chat.py:257-271,284-290; CLS row dropped).  One wave per output token, 4 per block.
+__global__ __launch_bounds__(256) void pixel_shuffle_ln_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                               const bf16_t* __restrict__ bias, bf16_t* __restrict__ out, int T,
+                                                               int G, int C, float eps, int transpose_v1) {
+  const int G2 = G / 2, lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= T * G2 * G2) return;
+  const int t = tok / (G2 * G2), r = tok - t * G2 * G2;
+  int i = r / G2, j = r - i * G2;
+  if (transpose_v1) { const int tmp = i; i = j; j = tmp; }
+  const bf16_t* base = x + (size_t)t * (G * G + 1) * C;
+  const int C4 = 4 * C;
+  // the 4 source rows
+  const bf16_t* src[4];
+#pragma unroll
+  for (int ab = 0; ab < 4; ++ab) src[ab] = base + (size_t)(1 + (2 * i + (ab >> 1)) * G + (2 * j + (ab & 1))) * C;
+  float s = 0.f;
+  for (int c = lane * 8; c < C4; c += 512) {
+    const u32x4 v = ld_global_16(src[c / C] + (c % C));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s += bf16lo_to_f32(v[q]) + bf16hi_to_f32(v[q]);
+  }
+  const float mean = wave_sum(s) / (float)C4;
+  float vs = 0.f;
+  for (int c = lane * 8; c < C4; c += 512) {
+    const u32x4 v = ld_global_16(src[c / C] + (c % C));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float lo = bf16lo_to_f32(v[q]) - mean, hi = bf16hi_to_f32(v[q]) - mean;
+      vs += lo * lo + hi * hi;
+    }
+  }
+  const float rs = rsqrtf(wave_sum(vs) / (float)C4 + eps);
+  bf16_t* orow = out + (size_t)tok * C4;
+  for (int c = lane * 8; c < C4; c += 512) {
+    const u32x4 v = ld_global_16(src[c / C] + (c % C)), wv = ld_global_16(w + c), bv = ld_global_16(bias + c);
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      o[q] = pack_bf16x2((bf16lo_to_f32(v[q]) - mean) * rs * bf16lo_to_f32(wv[q]) + bf16lo_to_f32(bv[q]),
+                         (bf16hi_to_f32(v[q]) - mean) * rs * bf16hi_to_f32(wv[q]) + bf16hi_to_f32(bv[q]));
+    st_global_16(orow + c, o);
+  }
+}
+extern "C" int vlaser_pixel_shuffle_ln(const void* x, const void* w, const void* b, void* out, int T, int G, int C, float eps,
+                                       int ps_v1, vl_stream_t s) {
+  VL_CHECK(x && w && b && out && G % 2 == 0 && C % 8 == 0, "vlaser_pixel_shuffle_ln: bad args");
+  const int toks = T * (G / 2) * (G / 2);
+  hipLaunchKernelGGL(pixel_shuffle_ln_kernel, dim3((toks + 3) / 4), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)w,
+                     (const bf16_t*)b, (bf16_t*)out, T, G, C, eps, ps_v1);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+// pure permutation variant (bit-exact data movement check of a5): out = pixel_shuffle(x[:,1:])
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int T, int G, int C,
+                                                            int transpose_v1) {
+  const int G2 = G / 2;
+  const int tok = blockIdx.x;
+  const int t = tok / (G2 * G2), r = tok - t * G2 * G2;
+  int i = r / G2, j = r - i * G2;
+  if (transpose_v1) { const int tmp = i; i = j; j = tmp; }
+  const bf16_t* base = x + (size_t)t * (G * G + 1) * C;
+  for (int c = threadIdx.x * 8; c < 4 * C; c += 256 * 8) {
+    const int ab = c / C;
+    const bf16_t* src = base + (size_t)(1 + (2 * i + (ab >> 1)) * G + (2 * j + (ab & 1))) * C + (c % C);
+    st_global_16(out + (size_t)tok * 4 * C + c, ld_global_16(src));
+  }
+}
+extern "C" int vlaser_pixel_shuffle(const void* x, void* out, int T, int G, int C, int ps_v1, vl_stream_t s) {
+  VL_CHECK(x && out && G % 2 == 0 && C % 8 == 0, "vlaser_pixel_shuffle: bad args");
+  hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(T * (G / 2) * (G / 2)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (bf16_t*)out, T,
+                     G, C, ps_v1);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- embedding + scatter
+// rank[s] = number of <IMG_CONTEXT> tokens before position s (row-major over [B,S]) if ids[s] is one, else -1.
+// Single block exclusive scan (n <= 2^20).  modeling_internvl_chat.py:422-425 / pizero_internvl.py:764-791.
+__global__ __launch_bounds__(1024) void img_rank_kernel(const int64_t* __restrict__ ids, int32_t* __restrict__ rank, int n, int64_t img_id,
+                                                        int32_t* __restrict__ count_out) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int f = (i < n && ids[i] == img_id) ? 1 : 0;
+    int incl = f;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int off = carry;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (i < n) rank[i] = f ? off + incl - 1 : -1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w) tot += wsum[w];
+      carry += tot;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && count_out) *count_out = carry;
+}
+// out[s,:] = rank[s] >= 0 ? vit[rank[s],:] : (zero_pad && ids[s]==pad_id ? 0 : embed[ids[s],:])
+__global__ __launch_bounds__(128) void embed_merge_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ rank,
+                                                          const bf16_t* __restrict__ embed, const bf16_t* __restrict__ vit,
+                                                          bf16_t* __restrict__ out, int H, int64_t pad_id, int zero_pad, int n_vit_rows) {
+  const int sidx = blockIdx.x;
+  const int64_t id = ids[sidx];
+  const int r = rank ? rank[sidx] : -1;
+  const bf16_t* src = nullptr;
+  if (r >= 0) { if (r < n_vit_rows) src = vit + (size_t)r * H; }
+  else if (!(zero_pad && id == pad_id)) src = embed + (size_t)id * H;
+  for (int c = threadIdx.x * 8; c < H; c += 128 * 8) {
+    u32x4 v = {0, 0, 0, 0};
+    if (src) v = ld_global_16(src + c);
+    st_global_16(out + (size_t)sidx * H + c, v);
+  }
+}
+extern "C" int vlaser_embed_merge(const int64_t* ids, int n, const void* embed, const void* vit, int n_vit_rows, void* out, int H,
+                                  long long img_id, long long pad_id, int zero_pad, int32_t* rank_ws, int32_t* count_out, vl_stream_t s) {
+  VL_CHECK(ids && embed && out && rank_ws && n > 0 && H % 8 == 0, "vlaser_embed_merge: bad args");
+  hipLaunchKernelGGL(img_rank_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, ids, rank_ws, n, (int64_t)img_id, count_out);
+  hipLaunchKernelGGL(embed_merge_kernel, dim3(n), dim3(128), 0, (hipStream_t)s, ids, rank_ws, (const bf16_t*)embed, (const bf16_t*)vit,
+                     (bf16_t*)out, H, (int64_t)pad_id, zero_pad, n_vit_rows);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- argmax (greedy)
+// out_id[m] = argmax_n logits[m, n] (lowest index wins ties, as torch.argmax); also optional embedding gather of
+// the winner into next_h[m,:] so the decode loop never leaves the device.
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int N, int64_t* __restrict__ out_id,
+                                                      const bf16_t* __restrict__ embed, bf16_t* __restrict__ next_h, int H) {
+  __shared__ float bv[16];
+  __shared__ int bi[16];
+  __shared__ int winner;
+  const int m = blockIdx.x;
+  const float* row = logits + (size_t)m * N;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int n = threadIdx.x; n < N; n += 1024) {
+    const float v = row[n];
+    if (v > best || (v == best && n < idx)) { best = v; idx = n; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+    out_id[m] = idx;
+    winner = idx;
+  }
+  __syncthreads();
+  if (next_h) {
+    const bf16_t* src = embed + (size_t)winner * H;
+    for (int c = threadIdx.x * 8; c < H; c += 1024 * 8) st_global_16(next_h + (size_t)m * H + c, ld_global_16(src + c));
+  }
+}
+extern "C" int vlaser_argmax(const float* logits, int M, int N, int64_t* out_id, const void* embed, void* next_h, int H, vl_stream_t s) {
+  VL_CHECK(logits && out_id && M > 0 && N > 0, "vlaser_argmax: bad args");
+  VL_CHECK(!next_h || (embed && H % 8 == 0), "vlaser_argmax: embed/H");
+  hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(1024), 0, (hipStream_t)s, logits, N, out_id, (const bf16_t*)embed, (bf16_t*)next_h, H);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- pi0 head glue
+// vla_prep: x_cat[m, 0:W] = sinusoidal(t) (sin half | cos half, modules.py:9-22), x_cat[m, W:2W] = W1 a[m] + b1
+// (modules.py:45-50).  action fp32 [M, adim].  One block per row m.
+__global__ __launch_bounds__(256) void vla_prep_kernel(const float* __restrict__ action, const bf16_t* __restrict__ w1,
+                                                       const bf16_t* __restrict__ b1, bf16_t* __restrict__ xcat, int Wd, int adim,
+                                                       float t, float max_period) {
+  const int m = blockIdx.x;
+  const int half = Wd / 2;
+  const float e = logf(max_period) / (float)(half - 1);
+  for (int c = threadIdx.x; c < Wd; c += 256) {
+    const int i = c < half ? c : c - half;
+    const float ang = t * expf(-e * (float)i);
+    xcat[(size_t)m * 2 * Wd + c] = f32_to_bf16(c < half ? sinf(ang) : cosf(ang));
+    float acc = bf16_to_f32(b1[c]);
+    for (int k = 0; k < adim; ++k) acc += bf16_to_f32(f32_to_bf16(action[m * adim + k])) * bf16_to_f32(w1[c * adim + k]);
+    xcat[(size_t)m * 2 * Wd + Wd + c] = f32_to_bf16(acc);
+  }
+}
+extern "C" int vlaser_vla_prep(const float* action, const void* w1, const void* b1, void* xcat, int M, int Wd, int adim, float t,
+                               float max_period, vl_stream_t s) {
+  VL_CHECK(action && w1 && b1 && xcat && M > 0, "vlaser_vla_prep: bad args");
+  hipLaunchKernelGGL(vla_prep_kernel, dim3(M), dim3(256), 0, (hipStream_t)s, action, (const bf16_t*)w1, (const bf16_t*)b1, (bf16_t*)xcat,
+                     Wd, adim, t, max_period);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// proprio encoder: out[m, :] = Wp p[m] + bp  (pizero_internvl.py:823).
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
+                                                           bf16_t* __restrict__ out, int N, int K) {
+  const int m = blockIdx.x;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float acc = bf16_to_f32(b[n]);
+    for (int k = 0; k < K; ++k) acc += bf16_to_f32(f32_to_bf16(x[m * K + k])) * bf16_to_f32(w[n * K + k]);
+    out[(size_t)m * N + n] = f32_to_bf16(acc);
+  }
+}
+extern "C" int vlaser_small_linear(const float* x, const void* w, const void* b, void* out, int M, int N, int K, vl_stream_t s) {
+  VL_CHECK(x && w && b && out && M > 0, "vlaser_small_linear: bad args");
+  hipLaunchKernelGGL(small_linear_kernel, dim3(M), dim3(256), 0, (hipStream_t)s, x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)out, N, K);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// vla_euler: h = bf16(h_in + sum partials); y = rmsnorm(h) (expert final norm, joint_model.py:804-808);
+// vel = Wd y + bd (pizero_internvl.py:911); action += dt * vel (:912); optional clamp on the last step (:927-932).
+// One block per row m (<=16 rows); 256 threads.
+__global__ __launch_bounds__(256) void vla_euler_kernel(const bf16_t* __restrict__ h_in, const float* __restrict__ partials, int n_partials,
+                                                        int M, const bf16_t* __restrict__ norm_w, float eps, const bf16_t* __restrict__ wd,
+                                                        const bf16_t* __restrict__ bd, float* __restrict__ action, int Wd, int adim, float dt,
+                                                        float clip, int do_clip, float* __restrict__ vel_out) {
+  __shared__ float ybuf[2048];
+  __shared__ float red[4];
+  const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ssq = 0.f;
+  for (int c = threadIdx.x; c < Wd; c += 256) {
+    float v = bf16_to_f32(h_in[(size_t)m * Wd + c]);
+    for (int s = 0; s < n_partials; ++s) v += partials[((size_t)s * M + m) * Wd + c];
+    v = round_bf16(v);
+    ybuf[c] = v;
+    ssq += v * v;
+  }
+  ssq = wave_sum(ssq);
+  if (lane == 0) red[wave] = ssq;
+  __syncthreads();
+  const float rs = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)Wd + eps);
+  for (int c = threadIdx.x; c < Wd; c += 256) ybuf[c] = round_bf16(round_bf16(ybuf[c] * rs) * bf16_to_f32(norm_w[c]));
+  __syncthreads();
+  // decoder: adim (<= 16) outputs, one wave-strided dot each
+  for (int j = wave; j < adim; j += 4) {
+    float acc = 0.f;
+    for (int c = lane; c < Wd; c += 64) acc += ybuf[c] * bf16_to_f32(wd[j * Wd + c]);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const float vel = round_bf16(acc + bf16_to_f32(bd[j]));
+      float av = action[m * adim + j] + dt * vel;
+      if (do_clip) av = fminf(fmaxf(av, -clip), clip);
+      action[m * adim + j] = av;
+      if (vel_out) vel_out[m * adim + j] = vel;
+    }
+  }
+}
+extern "C" int vlaser_vla_euler(const void* h_in, const float* partials, int n_partials, int M, const void* norm_w, float eps,
+                                const void* wd, const void* bd, float* action, int Wd, int adim, float dt, float clip, int do_clip,
+                                float* vel_out, vl_stream_t s) {
+  VL_CHECK(h_in && norm_w && wd && bd && action && M > 0 && Wd <= 2048, "vlaser_vla_euler: bad args");
+  hipLaunchKernelGGL(vla_euler_kernel, dim3(M), dim3(256), 0, (hipStream_t)s, (const bf16_t*)h_in, partials, n_partials, M,
+                     (const bf16_t*)norm_w, eps, (const bf16_t*)wd, (const bf16_t*)bd, action, Wd, adim, dt, clip, do_clip, vel_out);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// residual fix-up after the last layer of a prefill-with-skinny row: h = bf16(h_in + sum partials)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const bf16_t* __restrict__ h_in, const float* __restrict__ partials,
+                                                              int n_partials, int M, int K, bf16_t* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * K) return;
+  float v = bf16_to_f32(h_in[i]);
+  for (int s = 0; s < n_partials; ++s) v += partials[(size_t)s * M * K + i];
+  out[i] = f32_to_bf16(v);
+}
+extern "C" int vlaser_reduce_partials(const void* h_in, const float* partials, int n_partials, int M, int K, void* out, vl_stream_t s) {
+  VL_CHECK(h_in && out && (n_partials == 0 || partials), "vlaser_reduce_partials: bad args");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((M * K + 255) / 256), dim3(256), 0, (hipStream_t)s, (const bf16_t*)h_in, partials,
+                     n_partials, M, K, (bf16_t*)out);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// fp32 -> bf16 cast (pixel values / host inputs)
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (; i < n; i += stride) y[i] = f32_to_bf16(x[i]);
+}
+extern "C" int vlaser_cast_f32_bf16(const float* x, void* y, long long n, vl_stream_t s) {
+  VL_CHECK(x && y && n > 0, "vlaser_cast_f32_bf16: bad args");
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, x, (bf16_t*)y, (size_t)n);
+  VL_LAUNCH_CHECK();
+  return 0;
+}

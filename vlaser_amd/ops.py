@@ -1,0 +1,211 @@
+"""Thin torch-tensor wrappers over the C ABI (include/vlaser_hip.h).  PyTorch is plumbing here: it owns device
+memory and the stream; every op below is a launch of a hand-written gfx950 kernel in libvlaser_hip.so."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t, dtype=BF16):
+    assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    return t
+
+
+# ------------------------------------------------------------------------------------------------ weight packing
+def head_perm(head_dim=128):
+    """packed row p of a 128-row head <-> natural d = 16*(p//32) + p%16 + 64*((p%32)//16): puts the RoPE pair
+    (d, d+64) into the same MFMA lane (gemm.hip / skinny.hip QKV_ROPE epilogue)."""
+    p = torch.arange(head_dim)
+    return 16 * (p // 32) + (p % 16) + 64 * ((p % 32) // 16)
+
+
+def pack_qkv(qw, kw, vw, qb, kb, vb, head_dim=128):
+    w = torch.cat([qw, kw, vw], dim=0)
+    b = torch.cat([qb, kb, vb], dim=0)
+    nh = w.shape[0] // head_dim
+    idx = (torch.arange(nh)[:, None] * head_dim + head_perm(head_dim)[None, :]).reshape(-1).to(w.device)
+    return w[idx].contiguous(), b[idx].contiguous()
+
+
+def pack_gate_up(gw, uw):
+    """rows [32j, 32j+16) = gate rows 16j..16j+15, rows [32j+16, 32j+32) = up rows 16j..16j+15."""
+    I, K = gw.shape
+    assert I % 16 == 0
+    return torch.stack([gw.view(I // 16, 16, K), uw.view(I // 16, 16, K)], dim=1).reshape(2 * I, K).contiguous()
+
+
+def pack_patch_embed(w, kpad=640):
+    C_, k = w.shape[0], w[0].numel()
+    out = torch.zeros(C_, kpad, dtype=w.dtype, device=w.device)
+    out[:, :k] = w.reshape(C_, k)
+    return out
+
+
+def rope_table(n_pos, head_dim=128, theta=1e6, device='cuda'):
+    """fp32 cos/sin [n_pos, head_dim/2], same fp32 arithmetic as Qwen2RotaryEmbedding."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    f = torch.arange(n_pos).float()[:, None] * inv_freq[None, :]
+    return f.cos().contiguous().to(device), f.sin().contiguous().to(device)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm(epi, A, W, out=None, bias=None, res=None, ls=None, N=None, **kw):
+    _chk(A); _chk(W)
+    a = L.GemmArgs()
+    M, K = A.shape
+    a.A, a.W = A.data_ptr(), W.data_ptr()
+    a.M, a.N, a.K = M, (W.shape[0] if N is None else N), K
+    a.lda, a.ldw = A.stride(0), W.stride(0)
+    if out is not None:
+        a.out, a.ldo = out.data_ptr(), out.stride(0)
+    a.bias, a.res, a.ls = _p(bias), _p(res), _p(ls)
+    for k, v in kw.items():
+        setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    L.check(L.lib().vlaser_gemm(epi, C.byref(a), _stream()), 'vlaser_gemm')
+    return out
+
+
+def linear(x, W, bias=None, epi=None, res=None, ls=None, out=None, out_dtype=BF16):
+    """out[M,N] = epi(x @ W^T)."""
+    M, N = x.shape[0], W.shape[0]
+    if epi is None:
+        epi = L.EPI_BIAS if bias is not None else L.EPI_NONE
+    if out is None:
+        n_out = N // 2 if epi == L.EPI_SWIGLU else N
+        out = torch.empty(M, n_out, device=x.device, dtype=torch.float32 if epi == L.EPI_F32 else out_dtype)
+    return gemm(epi, x, W, out=out, bias=bias, res=res, ls=ls)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_args(q, k, vt, out, batch, sq, kv_len, n_q, n_kv, hd, q_str, k_str, vt_str, o_str, ld_vt, scale, mode,
+               causal_off=0, valid_len=None, blk_start=0, q_row_off=0):
+    a = L.AttnArgs()
+    a.q, a.k, a.vt, a.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
+    a.batch, a.sq, a.kv_len, a.n_q_heads, a.n_kv_heads, a.head_dim = batch, sq, kv_len, n_q, n_kv, hd
+    a.q_bs, a.q_hs, a.q_ss = q_str
+    a.k_bs, a.k_hs = k_str
+    a.vt_bs, a.vt_hs = vt_str
+    a.o_bs, a.o_ss = o_str
+    a.ld_vt, a.scale, a.mode, a.causal_off = ld_vt, scale, mode, causal_off
+    a.valid_len = _p(valid_len)
+    a.blk_start, a.q_row_off = blk_start, q_row_off
+    return a
+
+
+def attn_prefill(*args, **kw):
+    a = _attn_args(*args, **kw)
+    L.check(L.lib().vlaser_attn_prefill(C.byref(a), _stream()), 'vlaser_attn_prefill')
+
+
+def attn_skinny(*args, **kw):
+    a = _attn_args(*args, **kw)
+    L.check(L.lib().vlaser_attn_skinny(C.byref(a), _stream()), 'vlaser_attn_skinny')
+
+
+# ------------------------------------------------------------------------------------------------ skinny GEMV
+def skinny(pro, epi, x, W, M, N=None, K=None, k_splits=1, **kw):
+    a = L.SkinnyArgs()
+    a.x, a.W = x.data_ptr(), W.data_ptr()
+    a.M, a.N, a.K, a.ldw = M, (W.shape[0] if N is None else N), (W.shape[1] if K is None else K), W.stride(0)
+    a.k_splits = k_splits
+    a.eps = kw.pop('eps', 1e-6)
+    for k, v in kw.items():
+        setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    L.check(L.lib().vlaser_skinny(pro, epi, C.byref(a), _stream()), 'vlaser_skinny')
+
+
+def pick_k_splits(K, N, target_blocks=256):
+    """Smallest cross-block split-K factor that (a) keeps K/k_splits a multiple of 128 and (b) gives about one
+    block per CU (units = N/32)."""
+    units = (N + 31) // 32
+    best = 1
+    for s in range(1, 65):
+        if K % (s * 128):
+            continue
+        best = s
+        if units * s >= target_blocks:
+            break
+    return best
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def layernorm(x, w, b, eps, out=None):
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().vlaser_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), x.numel() // x.shape[-1],
+                                     x.shape[-1], eps, _stream()), 'vlaser_layernorm')
+    return out
+
+
+def rmsnorm(x, w, eps, out=None):
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().vlaser_rmsnorm(x.data_ptr(), w.data_ptr(), out.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], eps,
+                                   _stream()), 'vlaser_rmsnorm')
+    return out
+
+
+def im2col(pix, A, T, img, kpad):
+    L.check(L.lib().vlaser_im2col(pix.data_ptr(), A.data_ptr(), T, img, kpad, _stream()), 'vlaser_im2col')
+
+
+def vit_assemble(patch, cls, pos, h, T, P, Cc):
+    L.check(L.lib().vlaser_vit_assemble(patch.data_ptr(), cls.data_ptr(), pos.data_ptr(), h.data_ptr(), T, P, Cc, _stream()),
+            'vlaser_vit_assemble')
+
+
+def pixel_shuffle_ln(x, w, b, out, T, G, Cc, eps, ps_v1=0):
+    L.check(L.lib().vlaser_pixel_shuffle_ln(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), T, G, Cc, eps, ps_v1,
+                                            _stream()), 'vlaser_pixel_shuffle_ln')
+
+
+def pixel_shuffle(x, out, T, G, Cc, ps_v1=0):
+    L.check(L.lib().vlaser_pixel_shuffle(x.data_ptr(), out.data_ptr(), T, G, Cc, ps_v1, _stream()), 'vlaser_pixel_shuffle')
+
+
+def embed_merge(ids, embed, vit, out, img_id, pad_id, zero_pad, rank_ws, count_out=None):
+    n = ids.numel()
+    assert ids.dtype == torch.int64 and ids.is_contiguous()
+    L.check(L.lib().vlaser_embed_merge(ids.data_ptr(), n, embed.data_ptr(), _p(vit), 0 if vit is None else vit.shape[0] if vit.dim() == 2 else vit.numel() // vit.shape[-1],
+                                       out.data_ptr(), embed.shape[1], img_id, pad_id, int(zero_pad), rank_ws.data_ptr(),
+                                       _p(count_out), _stream()), 'vlaser_embed_merge')
+
+
+def argmax(logits, out_id, embed=None, next_h=None):
+    M, N = logits.shape
+    L.check(L.lib().vlaser_argmax(logits.data_ptr(), M, N, out_id.data_ptr(), _p(embed), _p(next_h),
+                                  0 if embed is None else embed.shape[1], _stream()), 'vlaser_argmax')
+
+
+def vla_prep(action, w1, b1, xcat, M, W, adim, t, max_period):
+    L.check(L.lib().vlaser_vla_prep(action.data_ptr(), w1.data_ptr(), b1.data_ptr(), xcat.data_ptr(), M, W, adim, t, max_period,
+                                    _stream()), 'vlaser_vla_prep')
+
+
+def small_linear(x, w, b, out, M, N, K):
+    L.check(L.lib().vlaser_small_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, _stream()),
+            'vlaser_small_linear')
+
+
+def vla_euler(h_in, partials, n_partials, M, norm_w, eps, wd, bd, action, W, adim, dt, clip, do_clip, vel_out=None):
+    L.check(L.lib().vlaser_vla_euler(h_in.data_ptr(), _p(partials), n_partials, M, norm_w.data_ptr(), eps, wd.data_ptr(),
+                                     bd.data_ptr(), action.data_ptr(), W, adim, dt, clip, int(do_clip), _p(vel_out), _stream()),
+            'vlaser_vla_euler')
+
+
+def reduce_partials(h_in, partials, n_partials, M, K, out):
+    L.check(L.lib().vlaser_reduce_partials(h_in.data_ptr(), _p(partials), n_partials, M, K, out.data_ptr(), _stream()),
+            'vlaser_reduce_partials')
+
+
+def cast_f32_bf16(x, y):
+    L.check(L.lib().vlaser_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), 'vlaser_cast_f32_bf16')
