@@ -153,6 +153,10 @@ int vlaser_vla_euler(const void* h_in, const float* partials, int n_partials, in
                      const void* bd, float* action, int W, int adim, float dt, float clip, int do_clip, float* vel_out, vl_stream_t stream);
 int vlaser_reduce_partials(const void* h_in, const float* partials, int n_partials, int M, int K, void* out, vl_stream_t stream);
 int vlaser_cast_f32_bf16(const float* x, void* y, long long n, vl_stream_t stream);
+/* CrossEntropyLoss rows (modeling_internvl_chat.py:231-243): loss_row[r] = lse(logits[r]) - logits[r,label], 0 for
+ * ignore_index; lse_row optional. */
+int vlaser_ce_rows(const float* logits, const int64_t* labels, int R, int N, long long ld, float* loss_row, float* lse_row,
+                   long long ignore_index, vl_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,86 @@
+"""Host-side integer / string logic pinned bit-exactly against reference-generated goldens (G1, G2, G4)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import torch
+
+from vlaser_amd import prep
+
+
+def test_chat_prompt_strings(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, 'g1_prompts.json')))
+    sysmsg = g['system_message']
+    assert prep.get_conv_template('internvl2_5').system_message == sysmsg
+    for name in ('chat_1tile', 'chat_13tiles'):
+        c = g[name]
+        q, _, t = prep.build_chat_query('internvl2_5', sysmsg, c['question'], c['num_patches_list'], 256)
+        assert hashlib.sha256(q.encode('utf-8')).hexdigest() == c['prompt_sha']
+        assert q[:120] == c['prompt_head'] and q[-80:] == c['prompt_tail']
+        assert q.count('<IMG_CONTEXT>') == c['img_count'] == 256 * sum(c['num_patches_list'])
+        assert t.sep.strip() == '<|im_end|>'
+    assert g['special'] == {'<IMG_CONTEXT>': 151667, '<img>': 151665, '</img>': 151666, '<|im_end|>': 151645,
+                            '<|endoftext|>': 151643, '<|im_start|>': 151644}
+    assert g['vocab_len'] == 151674
+    assert g['chat_1tile']['img_first'] == 41 and g['chat_1tile']['img_contiguous']
+
+
+def test_vla_prompt_layout(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, 'g1_prompts.json')))
+    for name in ('vla_spoon', 'vla_carrot'):
+        c = g[name]
+        q = prep.build_vla_query(c['text'])
+        assert q.count('<IMG_CONTEXT>') == 256 and q.startswith('<|im_start|>system\nNone<|im_end|>\n<|im_start|>user\n<img>')
+        assert c['img_first'] == 10 and c['img_count'] == 256
+        # ids: 10 prefix + 256 image + text, right-padded with <|endoftext|> to 384
+        non_img = c['ids_nonimg']
+        assert len(non_img) == 384 - 256 and non_img.count(151643) == 384 - c['n_valid']
+    img = torch.zeros(1, 1, 3, 448, 448, dtype=torch.uint8)
+    img[0, 0, 0] = 255; img[0, 0, 1] = 128; img[0, 0, 2, :100] = 7
+    pv = prep.vla_normalize_images(img)
+    probe = [float(pv[0, c, 0, 0]) for c in range(3)] + [float(pv[0, 2, 50, 0])]
+    np.testing.assert_allclose(probe, g['vla_spoon']['pixel_probe'], rtol=0, atol=1e-6)
+
+
+def test_dynamic_grid(golden_dir):
+    rows = json.load(open(os.path.join(golden_dir, 'g2_tiling.json')))
+    for r in rows:
+        cols_rows = prep.dynamic_grid(r['w'], r['h'], 1, r['max_num'], 448)
+        assert list(cols_rows) == r['grid'], r
+        n = cols_rows[0] * cols_rows[1]
+        assert (n + (1 if n != 1 else 0)) == r['n_tiles'], r
+
+
+def test_dynamic_preprocess_tiles():
+    from PIL import Image
+    im = Image.new('RGB', (640, 480))
+    tiles = prep.dynamic_preprocess(im, max_num=12, use_thumbnail=True)
+    assert len(tiles) == 13 and all(t.size == (448, 448) for t in tiles)
+    assert prep.load_image(im).shape == (13, 3, 448, 448)
+
+
+def test_vla_masks(golden_dir):
+    d = np.load(os.path.join(golden_dir, 'g3g4_shuffle_masks.npz'))
+    for n_valid in (277, 384, 1, 300):
+        am = torch.zeros(2, 384, dtype=torch.long)
+        am[0, :n_valid] = 1
+        am[1, :max(1, n_valid - 17)] = 1
+        m, vp, pp, ap = prep.build_causal_mask_and_position_ids(am, torch.float32)
+        assert np.array_equal((m == 0).numpy().astype(np.uint8), d[f'mask_{n_valid}_zero'])
+        assert set(m.unique().tolist()) <= {0.0, torch.finfo(torch.float32).min}
+        m1, m2 = prep.split_full_mask_into_submasks(m)
+        assert np.array_equal((m1 == 0).numpy().astype(np.uint8), d[f'mask_{n_valid}_sub1_zero'])
+        assert np.array_equal((m2 == 0).numpy().astype(np.uint8), d[f'mask_{n_valid}_sub2_zero'])
+        assert np.array_equal(vp.numpy(), d[f'pos_{n_valid}_vlm'])
+        assert np.array_equal(pp.numpy(), d[f'pos_{n_valid}_pro'])
+        assert np.array_equal(ap.numpy(), d[f'pos_{n_valid}_act'])
+        assert prep.mask_to_descriptor(m1).tolist() == [n_valid, max(1, n_valid - 17)]
+
+
+def test_normalize_bound_roundtrip():
+    lo, hi = torch.tensor([-0.1, 0.2]), torch.tensor([0.3, 0.9])
+    x = torch.tensor([[0.0, 0.5], [0.3, 0.2]])
+    y = prep.normalize_bound(x, lo, hi)
+    assert y.min() >= -1 and y.max() <= 1
+    torch.testing.assert_close(prep.denormalize_bound(y, lo, hi), x, rtol=0, atol=1e-6)

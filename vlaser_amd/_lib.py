@@ -58,6 +58,7 @@ _SIGS = {
     'vlaser_vla_euler': [vp, vp, i32, i32, vp, f32, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp],
     'vlaser_reduce_partials': [vp, vp, i32, i32, i32, vp, vp],
     'vlaser_cast_f32_bf16': [vp, vp, i64, vp],
+    'vlaser_ce_rows': [vp, vp, i32, i32, i64, vp, vp, i64, vp],
 }
 
 

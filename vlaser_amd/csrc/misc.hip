@@ -432,3 +432,42 @@ extern "C" int vlaser_cast_f32_bf16(const float* x, void* y, long long n, vl_str
   VL_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------- cross entropy rows
+// loss_row[r] = logsumexp(logits[r,:]) - logits[r,label]  (0 when label == ignore_index); one block per row.
+// CrossEntropyLoss of modeling_internvl_chat.py:231-243 = sum(loss_row) / count(label != -100).
+__global__ __launch_bounds__(1024) void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int N,
+                                                       long long ld, float* __restrict__ loss_row, float* __restrict__ lse_row,
+                                                       long long ignore_index) {
+  __shared__ float red[16];
+  const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t lab = labels[r];
+  const float* row = logits + (size_t)r * ld;
+  float mx = -INFINITY;
+  for (int n = threadIdx.x; n < N; n += 1024) mx = fmaxf(mx, row[n]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = red[0];
+  for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
+  __syncthreads();
+  float s = 0.f;
+  for (int n = threadIdx.x; n < N; n += 1024) s += __expf(row[n] - mx);
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int w = 0; w < 16; ++w) tot += red[w];
+    const float lse = mx + logf(tot);
+    if (lse_row) lse_row[r] = lse;
+    loss_row[r] = (lab == ignore_index) ? 0.f : lse - row[lab];
+  }
+}
+extern "C" int vlaser_ce_rows(const float* logits, const int64_t* labels, int R, int N, long long ld, float* loss_row, float* lse_row,
+                              long long ignore_index, vl_stream_t s) {
+  VL_CHECK(logits && labels && loss_row && R > 0 && N > 0, "vlaser_ce_rows: bad args");
+  hipLaunchKernelGGL(ce_rows_kernel, dim3(R), dim3(1024), 0, (hipStream_t)s, logits, labels, N, ld, loss_row, lse_row, ignore_index);
+  VL_LAUNCH_CHECK();
+  return 0;
+}

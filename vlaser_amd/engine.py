@@ -1,0 +1,237 @@
+"""Kernel sequencing for the three hot loops: InternViT tile encoder, Qwen2.5 prefill / greedy
+decode, and the pi0 joint prefill + 10-step Euler sampler.  Every arithmetic step is a launch of a gfx950 kernel
+from libvlaser_hip.so through vlaser_amd.ops; PyTorch only owns buffers and the stream.  All launches are
+asynchronous and allocation-free after construction, so whole phases can be captured in one HIP graph.
+
+Weights are stored in HBM in the layouts the kernels want (packed once at load):
+  * q/k/v fused into one [N,K] matrix with in-head row permutation (RoPE pair in one MFMA lane),
+  * gate/up interleaved in 16-row groups (SwiGLU is lane-local),
+  * patch-embedding conv flattened to [1024, 640] (K zero-padded from 588 to a multiple of 64),
+  * K cache [L][B,n_kv,S_max,128], V cache TRANSPOSED [L][B,n_kv,128,S_max] (MFMA A-fragment = one 16-byte load).
+"""
+import torch
+
+from . import _lib as L
+from . import ops
+from .config import LLMConfig, VisionConfig, VlaserConfig, VLAConfig
+
+BF = torch.bfloat16
+
+
+def _dev(t, device):
+    return t.to(device=device, dtype=BF).contiguous()
+
+
+class QwenLayerWeights:
+    """One Qwen2DecoderLayer in kernel layout."""
+
+    def __init__(self, sd, p, llm: LLMConfig, device):
+        g = lambda k: _dev(sd[p + k], device)
+        self.wqkv, self.bqkv = ops.pack_qkv(g('self_attn.q_proj.weight'), g('self_attn.k_proj.weight'),
+                                            g('self_attn.v_proj.weight'), g('self_attn.q_proj.bias'),
+                                            g('self_attn.k_proj.bias'), g('self_attn.v_proj.bias'), llm.head_dim)
+        self.wo = g('self_attn.o_proj.weight')
+        self.wgu = ops.pack_gate_up(g('mlp.gate_proj.weight'), g('mlp.up_proj.weight'))
+        self.wdown = g('mlp.down_proj.weight')
+        self.ln_in = g('input_layernorm.weight')
+        self.ln_post = g('post_attention_layernorm.weight')
+
+
+class QwenStack:
+    """Weights + geometry of one Qwen2 decoder stack (the VLM LLM or the action expert)."""
+
+    def __init__(self, sd, prefix, llm: LLMConfig, device, with_embed=True, with_head=True):
+        self.llm = llm
+        self.layers = [QwenLayerWeights(sd, f'{prefix}model.layers.{i}.', llm, device) for i in range(llm.num_hidden_layers)]
+        self.norm = _dev(sd[prefix + 'model.norm.weight'], device)
+        self.embed = _dev(sd[prefix + 'model.embed_tokens.weight'], device) if with_embed else None
+        self.head = _dev(sd[prefix + 'lm_head.weight'], device) if with_head and (prefix + 'lm_head.weight') in sd else None
+        H, I = llm.hidden_size, llm.intermediate_size
+        nqd = llm.num_attention_heads * llm.head_dim
+        self.ks_o = ops.pick_k_splits(nqd, H)
+        self.ks_down = ops.pick_k_splits(I, H)
+
+    @property
+    def nq(self):
+        return self.llm.num_attention_heads
+
+    @property
+    def nkv(self):
+        return self.llm.num_key_value_heads
+
+
+class KVCache:
+    """K [L][B,n_kv,S_max,128] and V^T [L][B,n_kv,128,S_max], zero-initialised (padding must stay finite)."""
+
+    def __init__(self, n_layers, batch, n_kv, s_max, device, head_dim=128):
+        assert s_max % 64 == 0
+        self.s_max, self.batch, self.n_kv, self.hd = s_max, batch, n_kv, head_dim
+        self.k = torch.zeros(n_layers, batch, n_kv, s_max, head_dim, dtype=BF, device=device)
+        self.vt = torch.zeros(n_layers, batch, n_kv, head_dim, s_max, dtype=BF, device=device)
+
+    def strides(self):
+        return (self.n_kv * self.s_max * self.hd, self.s_max * self.hd), (self.n_kv * self.hd * self.s_max, self.hd * self.s_max)
+
+
+# ------------------------------------------------------------------------------------------------------ ViT
+class VitEngine:
+    """InternViT-300M + pixel_shuffle + mlp1 (modeling_intern_vit.py:133-431, modeling_internvl_chat.py:257-291)."""
+
+    KPAD = 640
+
+    def __init__(self, sd, cfg: VlaserConfig, device, max_tiles=1):
+        v = cfg.vision
+        self.cfg, self.v, self.device = cfg, v, device
+        g = lambda k: _dev(sd[k], device)
+        e = 'vision_model.embeddings.'
+        self.w_pe = ops.pack_patch_embed(g(e + 'patch_embedding.weight'), self.KPAD)
+        self.b_pe = g(e + 'patch_embedding.bias')
+        self.cls = g(e + 'class_embedding').reshape(-1)
+        self.pos = g(e + 'position_embedding').reshape(v.num_positions, v.hidden_size)
+        self.layers = []
+        for i in range(v.num_hidden_layers):
+            p = f'vision_model.encoder.layers.{i}.'
+            self.layers.append({k: g(p + n) for k, n in [
+                ('wqkv', 'attn.qkv.weight'), ('bqkv', 'attn.qkv.bias'), ('wproj', 'attn.proj.weight'), ('bproj', 'attn.proj.bias'),
+                ('wfc1', 'mlp.fc1.weight'), ('bfc1', 'mlp.fc1.bias'), ('wfc2', 'mlp.fc2.weight'), ('bfc2', 'mlp.fc2.bias'),
+                ('n1w', 'norm1.weight'), ('n1b', 'norm1.bias'), ('n2w', 'norm2.weight'), ('n2b', 'norm2.bias'),
+                ('ls1', 'ls1'), ('ls2', 'ls2')]})
+        self.m0w, self.m0b = g('mlp1.0.weight'), g('mlp1.0.bias')
+        self.m1w, self.m1b = g('mlp1.1.weight'), g('mlp1.1.bias')
+        self.m3w, self.m3b = g('mlp1.3.weight'), g('mlp1.3.bias')
+        self.max_tiles = 0
+        self._alloc(max_tiles)
+
+    def _alloc(self, T):
+        if T <= self.max_tiles:
+            return
+        v, dev = self.v, self.device
+        S, C, Hn = v.num_positions, v.hidden_size, v.num_attention_heads
+        self.s_pad = (S + 63) // 64 * 64
+        z = lambda *s: torch.zeros(*s, dtype=BF, device=dev)
+        self.col = z(T * v.num_patches, self.KPAD)
+        self.patch = z(T * v.num_patches, C)
+        self.h = z(T * S, C)
+        self.x = z(T * S, C)
+        self.q = z(T, Hn, self.s_pad, v.head_dim)
+        self.k = z(T, Hn, self.s_pad, v.head_dim)
+        self.vt = z(T, Hn, v.head_dim, self.s_pad)
+        self.ao = z(T * S, C)
+        self.f = z(T * S, v.intermediate_size)
+        n_tok = T * self.cfg.num_image_token
+        self.psln = z(n_tok, 4 * C)
+        self.g = z(n_tok, self.cfg.llm.hidden_size)
+        self.feat = z(n_tok, self.cfg.llm.hidden_size)
+        self.max_tiles = T
+
+    def forward(self, pixel_values, return_layers=False):
+        """pixel_values bf16 [T,3,448,448] -> projected visual tokens bf16 [T*256, H_llm] (view into a workspace)."""
+        v, cfg = self.v, self.cfg
+        T = pixel_values.shape[0]
+        assert pixel_values.dtype == BF and pixel_values.is_contiguous() and pixel_values.shape[1:] == (3, v.image_size, v.image_size)
+        self._alloc(T)
+        S, C, Hn, hd, sp = v.num_positions, v.hidden_size, v.num_attention_heads, v.head_dim, self.s_pad
+        M = T * S
+        h, x, ao, f = self.h[:M], self.x[:M], self.ao[:M], self.f[:M]
+        ops.im2col(pixel_values, self.col, T, v.image_size, self.KPAD)
+        ops.linear(self.col[:T * v.num_patches], self.w_pe, self.b_pe, out=self.patch[:T * v.num_patches])
+        ops.vit_assemble(self.patch, self.cls, self.pos, h, T, v.num_patches, C)
+        layers_out = []
+        if return_layers:
+            layers_out.append(h.clone())
+        for lw in self.layers:
+            ops.layernorm(h, lw['n1w'], lw['n1b'], v.layer_norm_eps, out=x)
+            ops.gemm(L.EPI_VIT_QKV, x, lw['wqkv'], bias=lw['bqkv'], vq=self.q, vk=self.k, vvt=self.vt, vit_heads=Hn, vit_seq=S,
+                     vit_seq_pad=sp, q_scale=hd ** -0.5)
+            ops.attn_prefill(self.q, self.k, self.vt, ao, T, S, S, Hn, Hn, hd, (Hn * sp * hd, sp * hd, hd), (Hn * sp * hd, sp * hd),
+                             (Hn * hd * sp, hd * sp), (S * C, C), sp, 1.0, L.ATTN_FULL)
+            ops.gemm(L.EPI_BIAS_LS_RES, ao, lw['wproj'], out=h, bias=lw['bproj'], res=h, ls=lw['ls1'])
+            ops.layernorm(h, lw['n2w'], lw['n2b'], v.layer_norm_eps, out=x)
+            ops.gemm(L.EPI_BIAS_GELU, x, lw['wfc1'], out=f, bias=lw['bfc1'])
+            ops.gemm(L.EPI_BIAS_LS_RES, f, lw['wfc2'], out=h, bias=lw['bfc2'], res=h, ls=lw['ls2'])
+            if return_layers:
+                layers_out.append(h.clone())
+        n_tok = T * cfg.num_image_token
+        G = v.image_size // v.patch_size
+        ops.pixel_shuffle_ln(h, self.m0w, self.m0b, self.psln, T, G, C, 1e-5, 1 if cfg.ps_version == 'v1' else 0)
+        ops.gemm(L.EPI_BIAS_GELU, self.psln[:n_tok], self.m1w, out=self.g[:n_tok], bias=self.m1b)
+        ops.gemm(L.EPI_BIAS, self.g[:n_tok], self.m3w, out=self.feat[:n_tok], bias=self.m3b)
+        if return_layers:
+            return self.feat[:n_tok], layers_out
+        return self.feat[:n_tok]
+
+
+# ------------------------------------------------------------------------------------------------------ LLM
+class PrefillBuffers:
+    def __init__(self, stack: QwenStack, max_rows, device):
+        llm = stack.llm
+        z = lambda *s: torch.zeros(*s, dtype=BF, device=device)
+        self.x = z(max_rows, llm.hidden_size)
+        self.q = z(max_rows, stack.nq * llm.head_dim)
+        self.ao = z(max_rows, stack.nq * llm.head_dim)
+        self.act = z(max_rows, llm.intermediate_size)
+        self.max_rows = max_rows
+
+
+def prefill_layer(stack: QwenStack, lw: QwenLayerWeights, buf: PrefillBuffers, h, cache: KVCache, layer, rope, pos_ids, batch,
+                  tok_per_batch, attn_mode, valid_len=None, blk_start=0, causal_off=0, kv_len=None, skip_post_attn=False):
+    """One Qwen2DecoderLayer over M = batch*tok_per_batch rows with the big-GEMM kernels; K/V written to slots
+    [0, tok_per_batch) of the cache.  h is updated in place."""
+    llm = stack.llm
+    M = batch * tok_per_batch
+    nq, nkv, hd = stack.nq, stack.nkv, llm.head_dim
+    x, q, ao, act = buf.x[:M], buf.q[:M], buf.ao[:M], buf.act[:M]
+    ops.rmsnorm(h, lw.ln_in, llm.rms_norm_eps, out=x)
+    ops.gemm(L.EPI_QKV_ROPE, x, lw.wqkv, bias=lw.bqkv, q_out=q, k_cache=cache.k[layer], vt_cache=cache.vt[layer], rope_cos=rope[0],
+             rope_sin=rope[1], pos_ids=pos_ids, n_q_heads=nq, n_kv_heads=nkv, s_max=cache.s_max, tok_per_batch=tok_per_batch, slot_base=0)
+    ks, vs = cache.strides()
+    ops.attn_prefill(q, cache.k[layer], cache.vt[layer], ao, batch, tok_per_batch, tok_per_batch if kv_len is None else kv_len, nq, nkv, hd,
+                     (tok_per_batch * nq * hd, hd, nq * hd), ks, vs, (tok_per_batch * nq * hd, nq * hd), cache.s_max, hd ** -0.5,
+                     attn_mode, causal_off=causal_off, valid_len=valid_len, blk_start=blk_start)
+    if skip_post_attn:
+        return
+    ops.gemm(L.EPI_RES, ao, lw.wo, out=h, res=h)
+    ops.rmsnorm(h, lw.ln_post, llm.rms_norm_eps, out=x)
+    ops.gemm(L.EPI_SWIGLU, x, lw.wgu, out=act)
+    ops.gemm(L.EPI_RES, act, lw.wdown, out=h, res=h)
+
+
+class SkinnyBuffers:
+    """Workspace of the M <= 16 weight-streaming path (decode / proprio row / action tokens)."""
+
+    def __init__(self, stack: QwenStack, max_rows, device):
+        llm = stack.llm
+        H, I = llm.hidden_size, llm.intermediate_size
+        z = lambda *s: torch.zeros(*s, dtype=BF, device=device)
+        self.hA, self.hB = z(max_rows, H), z(max_rows, H)
+        self.q = z(max_rows, stack.nq * llm.head_dim)
+        self.ao = z(max_rows, stack.nq * llm.head_dim)
+        self.act = z(max_rows, I)
+        self.part_o = torch.zeros(stack.ks_o, max_rows, H, dtype=torch.float32, device=device)
+        self.part_d = torch.zeros(stack.ks_down, max_rows, H, dtype=torch.float32, device=device)
+
+
+def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in, partials, n_partials, cache: KVCache, layer, rope,
+                 pos_ids, batch, tok_per_batch, slot_base, kv_len, attn_mode, valid_len=None, blk_start=0, skip_post_attn=False):
+    """One decoder layer over M = batch*tok_per_batch <= 16 rows with the weight-streaming kernels (5 launches).
+    Input residual = h_in + sum(partials) (partials = down_proj slabs of the previous layer).  Returns
+    (h, partials, n_partials) describing this layer's output residual the same way."""
+    llm = stack.llm
+    M = batch * tok_per_batch
+    nq, nkv, hd = stack.nq, stack.nkv, llm.head_dim
+    H = llm.hidden_size
+    ops.skinny(L.PRO_NORM, L.SK_QKV_ROPE, h_in, lw.wqkv, M, partials=partials, n_partials=n_partials, norm_w=lw.ln_in,
+               eps=llm.rms_norm_eps, h_out=sb.hA, bias=lw.bqkv, q_out=sb.q, k_cache=cache.k[layer], vt_cache=cache.vt[layer],
+               rope_cos=rope[0], rope_sin=rope[1], pos_ids=pos_ids, n_q_heads=nq, n_kv_heads=nkv, s_max=cache.s_max,
+               tok_per_batch=tok_per_batch, slot_base=slot_base)
+    ks, vs = cache.strides()
+    ops.attn_skinny(sb.q, cache.k[layer], cache.vt[layer], sb.ao, batch, tok_per_batch, kv_len, nq, nkv, hd,
+                    (tok_per_batch * nq * hd, hd, nq * hd), ks, vs, (tok_per_batch * nq * hd, nq * hd), cache.s_max, hd ** -0.5,
+                    attn_mode, valid_len=valid_len, blk_start=blk_start)
+    if skip_post_attn:
+        return sb.hA, None, 0
+    ops.skinny(L.PRO_PLAIN, L.SK_PARTIAL, sb.ao, lw.wo, M, k_splits=stack.ks_o, out_f32=sb.part_o)
+    ops.skinny(L.PRO_NORM, L.SK_SWIGLU, sb.hA, lw.wgu, M, partials=sb.part_o, n_partials=stack.ks_o, norm_w=lw.ln_post,
+               eps=llm.rms_norm_eps, h_out=sb.hB, out=sb.act, ldo=llm.intermediate_size)
+    ops.skinny(L.PRO_PLAIN, L.SK_PARTIAL, sb.act, lw.wdown, M, k_splits=stack.ks_down, out_f32=sb.part_d)
+    return sb.hB, sb.part_d, stack.ks_down

@@ -1,0 +1,279 @@
+"""Drop-in mirror of the reference's `InternVLChatModel` surface (Vlaser_VLM/internvl_chat/internvl/model/
+internvl_chat/modeling_internvl_chat.py:39-450) running on hand-written gfx950 kernels.
+
+Same method names, argument meaning, attributes and error behaviour:
+  __init__(config)                      :48     (config: vlaser_amd.config.VlaserConfig or an HF-style dict)
+  load_state_dict(sd)                           HF checkpoint key names unchanged
+  extract_feature(pixel_values)         :273    [T,3,448,448] -> [T,256,H]
+  generate(pixel_values, input_ids, attention_mask, visual_features=None, **generate_kwargs)   :400
+  chat(tokenizer, pixel_values, question, generation_config, history=None, return_history=False, ...)   :343
+  batch_chat(...)                       :293
+  forward(pixel_values, input_ids, attention_mask, position_ids, image_flags, labels, ...)      :143
+Attributes read by callers: num_image_token, template, system_message, img_context_token_id, config.
+
+There is no CPU path: constructing the model without the HIP library / a GPU raises.
+"""
+from types import SimpleNamespace
+from typing import List, Optional
+
+import torch
+
+from . import _lib as L
+from . import ops, prep
+from .config import VlaserConfig
+from .engine import BF, KVCache, PrefillBuffers, QwenStack, SkinnyBuffers, VitEngine, prefill_layer, skinny_layer
+
+
+class InternVLChatModel:
+    def __init__(self, config: VlaserConfig, device='cuda', max_tiles=1, max_seq_len=1024, max_batch=1):
+        L.lib()   # fail loudly when the HIP library is missing
+        if not torch.cuda.is_available():
+            raise L.VlaserHipError('vlaser_amd needs an MI355X (gfx950) GPU: there is no CPU fallback')
+        self.config = config
+        self.device = torch.device(device)
+        self.num_image_token = config.num_image_token
+        self.template = config.template
+        self.ps_version = config.ps_version
+        self.select_layer = config.select_layer
+        self.downsample_ratio = config.downsample_ratio
+        self.conv_template = prep.get_conv_template(self.template)
+        self.system_message = self.conv_template.system_message
+        self.img_context_token_id = None
+        self.num_samples = 0
+        self._max_tiles, self._max_seq, self._max_batch = max_tiles, (max_seq_len + 63) // 64 * 64, max_batch
+        self.vit = None
+        self.llm = None
+        if config.select_layer != -1:
+            raise NotImplementedError('only select_layer == -1 (last hidden state) is implemented')
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd, strict=True):
+        need = ['vision_model.embeddings.class_embedding', 'mlp1.0.weight', 'language_model.model.embed_tokens.weight',
+                'language_model.lm_head.weight', 'language_model.model.norm.weight']
+        missing = [k for k in need if k not in sd]
+        if missing and strict:
+            raise KeyError(f'missing keys in state dict: {missing}')
+        self.vit = VitEngine(sd, self.config, self.device, max_tiles=self._max_tiles)
+        self.llm = QwenStack(sd, 'language_model.', self.config.llm, self.device)
+        self._alloc_llm()
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=[])
+
+    def _alloc_llm(self):
+        llm, dev = self.config.llm, self.device
+        self.cache = KVCache(llm.num_hidden_layers, self._max_batch, llm.num_key_value_heads, self._max_seq, dev, llm.head_dim)
+        self.pbuf = PrefillBuffers(self.llm, self._max_batch * self._max_seq, dev)
+        self.sbuf = SkinnyBuffers(self.llm, 16, dev)
+        self.rope = ops.rope_table(self._max_seq + 8, llm.head_dim, llm.rope_theta, dev)
+        self.h = torch.zeros(self._max_batch * self._max_seq, llm.hidden_size, dtype=BF, device=dev)
+        self.rank_ws = torch.zeros(self._max_batch * self._max_seq, dtype=torch.int32, device=dev)
+        self.img_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.logits = torch.zeros(16, llm.vocab_size, dtype=torch.float32, device=dev)
+        self.next_ids = torch.zeros(16, dtype=torch.int64, device=dev)
+        self.next_h = torch.zeros(16, llm.hidden_size, dtype=BF, device=dev)
+        self.pos1 = torch.zeros(16, dtype=torch.int32, device=dev)
+
+    def _ensure(self, batch, seq):
+        seq = (seq + 63) // 64 * 64
+        if batch > self._max_batch or seq > self._max_seq:
+            self._max_batch, self._max_seq = max(batch, self._max_batch), max(seq, self._max_seq)
+            self._alloc_llm()
+
+    # ------------------------------------------------------------------ vision
+    def _to_bf16(self, pixel_values):
+        pv = pixel_values.to(self.device)
+        if pv.dtype == torch.float32:
+            out = torch.empty(pv.shape, dtype=BF, device=self.device)
+            ops.cast_f32_bf16(pv.contiguous(), out)
+            return out
+        return pv.to(BF).contiguous()
+
+    def pixel_shuffle(self, x, scale_factor=0.5):
+        """[n,w,h,c] bf16 (no CLS) -> [n, w*s, h*s, c/s^2]: same permutation as modeling_internvl_chat.py:257-271."""
+        n, w, h, c = x.shape
+        assert w == h and scale_factor == 0.5
+        xin = torch.zeros(n, w * h + 1, c, dtype=BF, device=self.device)
+        xin[:, 1:] = x.reshape(n, w * h, c).to(BF)
+        out = torch.empty(n * (w // 2) * (h // 2), 4 * c, dtype=BF, device=self.device)
+        ops.pixel_shuffle(xin, out, n, w, c, 1 if self.ps_version == 'v1' else 0)
+        return out.view(n, w // 2, h // 2, 4 * c)
+
+    def extract_feature(self, pixel_values):
+        feats = self.vit.forward(self._to_bf16(pixel_values))
+        return feats.view(pixel_values.shape[0], self.num_image_token, -1).clone()
+
+    # ------------------------------------------------------------------ LLM plumbing
+    def _embed(self, input_ids, vit_embeds, zero_pad=False):
+        B, S = input_ids.shape
+        ids = input_ids.to(self.device).contiguous()
+        h = self.h[:B * S]
+        vit2d = None if vit_embeds is None else vit_embeds.reshape(-1, vit_embeds.shape[-1])
+        ops.embed_merge(ids, self.llm.embed, vit2d, h, self.img_context_token_id if self.img_context_token_id is not None else -1,
+                        self.config.pad_token_id, zero_pad, self.rank_ws, self.img_count)
+        return h
+
+    def _prefill(self, h, B, S, pos_ids):
+        for i, lw in enumerate(self.llm.layers):
+            prefill_layer(self.llm, lw, self.pbuf, h, self.cache, i, self.rope, pos_ids, B, S, L.ATTN_CAUSAL)
+        return h
+
+    def _head_last(self, h_last, partials, n_partials, M, greedy=True):
+        """final RMSNorm + lm_head on M rows -> fp32 logits (+ argmax and next-token embedding gather)."""
+        llm = self.config.llm
+        ops.skinny(L.PRO_NORM, L.SK_F32, h_last, self.llm.head, M, partials=partials, n_partials=n_partials, norm_w=self.llm.norm,
+                   eps=llm.rms_norm_eps, out_f32=self.logits)
+        if greedy:
+            ops.argmax(self.logits[:M], self.next_ids, self.llm.embed, self.next_h)
+
+    def _decode_step(self, B, L_cur):
+        """One greedy step for B sequences whose caches hold L_cur tokens: consumes self.next_h."""
+        self.pos1[:B].fill_(L_cur)
+        h, parts, npart = self.next_h, None, 0
+        for i, lw in enumerate(self.llm.layers):
+            h, parts, npart = skinny_layer(self.llm, lw, self.sbuf, h, parts, npart, self.cache, i, self.rope, self.pos1, B, 1, L_cur,
+                                           L_cur + 1, L.ATTN_FULL)
+        self._head_last(h, parts, npart, B)
+
+    # ------------------------------------------------------------------ public surfaces
+    @torch.no_grad()
+    def generate(self, pixel_values=None, input_ids=None, attention_mask=None, visual_features=None, generation_config=None,
+                 output_hidden_states=None, max_new_tokens=None, min_new_tokens=0, do_sample=False, eos_token_id=None,
+                 pad_token_id=None, return_logits=False, **generate_kwargs):
+        assert self.img_context_token_id is not None
+        if do_sample:
+            raise NotImplementedError('only greedy decoding (do_sample=False) is implemented')
+        if generation_config is not None:
+            max_new_tokens = max_new_tokens or getattr(generation_config, 'max_new_tokens', None)
+            eos_token_id = eos_token_id if eos_token_id is not None else getattr(generation_config, 'eos_token_id', None)
+        max_new_tokens = max_new_tokens or 20          # HF default max_length heritage
+        B, S = input_ids.shape
+        if attention_mask is not None and not bool(attention_mask.bool().all()):
+            raise NotImplementedError('padded batches (batch_chat) are a "next" row (SURVEY.md 8f-4)')
+        if B > 16:
+            raise ValueError('at most 16 sequences per generate() call')
+        self._ensure(B, S + max_new_tokens)
+        if pixel_values is not None:
+            vit_embeds = visual_features if visual_features is not None else self.vit.forward(self._to_bf16(pixel_values))
+            n_sel = int((input_ids == self.img_context_token_id).sum())
+            assert n_sel != 0
+            if n_sel != vit_embeds.numel() // vit_embeds.shape[-1]:
+                raise RuntimeError(f'shape mismatch: {n_sel} <IMG_CONTEXT> tokens vs {vit_embeds.numel() // vit_embeds.shape[-1]} visual tokens')
+        else:
+            vit_embeds = None
+        h = self._embed(input_ids, vit_embeds)
+        pos = torch.arange(S, dtype=torch.int32, device=self.device).repeat(B)
+        self._prefill(h, B, S, pos)
+        last = h.view(B, S, -1)[:, -1].contiguous()
+        self._head_last(last, None, 0, B)
+        out, logits_out = [], []
+        eos = eos_token_id if isinstance(eos_token_id, (list, tuple)) or eos_token_id is None else [eos_token_id]
+        finished = torch.zeros(B, dtype=torch.bool)
+        pad = pad_token_id if pad_token_id is not None else (eos[0] if eos else 0)
+        for step in range(max_new_tokens):
+            if return_logits:
+                logits_out.append(self.logits[:B].clone())
+            nxt = self.next_ids[:B].cpu()
+            nxt = torch.where(finished, torch.full_like(nxt, pad), nxt)
+            out.append(nxt)
+            if eos is not None and step + 1 >= min_new_tokens:
+                finished = finished | torch.isin(nxt, torch.tensor(eos))
+            if step == max_new_tokens - 1 or bool(finished.all()):
+                break
+            self._decode_step(B, S + step)
+        ids = torch.stack(out, dim=1).to(self.device)
+        if return_logits:
+            return ids, torch.stack(logits_out, dim=1)
+        return ids
+
+    def chat(self, tokenizer, pixel_values, question, generation_config, history=None, return_history=False,
+             num_patches_list=None, IMG_START_TOKEN='<img>', IMG_END_TOKEN='</img>', IMG_CONTEXT_TOKEN='<IMG_CONTEXT>',
+             verbose=False):
+        if num_patches_list is None:
+            num_patches_list = [pixel_values.shape[0]] if pixel_values is not None else []
+        assert pixel_values is None or len(pixel_values) == sum(num_patches_list)
+        self.img_context_token_id = tokenizer.convert_tokens_to_ids(IMG_CONTEXT_TOKEN)
+        query, question, template = prep.build_chat_query(self.template, self.system_message, question, num_patches_list,
+                                                          self.num_image_token, history, pixel_values is not None)
+        eos_token_id = tokenizer.convert_tokens_to_ids(template.sep.strip())
+        history = [] if history is None else history
+        if verbose and pixel_values is not None:
+            print(f'dynamic ViT batch size: {pixel_values.shape[0]}')
+        model_inputs = tokenizer(query, return_tensors='pt')
+        generation_config['eos_token_id'] = eos_token_id      # the reference mutates the caller's dict too (:381)
+        out = self.generate(pixel_values=pixel_values, input_ids=model_inputs['input_ids'],
+                            attention_mask=model_inputs['attention_mask'], **generation_config)
+        response = tokenizer.batch_decode(out, skip_special_tokens=True)[0]
+        response = response.split(template.sep.strip())[0].strip()
+        history.append((question, response))
+        if return_history:
+            return response, history
+        if verbose:
+            print(query.replace(IMG_CONTEXT_TOKEN, '').replace(f'{IMG_START_TOKEN}{IMG_END_TOKEN}', '<image>'), response)
+        return response
+
+    def batch_chat(self, tokenizer, pixel_values, questions, generation_config, num_patches_list=None, history=None,
+                   return_history=False, IMG_START_TOKEN='<img>', IMG_END_TOKEN='</img>', IMG_CONTEXT_TOKEN='<IMG_CONTEXT>',
+                   verbose=False, image_counts=None):
+        if history is not None or return_history:
+            print('Now multi-turn chat is not supported in batch_chat.')
+            raise NotImplementedError
+        # left-padded batched generation is a "next" row: run the queries one by one, same results
+        responses, off = [], 0
+        for q, n in zip(questions, num_patches_list):
+            pv = None if pixel_values is None else pixel_values[off:off + n]
+            off += n
+            responses.append(self.chat(tokenizer, pv, q, dict(generation_config), num_patches_list=[n]))
+        return responses
+
+    @torch.no_grad()
+    def forward(self, pixel_values, input_ids=None, attention_mask=None, position_ids=None, image_flags=None,
+                past_key_values=None, labels=None, use_cache=None, output_attentions=None, output_hidden_states=None,
+                return_dict=None, statistics=None, loss_weight=None, loss_reduction_all_gather=False):
+        """Inference forward (logits + CE loss).  The trainable SFT step lives in vlaser_amd.sft."""
+        if loss_weight is not None or past_key_values is not None:
+            raise NotImplementedError('packed-sequence loss weights / external caches are out of scope (SURVEY.md 8f-4)')
+        B, S = input_ids.shape
+        if attention_mask is not None and not bool(attention_mask.bool().all()):
+            raise NotImplementedError('padded batches are a "next" row (SURVEY.md 8f-4)')
+        self._ensure(B, S)
+        feats = self.vit.forward(self._to_bf16(pixel_values)).view(pixel_values.shape[0], self.num_image_token, -1)
+        if image_flags is not None:
+            feats = feats[image_flags.reshape(-1).to(self.device) == 1]
+        n_sel = int((input_ids == self.img_context_token_id).sum())
+        ignore_flag = False
+        feats2d = feats.reshape(-1, feats.shape[-1])
+        if n_sel != feats2d.shape[0]:
+            # reference falls back to the first n_token features and zeroes the loss (:184-190, 242-243)
+            print(f'warning: shape mismatch, input_embeds[selected].shape={n_sel}, vit_embeds.shape={tuple(feats2d.shape)}')
+            feats2d = feats2d[:n_sel].contiguous()
+            ignore_flag = True
+        h = self._embed(input_ids, feats2d)
+        if position_ids is None:
+            pos = torch.arange(S, dtype=torch.int32, device=self.device).repeat(B)
+        else:
+            pos = position_ids.to(self.device).to(torch.int32).reshape(-1).contiguous()
+        self._prefill(h, B, S, pos)
+        x = ops.rmsnorm(h[:B * S], self.llm.norm, self.config.llm.rms_norm_eps)
+        logits = ops.linear(x, self.llm.head, epi=L.EPI_F32).view(B, S, -1)
+        loss = None
+        if labels is not None:
+            from .sft import ce_loss
+            loss = ce_loss(logits[:, :-1].reshape(-1, logits.shape[-1]), labels[:, 1:].reshape(-1).to(self.device))
+            if ignore_flag:
+                loss = loss * 0.0
+        return SimpleNamespace(loss=loss, logits=logits, past_key_values=None, hidden_states=None, attentions=None)
+
+    __call__ = forward
+
+    # accessors the reference exposes (:442-450)
+    @property
+    def lm_head(self):
+        return self.llm.head
+
+    def get_input_embeddings(self):
+        return self.llm.embed
+
+    def get_output_embeddings(self):
+        return self.llm.head
+
+    def eval(self):
+        return self

@@ -1,0 +1,235 @@
+"""Drop-in mirror of the Vlaser-VLA inference surface `PiZero` / `PiZeroInference`
+(Vlaser_VLA/Simpler/src/model/vla/pizero_internvl.py:154-336,517-603,798-936,1286-1307) on gfx950 kernels.
+
+  infer_action(input_ids[B,384] i64, pixel_values[B*n,3,448,448], image_text_proprio_mask[B,1,385,385],
+               action_mask[B,1,4,389], vlm_position_ids[B,384], proprio_position_ids[B,1],
+               action_position_ids[B,4], proprios[B,1,7], noise=None, generator=None) -> [B,4,7]
+  build_causal_mask_and_position_ids(attention_mask, dtype), split_full_mask_into_submasks(mask)
+
+Extensions over the reference: an explicit `noise` / `generator` argument (the reference draws torch.randn inside
+the method, :879-881) and `valid_len` descriptors derived from the dense masks (the kernels never read the
+[B,1,389,389] tensors).  The whole call (ViT -> joint prefill -> 10 Euler steps) is allocation-free and is
+replayed from ONE HIP graph after the first call of a given batch size.
+
+Checkpoint: canonical (de-aliased) VLA state dict -- the InternVLChatModel keys plus action_expert.model.*,
+action_encoder.*, proprio_encoder.*, action_decoder.* (see `canonicalize_vla_state_dict`).
+"""
+import torch
+
+from . import _lib as L
+from . import ops, prep
+from .config import VLAConfig
+from .engine import BF, KVCache, PrefillBuffers, QwenStack, SkinnyBuffers, VitEngine, prefill_layer, skinny_layer
+
+
+def canonicalize_vla_state_dict(sd):
+    """Map the released `.pt` `data["model"]` key aliases onto canonical names (eval.py:196-212 strips
+    `_orig_mod.`; the same modules are registered under several names, pizero_internvl.py:253-288,508-510)."""
+    out = {}
+    rules = [('vision_tower.vision_model.', 'vision_model.'), ('internvl_model.vision_model.', 'vision_model.'),
+             ('multi_modal_projector.', 'mlp1.'), ('internvl_model.mlp1.', 'mlp1.'),
+             ('joint_model.mixtures.vlm.layers.', 'language_model.model.layers.'),
+             ('joint_model.mixtures.vlm.norm.', 'language_model.model.norm.'),
+             ('joint_model.mixtures.action.layers.', 'action_expert.model.layers.'),
+             ('joint_model.mixtures.proprio.layers.', 'action_expert.model.layers.'),
+             ('joint_model.mixtures.action.norm.', 'action_expert.model.norm.'),
+             ('joint_model.mixtures.proprio.norm.', 'action_expert.model.norm.'),
+             ('internvl_model.action_expert.model.norm.', 'action_expert.model.norm.'),
+             ('internvl_model.language_model.', 'language_model.'),
+             ('embed_tokens.', 'language_model.model.embed_tokens.'),
+             ('lm_head.', 'language_model.lm_head.')]
+    for k, v in sd.items():
+        if k.startswith('_orig_mod.'):
+            k = k[len('_orig_mod.'):]
+        for a, b in rules:
+            if k.startswith(a):
+                k = b + k[len(a):]
+                break
+        if k in out and out[k].shape != v.shape:
+            raise ValueError(f'alias collision with different shapes for {k}')
+        out.setdefault(k, v)
+    return out
+
+
+class PiZero:
+    def __init__(self, cfg: VLAConfig, device='cuda', max_batch=1, use_graph=True):
+        L.lib()
+        if not torch.cuda.is_available():
+            raise L.VlaserHipError('vlaser_amd needs an MI355X (gfx950) GPU: there is no CPU fallback')
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.max_image_text_tokens = cfg.max_image_text_tokens
+        self.num_proprio_tokens = cfg.num_proprio_tokens
+        self.num_action_tokens = cfg.num_action_tokens
+        self.total_num_tokens = self.max_image_text_tokens + self.num_proprio_tokens + self.num_action_tokens
+        self.num_inference_steps = cfg.num_inference_steps
+        self.horizon_steps = cfg.num_action_tokens
+        self.action_dim, self.proprio_dim = cfg.action_dim, cfg.proprio_dim
+        self.final_action_clip_value = cfg.final_action_clip_value
+        self.image_token_index = cfg.base.img_context_token_id
+        self.pad_token_id = cfg.base.pad_token_id
+        self.num_images = cfg.cond_steps
+        self.max_batch = max_batch
+        self.use_graph = use_graph
+        self._graphs = {}
+        if max_batch * cfg.num_action_tokens > 16:
+            raise ValueError('the weight-streaming action path handles batch * horizon <= 16 rows')
+
+    # ------------------------------------------------------------------ weights / workspace
+    def load_state_dict(self, sd, strict=True):
+        sd = canonicalize_vla_state_dict(sd)
+        cfg, dev = self.cfg, self.device
+        base = cfg.base
+        self.vit = VitEngine(sd, base, dev, max_tiles=self.max_batch * self.num_images)
+        self.vlm = QwenStack(sd, 'language_model.', base.llm, dev, with_embed=True, with_head=False)
+        self.expert = QwenStack(sd, 'action_expert.', cfg.expert, dev, with_embed=False, with_head=False)
+        g = lambda k: sd[k].to(device=dev, dtype=BF).contiguous()
+        self.ae_w1, self.ae_b1 = g('action_encoder.linear_1.weight'), g('action_encoder.linear_1.bias')
+        self.ae_w2, self.ae_b2 = g('action_encoder.linear_2.weight'), g('action_encoder.linear_2.bias')
+        self.ae_w3, self.ae_b3 = g('action_encoder.linear_3.weight'), g('action_encoder.linear_3.bias')
+        self.pe_w, self.pe_b = g('proprio_encoder.weight'), g('proprio_encoder.bias')
+        self.ad_w, self.ad_b = g('action_decoder.weight'), g('action_decoder.bias')
+        self._alloc()
+        return self
+
+    def _alloc(self):
+        cfg, dev, B = self.cfg, self.device, self.max_batch
+        llm = cfg.base.llm
+        T = self.max_image_text_tokens
+        self.s_max = (self.total_num_tokens + 63) // 64 * 64
+        self.cache = KVCache(llm.num_hidden_layers, B, llm.num_key_value_heads, self.s_max, dev, llm.head_dim)
+        self.pbuf = PrefillBuffers(self.vlm, B * T, dev)
+        self.sb_pro = SkinnyBuffers(self.expert, 16, dev)
+        self.sb_act = SkinnyBuffers(self.expert, 16, dev)
+        self.rope = ops.rope_table(T + 16, llm.head_dim, llm.rope_theta, dev)
+        W = cfg.action_hidden_size
+        z = lambda *s, dt=BF: torch.zeros(*s, dtype=dt, device=dev)
+        self.h_vlm = z(B * T, llm.hidden_size)
+        self.h_pro = z(16, W)
+        self.xcat = z(16, 2 * W)
+        self.e2 = z(16, W)
+        self.h_act = z(16, W)
+        self.action = z(16, cfg.action_dim, dt=torch.float32)
+        self.rank_ws = z(B * T, dt=torch.int32)
+        self.valid_len = z(B, dt=torch.int32)
+        # static inputs of the captured graph
+        self.in_ids = z(B, T, dt=torch.int64)
+        self.in_pix = z(B * self.num_images, 3, cfg.base.vision.image_size, cfg.base.vision.image_size)
+        self.in_proprio = z(B, cfg.proprio_dim, dt=torch.float32)
+        self.in_noise = z(B * self.num_action_tokens, cfg.action_dim, dt=torch.float32)
+        self.pos_vlm = z(B * T, dt=torch.int32)
+        self.pos_pro = z(B, dt=torch.int32)
+        self.pos_act = z(B * self.num_action_tokens, dt=torch.int32)
+
+    # ------------------------------------------------------------------ reference helpers (API parity)
+    def build_causal_mask_and_position_ids(self, attention_mask, dtype):
+        return prep.build_causal_mask_and_position_ids(attention_mask, dtype, self.max_image_text_tokens, self.num_proprio_tokens,
+                                                       self.num_action_tokens)
+
+    def split_full_mask_into_submasks(self, causal_mask):
+        return prep.split_full_mask_into_submasks(causal_mask, self.max_image_text_tokens, self.num_proprio_tokens,
+                                                  self.num_action_tokens)
+
+    def build_mixture_caches(self):
+        return self.cache
+
+    # ------------------------------------------------------------------ the hot path (all kernel launches)
+    def _run(self, B):
+        cfg = self.cfg
+        base, llm, ex = cfg.base, cfg.base.llm, cfg.expert
+        T, na = self.max_image_text_tokens, self.num_action_tokens
+        nL = llm.num_hidden_layers
+        # a1-a7, a12: ViT tiles -> projector -> scatter into the (zero-padded) text embeddings
+        feats = self.vit.forward(self.in_pix[:B * self.num_images])
+        h_vlm = self.h_vlm[:B * T]
+        ops.embed_merge(self.in_ids[:B], self.vlm.embed, feats, h_vlm, self.image_token_index, self.pad_token_id, True, self.rank_ws)
+        ops.small_linear(self.in_proprio, self.pe_w, self.pe_b, self.h_pro, B, cfg.action_hidden_size, cfg.proprio_dim)
+        # a13: joint prefill over {vlm, proprio}; K/V of both mixtures cached (post-RoPE), last layer skips o_proj+MLP
+        h_pro, parts, npart = self.h_pro, None, 0
+        for i in range(nL):
+            last = i == nL - 1
+            prefill_layer(self.vlm, self.vlm.layers[i], self.pbuf, h_vlm, self.cache, i, self.rope, self.pos_vlm, B, T,
+                          L.ATTN_PREFIX, valid_len=self.valid_len, blk_start=T, skip_post_attn=last)
+            h_pro, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_pro, h_pro, parts, npart, self.cache, i,
+                                               self.rope, self.pos_pro, B, 1, T, T + 1, L.ATTN_PREFIX, valid_len=self.valid_len,
+                                               blk_start=T, skip_post_attn=last)
+        # a14: flow-matching Euler integration over the cached prefix
+        M = B * na
+        self.action[:M].copy_(self.in_noise[:M])
+        n = self.num_inference_steps
+        dt = 1.0 / n
+        W = cfg.action_hidden_size
+        for s in range(n):
+            t = s * dt
+            ops.vla_prep(self.action, self.ae_w1, self.ae_b1, self.xcat, M, W, cfg.action_dim, t, cfg.time_max_period)
+            ops.skinny(L.PRO_PLAIN, L.SK_BIAS_SILU, self.xcat, self.ae_w2, M, out=self.e2, ldo=W, bias=self.ae_b2)
+            ops.skinny(L.PRO_PLAIN, L.SK_BIAS, self.e2, self.ae_w3, M, out=self.h_act, ldo=W, bias=self.ae_b3)
+            h, parts, npart = self.h_act, None, 0
+            for i in range(nL):
+                h, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_act, h, parts, npart, self.cache, i, self.rope,
+                                               self.pos_act, B, na, T + 1, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len,
+                                               blk_start=T)
+            clip = self.final_action_clip_value
+            ops.vla_euler(h, parts, npart, M, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action, W, cfg.action_dim, dt,
+                          clip if clip is not None else 0.0, clip is not None and s == n - 1)
+
+    @torch.no_grad()
+    def infer_action(self, input_ids, pixel_values, image_text_proprio_mask=None, action_mask=None, vlm_position_ids=None,
+                     proprio_position_ids=None, action_position_ids=None, proprios=None, noise=None, generator=None,
+                     valid_len=None):
+        cfg, dev = self.cfg, self.device
+        B = pixel_values.shape[0] // self.num_images
+        T, na = self.max_image_text_tokens, self.num_action_tokens
+        if B > self.max_batch:
+            raise ValueError(f'batch {B} > max_batch {self.max_batch}')
+        if input_ids.shape != (B, T):
+            raise ValueError(f'input_ids must be [B,{T}] (right-padded with pad_token_id), got {tuple(input_ids.shape)}')
+        # ---- stage inputs into the static buffers (host->device plumbing)
+        self.in_ids[:B].copy_(input_ids)
+        pv = pixel_values.to(dev)
+        if pv.dtype == torch.float32:
+            ops.cast_f32_bf16(pv.contiguous(), self.in_pix[:B * self.num_images])
+        else:
+            self.in_pix[:B * self.num_images].copy_(pv)
+        self.in_proprio[:B].copy_(proprios.reshape(B, -1).to(torch.float32))
+        if valid_len is None:
+            if image_text_proprio_mask is not None:
+                valid_len = prep.mask_to_descriptor(image_text_proprio_mask.to('cpu'), T)
+            else:
+                valid_len = (input_ids != self.pad_token_id).sum(-1)
+        self.valid_len[:B].copy_(valid_len.to(torch.int32))
+        bpos = lambda p, default: (default if p is None else p).to(torch.int32).reshape(-1)
+        self.pos_vlm[:B * T].copy_(bpos(vlm_position_ids, torch.arange(1, T + 1).repeat(B, 1)))
+        self.pos_pro[:B].copy_(bpos(proprio_position_ids, torch.ones(B, 1, dtype=torch.long)))
+        self.pos_act[:B * na].copy_(bpos(action_position_ids, torch.arange(2, 2 + na).repeat(B, 1)))
+        if noise is None:
+            noise = torch.randn((B, na, cfg.action_dim), generator=generator)      # reference: torch.randn inside (:879-881)
+        self.in_noise[:B * na].copy_(noise.reshape(B * na, -1).to(torch.float32))
+        # ---- run (HIP graph replay after the first call per batch size)
+        if self.use_graph:
+            g = self._graphs.get(B)
+            if g is None:
+                self._run(B)                      # warm-up: sets kernel attributes, touches every buffer
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._run(B)
+                self._graphs[B] = g
+            g.replay()
+        else:
+            self._run(B)
+        act = self.action[:B * na].view(B, na, cfg.action_dim)
+        return act[:, -cfg.horizon_steps:].clone()
+
+    def forward(self, *args, **kw):
+        return self.infer_action(*args, **kw)
+
+    __call__ = forward
+
+    def eval(self):
+        return self
+
+
+class PiZeroInference(PiZero):
+    """pizero_internvl.py:1286-1307."""
+    pass
