@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the Vlaser hot path on MI355X (contract: one JSON line on rank 0).
+
+    python bench.py --gpus N --steps K --warmup W [--workload vla_chunk]
+
+Workload `vla_chunk` = BASELINE.json configs[2]: Vlaser-2B-VLA image -> action-chunk forward (one 448x448 WidowX
+observation, 384-token prompt with 277 valid tokens, 7-DoF x 4-step chunk, 10 flow-matching Euler steps), batch 1,
+bf16 storage / fp32 accumulate, synthetic inputs and deterministic random-init weights of the true architecture
+(SURVEY.md 8d).  A "step" is one full infer_action() call with inputs already resident in HBM.
+Inference does not shard: N > 1 runs N independent replicas (one process per GPU, no data-path collective) and
+`value` is the whole-job rate = N*K chunks / max-over-ranks time ("scaling": "weak").
+
+Extra objects on the JSON line (tier contract 4):
+  roofline     : dominant kernel, algorithmic bytes per launch / HIP-event time per launch vs 8 TB/s HBM peak
+  cpu_baseline : this repo's CPU oracle (a port of the reference's fp32 CPU path) timed on the host cores on a
+                 bounded, depth-truncated sample and scaled linearly in depth (stated in `sample`)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_inputs(cfg, B, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    pv = torch.randn(B, 3, 448, 448, generator=g)
+    ids = torch.full((B, 384), cfg.pad_token_id)
+    ids[:, :10] = torch.randint(0, 151643, (B, 10), generator=g)
+    ids[:, 10:266] = cfg.img_context_token_id
+    ids[:, 266:277] = torch.randint(0, 151643, (B, 11), generator=g)
+    proprio = torch.rand(B, 1, 7, generator=g) * 2 - 1
+    noise = torch.randn(B, 4, 7, generator=g)
+    return ids, pv, proprio, noise
+
+
+def cpu_baseline(vla_full, seed=0):
+    """Oracle (fp32 torch-CPU port of the reference path) on a depth-truncated, full-width model; scaled to depth."""
+    from vlaser_amd import config as C, synth
+    from oracle import vla as ovla, vit as ovit
+    import torch.nn.functional as F
+    torch.set_num_threads(os.cpu_count())
+    dv, dl = 4, 4
+    cfg = C.truncated(vla_full.base, dv, dl)
+    vla = C.VLAConfig(base=cfg)
+    sd = synth.vla_state_dict(vla)
+    ids, pv, proprio, noise = make_inputs(cfg, 1, seed)
+    am = (ids != cfg.pad_token_id).long()
+    mask, vp, pp, ap = ovla.build_causal_mask_and_position_ids(am, torch.float32, vla)
+    m1, m2 = ovla.split_full_mask_into_submasks(mask, vla)
+    with torch.no_grad():
+        def run():
+            t0 = time.perf_counter()
+            emb = ovla.embed_image_text(sd, vla, ids, pv)
+            t1 = time.perf_counter()
+            caches = {'vlm': [], 'proprio': []}
+            pro = F.linear(proprio, sd['proprio_encoder.weight'], sd['proprio_encoder.bias'])
+            ovla.joint_forward(sd, vla, {'vlm': emb, 'proprio': pro}, {'vlm': vp, 'proprio': pp}, m1, caches)
+            t2 = time.perf_counter()
+            a = noise.clone()
+            for s in range(vla.num_inference_steps):
+                temb = ovla.sinusoidal_pos_emb(torch.full((1,), s * 0.1), vla.action_hidden_size, vla.time_max_period)
+                ae = ovla.action_encoder(sd, a, temb)
+                out = ovla.joint_forward(sd, vla, {'action': ae}, {'action': ap}, m2, caches, final_skip=())['action']
+                a = a + 0.1 * F.linear(out, sd['action_decoder.weight'], sd['action_decoder.bias'])
+            t3 = time.perf_counter()
+            return t1 - t0, t2 - t1, t3 - t2
+        run()                       # warm-up
+        ts = [run() for _ in range(2)]
+    tv, tp, te = [min(t[i] for t in ts) for i in range(3)]
+    full = tv * vla_full.base.vision.num_hidden_layers / dv + (tp + te) * vla_full.base.llm.num_hidden_layers / dl
+    return {'value': round(1.0 / full, 4), 'unit': 'action-chunks/s', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': f'oracle fp32 torch-CPU, full widths, ViT {dv}/24 + LLM/expert {dl}/28 layers, 10 Euler steps, batch 1; '
+                      f'phase times scaled linearly in depth (ViT x{24 // dv}, prefill+Euler x{28 // dl}); '
+                      f'measured {tv:.2f}+{tp:.2f}+{te:.2f} s -> est. {full:.1f} s/chunk'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='vla_chunk', choices=['vla_chunk'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl')      # RCCL on ROCm: used for the barrier and the max-over-ranks time only
+
+    from vlaser_amd import config as C, synth
+    from vlaser_amd.pizero import PiZeroInference
+    torch.set_grad_enabled(False)
+    vla = C.VLAConfig(base=C.vlaser_2b())
+    dev = f'cuda:{local}'
+    sd = synth.vla_state_dict(vla, device=dev, dtype=torch.bfloat16)
+    model = PiZeroInference(vla, device=dev, max_batch=1)
+    model.load_state_dict(sd)
+    del sd
+    torch.cuda.empty_cache()
+    ids, pv, proprio, noise = make_inputs(vla.base, 1, seed=rank)
+    # inputs resident in HBM before the timed region
+    ids_d, pv_d, pro_d, noise_d = ids.to(dev), pv.to(dev).to(torch.bfloat16), proprio.to(dev), noise.to(dev)
+    valid = (ids != vla.base.pad_token_id).sum(-1).to(dev)
+    call = lambda: model.infer_action(ids_d, pv_d, proprios=pro_d, noise=noise_d, valid_len=valid)
+
+    for _ in range(max(a.warmup, 1)):
+        out = call()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = call()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        line = {
+            'metric': 'action_chunks_per_sec', 'value': round(world * a.steps / dt, 3), 'unit': 'action-chunks/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'Vlaser-2B-VLA action-chunk inference: 1x448px image, 384-token prompt (277 valid), '
+                                   '7-DoF x 4-step chunk, 10 Euler steps, batch 1 per GPU (BASELINE configs[2])',
+                       'parallelism': f'replicas x{world} (no collective)', 'weights': 'random-init, true architecture'},
+        }
+        if world == 1 and not a.no_roofline:
+            avg_ms, byts, n = _probe(model, ids_d, pv_d, pro_d, noise_d, valid)
+            ach = byts / (avg_ms * 1e-3) / 1e9
+            line['roofline'] = {'bound': 'hbm', 'kernel': 'skinny_kernel<NORM,SWIGLU> (action-expert gate/up GEMV, N=17920 K=768)',
+                                'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
+                                'traffic': None, 'bytes_per_launch': byts, 'us_per_launch': round(avg_ms * 1e3, 3), 'launches_timed': n}
+        if world == 1 and not a.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(vla)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def _probe(model, ids_d, pv_d, pro_d, noise_d, valid):
+    """HIP-event time per launch of the dominant kernel (gate/up weight-streaming GEMV of the action expert,
+    skinny_kernel<NORM,SWIGLU>) inside eager (un-graphed) chunks, events on the launch stream."""
+    from vlaser_amd import ops, _lib as L
+    recs = []
+    orig = ops.skinny
+
+    def hooked(pro, epi, x, W, M, **kw):
+        if pro == L.PRO_NORM and epi == L.SK_SWIGLU:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(pro, epi, x, W, M, **kw)
+            e1.record()
+            # algorithmic bytes: packed gate/up weights once + normalised activations in + SwiGLU activations out
+            recs.append((e0, e1, W.numel() * 2 + M * W.shape[1] * 2 + M * (W.shape[0] // 2) * 2))
+        else:
+            orig(pro, epi, x, W, M, **kw)
+    import vlaser_amd.engine as eng
+    eng.ops.skinny = hooked
+    try:
+        model.use_graph = False
+        for _ in range(3):
+            model.infer_action(ids_d, pv_d, proprios=pro_d, noise=noise_d, valid_len=valid)
+        torch.cuda.synchronize()
+    finally:
+        eng.ops.skinny = orig
+        model.use_graph = True
+    ms = [e0.elapsed_time(e1) for e0, e1, _ in recs]
+    return sum(ms) / len(ms), recs[0][2], len(ms)
+
+
+if __name__ == '__main__':
+    main()
