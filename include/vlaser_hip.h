@@ -36,7 +36,8 @@ enum {
   VL_EPI_SWIGLU = 5,     /* W = gate/up interleaved in 16-row groups; out[m, n/2] = silu(g)*u */
   VL_EPI_QKV_ROPE = 6,   /* fused q/k/v projection + bias + RoPE + KV-cache write (Qwen2, head_dim 128) */
   VL_EPI_VIT_QKV = 7,    /* fused ViT qkv + bias, q*scale; writes Q,K [T,H,S,64] and V^T [T,H,64,Spad] */
-  VL_EPI_F32 = 8         /* out (float32) = acc   (full-vocab logits) */
+  VL_EPI_F32 = 8,        /* out (float32) = acc   (full-vocab logits) */
+  VL_EPI_PARTIAL = 9     /* split-K: out_f32[ks, m, n] = partial over K slice ks (reduced by vlaser_reduce_norm) */
 };
 
 typedef struct {
@@ -56,6 +57,9 @@ typedef struct {
   int n_q_heads, n_kv_heads, s_max, tok_per_batch, slot_base;
   /* VL_EPI_VIT_QKV */
   void* vq; void* vk; void* vvt; int vit_heads, vit_seq, vit_seq_pad; float q_scale;
+  /* VL_EPI_PARTIAL */
+  float* out_f32; int k_splits;
+  int force_bm;             /* 0 = heuristic, else tile height 32 / 64 / 128 (tests) */
 } VlaserGemmArgs;
 
 int vlaser_gemm(int epi, const VlaserGemmArgs* args, vl_stream_t stream);
@@ -157,6 +161,12 @@ int vlaser_cast_f32_bf16(const float* x, void* y, long long n, vl_stream_t strea
  * ignore_index; lse_row optional. */
 int vlaser_ce_rows(const float* logits, const int64_t* labels, int R, int N, long long ld, float* loss_row, float* lse_row,
                    long long ignore_index, vl_stream_t stream);
+/* Fused split-K reduction + residual (+bias, +layer-scale) + norm: the seam between a VL_EPI_PARTIAL GEMM and the
+ * next GEMM.   h = h_in + [ls *] (sum_s partials[s] [+ bias]);  x_out = norm(h) (kind 0 none / 1 RMS (Qwen2) / 2 LayerNorm).
+ * Replaces `residual + o_proj(...)` + post_attention_layernorm / `+ mlp(...)` + next input_layernorm (Qwen2DecoderLayer)
+ * and `h + ls*attn(...)`, norm2 / `h + ls*mlp(...)`, next norm1 (modeling_intern_vit.py:291-293). Row-wise, in place OK. */
+int vlaser_reduce_norm(const void* h_in, const float* partials, int n_partials, const void* bias, const void* ls, int norm_kind,
+                       const void* norm_w, const void* norm_b, float eps, void* h_out, void* x_out, int M, int C, vl_stream_t stream);
 
 #ifdef __cplusplus
 }

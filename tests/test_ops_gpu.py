@@ -369,3 +369,70 @@ def test_vla_glue(ops):
     vref = (y @ wd.float().t() + bd.float())
     close(vel, vref, rtol=1e-2, atol=5e-3, name='vel')
     close(act, a0 + 0.1 * vel, rtol=1e-5, atol=1e-6, name='euler')
+
+
+@pytest.mark.parametrize('bm', [32, 64, 128])
+def test_gemm_tile_heights(ops, bm):
+    from vlaser_amd import _lib as L
+    M, N, K = 385, 1536, 1536
+    x, w, b = rnd(M, K), rnd(N, K, std=0.05), rnd(N, std=0.5)
+    out = torch.zeros(M, N, dtype=BF, device='cuda')
+    ops.gemm(L.EPI_BIAS, x, w, out=out, bias=b, force_bm=bm)
+    close(out, x.float() @ w.float().t() + b.float(), name=f'bm{bm}')
+    g, u = rnd(2048, K, std=0.03, seed=1), rnd(2048, K, std=0.03, seed=2)
+    o2 = torch.zeros(M, 2048, dtype=BF, device='cuda')
+    ops.gemm(L.EPI_SWIGLU, x, ops.pack_gate_up(g, u), out=o2, force_bm=bm)
+    gr = (x.float() @ g.float().t()).to(BF).float(); ur = (x.float() @ u.float().t()).to(BF).float()
+    close(o2, F.silu(gr).to(BF).float() * ur, name=f'swiglu bm{bm}')
+
+
+@pytest.mark.parametrize('bm', [32, 64])
+def test_gemm_qkv_rope_small_tiles(ops, bm):
+    from vlaser_amd import _lib as L
+    B, S, H, nq, nkv, smax = 1, 100, 1536, 12, 2, 128
+    M = B * S
+    x = rnd(M, H)
+    qw, kw, vw = rnd(nq * 128, H, std=0.03, seed=1), rnd(nkv * 128, H, std=0.03, seed=2), rnd(nkv * 128, H, std=0.03, seed=3)
+    qb, kb, vb = rnd(nq * 128, std=0.3, seed=4), rnd(nkv * 128, std=0.3, seed=5), rnd(nkv * 128, std=0.3, seed=6)
+    W, Bv = ops.pack_qkv(qw, kw, vw, qb, kb, vb)
+    cos, sin = ops.rope_table(512)
+    pos = (torch.arange(S).repeat(B) + 1).int().cuda()
+    q_out = torch.zeros(M, nq * 128, dtype=BF, device='cuda')
+    kc = torch.zeros(B, nkv, smax, 128, dtype=BF, device='cuda'); vtc = torch.zeros(B, nkv, 128, smax, dtype=BF, device='cuda')
+    ops.gemm(L.EPI_QKV_ROPE, x, W, bias=Bv, q_out=q_out, k_cache=kc, vt_cache=vtc, rope_cos=cos, rope_sin=sin, pos_ids=pos,
+             n_q_heads=nq, n_kv_heads=nkv, s_max=smax, tok_per_batch=S, slot_base=0, force_bm=bm)
+    xf = x.float()
+    q = (xf @ qw.float().t() + qb.float()).to(BF).float().view(M, nq, 128)
+    k = (xf @ kw.float().t() + kb.float()).to(BF).float().view(M, nkv, 128)
+    v = (xf @ vw.float().t() + vb.float()).to(BF).float().view(M, nkv, 128)
+    close(q_out.view(M, nq, 128), _rope_ref(q, pos), name='q')
+    close(kc[:, :, :S], _rope_ref(k, pos).view(B, S, nkv, 128).permute(0, 2, 1, 3), name='k')
+    close(vtc[:, :, :, :S], v.view(B, S, nkv, 128).permute(0, 2, 3, 1), name='vT')
+
+
+@pytest.mark.parametrize('M,N,K,S', [(385, 1536, 8960, 7), (1025, 1024, 4096, 4), (100, 1024, 1024, 1)])
+def test_gemm_splitk_reduce_norm(ops, M, N, K, S):
+    from vlaser_amd import _lib as L
+    x, w = rnd(M, K), rnd(N, K, std=0.03)
+    part = torch.zeros(S, M, N, dtype=torch.float32, device='cuda')
+    ops.gemm(L.EPI_PARTIAL, x, w, out_f32=part, k_splits=S)
+    ref = x.float() @ w.float().t()
+    close(part.sum(0), ref, rtol=2e-3, atol=2e-3, name='partials')
+    h = rnd(M, N, seed=3); nw = (1 + 0.1 * rnd(N, seed=4).float()).to(BF); nb = rnd(N, std=0.1, seed=5)
+    bias = rnd(N, std=0.3, seed=6); ls = rnd(N, std=0.1, seed=7)
+    # RMS seam (Qwen2): h += sum; x = rms(h) * w
+    ho = torch.zeros_like(h); xo = torch.zeros_like(h)
+    ops.reduce_norm(h, part, S, M, N, ho, xo, norm=1, norm_w=nw)
+    href = (h.float() + ref).to(BF)
+    close(ho, href.float(), rtol=8e-3, name='h rms')
+    close(xo, _rms_ref(ho, nw), rtol=8e-3, name='x rms')
+    # LayerNorm seam (ViT): h += ls * (sum + bias); x = LN(h); in place
+    h2 = h.clone(); xo2 = torch.zeros_like(h)
+    ops.reduce_norm(h2, part, S, M, N, h2, xo2, bias=bias, ls=ls, norm=2, norm_w=nw, norm_b=nb, eps=1e-6)
+    href2 = h.float() + ls.float() * (ref + bias.float())
+    close(h2, href2, rtol=8e-3, name='h ln')
+    close(xo2, F.layer_norm(h2.float(), (N,), nw.float(), nb.float(), 1e-6), name='x ln')
+    # no norm
+    h3 = torch.zeros_like(h)
+    ops.reduce_norm(h, part, S, M, N, h3)
+    close(h3, href.float(), rtol=8e-3, name='h none')

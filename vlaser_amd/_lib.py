@@ -15,7 +15,8 @@ class GemmArgs(C.Structure):
                 ('ldo', i32), ('bias', vp), ('res', vp), ('ls', vp), ('q_out', vp), ('k_cache', vp), ('vt_cache', vp),
                 ('rope_cos', vp), ('rope_sin', vp), ('pos_ids', vp), ('n_q_heads', i32), ('n_kv_heads', i32),
                 ('s_max', i32), ('tok_per_batch', i32), ('slot_base', i32), ('vq', vp), ('vk', vp), ('vvt', vp),
-                ('vit_heads', i32), ('vit_seq', i32), ('vit_seq_pad', i32), ('q_scale', f32)]
+                ('vit_heads', i32), ('vit_seq', i32), ('vit_seq_pad', i32), ('q_scale', f32), ('out_f32', vp), ('k_splits', i32),
+                ('force_bm', i32)]
 
 
 class AttnArgs(C.Structure):
@@ -35,7 +36,7 @@ class SkinnyArgs(C.Structure):
 
 
 # enums (include/vlaser_hip.h)
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_LS_RES, EPI_RES, EPI_SWIGLU, EPI_QKV_ROPE, EPI_VIT_QKV, EPI_F32 = range(9)
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_LS_RES, EPI_RES, EPI_SWIGLU, EPI_QKV_ROPE, EPI_VIT_QKV, EPI_F32, EPI_PARTIAL = range(10)
 ATTN_FULL, ATTN_CAUSAL, ATTN_PREFIX = range(3)
 PRO_PLAIN, PRO_NORM = range(2)
 SK_PARTIAL, SK_QKV_ROPE, SK_SWIGLU, SK_F32, SK_BIAS, SK_BIAS_SILU = range(6)
@@ -59,6 +60,7 @@ _SIGS = {
     'vlaser_reduce_partials': [vp, vp, i32, i32, i32, vp, vp],
     'vlaser_cast_f32_bf16': [vp, vp, i64, vp],
     'vlaser_ce_rows': [vp, vp, i32, i32, i64, vp, vp, i64, vp],
+    'vlaser_reduce_norm': [vp, vp, i32, vp, vp, i32, vp, vp, f32, vp, vp, i32, i32, vp],
 }
 
 

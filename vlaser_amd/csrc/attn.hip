@@ -213,12 +213,14 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnP p) {
 }
 
 // ------------------------------------------------------------------------------------------------ skinny
-// grid (n_q_heads, B); block 1024 = 16 waves; wave w handles 32-key chunks w, w+16, ...; HD = 128.
+// grid (n_q_heads, B); block 512 = 8 waves; per pass a wave takes TWO 32-key chunks and issues every K and V^T
+// fragment load of both up front (one memory round trip per pass, 32 x 16 B in flight per lane); HD = 128.
 // Query rows: nq tokens (<=16) of ONE q head.  Visibility is uniform over the rows of a batch element:
 //   keys [0, lim1) U [lo2, hi2)   (lim1 = valid_len[b] or kv_len; causal decode passes lim1 = kv_len).
-__global__ __launch_bounds__(1024) void attn_skinny_kernel(AttnP p) {
+#define SK_WAVES 8
+__global__ __launch_bounds__(512) void attn_skinny_kernel(AttnP p) {
   constexpr int HD = 128, DC = 4, DT = 8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [16 waves][ m[16] l[16] o[16][128] ] fp32
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [8 waves][ m[16] l[16] o[16][128] ] fp32
   const VlaserAttnArgs& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
@@ -251,96 +253,108 @@ __global__ __launch_bounds__(1024) void attn_skinny_kernel(AttnP p) {
   float m_run = NEG_BIG, l_run = 0.f;
   const float sc = a.scale * 1.4426950408889634f;
 
-  for (int ci = wave; ci < n_chunks; ci += 16) {
-    const int key0 = (ci < n1 ? ci : c2_lo + (ci - n1)) << 5;
-    // issue all loads of the chunk up front (K: 2 tiles x 4 d-chunks, V^T: 8 d-tiles)
-    u32x4 kf[2][DC], vf[DT];
+  for (int base = wave * 2; base < n_chunks; base += 2 * SK_WAVES) {
+    u32x4 kf[2][2][DC], vf[2][DT];
+    int key0[2];
+    bool ok[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int key = key0 + (fr >> 2) * 8 + t * 4 + (fr & 3);
+    for (int c = 0; c < 2; ++c) {
+      const int ci = base + c;
+      ok[c] = ci < n_chunks;
+      key0[c] = (ci < n1 ? ci : c2_lo + (ci - n1)) << 5;
+      if (ok[c]) {
 #pragma unroll
-      for (int dc = 0; dc < DC; ++dc)
-        kf[t][dc] = (key < a.kv_len) ? ld_global_16(K + (size_t)key * HD + dc * 32 + g * 8) : u32x4{0, 0, 0, 0};
-    }
-    f32x4 s[2];
+        for (int t = 0; t < 2; ++t) {
+          const int key = key0[c] + (fr >> 2) * 8 + t * 4 + (fr & 3);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      f32x4 acc = {0, 0, 0, 0};
+          for (int dc = 0; dc < DC; ++dc)
+            kf[c][t][dc] = (key < a.kv_len) ? ld_global_16(K + (size_t)key * HD + dc * 32 + g * 8) : u32x4{0, 0, 0, 0};
+        }
 #pragma unroll
-      for (int dc = 0; dc < DC; ++dc) acc = mfma16(as_bf16x8(kf[t][dc]), qf[dc], acc);
-      s[t] = acc;
-    }
-    // V^T loads are issued after the K fragments are consumed (128-VGPR budget at 16 waves/block); their latency
-    // overlaps the softmax VALU work below
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) vf[dt] = ld_global_16(VT + (size_t)(dt * 16 + fr) * a.ld_vt + key0 + g * 8);
-    float mx = NEG_BIG;
-    bool vis[2][4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = key0 + g * 8 + t * 4 + r;
-        const bool v = (key < lim1) || (key >= lo2 && key < hi2);
-        vis[t][r] = v;
-        s[t][r] *= sc;
-        if (v) mx = fmaxf(mx, s[t][r]);
+        for (int dt = 0; dt < DT; ++dt) vf[c][dt] = ld_global_16(VT + (size_t)(dt * 16 + fr) * a.ld_vt + key0[c] + g * 8);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = fast_exp2(m_run - m_new);
-    m_run = m_new;
-    float pv[8], psum = 0.f;
+    }
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int c = 0; c < 2; ++c) {
+      if (!ok[c]) continue;
+      f32x4 s[2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pe = vis[t][r] ? fast_exp2(s[t][r] - m_new) : 0.f;
-        psum += pe;
-        pv[t * 4 + r] = pe;
+      for (int t = 0; t < 2; ++t) {
+        f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int dc = 0; dc < DC; ++dc) acc = mfma16(as_bf16x8(kf[c][t][dc]), qf[dc], acc);
+        s[t] = acc;
       }
-    l_run = l_run * alpha + psum;
-    u32x4 pk = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]), pack_bf16x2(pv[4], pv[5]), pack_bf16x2(pv[6], pv[7])};
-    const bf16x8 pf = as_bf16x8(pk);
+      float mx = NEG_BIG;
+      bool vis[2][4];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      f32x4 acc = o[dt];
-      acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
-      o[dt] = mfma16(as_bf16x8(vf[dt]), pf, acc);
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = key0[c] + g * 8 + t * 4 + r;
+          const bool v = (key < lim1) || (key >= lo2 && key < hi2);
+          vis[t][r] = v;
+          s[t][r] *= sc;
+          if (v) mx = fmaxf(mx, s[t][r]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = fast_exp2(m_run - m_new);
+      m_run = m_new;
+      float pv[8], psum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pe = vis[t][r] ? fast_exp2(s[t][r] - m_new) : 0.f;
+          psum += pe;
+          pv[t * 4 + r] = pe;
+        }
+      l_run = l_run * alpha + psum;
+      u32x4 pk = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]), pack_bf16x2(pv[4], pv[5]), pack_bf16x2(pv[6], pv[7])};
+      const bf16x8 pf = as_bf16x8(pk);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        f32x4 acc = o[dt];
+        acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
+        o[dt] = mfma16(as_bf16x8(vf[c][dt]), pf, acc);
+      }
     }
   }
   float l_tot = l_run + __shfl_xor(l_run, 16, 64);
   l_tot += __shfl_xor(l_tot, 32, 64);
 
   // flash-decoding merge through LDS
-  float* wm = reinterpret_cast<float*>(smem) + wave * (32 + 16 * 128);
+  constexpr int WS = 32 + 16 * 128;
+  float* wm = reinterpret_cast<float*>(smem) + wave * WS;
   float* wl = wm + 16;
   float* wo = wm + 32;
   if (g == 0) { wm[fr] = m_run; wl[fr] = l_tot; }
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) wo[fr * 128 + dt * 16 + g * 4 + r] = o[dt][r];
+  for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(wo + fr * 128 + dt * 16 + g * 4) = o[dt];
   __syncthreads();
-  // thread -> (row = tid / 64, d pair = (tid % 64) * 2): 16 rows x 128 d = 2048 outputs over 1024 threads
+  // thread -> (row = tid / 32, 4 consecutive d = (tid % 32) * 4): 16 rows x 128 d over 512 threads
   {
-    const int row = tid >> 6, d = (tid & 63) * 2;
+    const int row = tid >> 5, d = (tid & 31) * 4;
     if (row < a.sq) {
       const float* base = reinterpret_cast<const float*>(smem);
       float M = NEG_BIG;
-      for (int w = 0; w < 16; ++w) M = fmaxf(M, base[w * (32 + 2048) + row]);
-      float L = 0.f, o0 = 0.f, o1 = 0.f;
-      for (int w = 0; w < 16; ++w) {
-        const float* bw = base + w * (32 + 2048);
+#pragma unroll
+      for (int w = 0; w < SK_WAVES; ++w) M = fmaxf(M, base[w * WS + row]);
+      float Lsum = 0.f;
+      f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int w = 0; w < SK_WAVES; ++w) {
+        const float* bw = base + w * WS;
         const float f = fast_exp2(bw[row] - M);
-        L += bw[16 + row] * f;
-        o0 += bw[32 + row * 128 + d] * f;
-        o1 += bw[32 + row * 128 + d + 1] * f;
+        Lsum += bw[16 + row] * f;
+        const f32x4 ov = *reinterpret_cast<const f32x4*>(bw + 32 + row * 128 + d);
+        acc[0] += ov[0] * f; acc[1] += ov[1] * f; acc[2] += ov[2] * f; acc[3] += ov[3] * f;
       }
-      const float inv = L > 0.f ? 1.0f / L : 0.f;
+      const float inv = Lsum > 0.f ? 1.0f / Lsum : 0.f;
       bf16_t* O = reinterpret_cast<bf16_t*>(a.out) + (size_t)b * a.o_bs + (size_t)row * a.o_ss + h * HD + d;
-      *reinterpret_cast<uint32_t*>(O) = pack_bf16x2(o0 * inv, o1 * inv);
+      *reinterpret_cast<u32x2*>(O) = u32x2{pack_bf16x2(acc[0] * inv, acc[1] * inv), pack_bf16x2(acc[2] * inv, acc[3] * inv)};
     }
   }
 }
@@ -369,13 +383,13 @@ extern "C" int vlaser_attn_skinny(const VlaserAttnArgs* a, vl_stream_t s) {
   VL_CHECK(a->ld_vt % 32 == 0 && a->kv_len <= a->ld_vt, "vlaser_attn_skinny: bad cache geometry");
   VL_CHECK(a->mode == VL_ATTN_FULL || a->mode == VL_ATTN_PREFIX, "vlaser_attn_skinny: mode must be FULL or PREFIX");
   AttnP p; p.a = *a;
-  const int lds = 16 * (32 + 2048) * 4;
+  const int lds = SK_WAVES * (32 + 2048) * 4;
   static bool attr_set = false;
   if (!attr_set) {
     VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_skinny_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_skinny_kernel, dim3(a->n_q_heads, a->batch), dim3(1024), lds, stream, p);
+  hipLaunchKernelGGL(attn_skinny_kernel, dim3(a->n_q_heads, a->batch), dim3(64 * SK_WAVES), lds, stream, p);
   VL_LAUNCH_CHECK();
   return 0;
 }

@@ -1,7 +1,9 @@
 // bf16 MFMA GEMM for gfx950: out = epilogue(A[M,K] @ W[N,K]^T), fp32 accumulate.
 //
-// Tile 128(M) x 128(N) x 64(K), 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile as 4x4 MFMA 16x16x32
-// tiles.  Both operands are K-contiguous (activations [M,K], torch Linear weights [N,K]) so MFMA fragments are
+// Tile BM(M) x 128(N) x 64(K) with BM in {128, 64, 32}, 256 threads = 4 waves (2x2 for BM >= 64, 1x4 for BM = 32);
+// BM = 128 gives each wave a 64x64 sub-tile (4x4 MFMA 16x16x32 tiles).  Small-M prefill shapes (M = 385 / 1025
+// rows) pick the smaller BM and/or split-K (blockIdx.y, fp32 partial slabs reduced by the fused
+// residual+norm kernel in misc.hip) so that >= 256 workgroups exist to fill the chip.  Both operands are K-contiguous (activations [M,K], torch Linear weights [N,K]) so MFMA fragments are
 // 16-byte LDS reads.  Operands are issued "swapped" (W fragment as MFMA-A, activation fragment as MFMA-B) so
 // that each lane ends up with 4 CONSECUTIVE output columns n of one row m -> 8-byte stores and lane-local
 // fused epilogues (bias / GELU / layer-scale residual / SwiGLU / RoPE + KV-cache scatter).
@@ -11,7 +13,6 @@
 #include "common.h"
 #include "../../include/vlaser_hip.h"
 
-#define BM 128
 #define BN 128
 #define BK 64
 
@@ -26,6 +27,10 @@ template <int EPI>
 __device__ __forceinline__ void epilogue(const VlaserGemmArgs& a, int m, int n0, f32x4 v, f32x4 v2) {
   // v holds acc for output columns n0..n0+3 of row m. (v2: partner accumulator for SWIGLU / ROPE)
   if (m >= a.M) return;
+  if constexpr (EPI == VL_EPI_PARTIAL) {
+    if (n0 < a.N) *reinterpret_cast<f32x4*>(a.out_f32 + ((size_t)blockIdx.y * a.M + m) * a.N + n0) = v;
+    return;
+  }
   if constexpr (EPI == VL_EPI_F32) {
     float* o = reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n0;
 #pragma unroll
@@ -149,12 +154,17 @@ __device__ __forceinline__ void epilogue(const VlaserGemmArgs& a, int m, int n0,
   }
 }
 
-template <int EPI>
+template <int EPI, int BM>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 16K | W 16K]
+  constexpr int WR = BM >= 64 ? 2 : 1, WC = 4 / WR;     // wave grid
+  constexpr int WTM = BM / WR, WTN = BN / WC;           // wave tile
+  constexpr int MT = WTM / 16, NT = WTN / 16;
+  constexpr int ACH = BM / 32;                          // 16-byte A chunks per thread per K-step
+  constexpr int BUF = BM * 128 + 16384;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A BM*128 | W 16K]
   const VlaserGemmArgs& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WC, wc = wave % WC;
 
   // XCD-aware remap: block b runs on XCD b%8; give each XCD a contiguous chunk of the tile list (bijective form)
   const int nwg = gridDim.x;
@@ -165,39 +175,43 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   }
   const int tile_m = bid % p.tiles_m, tile_n = bid / p.tiles_m;  // consecutive tiles share the weight panel
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kc = a.K / (int)gridDim.y;                           // split-K slice of this block
+  const int kbase = blockIdx.y * kc;
 
   const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
   const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W);
 
-  // staging map: thread -> (row = tid/8 + 32*i, slot = tid%8), i = 0..3
+  // staging map: thread -> (row = tid/8 + 32*i, slot = tid%8)
   const int srow = tid >> 3, sslot = tid & 7;
-  u32x4 ra[4], rw[4];
+  u32x4 ra[ACH], rw[4];
   auto load_tile = [&](int kt) {
-    const int k0 = kt * BK + sslot * 8;
+    const int k0 = kbase + kt * BK + sslot * 8;
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+      const int rm = m0 + srow + 32 * i;
+      ra[i] = (rm < a.M) ? ld_global_16(A + (size_t)rm * a.lda + k0) : u32x4{0, 0, 0, 0};
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int rm = m0 + srow + 32 * i, rn = n0 + srow + 32 * i;
-      ra[i] = (rm < a.M) ? ld_global_16(A + (size_t)rm * a.lda + k0) : u32x4{0, 0, 0, 0};
+      const int rn = n0 + srow + 32 * i;
       rw[i] = (rn < a.N) ? ld_global_16(W + (size_t)rn * a.ldw + k0) : u32x4{0, 0, 0, 0};
     }
   };
   auto store_tile = [&](int buf) {
-    char* base = smem + buf * 32768;
+    char* base = smem + buf * BUF;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int row = srow + 32 * i;
-      *reinterpret_cast<u32x4*>(base + lds_off(row, sslot)) = ra[i];
-      *reinterpret_cast<u32x4*>(base + 16384 + lds_off(row, sslot)) = rw[i];
-    }
+    for (int i = 0; i < ACH; ++i) *reinterpret_cast<u32x4*>(base + lds_off(srow + 32 * i, sslot)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(base + BM * 128 + lds_off(srow + 32 * i, sslot)) = rw[i];
   };
 
-  f32x4 acc[4][4];  // [nt][mt]
+  f32x4 acc[NT][MT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-  const int nk = a.K / BK;
+  const int nk = kc / BK;
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -205,20 +219,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_tile(kt + 1);
-    const char* As = smem + buf * 32768;
-    const char* Ws = As + 16384;
+    const char* As = smem + buf * BUF;
+    const char* Ws = As + BM * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[4], fw[4];
+      bf16x8 fa[MT], fw[NT];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        fa[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + lds_off(wr * 64 + t * 16 + fr, ks * 4 + fq)));
-        fw[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ws + lds_off(wc * 64 + t * 16 + fr, ks * 4 + fq)));
-      }
+      for (int t = 0; t < MT; ++t)
+        fa[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + lds_off(wr * WTM + t * 16 + fr, ks * 4 + fq)));
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int t = 0; t < NT; ++t)
+        fw[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ws + lds_off(wc * WTN + t * 16 + fr, ks * 4 + fq)));
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma16(fw[nt], fa[mt], acc[nt][mt]);
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(fw[nt], fa[mt], acc[nt][mt]);
     }
     if (kt + 1 < nk) store_tile(buf ^ 1);
     __syncthreads();
@@ -226,32 +241,46 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 
   // epilogue: lane -> m = ... + (lane&15), n = ... + (lane>>4)*4 + reg
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wr * 64 + mt * 16 + fr;
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + wr * WTM + mt * 16 + fr;
     if constexpr (EPI == VL_EPI_SWIGLU || EPI == VL_EPI_QKV_ROPE) {
 #pragma unroll
-      for (int nt = 0; nt < 4; nt += 2) epilogue<EPI>(a, m, n0 + wc * 64 + nt * 16 + fq * 4, acc[nt][mt], acc[nt + 1][mt]);
+      for (int nt = 0; nt < NT; nt += 2) epilogue<EPI>(a, m, n0 + wc * WTN + nt * 16 + fq * 4, acc[nt][mt], acc[nt + 1][mt]);
     } else {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) epilogue<EPI>(a, m, n0 + wc * 64 + nt * 16 + fq * 4, acc[nt][mt], acc[nt][mt]);
+      for (int nt = 0; nt < NT; ++nt) epilogue<EPI>(a, m, n0 + wc * WTN + nt * 16 + fq * 4, acc[nt][mt], acc[nt][mt]);
     }
   }
 }
 
-template <int EPI>
-static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
+template <int EPI, int BM>
+static int launch_bm(const VlaserGemmArgs* args, hipStream_t stream, int splits) {
   GemmP p;
   p.a = *args;
   p.tiles_m = (args->M + BM - 1) / BM;
   p.tiles_n = (args->N + BN - 1) / BN;
+  constexpr int lds = 2 * (BM * 128 + 16384);
   static bool attr_set = false;
   if (!attr_set) {
-    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<EPI, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_kernel<EPI>, dim3(p.tiles_m * p.tiles_n), dim3(256), 65536, stream, p);
+  hipLaunchKernelGGL((gemm_kernel<EPI, BM>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), lds, stream, p);
   VL_LAUNCH_CHECK();
   return 0;
+}
+
+// tile-height heuristic: the largest BM that still yields >= ~one workgroup per CU (256 CUs)
+template <int EPI>
+static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
+  const int splits = (EPI == VL_EPI_PARTIAL && args->k_splits > 1) ? args->k_splits : 1;
+  const int tn = (args->N + BN - 1) / BN;
+  auto blocks = [&](int bm) { return ((args->M + bm - 1) / bm) * tn * splits; };
+  int bm = args->force_bm;
+  if (bm == 0) bm = blocks(128) >= 224 ? 128 : (blocks(64) >= 192 ? 64 : 32);
+  if (bm == 128) return launch_bm<EPI, 128>(args, stream, splits);
+  if (bm == 64) return launch_bm<EPI, 64>(args, stream, splits);
+  return launch_bm<EPI, 32>(args, stream, splits);
 }
 
 extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
@@ -259,11 +288,16 @@ extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   VL_CHECK(a && a->A && a->W, "vlaser_gemm: null operand");
   VL_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "vlaser_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
   VL_CHECK(a->K % BK == 0, "vlaser_gemm: K=%d must be a multiple of %d", a->K, BK);
+  VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128, "vlaser_gemm: force_bm must be 0/32/64/128");
   VL_CHECK(a->lda % 8 == 0 && a->ldw % 8 == 0, "vlaser_gemm: lda/ldw must be multiples of 8 (16-byte rows)");
   VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm: operands must be 16-byte aligned");
   switch (epi) {
     case VL_EPI_NONE: VL_CHECK(a->out, "out null"); return launch<VL_EPI_NONE>(a, stream);
     case VL_EPI_F32: VL_CHECK(a->out, "out null"); return launch<VL_EPI_F32>(a, stream);
+    case VL_EPI_PARTIAL:
+      VL_CHECK(a->out_f32 && a->N % 4 == 0, "partial: out_f32 null or N %% 4 != 0");
+      VL_CHECK(a->k_splits >= 1 && a->K % (a->k_splits * BK) == 0, "partial: K=%d not divisible by k_splits*64 (k_splits=%d)", a->K, a->k_splits);
+      return launch<VL_EPI_PARTIAL>(a, stream);
     case VL_EPI_BIAS: VL_CHECK(a->out && a->bias, "out/bias null"); return launch<VL_EPI_BIAS>(a, stream);
     case VL_EPI_BIAS_GELU: VL_CHECK(a->out && a->bias, "out/bias null"); return launch<VL_EPI_BIAS_GELU>(a, stream);
     case VL_EPI_BIAS_LS_RES:

@@ -471,3 +471,119 @@ extern "C" int vlaser_ce_rows(const float* logits, const int64_t* labels, int R,
   VL_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------- split-K seam
+// h = h_in + [ls *] (sum_s partials[s] [+ bias]); x_out = norm(h).  One wave per row, 4 rows per block; the row
+// (C <= 4096) stays in registers between the reduction and the normalisation; slab loads are issued 4 slabs at a
+// time (independent 16-byte loads) so the reduction costs ~ceil(S/4) L2 round trips.
+template <int NORM>  // 0 none, 1 RMS, 2 LayerNorm
+__global__ __launch_bounds__(256) void reduce_norm_kernel(const bf16_t* __restrict__ h_in, const float* __restrict__ partials, int S,
+                                                          const bf16_t* __restrict__ bias, const bf16_t* __restrict__ ls,
+                                                          const bf16_t* __restrict__ nw, const bf16_t* __restrict__ nb, float eps,
+                                                          bf16_t* __restrict__ h_out, bf16_t* __restrict__ x_out, int M, int C) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  constexpr int MAXC = 8;  // chunks of 8 per lane -> C <= 4096
+  u32x4 hv[MAXC];
+  const size_t slab = (size_t)M * C;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < C) {
+      const size_t off = (size_t)row * C + c;
+      float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      int sp = 0;
+      for (; sp + 4 <= S; sp += 4) {
+        f32x4 q[8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* pp = partials + (size_t)(sp + u) * slab + off;
+          q[2 * u] = *reinterpret_cast<const f32x4*>(pp);
+          q[2 * u + 1] = *reinterpret_cast<const f32x4*>(pp + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] += q[2 * u][j]; v[4 + j] += q[2 * u + 1][j]; }
+      }
+      for (; sp < S; ++sp) {
+        const float* pp = partials + (size_t)sp * slab + off;
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += p0[j]; v[4 + j] += p1[j]; }
+      }
+      const u32x4 hi = ld_global_16(h_in + off);
+      u32x4 bv = {0, 0, 0, 0}, lv = {0, 0, 0, 0};
+      if (bias) bv = ld_global_16(bias + c);
+      if (ls) lv = ld_global_16(ls + c);
+      u32x4 hr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float lo = v[2 * j] + bf16lo_to_f32(bv[j]), hi2 = v[2 * j + 1] + bf16hi_to_f32(bv[j]);
+        if (ls) { lo *= bf16lo_to_f32(lv[j]); hi2 *= bf16hi_to_f32(lv[j]); }
+        hr[j] = pack_bf16x2(bf16lo_to_f32(hi[j]) + lo, bf16hi_to_f32(hi[j]) + hi2);
+        const float a0 = bf16lo_to_f32(hr[j]), a1 = bf16hi_to_f32(hr[j]);
+        s1 += a0 + a1;
+        s2 += a0 * a0 + a1 * a1;
+      }
+      hv[i] = hr;
+      st_global_16(h_out + off, hr);
+    }
+  }
+  if constexpr (NORM == 0) return;
+  s1 = wave_sum(s1);
+  float mean = 0.f, rs;
+  if constexpr (NORM == 1) {
+    rs = rsqrtf(wave_sum(s2) / (float)C + eps);
+  } else {
+    mean = s1 / (float)C;
+    float vs = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+      if ((lane + 64 * i) * 8 < C)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a0 = bf16lo_to_f32(hv[i][j]) - mean, a1 = bf16hi_to_f32(hv[i][j]) - mean;
+          vs += a0 * a0 + a1 * a1;
+        }
+    rs = rsqrtf(wave_sum(vs) / (float)C + eps);
+  }
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < C) {
+      const u32x4 wv = ld_global_16(nw + c);
+      u32x4 bv = {0, 0, 0, 0};
+      if constexpr (NORM == 2) bv = ld_global_16(nb + c);
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float lo, hi;
+        if constexpr (NORM == 1) {
+          lo = round_bf16(bf16lo_to_f32(hv[i][j]) * rs) * bf16lo_to_f32(wv[j]);
+          hi = round_bf16(bf16hi_to_f32(hv[i][j]) * rs) * bf16hi_to_f32(wv[j]);
+        } else {
+          lo = (bf16lo_to_f32(hv[i][j]) - mean) * rs * bf16lo_to_f32(wv[j]) + bf16lo_to_f32(bv[j]);
+          hi = (bf16hi_to_f32(hv[i][j]) - mean) * rs * bf16hi_to_f32(wv[j]) + bf16hi_to_f32(bv[j]);
+        }
+        o[j] = pack_bf16x2(lo, hi);
+      }
+      st_global_16(x_out + (size_t)row * C + c, o);
+    }
+  }
+}
+extern "C" int vlaser_reduce_norm(const void* h_in, const float* partials, int S, const void* bias, const void* ls, int norm_kind,
+                                  const void* nw, const void* nb, float eps, void* h_out, void* x_out, int M, int C, vl_stream_t s) {
+  VL_CHECK(h_in && h_out && (S == 0 || partials) && M > 0 && C % 8 == 0 && C <= 4096, "vlaser_reduce_norm: bad args (C=%d)", C);
+  VL_CHECK(norm_kind == 0 || (nw && x_out && (norm_kind == 1 || nb)), "vlaser_reduce_norm: norm weights / x_out missing");
+  dim3 grid((M + 3) / 4), blk(256);
+#define RN_ARGS (const bf16_t*)h_in, partials, S, (const bf16_t*)bias, (const bf16_t*)ls, (const bf16_t*)nw, (const bf16_t*)nb, eps, \
+                (bf16_t*)h_out, (bf16_t*)x_out, M, C
+  if (norm_kind == 0) hipLaunchKernelGGL(reduce_norm_kernel<0>, grid, blk, 0, (hipStream_t)s, RN_ARGS);
+  else if (norm_kind == 1) hipLaunchKernelGGL(reduce_norm_kernel<1>, grid, blk, 0, (hipStream_t)s, RN_ARGS);
+  else hipLaunchKernelGGL(reduce_norm_kernel<2>, grid, blk, 0, (hipStream_t)s, RN_ARGS);
+#undef RN_ARGS
+  VL_LAUNCH_CHECK();
+  return 0;
+}

@@ -30,60 +30,8 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyP p) {
   char* xs = smem;                            // [M][xs_stride]
   float* red = reinterpret_cast<float*>(smem + ((a.M * p.xs_stride + 15) & ~15));  // [4 waves][2][64][4]
 
-  // ------------------------------------------------------------------ prologue: activations -> LDS (bf16)
-  if constexpr (PRO == VL_PRO_PLAIN) {
-    const bf16_t* X = reinterpret_cast<const bf16_t*>(a.x);
-    const int chunks_per_row = p.kb >> 3;
-    for (int c = tid; c < a.M * chunks_per_row; c += 256) {
-      const int m = c / chunks_per_row, j = c - m * chunks_per_row;
-      *reinterpret_cast<u32x4*>(xs + m * p.xs_stride + j * 16) = ld_global_16(X + (size_t)m * a.K + kb0 + j * 8);
-    }
-  } else {
-    // rows over waves; h = bf16(h_in + sum partials); xn = bf16(w * bf16(h * rsqrt(mean(h^2) + eps)))
-    const bf16_t* Hin = reinterpret_cast<const bf16_t*>(a.x);
-    const bf16_t* Wn = reinterpret_cast<const bf16_t*>(a.norm_w);
-    const bool write_h = (a.h_out != nullptr) && unit == 0 && ks == 0;
-    for (int m = wave; m < a.M; m += 4) {
-      float ssq = 0.f;
-      // pass 1: reduce, round, stash rounded h in LDS (as bf16), accumulate sum of squares
-      for (int c = lane * 8; c < a.K; c += 512) {
-        u32x4 hv = ld_global_16(Hin + (size_t)m * a.K + c);
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v[2 * j] = bf16lo_to_f32(hv[j]); v[2 * j + 1] = bf16hi_to_f32(hv[j]); }
-        for (int s = 0; s < a.n_partials; ++s) {
-          const float* pp = a.partials + ((size_t)s * a.M + m) * a.K + c;
-          const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { v[j] += p0[j]; v[4 + j] += p1[j]; }
-        }
-        u32x4 hr;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) hr[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const float lo = bf16lo_to_f32(hr[j]), hi = bf16hi_to_f32(hr[j]); ssq += lo * lo + hi * hi; }
-        *reinterpret_cast<u32x4*>(xs + m * p.xs_stride + c * 2) = hr;
-        if (write_h) st_global_16(reinterpret_cast<bf16_t*>(a.h_out) + (size_t)m * a.K + c, hr);
-      }
-      ssq = wave_sum(ssq);
-      const float rs = rsqrtf(ssq / (float)a.K + a.eps);
-      for (int c = lane * 8; c < a.K; c += 512) {
-        u32x4 hr = *reinterpret_cast<const u32x4*>(xs + m * p.xs_stride + c * 2);
-        const u32x4 wv = ld_global_16(Wn + c);
-        u32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float lo = round_bf16(bf16lo_to_f32(hr[j]) * rs) * bf16lo_to_f32(wv[j]);
-          const float hi = round_bf16(bf16hi_to_f32(hr[j]) * rs) * bf16hi_to_f32(wv[j]);
-          o[j] = pack_bf16x2(lo, hi);
-        }
-        *reinterpret_cast<u32x4*>(xs + m * p.xs_stride + c * 2) = o;
-      }
-    }
-  }
-  __syncthreads();
-
-  // ------------------------------------------------------------------ main loop: this wave's K quarter
+  // ------------------------------------------------------------------ weight stream set-up: this wave's K quarter; the first batch of
+  // weight loads is issued BEFORE the prologue so HBM latency overlaps the activation / partial-slab reads
   const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W);
   const int kw = p.kb >> 2;                   // K per wave (multiple of 32)
   const int kl0 = wave * kw;                  // block-local k start
@@ -108,6 +56,85 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyP p) {
     }
   };
   issue(0, c0, c1);
+
+  // ------------------------------------------------------------------ prologue: activations -> LDS (bf16)
+  if constexpr (PRO == VL_PRO_PLAIN) {
+    const bf16_t* X = reinterpret_cast<const bf16_t*>(a.x);
+    const int chunks_per_row = p.kb >> 3;
+    for (int c = tid; c < a.M * chunks_per_row; c += 256) {
+      const int m = c / chunks_per_row, j = c - m * chunks_per_row;
+      *reinterpret_cast<u32x4*>(xs + m * p.xs_stride + j * 16) = ld_global_16(X + (size_t)m * a.K + kb0 + j * 8);
+    }
+  } else {
+    // h = bf16(h_in + sum partials); xn = bf16(w * bf16(h * rsqrt(mean(h^2) + eps)))
+    // Phase 1: all 256 threads stride over the M*K/8 16-byte chunks; the partial-slab loads of a chunk are issued
+    // in independent batches of 4 slabs (8 x 16 B in flight per lane) -- one L2 round trip per batch instead of one
+    // per slab.  Phase 2: one wave per row takes the sum of squares from LDS and normalises in place.
+    const bf16_t* Hin = reinterpret_cast<const bf16_t*>(a.x);
+    const bf16_t* Wn = reinterpret_cast<const bf16_t*>(a.norm_w);
+    const bool write_h = (a.h_out != nullptr) && unit == 0 && ks == 0;
+    const int cpr = a.K >> 3;  // chunks per row
+    const size_t slab = (size_t)a.M * a.K;
+    for (int ch = tid; ch < a.M * cpr; ch += 256) {
+      const int m = ch / cpr, c = (ch - m * cpr) << 3;
+      const size_t off = (size_t)m * a.K + c;
+      const u32x4 hv = ld_global_16(Hin + off);
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[2 * j] = bf16lo_to_f32(hv[j]); v[2 * j + 1] = bf16hi_to_f32(hv[j]); }
+      int sp = 0;
+      for (; sp + 4 <= a.n_partials; sp += 4) {
+        f32x4 q[8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* pp = a.partials + (size_t)(sp + u) * slab + off;
+          q[2 * u] = *reinterpret_cast<const f32x4*>(pp);
+          q[2 * u + 1] = *reinterpret_cast<const f32x4*>(pp + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] += q[2 * u][j]; v[4 + j] += q[2 * u + 1][j]; }
+      }
+      for (; sp < a.n_partials; ++sp) {
+        const float* pp = a.partials + (size_t)sp * slab + off;
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += p0[j]; v[4 + j] += p1[j]; }
+      }
+      u32x4 hr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hr[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+      *reinterpret_cast<u32x4*>(xs + m * p.xs_stride + c * 2) = hr;
+      if (write_h) st_global_16(reinterpret_cast<bf16_t*>(a.h_out) + off, hr);
+    }
+    __syncthreads();
+    for (int m = wave; m < a.M; m += 4) {
+      float ssq = 0.f;
+      for (int c = lane * 8; c < a.K; c += 512) {
+        const u32x4 hr = *reinterpret_cast<const u32x4*>(xs + m * p.xs_stride + c * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float lo = bf16lo_to_f32(hr[j]), hi = bf16hi_to_f32(hr[j]); ssq += lo * lo + hi * hi; }
+      }
+      ssq = wave_sum(ssq);
+      const float rs = rsqrtf(ssq / (float)a.K + a.eps);
+      for (int c = lane * 8; c < a.K; c += 512) {
+        const u32x4 hr = *reinterpret_cast<const u32x4*>(xs + m * p.xs_stride + c * 2);
+        const u32x4 wv = ld_global_16(Wn + c);
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = round_bf16(bf16lo_to_f32(hr[j]) * rs) * bf16lo_to_f32(wv[j]);
+          const float hi = round_bf16(bf16hi_to_f32(hr[j]) * rs) * bf16hi_to_f32(wv[j]);
+          o[j] = pack_bf16x2(lo, hi);
+        }
+        *reinterpret_cast<u32x4*>(xs + m * p.xs_stride + c * 2) = o;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ main loop
   for (int s0 = 0; s0 < nsteps; s0 += U) {
     u32x4 n0[U], n1[U];
     issue(s0 + U, n0, n1);

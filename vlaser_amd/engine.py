@@ -50,6 +50,7 @@ class QwenStack:
         nqd = llm.num_attention_heads * llm.head_dim
         self.ks_o = ops.pick_k_splits(nqd, H)
         self.ks_down = ops.pick_k_splits(I, H)
+        self.nqd = nqd
 
     @property
     def nq(self):
@@ -100,6 +101,7 @@ class VitEngine:
         self.m1w, self.m1b = g('mlp1.1.weight'), g('mlp1.1.bias')
         self.m3w, self.m3b = g('mlp1.3.weight'), g('mlp1.3.bias')
         self.max_tiles = 0
+        self.part = None
         self._alloc(max_tiles)
 
     def _alloc(self, T):
@@ -139,16 +141,28 @@ class VitEngine:
         layers_out = []
         if return_layers:
             layers_out.append(h.clone())
-        for lw in self.layers:
-            ops.layernorm(h, lw['n1w'], lw['n1b'], v.layer_norm_eps, out=x)
+        # split-K factors for the two N = C outputs (proj, fc2): M*C/128^2 tiles alone cannot fill 256 CUs
+        sp_proj, sp_fc2 = ops.gemm_splits(M, C, C), ops.gemm_splits(M, C, v.intermediate_size)
+        need = max(sp_proj, sp_fc2) * M * C
+        if self.part is None or self.part.numel() < need:
+            self.part = torch.zeros(need, dtype=torch.float32, device=self.device)
+        nl = len(self.layers)
+        ops.layernorm(h, self.layers[0]['n1w'], self.layers[0]['n1b'], v.layer_norm_eps, out=x)
+        for li, lw in enumerate(self.layers):
             ops.gemm(L.EPI_VIT_QKV, x, lw['wqkv'], bias=lw['bqkv'], vq=self.q, vk=self.k, vvt=self.vt, vit_heads=Hn, vit_seq=S,
                      vit_seq_pad=sp, q_scale=hd ** -0.5)
             ops.attn_prefill(self.q, self.k, self.vt, ao, T, S, S, Hn, Hn, hd, (Hn * sp * hd, sp * hd, hd), (Hn * sp * hd, sp * hd),
                              (Hn * hd * sp, hd * sp), (S * C, C), sp, 1.0, L.ATTN_FULL)
-            ops.gemm(L.EPI_BIAS_LS_RES, ao, lw['wproj'], out=h, bias=lw['bproj'], res=h, ls=lw['ls1'])
-            ops.layernorm(h, lw['n2w'], lw['n2b'], v.layer_norm_eps, out=x)
+            # h += ls1 * (proj(ao) + b); x = LN2(h)      (modeling_intern_vit.py:291)
+            ops.gemm(L.EPI_PARTIAL, ao, lw['wproj'], out_f32=self.part, k_splits=sp_proj)
+            ops.reduce_norm(h, self.part, sp_proj, M, C, h, x, bias=lw['bproj'], ls=lw['ls1'], norm=2, norm_w=lw['n2w'],
+                            norm_b=lw['n2b'], eps=v.layer_norm_eps)
             ops.gemm(L.EPI_BIAS_GELU, x, lw['wfc1'], out=f, bias=lw['bfc1'])
-            ops.gemm(L.EPI_BIAS_LS_RES, f, lw['wfc2'], out=h, bias=lw['bfc2'], res=h, ls=lw['ls2'])
+            # h += ls2 * (fc2(f) + b); x = LN1 of the NEXT layer (:293)
+            ops.gemm(L.EPI_PARTIAL, f, lw['wfc2'], out_f32=self.part, k_splits=sp_fc2)
+            nxt = self.layers[li + 1] if li + 1 < nl else None
+            ops.reduce_norm(h, self.part, sp_fc2, M, C, h, x if nxt else None, bias=lw['bfc2'], ls=lw['ls2'], norm=2 if nxt else 0,
+                            norm_w=nxt['n1w'] if nxt else None, norm_b=nxt['n1b'] if nxt else None, eps=v.layer_norm_eps)
             if return_layers:
                 layers_out.append(h.clone())
         n_tok = T * cfg.num_image_token
@@ -171,17 +185,33 @@ class PrefillBuffers:
         self.ao = z(max_rows, stack.nq * llm.head_dim)
         self.act = z(max_rows, llm.intermediate_size)
         self.max_rows = max_rows
+        self._part = None
+        self.device = device
+
+    def partials(self, n):
+        if self._part is None or self._part.numel() < n:
+            self._part = torch.zeros(n, dtype=torch.float32, device=self.device)
+        return self._part
+
+
+def prefill_begin(stack: QwenStack, buf: PrefillBuffers, h, M):
+    """x = input_layernorm_0(h): the only stand-alone norm launch of a prefill (later norms are fused into the split-K seam)."""
+    ops.rmsnorm(h, stack.layers[0].ln_in, stack.llm.rms_norm_eps, out=buf.x[:M])
 
 
 def prefill_layer(stack: QwenStack, lw: QwenLayerWeights, buf: PrefillBuffers, h, cache: KVCache, layer, rope, pos_ids, batch,
-                  tok_per_batch, attn_mode, valid_len=None, blk_start=0, causal_off=0, kv_len=None, skip_post_attn=False):
+                  tok_per_batch, attn_mode, valid_len=None, blk_start=0, causal_off=0, kv_len=None, skip_post_attn=False,
+                  next_norm_w=None):
     """One Qwen2DecoderLayer over M = batch*tok_per_batch rows with the big-GEMM kernels; K/V written to slots
-    [0, tok_per_batch) of the cache.  h is updated in place."""
+    [0, tok_per_batch) of the cache.  Expects buf.x = input_layernorm(h); leaves buf.x = next_norm(h_out) when
+    next_norm_w is given (next layer's input_layernorm or the final norm).  h is updated in place.
+    o_proj / down_proj run split-K (their [M, H] outputs have too few tiles to fill 256 CUs); the fp32 slabs are
+    reduced by ONE fused kernel that also adds the residual and applies the following RMSNorm."""
     llm = stack.llm
     M = batch * tok_per_batch
     nq, nkv, hd = stack.nq, stack.nkv, llm.head_dim
+    H, I = llm.hidden_size, llm.intermediate_size
     x, q, ao, act = buf.x[:M], buf.q[:M], buf.ao[:M], buf.act[:M]
-    ops.rmsnorm(h, lw.ln_in, llm.rms_norm_eps, out=x)
     ops.gemm(L.EPI_QKV_ROPE, x, lw.wqkv, bias=lw.bqkv, q_out=q, k_cache=cache.k[layer], vt_cache=cache.vt[layer], rope_cos=rope[0],
              rope_sin=rope[1], pos_ids=pos_ids, n_q_heads=nq, n_kv_heads=nkv, s_max=cache.s_max, tok_per_batch=tok_per_batch, slot_base=0)
     ks, vs = cache.strides()
@@ -190,10 +220,14 @@ def prefill_layer(stack: QwenStack, lw: QwenLayerWeights, buf: PrefillBuffers, h
                      attn_mode, causal_off=causal_off, valid_len=valid_len, blk_start=blk_start)
     if skip_post_attn:
         return
-    ops.gemm(L.EPI_RES, ao, lw.wo, out=h, res=h)
-    ops.rmsnorm(h, lw.ln_post, llm.rms_norm_eps, out=x)
+    sp_o, sp_d = ops.gemm_splits(M, H, nq * hd), ops.gemm_splits(M, H, I)
+    part = buf.partials(max(sp_o, sp_d) * M * H)
+    ops.gemm(L.EPI_PARTIAL, ao, lw.wo, out_f32=part, k_splits=sp_o)
+    ops.reduce_norm(h, part, sp_o, M, H, h, x, norm=1, norm_w=lw.ln_post, eps=llm.rms_norm_eps)
     ops.gemm(L.EPI_SWIGLU, x, lw.wgu, out=act)
-    ops.gemm(L.EPI_RES, act, lw.wdown, out=h, res=h)
+    ops.gemm(L.EPI_PARTIAL, act, lw.wdown, out_f32=part, k_splits=sp_d)
+    ops.reduce_norm(h, part, sp_d, M, H, h, x if next_norm_w is not None else None, norm=1 if next_norm_w is not None else 0,
+                    norm_w=next_norm_w, eps=llm.rms_norm_eps)
 
 
 class SkinnyBuffers:

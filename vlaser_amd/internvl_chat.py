@@ -21,7 +21,7 @@ import torch
 from . import _lib as L
 from . import ops, prep
 from .config import VlaserConfig
-from .engine import BF, KVCache, PrefillBuffers, QwenStack, SkinnyBuffers, VitEngine, prefill_layer, skinny_layer
+from .engine import BF, KVCache, PrefillBuffers, QwenStack, SkinnyBuffers, VitEngine, prefill_begin, prefill_layer, skinny_layer
 
 
 class InternVLChatModel:
@@ -111,9 +111,13 @@ class InternVLChatModel:
                         self.config.pad_token_id, zero_pad, self.rank_ws, self.img_count)
         return h
 
-    def _prefill(self, h, B, S, pos_ids):
-        for i, lw in enumerate(self.llm.layers):
-            prefill_layer(self.llm, lw, self.pbuf, h, self.cache, i, self.rope, pos_ids, B, S, L.ATTN_CAUSAL)
+    def _prefill(self, h, B, S, pos_ids, final_norm=False):
+        """28x Qwen2DecoderLayer; with final_norm the last fused seam also applies model.norm into self.pbuf.x."""
+        layers = self.llm.layers
+        prefill_begin(self.llm, self.pbuf, h, B * S)
+        for i, lw in enumerate(layers):
+            nxt = layers[i + 1].ln_in if i + 1 < len(layers) else (self.llm.norm if final_norm else None)
+            prefill_layer(self.llm, lw, self.pbuf, h, self.cache, i, self.rope, pos_ids, B, S, L.ATTN_CAUSAL, next_norm_w=nxt)
         return h
 
     def _head_last(self, h_last, partials, n_partials, M, greedy=True):
@@ -251,9 +255,8 @@ class InternVLChatModel:
             pos = torch.arange(S, dtype=torch.int32, device=self.device).repeat(B)
         else:
             pos = position_ids.to(self.device).to(torch.int32).reshape(-1).contiguous()
-        self._prefill(h, B, S, pos)
-        x = ops.rmsnorm(h[:B * S], self.llm.norm, self.config.llm.rms_norm_eps)
-        logits = ops.linear(x, self.llm.head, epi=L.EPI_F32).view(B, S, -1)
+        self._prefill(h, B, S, pos, final_norm=True)
+        logits = ops.linear(self.pbuf.x[:B * S], self.llm.head, epi=L.EPI_F32).view(B, S, -1)
         loss = None
         if labels is not None:
             from .sft import ce_loss

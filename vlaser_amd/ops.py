@@ -207,5 +207,27 @@ def reduce_partials(h_in, partials, n_partials, M, K, out):
             'vlaser_reduce_partials')
 
 
+def reduce_norm(h_in, partials, n_partials, M, C, h_out, x_out=None, bias=None, ls=None, norm=0, norm_w=None, norm_b=None, eps=1e-6):
+    """h_out = h_in + [ls*](sum partials [+bias]); x_out = norm(h_out) (norm: 0 none, 1 RMS, 2 LayerNorm)."""
+    L.check(L.lib().vlaser_reduce_norm(h_in.data_ptr(), _p(partials), n_partials, _p(bias), _p(ls), norm, _p(norm_w), _p(norm_b), eps,
+                                       h_out.data_ptr(), _p(x_out), M, C, _stream()), 'vlaser_reduce_norm')
+
+
+def gemm_splits(M, N, K, target_blocks=256):
+    """Split-K factor for a [M,N] output so that tiles * splits ~ one workgroup per CU; K/splits stays a multiple of 64
+    and >= 256."""
+    def tiles(bm):
+        return ((M + bm - 1) // bm) * ((N + 127) // 128)
+    t = tiles(64)
+    best = 1
+    for s in range(1, 33):
+        if K % (s * 64) or K // s < 256:
+            continue
+        best = s
+        if t * s >= target_blocks:
+            break
+    return best
+
+
 def cast_f32_bf16(x, y):
     L.check(L.lib().vlaser_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), 'vlaser_cast_f32_bf16')

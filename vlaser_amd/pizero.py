@@ -19,7 +19,7 @@ import torch
 from . import _lib as L
 from . import ops, prep
 from .config import VLAConfig
-from .engine import BF, KVCache, PrefillBuffers, QwenStack, SkinnyBuffers, VitEngine, prefill_layer, skinny_layer
+from .engine import BF, KVCache, PrefillBuffers, QwenStack, SkinnyBuffers, VitEngine, prefill_begin, prefill_layer, skinny_layer
 
 
 def canonicalize_vla_state_dict(sd):
@@ -146,10 +146,12 @@ class PiZero:
         ops.small_linear(self.in_proprio, self.pe_w, self.pe_b, self.h_pro, B, cfg.action_hidden_size, cfg.proprio_dim)
         # a13: joint prefill over {vlm, proprio}; K/V of both mixtures cached (post-RoPE), last layer skips o_proj+MLP
         h_pro, parts, npart = self.h_pro, None, 0
+        prefill_begin(self.vlm, self.pbuf, h_vlm, B * T)
         for i in range(nL):
             last = i == nL - 1
             prefill_layer(self.vlm, self.vlm.layers[i], self.pbuf, h_vlm, self.cache, i, self.rope, self.pos_vlm, B, T,
-                          L.ATTN_PREFIX, valid_len=self.valid_len, blk_start=T, skip_post_attn=last)
+                          L.ATTN_PREFIX, valid_len=self.valid_len, blk_start=T, skip_post_attn=last,
+                          next_norm_w=None if last else self.vlm.layers[i + 1].ln_in)
             h_pro, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_pro, h_pro, parts, npart, self.cache, i,
                                                self.rope, self.pos_pro, B, 1, T, T + 1, L.ATTN_PREFIX, valid_len=self.valid_len,
                                                blk_start=T, skip_post_attn=last)
