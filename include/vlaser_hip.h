@@ -68,7 +68,8 @@ int vlaser_gemm(int epi, const VlaserGemmArgs* args, vl_stream_t stream);
  * vlaser_attn_prefill replaces FlashAttention.forward / InternAttention._naive_attn (modeling_intern_vit.py:51-96,
  * 210-227; non-causal, hd 64) and HF eager_attention_forward / flash_attention_2 for Qwen2 prefill (causal GQA,
  * hd 128; joint_model.py:631-656 with the vlm rows of the block mask).
- * vlaser_attn_skinny replaces the same call for <=16 query tokens over the KV cache: the proprio row of the joint
+ * vlaser_attn_skinny (writes split partials, merged by vlaser_skinny's VL_PRO_ATTN prologue) replaces the same call for
+ * <=16 query tokens over the KV cache: the proprio row of the joint
  * prefill, the 4 action tokens of every Euler step (pizero_internvl.py:896-908) and single-token greedy decode.
  * Masks are passed as descriptors instead of dense [B,1,Sq,Skv] additive tensors (pizero_internvl.py:517-603):
  * key j is visible to query row i iff  j < lim1(i)  ||  blk_start <= j < kv_len (rows >= blk_start only). */
@@ -88,6 +89,10 @@ typedef struct {
   const int32_t* valid_len; /* PREFIX: int32 [B] valid image/text prefix length (device) */
   int blk_start;            /* PREFIX: first key of the proprio/action block */
   int q_row_off;            /* PREFIX: global row index of query row 0 */
+  /* vlaser_attn_skinny only: flash-decoding partials per (b, kv head, split), rows r = hg*sq + tok (<= 32) */
+  float* part_m; float* part_l; /* fp32 [B, n_kv, n_splits, 32] */
+  float* part_o;                /* fp32 [B, n_kv, n_splits, 32, 128], unnormalised */
+  int n_splits;                 /* 1..8 key splits (grid.y) */
 } VlaserAttnArgs;
 
 int vlaser_attn_prefill(const VlaserAttnArgs* args, vl_stream_t stream);
@@ -99,7 +104,7 @@ int vlaser_attn_skinny(const VlaserAttnArgs* args, vl_stream_t stream);
  * mixture active) and of greedy decode, plus lm_head on the last position (modeling_internvl_chat.py:204).
  * Prologue VL_PRO_NORM fuses: residual + split-K partial reduction of the producer, bf16 rounding of the residual
  * stream, Qwen2RMSNorm.  Split-K partials are reduced by the CONSUMER's prologue (deterministic, no atomics). */
-enum { VL_PRO_PLAIN = 0, VL_PRO_NORM = 1 };
+enum { VL_PRO_PLAIN = 0, VL_PRO_NORM = 1, VL_PRO_ATTN = 2 /* x = merge of vlaser_attn_skinny partials (o_proj) */ };
 enum {
   VL_SK_PARTIAL = 0,   /* out_f32[ks, m, n] = partial over this block's K slice */
   VL_SK_QKV_ROPE = 1,  /* as VL_EPI_QKV_ROPE */
@@ -116,9 +121,10 @@ typedef struct {
   const void* norm_w;     /* NORM: bf16 [K] */
   float eps;
   void* h_out;            /* NORM: bf16 [M,K] = bf16(h_in + sum partials), written by block 0 (may be null) */
-  const void* W;          /* bf16 [N,K] */
-  int M, N, K, ldw;
-  int k_splits;           /* grid.y; K % (k_splits*128) == 0 */
+  const void* W;          /* bf16, FRAGMENT-MAJOR packed [k_splits][N/32][8 waves][K/(k_splits*256)][2][64][8] (ops.pack_skinny) */
+  int M, N, K, ldw;       /* N = padded row count (multiple of 32); ldw unused */
+  int n_valid;            /* un-padded N (0 = N): logits / partial row length */
+  int k_splits;           /* grid.y; K % (k_splits*256) == 0 */
   float* out_f32;
   void* out; int ldo;
   const void* bias;       /* bf16 [N] */
@@ -126,6 +132,8 @@ typedef struct {
   void* q_out; void* k_cache; void* vt_cache;
   const float* rope_cos; const float* rope_sin; const int32_t* pos_ids;
   int n_q_heads, n_kv_heads, s_max, tok_per_batch, slot_base;
+  /* VL_PRO_ATTN: x[m = b*nq+tok][h*128+d] = sum_s o_s e^(m_s-M) / sum_s l_s e^(m_s-M) */
+  const float* attn_m; const float* attn_l; const float* attn_o; int attn_splits, attn_group, attn_nq;
 } VlaserSkinnyArgs;
 
 int vlaser_skinny(int prologue, int epi, const VlaserSkinnyArgs* args, vl_stream_t stream);

@@ -187,27 +187,45 @@ def test_attn_prefix_block(ops):
         close(out[b, 384:], ref[b, 384:], name=f'proprio row b{b}')
 
 
-@pytest.mark.parametrize('nq_tok,kv_len,mode', [(4, 389, 'prefix'), (1, 385, 'prefix'), (1, 337, 'full'), (3, 1500, 'full')])
-def test_attn_skinny(ops, nq_tok, kv_len, mode):
+@pytest.mark.parametrize('nq_tok,kv_len,mode,nsp', [(4, 389, 'prefix', 4), (1, 385, 'prefix', 4), (1, 337, 'full', 3), (3, 1500, 'full', 8),
+                                                    (5, 40, 'full', 1), (2, 389, 'prefix', 7)])
+def test_attn_skinny_partials_and_merge(ops, nq_tok, kv_len, mode, nsp):
+    """Split partials of the GQA-aware skinny attention + the merge fused into the o_proj GEMV prologue."""
     from vlaser_amd import _lib as L
     B, nq, nkv, smax = 2, 12, 2, 1536
+    G = nq // nkv
     q = rnd(B * nq_tok, nq * 128, seed=1)
     k = rnd(B, nkv, smax, 128, seed=2); v = rnd(B, nkv, smax, 128, seed=3)
     vt = v.transpose(-1, -2).contiguous()
-    out = torch.zeros(B, nq_tok, nq * 128, dtype=BF, device='cuda')
     sc = 128 ** -0.5
     valid = torch.tensor([277, 300], dtype=torch.int32, device='cuda')
     kw = dict(valid_len=valid, blk_start=384) if mode == 'prefix' else {}
-    ops.attn_skinny(q, k, vt, out, B, nq_tok, kv_len, nq, nkv, 128, (nq_tok * nq * 128, 128, nq * 128),
-                    (nkv * smax * 128, smax * 128), (nkv * 128 * smax, 128 * smax), (nq_tok * nq * 128, nq * 128), smax, sc,
-                    L.ATTN_PREFIX if mode == 'prefix' else L.ATTN_FULL, **kw)
+    parts = ops.attn_partial_buffers(B, nkv, 'cuda', max_splits=nsp)
+    ops.attn_skinny(q, k, vt, parts, B, nq_tok, kv_len, nq, nkv, 128, (nq_tok * nq * 128, 128, nq * 128),
+                    (nkv * smax * 128, smax * 128), (nkv * 128 * smax, 128 * smax), smax, sc,
+                    L.ATTN_PREFIX if mode == 'prefix' else L.ATTN_FULL, nsp, **kw)
     j = torch.arange(kv_len, device='cuda')[None, None]
     if mode == 'prefix':
         vis = ((j < valid[:, None, None]) | (j >= 384)).expand(B, nq_tok, kv_len)
     else:
         vis = torch.ones(B, nq_tok, kv_len, dtype=torch.bool, device='cuda')
     qq = q.view(B, nq_tok, nq, 128).permute(0, 2, 1, 3)
-    close(out, _attn_ref(qq, k[:, :, :kv_len], v[:, :, :kv_len], sc, vis), name='skinny attn')
+    ref = _attn_ref(qq, k[:, :, :kv_len], v[:, :, :kv_len], sc, vis)          # [B, tok, nq*128]
+    # reference merge of the partials (base-2 running max), rows r = hg*nq_tok + tok
+    pm, pl, po = parts
+    M = pm.max(dim=2, keepdim=True).values
+    f = torch.exp2(pm - M)
+    o = (po * f[..., None]).sum(2) / (pl * f).sum(2)[..., None]                # [B, nkv, 32, 128]
+    o = o[:, :, :G * nq_tok].view(B, nkv, G, nq_tok, 128).permute(0, 3, 1, 2, 4).reshape(B, nq_tok, nq * 128)
+    close(o, ref, name='partials merged')
+    # merge fused into the o_proj skinny GEMV
+    Mrows, H = B * nq_tok, 768
+    wo = rnd(H, nq * 128, std=0.03, seed=9)
+    ks = 3
+    part = torch.zeros(ks, Mrows, H, dtype=torch.float32, device='cuda')
+    ops.skinny(L.PRO_ATTN, L.SK_PARTIAL, None, ops.pack_skinny(wo, ks), Mrows, out_f32=part, attn_m=pm, attn_l=pl, attn_o=po, attn_splits=nsp,
+               attn_group=G, attn_nq=nq_tok)
+    close(part.sum(0), ref.reshape(Mrows, -1).to(BF).float() @ wo.float().t(), rtol=2e-2, name='o_proj over merged attention')
 
 
 def _rms_ref(h, w, eps=1e-6):
@@ -215,12 +233,12 @@ def _rms_ref(h, w, eps=1e-6):
     return (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + eps)).to(BF).float() * w.float()
 
 
-@pytest.mark.parametrize('M,N,K,ks', [(4, 768, 1536, 6), (4, 768, 8960, 10), (1, 1536, 8960, 5), (16, 1536, 1536, 1), (5, 3584, 3584, 2)])
+@pytest.mark.parametrize('M,N,K,ks', [(4, 768, 1536, 6), (4, 768, 8960, 7), (1, 1536, 8960, 5), (16, 1536, 1536, 1), (5, 3584, 3584, 2), (2, 1536, 18944, 1)])
 def test_skinny_partial(ops, M, N, K, ks):
     from vlaser_amd import _lib as L
     x, w = rnd(M, K), rnd(N, K, std=0.03)
     part = torch.zeros(ks, M, N, dtype=torch.float32, device='cuda')
-    ops.skinny(L.PRO_PLAIN, L.SK_PARTIAL, x, w, M, k_splits=ks, out_f32=part)
+    ops.skinny(L.PRO_PLAIN, L.SK_PARTIAL, x, ops.pack_skinny(w, ks), M, out_f32=part)
     close(part.sum(0), x.float() @ w.float().t(), rtol=2e-3, atol=2e-3, name='partial sum')
     # each slab is the partial over its own K slice
     kb = K // ks
@@ -233,18 +251,18 @@ def test_skinny_bias_silu_f32(ops):
     x, w, b = rnd(M, K), rnd(N, K, std=0.03), rnd(N, std=0.3)
     ref = x.float() @ w.float().t() + b.float()
     out = torch.zeros(M, N, dtype=BF, device='cuda')
-    ops.skinny(L.PRO_PLAIN, L.SK_BIAS, x, w, M, out=out, ldo=N, bias=b)
+    ops.skinny(L.PRO_PLAIN, L.SK_BIAS, x, ops.pack_skinny(w), M, out=out, ldo=N, bias=b)
     close(out, ref, name='bias')
-    ops.skinny(L.PRO_PLAIN, L.SK_BIAS_SILU, x, w, M, out=out, ldo=N, bias=b)
+    ops.skinny(L.PRO_PLAIN, L.SK_BIAS_SILU, x, ops.pack_skinny(w), M, out=out, ldo=N, bias=b)
     close(out, F.silu(ref.to(BF).float()), name='bias_silu')
     N2 = 1002
     w2 = rnd(N2, K, std=0.03, seed=9)
     lg = torch.zeros(M, N2, dtype=torch.float32, device='cuda')
-    ops.skinny(L.PRO_PLAIN, L.SK_F32, x, w2, M, out_f32=lg)
+    ops.skinny(L.PRO_PLAIN, L.SK_F32, x, ops.pack_skinny(w2), M, out_f32=lg)
     close(lg, x.float() @ w2.float().t(), rtol=2e-3, atol=2e-3, name='f32 edge N')
 
 
-@pytest.mark.parametrize('M,H,I,npart', [(4, 768, 8960, 10), (1, 1536, 8960, 0), (4, 768, 8960, 3)])
+@pytest.mark.parametrize('M,H,I,npart', [(4, 768, 8960, 7), (1, 1536, 8960, 0), (4, 768, 8960, 3), (16, 768, 8960, 8), (3, 3584, 2048, 2)])
 def test_skinny_norm_swiglu(ops, M, H, I, npart):
     from vlaser_amd import _lib as L
     h, nw = rnd(M, H), (1 + 0.1 * rnd(H, seed=5).float()).to(BF)
@@ -252,7 +270,7 @@ def test_skinny_norm_swiglu(ops, M, H, I, npart):
     g, u = rnd(I, H, std=0.03, seed=1), rnd(I, H, std=0.03, seed=2)
     W = ops.pack_gate_up(g, u)
     out = torch.zeros(M, I, dtype=BF, device='cuda'); h_out = torch.zeros(M, H, dtype=BF, device='cuda')
-    ops.skinny(L.PRO_NORM, L.SK_SWIGLU, h, W, M, partials=parts, n_partials=npart, norm_w=nw, h_out=h_out, out=out, ldo=I)
+    ops.skinny(L.PRO_NORM, L.SK_SWIGLU, h, ops.pack_skinny(W), M, partials=parts, n_partials=npart, norm_w=nw, h_out=h_out, out=out, ldo=I)
     hs = (h.float() + (parts[:npart].sum(0) if npart else 0)).to(BF)
     assert torch.equal(h_out, hs) or (h_out.float() - hs.float()).abs().max() <= 2 ** -7 * hs.float().abs().max()
     xn = _rms_ref(h_out, nw).to(BF).float()
@@ -272,7 +290,7 @@ def test_skinny_norm_qkv_rope(ops):
     pos = (torch.arange(tok).repeat(B) + 2).int().cuda()
     q_out = torch.zeros(M, nq * 128, dtype=BF, device='cuda')
     kc = torch.zeros(B, nkv, smax, 128, dtype=BF, device='cuda'); vtc = torch.zeros(B, nkv, 128, smax, dtype=BF, device='cuda')
-    ops.skinny(L.PRO_NORM, L.SK_QKV_ROPE, h, W, M, n_partials=0, norm_w=nw, bias=Bv, q_out=q_out, k_cache=kc, vt_cache=vtc,
+    ops.skinny(L.PRO_NORM, L.SK_QKV_ROPE, h, ops.pack_skinny(W), M, n_partials=0, norm_w=nw, bias=Bv, q_out=q_out, k_cache=kc, vt_cache=vtc,
                rope_cos=cos, rope_sin=sin, pos_ids=pos, n_q_heads=nq, n_kv_heads=nkv, s_max=smax, tok_per_batch=tok, slot_base=385)
     xn = _rms_ref(h, nw).to(BF).float()
     q = (xn @ qw.float().t() + qb.float()).to(BF).float().view(M, nq, 128)

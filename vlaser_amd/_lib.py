@@ -24,21 +24,22 @@ class AttnArgs(C.Structure):
                 ('n_q_heads', i32), ('n_kv_heads', i32), ('head_dim', i32), ('q_bs', i64), ('q_hs', i64), ('q_ss', i64),
                 ('k_bs', i64), ('k_hs', i64), ('vt_bs', i64), ('vt_hs', i64), ('o_bs', i64), ('o_ss', i64),
                 ('ld_vt', i32), ('scale', f32), ('mode', i32), ('causal_off', i32), ('valid_len', vp),
-                ('blk_start', i32), ('q_row_off', i32)]
+                ('blk_start', i32), ('q_row_off', i32), ('part_m', vp), ('part_l', vp), ('part_o', vp), ('n_splits', i32)]
 
 
 class SkinnyArgs(C.Structure):
     _fields_ = [('x', vp), ('partials', vp), ('n_partials', i32), ('norm_w', vp), ('eps', f32), ('h_out', vp),
-                ('W', vp), ('M', i32), ('N', i32), ('K', i32), ('ldw', i32), ('k_splits', i32), ('out_f32', vp),
+                ('W', vp), ('M', i32), ('N', i32), ('K', i32), ('ldw', i32), ('n_valid', i32), ('k_splits', i32), ('out_f32', vp),
                 ('out', vp), ('ldo', i32), ('bias', vp), ('q_out', vp), ('k_cache', vp), ('vt_cache', vp),
                 ('rope_cos', vp), ('rope_sin', vp), ('pos_ids', vp), ('n_q_heads', i32), ('n_kv_heads', i32),
-                ('s_max', i32), ('tok_per_batch', i32), ('slot_base', i32)]
+                ('s_max', i32), ('tok_per_batch', i32), ('slot_base', i32), ('attn_m', vp), ('attn_l', vp), ('attn_o', vp),
+                ('attn_splits', i32), ('attn_group', i32), ('attn_nq', i32)]
 
 
 # enums (include/vlaser_hip.h)
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_LS_RES, EPI_RES, EPI_SWIGLU, EPI_QKV_ROPE, EPI_VIT_QKV, EPI_F32, EPI_PARTIAL = range(10)
 ATTN_FULL, ATTN_CAUSAL, ATTN_PREFIX = range(3)
-PRO_PLAIN, PRO_NORM = range(2)
+PRO_PLAIN, PRO_NORM, PRO_ATTN = range(3)
 SK_PARTIAL, SK_QKV_ROPE, SK_SWIGLU, SK_F32, SK_BIAS, SK_BIAS_SILU = range(6)
 
 _SIGS = {

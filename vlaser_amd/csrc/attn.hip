@@ -213,95 +213,101 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnP p) {
 }
 
 // ------------------------------------------------------------------------------------------------ skinny
-// grid (n_q_heads, B); block 512 = 8 waves; per pass a wave takes TWO 32-key chunks and issues every K and V^T
-// fragment load of both up front (one memory round trip per pass, 32 x 16 B in flight per lane); HD = 128.
-// Query rows: nq tokens (<=16) of ONE q head.  Visibility is uniform over the rows of a batch element:
-//   keys [0, lim1) U [lo2, hi2)   (lim1 = valid_len[b] or kv_len; causal decode passes lim1 = kv_len).
-#define SK_WAVES 8
-__global__ __launch_bounds__(512) void attn_skinny_kernel(AttnP p) {
+// <= 16 query tokens per batch element over a KV cache, GQA-aware and key-split:
+//   grid (n_kv_heads, n_splits, B); block = 4 waves; rows = (q-head-in-group hg, token) pairs of ONE kv head
+//   (r = hg*nq + tok, G*nq <= 32 -> two 16-row MFMA tiles), so K / V^T of a kv head are read ONCE for all its
+//   q heads; split s owns a contiguous run of 32-key chunks, one chunk per wave per pass, every K and V^T
+//   fragment of the chunk requested up front.  Per-CU traffic is ~1/n_splits of the cache instead of all of it.
+// Output = flash-decoding partials per (b, kv head, split): m, l [32] and unnormalised o [32][128] (fp32); they are
+// merged by the CONSUMER (o_proj skinny kernel, VL_PRO_ATTN prologue) -- no second launch, no atomics.
+// Visibility is uniform over the rows of a batch element: keys [0, lim1) U [lo2, hi2).
+#define SKA_WAVES 4
+__global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
   constexpr int HD = 128, DC = 4, DT = 8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [8 waves][ m[16] l[16] o[16][128] ] fp32
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 waves][ m[32] l[32] o[32][128] ] fp32
   const VlaserAttnArgs& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
-  const int h = blockIdx.x, b = blockIdx.y;
-  const int kvh = h / (a.n_q_heads / a.n_kv_heads);
-  const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (size_t)b * a.q_bs + (size_t)h * a.q_hs;
+  const int kvh = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+  const int G = a.n_q_heads / a.n_kv_heads, nq = a.sq, nrows = G * nq;
   const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (size_t)b * a.k_bs + (size_t)kvh * a.k_hs;
   const bf16_t* VT = reinterpret_cast<const bf16_t*>(a.vt) + (size_t)b * a.vt_bs + (size_t)kvh * a.vt_hs;
 
+  // chunk schedule depends on kernel arguments only (not on valid_len[b]): loads never wait for that value
+  const int n_chunks = (a.kv_len + 31) >> 5;
+  const int cps = (n_chunks + a.n_splits - 1) / a.n_splits;
+  const int c_begin = split * cps, c_end = min(n_chunks, c_begin + cps);
+
+  bf16x8 qf[2][DC];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int r = qt * 16 + fr;
+    const int hg = r / nq, tok = r - hg * nq;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (size_t)b * a.q_bs + (size_t)(kvh * G + hg) * a.q_hs + (size_t)tok * a.q_ss;
+#pragma unroll
+    for (int dc = 0; dc < DC; ++dc) {
+      u32x4 v = {0, 0, 0, 0};
+      if (r < nrows) v = ld_global_16(Q + dc * 32 + g * 8);
+      qf[qt][dc] = as_bf16x8(v);
+    }
+  }
   int lim1 = a.kv_len, lo2 = 0x7fffffff, hi2 = 0;
   if (a.mode == VL_ATTN_PREFIX) {
     lim1 = min(a.valid_len ? a.valid_len[b] : a.kv_len, a.kv_len);
     lo2 = a.blk_start; hi2 = a.kv_len;
   }
-  const int n1 = (lim1 + 31) >> 5;
-  int c2_lo = 0, c2_hi = 0;
-  if (hi2 > lo2) { c2_lo = max(n1, lo2 >> 5); c2_hi = (hi2 + 31) >> 5; }
-  const int n_chunks = n1 + max(0, c2_hi - c2_lo);
-
-  bf16x8 qf[DC];
+  f32x4 o[2][DT];
 #pragma unroll
-  for (int dc = 0; dc < DC; ++dc) {
-    u32x4 v = {0, 0, 0, 0};
-    if (fr < a.sq) v = ld_global_16(Q + (size_t)fr * a.q_ss + dc * 32 + g * 8);
-    qf[dc] = as_bf16x8(v);
-  }
-  f32x4 o[DT];
+  for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-  for (int i = 0; i < DT; ++i) o[i] = f32x4{0, 0, 0, 0};
-  float m_run = NEG_BIG, l_run = 0.f;
+    for (int i = 0; i < DT; ++i) o[qt][i] = f32x4{0, 0, 0, 0};
+  float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f};
   const float sc = a.scale * 1.4426950408889634f;
 
-  for (int base = wave * 2; base < n_chunks; base += 2 * SK_WAVES) {
-    u32x4 kf[2][2][DC], vf[2][DT];
-    int key0[2];
-    bool ok[2];
+  for (int ci = c_begin + wave; ci < c_end; ci += SKA_WAVES) {
+    const int key0 = ci << 5;
+    u32x4 kf[2][DC], vf[DT];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int ci = base + c;
-      ok[c] = ci < n_chunks;
-      key0[c] = (ci < n1 ? ci : c2_lo + (ci - n1)) << 5;
-      if (ok[c]) {
+    for (int t = 0; t < 2; ++t) {
+      const int key = key0 + (fr >> 2) * 8 + t * 4 + (fr & 3);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int key = key0[c] + (fr >> 2) * 8 + t * 4 + (fr & 3);
-#pragma unroll
-          for (int dc = 0; dc < DC; ++dc)
-            kf[c][t][dc] = (key < a.kv_len) ? ld_global_16(K + (size_t)key * HD + dc * 32 + g * 8) : u32x4{0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) vf[c][dt] = ld_global_16(VT + (size_t)(dt * 16 + fr) * a.ld_vt + key0[c] + g * 8);
-      }
+      for (int dc = 0; dc < DC; ++dc)
+        kf[t][dc] = (key < a.kv_len) ? ld_global_16(K + (size_t)key * HD + dc * 32 + g * 8) : u32x4{0, 0, 0, 0};
     }
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      if (!ok[c]) continue;
+    for (int dt = 0; dt < DT; ++dt) vf[dt] = ld_global_16(VT + (size_t)(dt * 16 + fr) * a.ld_vt + key0 + g * 8);
+    bool vis[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + g * 8 + t * 4 + r;
+        vis[t][r] = (key < lim1) || (key >= lo2 && key < hi2);
+      }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      if (qt * 16 >= nrows) continue;
       f32x4 s[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         f32x4 acc = {0, 0, 0, 0};
 #pragma unroll
-        for (int dc = 0; dc < DC; ++dc) acc = mfma16(as_bf16x8(kf[c][t][dc]), qf[dc], acc);
+        for (int dc = 0; dc < DC; ++dc) acc = mfma16(as_bf16x8(kf[t][dc]), qf[qt][dc], acc);
         s[t] = acc;
       }
       float mx = NEG_BIG;
-      bool vis[2][4];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = key0[c] + g * 8 + t * 4 + r;
-          const bool v = (key < lim1) || (key >= lo2 && key < hi2);
-          vis[t][r] = v;
           s[t][r] *= sc;
-          if (v) mx = fmaxf(mx, s[t][r]);
+          if (vis[t][r]) mx = fmaxf(mx, s[t][r]);
         }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = fast_exp2(m_run - m_new);
-      m_run = m_new;
+      const float m_new = fmaxf(m_run[qt], mx);
+      const float alpha = fast_exp2(m_run[qt] - m_new);
+      m_run[qt] = m_new;
       float pv[8], psum = 0.f;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -311,50 +317,58 @@ __global__ __launch_bounds__(512) void attn_skinny_kernel(AttnP p) {
           psum += pe;
           pv[t * 4 + r] = pe;
         }
-      l_run = l_run * alpha + psum;
+      l_run[qt] = l_run[qt] * alpha + psum;
       u32x4 pk = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]), pack_bf16x2(pv[4], pv[5]), pack_bf16x2(pv[6], pv[7])};
       const bf16x8 pf = as_bf16x8(pk);
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        f32x4 acc = o[dt];
+        f32x4 acc = o[qt][dt];
         acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
-        o[dt] = mfma16(as_bf16x8(vf[c][dt]), pf, acc);
+        o[qt][dt] = mfma16(as_bf16x8(vf[dt]), pf, acc);
       }
     }
   }
-  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-  l_tot += __shfl_xor(l_tot, 32, 64);
 
-  // flash-decoding merge through LDS
-  constexpr int WS = 32 + 16 * 128;
+  // in-block merge of the 4 waves through LDS, then one partial per (b, kvh, split)
+  constexpr int WS = 64 + 32 * 128;
   float* wm = reinterpret_cast<float*>(smem) + wave * WS;
-  float* wl = wm + 16;
-  float* wo = wm + 32;
-  if (g == 0) { wm[fr] = m_run; wl[fr] = l_tot; }
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(wo + fr * 128 + dt * 16 + g * 4) = o[dt];
+  for (int qt = 0; qt < 2; ++qt) {
+    float l_tot = l_run[qt] + __shfl_xor(l_run[qt], 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    if (g == 0) { wm[qt * 16 + fr] = m_run[qt]; wm[32 + qt * 16 + fr] = l_tot; }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(wm + 64 + (qt * 16 + fr) * 128 + dt * 16 + g * 4) = o[qt][dt];
+  }
   __syncthreads();
-  // thread -> (row = tid / 32, 4 consecutive d = (tid % 32) * 4): 16 rows x 128 d over 512 threads
   {
-    const int row = tid >> 5, d = (tid & 31) * 4;
-    if (row < a.sq) {
-      const float* base = reinterpret_cast<const float*>(smem);
+    const size_t pidx = ((size_t)b * a.n_kv_heads + kvh) * a.n_splits + split;
+    float* PM = a.part_m + pidx * 32;
+    float* PL = a.part_l + pidx * 32;
+    float* PO = a.part_o + pidx * 32 * 128;
+    const float* base = reinterpret_cast<const float*>(smem);
+    // thread -> (row = tid / 8, 16 consecutive d = (tid % 8) * 16)
+    const int row = tid >> 3, d0 = (tid & 7) * 16;
+    if (row < nrows) {
       float M = NEG_BIG;
 #pragma unroll
-      for (int w = 0; w < SK_WAVES; ++w) M = fmaxf(M, base[w * WS + row]);
+      for (int w = 0; w < SKA_WAVES; ++w) M = fmaxf(M, base[w * WS + row]);
       float Lsum = 0.f;
-      f32x4 acc = {0, 0, 0, 0};
+      f32x4 acc[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
 #pragma unroll
-      for (int w = 0; w < SK_WAVES; ++w) {
+      for (int w = 0; w < SKA_WAVES; ++w) {
         const float* bw = base + w * WS;
         const float f = fast_exp2(bw[row] - M);
-        Lsum += bw[16 + row] * f;
-        const f32x4 ov = *reinterpret_cast<const f32x4*>(bw + 32 + row * 128 + d);
-        acc[0] += ov[0] * f; acc[1] += ov[1] * f; acc[2] += ov[2] * f; acc[3] += ov[3] * f;
+        Lsum += bw[32 + row] * f;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 ov = *reinterpret_cast<const f32x4*>(bw + 64 + row * 128 + d0 + q4 * 4);
+          acc[q4][0] += ov[0] * f; acc[q4][1] += ov[1] * f; acc[q4][2] += ov[2] * f; acc[q4][3] += ov[3] * f;
+        }
       }
-      const float inv = Lsum > 0.f ? 1.0f / Lsum : 0.f;
-      bf16_t* O = reinterpret_cast<bf16_t*>(a.out) + (size_t)b * a.o_bs + (size_t)row * a.o_ss + h * HD + d;
-      *reinterpret_cast<u32x2*>(O) = u32x2{pack_bf16x2(acc[0] * inv, acc[1] * inv), pack_bf16x2(acc[2] * inv, acc[3] * inv)};
+      if ((tid & 7) == 0) { PM[row] = M; PL[row] = Lsum; }
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<f32x4*>(PO + row * 128 + d0 + q4 * 4) = acc[q4];
     }
   }
 }
@@ -377,19 +391,22 @@ extern "C" int vlaser_attn_prefill(const VlaserAttnArgs* a, vl_stream_t s) {
 
 extern "C" int vlaser_attn_skinny(const VlaserAttnArgs* a, vl_stream_t s) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(s);
-  VL_CHECK(a && a->q && a->k && a->vt && a->out, "vlaser_attn_skinny: null pointer");
+  VL_CHECK(a && a->q && a->k && a->vt, "vlaser_attn_skinny: null pointer");
+  VL_CHECK(a->part_m && a->part_l && a->part_o, "vlaser_attn_skinny: partial buffers null");
   VL_CHECK(a->head_dim == 128, "vlaser_attn_skinny: head_dim must be 128");
-  VL_CHECK(a->sq >= 1 && a->sq <= 16, "vlaser_attn_skinny: 1..16 query tokens, got %d", a->sq);
+  VL_CHECK(a->n_q_heads % a->n_kv_heads == 0, "vlaser_attn_skinny: GQA group mismatch");
+  VL_CHECK(a->sq >= 1 && a->sq * (a->n_q_heads / a->n_kv_heads) <= 32, "vlaser_attn_skinny: group*tokens must be <= 32 (tokens=%d)", a->sq);
   VL_CHECK(a->ld_vt % 32 == 0 && a->kv_len <= a->ld_vt, "vlaser_attn_skinny: bad cache geometry");
+  VL_CHECK(a->n_splits >= 1 && a->n_splits <= 8, "vlaser_attn_skinny: n_splits must be 1..8");
   VL_CHECK(a->mode == VL_ATTN_FULL || a->mode == VL_ATTN_PREFIX, "vlaser_attn_skinny: mode must be FULL or PREFIX");
   AttnP p; p.a = *a;
-  const int lds = SK_WAVES * (32 + 2048) * 4;
+  const int lds = SKA_WAVES * (64 + 32 * 128) * 4;
   static bool attr_set = false;
   if (!attr_set) {
     VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_skinny_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_skinny_kernel, dim3(a->n_q_heads, a->batch), dim3(64 * SK_WAVES), lds, stream, p);
+  hipLaunchKernelGGL(attn_skinny_kernel, dim3(a->n_kv_heads, a->n_splits, a->batch), dim3(64 * SKA_WAVES), lds, stream, p);
   VL_LAUNCH_CHECK();
   return 0;
 }

@@ -56,6 +56,26 @@ __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x));
 __device__ __forceinline__ u32x4 ld_global_16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st_global_16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
+// ---- split-K slab reduction: all loads of one call are independent and in flight together (one L2 round trip)
+// sum of the first S (<= NB) fp32 slabs into v; always issues NB independent load pairs (index clamped) -> one trip
+template <int NB>
+__device__ __forceinline__ void add_slabs_clamped(float (&v)[8], const float* base, size_t slab, int S) {
+  f32x4 q[2 * NB];
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const float* pp = base + (size_t)min(u, S - 1) * slab;
+    q[2 * u] = *reinterpret_cast<const f32x4*>(pp);
+    q[2 * u + 1] = *reinterpret_cast<const f32x4*>(pp + 4);
+  }
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const float w = u < S ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] += w * q[2 * u][j]; v[4 + j] += w * q[2 * u + 1][j]; }
+  }
+}
+
+
 // host-side error plumbing (api.cpp)
 void vlaser_set_error(const char* fmt, ...);
 #define VL_CHECK(cond, ...)            \

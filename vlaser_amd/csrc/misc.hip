@@ -367,7 +367,20 @@ __global__ __launch_bounds__(256) void vla_euler_kernel(const bf16_t* __restrict
   float ssq = 0.f;
   for (int c = threadIdx.x; c < Wd; c += 256) {
     float v = bf16_to_f32(h_in[(size_t)m * Wd + c]);
-    for (int s = 0; s < n_partials; ++s) v += partials[((size_t)s * M + m) * Wd + c];
+    {
+      float t[12];
+      int s = 0;
+      for (; s + 12 <= n_partials; s += 12) {
+#pragma unroll
+        for (int u = 0; u < 12; ++u) t[u] = partials[((size_t)(s + u) * M + m) * Wd + c];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) v += t[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 12; ++u) t[u] = (s + u < n_partials) ? partials[((size_t)(s + u) * M + m) * Wd + c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 12; ++u) v += t[u];
+    }
     v = round_bf16(v);
     ybuf[c] = v;
     ssq += v * v;
@@ -476,14 +489,13 @@ extern "C" int vlaser_ce_rows(const float* logits, const int64_t* labels, int R,
 // h = h_in + [ls *] (sum_s partials[s] [+ bias]); x_out = norm(h).  One wave per row, 4 rows per block; the row
 // (C <= 4096) stays in registers between the reduction and the normalisation; slab loads are issued 4 slabs at a
 // time (independent 16-byte loads) so the reduction costs ~ceil(S/4) L2 round trips.
-template <int NORM>  // 0 none, 1 RMS, 2 LayerNorm
+template <int NORM, int MAXC>  // NORM: 0 none, 1 RMS, 2 LayerNorm; MAXC: 16-byte chunks per lane (C <= 512*MAXC)
 __global__ __launch_bounds__(256) void reduce_norm_kernel(const bf16_t* __restrict__ h_in, const float* __restrict__ partials, int S,
                                                           const bf16_t* __restrict__ bias, const bf16_t* __restrict__ ls,
                                                           const bf16_t* __restrict__ nw, const bf16_t* __restrict__ nb, float eps,
                                                           bf16_t* __restrict__ h_out, bf16_t* __restrict__ x_out, int M, int C) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  constexpr int MAXC = 8;  // chunks of 8 per lane -> C <= 4096
   u32x4 hv[MAXC];
   const size_t slab = (size_t)M * C;
   float s1 = 0.f, s2 = 0.f;
@@ -493,25 +505,11 @@ __global__ __launch_bounds__(256) void reduce_norm_kernel(const bf16_t* __restri
     if (c < C) {
       const size_t off = (size_t)row * C + c;
       float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      int sp = 0;
-      for (; sp + 4 <= S; sp += 4) {
-        f32x4 q[8];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float* pp = partials + (size_t)(sp + u) * slab + off;
-          q[2 * u] = *reinterpret_cast<const f32x4*>(pp);
-          q[2 * u + 1] = *reinterpret_cast<const f32x4*>(pp + 4);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { v[j] += q[2 * u][j]; v[4 + j] += q[2 * u + 1][j]; }
-      }
-      for (; sp < S; ++sp) {
-        const float* pp = partials + (size_t)sp * slab + off;
-        const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] += p0[j]; v[4 + j] += p1[j]; }
+      if (S > 0) {
+        const float* pb = partials + off;
+        int Sr = S;
+        for (; Sr > 8; Sr -= 8, pb += 8 * slab) add_slabs_clamped<8>(v, pb, slab, 8);
+        add_slabs_clamped<8>(v, pb, slab, Sr);
       }
       const u32x4 hi = ld_global_16(h_in + off);
       u32x4 bv = {0, 0, 0, 0}, lv = {0, 0, 0, 0};
@@ -580,9 +578,15 @@ extern "C" int vlaser_reduce_norm(const void* h_in, const float* partials, int S
   dim3 grid((M + 3) / 4), blk(256);
 #define RN_ARGS (const bf16_t*)h_in, partials, S, (const bf16_t*)bias, (const bf16_t*)ls, (const bf16_t*)nw, (const bf16_t*)nb, eps, \
                 (bf16_t*)h_out, (bf16_t*)x_out, M, C
-  if (norm_kind == 0) hipLaunchKernelGGL(reduce_norm_kernel<0>, grid, blk, 0, (hipStream_t)s, RN_ARGS);
-  else if (norm_kind == 1) hipLaunchKernelGGL(reduce_norm_kernel<1>, grid, blk, 0, (hipStream_t)s, RN_ARGS);
-  else hipLaunchKernelGGL(reduce_norm_kernel<2>, grid, blk, 0, (hipStream_t)s, RN_ARGS);
+  if (C <= 2048) {
+    if (norm_kind == 0) hipLaunchKernelGGL((reduce_norm_kernel<0, 4>), grid, blk, 0, (hipStream_t)s, RN_ARGS);
+    else if (norm_kind == 1) hipLaunchKernelGGL((reduce_norm_kernel<1, 4>), grid, blk, 0, (hipStream_t)s, RN_ARGS);
+    else hipLaunchKernelGGL((reduce_norm_kernel<2, 4>), grid, blk, 0, (hipStream_t)s, RN_ARGS);
+  } else {
+    if (norm_kind == 0) hipLaunchKernelGGL((reduce_norm_kernel<0, 8>), grid, blk, 0, (hipStream_t)s, RN_ARGS);
+    else if (norm_kind == 1) hipLaunchKernelGGL((reduce_norm_kernel<1, 8>), grid, blk, 0, (hipStream_t)s, RN_ARGS);
+    else hipLaunchKernelGGL((reduce_norm_kernel<2, 8>), grid, blk, 0, (hipStream_t)s, RN_ARGS);
+  }
 #undef RN_ARGS
   VL_LAUNCH_CHECK();
   return 0;

@@ -1,17 +1,32 @@
 // Skinny (M <= 16 activation rows) weight-streaming GEMV on MFMA for gfx950 -- the HBM-bound regime of the 10
 // action-expert Euler steps and of greedy decode: every weight byte is read exactly once per call.
 //
-// Block = 4 waves; a block owns one "unit" = 32 consecutive (packed) weight rows = two 16-row MFMA tiles, and
-// the 4 waves split the block's K range (in-block split-K, reduced through LDS).  blockIdx.y adds cross-block
-// split-K for narrow outputs (o_proj / down_proj): fp32 partial slabs go to a workspace and are summed by the
-// CONSUMER's prologue -- deterministic, no atomics, no extra launch.
-// Weight fragments go global -> VGPR directly in MFMA layout (lane (r, kq) loads 16 B of row r at k + 8 kq): the
-// weights are streamed once and never shared between waves, so an LDS round trip would be pure overhead (guide:
-// "GEMV / M <= 16 decode weights: load straight to VGPRs, deep unroll").  Activations (a few KB) sit in LDS.
+// Geometry.  Block = 8 waves; a "unit" = 32 consecutive (packed) weight rows = two 16-row MFMA tiles; the 8 waves
+// split the block's K range (in-block split-K, reduced through LDS); blockIdx.y adds cross-block split-K for narrow
+// outputs (o_proj / down_proj): fp32 partial slabs go to a workspace and are summed by the CONSUMER's prologue --
+// deterministic, no atomics, no extra launch.  The grid is sized to <= one block per CU: a block owns a balanced
+// run of consecutive units, executes the (per-block redundant) prologue ONCE, and streams its units back to back.
+//
+// Memory layout.  Weights are PRE-PACKED in HBM in MFMA-fragment order (vlaser_amd.ops.pack_skinny):
+//     [k_split][unit][wave][k_step][tile][lane][8 bf16]
+// so every wave-level load is one contiguous 1 KiB and a wave's whole stream is contiguous.  Measured on MI355X
+// (tools/micro/pattern.hip): 27.5 MB stream, 256 blocks: contiguous 4.8 TB/s vs 3.3 TB/s for the row-major
+// fragment pattern (16 rows x 64 B per instruction).  Fragments go global -> VGPR directly (guide: "GEMV / M <= 16
+// decode weights: load straight to VGPRs"); activations (a few KB) sit in LDS.
+//
+// Latency engineering.  At M = 4 a launch lasts a few microseconds, so (a) the executed code path is kept small (one
+// copy of the K-loop / reduce / epilogue; a cold instruction cache is paid on every launch), (b) the first batch of
+// weight loads is issued at kernel entry, before the prologue, (c) the prologue requests the residual chunk, the
+// norm weight and all split-K slabs of its chunk together (one L2 round trip), (d) the next unit's fragments and
+// epilogue operands are requested before the current unit is consumed.
 // MFMA operands are swapped (W as A, x as B) so each lane owns 4 consecutive outputs n of one row m, sharing the
 // fused epilogues of the big GEMM (bias / SiLU / SwiGLU / RoPE + KV-cache scatter).
 #include "common.h"
 #include "../../include/vlaser_hip.h"
+
+#define SKW 8        // waves per block
+#define SKT (SKW * 64)
+#define SKU 8        // K-steps (of 32) per batch per wave
 
 struct SkinnyP {
   VlaserSkinnyArgs a;
@@ -19,179 +34,56 @@ struct SkinnyP {
   int kb;         // K per block
 };
 
-template <int PRO, int EPI>
-__global__ __launch_bounds__(256) void skinny_kernel(SkinnyP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const VlaserSkinnyArgs& a = p.a;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int fr = lane & 15, g = lane >> 4;
-  const int unit = blockIdx.x, ks = blockIdx.y;
-  const int kb0 = ks * p.kb;                  // first k of this block
-  char* xs = smem;                            // [M][xs_stride]
-  float* red = reinterpret_cast<float*>(smem + ((a.M * p.xs_stride + 15) & ~15));  // [4 waves][2][64][4]
+struct EpiOps {  // epilogue operands of one unit (wave 0 only)
+  float b0[4], b1[4], cs[4], sn[4];
+};
 
-  // ------------------------------------------------------------------ weight stream set-up: this wave's K quarter; the first batch of
-  // weight loads is issued BEFORE the prologue so HBM latency overlaps the activation / partial-slab reads
-  const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W);
-  const int kw = p.kb >> 2;                   // K per wave (multiple of 32)
-  const int kl0 = wave * kw;                  // block-local k start
-  const int row0 = unit * 32 + fr, row1 = row0 + 16;
-  const bool r0ok = row0 < a.N, r1ok = row1 < a.N;
-  const bf16_t* w0 = W + (size_t)(r0ok ? row0 : 0) * a.ldw + kb0 + kl0 + g * 8;
-  const bf16_t* w1 = W + (size_t)(r1ok ? row1 : 0) * a.ldw + kb0 + kl0 + g * 8;
-  const char* xrow = xs + (fr < a.M ? fr : 0) * p.xs_stride + (kl0 + g * 8) * 2;
-  const bool mok = fr < a.M;
-  f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-  const int nsteps = kw >> 5;
-  constexpr int U = 4;
-  u32x4 c0[U], c1[U];
-  auto issue = [&](int s0, u32x4* d0, u32x4* d1) {
+template <int EPI>
+__device__ __forceinline__ void load_epi(const VlaserSkinnyArgs& a, int unit, int m, int g, EpiOps& e) {
+  const int n0 = unit * 32 + g * 4;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int s = s0 + u;
-      if (s < nsteps) {
-        d0[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(w0 + s * 32));
-        d1[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(w1 + s * 32));
-      }
-    }
-  };
-  issue(0, c0, c1);
-
-  // ------------------------------------------------------------------ prologue: activations -> LDS (bf16)
-  if constexpr (PRO == VL_PRO_PLAIN) {
-    const bf16_t* X = reinterpret_cast<const bf16_t*>(a.x);
-    const int chunks_per_row = p.kb >> 3;
-    for (int c = tid; c < a.M * chunks_per_row; c += 256) {
-      const int m = c / chunks_per_row, j = c - m * chunks_per_row;
-      *reinterpret_cast<u32x4*>(xs + m * p.xs_stride + j * 16) = ld_global_16(X + (size_t)m * a.K + kb0 + j * 8);
-    }
-  } else {
-    // h = bf16(h_in + sum partials); xn = bf16(w * bf16(h * rsqrt(mean(h^2) + eps)))
-    // Phase 1: all 256 threads stride over the M*K/8 16-byte chunks; the partial-slab loads of a chunk are issued
-    // in independent batches of 4 slabs (8 x 16 B in flight per lane) -- one L2 round trip per batch instead of one
-    // per slab.  Phase 2: one wave per row takes the sum of squares from LDS and normalises in place.
-    const bf16_t* Hin = reinterpret_cast<const bf16_t*>(a.x);
-    const bf16_t* Wn = reinterpret_cast<const bf16_t*>(a.norm_w);
-    const bool write_h = (a.h_out != nullptr) && unit == 0 && ks == 0;
-    const int cpr = a.K >> 3;  // chunks per row
-    const size_t slab = (size_t)a.M * a.K;
-    for (int ch = tid; ch < a.M * cpr; ch += 256) {
-      const int m = ch / cpr, c = (ch - m * cpr) << 3;
-      const size_t off = (size_t)m * a.K + c;
-      const u32x4 hv = ld_global_16(Hin + off);
-      float v[8];
+  for (int j = 0; j < 4; ++j) { e.b0[j] = 0.f; e.b1[j] = 0.f; e.cs[j] = 1.f; e.sn[j] = 0.f; }
+  if constexpr (EPI == VL_SK_BIAS || EPI == VL_SK_BIAS_SILU || EPI == VL_SK_QKV_ROPE || EPI == VL_SK_F32) {
+    const bf16_t* bias = reinterpret_cast<const bf16_t*>(a.bias);
+    if (bias) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { v[2 * j] = bf16lo_to_f32(hv[j]); v[2 * j + 1] = bf16hi_to_f32(hv[j]); }
-      int sp = 0;
-      for (; sp + 4 <= a.n_partials; sp += 4) {
-        f32x4 q[8];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float* pp = a.partials + (size_t)(sp + u) * slab + off;
-          q[2 * u] = *reinterpret_cast<const f32x4*>(pp);
-          q[2 * u + 1] = *reinterpret_cast<const f32x4*>(pp + 4);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { v[j] += q[2 * u][j]; v[4 + j] += q[2 * u + 1][j]; }
-      }
-      for (; sp < a.n_partials; ++sp) {
-        const float* pp = a.partials + (size_t)sp * slab + off;
-        const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] += p0[j]; v[4 + j] += p1[j]; }
-      }
-      u32x4 hr;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) hr[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
-      *reinterpret_cast<u32x4*>(xs + m * p.xs_stride + c * 2) = hr;
-      if (write_h) st_global_16(reinterpret_cast<bf16_t*>(a.h_out) + off, hr);
-    }
-    __syncthreads();
-    for (int m = wave; m < a.M; m += 4) {
-      float ssq = 0.f;
-      for (int c = lane * 8; c < a.K; c += 512) {
-        const u32x4 hr = *reinterpret_cast<const u32x4*>(xs + m * p.xs_stride + c * 2);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const float lo = bf16lo_to_f32(hr[j]), hi = bf16hi_to_f32(hr[j]); ssq += lo * lo + hi * hi; }
-      }
-      ssq = wave_sum(ssq);
-      const float rs = rsqrtf(ssq / (float)a.K + a.eps);
-      for (int c = lane * 8; c < a.K; c += 512) {
-        const u32x4 hr = *reinterpret_cast<const u32x4*>(xs + m * p.xs_stride + c * 2);
-        const u32x4 wv = ld_global_16(Wn + c);
-        u32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float lo = round_bf16(bf16lo_to_f32(hr[j]) * rs) * bf16lo_to_f32(wv[j]);
-          const float hi = round_bf16(bf16hi_to_f32(hr[j]) * rs) * bf16hi_to_f32(wv[j]);
-          o[j] = pack_bf16x2(lo, hi);
-        }
-        *reinterpret_cast<u32x4*>(xs + m * p.xs_stride + c * 2) = o;
+      for (int j = 0; j < 4; ++j) {
+        if (n0 + j < a.n_valid) e.b0[j] = bf16_to_f32(bias[n0 + j]);
+        if (n0 + 16 + j < a.n_valid) e.b1[j] = bf16_to_f32(bias[n0 + 16 + j]);
       }
     }
   }
-  __syncthreads();
-
-  // ------------------------------------------------------------------ main loop
-  for (int s0 = 0; s0 < nsteps; s0 += U) {
-    u32x4 n0[U], n1[U];
-    issue(s0 + U, n0, n1);
+  if constexpr (EPI == VL_SK_QKV_ROPE) {
+    const int pp = n0 & 127, d = ((pp >> 5) << 4) + (pp & 15);
+    const int pos = a.pos_ids[m];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (s0 + u < nsteps) {
-        u32x4 xv = {0, 0, 0, 0};
-        if (mok) xv = *reinterpret_cast<const u32x4*>(xrow + (s0 + u) * 64);
-        const bf16x8 xf = as_bf16x8(xv);
-        acc0 = mfma16(as_bf16x8(r0ok ? c0[u] : u32x4{0, 0, 0, 0}), xf, acc0);
-        acc1 = mfma16(as_bf16x8(r1ok ? c1[u] : u32x4{0, 0, 0, 0}), xf, acc1);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) { c0[u] = n0[u]; c1[u] = n1[u]; }
+    for (int j = 0; j < 4; ++j) { e.cs[j] = a.rope_cos[(size_t)pos * 64 + d + j]; e.sn[j] = a.rope_sin[(size_t)pos * 64 + d + j]; }
   }
+}
 
-  // ------------------------------------------------------------------ in-block split-K reduce
-  if (wave != 0) {
-    float* r = red + ((wave - 1) * 2 * 64 + lane) * 4;
-    *reinterpret_cast<f32x4*>(r) = acc0;
-    *reinterpret_cast<f32x4*>(r + 64 * 4) = acc1;
-  }
-  __syncthreads();
-  if (wave != 0) return;
-#pragma unroll
-  for (int w = 0; w < 3; ++w) {
-    const float* r = red + (w * 2 * 64 + lane) * 4;
-    const f32x4 t0 = *reinterpret_cast<const f32x4*>(r), t1 = *reinterpret_cast<const f32x4*>(r + 64 * 4);
-    acc0 += t0;
-    acc1 += t1;
-  }
-
-  // ------------------------------------------------------------------ epilogue: lane -> row m = fr, n = unit*32 + t*16 + g*4 + j
-  const int m = fr;
-  if (m >= a.M) return;
+template <int EPI>
+__device__ __forceinline__ void skinny_epilogue(const VlaserSkinnyArgs& a, int ks, int unit, int m, int g, f32x4 acc0, f32x4 acc1,
+                                                const EpiOps& e) {
+  // lane -> row m, columns n = unit*32 + t*16 + g*4 + j  (acc0: t = 0, acc1: t = 1); n_valid = un-padded N
   const int n0 = unit * 32 + g * 4;
   if constexpr (EPI == VL_SK_PARTIAL) {
-    float* o = a.out_f32 + ((size_t)ks * a.M + m) * a.N;
-    if (n0 + 3 < a.N) *reinterpret_cast<f32x4*>(o + n0) = acc0;
-    if (n0 + 19 < a.N) *reinterpret_cast<f32x4*>(o + n0 + 16) = acc1;
+    float* o = a.out_f32 + ((size_t)ks * a.M + m) * a.n_valid;
+    if (n0 + 3 < a.n_valid) *reinterpret_cast<f32x4*>(o + n0) = acc0;
+    if (n0 + 19 < a.n_valid) *reinterpret_cast<f32x4*>(o + n0 + 16) = acc1;
   } else if constexpr (EPI == VL_SK_F32) {
-    float* o = a.out_f32 + (size_t)m * a.N;
-    const bf16_t* bias = reinterpret_cast<const bf16_t*>(a.bias);
+    float* o = a.out_f32 + (size_t)m * a.n_valid;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (n0 + j < a.N) o[n0 + j] = acc0[j] + (bias ? bf16_to_f32(bias[n0 + j]) : 0.f);
-      if (n0 + 16 + j < a.N) o[n0 + 16 + j] = acc1[j] + (bias ? bf16_to_f32(bias[n0 + 16 + j]) : 0.f);
+      if (n0 + j < a.n_valid) o[n0 + j] = acc0[j] + e.b0[j];
+      if (n0 + 16 + j < a.n_valid) o[n0 + 16 + j] = acc1[j] + e.b1[j];
     }
   } else if constexpr (EPI == VL_SK_BIAS || EPI == VL_SK_BIAS_SILU) {
-    const bf16_t* bias = reinterpret_cast<const bf16_t*>(a.bias);
     bf16_t* o = reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo;
     float r0[4], r1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      r0[j] = acc0[j] + bf16_to_f32(bias[n0 + j]);
-      r1[j] = acc1[j] + bf16_to_f32(bias[n0 + 16 + j]);
+      r0[j] = acc0[j] + e.b0[j];
+      r1[j] = acc1[j] + e.b1[j];
       if constexpr (EPI == VL_SK_BIAS_SILU) { r0[j] = silu(round_bf16(r0[j])); r1[j] = silu(round_bf16(r1[j])); }
     }
     *reinterpret_cast<u32x2*>(o + n0) = u32x2{pack_bf16x2(r0[0], r0[1]), pack_bf16x2(r0[2], r0[3])};
@@ -207,13 +99,11 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyP p) {
     // packed rows: n = head*128 + 32*j + 16*half + r ; acc0 = half 0 (d = 16*j + r), acc1 = half 1 (d + 64)
     const int head = n0 >> 7, pp = n0 & 127;
     const int d = ((pp >> 5) << 4) + (pp & 15);
-    const int pos = a.pos_ids[m];
-    const bf16_t* bias = reinterpret_cast<const bf16_t*>(a.bias);
     float x1[4], x2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      x1[j] = round_bf16(acc0[j] + bf16_to_f32(bias[n0 + j]));
-      x2[j] = round_bf16(acc1[j] + bf16_to_f32(bias[n0 + 16 + j]));
+      x1[j] = round_bf16(acc0[j] + e.b0[j]);
+      x2[j] = round_bf16(acc1[j] + e.b1[j]);
     }
     const int b = m / a.tok_per_batch;
     const int slot = a.slot_base + (m - b * a.tok_per_batch);
@@ -222,9 +112,8 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyP p) {
       float o1[4], o2[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float c = a.rope_cos[(size_t)pos * 64 + d + j], s = a.rope_sin[(size_t)pos * 64 + d + j];
-        o1[j] = x1[j] * c - x2[j] * s;
-        o2[j] = x2[j] * c + x1[j] * s;
+        o1[j] = x1[j] * e.cs[j] - x2[j] * e.sn[j];
+        o2[j] = x2[j] * e.cs[j] + x1[j] * e.sn[j];
       }
       bf16_t* dst = head < nq ? reinterpret_cast<bf16_t*>(a.q_out) + (size_t)m * nq * 128 + head * 128
                               : reinterpret_cast<bf16_t*>(a.k_cache) + (((size_t)b * nkv + (head - nq)) * a.s_max + slot) * 128;
@@ -242,42 +131,255 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyP p) {
 }
 
 template <int PRO, int EPI>
+__global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const VlaserSkinnyArgs& a = p.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int ks = blockIdx.y;
+  // balanced run of units for this block
+  const int n_units = a.N >> 5;
+  const int ulo = n_units / (int)gridDim.x, urem = n_units % (int)gridDim.x;
+  const int ucount = ulo + ((int)blockIdx.x < urem ? 1 : 0);
+  const int ustart = (int)blockIdx.x * ulo + min((int)blockIdx.x, urem);
+  const int kb0 = ks * p.kb;                  // first k of this block
+  char* xs = smem;                            // [M][xs_stride] activations (bf16)
+  const int xs_bytes = (a.M * p.xs_stride + 15) & ~15;
+  float* red = reinterpret_cast<float*>(smem + xs_bytes);                 // [2][SKW-1][2][64][4] fp32 (double-buffered per unit)
+  char* wn_lds = smem + xs_bytes + 2 * (SKW - 1) * 2 * 64 * 16;           // [K] bf16 norm weight (NORM prologue)
+
+  // ------------------------------------------------------------------ weight stream (fragment-major packed weights)
+  const int kw = p.kb / SKW;                  // K per wave (multiple of 32)
+  const int kl0 = wave * kw;                  // block-local k start
+  const int nsteps = kw >> 5;
+  const int nbatch = (nsteps + SKU - 1) / SKU;            // batches per unit
+  const int total = ucount * nbatch;
+  // 16-byte index of (ks, unit u, wave, step s, tile t, lane) = ((((ks*n_units + u)*SKW + wave)*nsteps + s)*2 + t)*64 + lane
+  const u32x4* wp = reinterpret_cast<const u32x4*>(a.W) + lane;
+  const size_t wave_base = ((size_t)ks * n_units * SKW + wave) * nsteps * 128;
+  const size_t unit_stride = (size_t)SKW * nsteps * 128;
+  u32x4 cw[2 * SKU], nw[2 * SKU];
+  EpiOps ce, ne;
+  const int m = fr;
+  auto issue = [&](int bi, u32x4* dst, EpiOps& e) {
+    const int ui = bi / nbatch, j = bi - ui * nbatch;
+    const u32x4* src = wp + wave_base + (size_t)(ustart + ui) * unit_stride + (size_t)j * SKU * 128;
+    const int ns = min(SKU, nsteps - j * SKU);
+#pragma unroll
+    for (int u = 0; u < SKU; ++u)
+      if (u < ns) {
+        dst[2 * u] = __builtin_nontemporal_load(src + u * 128);
+        dst[2 * u + 1] = __builtin_nontemporal_load(src + u * 128 + 64);
+      }
+    if (wave == 0 && j == 0 && m < a.M) load_epi<EPI>(a, ustart + ui, m, g, e);
+  };
+  issue(0, cw, ce);
+
+  // ------------------------------------------------------------------ prologue: activations -> LDS (bf16)
+  if constexpr (PRO == VL_PRO_PLAIN) {
+    const bf16_t* X = reinterpret_cast<const bf16_t*>(a.x);
+    const int chunks_per_row = p.kb >> 3;
+    for (int c = tid; c < a.M * chunks_per_row; c += SKT) {
+      const int mm = c / chunks_per_row, j = c - mm * chunks_per_row;
+      *reinterpret_cast<u32x4*>(xs + mm * p.xs_stride + j * 16) = ld_global_16(X + (size_t)mm * a.K + kb0 + j * 8);
+    }
+  } else if constexpr (PRO == VL_PRO_ATTN) {
+    // x[m][k] (k = h*128 + d) = flash-decoding merge of the attention partials of vlaser_attn_skinny
+    const int chunks_per_row = p.kb >> 3, G = a.attn_group, nq = a.attn_nq, S = a.attn_splits;
+    const int nkv = a.K / (128 * G);
+    for (int c = tid; c < a.M * chunks_per_row; c += SKT) {
+      const int mm = c / chunks_per_row, j = c - mm * chunks_per_row;
+      const int k = kb0 + j * 8, h = k >> 7, d = k & 127;
+      const int b = mm / nq, tok = mm - b * nq, kvh = h / G, hg = h - kvh * G, r = hg * nq + tok;
+      const size_t pbase = ((size_t)b * nkv + kvh) * S;
+      float ms[8], ls[8];
+      f32x4 o0[8], o1[8];
+#pragma unroll
+      for (int sp = 0; sp < 8; ++sp) {
+        const int sc = min(sp, S - 1);
+        ms[sp] = a.attn_m[(pbase + sc) * 32 + r];
+        ls[sp] = a.attn_l[(pbase + sc) * 32 + r];
+        const float* po = a.attn_o + ((pbase + sc) * 32 + r) * 128 + d;
+        o0[sp] = *reinterpret_cast<const f32x4*>(po);
+        o1[sp] = *reinterpret_cast<const f32x4*>(po + 4);
+      }
+      float Mx = -1.0e30f;
+#pragma unroll
+      for (int sp = 0; sp < 8; ++sp) Mx = fmaxf(Mx, ms[sp]);
+      float Ls = 0.f, v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int sp = 0; sp < 8; ++sp) {
+        const float f = sp < S ? __builtin_amdgcn_exp2f(ms[sp] - Mx) : 0.f;
+        Ls += ls[sp] * f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] += o0[sp][q] * f; v[4 + q] += o1[sp][q] * f; }
+      }
+      const float inv = Ls > 0.f ? 1.0f / Ls : 0.f;
+      u32x4 xr;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xr[q] = pack_bf16x2(v[2 * q] * inv, v[2 * q + 1] * inv);
+      *reinterpret_cast<u32x4*>(xs + mm * p.xs_stride + j * 16) = xr;
+    }
+  } else {
+    // h = bf16(h_in + sum partials); xn = bf16(w * bf16(h * rsqrt(mean(h^2) + eps)))
+    // Phase 1 (all threads, one 16-byte chunk each per pass): residual chunk + norm-weight chunk + every slab of the
+    // chunk are requested together; the rounded residual goes to LDS (and to h_out from block 0).
+    // Phase 2 (one wave per row, LDS only): sum of squares, normalise in place.
+    const bf16_t* Hin = reinterpret_cast<const bf16_t*>(a.x);
+    const bf16_t* Wn = reinterpret_cast<const bf16_t*>(a.norm_w);
+    const bool write_h = (a.h_out != nullptr) && blockIdx.x == 0 && ks == 0;
+    const int cpr = a.K >> 3;  // chunks per row
+    const size_t slab = (size_t)a.M * a.K;
+    for (int ch = tid; ch < a.M * cpr; ch += SKT) {
+      const int mm = ch / cpr, c = (ch - mm * cpr) << 3;
+      const size_t off = (size_t)mm * a.K + c;
+      const u32x4 hv = ld_global_16(Hin + off);
+      u32x4 wv = {0, 0, 0, 0};
+      if (mm == 0) wv = ld_global_16(Wn + c);
+      float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (a.n_partials > 0) {
+        const float* pb = a.partials + off;
+        int S = a.n_partials;
+        if (S <= 4) add_slabs_clamped<4>(v, pb, slab, S);
+        else {
+          for (; S > 8; S -= 8, pb += 8 * slab) add_slabs_clamped<8>(v, pb, slab, 8);
+          add_slabs_clamped<8>(v, pb, slab, S);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[2 * j] += bf16lo_to_f32(hv[j]); v[2 * j + 1] += bf16hi_to_f32(hv[j]); }
+      u32x4 hr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hr[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+      *reinterpret_cast<u32x4*>(xs + mm * p.xs_stride + c * 2) = hr;
+      if (mm == 0) *reinterpret_cast<u32x4*>(wn_lds + c * 2) = wv;
+      if (write_h) st_global_16(reinterpret_cast<bf16_t*>(a.h_out) + off, hr);
+    }
+    __syncthreads();
+    for (int mm = wave; mm < a.M; mm += SKW) {
+      float ssq = 0.f;
+      for (int c = lane * 8; c < a.K; c += 512) {
+        const u32x4 hr = *reinterpret_cast<const u32x4*>(xs + mm * p.xs_stride + c * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float lo = bf16lo_to_f32(hr[j]), hi = bf16hi_to_f32(hr[j]); ssq += lo * lo + hi * hi; }
+      }
+      ssq = wave_sum(ssq);
+      const float rs = rsqrtf(ssq / (float)a.K + a.eps);
+      for (int c = lane * 8; c < a.K; c += 512) {
+        const u32x4 hr = *reinterpret_cast<const u32x4*>(xs + mm * p.xs_stride + c * 2);
+        const u32x4 wv = *reinterpret_cast<const u32x4*>(wn_lds + c * 2);
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = round_bf16(bf16lo_to_f32(hr[j]) * rs) * bf16lo_to_f32(wv[j]);
+          const float hi = round_bf16(bf16hi_to_f32(hr[j]) * rs) * bf16hi_to_f32(wv[j]);
+          o[j] = pack_bf16x2(lo, hi);
+        }
+        *reinterpret_cast<u32x4*>(xs + mm * p.xs_stride + c * 2) = o;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ main loop: ONE copy of K-loop / reduce / epilogue
+  const char* xrow = xs + (fr < a.M ? fr : 0) * p.xs_stride + (kl0 + g * 8) * 2;
+  const bool mok = fr < a.M;
+  f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  int par = 0;
+  for (int bi = 0; bi < total; ++bi) {
+    const int ui = bi / nbatch, j = bi - ui * nbatch;
+    if (bi + 1 < total) issue(bi + 1, nw, ne);       // next batch's fragments (and epilogue operands) in flight
+    const int ns = min(SKU, nsteps - j * SKU);
+#pragma unroll
+    for (int u = 0; u < SKU; ++u)
+      if (u < ns) {
+        u32x4 xv = {0, 0, 0, 0};
+        if (mok) xv = *reinterpret_cast<const u32x4*>(xrow + (j * SKU + u) * 64);
+        const bf16x8 xf = as_bf16x8(xv);
+        acc0 = mfma16(as_bf16x8(cw[2 * u]), xf, acc0);
+        acc1 = mfma16(as_bf16x8(cw[2 * u + 1]), xf, acc1);
+      }
+    if (j == nbatch - 1) {
+      // in-block split-K reduce + epilogue of unit (ustart + ui); `red` is double-buffered by unit parity
+      float* rb = red + par * (SKW - 1) * 2 * 64 * 4;
+      if (wave != 0) {
+        float* r = rb + ((wave - 1) * 2 * 64 + lane) * 4;
+        *reinterpret_cast<f32x4*>(r) = acc0;
+        *reinterpret_cast<f32x4*>(r + 64 * 4) = acc1;
+      }
+      __syncthreads();
+      par ^= 1;
+      if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < SKW - 1; ++w) {
+          const float* r = rb + (w * 2 * 64 + lane) * 4;
+          acc0 += *reinterpret_cast<const f32x4*>(r);
+          acc1 += *reinterpret_cast<const f32x4*>(r + 64 * 4);
+        }
+        if (m < a.M) skinny_epilogue<EPI>(a, ks, ustart + ui, m, g, acc0, acc1, ce);
+      }
+      acc0 = f32x4{0, 0, 0, 0};
+      acc1 = f32x4{0, 0, 0, 0};
+    }
+    if (bi + 1 < total) {
+#pragma unroll
+      for (int u = 0; u < 2 * SKU; ++u) cw[u] = nw[u];
+      if (j == nbatch - 1) ce = ne;
+    }
+  }
+}
+
+template <int PRO, int EPI>
 static int launch(const VlaserSkinnyArgs* a, hipStream_t stream) {
   SkinnyP p;
   p.a = *a;
+  if (p.a.n_valid <= 0) p.a.n_valid = a->N;
   p.kb = a->K / a->k_splits;
   p.xs_stride = p.kb * 2 + 16;
-  const int lds = ((a->M * p.xs_stride + 15) & ~15) + 3 * 2 * 64 * 4 * 4;
+  const int lds = ((a->M * p.xs_stride + 15) & ~15) + 2 * (SKW - 1) * 2 * 64 * 16 + (PRO == VL_PRO_NORM ? a->K * 2 : 0);
+  const int n_units = a->N / 32;
+  int gx = 256 / a->k_splits;            // <= one block per CU (256 CUs)
+  if (gx > n_units) gx = n_units;
+  if (gx < 1) gx = 1;
   static int attr_lds = 0;
   if (lds > attr_lds) {
     VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel<PRO, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_lds = lds;
   }
-  hipLaunchKernelGGL((skinny_kernel<PRO, EPI>), dim3((a->N + 31) / 32, a->k_splits), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((skinny_kernel<PRO, EPI>), dim3(gx, a->k_splits), dim3(SKT), lds, stream, p);
   VL_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int vlaser_skinny(int pro, int epi, const VlaserSkinnyArgs* a, vl_stream_t s) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(s);
-  VL_CHECK(a && a->x && a->W, "vlaser_skinny: null operand");
+  VL_CHECK(a && a->W && (a->x || pro == VL_PRO_ATTN), "vlaser_skinny: null operand");
+  if (pro == VL_PRO_ATTN)
+    VL_CHECK(a->attn_m && a->attn_l && a->attn_o && a->attn_splits >= 1 && a->attn_splits <= 8 && a->attn_group >= 1 && a->attn_nq >= 1 &&
+                 a->K % (128 * a->attn_group) == 0,
+             "vlaser_skinny: bad attention-merge arguments");
   VL_CHECK(a->M >= 1 && a->M <= 16, "vlaser_skinny: M=%d must be in 1..16", a->M);
-  VL_CHECK(a->k_splits >= 1 && a->K % (a->k_splits * 128) == 0, "vlaser_skinny: K=%d not divisible by k_splits*128 (k_splits=%d)", a->K, a->k_splits);
-  VL_CHECK(a->ldw % 8 == 0 && ((uintptr_t)a->W & 15) == 0 && ((uintptr_t)a->x & 15) == 0, "vlaser_skinny: alignment");
-  VL_CHECK((size_t)a->M * (a->K / a->k_splits * 2 + 16) <= 150000, "vlaser_skinny: activation tile does not fit in LDS");
+  VL_CHECK(a->k_splits >= 1 && a->K % (a->k_splits * 32 * SKW) == 0, "vlaser_skinny: K=%d not divisible by k_splits*%d (k_splits=%d)", a->K,
+           32 * SKW, a->k_splits);
+  VL_CHECK(a->N % 32 == 0, "vlaser_skinny: N=%d must be a multiple of 32 (pack_skinny pads the weight rows; pass n_valid)", a->N);
+  VL_CHECK(a->n_valid <= a->N && (a->n_valid <= 0 || a->n_valid > a->N - 32), "vlaser_skinny: n_valid must lie in the last unit");
+  VL_CHECK(((uintptr_t)a->W & 15) == 0 && ((uintptr_t)a->x & 15) == 0, "vlaser_skinny: alignment");
+  VL_CHECK((size_t)a->M * (a->K / a->k_splits * 2 + 16) <= 120000, "vlaser_skinny: activation tile does not fit in LDS");
   if (pro == VL_PRO_NORM) {
     VL_CHECK(a->norm_w && a->k_splits == 1, "vlaser_skinny: NORM prologue needs norm_w and k_splits == 1");
     VL_CHECK(a->n_partials == 0 || a->partials, "vlaser_skinny: partials null");
   }
-  if (epi != VL_SK_F32 && epi != VL_SK_PARTIAL) VL_CHECK(a->N % 32 == 0, "vlaser_skinny: N must be a multiple of 32 for this epilogue");
-  if (epi == VL_SK_PARTIAL) VL_CHECK(a->N % 4 == 0 && a->out_f32, "vlaser_skinny: partial needs N%%4==0 and out_f32");
+  if (epi == VL_SK_PARTIAL) VL_CHECK(a->out_f32 && (a->n_valid <= 0 || a->n_valid % 4 == 0), "vlaser_skinny: partial needs out_f32 and n_valid %% 4 == 0");
   if (epi != VL_SK_PARTIAL) VL_CHECK(a->k_splits == 1, "vlaser_skinny: only VL_SK_PARTIAL may split K across blocks");
+  if (epi != VL_SK_F32 && epi != VL_SK_PARTIAL) VL_CHECK(a->n_valid <= 0 || a->n_valid == a->N, "vlaser_skinny: only F32/PARTIAL epilogues support a padded N");
+  if (epi == VL_SK_BIAS || epi == VL_SK_BIAS_SILU || epi == VL_SK_QKV_ROPE) VL_CHECK(a->bias, "vlaser_skinny: bias null");
 #define SK_CASE(P, E)                                   \
   if (pro == P && epi == E) return launch<P, E>(a, stream);
   SK_CASE(VL_PRO_PLAIN, VL_SK_PARTIAL)
   SK_CASE(VL_PRO_PLAIN, VL_SK_BIAS)
   SK_CASE(VL_PRO_PLAIN, VL_SK_BIAS_SILU)
   SK_CASE(VL_PRO_PLAIN, VL_SK_F32)
+  SK_CASE(VL_PRO_ATTN, VL_SK_PARTIAL)
   SK_CASE(VL_PRO_NORM, VL_SK_QKV_ROPE)
   SK_CASE(VL_PRO_NORM, VL_SK_SWIGLU)
   SK_CASE(VL_PRO_NORM, VL_SK_F32)

@@ -23,34 +23,44 @@ def _dev(t, device):
 
 
 class QwenLayerWeights:
-    """One Qwen2DecoderLayer in kernel layout."""
+    """One Qwen2DecoderLayer in kernel layout: row-major packed matrices for the MFMA GEMM (prefill) and/or
+    fragment-major copies for the weight-streaming skinny kernel (decode / action tokens)."""
 
-    def __init__(self, sd, p, llm: LLMConfig, device):
+    def __init__(self, sd, p, llm: LLMConfig, device, ks_o, ks_down, gemm=True, skinny=True):
         g = lambda k: _dev(sd[p + k], device)
-        self.wqkv, self.bqkv = ops.pack_qkv(g('self_attn.q_proj.weight'), g('self_attn.k_proj.weight'),
-                                            g('self_attn.v_proj.weight'), g('self_attn.q_proj.bias'),
-                                            g('self_attn.k_proj.bias'), g('self_attn.v_proj.bias'), llm.head_dim)
-        self.wo = g('self_attn.o_proj.weight')
-        self.wgu = ops.pack_gate_up(g('mlp.gate_proj.weight'), g('mlp.up_proj.weight'))
-        self.wdown = g('mlp.down_proj.weight')
+        wqkv, self.bqkv = ops.pack_qkv(g('self_attn.q_proj.weight'), g('self_attn.k_proj.weight'),
+                                       g('self_attn.v_proj.weight'), g('self_attn.q_proj.bias'),
+                                       g('self_attn.k_proj.bias'), g('self_attn.v_proj.bias'), llm.head_dim)
+        wo = g('self_attn.o_proj.weight')
+        wgu = ops.pack_gate_up(g('mlp.gate_proj.weight'), g('mlp.up_proj.weight'))
+        wdown = g('mlp.down_proj.weight')
         self.ln_in = g('input_layernorm.weight')
         self.ln_post = g('post_attention_layernorm.weight')
+        if gemm:
+            self.wqkv, self.wo, self.wgu, self.wdown = wqkv, wo, wgu, wdown
+        if skinny:
+            self.sk_qkv = ops.pack_skinny(wqkv, 1)
+            self.sk_o = ops.pack_skinny(wo, ks_o)
+            self.sk_gu = ops.pack_skinny(wgu, 1)
+            self.sk_down = ops.pack_skinny(wdown, ks_down)
 
 
 class QwenStack:
     """Weights + geometry of one Qwen2 decoder stack (the VLM LLM or the action expert)."""
 
-    def __init__(self, sd, prefix, llm: LLMConfig, device, with_embed=True, with_head=True):
+    def __init__(self, sd, prefix, llm: LLMConfig, device, with_embed=True, with_head=True, gemm=True, skinny=True):
         self.llm = llm
-        self.layers = [QwenLayerWeights(sd, f'{prefix}model.layers.{i}.', llm, device) for i in range(llm.num_hidden_layers)]
-        self.norm = _dev(sd[prefix + 'model.norm.weight'], device)
-        self.embed = _dev(sd[prefix + 'model.embed_tokens.weight'], device) if with_embed else None
-        self.head = _dev(sd[prefix + 'lm_head.weight'], device) if with_head and (prefix + 'lm_head.weight') in sd else None
         H, I = llm.hidden_size, llm.intermediate_size
         nqd = llm.num_attention_heads * llm.head_dim
         self.ks_o = ops.pick_k_splits(nqd, H)
         self.ks_down = ops.pick_k_splits(I, H)
         self.nqd = nqd
+        self.layers = [QwenLayerWeights(sd, f'{prefix}model.layers.{i}.', llm, device, self.ks_o, self.ks_down, gemm, skinny)
+                       for i in range(llm.num_hidden_layers)]
+        self.norm = _dev(sd[prefix + 'model.norm.weight'], device)
+        self.embed = _dev(sd[prefix + 'model.embed_tokens.weight'], device) if with_embed else None
+        self.head = _dev(sd[prefix + 'lm_head.weight'], device) if with_head and (prefix + 'lm_head.weight') in sd else None
+        self.sk_head = ops.pack_skinny(self.head, 1) if (self.head is not None and skinny) else None
 
     @property
     def nq(self):
@@ -241,6 +251,7 @@ class SkinnyBuffers:
         self.q = z(max_rows, stack.nq * llm.head_dim)
         self.ao = z(max_rows, stack.nq * llm.head_dim)
         self.act = z(max_rows, I)
+        self.attn_parts = ops.attn_partial_buffers(max_rows, stack.nkv, device)
         self.part_o = torch.zeros(stack.ks_o, max_rows, H, dtype=torch.float32, device=device)
         self.part_d = torch.zeros(stack.ks_down, max_rows, H, dtype=torch.float32, device=device)
 
@@ -254,18 +265,21 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
     M = batch * tok_per_batch
     nq, nkv, hd = stack.nq, stack.nkv, llm.head_dim
     H = llm.hidden_size
-    ops.skinny(L.PRO_NORM, L.SK_QKV_ROPE, h_in, lw.wqkv, M, partials=partials, n_partials=n_partials, norm_w=lw.ln_in,
+    ops.skinny(L.PRO_NORM, L.SK_QKV_ROPE, h_in, lw.sk_qkv, M, partials=partials, n_partials=n_partials, norm_w=lw.ln_in,
                eps=llm.rms_norm_eps, h_out=sb.hA, bias=lw.bqkv, q_out=sb.q, k_cache=cache.k[layer], vt_cache=cache.vt[layer],
                rope_cos=rope[0], rope_sin=rope[1], pos_ids=pos_ids, n_q_heads=nq, n_kv_heads=nkv, s_max=cache.s_max,
                tok_per_batch=tok_per_batch, slot_base=slot_base)
     ks, vs = cache.strides()
-    ops.attn_skinny(sb.q, cache.k[layer], cache.vt[layer], sb.ao, batch, tok_per_batch, kv_len, nq, nkv, hd,
-                    (tok_per_batch * nq * hd, hd, nq * hd), ks, vs, (tok_per_batch * nq * hd, nq * hd), cache.s_max, hd ** -0.5,
-                    attn_mode, valid_len=valid_len, blk_start=blk_start)
+    nsp = ops.attn_splits(kv_len)
+    ops.attn_skinny(sb.q, cache.k[layer], cache.vt[layer], sb.attn_parts, batch, tok_per_batch, kv_len, nq, nkv, hd,
+                    (tok_per_batch * nq * hd, hd, nq * hd), ks, vs, cache.s_max, hd ** -0.5, attn_mode, nsp, valid_len=valid_len,
+                    blk_start=blk_start)
     if skip_post_attn:
         return sb.hA, None, 0
-    ops.skinny(L.PRO_PLAIN, L.SK_PARTIAL, sb.ao, lw.wo, M, k_splits=stack.ks_o, out_f32=sb.part_o)
-    ops.skinny(L.PRO_NORM, L.SK_SWIGLU, sb.hA, lw.wgu, M, partials=sb.part_o, n_partials=stack.ks_o, norm_w=lw.ln_post,
+    # o_proj: the prologue merges the attention split partials (flash-decoding) straight into its activation tile
+    ops.skinny(L.PRO_ATTN, L.SK_PARTIAL, None, lw.sk_o, M, out_f32=sb.part_o, attn_m=sb.attn_parts[0],
+               attn_l=sb.attn_parts[1], attn_o=sb.attn_parts[2], attn_splits=nsp, attn_group=nq // nkv, attn_nq=tok_per_batch)
+    ops.skinny(L.PRO_NORM, L.SK_SWIGLU, sb.hA, lw.sk_gu, M, partials=sb.part_o, n_partials=stack.ks_o, norm_w=lw.ln_post,
                eps=llm.rms_norm_eps, h_out=sb.hB, out=sb.act, ldo=llm.intermediate_size)
-    ops.skinny(L.PRO_PLAIN, L.SK_PARTIAL, sb.act, lw.wdown, M, k_splits=stack.ks_down, out_f32=sb.part_d)
+    ops.skinny(L.PRO_PLAIN, L.SK_PARTIAL, sb.act, lw.sk_down, M, out_f32=sb.part_d)
     return sb.hB, sb.part_d, stack.ks_down

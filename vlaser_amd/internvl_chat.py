@@ -123,7 +123,7 @@ class InternVLChatModel:
     def _head_last(self, h_last, partials, n_partials, M, greedy=True):
         """final RMSNorm + lm_head on M rows -> fp32 logits (+ argmax and next-token embedding gather)."""
         llm = self.config.llm
-        ops.skinny(L.PRO_NORM, L.SK_F32, h_last, self.llm.head, M, partials=partials, n_partials=n_partials, norm_w=self.llm.norm,
+        ops.skinny(L.PRO_NORM, L.SK_F32, h_last, self.llm.sk_head, M, partials=partials, n_partials=n_partials, norm_w=self.llm.norm,
                    eps=llm.rms_norm_eps, out_f32=self.logits)
         if greedy:
             ops.argmax(self.logits[:M], self.next_ids, self.llm.embed, self.next_h)

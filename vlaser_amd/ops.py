@@ -89,9 +89,9 @@ def linear(x, W, bias=None, epi=None, res=None, ls=None, out=None, out_dtype=BF1
 
 # ------------------------------------------------------------------------------------------------ attention
 def _attn_args(q, k, vt, out, batch, sq, kv_len, n_q, n_kv, hd, q_str, k_str, vt_str, o_str, ld_vt, scale, mode,
-               causal_off=0, valid_len=None, blk_start=0, q_row_off=0):
+               causal_off=0, valid_len=None, blk_start=0, q_row_off=0, parts=None, n_splits=1):
     a = L.AttnArgs()
-    a.q, a.k, a.vt, a.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
+    a.q, a.k, a.vt, a.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), _p(out)
     a.batch, a.sq, a.kv_len, a.n_q_heads, a.n_kv_heads, a.head_dim = batch, sq, kv_len, n_q, n_kv, hd
     a.q_bs, a.q_hs, a.q_ss = q_str
     a.k_bs, a.k_hs = k_str
@@ -100,6 +100,9 @@ def _attn_args(q, k, vt, out, batch, sq, kv_len, n_q, n_kv, hd, q_str, k_str, vt
     a.ld_vt, a.scale, a.mode, a.causal_off = ld_vt, scale, mode, causal_off
     a.valid_len = _p(valid_len)
     a.blk_start, a.q_row_off = blk_start, q_row_off
+    if parts is not None:
+        a.part_m, a.part_l, a.part_o = parts[0].data_ptr(), parts[1].data_ptr(), parts[2].data_ptr()
+    a.n_splits = n_splits
     return a
 
 
@@ -108,30 +111,67 @@ def attn_prefill(*args, **kw):
     L.check(L.lib().vlaser_attn_prefill(C.byref(a), _stream()), 'vlaser_attn_prefill')
 
 
-def attn_skinny(*args, **kw):
-    a = _attn_args(*args, **kw)
+def attn_splits(kv_len):
+    """Key splits of the skinny attention: about 4 chunks (of 32 keys) per block, at most 8 splits."""
+    return max(1, min(8, (((kv_len + 31) // 32) + 3) // 4))
+
+
+def attn_skinny(q, k, vt, parts, batch, sq, kv_len, n_q, n_kv, hd, q_str, k_str, vt_str, ld_vt, scale, mode, n_splits, **kw):
+    """Writes flash-decoding partials (m, l, o) per (b, kv head, split) into `parts`; merged by skinny(PRO_ATTN)."""
+    a = _attn_args(q, k, vt, None, batch, sq, kv_len, n_q, n_kv, hd, q_str, k_str, vt_str, (0, 0), ld_vt, scale, mode, parts=parts,
+                   n_splits=n_splits, **kw)
     L.check(L.lib().vlaser_attn_skinny(C.byref(a), _stream()), 'vlaser_attn_skinny')
 
 
+def attn_partial_buffers(batch, n_kv, device, max_splits=8):
+    z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
+    return z(batch, n_kv, max_splits, 32), z(batch, n_kv, max_splits, 32), z(batch, n_kv, max_splits, 32, 128)
+
+
 # ------------------------------------------------------------------------------------------------ skinny GEMV
-def skinny(pro, epi, x, W, M, N=None, K=None, k_splits=1, **kw):
+class PackedW:
+    """Weight [N,K] packed for the skinny kernel: fragment-major [k_splits][N/32][8 waves][steps][2 tiles][64 lanes][8]."""
+    __slots__ = ('t', 'N', 'n_valid', 'K', 'k_splits')
+
+    def __init__(self, t, N, n_valid, K, k_splits):
+        self.t, self.N, self.n_valid, self.K, self.k_splits = t, N, n_valid, K, k_splits
+
+
+SK_WAVES = 8
+
+
+def pack_skinny(W, k_splits=1):
+    """Row-major [N,K] bf16 -> PackedW.  Lane (r = l&15, g = l>>4) of wave w, K-step s, tile t of unit u, split ks holds
+    W[u*32 + t*16 + r, ks*kb + w*kw + s*32 + g*8 : +8]; each wave-level load is a contiguous 1 KiB."""
+    N, K = W.shape
+    assert K % (k_splits * 32 * SK_WAVES) == 0, (K, k_splits)
+    Np = (N + 31) // 32 * 32
+    if Np != N:
+        W = torch.cat([W, torch.zeros(Np - N, K, dtype=W.dtype, device=W.device)], 0)
+    ns = K // (k_splits * SK_WAVES * 32)
+    v = W.view(Np // 32, 2, 16, k_splits, SK_WAVES, ns, 4, 8)          # [u, t, r, ks, w, s, g, e]
+    v = v.permute(3, 0, 4, 5, 1, 6, 2, 7).contiguous()                 # [ks, u, w, s, t, g, r, e]
+    return PackedW(v.reshape(-1), Np, N, K, k_splits)
+
+
+def skinny(pro, epi, x, W: PackedW, M, **kw):
     a = L.SkinnyArgs()
-    a.x, a.W = x.data_ptr(), W.data_ptr()
-    a.M, a.N, a.K, a.ldw = M, (W.shape[0] if N is None else N), (W.shape[1] if K is None else K), W.stride(0)
-    a.k_splits = k_splits
+    a.x, a.W = _p(x), W.t.data_ptr()
+    a.M, a.N, a.K, a.ldw, a.n_valid = M, W.N, W.K, W.K, W.n_valid
+    a.k_splits = W.k_splits
     a.eps = kw.pop('eps', 1e-6)
     for k, v in kw.items():
         setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
     L.check(L.lib().vlaser_skinny(pro, epi, C.byref(a), _stream()), 'vlaser_skinny')
 
 
-def pick_k_splits(K, N, target_blocks=256):
-    """Smallest cross-block split-K factor that (a) keeps K/k_splits a multiple of 128 and (b) gives about one
-    block per CU (units = N/32)."""
+def pick_k_splits(K, N, target_blocks=160):
+    """Smallest cross-block split-K factor that (a) keeps K/k_splits a multiple of 256 (8 waves x 32) and (b) gives
+    about one block per CU (units = N/32)."""
     units = (N + 31) // 32
     best = 1
-    for s in range(1, 65):
-        if K % (s * 128):
+    for s in range(1, 9):            # <= 8 slabs: the consumer's prologue sums them in ONE batch of loads
+        if K % (s * 256):
             continue
         best = s
         if units * s >= target_blocks:

@@ -81,12 +81,12 @@ class PiZero:
         cfg, dev = self.cfg, self.device
         base = cfg.base
         self.vit = VitEngine(sd, base, dev, max_tiles=self.max_batch * self.num_images)
-        self.vlm = QwenStack(sd, 'language_model.', base.llm, dev, with_embed=True, with_head=False)
-        self.expert = QwenStack(sd, 'action_expert.', cfg.expert, dev, with_embed=False, with_head=False)
+        self.vlm = QwenStack(sd, 'language_model.', base.llm, dev, with_embed=True, with_head=False, gemm=True, skinny=False)
+        self.expert = QwenStack(sd, 'action_expert.', cfg.expert, dev, with_embed=False, with_head=False, gemm=False, skinny=True)
         g = lambda k: sd[k].to(device=dev, dtype=BF).contiguous()
         self.ae_w1, self.ae_b1 = g('action_encoder.linear_1.weight'), g('action_encoder.linear_1.bias')
-        self.ae_w2, self.ae_b2 = g('action_encoder.linear_2.weight'), g('action_encoder.linear_2.bias')
-        self.ae_w3, self.ae_b3 = g('action_encoder.linear_3.weight'), g('action_encoder.linear_3.bias')
+        self.ae_w2, self.ae_b2 = ops.pack_skinny(g('action_encoder.linear_2.weight')), g('action_encoder.linear_2.bias')
+        self.ae_w3, self.ae_b3 = ops.pack_skinny(g('action_encoder.linear_3.weight')), g('action_encoder.linear_3.bias')
         self.pe_w, self.pe_b = g('proprio_encoder.weight'), g('proprio_encoder.bias')
         self.ad_w, self.ad_b = g('action_decoder.weight'), g('action_decoder.bias')
         self._alloc()
