@@ -121,9 +121,10 @@ typedef struct {
   const void* norm_w;     /* NORM: bf16 [K] */
   float eps;
   void* h_out;            /* NORM: bf16 [M,K] = bf16(h_in + sum partials), written by block 0 (may be null) */
-  const void* W;          /* bf16, FRAGMENT-MAJOR packed [k_splits][N/32][8 waves][K/(k_splits*256)][2][64][8] (ops.pack_skinny) */
+  const void* W;          /* bf16, FRAGMENT-MAJOR packed [k_splits][N/(16 T)][8 waves][K/(k_splits*256)][T tiles][64][8], T = tiles_per_unit (ops.pack_skinny) */
   int M, N, K, ldw;       /* N = padded row count (multiple of 32); ldw unused */
   int n_valid;            /* un-padded N (0 = N): logits / partial row length */
+  int tiles_per_unit;     /* 0/2: units of 32 rows; 6: units of 96 rows (packing must match) */
   int k_splits;           /* grid.y; K % (k_splits*256) == 0 */
   float* out_f32;
   void* out; int ldo;
@@ -134,6 +135,7 @@ typedef struct {
   int n_q_heads, n_kv_heads, s_max, tok_per_batch, slot_base;
   /* VL_PRO_ATTN: x[m = b*nq+tok][h*128+d] = sum_s o_s e^(m_s-M) / sum_s l_s e^(m_s-M) */
   const float* attn_m; const float* attn_l; const float* attn_o; int attn_splits, attn_group, attn_nq;
+  unsigned long long* dbg; /* optional: per-block timestamps [grid][8] (wall_clock64, 100 MHz) for kernel tuning */
 } VlaserSkinnyArgs;
 
 int vlaser_skinny(int prologue, int epi, const VlaserSkinnyArgs* args, vl_stream_t stream);

@@ -233,7 +233,7 @@ def _rms_ref(h, w, eps=1e-6):
     return (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + eps)).to(BF).float() * w.float()
 
 
-@pytest.mark.parametrize('M,N,K,ks', [(4, 768, 1536, 6), (4, 768, 8960, 7), (1, 1536, 8960, 5), (16, 1536, 1536, 1), (5, 3584, 3584, 2), (2, 1536, 18944, 1)])
+@pytest.mark.parametrize('M,N,K,ks', [(4, 768, 1536, 6), (4, 768, 8960, 7), (1, 1536, 8960, 5), (16, 1536, 1536, 1), (5, 3584, 3584, 2), (2, 1536, 18944, 37)])
 def test_skinny_partial(ops, M, N, K, ks):
     from vlaser_amd import _lib as L
     x, w = rnd(M, K), rnd(N, K, std=0.03)
@@ -262,7 +262,7 @@ def test_skinny_bias_silu_f32(ops):
     close(lg, x.float() @ w2.float().t(), rtol=2e-3, atol=2e-3, name='f32 edge N')
 
 
-@pytest.mark.parametrize('M,H,I,npart', [(4, 768, 8960, 7), (1, 1536, 8960, 0), (4, 768, 8960, 3), (16, 768, 8960, 8), (3, 3584, 2048, 2)])
+@pytest.mark.parametrize('M,H,I,npart', [(4, 768, 8960, 7), (1, 1536, 8960, 0), (4, 768, 8960, 3), (16, 768, 8960, 8), (3, 2048, 2048, 2)])
 def test_skinny_norm_swiglu(ops, M, H, I, npart):
     from vlaser_amd import _lib as L
     h, nw = rnd(M, H), (1 + 0.1 * rnd(H, seed=5).float()).to(BF)
@@ -270,12 +270,17 @@ def test_skinny_norm_swiglu(ops, M, H, I, npart):
     g, u = rnd(I, H, std=0.03, seed=1), rnd(I, H, std=0.03, seed=2)
     W = ops.pack_gate_up(g, u)
     out = torch.zeros(M, I, dtype=BF, device='cuda'); h_out = torch.zeros(M, H, dtype=BF, device='cuda')
+    if H == 768:      # 96-row units (tiles_per_unit = 6) must give the same result
+        out6 = torch.zeros(M, I, dtype=BF, device='cuda')
+        ops.skinny(L.PRO_NORM, L.SK_SWIGLU, h, ops.pack_skinny(W, 1, 6), M, partials=parts, n_partials=npart, norm_w=nw, out=out6, ldo=I)
     ops.skinny(L.PRO_NORM, L.SK_SWIGLU, h, ops.pack_skinny(W), M, partials=parts, n_partials=npart, norm_w=nw, h_out=h_out, out=out, ldo=I)
     hs = (h.float() + (parts[:npart].sum(0) if npart else 0)).to(BF)
     assert torch.equal(h_out, hs) or (h_out.float() - hs.float()).abs().max() <= 2 ** -7 * hs.float().abs().max()
     xn = _rms_ref(h_out, nw).to(BF).float()
     gr = (xn @ g.float().t()).to(BF).float(); ur = (xn @ u.float().t()).to(BF).float()
     close(out, F.silu(gr).to(BF).float() * ur, name='norm swiglu')
+    if H == 768:
+        assert torch.equal(out6, out)
 
 
 def test_skinny_norm_qkv_rope(ops):

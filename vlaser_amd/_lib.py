@@ -29,11 +29,11 @@ class AttnArgs(C.Structure):
 
 class SkinnyArgs(C.Structure):
     _fields_ = [('x', vp), ('partials', vp), ('n_partials', i32), ('norm_w', vp), ('eps', f32), ('h_out', vp),
-                ('W', vp), ('M', i32), ('N', i32), ('K', i32), ('ldw', i32), ('n_valid', i32), ('k_splits', i32), ('out_f32', vp),
+                ('W', vp), ('M', i32), ('N', i32), ('K', i32), ('ldw', i32), ('n_valid', i32), ('tiles_per_unit', i32), ('k_splits', i32), ('out_f32', vp),
                 ('out', vp), ('ldo', i32), ('bias', vp), ('q_out', vp), ('k_cache', vp), ('vt_cache', vp),
                 ('rope_cos', vp), ('rope_sin', vp), ('pos_ids', vp), ('n_q_heads', i32), ('n_kv_heads', i32),
                 ('s_max', i32), ('tok_per_batch', i32), ('slot_base', i32), ('attn_m', vp), ('attn_l', vp), ('attn_o', vp),
-                ('attn_splits', i32), ('attn_group', i32), ('attn_nq', i32)]
+                ('attn_splits', i32), ('attn_group', i32), ('attn_nq', i32), ('dbg', vp)]
 
 
 # enums (include/vlaser_hip.h)

@@ -69,9 +69,9 @@ __device__ __forceinline__ void add_slabs_clamped(float (&v)[8], const float* ba
   }
 #pragma unroll
   for (int u = 0; u < NB; ++u) {
-    const float w = u < S ? 1.f : 0.f;
+    const bool on = u < S;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { v[j] += w * q[2 * u][j]; v[4 + j] += w * q[2 * u + 1][j]; }
+    for (int j = 0; j < 4; ++j) { v[j] += on ? q[2 * u][j] : 0.f; v[4 + j] += on ? q[2 * u + 1][j] : 0.f; }
   }
 }
 

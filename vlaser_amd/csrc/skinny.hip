@@ -1,11 +1,11 @@
 // Skinny (M <= 16 activation rows) weight-streaming GEMV on MFMA for gfx950 -- the HBM-bound regime of the 10
 // action-expert Euler steps and of greedy decode: every weight byte is read exactly once per call.
 //
-// Geometry.  Block = 8 waves; a "unit" = 32 consecutive (packed) weight rows = two 16-row MFMA tiles; the 8 waves
-// split the block's K range (in-block split-K, reduced through LDS); blockIdx.y adds cross-block split-K for narrow
-// outputs (o_proj / down_proj): fp32 partial slabs go to a workspace and are summed by the CONSUMER's prologue --
-// deterministic, no atomics, no extra launch.  The grid is sized to <= one block per CU: a block owns a balanced
-// run of consecutive units, executes the (per-block redundant) prologue ONCE, and streams its units back to back.
+// Geometry.  Block = 8 waves; a "unit" = TPU x 16 consecutive (packed) weight rows (TPU = 2 or 6 MFMA tiles); the 8
+// waves split the block's K range (in-block split-K, reduced through LDS); blockIdx.y adds cross-block split-K for
+// narrow outputs (o_proj / down_proj): fp32 partial slabs go to a workspace and are summed by the CONSUMER's
+// prologue -- deterministic, no atomics, no extra launch.  The grid is sized to <= one block per CU: a block owns a
+// balanced run of consecutive units and executes the (per-block redundant) prologue ONCE.
 //
 // Memory layout.  Weights are PRE-PACKED in HBM in MFMA-fragment order (vlaser_amd.ops.pack_skinny):
 //     [k_split][unit][wave][k_step][tile][lane][8 bf16]
@@ -14,19 +14,24 @@
 // fragment pattern (16 rows x 64 B per instruction).  Fragments go global -> VGPR directly (guide: "GEMV / M <= 16
 // decode weights: load straight to VGPRs"); activations (a few KB) sit in LDS.
 //
-// Latency engineering.  At M = 4 a launch lasts a few microseconds, so (a) the executed code path is kept small (one
-// copy of the K-loop / reduce / epilogue; a cold instruction cache is paid on every launch), (b) the first batch of
-// weight loads is issued at kernel entry, before the prologue, (c) the prologue requests the residual chunk, the
-// norm weight and all split-K slabs of its chunk together (one L2 round trip), (d) the next unit's fragments and
-// epilogue operands are requested before the current unit is consumed.
+// Latency engineering (a launch lasts only a few microseconds at M = 4, so every serialized round trip shows):
+//   * NS, the number of 32-wide K-steps per wave, is a TEMPLATE parameter: every load of a unit is unconditional and
+//     straight-line, so hipcc can count vmcnt exactly (a load behind a runtime condition makes it fall back to
+//     vmcnt(0) at every use and serialises the whole stream -- guide 5 "three .s-level traps" (c));
+//   * the (small, L2-resident) prologue requests -- residual chunk, norm weight, ALL split-K slabs of the chunk,
+//     epilogue operands -- are issued first and the unit's weight fragments right behind them; vmcnt retires in
+//     issue order, so the prologue's LDS phases run while the weights are still in flight;
+//   * the next unit's fragments are requested before the current unit is consumed (last iteration peeled);
+//   * one copy of K-loop / reduce / epilogue per peel: small code, a cold instruction cache is paid on every launch.
 // MFMA operands are swapped (W as A, x as B) so each lane owns 4 consecutive outputs n of one row m, sharing the
 // fused epilogues of the big GEMM (bias / SiLU / SwiGLU / RoPE + KV-cache scatter).
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/vlaser_hip.h"
 
 #define SKW 8        // waves per block
 #define SKT (SKW * 64)
-#define SKU 8        // K-steps (of 32) per batch per wave
 
 struct SkinnyP {
   VlaserSkinnyArgs a;
@@ -34,38 +39,43 @@ struct SkinnyP {
   int kb;         // K per block
 };
 
-struct EpiOps {  // epilogue operands of one unit (wave 0 only)
-  float b0[4], b1[4], cs[4], sn[4];
+struct EpiOps {  // epilogue operands of one tile pair
+  u32x2 b0, b1;  // 4 bf16 bias values of tile 0 / tile 1
+  f32x4 cs, sn;  // RoPE cos / sin
 };
 
 template <int EPI>
-__device__ __forceinline__ void load_epi(const VlaserSkinnyArgs& a, int unit, int m, int g, EpiOps& e) {
-  const int n0 = unit * 32 + g * 4;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { e.b0[j] = 0.f; e.b1[j] = 0.f; e.cs[j] = 1.f; e.sn[j] = 0.f; }
+__device__ __forceinline__ void load_epi(const VlaserSkinnyArgs& a, int pair, int m, int g, EpiOps& e) {
+  // unconditional (clamped) vector loads; pair = index of the 32-row group
+  const int n0 = min(pair, (a.N >> 5) - 1) * 32 + g * 4;
   if constexpr (EPI == VL_SK_BIAS || EPI == VL_SK_BIAS_SILU || EPI == VL_SK_QKV_ROPE || EPI == VL_SK_F32) {
-    const bf16_t* bias = reinterpret_cast<const bf16_t*>(a.bias);
+    const bf16_t* bias = reinterpret_cast<const bf16_t*>(a.bias);   // padded to N by the host wrapper (or null for F32)
     if (bias) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (n0 + j < a.n_valid) e.b0[j] = bf16_to_f32(bias[n0 + j]);
-        if (n0 + 16 + j < a.n_valid) e.b1[j] = bf16_to_f32(bias[n0 + 16 + j]);
-      }
+      e.b0 = *reinterpret_cast<const u32x2*>(bias + n0);
+      e.b1 = *reinterpret_cast<const u32x2*>(bias + n0 + 16);
+    } else {
+      e.b0 = u32x2{0, 0};
+      e.b1 = u32x2{0, 0};
     }
   }
   if constexpr (EPI == VL_SK_QKV_ROPE) {
     const int pp = n0 & 127, d = ((pp >> 5) << 4) + (pp & 15);
-    const int pos = a.pos_ids[m];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { e.cs[j] = a.rope_cos[(size_t)pos * 64 + d + j]; e.sn[j] = a.rope_sin[(size_t)pos * 64 + d + j]; }
+    const int pos = a.pos_ids[min(m, a.M - 1)];
+    e.cs = *reinterpret_cast<const f32x4*>(a.rope_cos + (size_t)pos * 64 + d);
+    e.sn = *reinterpret_cast<const f32x4*>(a.rope_sin + (size_t)pos * 64 + d);
   }
 }
 
 template <int EPI>
-__device__ __forceinline__ void skinny_epilogue(const VlaserSkinnyArgs& a, int ks, int unit, int m, int g, f32x4 acc0, f32x4 acc1,
+__device__ __forceinline__ void skinny_epilogue(const VlaserSkinnyArgs& a, int ks, int pair, int m, int g, f32x4 acc0, f32x4 acc1,
                                                 const EpiOps& e) {
-  // lane -> row m, columns n = unit*32 + t*16 + g*4 + j  (acc0: t = 0, acc1: t = 1); n_valid = un-padded N
-  const int n0 = unit * 32 + g * 4;
+  // lane -> row m, columns n = pair*32 + t*16 + g*4 + j  (acc0: t = 0, acc1: t = 1); n_valid = un-padded N
+  const int n0 = pair * 32 + g * 4;
+  float b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0};
+  if constexpr (EPI == VL_SK_BIAS || EPI == VL_SK_BIAS_SILU || EPI == VL_SK_QKV_ROPE || EPI == VL_SK_F32) {
+    b0[0] = bf16lo_to_f32(e.b0[0]); b0[1] = bf16hi_to_f32(e.b0[0]); b0[2] = bf16lo_to_f32(e.b0[1]); b0[3] = bf16hi_to_f32(e.b0[1]);
+    b1[0] = bf16lo_to_f32(e.b1[0]); b1[1] = bf16hi_to_f32(e.b1[0]); b1[2] = bf16lo_to_f32(e.b1[1]); b1[3] = bf16hi_to_f32(e.b1[1]);
+  }
   if constexpr (EPI == VL_SK_PARTIAL) {
     float* o = a.out_f32 + ((size_t)ks * a.M + m) * a.n_valid;
     if (n0 + 3 < a.n_valid) *reinterpret_cast<f32x4*>(o + n0) = acc0;
@@ -74,23 +84,24 @@ __device__ __forceinline__ void skinny_epilogue(const VlaserSkinnyArgs& a, int k
     float* o = a.out_f32 + (size_t)m * a.n_valid;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (n0 + j < a.n_valid) o[n0 + j] = acc0[j] + e.b0[j];
-      if (n0 + 16 + j < a.n_valid) o[n0 + 16 + j] = acc1[j] + e.b1[j];
+      if (n0 + j < a.n_valid) o[n0 + j] = acc0[j] + b0[j];
+      if (n0 + 16 + j < a.n_valid) o[n0 + 16 + j] = acc1[j] + b1[j];
     }
   } else if constexpr (EPI == VL_SK_BIAS || EPI == VL_SK_BIAS_SILU) {
     bf16_t* o = reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo;
     float r0[4], r1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      r0[j] = acc0[j] + e.b0[j];
-      r1[j] = acc1[j] + e.b1[j];
+      r0[j] = acc0[j] + b0[j];
+      r1[j] = acc1[j] + b1[j];
       if constexpr (EPI == VL_SK_BIAS_SILU) { r0[j] = silu(round_bf16(r0[j])); r1[j] = silu(round_bf16(r1[j])); }
     }
     *reinterpret_cast<u32x2*>(o + n0) = u32x2{pack_bf16x2(r0[0], r0[1]), pack_bf16x2(r0[2], r0[3])};
     *reinterpret_cast<u32x2*>(o + n0 + 16) = u32x2{pack_bf16x2(r1[0], r1[1]), pack_bf16x2(r1[2], r1[3])};
   } else if constexpr (EPI == VL_SK_SWIGLU) {
-    // unit = [gate16 | up16]; output columns unit*16 + g*4 + j
-    bf16_t* o = reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + unit * 16 + g * 4;
+    // pair = [gate16 | up16]; output columns pair*16 + g*4 + j
+    if (pair * 32 >= a.n_valid) return;      // zero-padded tail
+    bf16_t* o = reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + pair * 16 + g * 4;
     float r[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) r[j] = round_bf16(silu(round_bf16(acc0[j]))) * round_bf16(acc1[j]);
@@ -102,8 +113,8 @@ __device__ __forceinline__ void skinny_epilogue(const VlaserSkinnyArgs& a, int k
     float x1[4], x2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      x1[j] = round_bf16(acc0[j] + e.b0[j]);
-      x2[j] = round_bf16(acc1[j] + e.b1[j]);
+      x1[j] = round_bf16(acc0[j] + b0[j]);
+      x2[j] = round_bf16(acc1[j] + b1[j]);
     }
     const int b = m / a.tok_per_batch;
     const int slot = a.slot_base + (m - b * a.tok_per_batch);
@@ -130,65 +141,66 @@ __device__ __forceinline__ void skinny_epilogue(const VlaserSkinnyArgs& a, int k
   }
 }
 
-template <int PRO, int EPI>
+template <int PRO, int EPI, int TPU, int NS>
 __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
+  constexpr int RPU = TPU * 16;                 // rows per unit
+  constexpr int NF = TPU * NS;                  // fragments (16-byte loads) per lane per unit
+  constexpr bool NEED_EPI = (EPI == VL_SK_BIAS || EPI == VL_SK_BIAS_SILU || EPI == VL_SK_QKV_ROPE || EPI == VL_SK_F32);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const VlaserSkinnyArgs& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int ks = blockIdx.y;
+  unsigned long long* dbg = a.dbg ? a.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+#define STAMP(i) do { if (dbg && tid == 0) dbg[i] = wall_clock64(); } while (0)
+  STAMP(0);
   // balanced run of units for this block
-  const int n_units = a.N >> 5;
+  const int n_units = a.N / RPU;
   const int ulo = n_units / (int)gridDim.x, urem = n_units % (int)gridDim.x;
   const int ucount = ulo + ((int)blockIdx.x < urem ? 1 : 0);
   const int ustart = (int)blockIdx.x * ulo + min((int)blockIdx.x, urem);
   const int kb0 = ks * p.kb;                  // first k of this block
   char* xs = smem;                            // [M][xs_stride] activations (bf16)
   const int xs_bytes = (a.M * p.xs_stride + 15) & ~15;
-  float* red = reinterpret_cast<float*>(smem + xs_bytes);                 // [2][SKW-1][2][64][4] fp32 (double-buffered per unit)
-  char* wn_lds = smem + xs_bytes + 2 * (SKW - 1) * 2 * 64 * 16;           // [K] bf16 norm weight (NORM prologue)
+  float* red = reinterpret_cast<float*>(smem + xs_bytes);                 // [2][SKW-1][TPU][64][4] fp32 (double-buffered per unit)
+  char* wn_lds = smem + xs_bytes + 2 * (SKW - 1) * TPU * 64 * 16;         // [K] bf16 norm weight (NORM prologue)
 
   // ------------------------------------------------------------------ weight stream (fragment-major packed weights)
-  const int kw = p.kb / SKW;                  // K per wave (multiple of 32)
-  const int kl0 = wave * kw;                  // block-local k start
-  const int nsteps = kw >> 5;
-  const int nbatch = (nsteps + SKU - 1) / SKU;            // batches per unit
-  const int total = ucount * nbatch;
-  // 16-byte index of (ks, unit u, wave, step s, tile t, lane) = ((((ks*n_units + u)*SKW + wave)*nsteps + s)*2 + t)*64 + lane
-  const u32x4* wp = reinterpret_cast<const u32x4*>(a.W) + lane;
-  const size_t wave_base = ((size_t)ks * n_units * SKW + wave) * nsteps * 128;
-  const size_t unit_stride = (size_t)SKW * nsteps * 128;
-  u32x4 cw[2 * SKU], nw[2 * SKU];
-  EpiOps ce, ne;
+  const int kl0 = wave * (NS * 32);           // block-local k start of this wave
+  // 16-byte index of (ks, unit u, wave, step s, tile t, lane) = ((((ks*n_units + u)*SKW + wave)*NS + s)*TPU + t)*64 + lane
+  const u32x4* wp = reinterpret_cast<const u32x4*>(a.W) + ((size_t)ks * n_units * SKW + wave) * (NF * 64) + lane;
+  constexpr size_t unit_stride = (size_t)SKW * NF * 64;
   const int m = fr;
-  auto issue = [&](int bi, u32x4* dst, EpiOps& e) {
-    const int ui = bi / nbatch, j = bi - ui * nbatch;
-    const u32x4* src = wp + wave_base + (size_t)(ustart + ui) * unit_stride + (size_t)j * SKU * 128;
-    const int ns = min(SKU, nsteps - j * SKU);
+  u32x4 cw[NF], nw[NF];                      // current / next unit (both requested at entry)
+  EpiOps ce[NEED_EPI ? TPU / 2 : 1], ne[NEED_EPI ? TPU / 2 : 1];
+  auto load_unit = [&](int ui, u32x4* dst, EpiOps* e) {
+    const u32x4* src = wp + (size_t)(ustart + ui) * unit_stride;
 #pragma unroll
-    for (int u = 0; u < SKU; ++u)
-      if (u < ns) {
-        dst[2 * u] = __builtin_nontemporal_load(src + u * 128);
-        dst[2 * u + 1] = __builtin_nontemporal_load(src + u * 128 + 64);
-      }
-    if (wave == 0 && j == 0 && m < a.M) load_epi<EPI>(a, ustart + ui, m, g, e);
+    for (int f = 0; f < NF; ++f) dst[f] = __builtin_nontemporal_load(src + f * 64);
+    if constexpr (NEED_EPI) {
+#pragma unroll
+      for (int pr = 0; pr < TPU / 2; ++pr) load_epi<EPI>(a, (ustart + ui) * (TPU / 2) + pr, m, g, e[pr]);
+    }
   };
-  issue(0, cw, ce);
 
   // ------------------------------------------------------------------ prologue: activations -> LDS (bf16)
+  // fast path: one 16-byte chunk per thread, all loads unconditional (index clamped); extra chunks (M*K/8 > 512) loop
   if constexpr (PRO == VL_PRO_PLAIN) {
     const bf16_t* X = reinterpret_cast<const bf16_t*>(a.x);
-    const int chunks_per_row = p.kb >> 3;
-    for (int c = tid; c < a.M * chunks_per_row; c += SKT) {
-      const int mm = c / chunks_per_row, j = c - mm * chunks_per_row;
-      *reinterpret_cast<u32x4*>(xs + mm * p.xs_stride + j * 16) = ld_global_16(X + (size_t)mm * a.K + kb0 + j * 8);
-    }
+    const int cpr = p.kb >> 3, nch = a.M * cpr;
+    const int c0 = min(tid, nch - 1);
+    const u32x4 x0 = ld_global_16(X + (size_t)(c0 / cpr) * a.K + kb0 + (c0 % cpr) * 8);
+    load_unit(0, cw, ce);
+    if (tid < nch) *reinterpret_cast<u32x4*>(xs + (c0 / cpr) * p.xs_stride + (c0 % cpr) * 16) = x0;
+    for (int c = tid + SKT; c < nch; c += SKT)
+      *reinterpret_cast<u32x4*>(xs + (c / cpr) * p.xs_stride + (c % cpr) * 16) = ld_global_16(X + (size_t)(c / cpr) * a.K + kb0 + (c % cpr) * 8);
   } else if constexpr (PRO == VL_PRO_ATTN) {
     // x[m][k] (k = h*128 + d) = flash-decoding merge of the attention partials of vlaser_attn_skinny
-    const int chunks_per_row = p.kb >> 3, G = a.attn_group, nq = a.attn_nq, S = a.attn_splits;
+    const int cpr = p.kb >> 3, nch = a.M * cpr, G = a.attn_group, nq = a.attn_nq, S = a.attn_splits;
     const int nkv = a.K / (128 * G);
-    for (int c = tid; c < a.M * chunks_per_row; c += SKT) {
-      const int mm = c / chunks_per_row, j = c - mm * chunks_per_row;
+    auto attn_pass = [&](int cbase, auto issue_tag) {
+      const int c = min(cbase + tid, nch - 1);
+      const int mm = c / cpr, j = c - mm * cpr;
       const int k = kb0 + j * 8, h = k >> 7, d = k & 127;
       const int b = mm / nq, tok = mm - b * nq, kvh = h / G, hg = h - kvh * G, r = hg * nq + tok;
       const size_t pbase = ((size_t)b * nkv + kvh) * S;
@@ -203,6 +215,7 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
         o0[sp] = *reinterpret_cast<const f32x4*>(po);
         o1[sp] = *reinterpret_cast<const f32x4*>(po + 4);
       }
+      if constexpr (decltype(issue_tag)::value) load_unit(0, cw, ce);
       float Mx = -1.0e30f;
 #pragma unroll
       for (int sp = 0; sp < 8; ++sp) Mx = fmaxf(Mx, ms[sp]);
@@ -218,44 +231,79 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
       u32x4 xr;
 #pragma unroll
       for (int q = 0; q < 4; ++q) xr[q] = pack_bf16x2(v[2 * q] * inv, v[2 * q + 1] * inv);
-      *reinterpret_cast<u32x4*>(xs + mm * p.xs_stride + j * 16) = xr;
-    }
+      if (cbase + tid < nch) *reinterpret_cast<u32x4*>(xs + mm * p.xs_stride + j * 16) = xr;
+    };
+    attn_pass(0, std::true_type{});
+    for (int cbase = SKT; cbase < nch; cbase += SKT) attn_pass(cbase, std::false_type{});
   } else {
     // h = bf16(h_in + sum partials); xn = bf16(w * bf16(h * rsqrt(mean(h^2) + eps)))
-    // Phase 1 (all threads, one 16-byte chunk each per pass): residual chunk + norm-weight chunk + every slab of the
-    // chunk are requested together; the rounded residual goes to LDS (and to h_out from block 0).
-    // Phase 2 (one wave per row, LDS only): sum of squares, normalise in place.
+    // Phase 1 (all threads, one 16-byte chunk each per pass): residual chunk + norm-weight chunk + the first 8 slabs of
+    // the chunk are requested together, the weight stream right behind them; the rounded residual goes to LDS (and to
+    // h_out from block 0).   Phase 2 (one wave per row, LDS only): sum of squares, normalise in place.
     const bf16_t* Hin = reinterpret_cast<const bf16_t*>(a.x);
     const bf16_t* Wn = reinterpret_cast<const bf16_t*>(a.norm_w);
     const bool write_h = (a.h_out != nullptr) && blockIdx.x == 0 && ks == 0;
-    const int cpr = a.K >> 3;  // chunks per row
+    const int cpr = a.K >> 3, nch = a.M * cpr;
     const size_t slab = (size_t)a.M * a.K;
-    for (int ch = tid; ch < a.M * cpr; ch += SKT) {
+    const int S = a.n_partials;
+    // one pass = one 16-byte chunk per thread: residual + norm weight + slabs requested together (clamped, unconditional);
+    // the rounded residual goes to LDS (and to h_out from block 0)
+    auto norm_pass = [&](int cbase, auto issue_tag) {
+      const int ch = min(cbase + tid, nch - 1);
       const int mm = ch / cpr, c = (ch - mm * cpr) << 3;
       const size_t off = (size_t)mm * a.K + c;
       const u32x4 hv = ld_global_16(Hin + off);
-      u32x4 wv = {0, 0, 0, 0};
-      if (mm == 0) wv = ld_global_16(Wn + c);
+      const u32x4 wv = ld_global_16(Wn + c);
       float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (a.n_partials > 0) {
-        const float* pb = a.partials + off;
-        int S = a.n_partials;
-        if (S <= 4) add_slabs_clamped<4>(v, pb, slab, S);
-        else {
-          for (; S > 8; S -= 8, pb += 8 * slab) add_slabs_clamped<8>(v, pb, slab, 8);
-          add_slabs_clamped<8>(v, pb, slab, S);
+      if (S <= 4) {
+        f32x4 q[8];
+        const float* pbase = S > 0 ? a.partials + off : reinterpret_cast<const float*>(Hin);   // any valid address when S == 0
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* pp = pbase + (size_t)(S > 0 ? min(u, S - 1) : 0) * slab;
+          q[2 * u] = *reinterpret_cast<const f32x4*>(pp);
+          q[2 * u + 1] = *reinterpret_cast<const f32x4*>(pp + 4);
         }
+        if constexpr (decltype(issue_tag)::value) load_unit(0, cw, ce);       // weight stream right behind the prologue requests
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool on = u < S;     // select, not multiply: the clamped dummy loads may hold non-finite bit patterns
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] += on ? q[2 * u][j] : 0.f; v[4 + j] += on ? q[2 * u + 1][j] : 0.f; }
+        }
+      } else {
+        f32x4 q[16];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float* pp = a.partials + off + (size_t)min(u, S - 1) * slab;
+          q[2 * u] = *reinterpret_cast<const f32x4*>(pp);
+          q[2 * u + 1] = *reinterpret_cast<const f32x4*>(pp + 4);
+        }
+        if constexpr (decltype(issue_tag)::value) load_unit(0, cw, ce);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool on = u < S;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] += on ? q[2 * u][j] : 0.f; v[4 + j] += on ? q[2 * u + 1][j] : 0.f; }
+        }
+        for (int Sr = S - 8; Sr > 0; Sr -= 8) add_slabs_clamped<8>(v, a.partials + off + (size_t)(S - Sr) * slab, slab, min(Sr, 8));
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) { v[2 * j] += bf16lo_to_f32(hv[j]); v[2 * j + 1] += bf16hi_to_f32(hv[j]); }
       u32x4 hr;
 #pragma unroll
       for (int j = 0; j < 4; ++j) hr[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
-      *reinterpret_cast<u32x4*>(xs + mm * p.xs_stride + c * 2) = hr;
-      if (mm == 0) *reinterpret_cast<u32x4*>(wn_lds + c * 2) = wv;
-      if (write_h) st_global_16(reinterpret_cast<bf16_t*>(a.h_out) + off, hr);
-    }
+      if (cbase + tid < nch) {
+        *reinterpret_cast<u32x4*>(xs + mm * p.xs_stride + c * 2) = hr;
+        if (mm == 0) *reinterpret_cast<u32x4*>(wn_lds + c * 2) = wv;
+        if (write_h) st_global_16(reinterpret_cast<bf16_t*>(a.h_out) + off, hr);
+      }
+    };
+    norm_pass(0, std::true_type{});
+    for (int cbase = SKT; cbase < nch; cbase += SKT) norm_pass(cbase, std::false_type{});
     __syncthreads();
+    STAMP(1);
+    // phase 2 (one wave per row, LDS only): sum of squares, normalise in place
     for (int mm = wave; mm < a.M; mm += SKW) {
       float ssq = 0.f;
       for (int c = lane * 8; c < a.K; c += 512) {
@@ -280,75 +328,110 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
     }
   }
   __syncthreads();
+  STAMP(2);
 
-  // ------------------------------------------------------------------ main loop: ONE copy of K-loop / reduce / epilogue
+  // ------------------------------------------------------------------ main loop (last unit peeled: no dangling prefetch)
   const char* xrow = xs + (fr < a.M ? fr : 0) * p.xs_stride + (kl0 + g * 8) * 2;
   const bool mok = fr < a.M;
-  f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
   int par = 0;
-  for (int bi = 0; bi < total; ++bi) {
-    const int ui = bi / nbatch, j = bi - ui * nbatch;
-    if (bi + 1 < total) issue(bi + 1, nw, ne);       // next batch's fragments (and epilogue operands) in flight
-    const int ns = min(SKU, nsteps - j * SKU);
+  auto consume_finish = [&](int ui, const u32x4* w, const EpiOps* e) {
+    f32x4 acc[TPU];
 #pragma unroll
-    for (int u = 0; u < SKU; ++u)
-      if (u < ns) {
-        u32x4 xv = {0, 0, 0, 0};
-        if (mok) xv = *reinterpret_cast<const u32x4*>(xrow + (j * SKU + u) * 64);
-        const bf16x8 xf = as_bf16x8(xv);
-        acc0 = mfma16(as_bf16x8(cw[2 * u]), xf, acc0);
-        acc1 = mfma16(as_bf16x8(cw[2 * u + 1]), xf, acc1);
-      }
-    if (j == nbatch - 1) {
-      // in-block split-K reduce + epilogue of unit (ustart + ui); `red` is double-buffered by unit parity
-      float* rb = red + par * (SKW - 1) * 2 * 64 * 4;
-      if (wave != 0) {
-        float* r = rb + ((wave - 1) * 2 * 64 + lane) * 4;
-        *reinterpret_cast<f32x4*>(r) = acc0;
-        *reinterpret_cast<f32x4*>(r + 64 * 4) = acc1;
-      }
-      __syncthreads();
-      par ^= 1;
-      if (wave == 0) {
+    for (int t = 0; t < TPU; ++t) acc[t] = f32x4{0, 0, 0, 0};
 #pragma unroll
-        for (int w = 0; w < SKW - 1; ++w) {
-          const float* r = rb + (w * 2 * 64 + lane) * 4;
-          acc0 += *reinterpret_cast<const f32x4*>(r);
-          acc1 += *reinterpret_cast<const f32x4*>(r + 64 * 4);
-        }
-        if (m < a.M) skinny_epilogue<EPI>(a, ks, ustart + ui, m, g, acc0, acc1, ce);
-      }
-      acc0 = f32x4{0, 0, 0, 0};
-      acc1 = f32x4{0, 0, 0, 0};
+    for (int u = 0; u < NS; ++u) {
+      u32x4 xv = {0, 0, 0, 0};
+      if (mok) xv = *reinterpret_cast<const u32x4*>(xrow + u * 64);
+      const bf16x8 xf = as_bf16x8(xv);
+#pragma unroll
+      for (int t = 0; t < TPU; ++t) acc[t] = mfma16(as_bf16x8(w[TPU * u + t]), xf, acc[t]);
     }
-    if (bi + 1 < total) {
+    if (ui == 0) { asm volatile("" ::"v"(acc[0][0])); STAMP(3); }
+    // in-block split-K reduce + epilogue; `red` is double-buffered by unit parity
+    float* rb = red + par * (SKW - 1) * TPU * 64 * 4;
+    if (wave != 0) {
+      float* r = rb + ((wave - 1) * TPU * 64 + lane) * 4;
 #pragma unroll
-      for (int u = 0; u < 2 * SKU; ++u) cw[u] = nw[u];
-      if (j == nbatch - 1) ce = ne;
+      for (int t = 0; t < TPU; ++t) *reinterpret_cast<f32x4*>(r + t * 64 * 4) = acc[t];
+    }
+    __syncthreads();
+    if (ui == 0) STAMP(4);
+    par ^= 1;
+    if (wave == 0) {
+#pragma unroll
+      for (int w2 = 0; w2 < SKW - 1; ++w2) {
+        const float* r = rb + (w2 * TPU * 64 + lane) * 4;
+#pragma unroll
+        for (int t = 0; t < TPU; ++t) acc[t] += *reinterpret_cast<const f32x4*>(r + t * 64 * 4);
+      }
+      if (m < a.M) {
+#pragma unroll
+        for (int pr = 0; pr < TPU / 2; ++pr)
+          skinny_epilogue<EPI>(a, ks, (ustart + ui) * (TPU / 2) + pr, m, g, acc[2 * pr], acc[2 * pr + 1], e[NEED_EPI ? pr : 0]);
+      }
+    }
+  };
+  // while unit ui is consumed, unit ui+1 is in flight; last unit peeled (no dangling prefetch)
+  for (int ui = 0; ui + 1 < ucount; ++ui) {
+    load_unit(ui + 1, nw, ne);
+    consume_finish(ui, cw, ce);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) cw[f] = nw[f];
+    if constexpr (NEED_EPI) {
+#pragma unroll
+      for (int pr = 0; pr < TPU / 2; ++pr) ce[pr] = ne[pr];
     }
   }
+  consume_finish(ucount - 1, cw, ce);
+  STAMP(5);
+#undef STAMP
 }
 
-template <int PRO, int EPI>
-static int launch(const VlaserSkinnyArgs* a, hipStream_t stream) {
+template <int PRO, int EPI, int TPU, int NS>
+static int launch_ns(const VlaserSkinnyArgs* a, hipStream_t stream) {
   SkinnyP p;
   p.a = *a;
   if (p.a.n_valid <= 0) p.a.n_valid = a->N;
   p.kb = a->K / a->k_splits;
   p.xs_stride = p.kb * 2 + 16;
-  const int lds = ((a->M * p.xs_stride + 15) & ~15) + 2 * (SKW - 1) * 2 * 64 * 16 + (PRO == VL_PRO_NORM ? a->K * 2 : 0);
-  const int n_units = a->N / 32;
+  const int lds = ((a->M * p.xs_stride + 15) & ~15) + 2 * (SKW - 1) * TPU * 64 * 16 + (PRO == VL_PRO_NORM ? a->K * 2 : 0);
+  const int n_units = a->N / (16 * TPU);
   int gx = 256 / a->k_splits;            // <= one block per CU (256 CUs)
   if (gx > n_units) gx = n_units;
   if (gx < 1) gx = 1;
   static int attr_lds = 0;
   if (lds > attr_lds) {
-    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel<PRO, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel<PRO, EPI, TPU, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_lds = lds;
   }
-  hipLaunchKernelGGL((skinny_kernel<PRO, EPI>), dim3(gx, a->k_splits), dim3(SKT), lds, stream, p);
+  hipLaunchKernelGGL((skinny_kernel<PRO, EPI, TPU, NS>), dim3(gx, a->k_splits), dim3(SKT), lds, stream, p);
   VL_LAUNCH_CHECK();
   return 0;
+}
+
+template <int PRO, int EPI>
+static int launch(const VlaserSkinnyArgs* a, hipStream_t stream) {
+  const int ns = a->K / a->k_splits / (32 * SKW);
+  if (a->tiles_per_unit == 6) {
+    if constexpr (PRO == VL_PRO_NORM && EPI == VL_SK_SWIGLU) {
+      if (ns == 3) return launch_ns<PRO, EPI, 6, 3>(a, stream);
+    }
+    vlaser_set_error("vlaser_skinny: tiles_per_unit = 6 is only built for NORM + SWIGLU with K = 768");
+    return -1;
+  }
+  switch (ns) {
+    case 1: return launch_ns<PRO, EPI, 2, 1>(a, stream);
+    case 2: return launch_ns<PRO, EPI, 2, 2>(a, stream);
+    case 3: return launch_ns<PRO, EPI, 2, 3>(a, stream);
+    case 4: return launch_ns<PRO, EPI, 2, 4>(a, stream);
+    case 5: return launch_ns<PRO, EPI, 2, 5>(a, stream);
+    case 6: return launch_ns<PRO, EPI, 2, 6>(a, stream);
+    case 7: return launch_ns<PRO, EPI, 2, 7>(a, stream);
+    case 8: return launch_ns<PRO, EPI, 2, 8>(a, stream);
+    default:
+      vlaser_set_error("vlaser_skinny: K/(k_splits*256) = %d K-steps per wave unsupported (1..8): raise k_splits", ns);
+      return -1;
+  }
 }
 
 extern "C" int vlaser_skinny(int pro, int epi, const VlaserSkinnyArgs* a, vl_stream_t s) {
@@ -361,8 +444,11 @@ extern "C" int vlaser_skinny(int pro, int epi, const VlaserSkinnyArgs* a, vl_str
   VL_CHECK(a->M >= 1 && a->M <= 16, "vlaser_skinny: M=%d must be in 1..16", a->M);
   VL_CHECK(a->k_splits >= 1 && a->K % (a->k_splits * 32 * SKW) == 0, "vlaser_skinny: K=%d not divisible by k_splits*%d (k_splits=%d)", a->K,
            32 * SKW, a->k_splits);
-  VL_CHECK(a->N % 32 == 0, "vlaser_skinny: N=%d must be a multiple of 32 (pack_skinny pads the weight rows; pass n_valid)", a->N);
-  VL_CHECK(a->n_valid <= a->N && (a->n_valid <= 0 || a->n_valid > a->N - 32), "vlaser_skinny: n_valid must lie in the last unit");
+  VL_CHECK(a->tiles_per_unit == 0 || a->tiles_per_unit == 2 || a->tiles_per_unit == 6, "vlaser_skinny: tiles_per_unit must be 2 or 6");
+  VL_CHECK(a->N % (a->tiles_per_unit == 6 ? 96 : 32) == 0,
+           "vlaser_skinny: N=%d must be a multiple of the unit height (pack_skinny pads the weight rows; pass n_valid)", a->N);
+  VL_CHECK(a->n_valid <= a->N && (a->n_valid <= 0 || a->n_valid > a->N - (a->tiles_per_unit == 6 ? 96 : 32)),
+           "vlaser_skinny: n_valid must lie in the last unit");
   VL_CHECK(((uintptr_t)a->W & 15) == 0 && ((uintptr_t)a->x & 15) == 0, "vlaser_skinny: alignment");
   VL_CHECK((size_t)a->M * (a->K / a->k_splits * 2 + 16) <= 120000, "vlaser_skinny: activation tile does not fit in LDS");
   if (pro == VL_PRO_NORM) {
@@ -371,8 +457,11 @@ extern "C" int vlaser_skinny(int pro, int epi, const VlaserSkinnyArgs* a, vl_str
   }
   if (epi == VL_SK_PARTIAL) VL_CHECK(a->out_f32 && (a->n_valid <= 0 || a->n_valid % 4 == 0), "vlaser_skinny: partial needs out_f32 and n_valid %% 4 == 0");
   if (epi != VL_SK_PARTIAL) VL_CHECK(a->k_splits == 1, "vlaser_skinny: only VL_SK_PARTIAL may split K across blocks");
-  if (epi != VL_SK_F32 && epi != VL_SK_PARTIAL) VL_CHECK(a->n_valid <= 0 || a->n_valid == a->N, "vlaser_skinny: only F32/PARTIAL epilogues support a padded N");
+  if (epi != VL_SK_F32 && epi != VL_SK_PARTIAL && epi != VL_SK_SWIGLU)
+    VL_CHECK(a->n_valid <= 0 || a->n_valid == a->N, "vlaser_skinny: only F32/PARTIAL/SWIGLU epilogues support a padded N");
+  if (epi == VL_SK_SWIGLU) VL_CHECK(a->n_valid <= 0 || a->n_valid % 32 == 0, "vlaser_skinny: SWIGLU needs whole [gate16|up16] groups");
   if (epi == VL_SK_BIAS || epi == VL_SK_BIAS_SILU || epi == VL_SK_QKV_ROPE) VL_CHECK(a->bias, "vlaser_skinny: bias null");
+  if (epi == VL_SK_F32) VL_CHECK(a->bias == nullptr || a->n_valid <= 0 || a->n_valid == a->N, "vlaser_skinny: F32 bias needs an un-padded N");
 #define SK_CASE(P, E)                                   \
   if (pro == P && epi == E) return launch<P, E>(a, stream);
   SK_CASE(VL_PRO_PLAIN, VL_SK_PARTIAL)

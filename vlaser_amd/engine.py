@@ -41,7 +41,9 @@ class QwenLayerWeights:
         if skinny:
             self.sk_qkv = ops.pack_skinny(wqkv, 1)
             self.sk_o = ops.pack_skinny(wo, ks_o)
-            self.sk_gu = ops.pack_skinny(wgu, 1)
+            # wide output + short K (action expert: 17920 x 768): 96-row units -> one unit per block, single load batch
+            tpu = 2      # 96-row units (tpu = 6) measured slower on MI355X (12.3 vs 11.2 us): kept in the kernel, not used
+            self.sk_gu = ops.pack_skinny(wgu, 1, tpu)
             self.sk_down = ops.pack_skinny(wdown, ks_down)
 
 
