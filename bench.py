@@ -42,12 +42,15 @@ def make_inputs(cfg, B, seed=0):
 
 
 def cpu_baseline(vla_full, seed=0):
-    """Oracle (fp32 torch-CPU port of the reference path) on a depth-truncated, full-width model; scaled to depth."""
+    """Oracle (fp32 torch-CPU port of the reference path) on a bounded, depth-truncated, full-width sample; scaled to
+    depth and to the 10 Euler steps.  Thread count is capped at 32: the oracle's small matmuls get slower, not faster,
+    with more threads (measured on the 256-core GPU-box host)."""
     from vlaser_amd import config as C, synth
-    from oracle import vla as ovla, vit as ovit
+    from oracle import vla as ovla
     import torch.nn.functional as F
-    torch.set_num_threads(os.cpu_count())
-    dv, dl = 4, 4
+    threads = min(os.cpu_count(), 32)
+    torch.set_num_threads(threads)
+    dv, dl, de = 2, 2, 2                      # ViT layers, LLM/expert layers, Euler steps in the sample
     cfg = C.truncated(vla_full.base, dv, dl)
     vla = C.VLAConfig(base=cfg)
     sd = synth.vla_state_dict(vla)
@@ -65,7 +68,7 @@ def cpu_baseline(vla_full, seed=0):
             ovla.joint_forward(sd, vla, {'vlm': emb, 'proprio': pro}, {'vlm': vp, 'proprio': pp}, m1, caches)
             t2 = time.perf_counter()
             a = noise.clone()
-            for s in range(vla.num_inference_steps):
+            for s in range(de):
                 temb = ovla.sinusoidal_pos_emb(torch.full((1,), s * 0.1), vla.action_hidden_size, vla.time_max_period)
                 ae = ovla.action_encoder(sd, a, temb)
                 out = ovla.joint_forward(sd, vla, {'action': ae}, {'action': ap}, m2, caches, final_skip=())['action']
@@ -75,11 +78,12 @@ def cpu_baseline(vla_full, seed=0):
         run()                       # warm-up
         ts = [run() for _ in range(2)]
     tv, tp, te = [min(t[i] for t in ts) for i in range(3)]
-    full = tv * vla_full.base.vision.num_hidden_layers / dv + (tp + te) * vla_full.base.llm.num_hidden_layers / dl
-    return {'value': round(1.0 / full, 4), 'unit': 'action-chunks/s', 'cores': os.cpu_count(), 'kind': 'port',
-            'sample': f'oracle fp32 torch-CPU, full widths, ViT {dv}/24 + LLM/expert {dl}/28 layers, 10 Euler steps, batch 1; '
-                      f'phase times scaled linearly in depth (ViT x{24 // dv}, prefill+Euler x{28 // dl}); '
-                      f'measured {tv:.2f}+{tp:.2f}+{te:.2f} s -> est. {full:.1f} s/chunk'}
+    nv, nl, ne = vla_full.base.vision.num_hidden_layers, vla_full.base.llm.num_hidden_layers, vla_full.num_inference_steps
+    full = tv * nv / dv + tp * nl / dl + te * (nl / dl) * (ne / de)
+    return {'value': round(1.0 / full, 4), 'unit': 'action-chunks/s', 'cores': threads, 'kind': 'port',
+            'sample': f'oracle fp32 torch-CPU ({threads} threads of {os.cpu_count()} host cores), full widths, ViT {dv}/{nv} layers, '
+                      f'LLM/expert {dl}/{nl} layers, {de}/{ne} Euler steps, batch 1; phase times scaled linearly '
+                      f'(measured {tv:.2f}+{tp:.2f}+{te:.2f} s -> est. {full:.1f} s/chunk)'}
 
 
 def main():
@@ -147,9 +151,9 @@ def main():
                        'parallelism': f'replicas x{world} (no collective)', 'weights': 'random-init, true architecture'},
         }
         if world == 1 and not a.no_roofline:
-            avg_ms, byts, n = _probe(model, ids_d, pv_d, pro_d, noise_d, valid)
+            avg_ms, byts, n = _probe(model)
             ach = byts / (avg_ms * 1e-3) / 1e9
-            line['roofline'] = {'bound': 'hbm', 'kernel': 'skinny_kernel<NORM,SWIGLU> (action-expert gate/up GEMV, N=17920 K=768)',
+            line['roofline'] = {'bound': 'hbm', 'kernel': 'skinny_kernel<NORM,SWIGLU> (action-expert gate/up GEMV, N=17920 K=768, M=4; 307 launches per chunk)',
                                 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
                                 'traffic': None, 'bytes_per_launch': byts, 'us_per_launch': round(avg_ms * 1e3, 3), 'launches_timed': n}
         if world == 1 and not a.no_cpu_baseline:
@@ -159,35 +163,40 @@ def main():
         dist.destroy_process_group()
 
 
-def _probe(model, ids_d, pv_d, pro_d, noise_d, valid):
-    """HIP-event time per launch of the dominant kernel (gate/up weight-streaming GEMV of the action expert,
-    skinny_kernel<NORM,SWIGLU>) inside eager (un-graphed) chunks, events on the launch stream."""
+def _probe(model):
+    """Per-launch time of the dominant kernel -- the action expert's gate/up weight-streaming GEMV
+    (skinny_kernel<NORM,SWIGLU>, 27.5 MB of packed weights per launch) -- measured with HIP events on the launch
+    stream around replays of a HIP graph holding the 28 layers' launches back to back (each launch streams a
+    different layer's weights, i.e. HBM-cold exactly as in the real chunk).  Includes the ~1.6 us inter-kernel
+    boundary of the graph, so it is an upper bound of the rocprof kernel duration."""
     from vlaser_amd import ops, _lib as L
-    recs = []
-    orig = ops.skinny
+    ex, sb, cfg = model.expert, model.sb_act, model.cfg
+    M = cfg.num_action_tokens
+    llm = ex.llm
 
-    def hooked(pro, epi, x, W, M, **kw):
-        if pro == L.PRO_NORM and epi == L.SK_SWIGLU:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            orig(pro, epi, x, W, M, **kw)
-            e1.record()
-            # algorithmic bytes: packed gate/up weights once + normalised activations in + SwiGLU activations out
-            recs.append((e0, e1, W.numel() * 2 + M * W.shape[1] * 2 + M * (W.shape[0] // 2) * 2))
-        else:
-            orig(pro, epi, x, W, M, **kw)
-    import vlaser_amd.engine as eng
-    eng.ops.skinny = hooked
-    try:
-        model.use_graph = False
-        for _ in range(3):
-            model.infer_action(ids_d, pv_d, proprios=pro_d, noise=noise_d, valid_len=valid)
-        torch.cuda.synchronize()
-    finally:
-        eng.ops.skinny = orig
-        model.use_graph = True
-    ms = [e0.elapsed_time(e1) for e0, e1, _ in recs]
-    return sum(ms) / len(ms), recs[0][2], len(ms)
+    def seq():
+        for lw in ex.layers:
+            ops.skinny(L.PRO_NORM, L.SK_SWIGLU, sb.hA, lw.sk_gu, M, partials=sb.part_o, n_partials=ex.ks_o, norm_w=lw.ln_post,
+                       eps=llm.rms_norm_eps, h_out=sb.hB, out=sb.act, ldo=llm.intermediate_size)
+    seq()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        seq()
+    g.replay()
+    torch.cuda.synchronize()
+    reps = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    n = reps * len(ex.layers)
+    w = ex.layers[0].sk_gu
+    # algorithmic bytes per launch: packed gate/up weights once + residual/partials in + SwiGLU activations out
+    byts = w.n_valid * w.K * 2 + M * w.K * 2 + ex.ks_o * M * w.K * 4 + M * (w.n_valid // 2) * 2
+    return e0.elapsed_time(e1) / n, byts, n
 
 
 if __name__ == '__main__':

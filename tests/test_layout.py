@@ -1,0 +1,129 @@
+"""Host-side contract checks that run without a GPU: the C-ABI library loads and exports every symbol declared in
+include/vlaser_hip.h, ctypes structs mirror the header, the product never imports the oracle, and the product fails
+loudly (no CPU fallback) when there is no GPU."""
+import ast
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header():
+    return open(os.path.join(ROOT, 'include', 'vlaser_hip.h')).read()
+
+
+def test_library_exports_every_declared_symbol():
+    from vlaser_amd import _lib
+    lib = _lib.lib()
+    names = set(re.findall(r'\b(?:int|const char\*)\s+(vlaser_\w+)\s*\(', _header()))
+    assert len(names) >= 20
+    for n in sorted(names):
+        assert hasattr(lib, n), f'{n} declared in include/vlaser_hip.h but not exported by libvlaser_hip.so'
+    assert lib.vlaser_abi_version() == 1
+    # every bound signature refers to a declared symbol
+    assert set(_lib._SIGS) <= names
+
+
+def _struct_fields(name):
+    h = _header()
+    end = h.index('} ' + name + ';')
+    body = h[h.rindex('typedef struct {', 0, end) + len('typedef struct {'):end]
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    fields = []
+    for stmt in body.split(';'):
+        stmt = stmt.strip()
+        if not stmt:
+            continue
+        for part in stmt.split(','):
+            ident = re.findall(r'(\w+)\s*$', part.strip().replace('*', ' '))
+            if ident:
+                fields.append(ident[0])
+    return fields
+
+
+@pytest.mark.parametrize('cname,pyname', [('VlaserGemmArgs', 'GemmArgs'), ('VlaserAttnArgs', 'AttnArgs'), ('VlaserSkinnyArgs', 'SkinnyArgs')])
+def test_ctypes_structs_mirror_header(cname, pyname):
+    from vlaser_amd import _lib
+    assert [f[0] for f in getattr(_lib, pyname)._fields_] == _struct_fields(cname)
+
+
+def test_enum_values_mirror_header():
+    from vlaser_amd import _lib
+    h = _header()
+    for name, val in re.findall(r'\b(VL_\w+)\s*=\s*(\d+)', h):
+        py = name[3:]
+        if hasattr(_lib, py):
+            assert getattr(_lib, py) == int(val), name
+
+
+def test_product_never_imports_oracle_or_reference():
+    pkg = os.path.join(ROOT, 'vlaser_amd')
+    for fn in os.listdir(pkg):
+        if not fn.endswith('.py'):
+            continue
+        tree = ast.parse(open(os.path.join(pkg, fn)).read())
+        for node in ast.walk(tree):
+            mods = []
+            if isinstance(node, ast.Import):
+                mods = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                mods = [node.module or '']
+            for m in mods:
+                assert not m.startswith('oracle') and 'ref_import' not in m, f'{fn} imports {m}'
+        assert '/root/reference' not in open(os.path.join(pkg, fn)).read()
+    for fn in ('bench.py', '__graft_entry__.py'):
+        assert '/root/reference' not in open(os.path.join(ROOT, fn)).read()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_no_cpu_fallback():
+    from vlaser_amd import _lib, config as C
+    from vlaser_amd.internvl_chat import InternVLChatModel
+    from vlaser_amd.pizero import PiZeroInference
+    with pytest.raises(_lib.VlaserHipError):
+        InternVLChatModel(C.vlaser_2b())
+    with pytest.raises(_lib.VlaserHipError):
+        PiZeroInference(C.VLAConfig())
+
+
+def test_bad_arguments_return_errors_not_crashes():
+    """Argument validation happens on the host before any launch, so it can be exercised without a GPU."""
+    from vlaser_amd import _lib
+    lib = _lib.lib()
+    a = _lib.GemmArgs()
+    assert lib.vlaser_gemm(0, ctypes.byref(a), None) != 0
+    assert b'null' in lib.vlaser_last_error()
+    a.A, a.W, a.out = 16, 16, 16
+    a.M, a.N, a.K, a.lda, a.ldw, a.ldo = 4, 4, 100, 104, 104, 4
+    assert lib.vlaser_gemm(0, ctypes.byref(a), None) != 0
+    assert b'multiple of 64' in lib.vlaser_last_error()
+    s = _lib.SkinnyArgs()
+    s.x, s.W, s.M, s.N, s.K, s.k_splits = 16, 16, 17, 32, 256, 1
+    assert lib.vlaser_skinny(0, 0, ctypes.byref(s), None) != 0
+    assert b'1..16' in lib.vlaser_last_error()
+
+
+def test_weight_packing_roundtrip():
+    """pack_qkv / pack_gate_up / pack_skinny are pure permutations (CPU check of the index maps)."""
+    from vlaser_amd import ops
+    perm = ops.head_perm(128)
+    assert sorted(perm.tolist()) == list(range(128))
+    # RoPE pair (d, d+64) lands 16 packed rows apart inside the same 32-row group
+    inv = torch.empty(128, dtype=torch.long); inv[perm] = torch.arange(128)
+    for d in range(64):
+        assert inv[d + 64] - inv[d] == 16 and inv[d] // 32 == inv[d + 64] // 32
+    g = torch.arange(64 * 8, dtype=torch.float32).view(64, 8); u = -g
+    gu = ops.pack_gate_up(g, u)
+    assert torch.equal(gu[0:16], g[0:16]) and torch.equal(gu[16:32], u[0:16]) and torch.equal(gu[32:48], g[16:32])
+    W = torch.arange(70 * 512, dtype=torch.float32).view(70, 512).to(torch.bfloat16)
+    for ks in (1, 2):
+        pw = ops.pack_skinny(W, ks)
+        assert pw.N == 96 and pw.n_valid == 70 and pw.t.numel() == 96 * 512
+        ns = 512 // (ks * 8 * 32)
+        v = pw.t.view(ks, 3, 8, ns, 2, 4, 16, 8)        # [ks, u, w, s, t, g, r, e]
+        k0 = 1 * (512 // ks) * 0 + 3 * ns * 32 + 0 * 32 + 2 * 8      # ks=0, wave 3, step 0, g=2
+        assert torch.equal(v[0, 1, 3, 0, 1, 2, 5], W[32 + 16 + 5, k0:k0 + 8])
