@@ -60,6 +60,9 @@ typedef struct {
   /* VL_EPI_PARTIAL */
   float* out_f32; int k_splits;
   int force_bm;             /* 0 = heuristic, else tile height 32 / 64 / 128 (tests) */
+  /* batched GEMM (attention backward through materialised per-head matrices): blockIdx.z = batch index z;
+   * A += z*a_bs, out += z*o_bs, W += (z / w_group)*w_bs  (element strides; batch 0/1 = plain GEMM) */
+  int batch; long long a_bs, w_bs, o_bs; int w_group;
 } VlaserGemmArgs;
 
 int vlaser_gemm(int epi, const VlaserGemmArgs* args, vl_stream_t stream);
@@ -177,6 +180,45 @@ int vlaser_ce_rows(const float* logits, const int64_t* labels, int R, int N, lon
  * and `h + ls*attn(...)`, norm2 / `h + ls*mlp(...)`, next norm1 (modeling_intern_vit.py:291-293). Row-wise, in place OK. */
 int vlaser_reduce_norm(const void* h_in, const float* partials, int n_partials, const void* bias, const void* ls, int norm_kind,
                        const void* norm_w, const void* norm_b, float eps, void* h_out, void* x_out, int M, int C, vl_stream_t stream);
+
+/* ---- SFT step: backward + optimizer kernels ---------------------------------------------------
+ * The trainable step reproduces HF Trainer + DeepSpeed bf16 semantics for InternVLChatModel.forward with labels
+ * (modeling_internvl_chat.py:143-255; internvl_chat_finetune.py:1041-1057; zero_stage1_config.json): bf16 params
+ * and grads, fp32 master weights and AdamW moments, per-layer activation recompute. GEMM-shaped work (dgrad, wgrad,
+ * attention backward through materialised per-head score matrices) reuses vlaser_gemm on transposed operands. */
+/* out[c*ld_out + r] = in[r*ld_in + c] for r < rows, 0 for rows <= r < pad_rows (bf16); batched with element strides */
+int vlaser_transpose(const void* in, void* out, int rows, int cols, int ld_in, int ld_out, int pad_rows, int batch, long long in_bs, long long out_bs,
+                     vl_stream_t stream);
+/* causal softmax of fp32 scores [B, S, ld] * scale -> P bf16 [B, S, ld] (0 beyond the diagonal / beyond S) */
+int vlaser_softmax_causal(const float* scores, void* P, int batch, int S, int ld, float scale, vl_stream_t stream);
+/* dS = P o (dP - D) * scale with D[q] = sum_d dO[q,d] O[q,d]; writes dS [H,S,ld] and the grouped transposes
+ * dS_T, P_T [n_kv, ld, G*ld] (key-major, contraction axis (g, q)) for the dK / dV GEMMs */
+int vlaser_attn_bwd_ds(const void* P, const float* dP, const void* dO, const void* O, void* dS, void* dS_T, void* P_T, int n_heads,
+                       int n_kv, int S, int ld, int hd, float scale, vl_stream_t stream);
+/* inverse RoPE on dq/dk + pack [dq | dk | dv] (natural [S, heads*128]) into the packed q/k/v column order */
+int vlaser_rope_bwd_pack(const void* dq, const void* dk, const void* dv, const float* rope_cos, const float* rope_sin, const int32_t* pos_ids,
+                         void* out_packed, int S, int n_q, int n_kv, vl_stream_t stream);
+/* Qwen2RMSNorm backward: dx_out = dres + rmsnorm_bwd(dy, x, w); dw_rows (fp32 [S, C] scratch-free): column sums go to dw
+ * through vlaser_colsum_mul.  x is the (bf16) norm input. */
+int vlaser_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* dres, void* dx_out, int S, int C, float eps, vl_stream_t stream);
+/* out[c] = sum_s a[s,c] * f(b)[s,c]: mode 0: 1; 1: b; 2: rmsnorm-normalised b (b = norm input); 3: layernorm-normalised b */
+int vlaser_colsum_mul(const void* a, const void* b, float* out, int S, int C, int mode, float eps, float* rowstat_ws /* float[2*S] for modes 2, 3 */, vl_stream_t stream);
+/* SwiGLU on the packed [gate16|up16] layout: act[s, I] from gu[s, 2I]; backward: dgu from (gu, dact) */
+int vlaser_swiglu(const void* gu, void* act, int S, int I, vl_stream_t stream);
+int vlaser_swiglu_bwd(const void* gu, const void* dact, void* dgu, int S, int I, vl_stream_t stream);
+/* dlogits[r, v] = (exp(logit - lse[r]) - [v == label]) * scale for label != ignore, else 0; bf16 [R, ld_out] zero padded */
+int vlaser_ce_dlogits(const float* logits, const float* lse, const int64_t* labels, void* out, int R, int V, long long ld_in, int ld_out,
+                      float scale, long long ignore_index, vl_stream_t stream);
+/* dEmbed[ids[s], :] += dh[s, :] for positions whose rank < 0 (text tokens); deterministic (sequential over positions) */
+int vlaser_embed_scatter_add(const int64_t* ids, const int32_t* rank, const void* dh, void* dembed, int n, int H, vl_stream_t stream);
+/* GELU(erf) backward: dx = dy * gelu'(x)  (x = pre-activation, bf16) */
+int vlaser_gelu_bwd(const void* x, const void* dy, void* dx, long long n, vl_stream_t stream);
+/* fused AdamW on a flat shard: g bf16 -> fp32 (times grad_scale), m/v/master fp32 updated, bf16 param written.
+ * DeepSpeed FusedAdam semantics (adam_w_mode): p = p*(1 - lr*wd) - lr * mhat / (sqrt(vhat) + eps). */
+int vlaser_adamw(void* param_bf16, float* master, float* m, float* v, const void* grad_bf16, long long n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, float grad_scale, int step, vl_stream_t stream);
+/* out[0] += sum of squares of a bf16 buffer (gradient norm); out must be zeroed by the caller */
+int vlaser_sumsq(const void* x, long long n, float* out, float* partial_ws /* float[1024] */, vl_stream_t stream);
 
 #ifdef __cplusplus
 }

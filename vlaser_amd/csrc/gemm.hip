@@ -178,8 +178,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   const int kc = a.K / (int)gridDim.y;                           // split-K slice of this block
   const int kbase = blockIdx.y * kc;
 
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
-  const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W);
+  const int bz = blockIdx.z;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A) + (size_t)bz * a.a_bs;
+  const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W) + (size_t)(a.w_group > 1 ? bz / a.w_group : bz) * a.w_bs;
 
   // staging map: thread -> (row = tid/8 + 32*i, slot = tid%8)
   const int srow = tid >> 3, sslot = tid & 7;
@@ -240,15 +241,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   }
 
   // epilogue: lane -> m = ... + (lane&15), n = ... + (lane>>4)*4 + reg
+  VlaserGemmArgs ea = a;      // batched: shift the output (bf16 / fp32 / partial) of this batch element
+  if (bz > 0) {
+    if (ea.out) ea.out = reinterpret_cast<char*>(ea.out) + (size_t)bz * a.o_bs * (EPI == VL_EPI_F32 ? 4 : 2);
+    if (ea.out_f32) ea.out_f32 += (size_t)bz * a.o_bs;
+    if (ea.res) ea.res = reinterpret_cast<const char*>(ea.res) + (size_t)bz * a.o_bs * 2;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m0 + wr * WTM + mt * 16 + fr;
     if constexpr (EPI == VL_EPI_SWIGLU || EPI == VL_EPI_QKV_ROPE) {
 #pragma unroll
-      for (int nt = 0; nt < NT; nt += 2) epilogue<EPI>(a, m, n0 + wc * WTN + nt * 16 + fq * 4, acc[nt][mt], acc[nt + 1][mt]);
+      for (int nt = 0; nt < NT; nt += 2) epilogue<EPI>(ea, m, n0 + wc * WTN + nt * 16 + fq * 4, acc[nt][mt], acc[nt + 1][mt]);
     } else {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) epilogue<EPI>(a, m, n0 + wc * WTN + nt * 16 + fq * 4, acc[nt][mt], acc[nt][mt]);
+      for (int nt = 0; nt < NT; ++nt) epilogue<EPI>(ea, m, n0 + wc * WTN + nt * 16 + fq * 4, acc[nt][mt], acc[nt][mt]);
     }
   }
 }
@@ -265,7 +272,7 @@ static int launch_bm(const VlaserGemmArgs* args, hipStream_t stream, int splits)
     VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<EPI, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<EPI, BM>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((gemm_kernel<EPI, BM>), dim3(p.tiles_m * p.tiles_n, splits, args->batch > 1 ? args->batch : 1), dim3(256), lds, stream, p);
   VL_LAUNCH_CHECK();
   return 0;
 }
@@ -275,7 +282,8 @@ template <int EPI>
 static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
   const int splits = (EPI == VL_EPI_PARTIAL && args->k_splits > 1) ? args->k_splits : 1;
   const int tn = (args->N + BN - 1) / BN;
-  auto blocks = [&](int bm) { return ((args->M + bm - 1) / bm) * tn * splits; };
+  const int nb = args->batch > 1 ? args->batch : 1;
+  auto blocks = [&](int bm) { return ((args->M + bm - 1) / bm) * tn * splits * nb; };
   int bm = args->force_bm;
   if (bm == 0) bm = blocks(128) >= 224 ? 128 : (blocks(64) >= 192 ? 64 : 32);
   if (bm == 128) return launch_bm<EPI, 128>(args, stream, splits);
@@ -288,6 +296,7 @@ extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   VL_CHECK(a && a->A && a->W, "vlaser_gemm: null operand");
   VL_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "vlaser_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
   VL_CHECK(a->K % BK == 0, "vlaser_gemm: K=%d must be a multiple of %d", a->K, BK);
+  VL_CHECK(a->batch <= 1 || (epi == VL_EPI_NONE || epi == VL_EPI_F32 || epi == VL_EPI_BIAS), "vlaser_gemm: batched mode supports NONE / F32 / BIAS epilogues");
   VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128, "vlaser_gemm: force_bm must be 0/32/64/128");
   VL_CHECK(a->lda % 8 == 0 && a->ldw % 8 == 0, "vlaser_gemm: lda/ldw must be multiples of 8 (16-byte rows)");
   VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm: operands must be 16-byte aligned");

@@ -1,0 +1,369 @@
+// Backward / optimizer kernels of the SFT step for gfx950.  All are HBM-bound row / element kernels:
+// 16-byte vector accesses where the layout allows, fp32 statistics, deterministic reductions (no atomics).
+// GEMM-shaped backward work (dgrad, wgrad, attention backward through materialised per-head score matrices) goes
+// through vlaser_gemm on transposed operands produced by transpose_kernel.
+#include "common.h"
+#include "../../include/vlaser_hip.h"
+
+// ---------------------------------------------------------------------------------------------- transpose (bf16)
+// out[b][c*ld_out + r] = in[b][r][c] for r < rows, 0 for rows <= r < pad_rows; 64x64 tiles through LDS.
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int rows, int cols, int ld_in,
+                                                        int ld_out, int pad_rows, long long in_bs, long long out_bs) {
+  __shared__ bf16_t tile[64][66];
+  const int b = blockIdx.z, r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const bf16_t* src = in + (size_t)b * in_bs;
+  bf16_t* dst = out + (size_t)b * out_bs;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(size_t)(r0 + r) * ld_in + c0 + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (c0 + c < cols && r0 + r < pad_rows) dst[(size_t)(c0 + c) * ld_out + r0 + r] = tile[r][c];
+  }
+}
+extern "C" int vlaser_transpose(const void* in, void* out, int rows, int cols, int ld_in, int ld_out, int pad_rows, int batch, long long in_bs,
+                                long long out_bs, vl_stream_t s) {
+  VL_CHECK(in && out && rows > 0 && cols > 0 && pad_rows >= rows && ld_out >= pad_rows && batch >= 1, "vlaser_transpose: bad args");
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 63) / 64, (pad_rows + 63) / 64, batch), dim3(256), 0, (hipStream_t)s, (const bf16_t*)in,
+                     (bf16_t*)out, rows, cols, ld_in, ld_out, pad_rows, in_bs, out_bs);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- causal softmax
+// P[b, q, k] = softmax_k(scale * scores[b, q, k]) over k <= q, 0 elsewhere (k < ld).  One wave per row.
+__global__ __launch_bounds__(256) void softmax_causal_kernel(const float* __restrict__ sc, bf16_t* __restrict__ P, int S, int ld, float scale) {
+  const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+  if (q >= S) return;
+  const float* row = sc + ((size_t)b * S + q) * ld;
+  bf16_t* prow = P + ((size_t)b * S + q) * ld;
+  float mx = -INFINITY;
+  for (int k = lane; k <= q; k += 64) mx = fmaxf(mx, row[k] * scale);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int k = lane; k <= q; k += 64) sum += __expf(row[k] * scale - mx);
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int k = lane; k < ld; k += 64) prow[k] = (k <= q) ? f32_to_bf16(__expf(row[k] * scale - mx) * inv) : (bf16_t)0;
+}
+extern "C" int vlaser_softmax_causal(const float* scores, void* P, int batch, int S, int ld, float scale, vl_stream_t s) {
+  VL_CHECK(scores && P && S > 0 && ld >= S, "vlaser_softmax_causal: bad args");
+  hipLaunchKernelGGL(softmax_causal_kernel, dim3((S + 3) / 4, batch), dim3(256), 0, (hipStream_t)s, scores, (bf16_t*)P, S, ld, scale);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- attention backward dS
+// D[q] = sum_d dO[q, h*hd + d] * O[q, h*hd + d];  dS[h,q,k] = P * (dP - D) * scale.
+// Writes dS [H, S, ld] and the grouped transposes dS_T / P_T [n_kv, ld(k), G*ld] at [kvh][k][g*ld + q] (zero padded rows/cols
+// come from the zero-initialised buffers: only k, q < S are written).  One wave per (h, q) row.
+__global__ __launch_bounds__(256) void attn_bwd_ds_kernel(const bf16_t* __restrict__ P, const float* __restrict__ dP, const bf16_t* __restrict__ dO,
+                                                          const bf16_t* __restrict__ O, bf16_t* __restrict__ dS, bf16_t* __restrict__ dS_T,
+                                                          bf16_t* __restrict__ P_T, int H, int n_kv, int S, int ld, int hd, float scale) {
+  const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y;
+  if (q >= S) return;
+  const int G = H / n_kv, kvh = h / G, g = h - kvh * G;
+  const bf16_t* dorow = dO + (size_t)q * H * hd + h * hd;
+  const bf16_t* orow = O + (size_t)q * H * hd + h * hd;
+  float d = 0.f;
+  for (int i = lane; i < hd; i += 64) d += bf16_to_f32(dorow[i]) * bf16_to_f32(orow[i]);
+  d = wave_sum(d);
+  const size_t ro = ((size_t)h * S + q) * ld;
+  bf16_t* dsT = dS_T + (size_t)kvh * ld * G * ld + (size_t)g * ld + q;
+  bf16_t* pT = P_T + (size_t)kvh * ld * G * ld + (size_t)g * ld + q;
+  for (int k = lane; k < ld; k += 64) {
+    const float p = bf16_to_f32(P[ro + k]);
+    const bf16_t ds = (k <= q) ? f32_to_bf16(p * (dP[ro + k] - d) * scale) : (bf16_t)0;
+    dS[ro + k] = ds;
+    if (k < S) {
+      dsT[(size_t)k * G * ld] = ds;
+      pT[(size_t)k * G * ld] = P[ro + k];
+    }
+  }
+}
+extern "C" int vlaser_attn_bwd_ds(const void* P, const float* dP, const void* dO, const void* O, void* dS, void* dS_T, void* P_T, int H, int n_kv,
+                                  int S, int ld, int hd, float scale, vl_stream_t s) {
+  VL_CHECK(P && dP && dO && O && dS && dS_T && P_T && H % n_kv == 0 && ld >= S, "vlaser_attn_bwd_ds: bad args");
+  hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3((S + 3) / 4, H), dim3(256), 0, (hipStream_t)s, (const bf16_t*)P, dP, (const bf16_t*)dO,
+                     (const bf16_t*)O, (bf16_t*)dS, (bf16_t*)dS_T, (bf16_t*)P_T, H, n_kv, S, ld, hd, scale);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- RoPE backward + pack
+// forward: o1 = x1 c - x2 s, o2 = x2 c + x1 s (x1 = d < 64, x2 = d + 64)  =>  dx1 = do1 c + do2 s, dx2 = do2 c - do1 s.
+// Output column order = packed q/k/v rows (ops.head_perm): col = head*128 + 32*(d/16) + 16*half + d%16, d in [0,64).
+__global__ __launch_bounds__(256) void rope_bwd_pack_kernel(const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dk, const bf16_t* __restrict__ dv,
+                                                            const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                            const int32_t* __restrict__ pos_ids, bf16_t* __restrict__ out, int n_q, int n_kv) {
+  const int s = blockIdx.x, nh = n_q + 2 * n_kv;
+  const int pos = pos_ids[s];
+  for (int i = threadIdx.x; i < nh * 64; i += 256) {
+    const int head = i >> 6, d = i & 63;
+    const bf16_t* src;
+    bool rot = true;
+    if (head < n_q) src = dq + (size_t)s * n_q * 128 + head * 128;
+    else if (head < n_q + n_kv) src = dk + (size_t)s * n_kv * 128 + (head - n_q) * 128;
+    else { src = dv + (size_t)s * n_kv * 128 + (head - n_q - n_kv) * 128; rot = false; }
+    const float g1 = bf16_to_f32(src[d]), g2 = bf16_to_f32(src[d + 64]);
+    float x1 = g1, x2 = g2;
+    if (rot) {
+      const float c = cosT[(size_t)pos * 64 + d], sn = sinT[(size_t)pos * 64 + d];
+      x1 = g1 * c + g2 * sn;
+      x2 = g2 * c - g1 * sn;
+    }
+    bf16_t* o = out + (size_t)s * nh * 128 + head * 128 + 32 * (d >> 4) + (d & 15);
+    o[0] = f32_to_bf16(x1);
+    o[16] = f32_to_bf16(x2);
+  }
+}
+extern "C" int vlaser_rope_bwd_pack(const void* dq, const void* dk, const void* dv, const float* c, const float* sn, const int32_t* pos, void* out,
+                                    int S, int n_q, int n_kv, vl_stream_t s) {
+  VL_CHECK(dq && dk && dv && c && sn && pos && out && S > 0, "vlaser_rope_bwd_pack: bad args");
+  hipLaunchKernelGGL(rope_bwd_pack_kernel, dim3(S), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dq, (const bf16_t*)dk, (const bf16_t*)dv, c, sn, pos,
+                     (bf16_t*)out, n_q, n_kv);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- RMSNorm backward
+// y = w * bf16(x rs), rs = rsqrt(mean(x^2) + eps).  dx = rs * (g - xhat * mean(g xhat)), g = w dy, xhat = x rs.
+// dx_out = dres + dx.  One wave per row.
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                          const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, int S, int C, float eps) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= S) return;
+  const size_t ro = (size_t)row * C;
+  float ss = 0.f, dot = 0.f;
+  for (int c = lane * 8; c < C; c += 512) {
+    const u32x4 xv = ld_global_16(x + ro + c), gv = ld_global_16(dy + ro + c), wv = ld_global_16(w + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x0 = bf16lo_to_f32(xv[j]), x1 = bf16hi_to_f32(xv[j]);
+      ss += x0 * x0 + x1 * x1;
+      dot += x0 * bf16lo_to_f32(gv[j]) * bf16lo_to_f32(wv[j]) + x1 * bf16hi_to_f32(gv[j]) * bf16hi_to_f32(wv[j]);
+    }
+  }
+  ss = wave_sum(ss);
+  dot = wave_sum(dot);
+  const float rs = rsqrtf(ss / (float)C + eps);
+  const float coef = dot * rs * rs * rs / (float)C;   // = rs * mean(g xhat) * rs
+  for (int c = lane * 8; c < C; c += 512) {
+    const u32x4 xv = ld_global_16(x + ro + c), gv = ld_global_16(dy + ro + c), wv = ld_global_16(w + c);
+    u32x4 rv = {0, 0, 0, 0};
+    if (dres) rv = ld_global_16(dres + ro + c);
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float lo = bf16lo_to_f32(rv[j]) + rs * bf16lo_to_f32(gv[j]) * bf16lo_to_f32(wv[j]) - coef * bf16lo_to_f32(xv[j]);
+      const float hi = bf16hi_to_f32(rv[j]) + rs * bf16hi_to_f32(gv[j]) * bf16hi_to_f32(wv[j]) - coef * bf16hi_to_f32(xv[j]);
+      o[j] = pack_bf16x2(lo, hi);
+    }
+    st_global_16(dx + ro + c, o);
+  }
+}
+extern "C" int vlaser_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* dres, void* dx, int S, int C, float eps, vl_stream_t s) {
+  VL_CHECK(dy && x && w && dx && S > 0 && C % 8 == 0, "vlaser_rmsnorm_bwd: bad args");
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((S + 3) / 4), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w,
+                     (const bf16_t*)dres, (bf16_t*)dx, S, C, eps);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- column sums
+// out[c] = sum_s a[s,c] * f(s,c): mode 0: 1; mode 1: b[s,c]; mode 2: b[s,c] * rs_s (rs recomputed per row from b);
+// mode 3: LayerNorm-normalised b ((b - mean_s) * rs_s).  Block = 64 columns x 4 row-slices; deterministic.
+__global__ __launch_bounds__(256) void colsum_mul_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const float* __restrict__ rowstat,
+                                                         float* __restrict__ out, int S, int C, int mode) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < C) {
+    for (int s = slice; s < S; s += 4) {
+      float v = bf16_to_f32(a[(size_t)s * C + c]);
+      if (mode == 1) v *= bf16_to_f32(b[(size_t)s * C + c]);
+      else if (mode == 2) v *= bf16_to_f32(b[(size_t)s * C + c]) * rowstat[2 * s + 1];
+      else if (mode == 3) v *= (bf16_to_f32(b[(size_t)s * C + c]) - rowstat[2 * s]) * rowstat[2 * s + 1];
+      acc += v;
+    }
+  }
+  red[slice][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (slice == 0 && c < C) out[c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+// per-row statistics (mean, rs) of a bf16 matrix: rms mode (mean = 0, rs = rsqrt(mean(x^2)+eps)) or layernorm mode
+__global__ __launch_bounds__(256) void rowstat_kernel(const bf16_t* __restrict__ x, float* __restrict__ st, int S, int C, float eps, int layernorm) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= S) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < C; c += 64) { const float v = bf16_to_f32(x[(size_t)row * C + c]); s1 += v; s2 += v * v; }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  float mean = 0.f, rs;
+  if (layernorm) {
+    mean = s1 / (float)C;
+    float vs = 0.f;
+    for (int c = lane; c < C; c += 64) { const float v = bf16_to_f32(x[(size_t)row * C + c]) - mean; vs += v * v; }
+    vs = wave_sum(vs);
+    rs = rsqrtf(vs / (float)C + eps);
+  } else {
+    rs = rsqrtf(s2 / (float)C + eps);
+  }
+  if (lane == 0) { st[2 * row] = mean; st[2 * row + 1] = rs; }
+}
+extern "C" int vlaser_colsum_mul(const void* a, const void* b, float* out, int S, int C, int mode, float eps, float* rowstat_ws, vl_stream_t s) {
+  VL_CHECK(a && out && S > 0 && C > 0 && mode >= 0 && mode <= 3 && (mode == 0 || b), "vlaser_colsum_mul: bad args");
+  VL_CHECK(mode < 2 || rowstat_ws, "vlaser_colsum_mul: modes 2/3 need a float[2*S] row-statistics workspace");
+  float* st = rowstat_ws;
+  if (mode >= 2) {
+    hipLaunchKernelGGL(rowstat_kernel, dim3((S + 3) / 4), dim3(256), 0, (hipStream_t)s, (const bf16_t*)b, st, S, C, eps, mode == 3);
+  }
+  hipLaunchKernelGGL(colsum_mul_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)s, (const bf16_t*)a, (const bf16_t*)b, st, out, S, C, mode);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- SwiGLU fwd / bwd
+// packed layout: columns [32j, 32j+16) = gate channels 16j.., [32j+16, 32j+32) = up channels 16j..
+__global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act, long long n, int I) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long s = i / I;
+    const int c = (int)(i - s * I);
+    const bf16_t* p = gu + s * 2 * I + (c >> 4) * 32 + (c & 15);
+    const float g = bf16_to_f32(p[0]), u = bf16_to_f32(p[16]);
+    act[i] = f32_to_bf16(round_bf16(silu(g)) * u);
+  }
+}
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dact, bf16_t* __restrict__ dgu,
+                                                         long long n, int I) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long s = i / I;
+    const int c = (int)(i - s * I);
+    const size_t o = s * 2 * I + (c >> 4) * 32 + (c & 15);
+    const float g = bf16_to_f32(gu[o]), u = bf16_to_f32(gu[o + 16]), d = bf16_to_f32(dact[i]);
+    const float sig = 1.0f / (1.0f + __expf(-g));
+    dgu[o] = f32_to_bf16(d * u * sig * (1.0f + g * (1.0f - sig)));
+    dgu[o + 16] = f32_to_bf16(d * g * sig);
+  }
+}
+extern "C" int vlaser_swiglu(const void* gu, void* act, int S, int I, vl_stream_t s) {
+  VL_CHECK(gu && act && S > 0 && I % 16 == 0, "vlaser_swiglu: bad args");
+  hipLaunchKernelGGL(swiglu_kernel, dim3(2048), dim3(256), 0, (hipStream_t)s, (const bf16_t*)gu, (bf16_t*)act, (long long)S * I, I);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vlaser_swiglu_bwd(const void* gu, const void* dact, void* dgu, int S, int I, vl_stream_t s) {
+  VL_CHECK(gu && dact && dgu && S > 0 && I % 16 == 0, "vlaser_swiglu_bwd: bad args");
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(2048), dim3(256), 0, (hipStream_t)s, (const bf16_t*)gu, (const bf16_t*)dact, (bf16_t*)dgu, (long long)S * I, I);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- CE backward
+__global__ __launch_bounds__(256) void ce_dlogits_kernel(const float* __restrict__ logits, const float* __restrict__ lse, const int64_t* __restrict__ labels,
+                                                         bf16_t* __restrict__ out, int V, long long ld_in, int ld_out, float scale, long long ignore) {
+  const int r = blockIdx.y;
+  const int64_t lab = labels[r];
+  const float l = lse[r];
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < ld_out; v += gridDim.x * 256) {
+    float g = 0.f;
+    if (v < V && lab != ignore) g = (__expf(logits[(size_t)r * ld_in + v] - l) - (v == lab ? 1.f : 0.f)) * scale;
+    out[(size_t)r * ld_out + v] = f32_to_bf16(g);
+  }
+}
+extern "C" int vlaser_ce_dlogits(const float* logits, const float* lse, const int64_t* labels, void* out, int R, int V, long long ld_in, int ld_out,
+                                 float scale, long long ignore, vl_stream_t s) {
+  VL_CHECK(logits && lse && labels && out && R > 0 && ld_out >= V, "vlaser_ce_dlogits: bad args");
+  hipLaunchKernelGGL(ce_dlogits_kernel, dim3(64, R), dim3(256), 0, (hipStream_t)s, logits, lse, labels, (bf16_t*)out, V, ld_in, ld_out, scale, ignore);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- embedding backward
+// dEmbed[ids[s]] += dh[s] for text positions (rank < 0); one block per 64-column slice walks the positions in order
+__global__ __launch_bounds__(64) void embed_scatter_add_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ rank,
+                                                               const bf16_t* __restrict__ dh, bf16_t* __restrict__ dembed, int n, int H) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= H) return;
+  for (int s = 0; s < n; ++s) {
+    if (rank[s] >= 0) continue;
+    bf16_t* p = dembed + (size_t)ids[s] * H + c;
+    *p = f32_to_bf16(bf16_to_f32(*p) + bf16_to_f32(dh[(size_t)s * H + c]));
+  }
+}
+extern "C" int vlaser_embed_scatter_add(const int64_t* ids, const int32_t* rank, const void* dh, void* dembed, int n, int H, vl_stream_t s) {
+  VL_CHECK(ids && rank && dh && dembed && n > 0, "vlaser_embed_scatter_add: bad args");
+  hipLaunchKernelGGL(embed_scatter_add_kernel, dim3((H + 63) / 64), dim3(64), 0, (hipStream_t)s, ids, rank, (const bf16_t*)dh, (bf16_t*)dembed, n, H);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- GELU backward
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = bf16_to_f32(x[i]);
+    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
+    dx[i] = f32_to_bf16(bf16_to_f32(dy[i]) * (cdf + v * pdf));
+  }
+}
+extern "C" int vlaser_gelu_bwd(const void* x, const void* dy, void* dx, long long n, vl_stream_t s) {
+  VL_CHECK(x && dy && dx && n > 0, "vlaser_gelu_bwd: bad args");
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- fused AdamW
+// DeepSpeed FusedAdam (adam_w_mode=1, bias_correction=1) on fp32 master weights; bf16 params refreshed from the master.
+__global__ __launch_bounds__(256) void adamw_kernel(bf16_t* __restrict__ p, float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
+                                                    const bf16_t* __restrict__ g, long long n, float lr, float b1, float b2, float eps, float wd,
+                                                    float gscale, float bc1, float bc2) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gr = bf16_to_f32(g[i]) * gscale;
+    const float mi = b1 * m[i] + (1.0f - b1) * gr;
+    const float vi = b2 * v[i] + (1.0f - b2) * gr * gr;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    float w = master[i];
+    w = w * (1.0f - lr * wd) - (lr / bc1) * (mi / denom);
+    master[i] = w;
+    p[i] = f32_to_bf16(w);
+  }
+}
+extern "C" int vlaser_adamw(void* p, float* master, float* m, float* v, const void* g, long long n, float lr, float b1, float b2, float eps, float wd,
+                            float gscale, int step, vl_stream_t s) {
+  VL_CHECK(p && master && m && v && g && n > 0 && step >= 1, "vlaser_adamw: bad args");
+  const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (bf16_t*)p, master, m, v, (const bf16_t*)g, n, lr, b1, b2, eps, wd,
+                     gscale, bc1, bc2);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- sum of squares
+__global__ __launch_bounds__(256) void sumsq_kernel(const bf16_t* __restrict__ x, long long n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) { const float v = bf16_to_f32(x[i]); acc += v * v; }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sumsq_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) acc += partial[i];
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) out[0] += acc;
+}
+extern "C" int vlaser_sumsq(const void* x, long long n, float* out, float* partial_ws, vl_stream_t s) {
+  VL_CHECK(x && out && partial_ws && n > 0, "vlaser_sumsq: bad args (partial_ws = float[1024] workspace)");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, n, partial_ws);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partial_ws, 1024, out);
+  VL_LAUNCH_CHECK();
+  return 0;
+}

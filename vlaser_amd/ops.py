@@ -76,6 +76,20 @@ def gemm(epi, A, W, out=None, bias=None, res=None, ls=None, N=None, **kw):
     return out
 
 
+def gemm_raw(epi, A, W, out, M, N, K, lda, ldw, ldo, **kw):
+    """Fully explicit GEMM call (views / batched operands): pointers from the tensors, geometry from the arguments."""
+    a = L.GemmArgs()
+    a.A, a.W = A.data_ptr(), W.data_ptr()
+    a.M, a.N, a.K, a.lda, a.ldw, a.ldo = M, N, K, lda, ldw, ldo
+    if epi in (L.EPI_PARTIAL,):
+        a.out_f32 = out.data_ptr()
+    else:
+        a.out = out.data_ptr()
+    for k, v in kw.items():
+        setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    L.check(L.lib().vlaser_gemm(epi, C.byref(a), _stream()), 'vlaser_gemm')
+
+
 def linear(x, W, bias=None, epi=None, res=None, ls=None, out=None, out_dtype=BF16):
     """out[M,N] = epi(x @ W^T)."""
     M, N = x.shape[0], W.shape[0]
@@ -278,3 +292,70 @@ def gemm_splits(M, N, K, target_blocks=256):
 
 def cast_f32_bf16(x, y):
     L.check(L.lib().vlaser_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), 'vlaser_cast_f32_bf16')
+
+
+# ------------------------------------------------------------------------------------------------ SFT (backward / optimizer)
+def transpose(x, out, rows, cols, ld_in, ld_out, pad_rows=None, batch=1, in_bs=0, out_bs=0):
+    L.check(L.lib().vlaser_transpose(x.data_ptr(), out.data_ptr(), rows, cols, ld_in, ld_out, ld_out if pad_rows is None else pad_rows, batch,
+                                     in_bs, out_bs, _stream()), 'vlaser_transpose')
+
+
+def softmax_causal(scores, P, batch, S, ld, scale):
+    L.check(L.lib().vlaser_softmax_causal(scores.data_ptr(), P.data_ptr(), batch, S, ld, scale, _stream()), 'vlaser_softmax_causal')
+
+
+def attn_bwd_ds(P, dP, dO, O, dS, dS_T, P_T, H, n_kv, S, ld, hd, scale):
+    L.check(L.lib().vlaser_attn_bwd_ds(P.data_ptr(), dP.data_ptr(), dO.data_ptr(), O.data_ptr(), dS.data_ptr(), dS_T.data_ptr(), P_T.data_ptr(),
+                                       H, n_kv, S, ld, hd, scale, _stream()), 'vlaser_attn_bwd_ds')
+
+
+def rope_bwd_pack(dq, dk, dv, cos, sin, pos, out, S, n_q, n_kv):
+    L.check(L.lib().vlaser_rope_bwd_pack(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), cos.data_ptr(), sin.data_ptr(), pos.data_ptr(),
+                                         out.data_ptr(), S, n_q, n_kv, _stream()), 'vlaser_rope_bwd_pack')
+
+
+def rmsnorm_bwd(dy, x, w, dres, dx, S, Cc, eps):
+    L.check(L.lib().vlaser_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), _p(dres), dx.data_ptr(), S, Cc, eps, _stream()),
+            'vlaser_rmsnorm_bwd')
+
+
+def colsum_mul(a, b, out, S, Cc, mode=0, eps=1e-6, ws=None):
+    L.check(L.lib().vlaser_colsum_mul(a.data_ptr(), _p(b), out.data_ptr(), S, Cc, mode, eps, _p(ws), _stream()), 'vlaser_colsum_mul')
+
+
+def swiglu(gu, act, S, I):
+    L.check(L.lib().vlaser_swiglu(gu.data_ptr(), act.data_ptr(), S, I, _stream()), 'vlaser_swiglu')
+
+
+def swiglu_bwd(gu, dact, dgu, S, I):
+    L.check(L.lib().vlaser_swiglu_bwd(gu.data_ptr(), dact.data_ptr(), dgu.data_ptr(), S, I, _stream()), 'vlaser_swiglu_bwd')
+
+
+def ce_rows(logits, labels, loss_rows, lse_rows, ignore_index=-100):
+    R, V = logits.shape
+    L.check(L.lib().vlaser_ce_rows(logits.data_ptr(), labels.data_ptr(), R, V, logits.stride(0), loss_rows.data_ptr(), _p(lse_rows),
+                                   ignore_index, _stream()), 'vlaser_ce_rows')
+
+
+def ce_dlogits(logits, lse, labels, out, scale, ignore_index=-100):
+    R, V = logits.shape
+    L.check(L.lib().vlaser_ce_dlogits(logits.data_ptr(), lse.data_ptr(), labels.data_ptr(), out.data_ptr(), R, V, logits.stride(0), out.stride(0),
+                                      scale, ignore_index, _stream()), 'vlaser_ce_dlogits')
+
+
+def embed_scatter_add(ids, rank, dh, dembed, n, H):
+    L.check(L.lib().vlaser_embed_scatter_add(ids.data_ptr(), rank.data_ptr(), dh.data_ptr(), dembed.data_ptr(), n, H, _stream()),
+            'vlaser_embed_scatter_add')
+
+
+def gelu_bwd(x, dy, dx):
+    L.check(L.lib().vlaser_gelu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _stream()), 'vlaser_gelu_bwd')
+
+
+def adamw(param, master, m, v, grad, lr, beta1, beta2, eps, wd, gscale, step):
+    L.check(L.lib().vlaser_adamw(param.data_ptr(), master.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), param.numel(), lr, beta1, beta2,
+                                 eps, wd, gscale, step, _stream()), 'vlaser_adamw')
+
+
+def sumsq(x, out, ws):
+    L.check(L.lib().vlaser_sumsq(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), _stream()), 'vlaser_sumsq')

@@ -1,10 +1,32 @@
-"""SFT-step pieces (modeling_internvl_chat.py:204-243 + the data-parallel step of SURVEY.md 8 a15).
-Round 1 holds the loss head only; the trainable step (backward kernels, fused AdamW, bucketed RCCL gradient
-reduction) is the next row of the scope table."""
+"""SFT data-parallel step of InternVLChatModel on MI355X.
+
+Reproduces the step semantics of the reference's SFT launcher
+(`internvl_chat_finetune.py:798-1068` + `shell/internvl3.0/2nd_finetune/internvl3_2b_dynamic_res_2nd_finetune_full.sh:25-69`
++ `zero_stage1_config.json`) without its control plane (HF Trainer / DeepSpeed):
+
+  * forward  = `InternVLChatModel.forward` with labels (`modeling_internvl_chat.py:143-255`): frozen ViT, trainable mlp1 + LLM,
+    visual-token scatter, shifted CrossEntropy (mean over labels != -100);
+  * backward with per-layer activation recompute (the reference checkpoints every LLM layer, `internvl_chat_finetune.py:975-979`);
+  * data parallelism: micro-batch sharded over ranks, gradients averaged with bucketed RCCL reduce-scatter issued as soon as a
+    bucket's layers have finished their backward (overlaps the remaining backward), ZeRO-1: every rank owns 1/N of each bucket's
+    fp32 master weights + AdamW moments, updates its shard, all-gathers the bf16 parameters;
+  * AdamW (beta .9/.999, eps 1e-8, weight decay, bias correction) on fp32 masters, bf16 params/grads, grad-norm clipping.
+
+All arithmetic runs in hand-written gfx950 kernels (vlaser_amd/csrc); torch is device memory, streams and RCCL.
+Parameters live in ONE flat bf16 buffer in kernel layout (q/k/v fused+permuted, gate/up interleaved) ordered
+[lm_head, final norm, layer L-1 ... layer 0, embed_tokens, mlp1] so gradient buckets complete front to back.
+"""
+import math
+from types import SimpleNamespace
+
 import torch
 
 from . import _lib as L
-from .ops import _stream
+from . import dp, ops
+from .config import VlaserConfig
+from .engine import BF, KVCache, VitEngine
+
+F32 = torch.float32
 
 
 def ce_loss(logits, labels, ignore_index=-100):
@@ -14,7 +36,492 @@ def ce_loss(logits, labels, ignore_index=-100):
     labels = labels.to(device=logits.device, dtype=torch.int64).contiguous()
     R, V = logits.shape
     rows = torch.empty(R, dtype=torch.float32, device=logits.device)
-    L.check(L.lib().vlaser_ce_rows(logits.data_ptr(), labels.data_ptr(), R, V, logits.stride(0), rows.data_ptr(), None,
-                                   ignore_index, _stream()), 'vlaser_ce_rows')
+    ops.ce_rows(logits, labels, rows, None, ignore_index)
     n = (labels != ignore_index).sum().clamp(min=1)
     return rows.sum() / n
+
+
+class FlatParams:
+    """Flat bf16 parameter / gradient buffers with named views (+ fp32 master / moments for the local ZeRO-1 shard)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.specs = []          # (name, shape, offset)
+        self.n = 0
+
+    def add(self, name, shape):
+        numel = 1
+        for s in shape:
+            numel *= s
+        self.specs.append((name, tuple(shape), self.n))
+        self.n += (numel + 127) // 128 * 128          # 256-byte aligned views
+        return len(self.specs) - 1
+
+    def finalize(self, pad_to=1):
+        self.n = (self.n + pad_to - 1) // pad_to * pad_to
+        self.p = torch.zeros(self.n, dtype=BF, device=self.device)
+        self.g = torch.zeros(self.n, dtype=BF, device=self.device)
+        self.view = {}
+        self.gview = {}
+        for name, shape, off in self.specs:
+            numel = 1
+            for s in shape:
+                numel *= s
+            self.view[name] = self.p[off:off + numel].view(shape)
+            self.gview[name] = self.g[off:off + numel].view(shape)
+
+    def offset_of(self, name):
+        for n, _, off in self.specs:
+            if n == name:
+                return off
+        raise KeyError(name)
+
+
+class SFTModel:
+    """Trainable Vlaser-2B SFT step (per rank).  `step(pixel_values, input_ids, labels)` runs forward, backward, the
+    gradient exchange and the optimizer update and returns the (rank-local) loss."""
+
+    def __init__(self, cfg: VlaserConfig, device='cuda', max_seq_len=576, max_tiles=1, lr=2e-5, weight_decay=0.05, betas=(0.9, 0.999),
+                 eps=1e-8, max_grad_norm=1.0, process_group=None, bucket_layers=4, seed_state_dict=None):
+        L.lib()
+        if not torch.cuda.is_available():
+            raise L.VlaserHipError('vlaser_amd needs an MI355X (gfx950) GPU: there is no CPU fallback')
+        self.cfg, self.device = cfg, torch.device(device)
+        self.llm = cfg.llm
+        self.S_max = (max_seq_len + 63) // 64 * 64
+        self.lr, self.wd, self.betas, self.eps, self.max_grad_norm = lr, weight_decay, betas, eps, max_grad_norm
+        self.pg = process_group
+        self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
+        self.rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
+        self.bucket_layers = bucket_layers
+        self.step_count = 0
+        self.img_context_token_id = cfg.img_context_token_id
+        self.max_tiles = max_tiles
+        if seed_state_dict is not None:
+            self.load_state_dict(seed_state_dict)
+
+    # ------------------------------------------------------------------ parameters
+    def load_state_dict(self, sd):
+        cfg, llm, dev = self.cfg, self.llm, self.device
+        self.vit = VitEngine(sd, cfg, dev, max_tiles=self.max_tiles)     # frozen (freeze_backbone True)
+        H, I, V = llm.hidden_size, llm.intermediate_size, llm.vocab_size
+        nq, nkv, hd = llm.num_attention_heads, llm.num_key_value_heads, llm.head_dim
+        NQ = (nq + 2 * nkv) * hd
+        self.Vp = (V + 63) // 64 * 64
+        fp = FlatParams(dev)
+        fp.add('head', (V, H))
+        fp.add('norm', (H,))
+        self.bucket_bounds = [0]                  # flat offsets where a gradient bucket ends
+        for i in reversed(range(llm.num_hidden_layers)):
+            for nm, shp in [('wqkv', (NQ, H)), ('bqkv', (NQ,)), ('wo', (H, nq * hd)), ('wgu', (2 * I, H)), ('wdown', (H, I)), ('ln_in', (H,)),
+                            ('ln_post', (H,))]:
+                fp.add(f'l{i}.{nm}', shp)
+        fp.add('embed', (V, H))
+        C4 = cfg.vision.hidden_size * 4
+        for nm, shp in [('m0w', (C4,)), ('m0b', (C4,)), ('m1w', (H, C4)), ('m1b', (H,)), ('m3w', (H, H)), ('m3b', (H,))]:
+            fp.add('mlp1.' + nm, shp)
+        fp.finalize(pad_to=128 * self.world * 8)
+        self.fp = fp
+        g = lambda k: sd[k].to(device=dev, dtype=BF)
+        fp.view['head'].copy_(g('language_model.lm_head.weight'))
+        fp.view['norm'].copy_(g('language_model.model.norm.weight'))
+        fp.view['embed'].copy_(g('language_model.model.embed_tokens.weight'))
+        for i in range(llm.num_hidden_layers):
+            p = f'language_model.model.layers.{i}.'
+            wqkv, bqkv = ops.pack_qkv(g(p + 'self_attn.q_proj.weight'), g(p + 'self_attn.k_proj.weight'), g(p + 'self_attn.v_proj.weight'),
+                                      g(p + 'self_attn.q_proj.bias'), g(p + 'self_attn.k_proj.bias'), g(p + 'self_attn.v_proj.bias'), hd)
+            fp.view[f'l{i}.wqkv'].copy_(wqkv); fp.view[f'l{i}.bqkv'].copy_(bqkv)
+            fp.view[f'l{i}.wo'].copy_(g(p + 'self_attn.o_proj.weight'))
+            fp.view[f'l{i}.wgu'].copy_(ops.pack_gate_up(g(p + 'mlp.gate_proj.weight'), g(p + 'mlp.up_proj.weight')))
+            fp.view[f'l{i}.wdown'].copy_(g(p + 'mlp.down_proj.weight'))
+            fp.view[f'l{i}.ln_in'].copy_(g(p + 'input_layernorm.weight'))
+            fp.view[f'l{i}.ln_post'].copy_(g(p + 'post_attention_layernorm.weight'))
+        for nm, k in [('m0w', 'mlp1.0.weight'), ('m0b', 'mlp1.0.bias'), ('m1w', 'mlp1.1.weight'), ('m1b', 'mlp1.1.bias'),
+                      ('m3w', 'mlp1.3.weight'), ('m3b', 'mlp1.3.bias')]:
+            fp.view['mlp1.' + nm].copy_(g(k))
+        # gradient buckets: [head+norm], groups of `bucket_layers` layers (reverse order), [embed+mlp1]; each padded to world*128
+        bounds = [fp.offset_of(f'l{llm.num_hidden_layers - 1}.wqkv')]
+        layers_rev = list(reversed(range(llm.num_hidden_layers)))
+        for j in range(self.bucket_layers, llm.num_hidden_layers, self.bucket_layers):
+            bounds.append(fp.offset_of(f'l{layers_rev[j]}.wqkv'))
+        bounds.append(fp.offset_of('embed'))
+        bounds.append(fp.n)
+        self.buckets = []
+        lo = 0
+        for hi in bounds:
+            if hi > lo:
+                self.buckets.append((lo, hi))
+                lo = hi
+        # ZeRO-1: every rank owns the slice [lo + r*len/N, lo + (r+1)*len/N) of each bucket (bucket lengths are multiples of 128;
+        # uneven division is handled by padding the reduce-scatter input)
+        self.shards = dp.plan_shards(self.buckets, self.world, self.rank)
+        n_shard = sum(hi - lo for lo, hi, _ in self.shards)
+        self.master = torch.zeros(n_shard, dtype=F32, device=dev)
+        self.m = torch.zeros(n_shard, dtype=F32, device=dev)
+        self.v = torch.zeros(n_shard, dtype=F32, device=dev)
+        o = 0
+        self.shard_off = []
+        for lo, hi, _ in self.shards:
+            self.master[o:o + hi - lo].copy_(fp.p[lo:hi].float())
+            self.shard_off.append(o)
+            o += hi - lo
+        self._alloc_workspace()
+        self._refresh_transposes()
+        return self
+
+    def _alloc_workspace(self):
+        cfg, llm, dev = self.cfg, self.llm, self.device
+        H, I, V = llm.hidden_size, llm.intermediate_size, llm.vocab_size
+        nq, nkv, hd = llm.num_attention_heads, llm.num_key_value_heads, llm.head_dim
+        NQ = (nq + 2 * nkv) * hd
+        S, Lyr = self.S_max, llm.num_hidden_layers
+        z = lambda *s, dt=BF: torch.zeros(*s, dtype=dt, device=dev)
+        C4 = cfg.vision.hidden_size * 4
+        # derived (non-parameter) transposed weights for the dgrad GEMMs
+        self.wT = {}
+        for i in range(Lyr):
+            self.wT[i] = dict(wqkv=z(H, NQ), wo=z(nq * hd, H), wgu=z(H, 2 * I), wdown=z(I, H))
+        self.headT = z(H, self.Vp)
+        self.m1wT, self.m3wT = z(C4, H), z(H, H)
+        # activations
+        self.h_in = z(Lyr + 1, S, H)               # layer inputs (checkpoints) + final hidden
+        self.cache = KVCache(1, 1, nkv, S, dev, hd)     # one layer's K / V^T (recomputed per layer)
+        self.rope = ops.rope_table(S + 8, hd, llm.rope_theta, dev)
+        self.x1, self.x2, self.h2 = z(S, H), z(S, H), z(S, H)
+        self.q, self.ao = z(S, nq * hd), z(S, nq * hd)
+        self.gu, self.act = z(S, 2 * I), z(S, I)
+        self.part = torch.zeros(8 * S * H, dtype=F32, device=dev)
+        self.xn = z(S, H)
+        # backward buffers
+        self.dh, self.dh2, self.dx = z(S, H), z(S, H), z(S, H)
+        self.dact, self.dgu = z(S, I), z(S, 2 * I)
+        self.dao, self.dq, self.dk, self.dv = z(S, nq * hd), z(S, nq * hd), z(S, nkv * hd), z(S, nkv * hd)
+        self.dqkv = z(S, NQ)
+        G = nq // nkv
+        self.sc = torch.zeros(nq, S, S, dtype=F32, device=dev)
+        self.dP = torch.zeros(nq, S, S, dtype=F32, device=dev)
+        self.P, self.dS = z(nq, S, S), z(nq, S, S)
+        self.dS_T, self.P_T = z(nkv, S, G * S), z(nkv, S, G * S)
+        self.Vn, self.KT = z(nkv, S, hd), z(nkv, hd, S)
+        self.QT, self.dOT = z(nkv, hd, G * S), z(nkv, hd, G * S)
+        self.tA = z(max(2 * I, NQ, H, C4) * S)      # transposed-activation scratch (dY^T)
+        self.tB = z(max(I, H, nq * hd, C4) * S)     # transposed-activation scratch (X^T)
+        self.col = torch.zeros(max(2 * I, NQ, C4, H), dtype=F32, device=dev)
+        self.rowstat = torch.zeros(2 * max(S, self.max_tiles * cfg.num_image_token), dtype=F32, device=dev)
+        self.sumsq_ws = torch.zeros(1024, dtype=F32, device=dev)
+        self.gnorm2 = torch.zeros(1, dtype=F32, device=dev)
+        self.rank_ws = torch.zeros(S, dtype=torch.int32, device=dev)
+        # mlp1
+        nt = self.max_tiles * cfg.num_image_token
+        self.ps_raw, self.ps_ln = z(nt, C4), z(nt, C4)
+        self.z1, self.g1, self.feat = z(nt, H), z(nt, H), z(nt, H)
+        self.dvit, self.dg1, self.dz1, self.dln = z(nt, H), z(nt, H), z(nt, H), z(nt, C4)
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+
+    def _refresh_transposes(self):
+        """W^T copies used by the dgrad GEMMs (dX = dY @ W needs W with the contraction axis contiguous)."""
+        v = self.fp.view
+        for i in range(self.llm.num_hidden_layers):
+            for nm in ('wqkv', 'wo', 'wgu', 'wdown'):
+                w = v[f'l{i}.{nm}']
+                ops.transpose(w, self.wT[i][nm], w.shape[0], w.shape[1], w.shape[1], w.shape[0])
+        ops.transpose(v['head'], self.headT, v['head'].shape[0], v['head'].shape[1], v['head'].shape[1], self.Vp)
+        ops.transpose(v['mlp1.m1w'], self.m1wT, *v['mlp1.m1w'].shape, v['mlp1.m1w'].shape[1], v['mlp1.m1w'].shape[0])
+        ops.transpose(v['mlp1.m3w'], self.m3wT, *v['mlp1.m3w'].shape, v['mlp1.m3w'].shape[1], v['mlp1.m3w'].shape[0])
+
+    # ------------------------------------------------------------------ small helpers
+    def _wgrad(self, dY, X, out, S, bias_out=None):
+        """out[N,K] = dY[S,N]^T @ X[S,K] (bf16): both operands transposed to [*, Sp] (zero padded) then one NT GEMM."""
+        N, K = dY.shape[1], X.shape[1]
+        Sp = (S + 63) // 64 * 64
+        tA = self.tA[:N * Sp].view(N, Sp)
+        tB = self.tB[:K * Sp].view(K, Sp)
+        ops.transpose(dY, tA, S, N, dY.stride(0), Sp)
+        ops.transpose(X, tB, S, K, X.stride(0), Sp)
+        ops.gemm(L.EPI_NONE, tA, tB, out=out)
+        if bias_out is not None:
+            ops.colsum_mul(dY, None, self.col, S, N, 0)
+            bias_out.copy_(self.col[:N])
+
+    def _norm_wgrad(self, dy, x, out, S, Cc, mode=2, eps=1e-6):
+        ops.colsum_mul(dy, x, self.col, S, Cc, mode, eps, self.rowstat)
+        out.copy_(self.col[:Cc])
+
+    # ------------------------------------------------------------------ forward of one layer with everything saved for its backward
+    def _layer_forward(self, i, h_in, S, pos):
+        llm = self.llm
+        v = self.fp.view
+        H, I = llm.hidden_size, llm.intermediate_size
+        nq, nkv, hd = llm.num_attention_heads, llm.num_key_value_heads, llm.head_dim
+        x1, x2, h2, q, ao, gu, act = self.x1[:S], self.x2[:S], self.h2[:S], self.q[:S], self.ao[:S], self.gu[:S], self.act[:S]
+        ops.rmsnorm(h_in, v[f'l{i}.ln_in'], llm.rms_norm_eps, out=x1)
+        ops.gemm(L.EPI_QKV_ROPE, x1, v[f'l{i}.wqkv'], bias=v[f'l{i}.bqkv'], q_out=q, k_cache=self.cache.k[0], vt_cache=self.cache.vt[0],
+                 rope_cos=self.rope[0], rope_sin=self.rope[1], pos_ids=pos, n_q_heads=nq, n_kv_heads=nkv, s_max=self.cache.s_max,
+                 tok_per_batch=S, slot_base=0)
+        ks, vs = self.cache.strides()
+        ops.attn_prefill(q, self.cache.k[0], self.cache.vt[0], ao, 1, S, S, nq, nkv, hd, (S * nq * hd, hd, nq * hd), ks, vs,
+                         (S * nq * hd, nq * hd), self.cache.s_max, hd ** -0.5, L.ATTN_CAUSAL)
+        sp = ops.gemm_splits(S, H, nq * hd)
+        ops.gemm(L.EPI_PARTIAL, ao, v[f'l{i}.wo'], out_f32=self.part, k_splits=sp)
+        ops.reduce_norm(h_in, self.part, sp, S, H, h2, x2, norm=1, norm_w=v[f'l{i}.ln_post'], eps=llm.rms_norm_eps)
+        ops.gemm(L.EPI_NONE, x2, v[f'l{i}.wgu'], out=gu)
+        ops.swiglu(gu, act, S, I)
+        return x1, x2, h2, q, ao, gu, act
+
+    def _layer_out(self, i, S, h2, act, h_out):
+        llm = self.llm
+        sp = ops.gemm_splits(S, llm.hidden_size, llm.intermediate_size)
+        ops.gemm(L.EPI_PARTIAL, act, self.fp.view[f'l{i}.wdown'], out_f32=self.part, k_splits=sp)
+        ops.reduce_norm(h2, self.part, sp, S, llm.hidden_size, h_out)
+
+    # ------------------------------------------------------------------ forward (loss) + backward (grads into self.fp.g)
+    def forward_backward(self, pixel_values, input_ids, labels, image_flags=None, on_bucket_ready=None):
+        cfg, llm, dev = self.cfg, self.llm, self.device
+        v, gv = self.fp.view, self.fp.gview
+        B, S = input_ids.shape
+        assert B == 1 and S <= self.S_max, 'per-GPU micro-batch 1 (BASELINE config 5)'
+        H, I, V = llm.hidden_size, llm.intermediate_size, llm.vocab_size
+        nq, nkv, hd = llm.num_attention_heads, llm.num_key_value_heads, llm.head_dim
+        Lyr = llm.num_hidden_layers
+        ids = input_ids.to(dev).contiguous()
+        pos = torch.arange(S, dtype=torch.int32, device=dev)
+        self.fp.g.zero_()
+        # ---- vision tower (frozen) + trainable projector (mlp1), with the intermediates mlp1's backward needs
+        T = pixel_values.shape[0]
+        pv = pixel_values.to(dev)
+        if pv.dtype != BF:
+            pvb = torch.empty(pv.shape, dtype=BF, device=dev)
+            ops.cast_f32_bf16(pv.float().contiguous(), pvb)
+            pv = pvb
+        vit_w = self.vit
+        vit_w.m0w, vit_w.m0b = v['mlp1.m0w'], v['mlp1.m0b']       # the projector weights are the trainable views
+        vit_w.m1w, vit_w.m1b, vit_w.m3w, vit_w.m3b = v['mlp1.m1w'], v['mlp1.m1b'], v['mlp1.m3w'], v['mlp1.m3b']
+        vit_w.forward(pv)                                          # leaves the last hidden state in vit_w.h
+        nt = T * cfg.num_image_token
+        C1 = cfg.vision.hidden_size
+        G_ = cfg.vision.image_size // cfg.vision.patch_size
+        ps_raw, ps_ln, z1, g1, feat = self.ps_raw[:nt], self.ps_ln[:nt], self.z1[:nt], self.g1[:nt], self.feat[:nt]
+        ops.pixel_shuffle(vit_w.h, ps_raw, T, G_, C1, 1 if cfg.ps_version == 'v1' else 0)
+        ops.pixel_shuffle_ln(vit_w.h, v['mlp1.m0w'], v['mlp1.m0b'], ps_ln, T, G_, C1, 1e-5, 1 if cfg.ps_version == 'v1' else 0)
+        ops.gemm(L.EPI_BIAS, ps_ln, v['mlp1.m1w'], out=z1, bias=v['mlp1.m1b'])
+        ops.gemm(L.EPI_BIAS_GELU, ps_ln, v['mlp1.m1w'], out=g1, bias=v['mlp1.m1b'])
+        ops.gemm(L.EPI_BIAS, g1, v['mlp1.m3w'], out=feat, bias=v['mlp1.m3b'])
+        if image_flags is not None:
+            keep = image_flags.reshape(-1).to(dev) == 1
+            feat_used = feat.view(T, cfg.num_image_token, H)[keep].reshape(-1, H).contiguous()
+        else:
+            feat_used = feat
+        n_img = int((ids == self.img_context_token_id).sum())
+        if n_img != feat_used.shape[0]:
+            raise RuntimeError(f'shape mismatch: {n_img} <IMG_CONTEXT> tokens vs {feat_used.shape[0]} visual tokens')
+        # ---- embeddings + visual-token scatter
+        h0 = self.h_in[0, :S]
+        ops.embed_merge(ids, v['embed'], feat_used, h0, self.img_context_token_id, cfg.pad_token_id, False, self.rank_ws)
+        # ---- forward through the layers, keeping only the layer inputs (activation checkpointing)
+        for i in range(Lyr):
+            _, _, h2, _, _, _, act = self._layer_forward(i, self.h_in[i, :S], S, pos)
+            self._layer_out(i, S, h2, act, self.h_in[i + 1, :S])
+        h_fin = self.h_in[Lyr, :S]
+        # ---- loss head on the labelled rows only (rows with label -100 contribute neither loss nor gradient)
+        lab = labels.to(dev).reshape(-1)
+        tgt = torch.full((S,), -100, dtype=torch.int64, device=dev)
+        tgt[:S - 1] = lab[1:]                                        # shift: position t predicts token t+1
+        rows = (tgt != -100).nonzero().flatten()
+        R = int(rows.numel())
+        xn = self.xn[:S]
+        ops.rmsnorm(h_fin, v['norm'], llm.rms_norm_eps, out=xn)
+        if R == 0:
+            return torch.zeros((), device=dev)
+        x_rows = xn.index_select(0, rows).contiguous()
+        t_rows = tgt.index_select(0, rows).contiguous()
+        logits = ops.linear(x_rows, v['head'], epi=L.EPI_F32)         # [R, V] fp32
+        loss_rows = torch.empty(R, dtype=F32, device=dev)
+        lse = torch.empty(R, dtype=F32, device=dev)
+        ops.ce_rows(logits, t_rows, loss_rows, lse)
+        loss = loss_rows.sum() / R
+        # ================================================================ backward
+        dlog = torch.zeros(R, self.Vp, dtype=BF, device=dev)
+        ops.ce_dlogits(logits, lse, t_rows, dlog, 1.0 / R)
+        dx_rows = torch.empty(R, H, dtype=BF, device=dev)
+        ops.gemm(L.EPI_NONE, dlog, self.headT, out=dx_rows)          # dX = dlogits @ W_head
+        Rp = (R + 63) // 64 * 64
+        tA = torch.empty(V, Rp, dtype=BF, device=dev)
+        tB = torch.empty(H, Rp, dtype=BF, device=dev)
+        ops.transpose(dlog, tA, R, V, self.Vp, Rp)
+        ops.transpose(x_rows, tB, R, H, H, Rp)
+        ops.gemm(L.EPI_NONE, tA, tB, out=gv['head'])                 # dW_head = dlogits^T @ x
+        dxn = self.dx[:S]
+        dxn.zero_()
+        dxn.index_copy_(0, rows, dx_rows)
+        dh = self.dh[:S]
+        ops.rmsnorm_bwd(dxn, h_fin, v['norm'], None, dh, S, H, llm.rms_norm_eps)
+        self._norm_wgrad(dxn, h_fin, gv['norm'], S, H, 2, llm.rms_norm_eps)
+        if on_bucket_ready:
+            on_bucket_ready(0)
+        G = nq // nkv
+        Sp = (S + 63) // 64 * 64
+        sc = self.sc.view(-1)[:nq * S * Sp].view(nq, S, Sp)
+        dP = self.dP.view(-1)[:nq * S * Sp].view(nq, S, Sp)
+        P = self.P.view(-1)[:nq * S * Sp].view(nq, S, Sp)
+        dS = self.dS.view(-1)[:nq * S * Sp].view(nq, S, Sp)
+        dS_T = self.dS_T.view(-1)[:nkv * Sp * G * Sp].view(nkv, Sp, G * Sp)
+        P_T = self.P_T.view(-1)[:nkv * Sp * G * Sp].view(nkv, Sp, G * Sp)
+        dS_T.zero_(); P_T.zero_()
+        Vn = self.Vn.view(-1)[:nkv * Sp * hd].view(nkv, Sp, hd)
+        KT = self.KT.view(-1)[:nkv * hd * Sp].view(nkv, hd, Sp)
+        QT = self.QT.view(-1)[:nkv * hd * G * Sp].view(nkv, hd, G * Sp)
+        dOT = self.dOT.view(-1)[:nkv * hd * G * Sp].view(nkv, hd, G * Sp)
+        sm = self.cache.s_max
+        scale = hd ** -0.5
+        bucket_of_layer = {}
+        layers_rev = list(reversed(range(Lyr)))
+        for j, li in enumerate(layers_rev):
+            bucket_of_layer[li] = 1 + j // self.bucket_layers
+        for i in reversed(range(Lyr)):
+            h_in = self.h_in[i, :S]
+            x1, x2, h2, q, ao, gu, act = self._layer_forward(i, h_in, S, pos)      # recompute
+            wT = self.wT[i]
+            dact, dgu, dx, dh2, dao = self.dact[:S], self.dgu[:S], self.dx[:S], self.dh2[:S], self.dao[:S]
+            # MLP: h3 = h2 + act Wd^T ; act = silu(g) u ; [g|u] = x2 Wgu^T ; x2 = rms(h2) w_post
+            ops.gemm(L.EPI_NONE, dh, wT['wdown'], out=dact)
+            self._wgrad(dh, act, gv[f'l{i}.wdown'], S)
+            ops.swiglu_bwd(gu, dact, dgu, S, I)
+            ops.gemm(L.EPI_NONE, dgu, wT['wgu'], out=dx)
+            self._wgrad(dgu, x2, gv[f'l{i}.wgu'], S)
+            ops.rmsnorm_bwd(dx, h2, v[f'l{i}.ln_post'], dh, dh2, S, H, llm.rms_norm_eps)
+            self._norm_wgrad(dx, h2, gv[f'l{i}.ln_post'], S, H, 2, llm.rms_norm_eps)
+            # attention block: h2 = h_in + ao Wo^T
+            ops.gemm(L.EPI_NONE, dh2, wT['wo'], out=dao)
+            self._wgrad(dh2, ao, gv[f'l{i}.wo'], S)
+            # attention backward through materialised per-head score matrices (S is small: 12 x S x S)
+            Kc, VTc = self.cache.k[0, 0], self.cache.vt[0, 0]                 # [nkv, s_max, hd], [nkv, hd, s_max]
+            ops.gemm_raw(L.EPI_F32, q, Kc, sc, S, S, hd, nq * hd, hd, Sp, batch=nq, a_bs=hd, w_bs=sm * hd, o_bs=S * Sp, w_group=G)     # Q K^T
+            ops.softmax_causal(sc, P, nq, S, Sp, scale)
+            ops.transpose(VTc, Vn, hd, S, sm, hd, hd, nkv, hd * sm, Sp * hd)        # V^T [hd, S] -> V [S, hd]
+            ops.gemm_raw(L.EPI_F32, dao, Vn, dP, S, S, hd, nq * hd, hd, Sp, batch=nq, a_bs=hd, w_bs=Sp * hd, o_bs=S * Sp, w_group=G)   # dO V^T
+            ops.attn_bwd_ds(P, dP, dao, ao, dS, dS_T, P_T, nq, nkv, S, Sp, hd, scale)
+            ops.transpose(Kc, KT, S, hd, hd, Sp, Sp, nkv, sm * hd, hd * Sp)         # K [S, hd] -> K^T [hd, Sp]
+            ops.gemm_raw(L.EPI_NONE, dS, KT, self.dq, S, hd, Sp, Sp, Sp, nq * hd, batch=nq, a_bs=S * Sp, w_bs=hd * Sp, o_bs=hd, w_group=G)  # dQ = dS K
+            for g_ in range(G):      # grouped transposes: [kvh][d][g*Sp + q]
+                ops.transpose(q[:, g_ * hd:], QT[:, :, g_ * Sp:], S, hd, nq * hd, G * Sp, Sp, nkv, G * hd, hd * G * Sp)
+                ops.transpose(dao[:, g_ * hd:], dOT[:, :, g_ * Sp:], S, hd, nq * hd, G * Sp, Sp, nkv, G * hd, hd * G * Sp)
+            ops.gemm_raw(L.EPI_NONE, dS_T, QT, self.dk, S, hd, G * Sp, G * Sp, G * Sp, nkv * hd, batch=nkv, a_bs=Sp * G * Sp, w_bs=hd * G * Sp,
+                         o_bs=hd, w_group=1)                                                                                             # dK = dS^T Q
+            ops.gemm_raw(L.EPI_NONE, P_T, dOT, self.dv, S, hd, G * Sp, G * Sp, G * Sp, nkv * hd, batch=nkv, a_bs=Sp * G * Sp, w_bs=hd * G * Sp,
+                         o_bs=hd, w_group=1)                                                                                             # dV = P^T dO
+            dqkv = self.dqkv[:S]
+            ops.rope_bwd_pack(self.dq[:S], self.dk[:S], self.dv[:S], self.rope[0], self.rope[1], pos, dqkv, S, nq, nkv)
+            ops.gemm(L.EPI_NONE, dqkv, wT['wqkv'], out=dx)
+            self._wgrad(dqkv, x1, gv[f'l{i}.wqkv'], S, bias_out=gv[f'l{i}.bqkv'])
+            ops.rmsnorm_bwd(dx, h_in, v[f'l{i}.ln_in'], dh2, dh, S, H, llm.rms_norm_eps)
+            self._norm_wgrad(dx, h_in, gv[f'l{i}.ln_in'], S, H, 2, llm.rms_norm_eps)
+            if on_bucket_ready and (i == 0 or bucket_of_layer[i - 1] != bucket_of_layer[i]):
+                on_bucket_ready(bucket_of_layer[i])
+        # ---- embeddings (text rows) and projector (image rows)
+        ops.embed_scatter_add(ids, self.rank_ws, dh, gv['embed'], S, H)
+        img_rows = (ids.reshape(-1) == self.img_context_token_id).nonzero().flatten()
+        dfeat_used = dh.index_select(0, img_rows).contiguous()
+        dvit = self.dvit[:nt]
+        if image_flags is not None:
+            dvit.zero_()
+            dvit.view(T, cfg.num_image_token, H)[keep] = dfeat_used.view(-1, cfg.num_image_token, H)
+        else:
+            dvit.copy_(dfeat_used)
+        dg1, dz1, dln = self.dg1[:nt], self.dz1[:nt], self.dln[:nt]
+        ops.gemm(L.EPI_NONE, dvit, self.m3wT, out=dg1)
+        self._wgrad(dvit, g1, gv['mlp1.m3w'], nt, bias_out=gv['mlp1.m3b'])
+        ops.gelu_bwd(z1, dg1, dz1)
+        self._wgrad(dz1, ps_ln, gv['mlp1.m1w'], nt, bias_out=gv['mlp1.m1b'])
+        ops.gemm(L.EPI_NONE, dz1, self.m1wT, out=dln)
+        C4 = C1 * 4
+        ops.colsum_mul(dln, ps_raw, self.col, nt, C4, 3, 1e-5, self.rowstat)
+        gv['mlp1.m0w'].copy_(self.col[:C4])
+        ops.colsum_mul(dln, None, self.col, nt, C4, 0)
+        gv['mlp1.m0b'].copy_(self.col[:C4])
+        if on_bucket_ready:
+            on_bucket_ready(len(self.buckets) - 1)
+        return loss
+
+    # ------------------------------------------------------------------ optimizer / data parallel
+    def _exchange_bucket(self, b):
+        """mean reduce-scatter of bucket b on the comm stream (RCCL), issued as soon as its gradients are complete."""
+        if self.world == 1:
+            return
+        lo, hi = self.buckets[b]
+        s_lo, s_hi, per = self.shards[b]
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ev)
+            dp.reduce_scatter_mean(self.fp.g, self.buckets[b], self.shards[b], self.pg)
+
+    def optimizer_step(self, lr=None):
+        lr = self.lr if lr is None else lr
+        self.step_count += 1
+        if self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        # global gradient norm over the (reduced) shards -> clip factor
+        self.gnorm2.zero_()
+        for (s_lo, s_hi, _) in self.shards:
+            if s_hi > s_lo:
+                ops.sumsq(self.fp.g[s_lo:s_hi], self.gnorm2, self.sumsq_ws)
+        if self.world > 1:
+            torch.distributed.all_reduce(self.gnorm2, group=self.pg)
+        gnorm = float(self.gnorm2.sqrt())
+        scale = 1.0
+        if self.max_grad_norm and gnorm > self.max_grad_norm:
+            scale = self.max_grad_norm / (gnorm + 1e-6)
+        for (s_lo, s_hi, per), o in zip(self.shards, self.shard_off):
+            if s_hi > s_lo:
+                n = s_hi - s_lo
+                ops.adamw(self.fp.p[s_lo:s_hi], self.master[o:o + n], self.m[o:o + n], self.v[o:o + n], self.fp.g[s_lo:s_hi], lr, self.betas[0],
+                          self.betas[1], self.eps, self.wd, scale, self.step_count)
+        if self.world > 1:                                   # ZeRO-1: all-gather the updated bf16 parameters, bucket by bucket
+            for bkt, shd in zip(self.buckets, self.shards):
+                dp.all_gather_params(self.fp.p, bkt, shd, self.pg)
+        self._refresh_transposes()
+        return gnorm
+
+    def step(self, pixel_values, input_ids, labels, image_flags=None, lr=None):
+        loss = self.forward_backward(pixel_values, input_ids, labels, image_flags, on_bucket_ready=self._exchange_bucket)
+        gnorm = self.optimizer_step(lr)
+        return SimpleNamespace(loss=loss, grad_norm=gnorm)
+
+    # ------------------------------------------------------------------ export (HF key names, un-packed layouts)
+    def state_dict(self):
+        llm = self.llm
+        v = self.fp.view
+        nq, nkv, hd = llm.num_attention_heads, llm.num_key_value_heads, llm.head_dim
+        inv = torch.empty(hd, dtype=torch.long)
+        inv[ops.head_perm(hd)] = torch.arange(hd)
+        out = {'language_model.lm_head.weight': v['head'].clone(), 'language_model.model.norm.weight': v['norm'].clone(),
+               'language_model.model.embed_tokens.weight': v['embed'].clone()}
+        for i in range(llm.num_hidden_layers):
+            p = f'language_model.model.layers.{i}.'
+            w, b = v[f'l{i}.wqkv'], v[f'l{i}.bqkv']
+            nh = nq + 2 * nkv
+            idx = (torch.arange(nh)[:, None] * hd + inv[None, :]).reshape(-1).to(w.device)
+            wn, bn = w[idx], b[idx]              # natural row order: packed[head*128 + inv[d]] = natural[head*128 + d]
+            out[p + 'self_attn.q_proj.weight'], out[p + 'self_attn.q_proj.bias'] = wn[:nq * hd].clone(), bn[:nq * hd].clone()
+            out[p + 'self_attn.k_proj.weight'], out[p + 'self_attn.k_proj.bias'] = wn[nq * hd:(nq + nkv) * hd].clone(), bn[nq * hd:(nq + nkv) * hd].clone()
+            out[p + 'self_attn.v_proj.weight'], out[p + 'self_attn.v_proj.bias'] = wn[(nq + nkv) * hd:].clone(), bn[(nq + nkv) * hd:].clone()
+            out[p + 'self_attn.o_proj.weight'] = v[f'l{i}.wo'].clone()
+            gu = v[f'l{i}.wgu'].view(-1, 2, 16, llm.hidden_size)
+            out[p + 'mlp.gate_proj.weight'] = gu[:, 0].reshape(-1, llm.hidden_size).clone()
+            out[p + 'mlp.up_proj.weight'] = gu[:, 1].reshape(-1, llm.hidden_size).clone()
+            out[p + 'mlp.down_proj.weight'] = v[f'l{i}.wdown'].clone()
+            out[p + 'input_layernorm.weight'] = v[f'l{i}.ln_in'].clone()
+            out[p + 'post_attention_layernorm.weight'] = v[f'l{i}.ln_post'].clone()
+        for nm, k in [('m0w', 'mlp1.0.weight'), ('m0b', 'mlp1.0.bias'), ('m1w', 'mlp1.1.weight'), ('m1b', 'mlp1.1.bias'),
+                      ('m3w', 'mlp1.3.weight'), ('m3b', 'mlp1.3.bias')]:
+            out[k] = v['mlp1.' + nm].clone()
+        return out
+
+    def named_grads(self):
+        """Gradients under HF key names (un-packed), for parity tests."""
+        saved = self.fp.view
+        self.fp.view = self.fp.gview
+        try:
+            return self.state_dict()
+        finally:
+            self.fp.view = saved
