@@ -86,12 +86,62 @@ def cpu_baseline(vla_full, seed=0):
                       f'(measured {tv:.2f}+{tp:.2f}+{te:.2f} s -> est. {full:.1f} s/chunk)'}
 
 
+def sft_bench(rank, world, local, dist, steps, warmup=2):
+    """BASELINE configs[4]: Vlaser-2B SFT, data parallel, per-GPU micro-batch 1, T = 1 tile, S = 560 (48 + 256 image + 256 text),
+    labels on the last 128 positions, ViT frozen, per-layer recompute, bf16 params / fp32 AdamW, ZeRO-1 RCCL exchange."""
+    from vlaser_amd import config as C, synth
+    from vlaser_amd.sft import SFTModel
+    dev = f'cuda:{local}'
+    cfg = C.vlaser_2b()
+    sd = synth.vlm_state_dict(cfg, device=dev, dtype=torch.bfloat16)
+    model = SFTModel(cfg, device=dev, max_seq_len=576, process_group=(dist.group.WORLD if dist is not None else None))
+    model.load_state_dict(sd)
+    del sd
+    torch.cuda.empty_cache()
+    g = torch.Generator().manual_seed(1000 + rank)
+    S = 560
+    ids = torch.cat([torch.randint(0, 151643, (41,), generator=g), torch.full((256,), cfg.img_context_token_id),
+                     torch.randint(0, 151643, (S - 41 - 256,), generator=g)])[None]
+    labels = torch.full_like(ids, -100)
+    labels[0, -128:] = ids[0, -128:]
+    pv = torch.randn(1, 3, 448, 448, generator=g).to(dev).to(torch.bfloat16)
+    ids_d, lab_d = ids.to(dev), labels.to(dev)
+    out = None
+    for _ in range(warmup):
+        out = model.step(pv, ids_d, lab_d)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = model.step(pv, ids_d, lab_d)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss = float(out.loss)
+    assert loss == loss, 'SFT loss is NaN'
+    del model
+    torch.cuda.empty_cache()
+    # algorithmic work per rank-step (SURVEY 8d): 7592 GFLOP for 560 tokens
+    return {'metric': 'sft_tokens_per_sec', 'value': round(world * steps * S / dt, 1), 'unit': 'tokens/s', 'ms_per_step': round(dt / steps * 1e3, 2),
+            'steps': steps, 'tokens_per_rank_step': S, 'last_loss': round(loss, 4), 'parallelism': f'dp{world} (ZeRO-1 bucketed RCCL reduce-scatter + all-gather)',
+            'mfma_frac': round(7592e9 * world * steps / dt / (world * 2.5e15), 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default='vla_chunk', choices=['vla_chunk'])
+    ap.add_argument('--workload', default='both', choices=['vla_chunk', 'sft', 'both'])
+    ap.add_argument('--sft-steps', type=int, default=6)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     a = ap.parse_args()
@@ -105,9 +155,20 @@ def main():
         import torch.distributed as dist
         dist.init_process_group('nccl')      # RCCL on ROCm: used for the barrier and the max-over-ranks time only
 
+    torch.set_grad_enabled(False)
+    sft_line = None
+    if a.workload in ('sft', 'both'):
+        sft_line = sft_bench(rank, world, local, dist, a.sft_steps)
+    if a.workload == 'sft':
+        if rank == 0:
+            sft_line.update({'n_gpus': world, 'warmup': 2, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
+                             'data': 'synthetic', 'config': {'workload': 'Vlaser-2B SFT, per-GPU micro-batch 1, S=560 (BASELINE configs[4])'}})
+            print(json.dumps(sft_line), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     from vlaser_amd import config as C, synth
     from vlaser_amd.pizero import PiZeroInference
-    torch.set_grad_enabled(False)
     vla = C.VLAConfig(base=C.vlaser_2b())
     dev = f'cuda:{local}'
     sd = synth.vla_state_dict(vla, device=dev, dtype=torch.bfloat16)
@@ -158,6 +219,8 @@ def main():
                                 'traffic': None, 'bytes_per_launch': byts, 'us_per_launch': round(avg_ms * 1e3, 3), 'launches_timed': n}
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(vla)
+        if sft_line is not None:
+            line['sft'] = sft_line
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
