@@ -178,7 +178,7 @@ int vlaser_ce_rows(const float* logits, const int64_t* labels, int R, int N, lon
  * next GEMM.   h = h_in + [ls *] (sum_s partials[s] [+ bias]);  x_out = norm(h) (kind 0 none / 1 RMS (Qwen2) / 2 LayerNorm).
  * Replaces `residual + o_proj(...)` + post_attention_layernorm / `+ mlp(...)` + next input_layernorm (Qwen2DecoderLayer)
  * and `h + ls*attn(...)`, norm2 / `h + ls*mlp(...)`, next norm1 (modeling_intern_vit.py:291-293). Row-wise, in place OK. */
-int vlaser_reduce_norm(const void* h_in, const float* partials, int n_partials, const void* bias, const void* ls, int norm_kind,
+int vlaser_reduce_norm(const void* h_in /* may be null = 0 */, const float* partials, int n_partials, const void* bias, const void* ls, int norm_kind,
                        const void* norm_w, const void* norm_b, float eps, void* h_out, void* x_out, int M, int C, vl_stream_t stream);
 
 /* ---- SFT step: backward + optimizer kernels ---------------------------------------------------
@@ -202,7 +202,7 @@ int vlaser_rope_bwd_pack(const void* dq, const void* dk, const void* dv, const f
  * through vlaser_colsum_mul.  x is the (bf16) norm input. */
 int vlaser_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* dres, void* dx_out, int S, int C, float eps, vl_stream_t stream);
 /* out[c] = sum_s a[s,c] * f(b)[s,c]: mode 0: 1; 1: b; 2: rmsnorm-normalised b (b = norm input); 3: layernorm-normalised b */
-int vlaser_colsum_mul(const void* a, const void* b, float* out, int S, int C, int mode, float eps, float* rowstat_ws /* float[2*S] for modes 2, 3 */, vl_stream_t stream);
+int vlaser_colsum_mul(const void* a, const void* b, float* out, int S, int C, int mode, float eps, float* ws /* float[2*S + 16*C] scratch */, vl_stream_t stream);
 /* SwiGLU on the packed [gate16|up16] layout: act[s, I] from gu[s, 2I]; backward: dgu from (gu, dact) */
 int vlaser_swiglu(const void* gu, void* act, int S, int I, vl_stream_t stream);
 int vlaser_swiglu_bwd(const void* gu, const void* dact, void* dgu, int S, int I, vl_stream_t stream);

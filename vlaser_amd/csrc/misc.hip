@@ -511,7 +511,8 @@ __global__ __launch_bounds__(256) void reduce_norm_kernel(const bf16_t* __restri
         for (; Sr > 8; Sr -= 8, pb += 8 * slab) add_slabs_clamped<8>(v, pb, slab, 8);
         add_slabs_clamped<8>(v, pb, slab, Sr);
       }
-      const u32x4 hi = ld_global_16(h_in + off);
+      u32x4 hi = {0, 0, 0, 0};
+      if (h_in) hi = ld_global_16(h_in + off);
       u32x4 bv = {0, 0, 0, 0}, lv = {0, 0, 0, 0};
       if (bias) bv = ld_global_16(bias + c);
       if (ls) lv = ld_global_16(ls + c);
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(256) void reduce_norm_kernel(const bf16_t* __restri
 }
 extern "C" int vlaser_reduce_norm(const void* h_in, const float* partials, int S, const void* bias, const void* ls, int norm_kind,
                                   const void* nw, const void* nb, float eps, void* h_out, void* x_out, int M, int C, vl_stream_t s) {
-  VL_CHECK(h_in && h_out && (S == 0 || partials) && M > 0 && C % 8 == 0 && C <= 4096, "vlaser_reduce_norm: bad args (C=%d)", C);
+  VL_CHECK(h_out && (S == 0 || partials) && M > 0 && C % 8 == 0 && C <= 4096, "vlaser_reduce_norm: bad args (C=%d)", C);
   VL_CHECK(norm_kind == 0 || (nw && x_out && (norm_kind == 1 || nb)), "vlaser_reduce_norm: norm weights / x_out missing");
   dim3 grid((M + 3) / 4), blk(256);
 #define RN_ARGS (const bf16_t*)h_in, partials, S, (const bf16_t*)bias, (const bf16_t*)ls, (const bf16_t*)nw, (const bf16_t*)nb, eps, \

@@ -175,13 +175,17 @@ extern "C" int vlaser_rmsnorm_bwd(const void* dy, const void* x, const void* w, 
 // ---------------------------------------------------------------------------------------------- column sums
 // out[c] = sum_s a[s,c] * f(s,c): mode 0: 1; mode 1: b[s,c]; mode 2: b[s,c] * rs_s (rs recomputed per row from b);
 // mode 3: LayerNorm-normalised b ((b - mean_s) * rs_s).  Block = 64 columns x 4 row-slices; deterministic.
+#define CS_SLICES 16
 __global__ __launch_bounds__(256) void colsum_mul_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const float* __restrict__ rowstat,
-                                                         float* __restrict__ out, int S, int C, int mode) {
+                                                         float* __restrict__ partial, int S, int C, int mode) {
+  // grid (C/64, CS_SLICES): block = 64 columns x 4 row lanes over the rows of its slice; partial[slice][c]
   __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane_r = threadIdx.x >> 6;
+  const int rows_per = (S + CS_SLICES - 1) / CS_SLICES;
+  const int s0 = blockIdx.y * rows_per, s1 = min(S, s0 + rows_per);
   float acc = 0.f;
   if (c < C) {
-    for (int s = slice; s < S; s += 4) {
+    for (int s = s0 + lane_r; s < s1; s += 4) {
       float v = bf16_to_f32(a[(size_t)s * C + c]);
       if (mode == 1) v *= bf16_to_f32(b[(size_t)s * C + c]);
       else if (mode == 2) v *= bf16_to_f32(b[(size_t)s * C + c]) * rowstat[2 * s + 1];
@@ -189,9 +193,17 @@ __global__ __launch_bounds__(256) void colsum_mul_kernel(const bf16_t* __restric
       acc += v;
     }
   }
-  red[slice][threadIdx.x & 63] = acc;
+  red[lane_r][threadIdx.x & 63] = acc;
   __syncthreads();
-  if (slice == 0 && c < C) out[c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (lane_r == 0 && c < C) partial[(size_t)blockIdx.y * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.f;
+#pragma unroll
+  for (int r = 0; r < CS_SLICES; ++r) acc += partial[(size_t)r * C + c];
+  out[c] = acc;
 }
 // per-row statistics (mean, rs) of a bf16 matrix: rms mode (mean = 0, rs = rsqrt(mean(x^2)+eps)) or layernorm mode
 __global__ __launch_bounds__(256) void rowstat_kernel(const bf16_t* __restrict__ x, float* __restrict__ st, int S, int C, float eps, int layernorm) {
@@ -212,14 +224,16 @@ __global__ __launch_bounds__(256) void rowstat_kernel(const bf16_t* __restrict__
   }
   if (lane == 0) { st[2 * row] = mean; st[2 * row + 1] = rs; }
 }
-extern "C" int vlaser_colsum_mul(const void* a, const void* b, float* out, int S, int C, int mode, float eps, float* rowstat_ws, vl_stream_t s) {
-  VL_CHECK(a && out && S > 0 && C > 0 && mode >= 0 && mode <= 3 && (mode == 0 || b), "vlaser_colsum_mul: bad args");
-  VL_CHECK(mode < 2 || rowstat_ws, "vlaser_colsum_mul: modes 2/3 need a float[2*S] row-statistics workspace");
-  float* st = rowstat_ws;
+extern "C" int vlaser_colsum_mul(const void* a, const void* b, float* out, int S, int C, int mode, float eps, float* ws, vl_stream_t s) {
+  VL_CHECK(a && out && ws && S > 0 && C > 0 && mode >= 0 && mode <= 3 && (mode == 0 || b), "vlaser_colsum_mul: bad args (ws = float[2*S + 16*C])");
+  float* st = ws;
+  float* partial = ws + 2 * S;
   if (mode >= 2) {
     hipLaunchKernelGGL(rowstat_kernel, dim3((S + 3) / 4), dim3(256), 0, (hipStream_t)s, (const bf16_t*)b, st, S, C, eps, mode == 3);
   }
-  hipLaunchKernelGGL(colsum_mul_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)s, (const bf16_t*)a, (const bf16_t*)b, st, out, S, C, mode);
+  hipLaunchKernelGGL(colsum_mul_kernel, dim3((C + 63) / 64, CS_SLICES), dim3(256), 0, (hipStream_t)s, (const bf16_t*)a, (const bf16_t*)b, st, partial, S, C,
+                     mode);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)s, partial, out, C);
   VL_LAUNCH_CHECK();
   return 0;
 }
@@ -320,22 +334,38 @@ extern "C" int vlaser_gelu_bwd(const void* x, const void* dy, void* dx, long lon
 __global__ __launch_bounds__(256) void adamw_kernel(bf16_t* __restrict__ p, float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
                                                     const bf16_t* __restrict__ g, long long n, float lr, float b1, float b2, float eps, float wd,
                                                     float gscale, float bc1, float bc2) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const float gr = bf16_to_f32(g[i]) * gscale;
-    const float mi = b1 * m[i] + (1.0f - b1) * gr;
-    const float vi = b2 * v[i] + (1.0f - b2) * gr * gr;
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-    float w = master[i];
-    w = w * (1.0f - lr * wd) - (lr / bc1) * (mi / denom);
-    master[i] = w;
-    p[i] = f32_to_bf16(w);
+  const float rbc2 = rsqrtf(bc2), step = lr / bc1, decay = 1.0f - lr * wd;
+  const long long n4 = n >> 2;                 // 4 elements per thread per iteration (16-byte fp32 vectors, 8-byte bf16 vectors)
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const u32x2 gv = *reinterpret_cast<const u32x2*>(g + 4 * i);
+    f32x4 mv = *reinterpret_cast<const f32x4*>(m + 4 * i), vv = *reinterpret_cast<const f32x4*>(v + 4 * i),
+          wv = *reinterpret_cast<const f32x4*>(master + 4 * i);
+    const float gr[4] = {bf16lo_to_f32(gv[0]) * gscale, bf16hi_to_f32(gv[0]) * gscale, bf16lo_to_f32(gv[1]) * gscale, bf16hi_to_f32(gv[1]) * gscale};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mv[j] = b1 * mv[j] + (1.0f - b1) * gr[j];
+      vv[j] = b2 * vv[j] + (1.0f - b2) * gr[j] * gr[j];
+      wv[j] = wv[j] * decay - step * (mv[j] / (sqrtf(vv[j]) * rbc2 + eps));
+    }
+    *reinterpret_cast<f32x4*>(m + 4 * i) = mv;
+    *reinterpret_cast<f32x4*>(v + 4 * i) = vv;
+    *reinterpret_cast<f32x4*>(master + 4 * i) = wv;
+    *reinterpret_cast<u32x2*>(p + 4 * i) = u32x2{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3])};
   }
+  if (blockIdx.x == 0)
+    for (long long i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+      const float gr = bf16_to_f32(g[i]) * gscale;
+      const float mi = b1 * m[i] + (1.0f - b1) * gr, vi = b2 * v[i] + (1.0f - b2) * gr * gr;
+      m[i] = mi; v[i] = vi;
+      const float w = master[i] * decay - step * (mi / (sqrtf(vi) * rbc2 + eps));
+      master[i] = w;
+      p[i] = f32_to_bf16(w);
+    }
 }
 extern "C" int vlaser_adamw(void* p, float* master, float* m, float* v, const void* g, long long n, float lr, float b1, float b2, float eps, float wd,
                             float gscale, int step, vl_stream_t s) {
   VL_CHECK(p && master && m && v && g && n > 0 && step >= 1, "vlaser_adamw: bad args");
+  VL_CHECK((((uintptr_t)p | (uintptr_t)g) & 7) == 0 && (((uintptr_t)master | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "vlaser_adamw: alignment");
   const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (bf16_t*)p, master, m, v, (const bf16_t*)g, n, lr, b1, b2, eps, wd,
@@ -348,7 +378,15 @@ extern "C" int vlaser_adamw(void* p, float* master, float* m, float* v, const vo
 __global__ __launch_bounds__(256) void sumsq_kernel(const bf16_t* __restrict__ x, long long n, float* __restrict__ partial) {
   __shared__ float red[4];
   float acc = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) { const float v = bf16_to_f32(x[i]); acc += v * v; }
+  const long long n8 = n >> 3;
+  const u32x4* xv = reinterpret_cast<const u32x4*>(x);     // 16-byte aligned (flat buffer views are 256-byte aligned)
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const u32x4 v = xv[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float lo = bf16lo_to_f32(v[j]), hi = bf16hi_to_f32(v[j]); acc += lo * lo + hi * hi; }
+  }
+  if (blockIdx.x == 0)
+    for (long long i = (n8 << 3) + threadIdx.x; i < n; i += 256) { const float v = bf16_to_f32(x[i]); acc += v * v; }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
@@ -361,7 +399,7 @@ __global__ void sumsq_final_kernel(const float* __restrict__ partial, int n, flo
   if (threadIdx.x == 0) out[0] += acc;
 }
 extern "C" int vlaser_sumsq(const void* x, long long n, float* out, float* partial_ws, vl_stream_t s) {
-  VL_CHECK(x && out && partial_ws && n > 0, "vlaser_sumsq: bad args (partial_ws = float[1024] workspace)");
+  VL_CHECK(x && out && partial_ws && n > 0 && ((uintptr_t)x & 15) == 0, "vlaser_sumsq: bad args (partial_ws = float[1024] workspace; x 16-byte aligned)");
   hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, n, partial_ws);
   hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partial_ws, 1024, out);
   VL_LAUNCH_CHECK();

@@ -270,7 +270,7 @@ def reduce_partials(h_in, partials, n_partials, M, K, out):
 
 def reduce_norm(h_in, partials, n_partials, M, C, h_out, x_out=None, bias=None, ls=None, norm=0, norm_w=None, norm_b=None, eps=1e-6):
     """h_out = h_in + [ls*](sum partials [+bias]); x_out = norm(h_out) (norm: 0 none, 1 RMS, 2 LayerNorm)."""
-    L.check(L.lib().vlaser_reduce_norm(h_in.data_ptr(), _p(partials), n_partials, _p(bias), _p(ls), norm, _p(norm_w), _p(norm_b), eps,
+    L.check(L.lib().vlaser_reduce_norm(_p(h_in), _p(partials), n_partials, _p(bias), _p(ls), norm, _p(norm_w), _p(norm_b), eps,
                                        h_out.data_ptr(), _p(x_out), M, C, _stream()), 'vlaser_reduce_norm')
 
 

@@ -190,7 +190,7 @@ class SFTModel:
         self.x1, self.x2, self.h2 = z(S, H), z(S, H), z(S, H)
         self.q, self.ao = z(S, nq * hd), z(S, nq * hd)
         self.gu, self.act = z(S, 2 * I), z(S, I)
-        self.part = torch.zeros(8 * S * H, dtype=F32, device=dev)
+        self.part = torch.zeros(8 * S * max(H, I), dtype=F32, device=dev)
         self.xn = z(S, H)
         # backward buffers
         self.dh, self.dh2, self.dx = z(S, H), z(S, H), z(S, H)
@@ -207,7 +207,7 @@ class SFTModel:
         self.tA = z(max(2 * I, NQ, H, C4) * S)      # transposed-activation scratch (dY^T)
         self.tB = z(max(I, H, nq * hd, C4) * S)     # transposed-activation scratch (X^T)
         self.col = torch.zeros(max(2 * I, NQ, C4, H), dtype=F32, device=dev)
-        self.rowstat = torch.zeros(2 * max(S, self.max_tiles * cfg.num_image_token), dtype=F32, device=dev)
+        self.rowstat = torch.zeros(2 * max(S, self.max_tiles * cfg.num_image_token) + 16 * max(2 * I, NQ, C4, H), dtype=F32, device=dev)   # colsum scratch
         self.sumsq_ws = torch.zeros(1024, dtype=F32, device=dev)
         self.gnorm2 = torch.zeros(1, dtype=F32, device=dev)
         self.rank_ws = torch.zeros(S, dtype=torch.int32, device=dev)
@@ -240,8 +240,19 @@ class SFTModel:
         ops.transpose(X, tB, S, K, X.stride(0), Sp)
         ops.gemm(L.EPI_NONE, tA, tB, out=out)
         if bias_out is not None:
-            ops.colsum_mul(dY, None, self.col, S, N, 0)
+            ops.colsum_mul(dY, None, self.col, S, N, 0, ws=self.rowstat)
             bias_out.copy_(self.col[:N])
+
+    def _dgrad(self, dY, WT, out, S):
+        """out[S,K] = dY[S,N] @ W[N,K] with W^T [K,N] resident; long contractions over few output tiles run split-K."""
+        Kout, Nin = WT.shape
+        sp = ops.gemm_splits(S, Kout, Nin)
+        if sp > 1:
+            part = self.part[:sp * S * Kout]
+            ops.gemm(L.EPI_PARTIAL, dY, WT, out_f32=part, k_splits=sp)
+            ops.reduce_norm(None, part, sp, S, Kout, out)
+        else:
+            ops.gemm(L.EPI_NONE, dY, WT, out=out)
 
     def _norm_wgrad(self, dy, x, out, S, Cc, mode=2, eps=1e-6):
         ops.colsum_mul(dy, x, self.col, S, Cc, mode, eps, self.rowstat)
@@ -383,15 +394,15 @@ class SFTModel:
             wT = self.wT[i]
             dact, dgu, dx, dh2, dao = self.dact[:S], self.dgu[:S], self.dx[:S], self.dh2[:S], self.dao[:S]
             # MLP: h3 = h2 + act Wd^T ; act = silu(g) u ; [g|u] = x2 Wgu^T ; x2 = rms(h2) w_post
-            ops.gemm(L.EPI_NONE, dh, wT['wdown'], out=dact)
+            self._dgrad(dh, wT['wdown'], dact, S)
             self._wgrad(dh, act, gv[f'l{i}.wdown'], S)
             ops.swiglu_bwd(gu, dact, dgu, S, I)
-            ops.gemm(L.EPI_NONE, dgu, wT['wgu'], out=dx)
+            self._dgrad(dgu, wT['wgu'], dx, S)
             self._wgrad(dgu, x2, gv[f'l{i}.wgu'], S)
             ops.rmsnorm_bwd(dx, h2, v[f'l{i}.ln_post'], dh, dh2, S, H, llm.rms_norm_eps)
             self._norm_wgrad(dx, h2, gv[f'l{i}.ln_post'], S, H, 2, llm.rms_norm_eps)
             # attention block: h2 = h_in + ao Wo^T
-            ops.gemm(L.EPI_NONE, dh2, wT['wo'], out=dao)
+            self._dgrad(dh2, wT['wo'], dao, S)
             self._wgrad(dh2, ao, gv[f'l{i}.wo'], S)
             # attention backward through materialised per-head score matrices (S is small: 12 x S x S)
             Kc, VTc = self.cache.k[0, 0], self.cache.vt[0, 0]                 # [nkv, s_max, hd], [nkv, hd, s_max]
@@ -411,7 +422,7 @@ class SFTModel:
                          o_bs=hd, w_group=1)                                                                                             # dV = P^T dO
             dqkv = self.dqkv[:S]
             ops.rope_bwd_pack(self.dq[:S], self.dk[:S], self.dv[:S], self.rope[0], self.rope[1], pos, dqkv, S, nq, nkv)
-            ops.gemm(L.EPI_NONE, dqkv, wT['wqkv'], out=dx)
+            self._dgrad(dqkv, wT['wqkv'], dx, S)
             self._wgrad(dqkv, x1, gv[f'l{i}.wqkv'], S, bias_out=gv[f'l{i}.bqkv'])
             ops.rmsnorm_bwd(dx, h_in, v[f'l{i}.ln_in'], dh2, dh, S, H, llm.rms_norm_eps)
             self._norm_wgrad(dx, h_in, gv[f'l{i}.ln_in'], S, H, 2, llm.rms_norm_eps)
@@ -436,7 +447,7 @@ class SFTModel:
         C4 = C1 * 4
         ops.colsum_mul(dln, ps_raw, self.col, nt, C4, 3, 1e-5, self.rowstat)
         gv['mlp1.m0w'].copy_(self.col[:C4])
-        ops.colsum_mul(dln, None, self.col, nt, C4, 0)
+        ops.colsum_mul(dln, None, self.col, nt, C4, 0, ws=self.rowstat)
         gv['mlp1.m0b'].copy_(self.col[:C4])
         if on_bucket_ready:
             on_bucket_ready(len(self.buckets) - 1)
