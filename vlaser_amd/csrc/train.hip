@@ -23,11 +23,47 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
     if (c0 + c < cols && r0 + r < pad_rows) dst[(size_t)(c0 + c) * ld_out + r0 + r] = tile[r][c];
   }
 }
+// vector variant: 16-byte global loads and stores on both sides (rows, cols, ld_in, ld_out, pad_rows multiples of 8,
+// 16-byte aligned bases); LDS tile row stride 72 elements keeps ds_write_b128 aligned.
+__global__ __launch_bounds__(256) void transpose_vec_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int rows, int cols, int ld_in,
+                                                            int ld_out, int pad_rows, long long in_bs, long long out_bs) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];
+  const int b = blockIdx.z, r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const bf16_t* src = in + (size_t)b * in_bs;
+  bf16_t* dst = out + (size_t)b * out_bs;
+  const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 8;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int r = tr + pass * 32;
+    u32x4 v = {0, 0, 0, 0};
+    if (r0 + r < rows && c0 + tc < cols) v = ld_global_16(src + (size_t)(r0 + r) * ld_in + c0 + tc);
+    *reinterpret_cast<u32x4*>(&tile[r][tc]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int c = tr + pass * 32;            // output row (= input column)
+    if (c0 + c < cols && r0 + tc < pad_rows) {
+      bf16_t e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = tile[tc + j][c];
+      u32x4 v = {(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16), (uint32_t)e[4] | ((uint32_t)e[5] << 16),
+                 (uint32_t)e[6] | ((uint32_t)e[7] << 16)};
+      st_global_16(dst + (size_t)(c0 + c) * ld_out + r0 + tc, v);
+    }
+  }
+}
 extern "C" int vlaser_transpose(const void* in, void* out, int rows, int cols, int ld_in, int ld_out, int pad_rows, int batch, long long in_bs,
                                 long long out_bs, vl_stream_t s) {
   VL_CHECK(in && out && rows > 0 && cols > 0 && pad_rows >= rows && ld_out >= pad_rows && batch >= 1, "vlaser_transpose: bad args");
-  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 63) / 64, (pad_rows + 63) / 64, batch), dim3(256), 0, (hipStream_t)s, (const bf16_t*)in,
-                     (bf16_t*)out, rows, cols, ld_in, ld_out, pad_rows, in_bs, out_bs);
+  const dim3 grid((cols + 63) / 64, (pad_rows + 63) / 64, batch);
+  const bool vec = ((rows | cols | ld_in | ld_out | pad_rows) & 7) == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0 && ((in_bs | out_bs) & 7) == 0;
+  if (vec)
+    hipLaunchKernelGGL(transpose_vec_kernel, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)in, (bf16_t*)out, rows, cols, ld_in, ld_out, pad_rows,
+                       in_bs, out_bs);
+  else
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)in, (bf16_t*)out, rows, cols, ld_in, ld_out, pad_rows, in_bs,
+                       out_bs);
   VL_LAUNCH_CHECK();
   return 0;
 }

@@ -217,9 +217,21 @@ class SFTModel:
         self.z1, self.g1, self.feat = z(nt, H), z(nt, H), z(nt, H)
         self.dvit, self.dg1, self.dz1, self.dln = z(nt, H), z(nt, H), z(nt, H), z(nt, C4)
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        self.aux_stream = torch.cuda.Stream(device=dev)        # weight transposes overlap the next step's forward
+        self.wT_ready = None
 
     def _refresh_transposes(self):
-        """W^T copies used by the dgrad GEMMs (dX = dY @ W needs W with the contraction axis contiguous)."""
+        """W^T copies used by the dgrad GEMMs (dX = dY @ W needs W with the contraction axis contiguous).  Issued on a side
+        stream: only the backward needs them, so they overlap the next forward."""
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.aux_stream):
+            self.aux_stream.wait_event(ev)
+            self._refresh_transposes_now()
+            self.wT_ready = torch.cuda.Event()
+            self.wT_ready.record()
+
+    def _refresh_transposes_now(self):
         v = self.fp.view
         for i in range(self.llm.num_hidden_layers):
             for nm in ('wqkv', 'wo', 'wgu', 'wdown'):
@@ -351,6 +363,8 @@ class SFTModel:
         ops.ce_rows(logits, t_rows, loss_rows, lse)
         loss = loss_rows.sum() / R
         # ================================================================ backward
+        if self.wT_ready is not None:
+            torch.cuda.current_stream().wait_event(self.wT_ready)
         dlog = torch.zeros(R, self.Vp, dtype=BF, device=dev)
         ops.ce_dlogits(logits, lse, t_rows, dlog, 1.0 / R)
         dx_rows = torch.empty(R, H, dtype=BF, device=dev)
