@@ -104,6 +104,124 @@ def test_greedy_ids_bit_exact(vlm, g56):
     assert gen2.cpu().tolist() == [[first]]
 
 
+def test_ragged_batch_generate_bit_exact(vlm, golden_dir):
+    """Left-padded 2-prompt batch (batch_chat's generate call): ids bit-exact against the reference's HF generate, and the
+    same ids when the caller pads on the right instead."""
+    d = np.load(os.path.join(golden_dir, 'g6b_ragged.npz'))
+    assert float(d['greedy_margin'].min()) > 0.04
+    pv = torch.cat([_pv(int(s)) for s in d['seeds']])
+    ids, am = torch.from_numpy(d['input_ids']), torch.from_numpy(d['attention_mask'])
+    gen, lg = vlm.generate(pv, ids, attention_mask=am, max_new_tokens=6, return_logits=True)
+    assert gen.cpu().tolist() == d['greedy_ids'].tolist()
+    top = lg.topk(4, dim=-1).values.cpu().numpy()
+    assert np.abs(top - d['greedy_top_vals']).max() < 3e-2 * np.abs(d['greedy_top_vals']).max()
+    n1 = int(am[1].sum())
+    ids_r, am_r = ids.clone(), am.clone()
+    ids_r[1, :n1], ids_r[1, n1:] = ids[1, -n1:], 151643
+    am_r[1, :n1], am_r[1, n1:] = 1, 0
+    assert vlm.generate(pv, ids_r, attention_mask=am_r, max_new_tokens=6).cpu().tolist() == d['greedy_ids'].tolist()
+    # each prompt alone gives the same continuation
+    solo = vlm.generate(pv[1:], ids[1:, -n1:], max_new_tokens=6)
+    assert solo.cpu().tolist() == d['greedy_ids'][1:].tolist()
+
+
+class _StubTokenizer:
+    """Test stand-in for the HF Qwen2 tokenizer (absent on the GPU box).  Special tokens map to their real ids; the
+    golden chat prompt maps to the ids the real tokenizer produced for it (tests/golden/g1_prompts.json); any other text
+    is split on whitespace and hashed, which is enough to drive chat()/batch_chat() plumbing deterministically."""
+    SPECIAL = {'<IMG_CONTEXT>': 151667, '<img>': 151665, '</img>': 151666, '<|im_end|>': 151645, '<|endoftext|>': 151643,
+               '<|im_start|>': 151644}
+
+    def __init__(self, golden):
+        import hashlib
+        self._sha = lambda q: hashlib.sha256(q.encode('utf-8')).hexdigest()
+        c = golden['chat_1tile']
+        non = list(c['ids_nonimg'])
+        self.known = {c['prompt_sha']: non[:c['img_first']] + [151667] * c['img_count'] + non[c['img_first']:]}
+        self.padding_side = 'right'
+
+    def convert_tokens_to_ids(self, t):
+        return self.SPECIAL[t]
+
+    def _encode(self, q):
+        import re
+        import zlib
+        if self._sha(q) in self.known:
+            return self.known[self._sha(q)]
+        out = []
+        for piece in re.split('(' + '|'.join(re.escape(k) for k in self.SPECIAL) + ')', q):
+            if piece in self.SPECIAL:
+                out.append(self.SPECIAL[piece])
+            else:
+                out += [zlib.crc32(w.encode('utf-8')) % 151643 for w in piece.split()]
+        return out
+
+    def __call__(self, queries, return_tensors='pt', padding=False):
+        rows = [self._encode(q) for q in ([queries] if isinstance(queries, str) else queries)]
+        S = max(len(r) for r in rows)
+        ids = torch.full((len(rows), S), 151643, dtype=torch.long)
+        am = torch.zeros(len(rows), S, dtype=torch.long)
+        for b, r in enumerate(rows):
+            sl = slice(S - len(r), S) if self.padding_side == 'left' else slice(0, len(r))
+            ids[b, sl] = torch.tensor(r)
+            am[b, sl] = 1
+        return {'input_ids': ids, 'attention_mask': am}
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        return [' '.join(f't{int(i)}' for i in row if not (skip_special_tokens and int(i) >= 151643)) for row in ids]
+
+
+def test_chat_and_batch_chat_surfaces(vlm, golden_dir):
+    """chat() (modeling_internvl_chat.py:343-398) and batch_chat() (:293-341): prompt assembly -> ids -> greedy decode
+    -> response split; the batched (left-padded) path returns what the one-by-one path returns."""
+    import json
+    g = json.load(open(os.path.join(golden_dir, 'g1_prompts.json')))
+    tok = _StubTokenizer(g)
+    vlm.system_message = g['system_message']
+    q1 = g['chat_1tile']['question']
+    q2 = 'Where is the red cup?'
+    pv = torch.cat([_pv(3), _pv(4)])
+    gc = dict(max_new_tokens=5, do_sample=False)
+    r1, hist = vlm.chat(tok, pv[:1], q1, dict(gc), return_history=True)
+    assert hist == [('<image>\n' + q1, r1)] and r1.startswith('t') and len(r1.split()) <= 5
+    # the ids chat() fed to generate() are the real tokenizer's ids for this prompt
+    ids1 = tok(vlm_query(vlm, q1))['input_ids']
+    assert ids1.shape[1] == g['chat_1tile']['n_tokens']
+    direct = vlm.generate(pv[:1], ids1, max_new_tokens=5, eos_token_id=151645)
+    assert tok.batch_decode(direct)[0] == r1
+    gc2 = dict(gc)
+    both = vlm.batch_chat(tok, pv, [q1, q2], gc2, num_patches_list=[1, 1])
+    # batch_chat == decode(generate(left-padded batch)); against the one-by-one path the ids agree up to the first step
+    # whose top-2 logit margin is inside bf16 noise (random-init logits are nearly flat; the golden-margin cases are
+    # test_ragged_batch_generate_bit_exact), and the logits agree within the stated tolerance
+    tok.padding_side = 'left'
+    mi = tok([vlm_query(vlm, q1), vlm_query(vlm, q2)], padding=True)
+    bgen, blg = vlm.generate(pv, mi['input_ids'], attention_mask=mi['attention_mask'], max_new_tokens=5, eos_token_id=151645,
+                             return_logits=True)
+    assert both == [r.strip() for r in tok.batch_decode(bgen)]
+    for b, q in enumerate((q1, q2)):
+        n = int(mi['attention_mask'][b].sum())
+        sgen, slg = vlm.generate(pv[b:b + 1], mi['input_ids'][b:b + 1, -n:], max_new_tokens=5, eos_token_id=151645, return_logits=True)
+        assert (blg[b, 0] - slg[0, 0]).abs().max() < 3e-2 * slg[0, 0].abs().max()
+        t2 = slg[0].topk(2, dim=-1).values
+        margin = (t2[:, 0] - t2[:, 1]).cpu()
+        n_clear = 0
+        while n_clear < min(sgen.shape[1], bgen.shape[1]) and n_clear < margin.shape[0] and margin[n_clear] > 0.08:
+            n_clear += 1
+        assert bgen[b, :n_clear].tolist() == sgen[0, :n_clear].tolist()
+    assert gc2['eos_token_id'] == 151645 and tok.padding_side == 'left'      # same side effects as the reference
+    with pytest.raises(NotImplementedError):
+        vlm.batch_chat(tok, pv, [q1, q2], dict(gc), num_patches_list=[1, 1], return_history=True)
+    # text-only chat (pixel_values=None, :347-349)
+    r3 = vlm.chat(tok, None, 'Hello there', dict(gc))
+    assert isinstance(r3, str)
+
+
+def vlm_query(vlm, question):
+    from vlaser_amd import prep
+    return prep.build_chat_query(vlm.template, vlm.system_message, question, [1], vlm.num_image_token, None, True)[0]
+
+
 def test_mismatched_image_tokens_raises(vlm, g56):
     pv, ids = _pv(0), torch.from_numpy(g56['input_ids']).clone()
     ids[0, 100] = 5        # 255 <IMG_CONTEXT> tokens for 256 visual tokens

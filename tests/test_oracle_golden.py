@@ -87,6 +87,19 @@ def test_vlm_logits_loss_greedy(g56, golden_model):
     np.testing.assert_allclose(lg[0].topk(4, dim=-1).values.numpy(), g56['greedy_top_vals'], rtol=1e-4, atol=2e-5)
 
 
+def test_ragged_batch_generate(golden_dir, golden_model):
+    """batch_chat's left-padded generate (modeling_internvl_chat.py:318-341): the oracle's mask/position handling against
+    the reference's own HF generate on a 2-prompt batch of different lengths."""
+    cfg, _, sd = golden_model
+    d = np.load(os.path.join(golden_dir, 'g6b_ragged.npz'))
+    pv = torch.cat([torch.randn(1, 3, 448, 448, generator=torch.Generator().manual_seed(int(s))) for s in d['seeds']])
+    ids, am = torch.from_numpy(d['input_ids']), torch.from_numpy(d['attention_mask'])
+    assert am[0].all() and not am[1].all() and am[1, -1] == 1          # row 1 is left padded
+    gen, lg = ovlm.generate(sd, cfg, pv, ids, attention_mask=am, max_new_tokens=6, eos_token_id=None, return_logits=True)
+    assert np.array_equal(gen.numpy(), d['greedy_ids'])
+    np.testing.assert_allclose(lg.topk(4, dim=-1).values.numpy(), d['greedy_top_vals'], rtol=1e-4, atol=2e-5)
+
+
 def test_infer_action(golden_dir, golden_model):
     _, vla, sd = golden_model
     d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))

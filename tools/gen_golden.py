@@ -239,6 +239,39 @@ def g5_g6(cfg, sd, ref_vlm):
     print('G5/G6 ok greedy', d['greedy_ids'], 'margins', d['greedy_margin'], 'loss', d['sft_loss'])
 
 
+def g6b_ragged(cfg, ref_vlm):
+    """batch_chat's generate call (modeling_internvl_chat.py:326-341): two prompts of different length, LEFT padded
+    (tokenizer.padding_side = 'left' :318) with an attention mask; greedy ids from the reference's own generate."""
+    ref_vlm.img_context_token_id = 151667
+    pad = 151643
+    for sa in range(11, 400, 2):                      # first seed pair whose greedy margins clear bf16 logit noise
+        pv_a, ids_a = make_inputs(cfg, seed=sa, n_tiles=1, n_text=32)
+        pv_b, ids_b = make_inputs(cfg, seed=sa + 1, n_tiles=1, n_text=9)
+        S = max(ids_a.shape[1], ids_b.shape[1])
+        ids = torch.full((2, S), pad, dtype=torch.long)
+        am = torch.zeros(2, S, dtype=torch.long)
+        for b, x in enumerate((ids_a, ids_b)):
+            ids[b, S - x.shape[1]:] = x[0]
+            am[b, S - x.shape[1]:] = 1
+        pv = torch.cat([pv_a, pv_b])
+        gen = ref_vlm.generate(pixel_values=pv, input_ids=ids, attention_mask=am, max_new_tokens=6, min_new_tokens=6,
+                               do_sample=False, eos_token_id=151645, pad_token_id=pad, output_scores=True,
+                               return_dict_in_generate=True)
+        sc = torch.stack(gen.scores, dim=1)              # [2, 8, V]
+        t2 = sc.topk(2, dim=-1).values
+        margin = t2[..., 0] - t2[..., 1]
+        print('seeds', sa, sa + 1, 'min margin', float(margin.min()))
+        if float(margin.min()) > 0.03:
+            break
+    else:
+        raise SystemExit('no seed pair with a clear greedy margin')
+    d = dict(seeds=np.array([sa, sa + 1]), n_text=np.array([32, 9]), input_ids=ids.numpy(), attention_mask=am.numpy(),
+             greedy_ids=gen.sequences.numpy(), greedy_margin=margin.numpy(),
+             greedy_top_vals=sc.topk(4, dim=-1).values.numpy())
+    np.savez_compressed(os.path.join(OUT, 'g6b_ragged.npz'), **d)
+    print('G6b ok greedy', d['greedy_ids'], 'margins', d['greedy_margin'])
+
+
 # ----------------------------------------------------------------------------------------------- G7: infer_action
 class _FakeJoint:
     """Carries exactly the attributes JointModel.forward / build_mixture_caches read (joint_model.py:702-814)."""
@@ -326,14 +359,18 @@ def g7_vla(vla, sd, ref_vlm):
 
 
 def main():
-    tok = ref_import.tokenizer()
-    g1_prompts(tok)
-    g2_tiling()
+    if '--only-g6b' not in sys.argv:
+        tok = ref_import.tokenizer()
+        g1_prompts(tok)
+        g2_tiling()
     cfg = C.truncated(C.vlaser_2b(), VIT_L, LLM_L)
     vla = C.VLAConfig(base=cfg)
     sd = synth.vla_state_dict(vla, with_head=True)
     vlm_sd = {k: v for k, v in sd.items() if k.startswith(('vision_model.', 'mlp1.', 'language_model.'))}
     ref_vlm = build_ref_vlm(cfg, vlm_sd)
+    if '--only-g6b' in sys.argv:
+        return g6b_ragged(cfg, ref_vlm)
+    g6b_ragged(cfg, ref_vlm)
     g3_g4(ref_vlm)
     g5_g6(cfg, sd, ref_vlm)
     g7_vla(vla, sd, ref_vlm)

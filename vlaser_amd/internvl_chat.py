@@ -128,14 +128,36 @@ class InternVLChatModel:
         if greedy:
             ops.argmax(self.logits[:M], self.next_ids, self.llm.embed, self.next_h)
 
-    def _decode_step(self, B, L_cur):
-        """One greedy step for B sequences whose caches hold L_cur tokens: consumes self.next_h."""
-        self.pos1[:B].fill_(L_cur)
+    def _decode_step(self, B, L_cur, lens=None, step=0):
+        """One greedy step for B sequences: consumes self.next_h.  Uniform batches hold L_cur cached tokens each.  Ragged
+        batches (lens = int32 [B] prompt lengths on the device) keep prompt b in slots [0, lens[b]) and every generated
+        token in the common slots [L_cur, L_cur + step]: the PREFIX descriptor (valid_len = lens, blk_start = L_cur)
+        replaces HF's left-padding + additive mask (modeling_internvl_chat.py:326-341) with the same visibility."""
+        if lens is None:
+            self.pos1[:B].fill_(L_cur)
+            slot, kv_len, mode, kw = L_cur, L_cur + 1, L.ATTN_FULL, {}
+        else:
+            torch.add(lens, step, out=self.pos1[:B])
+            slot, kv_len, mode, kw = L_cur + step, L_cur + step + 1, L.ATTN_PREFIX, dict(valid_len=lens, blk_start=L_cur)
         h, parts, npart = self.next_h, None, 0
         for i, lw in enumerate(self.llm.layers):
-            h, parts, npart = skinny_layer(self.llm, lw, self.sbuf, h, parts, npart, self.cache, i, self.rope, self.pos1, B, 1, L_cur,
-                                           L_cur + 1, L.ATTN_FULL)
+            h, parts, npart = skinny_layer(self.llm, lw, self.sbuf, h, parts, npart, self.cache, i, self.rope, self.pos1, B, 1, slot,
+                                           kv_len, mode, **kw)
         self._head_last(h, parts, npart, B)
+
+    @staticmethod
+    def _compact_padded(input_ids, attention_mask, pad):
+        """Padded batch (either side) -> right-padded ids trimmed to the longest prompt + int32 lengths.  Valid tokens keep
+        their order, so the row-major <IMG_CONTEXT> scatter order (:418-427) is unchanged."""
+        am = attention_mask.bool().cpu()
+        lens = am.sum(1)
+        if int(lens.min()) == 0:
+            raise ValueError('a sequence of the batch has no valid token')
+        S = int(lens.max())
+        ids = torch.full((input_ids.shape[0], S), pad, dtype=input_ids.dtype)
+        for b in range(input_ids.shape[0]):
+            ids[b, :int(lens[b])] = input_ids[b].cpu()[am[b]]
+        return ids, lens.to(torch.int32)
 
     # ------------------------------------------------------------------ public surfaces
     @torch.no_grad()
@@ -149,9 +171,12 @@ class InternVLChatModel:
             max_new_tokens = max_new_tokens or getattr(generation_config, 'max_new_tokens', None)
             eos_token_id = eos_token_id if eos_token_id is not None else getattr(generation_config, 'eos_token_id', None)
         max_new_tokens = max_new_tokens or 20          # HF default max_length heritage
-        B, S = input_ids.shape
+        B = input_ids.shape[0]
+        lens = None
         if attention_mask is not None and not bool(attention_mask.bool().all()):
-            raise NotImplementedError('padded batches (batch_chat) are a "next" row (SURVEY.md 8f-4)')
+            input_ids, lens_cpu = self._compact_padded(input_ids, attention_mask, self.config.pad_token_id)
+            lens = lens_cpu.to(self.device)
+        S = input_ids.shape[1]
         if B > 16:
             raise ValueError('at most 16 sequences per generate() call')
         self._ensure(B, S + max_new_tokens)
@@ -166,7 +191,10 @@ class InternVLChatModel:
         h = self._embed(input_ids, vit_embeds)
         pos = torch.arange(S, dtype=torch.int32, device=self.device).repeat(B)
         self._prefill(h, B, S, pos)
-        last = h.view(B, S, -1)[:, -1].contiguous()
+        if lens is None:
+            last = h.view(B, S, -1)[:, -1].contiguous()
+        else:                                       # causal prefill: right padding never reaches a valid row
+            last = h.view(B, S, -1)[torch.arange(B, device=self.device), (lens - 1).long()].contiguous()
         self._head_last(last, None, 0, B)
         out, logits_out = [], []
         eos = eos_token_id if isinstance(eos_token_id, (list, tuple)) or eos_token_id is None else [eos_token_id]
@@ -182,7 +210,7 @@ class InternVLChatModel:
                 finished = finished | torch.isin(nxt, torch.tensor(eos))
             if step == max_new_tokens - 1 or bool(finished.all()):
                 break
-            self._decode_step(B, S + step)
+            self._decode_step(B, S + step) if lens is None else self._decode_step(B, S, lens, step)
         ids = torch.stack(out, dim=1).to(self.device)
         if return_logits:
             return ids, torch.stack(logits_out, dim=1)
@@ -220,13 +248,32 @@ class InternVLChatModel:
         if history is not None or return_history:
             print('Now multi-turn chat is not supported in batch_chat.')
             raise NotImplementedError
-        # left-padded batched generation is a "next" row: run the queries one by one, same results
-        responses, off = [], 0
-        for q, n in zip(questions, num_patches_list):
-            pv = None if pixel_values is None else pixel_values[off:off + n]
-            off += n
-            responses.append(self.chat(tokenizer, pv, q, dict(generation_config), num_patches_list=[n]))
-        return responses
+        if image_counts is not None:
+            num_patches_list = image_counts
+            print('Warning: `image_counts` is deprecated. Please use `num_patches_list` instead.')
+        self.img_context_token_id = tokenizer.convert_tokens_to_ids(IMG_CONTEXT_TOKEN)
+        if verbose and pixel_values is not None:
+            print(f'dynamic ViT batch size: {pixel_values.shape[0]}')
+        queries, template = [], None
+        for idx, num_patches in enumerate(num_patches_list):
+            question = questions[idx]
+            if pixel_values is not None and '<image>' not in question:
+                question = '<image>\n' + question
+            query, _, template = prep.build_chat_query(self.template, self.system_message, question, [num_patches],
+                                                       self.num_image_token, None, pixel_values is not None)
+            queries.append(query)
+        tokenizer.padding_side = 'left'                    # as the reference does (:318)
+        model_inputs = tokenizer(queries, return_tensors='pt', padding=True)
+        eos_token_id = tokenizer.convert_tokens_to_ids(template.sep.strip())
+        generation_config['eos_token_id'] = eos_token_id
+        responses = []
+        for b0 in range(0, len(queries), 16):              # the weight-streaming decode handles <= 16 rows per launch
+            n_tiles0, n_tiles1 = sum(num_patches_list[:b0]), sum(num_patches_list[:b0 + 16])
+            pv = None if pixel_values is None else pixel_values[n_tiles0:n_tiles1]
+            out = self.generate(pixel_values=pv, input_ids=model_inputs['input_ids'][b0:b0 + 16],
+                                attention_mask=model_inputs['attention_mask'][b0:b0 + 16], **generation_config)
+            responses += tokenizer.batch_decode(out, skip_special_tokens=True)
+        return [r.split(template.sep.strip())[0].strip() for r in responses]
 
     @torch.no_grad()
     def forward(self, pixel_values, input_ids=None, attention_mask=None, position_ids=None, image_flags=None,
@@ -237,7 +284,10 @@ class InternVLChatModel:
             raise NotImplementedError('packed-sequence loss weights / external caches are out of scope (SURVEY.md 8f-4)')
         B, S = input_ids.shape
         if attention_mask is not None and not bool(attention_mask.bool().all()):
-            raise NotImplementedError('padded batches are a "next" row (SURVEY.md 8f-4)')
+            am = attention_mask.bool()
+            if not bool((am[:, :-1] | ~am[:, 1:]).all()):      # a 0 followed by a 1: not right padded
+                raise NotImplementedError('forward() takes unpadded or right-padded batches (the SFT collator pads on the '
+                                          'right, pad_data_collator.py:57-72); causal attention keeps pads out of valid rows')
         self._ensure(B, S)
         feats = self.vit.forward(self._to_bf16(pixel_values)).view(pixel_values.shape[0], self.num_image_token, -1)
         if image_flags is not None:
