@@ -1,5 +1,6 @@
 """world_size-2 gloo test (CPU) of the data-parallel exchange used by the SFT step: bucketed mean reduce-scatter with
 ZeRO-1 shard ownership + all-gather of updated parameters == single-process average."""
+import math
 import os
 import sys
 
@@ -61,3 +62,23 @@ def test_plan_shards_covers_bucket():
                 cover[i] |= set(range(lo, hi))
         for (lo, hi), c in zip(buckets, cover):
             assert c == set(range(lo, hi))
+
+
+def test_cosine_lr_matches_hf_schedule():
+    """HF get_cosine_schedule_with_warmup (the SFT launcher's scheduler) restated; compared with torch's LambdaLR driven by
+    the published lambda."""
+    from vlaser_amd.sft import cosine_lr
+    total, base, ratio = 200, 2e-5, 0.03
+    warm = math.ceil(total * ratio)
+
+    def lam(cur):
+        if cur < warm:
+            return float(cur) / float(max(1, warm))
+        prog = float(cur - warm) / float(max(1, total - warm))
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 2.0 * 0.5 * prog)))
+    opt = torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=base)
+    sch = torch.optim.lr_scheduler.LambdaLR(opt, lam)
+    for step in range(total):
+        assert abs(cosine_lr(step, total, base, ratio) - sch.get_last_lr()[0]) < 1e-12
+        opt.step(); sch.step()
+    assert cosine_lr(0, total, base) == 0.0 and abs(cosine_lr(warm, total, base) - base) < 1e-12

@@ -41,6 +41,17 @@ def ce_loss(logits, labels, ignore_index=-100):
     return rows.sum() / n
 
 
+def cosine_lr(step, total_steps, base_lr, warmup_ratio=0.03):
+    """Learning rate used for optimizer step number `step` (0-based): HF `get_cosine_schedule_with_warmup` as the SFT
+    launcher configures it (`--lr_scheduler_type cosine --warmup_ratio 0.03 --learning_rate 2e-5`, …2b…full.sh:55-58):
+    linear warm-up over ceil(total*ratio) steps, then half a cosine down to 0."""
+    warm = math.ceil(total_steps * warmup_ratio)
+    if step < warm:
+        return base_lr * step / max(1, warm)
+    prog = (step - warm) / max(1, total_steps - warm)
+    return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+
+
 class FlatParams:
     """Flat bf16 parameter / gradient buffers with named views (+ fp32 master / moments for the local ZeRO-1 shard)."""
 
@@ -507,7 +518,10 @@ class SFTModel:
         self._refresh_transposes()
         return gnorm
 
-    def step(self, pixel_values, input_ids, labels, image_flags=None, lr=None):
+    def step(self, pixel_values, input_ids, labels, image_flags=None, lr=None, total_steps=None):
+        """One optimizer step.  With `total_steps` the learning rate follows the launcher's cosine schedule."""
+        if lr is None and total_steps is not None:
+            lr = cosine_lr(self.step_count, total_steps, self.lr)
         loss = self.forward_backward(pixel_values, input_ids, labels, image_flags, on_bucket_ready=self._exchange_bucket)
         gnorm = self.optimizer_step(lr)
         return SimpleNamespace(loss=loss, grad_norm=gnorm)
