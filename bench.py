@@ -151,8 +151,10 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('VLASER_FORCE_DP') == '1':      # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
+        for k, v in (('MASTER_ADDR', '127.0.0.1'), ('MASTER_PORT', '29533'), ('RANK', '0'), ('WORLD_SIZE', '1')):
+            os.environ.setdefault(k, v)
         dist.init_process_group('nccl')      # RCCL on ROCm: used for the barrier and the max-over-ranks time only
 
     torch.set_grad_enabled(False)
@@ -163,9 +165,7 @@ def main():
         if rank == 0:
             sft_line.update({'n_gpus': world, 'warmup': 2, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
                              'data': 'synthetic', 'config': {'workload': 'Vlaser-2B SFT, per-GPU micro-batch 1, S=560 (BASELINE configs[4])'}})
-            print(json.dumps(sft_line), flush=True)
-        if dist is not None:
-            dist.destroy_process_group()
+        _finish(dist, sft_line if rank == 0 else None)
         return
     from vlaser_amd import config as C, synth
     from vlaser_amd.pizero import PiZeroInference
@@ -202,6 +202,7 @@ def main():
         dt = t.item()
     assert torch.isfinite(out).all()
 
+    line = None
     if rank == 0:
         line = {
             'metric': 'action_chunks_per_sec', 'value': round(world * a.steps / dt, 3), 'unit': 'action-chunks/s',
@@ -211,7 +212,7 @@ def main():
                                    '7-DoF x 4-step chunk, 10 Euler steps, batch 1 per GPU (BASELINE configs[2])',
                        'parallelism': f'replicas x{world} (no collective)', 'weights': 'random-init, true architecture'},
         }
-        if world == 1 and not a.no_roofline:
+        if not a.no_roofline:
             avg_ms, byts, n = _probe(model)
             ach = byts / (avg_ms * 1e-3) / 1e9
             line['roofline'] = {'bound': 'hbm', 'kernel': 'skinny_kernel<NORM,SWIGLU> (action-expert gate/up GEMV, N=17920 K=768, M=4; 307 launches per chunk)',
@@ -221,9 +222,18 @@ def main():
             line['cpu_baseline'] = cpu_baseline(vla)
         if sft_line is not None:
             line['sft'] = sft_line
-        print(json.dumps(line), flush=True)
+    _finish(dist, line if rank == 0 else None)
+
+
+def _finish(dist, line):
+    """Tear the process group down first and flush C stdio (RCCL prints its version banner there), so that the JSON line is
+    the last thing rank 0 writes."""
     if dist is not None:
         dist.destroy_process_group()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if line is not None:
+        print(json.dumps(line), flush=True)
 
 
 def _probe(model):

@@ -85,7 +85,9 @@ def skinny_cases():
 def gemm_cases():
     NL = 8
     for (M, N, K, name) in [(384, 2048, 1536, 'llm qkv'), (384, 1536, 1536, 'llm o'), (384, 17920, 1536, 'llm gate/up'), (384, 1536, 8960, 'llm down'),
-                            (1025, 3072, 1024, 'vit qkv'), (1025, 1024, 1024, 'vit proj'), (1025, 4096, 1024, 'vit fc1'), (1025, 1024, 4096, 'vit fc2')]:
+                            (1025, 3072, 1024, 'vit qkv'), (1025, 1024, 1024, 'vit proj'), (1025, 4096, 1024, 'vit fc1'), (1025, 1024, 4096, 'vit fc2'),
+                            (560, 17920, 1536, 'sft gate/up'), (560, 1536, 8960, 'sft down'), (17920, 1536, 576, 'sft wgrad gu'), (1536, 8960, 576, 'sft wgrad down'),
+                            (560, 1536, 17920, 'sft dgrad gu')]:
         x = rnd(M, K, std=1.0); ws = [rnd(N, K) for _ in range(NL)]
         out = torch.zeros(M, N, dtype=BF, device=dev)
         fl = 2.0 * M * N * K

@@ -15,6 +15,9 @@
 
 #define BN 128
 #define BK 64
+#ifndef GEMM_PD
+#define GEMM_PD 3
+#endif
 
 struct GemmP {
   VlaserGemmArgs a;
@@ -156,6 +159,7 @@ __device__ __forceinline__ void epilogue(const VlaserGemmArgs& a, int m, int n0,
 
 template <int EPI, int BM>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+  constexpr int PD = GEMM_PD;                           // K-tiles in flight (register stages)
   constexpr int WR = BM >= 64 ? 2 : 1, WC = 4 / WR;     // wave grid
   constexpr int WTM = BM / WR, WTN = BN / WC;           // wave tile
   constexpr int MT = WTM / 16, NT = WTN / 16;
@@ -182,28 +186,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A) + (size_t)bz * a.a_bs;
   const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W) + (size_t)(a.w_group > 1 ? bz / a.w_group : bz) * a.w_bs;
 
-  // staging map: thread -> (row = tid/8 + 32*i, slot = tid%8)
+  // staging map: thread -> (row = tid/8 + 32*i, slot = tid%8).  PD K-tiles are kept in flight in registers: with one
+  // workgroup per CU (the small-M shapes of this path) a single tile of look-ahead leaves every K-step waiting a
+  // full L2/HBM round trip.  Loads are unconditional (row indices clamped; rows >= M / N only feed outputs the
+  // epilogue drops) so hipcc can count them with vmcnt(n) instead of draining to 0 (guide: lesson 1 in DESIGN.md).
   const int srow = tid >> 3, sslot = tid & 7;
-  u32x4 ra[ACH], rw[4];
-  auto load_tile = [&](int kt) {
-    const int k0 = kbase + kt * BK + sslot * 8;
+  u32x4 ra[PD][ACH], rw[PD][4];
+  const bf16_t* pa[ACH];
+  const bf16_t* pw[4];
 #pragma unroll
-    for (int i = 0; i < ACH; ++i) {
-      const int rm = m0 + srow + 32 * i;
-      ra[i] = (rm < a.M) ? ld_global_16(A + (size_t)rm * a.lda + k0) : u32x4{0, 0, 0, 0};
-    }
+  for (int i = 0; i < ACH; ++i) pa[i] = A + (size_t)min(m0 + srow + 32 * i, a.M - 1) * a.lda + kbase + sslot * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rn = n0 + srow + 32 * i;
-      rw[i] = (rn < a.N) ? ld_global_16(W + (size_t)rn * a.ldw + k0) : u32x4{0, 0, 0, 0};
-    }
+  for (int i = 0; i < 4; ++i) pw[i] = W + (size_t)min(n0 + srow + 32 * i, a.N - 1) * a.ldw + kbase + sslot * 8;
+  const int nk = kc / BK;
+  auto load_tile = [&](int kt, int st) {
+    const int ko = min(kt, nk - 1) * BK;
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) ra[st][i] = ld_global_16(pa[i] + ko);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rw[st][i] = ld_global_16(pw[i] + ko);
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, int st) {
     char* base = smem + buf * BUF;
 #pragma unroll
-    for (int i = 0; i < ACH; ++i) *reinterpret_cast<u32x4*>(base + lds_off(srow + 32 * i, sslot)) = ra[i];
+    for (int i = 0; i < ACH; ++i) *reinterpret_cast<u32x4*>(base + lds_off(srow + 32 * i, sslot)) = ra[st][i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(base + BM * 128 + lds_off(srow + 32 * i, sslot)) = rw[i];
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(base + BM * 128 + lds_off(srow + 32 * i, sslot)) = rw[st][i];
   };
 
   f32x4 acc[NT][MT];
@@ -212,14 +220,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-  const int nk = kc / BK;
-  load_tile(0);
-  store_tile(0);
+#pragma unroll
+  for (int st = 0; st < PD; ++st) {          // issue order = consumption order (vmcnt retires in order); pinned so the
+    load_tile(st, st);                       // loop-header wait state matches the steady state of the back edge
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  store_tile(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  load_tile(PD, 0);
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
+  auto kstep = [&](int kt, int nst) __attribute__((always_inline)) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
     const char* As = smem + buf * BUF;
     const char* Ws = As + BM * 128;
 #pragma unroll
@@ -236,9 +249,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(fw[nt], fa[mt], acc[nt][mt]);
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+    store_tile(buf ^ 1, nst);              // register stage nst holds tile kt+1 (clamped duplicate past the end)
+    __builtin_amdgcn_sched_barrier(0);     // keep each refill where it is written: hipcc otherwise clusters the PD
+    load_tile(kt + 1 + PD, nst);           // refills of an unrolled round and the in-flight depth decays 3,2,1
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+  };
+  // full rounds carry no conditionals (a branch inside the round makes the waitcnt pass drain vmcnt to 0 at the loop
+  // header); the < PD leftover K-steps run after the loop
+  int kt0 = 0;
+  for (; kt0 + PD <= nk; kt0 += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) kstep(kt0 + u, (u + 1) % PD);
   }
+#pragma unroll
+  for (int u = 0; u < PD - 1; ++u)
+    if (kt0 + u < nk) kstep(kt0 + u, (u + 1) % PD);
 
   // epilogue: lane -> m = ... + (lane&15), n = ... + (lane>>4)*4 + reg
   VlaserGemmArgs ea = a;      // batched: shift the output (bf16 / fp32 / partial) of this batch element

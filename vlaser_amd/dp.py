@@ -38,12 +38,13 @@ def reduce_scatter_mean(flat_g, bucket, shard, group=None):
         if s_hi > s_lo:
             flat_g[s_lo:s_hi] = tmp[s_lo - lo:s_hi - lo].to(flat_g.dtype)
         return
-    if n != per * world:                                        # ragged tail: pad the input of the collective
-        pad = torch.zeros(per * world, dtype=flat_g.dtype, device=flat_g.device)
-        pad[:n] = inp
-        inp = pad
+    if n == per * world:                                        # the SFT buckets are padded to world*128: in place, no copies
+        dist.reduce_scatter_tensor(flat_g[s_lo:s_hi], inp, op=dist.ReduceOp.AVG, group=group)
+        return
+    pad = torch.zeros(per * world, dtype=flat_g.dtype, device=flat_g.device)      # ragged tail: pad the collective's input
+    pad[:n] = inp
     out = torch.empty(per, dtype=flat_g.dtype, device=flat_g.device)
-    dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.AVG, group=group)
+    dist.reduce_scatter_tensor(out, pad, op=dist.ReduceOp.AVG, group=group)
     if s_hi > s_lo:
         flat_g[s_lo:s_hi].copy_(out[:s_hi - s_lo])
 
@@ -53,6 +54,9 @@ def all_gather_params(flat_p, bucket, shard, group=None):
     lo, hi = bucket
     s_lo, s_hi, per = shard
     world = dist.get_world_size(group)
+    if dist.get_backend(group) != 'gloo' and hi - lo == per * world:          # in place: slice r of the bucket is rank r's input
+        dist.all_gather_into_tensor(flat_p[lo:hi], flat_p[s_lo:s_hi], group=group)
+        return
     mine = torch.zeros(per, dtype=flat_p.dtype, device=flat_p.device)
     if s_hi > s_lo:
         mine[:s_hi - s_lo] = flat_p[s_lo:s_hi]

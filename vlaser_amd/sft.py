@@ -17,6 +17,7 @@ Parameters live in ONE flat bf16 buffer in kernel layout (q/k/v fused+permuted, 
 [lm_head, final norm, layer L-1 ... layer 0, embed_tokens, mlp1] so gradient buckets complete front to back.
 """
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -103,6 +104,8 @@ class SFTModel:
         self.lr, self.wd, self.betas, self.eps, self.max_grad_norm = lr, weight_decay, betas, eps, max_grad_norm
         self.pg = process_group
         self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
+        # VLASER_FORCE_DP=1 runs the collectives even at world size 1 (single-GPU check of the RCCL call sequence)
+        self.dp_active = self.world > 1 or (process_group is not None and os.environ.get('VLASER_FORCE_DP') == '1')
         self.rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
         self.bucket_layers = bucket_layers
         self.step_count = 0
@@ -227,7 +230,7 @@ class SFTModel:
         self.ps_raw, self.ps_ln = z(nt, C4), z(nt, C4)
         self.z1, self.g1, self.feat = z(nt, H), z(nt, H), z(nt, H)
         self.dvit, self.dg1, self.dz1, self.dln = z(nt, H), z(nt, H), z(nt, H), z(nt, C4)
-        self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.dp_active else None
         self.aux_stream = torch.cuda.Stream(device=dev)        # weight transposes overlap the next step's forward
         self.wT_ready = None
 
@@ -481,7 +484,7 @@ class SFTModel:
     # ------------------------------------------------------------------ optimizer / data parallel
     def _exchange_bucket(self, b):
         """mean reduce-scatter of bucket b on the comm stream (RCCL), issued as soon as its gradients are complete."""
-        if self.world == 1:
+        if not self.dp_active:
             return
         lo, hi = self.buckets[b]
         s_lo, s_hi, per = self.shards[b]
@@ -494,14 +497,14 @@ class SFTModel:
     def optimizer_step(self, lr=None):
         lr = self.lr if lr is None else lr
         self.step_count += 1
-        if self.world > 1:
+        if self.dp_active:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         # global gradient norm over the (reduced) shards -> clip factor
         self.gnorm2.zero_()
         for (s_lo, s_hi, _) in self.shards:
             if s_hi > s_lo:
                 ops.sumsq(self.fp.g[s_lo:s_hi], self.gnorm2, self.sumsq_ws)
-        if self.world > 1:
+        if self.dp_active:
             torch.distributed.all_reduce(self.gnorm2, group=self.pg)
         gnorm = float(self.gnorm2.sqrt())
         scale = 1.0
@@ -512,7 +515,7 @@ class SFTModel:
                 n = s_hi - s_lo
                 ops.adamw(self.fp.p[s_lo:s_hi], self.master[o:o + n], self.m[o:o + n], self.v[o:o + n], self.fp.g[s_lo:s_hi], lr, self.betas[0],
                           self.betas[1], self.eps, self.wd, scale, self.step_count)
-        if self.world > 1:                                   # ZeRO-1: all-gather the updated bf16 parameters, bucket by bucket
+        if self.dp_active:                                   # ZeRO-1: all-gather the updated bf16 parameters, bucket by bucket
             for bkt, shd in zip(self.buckets, self.shards):
                 dp.all_gather_params(self.fp.p, bkt, shd, self.pg)
         self._refresh_transposes()
