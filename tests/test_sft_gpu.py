@@ -73,6 +73,22 @@ def test_loss_and_grads_vs_oracle_autograd(setup):
     print('worst relative gradient error', worst)
 
 
+def test_recompute_mode_gives_identical_grads(setup):
+    """Per-layer recompute (the reference's grad_checkpoint) and the default keep-activations backward run the same
+    kernels on the same values: gradients agree bit for bit."""
+    from vlaser_amd.sft import SFTModel
+    cfg, sd, m, pv, ids, labels, _ = setup
+    loss = m.forward_backward(pv, ids, labels)
+    g_keep = {k: v.clone() for k, v in m.named_grads().items()}
+    m2 = SFTModel(cfg, max_seq_len=ids.shape[1], lr=1e-3, weight_decay=0.05, recompute=True)
+    m2.load_state_dict(sd)
+    assert m2.x1.shape[0] == 1 and m.x1.shape[0] == cfg.llm.num_hidden_layers
+    loss2 = m2.forward_backward(pv, ids, labels)
+    assert loss.item() == loss2.item()
+    for k, g in m2.named_grads().items():
+        assert torch.equal(g, g_keep[k]), k
+
+
 def test_adamw_matches_torch(setup):
     from vlaser_amd import ops
     n = 100_000

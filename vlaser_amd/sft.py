@@ -94,7 +94,7 @@ class SFTModel:
     gradient exchange and the optimizer update and returns the (rank-local) loss."""
 
     def __init__(self, cfg: VlaserConfig, device='cuda', max_seq_len=576, max_tiles=1, lr=2e-5, weight_decay=0.05, betas=(0.9, 0.999),
-                 eps=1e-8, max_grad_norm=1.0, process_group=None, bucket_layers=4, seed_state_dict=None):
+                 eps=1e-8, max_grad_norm=1.0, process_group=None, bucket_layers=4, seed_state_dict=None, recompute=False):
         L.lib()
         if not torch.cuda.is_available():
             raise L.VlaserHipError('vlaser_amd needs an MI355X (gfx950) GPU: there is no CPU fallback')
@@ -108,6 +108,10 @@ class SFTModel:
         self.dp_active = self.world > 1 or (process_group is not None and os.environ.get('VLASER_FORCE_DP') == '1')
         self.rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
         self.bucket_layers = bucket_layers
+        # The reference checkpoints every LLM layer (grad_checkpoint, …full.sh:46) to fit 80 GB parts; one layer's saved
+        # activations are ~39 MB at S=560, 1.1 GB for 28 layers -- noise next to 288 GB, so they are kept by default and the
+        # backward re-runs nothing.  recompute=True restores the per-layer recompute (same values either way).
+        self.recompute = recompute
         self.step_count = 0
         self.img_context_token_id = cfg.img_context_token_id
         self.max_tiles = max_tiles
@@ -199,11 +203,12 @@ class SFTModel:
         self.m1wT, self.m3wT = z(C4, H), z(H, H)
         # activations
         self.h_in = z(Lyr + 1, S, H)               # layer inputs (checkpoints) + final hidden
-        self.cache = KVCache(1, 1, nkv, S, dev, hd)     # one layer's K / V^T (recomputed per layer)
+        Lk = 1 if self.recompute else Lyr          # saved-activation slots: one (reused) or one per layer
+        self.cache = KVCache(Lk, 1, nkv, S, dev, hd)    # K / V^T per slot
         self.rope = ops.rope_table(S + 8, hd, llm.rope_theta, dev)
-        self.x1, self.x2, self.h2 = z(S, H), z(S, H), z(S, H)
-        self.q, self.ao = z(S, nq * hd), z(S, nq * hd)
-        self.gu, self.act = z(S, 2 * I), z(S, I)
+        self.x1, self.x2, self.h2 = z(Lk, S, H), z(Lk, S, H), z(Lk, S, H)
+        self.q, self.ao = z(Lk, S, nq * hd), z(Lk, S, nq * hd)
+        self.gu, self.act = z(Lk, S, 2 * I), z(Lk, S, I)
         self.part = torch.zeros(8 * S * max(H, I), dtype=F32, device=dev)
         self.xn = z(S, H)
         # backward buffers
@@ -290,13 +295,14 @@ class SFTModel:
         v = self.fp.view
         H, I = llm.hidden_size, llm.intermediate_size
         nq, nkv, hd = llm.num_attention_heads, llm.num_key_value_heads, llm.head_dim
-        x1, x2, h2, q, ao, gu, act = self.x1[:S], self.x2[:S], self.h2[:S], self.q[:S], self.ao[:S], self.gu[:S], self.act[:S]
+        x1, x2, h2, q, ao, gu, act = self._saved(i, S)
+        j = 0 if self.recompute else i
         ops.rmsnorm(h_in, v[f'l{i}.ln_in'], llm.rms_norm_eps, out=x1)
-        ops.gemm(L.EPI_QKV_ROPE, x1, v[f'l{i}.wqkv'], bias=v[f'l{i}.bqkv'], q_out=q, k_cache=self.cache.k[0], vt_cache=self.cache.vt[0],
+        ops.gemm(L.EPI_QKV_ROPE, x1, v[f'l{i}.wqkv'], bias=v[f'l{i}.bqkv'], q_out=q, k_cache=self.cache.k[j], vt_cache=self.cache.vt[j],
                  rope_cos=self.rope[0], rope_sin=self.rope[1], pos_ids=pos, n_q_heads=nq, n_kv_heads=nkv, s_max=self.cache.s_max,
                  tok_per_batch=S, slot_base=0)
         ks, vs = self.cache.strides()
-        ops.attn_prefill(q, self.cache.k[0], self.cache.vt[0], ao, 1, S, S, nq, nkv, hd, (S * nq * hd, hd, nq * hd), ks, vs,
+        ops.attn_prefill(q, self.cache.k[j], self.cache.vt[j], ao, 1, S, S, nq, nkv, hd, (S * nq * hd, hd, nq * hd), ks, vs,
                          (S * nq * hd, nq * hd), self.cache.s_max, hd ** -0.5, L.ATTN_CAUSAL)
         sp = ops.gemm_splits(S, H, nq * hd)
         ops.gemm(L.EPI_PARTIAL, ao, v[f'l{i}.wo'], out_f32=self.part, k_splits=sp)
@@ -304,6 +310,10 @@ class SFTModel:
         ops.gemm(L.EPI_NONE, x2, v[f'l{i}.wgu'], out=gu)
         ops.swiglu(gu, act, S, I)
         return x1, x2, h2, q, ao, gu, act
+
+    def _saved(self, i, S):
+        j = 0 if self.recompute else i
+        return (self.x1[j, :S], self.x2[j, :S], self.h2[j, :S], self.q[j, :S], self.ao[j, :S], self.gu[j, :S], self.act[j, :S])
 
     def _layer_out(self, i, S, h2, act, h_out):
         llm = self.llm
@@ -354,7 +364,7 @@ class SFTModel:
         # ---- embeddings + visual-token scatter
         h0 = self.h_in[0, :S]
         ops.embed_merge(ids, v['embed'], feat_used, h0, self.img_context_token_id, cfg.pad_token_id, False, self.rank_ws)
-        # ---- forward through the layers, keeping only the layer inputs (activation checkpointing)
+        # ---- forward through the layers (saved activations per layer, or only the layer inputs when recompute=True)
         for i in range(Lyr):
             _, _, h2, _, _, _, act = self._layer_forward(i, self.h_in[i, :S], S, pos)
             self._layer_out(i, S, h2, act, self.h_in[i + 1, :S])
@@ -418,7 +428,8 @@ class SFTModel:
             bucket_of_layer[li] = 1 + j // self.bucket_layers
         for i in reversed(range(Lyr)):
             h_in = self.h_in[i, :S]
-            x1, x2, h2, q, ao, gu, act = self._layer_forward(i, h_in, S, pos)      # recompute
+            x1, x2, h2, q, ao, gu, act = self._layer_forward(i, h_in, S, pos) if self.recompute else self._saved(i, S)
+            kslot = 0 if self.recompute else i
             wT = self.wT[i]
             dact, dgu, dx, dh2, dao = self.dact[:S], self.dgu[:S], self.dx[:S], self.dh2[:S], self.dao[:S]
             # MLP: h3 = h2 + act Wd^T ; act = silu(g) u ; [g|u] = x2 Wgu^T ; x2 = rms(h2) w_post
@@ -433,7 +444,7 @@ class SFTModel:
             self._dgrad(dh2, wT['wo'], dao, S)
             self._wgrad(dh2, ao, gv[f'l{i}.wo'], S)
             # attention backward through materialised per-head score matrices (S is small: 12 x S x S)
-            Kc, VTc = self.cache.k[0, 0], self.cache.vt[0, 0]                 # [nkv, s_max, hd], [nkv, hd, s_max]
+            Kc, VTc = self.cache.k[kslot, 0], self.cache.vt[kslot, 0]         # [nkv, s_max, hd], [nkv, hd, s_max]
             ops.gemm_raw(L.EPI_F32, q, Kc, sc, S, S, hd, nq * hd, hd, Sp, batch=nq, a_bs=hd, w_bs=sm * hd, o_bs=S * Sp, w_group=G)     # Q K^T
             ops.softmax_causal(sc, P, nq, S, Sp, scale)
             ops.transpose(VTc, Vn, hd, S, sm, hd, hd, nkv, hd * sm, Sp * hd)        # V^T [hd, S] -> V [S, hd]
