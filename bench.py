@@ -217,12 +217,23 @@ def main():
             ach = byts / (avg_ms * 1e-3) / 1e9
             line['roofline'] = {'bound': 'hbm', 'kernel': 'skinny_kernel<NORM,SWIGLU> (action-expert gate/up GEMV, N=17920 K=768, M=4; 307 launches per chunk)',
                                 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                                'traffic': None, 'bytes_per_launch': byts, 'us_per_launch': round(avg_ms * 1e3, 3), 'launches_timed': n}
+                                'traffic': _pmc_traffic(), 'bytes_per_launch': byts, 'us_per_launch': round(avg_ms * 1e3, 3), 'launches_timed': n}
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(vla)
         if sft_line is not None:
             line['sft'] = sft_line
     _finish(dist, line if rank == 0 else None)
+
+
+def _pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from hardware counters.  rocprofv3 --pmc cannot run under torch on this
+    image, so the counters are collected by the torch-free harness tools/pmc/skinny_pmc.cpp on the same kernel and shape
+    (profiles/r01g_pmc_dominant_kernel.md has the commands and the gfx950 FETCH_SIZE correction); None if absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01g_pmc_dominant_kernel.json')
+    try:
+        return json.load(open(path))['traffic_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def _finish(dist, line):
