@@ -17,17 +17,17 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(
 __device__ __forceinline__ float bf16lo_to_f32(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi_to_f32(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
-// round-to-nearest-even f32 -> bf16 (NaN kept quiet)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even f32 -> bf16: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, two values per
+// instruction); hipcc selects it for __bf16 conversions.  A software RNE costs ~7 VALU ops per value, which made the
+// norm / epilogue phases of the small kernels instruction-issue bound.
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
-__device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+__device__ __forceinline__ float round_bf16(float f) { return (float)(__bf16)f; }
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) {
   union { u32x4 u; bf16x8 b; } x;
