@@ -37,6 +37,7 @@ struct SkinnyP {
   VlaserSkinnyArgs a;
   int xs_stride;  // bytes per LDS activation row
   int kb;         // K per block
+  float inv_cpr;  // 8 / K: chunk -> row without an integer division
 };
 
 struct EpiOps {  // epilogue operands of one tile pair
@@ -141,7 +142,10 @@ __device__ __forceinline__ void skinny_epilogue(const VlaserSkinnyArgs& a, int k
   }
 }
 
-template <int PRO, int EPI, int TPU, int NS>
+// SP >= 0 (NORM prologue): the split-K slab count is a compile-time constant -> exactly 2 + 2*SP loads per chunk and no
+// clamped dummy loads / selects.  The prologue is instruction-issue bound (8 waves share 4 SIMDs, ~8 cycles per VALU op
+// per wave), so the generic runtime-count path (SP = -1) costs ~2 us more per launch at SP = 5.
+template <int PRO, int EPI, int TPU, int NS, int SP = -1>
 __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
   constexpr int RPU = TPU * 16;                 // rows per unit
   constexpr int NF = TPU * NS;                  // fragments (16-byte loads) per lane per unit
@@ -246,6 +250,42 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
     const int cpr = a.K >> 3, nch = a.M * cpr;
     const size_t slab = (size_t)a.M * a.K;
     const int S = a.n_partials;
+    if constexpr (SP >= 0) {
+      auto norm_pass_exact = [&](int cbase, auto issue_tag) {
+        const int ch = min(cbase + tid, nch - 1);
+        const int mm = (int)(((float)ch + 0.5f) * p.inv_cpr), c = (ch - mm * cpr) << 3;    // chunk -> (row, column) without an integer division
+        const int off = mm * a.K + c, slab32 = a.M * a.K;
+        const u32x4 hv = ld_global_16(Hin + off);
+        const u32x4 wv = ld_global_16(Wn + c);
+        f32x4 q[SP > 0 ? 2 * SP : 1];
+#pragma unroll
+        for (int u = 0; u < SP; ++u) {
+          const float* pp = a.partials + (off + u * slab32);
+          q[2 * u] = *reinterpret_cast<const f32x4*>(pp);
+          q[2 * u + 1] = *reinterpret_cast<const f32x4*>(pp + 4);
+        }
+        if constexpr (decltype(issue_tag)::value) load_unit(0, cw, ce);       // weight stream right behind the prologue requests
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[2 * j] = bf16lo_to_f32(hv[j]); v[2 * j + 1] = bf16hi_to_f32(hv[j]); }
+        float sl[8] = {0, 0, 0, 0, 0, 0, 0, 0};                               // slabs first, residual last: same order as the generic path
+#pragma unroll
+        for (int u = 0; u < SP; ++u) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { sl[j] += q[2 * u][j]; sl[4 + j] += q[2 * u + 1][j]; }
+        }
+        u32x4 hr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hr[j] = pack_bf16x2(sl[2 * j] + v[2 * j], sl[2 * j + 1] + v[2 * j + 1]);
+        if (cbase + tid < nch) {
+          *reinterpret_cast<u32x4*>(xs + mm * p.xs_stride + c * 2) = hr;
+          if (mm == 0) *reinterpret_cast<u32x4*>(wn_lds + c * 2) = wv;
+          if (write_h) st_global_16(reinterpret_cast<bf16_t*>(a.h_out) + off, hr);
+        }
+      };
+      norm_pass_exact(0, std::true_type{});
+      for (int cbase = SKT; cbase < nch; cbase += SKT) norm_pass_exact(cbase, std::false_type{});
+    } else {
     // one pass = one 16-byte chunk per thread: residual + norm weight + slabs requested together (clamped, unconditional);
     // the rounded residual goes to LDS (and to h_out from block 0)
     auto norm_pass = [&](int cbase, auto issue_tag) {
@@ -301,6 +341,7 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
     };
     norm_pass(0, std::true_type{});
     for (int cbase = SKT; cbase < nch; cbase += SKT) norm_pass(cbase, std::false_type{});
+    }  // SP < 0
     __syncthreads();
     STAMP(1);
     // phase 2 (one wave per row, LDS only): sum of squares, normalise in place
@@ -387,6 +428,18 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
 #undef STAMP
 }
 
+template <int PRO, int EPI, int TPU, int NS, int SP>
+static int launch_sp(const VlaserSkinnyArgs* a, hipStream_t stream, SkinnyP& p, int gx, int lds) {
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
+    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel<PRO, EPI, TPU, NS, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL((skinny_kernel<PRO, EPI, TPU, NS, SP>), dim3(gx, a->k_splits), dim3(SKT), lds, stream, p);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int PRO, int EPI, int TPU, int NS>
 static int launch_ns(const VlaserSkinnyArgs* a, hipStream_t stream) {
   SkinnyP p;
@@ -394,19 +447,23 @@ static int launch_ns(const VlaserSkinnyArgs* a, hipStream_t stream) {
   if (p.a.n_valid <= 0) p.a.n_valid = a->N;
   p.kb = a->K / a->k_splits;
   p.xs_stride = p.kb * 2 + 16;
+  p.inv_cpr = 8.0f / (float)a->K;
   const int lds = ((a->M * p.xs_stride + 15) & ~15) + 2 * (SKW - 1) * TPU * 64 * 16 + (PRO == VL_PRO_NORM ? a->K * 2 : 0);
   const int n_units = a->N / (16 * TPU);
   int gx = 256 / a->k_splits;            // <= one block per CU (256 CUs)
   if (gx > n_units) gx = n_units;
   if (gx < 1) gx = 1;
-  static int attr_lds = 0;
-  if (lds > attr_lds) {
-    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel<PRO, EPI, TPU, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_lds = lds;
+  // exact slab-count variants for the hidden sizes / split factors this path produces (engine.py: ks_o, ks_down)
+  if constexpr (PRO == VL_PRO_NORM && TPU == 2 && (NS == 3 || NS == 6)) {
+    switch (a->n_partials) {
+      case 0: return launch_sp<PRO, EPI, TPU, NS, 0>(a, stream, p, gx, lds);
+      case 2: return launch_sp<PRO, EPI, TPU, NS, 2>(a, stream, p, gx, lds);
+      case 3: return launch_sp<PRO, EPI, TPU, NS, 3>(a, stream, p, gx, lds);
+      case 5: return launch_sp<PRO, EPI, TPU, NS, 5>(a, stream, p, gx, lds);
+      default: break;
+    }
   }
-  hipLaunchKernelGGL((skinny_kernel<PRO, EPI, TPU, NS>), dim3(gx, a->k_splits), dim3(SKT), lds, stream, p);
-  VL_LAUNCH_CHECK();
-  return 0;
+  return launch_sp<PRO, EPI, TPU, NS, -1>(a, stream, p, gx, lds);
 }
 
 template <int PRO, int EPI>
