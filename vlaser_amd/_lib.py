@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libvlaser_hip.so')
+LIB_PATH = os.environ.get('VLASER_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libvlaser_hip.so')     # env: an alternative build of the same ABI
 _lib = None
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float

@@ -37,8 +37,13 @@ struct SkinnyP {
   VlaserSkinnyArgs a;
   int xs_stride;  // bytes per LDS activation row
   int kb;         // K per block
-  float inv_cpr;  // 8 / K: chunk -> row without an integer division
+  float inv_cpr;  // 8 / kb: chunk -> row without an integer division
+  int ulo, urem;  // units per block = ulo (+1 for the first urem blocks): host-side, integer division is slow on the device
+  int attn_nkv;   // ATTN prologue: K / (128 * attn_group)
 };
+
+// x / d for small non-negative ints through a float reciprocal (an integer division is ~40 VALU ops on gfx950)
+__device__ __forceinline__ int fdiv(int x, float inv_d) { return (int)(((float)x + 0.5f) * inv_d); }
 
 struct EpiOps {  // epilogue operands of one tile pair
   u32x2 b0, b1;  // 4 bf16 bias values of tile 0 / tile 1
@@ -117,7 +122,7 @@ __device__ __forceinline__ void skinny_epilogue(const VlaserSkinnyArgs& a, int k
       x1[j] = round_bf16(acc0[j] + b0[j]);
       x2[j] = round_bf16(acc1[j] + b1[j]);
     }
-    const int b = m / a.tok_per_batch;
+    const int b = fdiv(m, __builtin_amdgcn_rcpf((float)a.tok_per_batch));
     const int slot = a.slot_base + (m - b * a.tok_per_batch);
     const int nq = a.n_q_heads, nkv = a.n_kv_heads;
     if (head < nq + nkv) {
@@ -142,7 +147,7 @@ __device__ __forceinline__ void skinny_epilogue(const VlaserSkinnyArgs& a, int k
   }
 }
 
-// SP >= 0 (NORM prologue): the split-K slab count is a compile-time constant -> exactly 2 + 2*SP loads per chunk and no
+// SP > 0 (ATTN prologue): exact attention-split count.  SP >= 0 (NORM prologue): the split-K slab count is a compile-time constant -> exactly 2 + 2*SP loads per chunk and no
 // clamped dummy loads / selects.  The prologue is instruction-issue bound (8 waves share 4 SIMDs, ~8 cycles per VALU op
 // per wave), so the generic runtime-count path (SP = -1) costs ~2 us more per launch at SP = 5.
 template <int PRO, int EPI, int TPU, int NS, int SP = -1>
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
   STAMP(0);
   // balanced run of units for this block
   const int n_units = a.N / RPU;
-  const int ulo = n_units / (int)gridDim.x, urem = n_units % (int)gridDim.x;
+  const int ulo = p.ulo, urem = p.urem;
   const int ucount = ulo + ((int)blockIdx.x < urem ? 1 : 0);
   const int ustart = (int)blockIdx.x * ulo + min((int)blockIdx.x, urem);
   const int kb0 = ks * p.kb;                  // first k of this block
@@ -193,26 +198,29 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
     const bf16_t* X = reinterpret_cast<const bf16_t*>(a.x);
     const int cpr = p.kb >> 3, nch = a.M * cpr;
     const int c0 = min(tid, nch - 1);
-    const u32x4 x0 = ld_global_16(X + (size_t)(c0 / cpr) * a.K + kb0 + (c0 % cpr) * 8);
+    const int r0 = fdiv(c0, p.inv_cpr), j0 = c0 - r0 * cpr;
+    const u32x4 x0 = ld_global_16(X + (size_t)r0 * a.K + kb0 + j0 * 8);
     load_unit(0, cw, ce);
-    if (tid < nch) *reinterpret_cast<u32x4*>(xs + (c0 / cpr) * p.xs_stride + (c0 % cpr) * 16) = x0;
+    if (tid < nch) *reinterpret_cast<u32x4*>(xs + r0 * p.xs_stride + j0 * 16) = x0;
     for (int c = tid + SKT; c < nch; c += SKT)
       *reinterpret_cast<u32x4*>(xs + (c / cpr) * p.xs_stride + (c % cpr) * 16) = ld_global_16(X + (size_t)(c / cpr) * a.K + kb0 + (c % cpr) * 8);
   } else if constexpr (PRO == VL_PRO_ATTN) {
     // x[m][k] (k = h*128 + d) = flash-decoding merge of the attention partials of vlaser_attn_skinny
     const int cpr = p.kb >> 3, nch = a.M * cpr, G = a.attn_group, nq = a.attn_nq, S = a.attn_splits;
-    const int nkv = a.K / (128 * G);
+    const int nkv = p.attn_nkv;
     auto attn_pass = [&](int cbase, auto issue_tag) {
       const int c = min(cbase + tid, nch - 1);
-      const int mm = c / cpr, j = c - mm * cpr;
+      const int mm = fdiv(c, p.inv_cpr), j = c - mm * cpr;
       const int k = kb0 + j * 8, h = k >> 7, d = k & 127;
-      const int b = mm / nq, tok = mm - b * nq, kvh = h / G, hg = h - kvh * G, r = hg * nq + tok;
+      const int b = fdiv(mm, __builtin_amdgcn_rcpf((float)nq)), tok = mm - b * nq, kvh = fdiv(h, __builtin_amdgcn_rcpf((float)G)), hg = h - kvh * G,
+                r = hg * nq + tok;
       const size_t pbase = ((size_t)b * nkv + kvh) * S;
-      float ms[8], ls[8];
-      f32x4 o0[8], o1[8];
+      constexpr int NSPL = SP > 0 ? SP : 8;      // SP > 0: exact split count (no clamped dummy loads)
+      float ms[NSPL], ls[NSPL];
+      f32x4 o0[NSPL], o1[NSPL];
 #pragma unroll
-      for (int sp = 0; sp < 8; ++sp) {
-        const int sc = min(sp, S - 1);
+      for (int sp = 0; sp < NSPL; ++sp) {
+        const int sc = SP > 0 ? sp : min(sp, S - 1);
         ms[sp] = a.attn_m[(pbase + sc) * 32 + r];
         ls[sp] = a.attn_l[(pbase + sc) * 32 + r];
         const float* po = a.attn_o + ((pbase + sc) * 32 + r) * 128 + d;
@@ -222,11 +230,11 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
       if constexpr (decltype(issue_tag)::value) load_unit(0, cw, ce);
       float Mx = -1.0e30f;
 #pragma unroll
-      for (int sp = 0; sp < 8; ++sp) Mx = fmaxf(Mx, ms[sp]);
+      for (int sp = 0; sp < NSPL; ++sp) Mx = fmaxf(Mx, ms[sp]);
       float Ls = 0.f, v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int sp = 0; sp < 8; ++sp) {
-        const float f = sp < S ? __builtin_amdgcn_exp2f(ms[sp] - Mx) : 0.f;
+      for (int sp = 0; sp < NSPL; ++sp) {
+        const float f = (SP > 0 || sp < S) ? __builtin_amdgcn_exp2f(ms[sp] - Mx) : 0.f;
         Ls += ls[sp] * f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) { v[q] += o0[sp][q] * f; v[4 + q] += o1[sp][q] * f; }
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
     if constexpr (SP >= 0) {
       auto norm_pass_exact = [&](int cbase, auto issue_tag) {
         const int ch = min(cbase + tid, nch - 1);
-        const int mm = (int)(((float)ch + 0.5f) * p.inv_cpr), c = (ch - mm * cpr) << 3;    // chunk -> (row, column) without an integer division
+        const int mm = fdiv(ch, p.inv_cpr), c = (ch - mm * cpr) << 3;
         const int off = mm * a.K + c, slab32 = a.M * a.K;
         const u32x4 hv = ld_global_16(Hin + off);
         const u32x4 wv = ld_global_16(Wn + c);
@@ -447,13 +455,29 @@ static int launch_ns(const VlaserSkinnyArgs* a, hipStream_t stream) {
   if (p.a.n_valid <= 0) p.a.n_valid = a->N;
   p.kb = a->K / a->k_splits;
   p.xs_stride = p.kb * 2 + 16;
-  p.inv_cpr = 8.0f / (float)a->K;
+  p.inv_cpr = 8.0f / (float)p.kb;
   const int lds = ((a->M * p.xs_stride + 15) & ~15) + 2 * (SKW - 1) * TPU * 64 * 16 + (PRO == VL_PRO_NORM ? a->K * 2 : 0);
   const int n_units = a->N / (16 * TPU);
   int gx = 256 / a->k_splits;            // <= one block per CU (256 CUs)
   if (gx > n_units) gx = n_units;
   if (gx < 1) gx = 1;
+  p.ulo = n_units / gx;
+  p.urem = n_units % gx;
+  p.attn_nkv = PRO == VL_PRO_ATTN ? a->K / (128 * a->attn_group) : 0;
   // exact slab-count variants for the hidden sizes / split factors this path produces (engine.py: ks_o, ks_down)
+  if constexpr (PRO == VL_PRO_ATTN && TPU == 2 && (NS == 2 || NS == 3)) {   // exact attention-split count (o_proj of the expert / LLM)
+    switch (a->attn_splits) {
+      case 1: return launch_sp<PRO, EPI, TPU, NS, 1>(a, stream, p, gx, lds);
+      case 2: return launch_sp<PRO, EPI, TPU, NS, 2>(a, stream, p, gx, lds);
+      case 3: return launch_sp<PRO, EPI, TPU, NS, 3>(a, stream, p, gx, lds);
+      case 4: return launch_sp<PRO, EPI, TPU, NS, 4>(a, stream, p, gx, lds);
+      case 5: return launch_sp<PRO, EPI, TPU, NS, 5>(a, stream, p, gx, lds);
+      case 6: return launch_sp<PRO, EPI, TPU, NS, 6>(a, stream, p, gx, lds);
+      case 7: return launch_sp<PRO, EPI, TPU, NS, 7>(a, stream, p, gx, lds);
+      case 8: return launch_sp<PRO, EPI, TPU, NS, 8>(a, stream, p, gx, lds);
+      default: break;
+    }
+  }
   if constexpr (PRO == VL_PRO_NORM && TPU == 2 && (NS == 3 || NS == 6)) {
     switch (a->n_partials) {
       case 0: return launch_sp<PRO, EPI, TPU, NS, 0>(a, stream, p, gx, lds);
