@@ -16,7 +16,7 @@
 #define BN 128
 #define BK 64
 #ifndef GEMM_PD
-#define GEMM_PD 3
+#define GEMM_PD 2
 #endif
 
 struct GemmP {
