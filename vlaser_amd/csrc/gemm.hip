@@ -311,7 +311,9 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
   const int nb = args->batch > 1 ? args->batch : 1;
   auto blocks = [&](int bm) { return ((args->M + bm - 1) / bm) * tn * splits * nb; };
   int bm = args->force_bm;
-  if (bm == 0) bm = blocks(128) >= 224 ? 128 : (blocks(64) >= 192 ? 64 : 32);
+  // measured on the path's shapes (tools/micro/kernel_lab.py): BM = 64 beats or ties BM = 128 everywhere up to ~1700
+  // tiles (two 64-row workgroups per CU overlap each other's staging); 128 only pays on far larger grids
+  if (bm == 0) bm = blocks(128) >= 2048 ? 128 : (blocks(64) >= 192 ? 64 : 32);
   if (bm == 128) return launch_bm<EPI, 128>(args, stream, splits);
   if (bm == 64) return launch_bm<EPI, 64>(args, stream, splits);
   return launch_bm<EPI, 32>(args, stream, splits);
