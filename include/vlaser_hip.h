@@ -186,9 +186,10 @@ int vlaser_reduce_norm(const void* h_in /* may be null = 0 */, const float* part
  * (modeling_internvl_chat.py:143-255; internvl_chat_finetune.py:1041-1057; zero_stage1_config.json): bf16 params
  * and grads, fp32 master weights and AdamW moments, per-layer activation recompute. GEMM-shaped work (dgrad, wgrad,
  * attention backward through materialised per-head score matrices) reuses vlaser_gemm on transposed operands. */
-/* out[c*ld_out + r] = in[r*ld_in + c] for r < rows, 0 for rows <= r < pad_rows (bf16); batched with element strides */
+/* out[c*ld_out + r] = in[r*ld_in + c] for r < rows, 0 for rows <= r < pad_rows (bf16); two-level batch with element
+ * strides: matrix (b, i), b < batch, i < inner (inner >= 1), starts at in + b*in_bs + i*in_is / out + b*out_bs + i*out_is */
 int vlaser_transpose(const void* in, void* out, int rows, int cols, int ld_in, int ld_out, int pad_rows, int batch, long long in_bs, long long out_bs,
-                     vl_stream_t stream);
+                     int inner, long long in_is, long long out_is, vl_stream_t stream);
 /* causal softmax of fp32 scores [B, S, ld] * scale -> P bf16 [B, S, ld] (0 beyond the diagonal / beyond S) */
 int vlaser_softmax_causal(const float* scores, void* P, int batch, int S, int ld, float scale, vl_stream_t stream);
 /* dS = P o (dP - D) * scale with D[q] = sum_d dO[q,d] O[q,d]; writes dS [H,S,ld] and the grouped transposes

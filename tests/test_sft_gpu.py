@@ -142,6 +142,14 @@ def test_backward_kernels_oplevel():
     out = torch.full((C, 128), 7, dtype=BF, device='cuda')
     ops.transpose(x, out, S, C, C, 128)
     assert torch.equal(out[:, :S], x.t()) and (out[:, S:] == 0).all()
+    # two-level batch (the grouped Q^T / dO^T of the attention backward): [S2, (kvh, g, d)] -> [kvh][d][g*Sp + s]
+    S2, nkv, G_, hd, Sp = 40, 2, 3, 64, 64
+    qx = torch.randn(S2, nkv * G_ * hd, generator=g).to(BF).cuda()
+    qt = torch.full((nkv, hd, G_ * Sp), 7, dtype=BF, device='cuda')
+    ops.transpose(qx, qt, S2, hd, nkv * G_ * hd, G_ * Sp, Sp, nkv, G_ * hd, hd * G_ * Sp, inner=G_, in_is=hd, out_is=Sp)
+    ref = torch.zeros(nkv, hd, G_, Sp, dtype=BF, device='cuda')
+    ref[:, :, :, :S2] = qx.view(S2, nkv, G_, hd).permute(1, 3, 2, 0)
+    assert torch.equal(qt.view(nkv, hd, G_, Sp), ref)
     # swiglu fwd / bwd on the packed layout
     I = 64
     gu_nat = torch.randn(S, 2, I, generator=g)

@@ -8,11 +8,12 @@
 // ---------------------------------------------------------------------------------------------- transpose (bf16)
 // out[b][c*ld_out + r] = in[b][r][c] for r < rows, 0 for rows <= r < pad_rows; 64x64 tiles through LDS.
 __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int rows, int cols, int ld_in,
-                                                        int ld_out, int pad_rows, long long in_bs, long long out_bs) {
+                                                        int ld_out, int pad_rows, long long in_bs, long long out_bs, int inner, long long in_is,
+                                                        long long out_is) {
   __shared__ bf16_t tile[64][66];
-  const int b = blockIdx.z, r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  const bf16_t* src = in + (size_t)b * in_bs;
-  bf16_t* dst = out + (size_t)b * out_bs;
+  const int b = blockIdx.z / inner, bi = blockIdx.z - b * inner, r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const bf16_t* src = in + (size_t)b * in_bs + (size_t)bi * in_is;
+  bf16_t* dst = out + (size_t)b * out_bs + (size_t)bi * out_is;
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int r = i >> 6, c = i & 63;
     tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(size_t)(r0 + r) * ld_in + c0 + c] : (bf16_t)0;
@@ -26,11 +27,11 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
 // vector variant: 16-byte global loads and stores on both sides (rows, cols, ld_in, ld_out, pad_rows multiples of 8,
 // 16-byte aligned bases); LDS tile row stride 72 elements keeps ds_write_b128 aligned.
 __global__ __launch_bounds__(256) void transpose_vec_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int rows, int cols, int ld_in,
-                                                            int ld_out, int pad_rows, long long in_bs, long long out_bs) {
+                                                            int ld_out, int pad_rows, long long in_bs, long long out_bs, int inner, long long in_is, long long out_is) {
   __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];
-  const int b = blockIdx.z, r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  const bf16_t* src = in + (size_t)b * in_bs;
-  bf16_t* dst = out + (size_t)b * out_bs;
+  const int b = blockIdx.z / inner, bi = blockIdx.z - b * inner, r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const bf16_t* src = in + (size_t)b * in_bs + (size_t)bi * in_is;
+  bf16_t* dst = out + (size_t)b * out_bs + (size_t)bi * out_is;
   const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 8;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
@@ -54,16 +55,17 @@ __global__ __launch_bounds__(256) void transpose_vec_kernel(const bf16_t* __rest
   }
 }
 extern "C" int vlaser_transpose(const void* in, void* out, int rows, int cols, int ld_in, int ld_out, int pad_rows, int batch, long long in_bs,
-                                long long out_bs, vl_stream_t s) {
-  VL_CHECK(in && out && rows > 0 && cols > 0 && pad_rows >= rows && ld_out >= pad_rows && batch >= 1, "vlaser_transpose: bad args");
-  const dim3 grid((cols + 63) / 64, (pad_rows + 63) / 64, batch);
-  const bool vec = ((rows | cols | ld_in | ld_out | pad_rows) & 7) == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0 && ((in_bs | out_bs) & 7) == 0;
+                                long long out_bs, int inner, long long in_is, long long out_is, vl_stream_t s) {
+  VL_CHECK(in && out && rows > 0 && cols > 0 && pad_rows >= rows && ld_out >= pad_rows && batch >= 1 && inner >= 1, "vlaser_transpose: bad args");
+  const dim3 grid((cols + 63) / 64, (pad_rows + 63) / 64, batch * inner);
+  const bool vec = ((rows | cols | ld_in | ld_out | pad_rows) & 7) == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0 &&
+                   ((in_bs | out_bs | in_is | out_is) & 7) == 0;
   if (vec)
     hipLaunchKernelGGL(transpose_vec_kernel, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)in, (bf16_t*)out, rows, cols, ld_in, ld_out, pad_rows,
-                       in_bs, out_bs);
+                       in_bs, out_bs, inner, in_is, out_is);
   else
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)in, (bf16_t*)out, rows, cols, ld_in, ld_out, pad_rows, in_bs,
-                       out_bs);
+                       out_bs, inner, in_is, out_is);
   VL_LAUNCH_CHECK();
   return 0;
 }

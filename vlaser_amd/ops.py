@@ -295,9 +295,9 @@ def cast_f32_bf16(x, y):
 
 
 # ------------------------------------------------------------------------------------------------ SFT (backward / optimizer)
-def transpose(x, out, rows, cols, ld_in, ld_out, pad_rows=None, batch=1, in_bs=0, out_bs=0):
+def transpose(x, out, rows, cols, ld_in, ld_out, pad_rows=None, batch=1, in_bs=0, out_bs=0, inner=1, in_is=0, out_is=0):
     L.check(L.lib().vlaser_transpose(x.data_ptr(), out.data_ptr(), rows, cols, ld_in, ld_out, ld_out if pad_rows is None else pad_rows, batch,
-                                     in_bs, out_bs, _stream()), 'vlaser_transpose')
+                                     in_bs, out_bs, inner, in_is, out_is, _stream()), 'vlaser_transpose')
 
 
 def softmax_causal(scores, P, batch, S, ld, scale):

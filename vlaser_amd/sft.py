@@ -452,9 +452,9 @@ class SFTModel:
             ops.attn_bwd_ds(P, dP, dao, ao, dS, dS_T, P_T, nq, nkv, S, Sp, hd, scale)
             ops.transpose(Kc, KT, S, hd, hd, Sp, Sp, nkv, sm * hd, hd * Sp)         # K [S, hd] -> K^T [hd, Sp]
             ops.gemm_raw(L.EPI_NONE, dS, KT, self.dq, S, hd, Sp, Sp, Sp, nq * hd, batch=nq, a_bs=S * Sp, w_bs=hd * Sp, o_bs=hd, w_group=G)  # dQ = dS K
-            for g_ in range(G):      # grouped transposes: [kvh][d][g*Sp + q]
-                ops.transpose(q[:, g_ * hd:], QT[:, :, g_ * Sp:], S, hd, nq * hd, G * Sp, Sp, nkv, G * hd, hd * G * Sp)
-                ops.transpose(dao[:, g_ * hd:], dOT[:, :, g_ * Sp:], S, hd, nq * hd, G * Sp, Sp, nkv, G * hd, hd * G * Sp)
+            # grouped transposes [S, (kvh, g, d)] -> [kvh][d][g*Sp + q]: outer batch = kv head, inner = q head of the group
+            ops.transpose(q, QT, S, hd, nq * hd, G * Sp, Sp, nkv, G * hd, hd * G * Sp, inner=G, in_is=hd, out_is=Sp)
+            ops.transpose(dao, dOT, S, hd, nq * hd, G * Sp, Sp, nkv, G * hd, hd * G * Sp, inner=G, in_is=hd, out_is=Sp)
             ops.gemm_raw(L.EPI_NONE, dS_T, QT, self.dk, S, hd, G * Sp, G * Sp, G * Sp, nkv * hd, batch=nkv, a_bs=Sp * G * Sp, w_bs=hd * G * Sp,
                          o_bs=hd, w_group=1)                                                                                             # dK = dS^T Q
             ops.gemm_raw(L.EPI_NONE, P_T, dOT, self.dv, S, hd, G * Sp, G * Sp, G * Sp, nkv * hd, batch=nkv, a_bs=Sp * G * Sp, w_bs=hd * G * Sp,
