@@ -313,7 +313,11 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
   int bm = args->force_bm;
   // measured on the path's shapes (tools/micro/kernel_lab.py): BM = 64 beats or ties BM = 128 everywhere up to ~1700
   // tiles (two 64-row workgroups per CU overlap each other's staging); 128 only pays on far larger grids
-  if (bm == 0) bm = blocks(128) >= 2048 ? 128 : (blocks(64) >= 192 ? 64 : 32);
+  if (bm == 0) {
+    bm = blocks(128) >= 2048 ? 128 : (blocks(64) >= 192 ? 64 : 32);
+    // the one measured exception: the prefill gate/up GEMM (SwiGLU epilogue, M a multiple of 128, >= 400 tiles): 36.5 vs 42.8 us
+    if (EPI == VL_EPI_SWIGLU && args->M % 128 == 0 && blocks(128) >= 400) bm = 128;
+  }
   if (bm == 128) return launch_bm<EPI, 128>(args, stream, splits);
   if (bm == 64) return launch_bm<EPI, 64>(args, stream, splits);
   return launch_bm<EPI, 32>(args, stream, splits);
