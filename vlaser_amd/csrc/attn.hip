@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     const int r = qt * 16 + fr;
-    const int hg = r / nq, tok = r - hg * nq;
+    const int hg = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)nq)), tok = r - hg * nq;     // r / nq without an integer division
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (size_t)b * a.q_bs + (size_t)(kvh * G + hg) * a.q_hs + (size_t)tok * a.q_ss;
 #pragma unroll
     for (int dc = 0; dc < DC; ++dc) {
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
       const int key = key0 + (fr >> 2) * 8 + t * 4 + (fr & 3);
 #pragma unroll
       for (int dc = 0; dc < DC; ++dc)
-        kf[t][dc] = (key < a.kv_len) ? ld_global_16(K + (size_t)key * HD + dc * 32 + g * 8) : u32x4{0, 0, 0, 0};
+        kf[t][dc] = ld_global_16(K + (size_t)min(key, a.kv_len - 1) * HD + dc * 32 + g * 8);   // clamped, unconditional: keys >= kv_len are never visible
     }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) vf[dt] = ld_global_16(VT + (size_t)(dt * 16 + fr) * a.ld_vt + key0 + g * 8);
@@ -332,6 +332,8 @@ __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
   // in-block merge of the 4 waves through LDS, then one partial per (b, kvh, split)
   constexpr int WS = 64 + 32 * 128;
   float* wm = reinterpret_cast<float*>(smem) + wave * WS;
+  const int nwa = min(SKA_WAVES, c_end - c_begin);     // waves that owned at least one chunk (block-uniform)
+  if (wave < nwa) {
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     float l_tot = l_run[qt] + __shfl_xor(l_run[qt], 16, 64);
@@ -339,6 +341,7 @@ __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
     if (g == 0) { wm[qt * 16 + fr] = m_run[qt]; wm[32 + qt * 16 + fr] = l_tot; }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(wm + 64 + (qt * 16 + fr) * 128 + dt * 16 + g * 4) = o[qt][dt];
+  }
   }
   __syncthreads();
   {
@@ -352,11 +355,13 @@ __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
     if (row < nrows) {
       float M = NEG_BIG;
 #pragma unroll
-      for (int w = 0; w < SKA_WAVES; ++w) M = fmaxf(M, base[w * WS + row]);
+      for (int w = 0; w < SKA_WAVES; ++w)
+        if (w < nwa) M = fmaxf(M, base[w * WS + row]);
       float Lsum = 0.f;
       f32x4 acc[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
 #pragma unroll
       for (int w = 0; w < SKA_WAVES; ++w) {
+        if (w >= nwa) break;
         const float* bw = base + w * WS;
         const float f = fast_exp2(bw[row] - M);
         Lsum += bw[32 + row] * f;
