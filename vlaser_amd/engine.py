@@ -213,9 +213,10 @@ def prefill_begin(stack: QwenStack, buf: PrefillBuffers, h, M):
 
 def prefill_layer(stack: QwenStack, lw: QwenLayerWeights, buf: PrefillBuffers, h, cache: KVCache, layer, rope, pos_ids, batch,
                   tok_per_batch, attn_mode, valid_len=None, blk_start=0, causal_off=0, kv_len=None, skip_post_attn=False,
-                  next_norm_w=None):
+                  next_norm_w=None, slot_base=0):
     """One Qwen2DecoderLayer over M = batch*tok_per_batch rows with the big-GEMM kernels; K/V written to slots
-    [0, tok_per_batch) of the cache.  Expects buf.x = input_layernorm(h); leaves buf.x = next_norm(h_out) when
+    [slot_base, slot_base + tok_per_batch) of the cache (slot_base > 0: decode steps of models too wide for the
+    weight-streaming kernels).  Expects buf.x = input_layernorm(h); leaves buf.x = next_norm(h_out) when
     next_norm_w is given (next layer's input_layernorm or the final norm).  h is updated in place.
     o_proj / down_proj run split-K (their [M, H] outputs have too few tiles to fill 256 CUs); the fp32 slabs are
     reduced by ONE fused kernel that also adds the residual and applies the following RMSNorm."""
@@ -225,11 +226,11 @@ def prefill_layer(stack: QwenStack, lw: QwenLayerWeights, buf: PrefillBuffers, h
     H, I = llm.hidden_size, llm.intermediate_size
     x, q, ao, act = buf.x[:M], buf.q[:M], buf.ao[:M], buf.act[:M]
     ops.gemm(L.EPI_QKV_ROPE, x, lw.wqkv, bias=lw.bqkv, q_out=q, k_cache=cache.k[layer], vt_cache=cache.vt[layer], rope_cos=rope[0],
-             rope_sin=rope[1], pos_ids=pos_ids, n_q_heads=nq, n_kv_heads=nkv, s_max=cache.s_max, tok_per_batch=tok_per_batch, slot_base=0)
+             rope_sin=rope[1], pos_ids=pos_ids, n_q_heads=nq, n_kv_heads=nkv, s_max=cache.s_max, tok_per_batch=tok_per_batch, slot_base=slot_base)
     ks, vs = cache.strides()
     ops.attn_prefill(q, cache.k[layer], cache.vt[layer], ao, batch, tok_per_batch, tok_per_batch if kv_len is None else kv_len, nq, nkv, hd,
                      (tok_per_batch * nq * hd, hd, nq * hd), ks, vs, (tok_per_batch * nq * hd, nq * hd), cache.s_max, hd ** -0.5,
-                     attn_mode, causal_off=causal_off, valid_len=valid_len, blk_start=blk_start)
+                     attn_mode, causal_off=causal_off, valid_len=valid_len, blk_start=blk_start, q_row_off=slot_base)
     if skip_post_attn:
         return
     sp_o, sp_d = ops.gemm_splits(M, H, nq * hd), ops.gemm_splits(M, H, I)

@@ -54,7 +54,8 @@ class InternVLChatModel:
         if missing and strict:
             raise KeyError(f'missing keys in state dict: {missing}')
         self.vit = VitEngine(sd, self.config, self.device, max_tiles=self._max_tiles)
-        self.llm = QwenStack(sd, 'language_model.', self.config.llm, self.device)
+        self.use_skinny = ops.skinny_supported(self.config.llm)      # Vlaser-8B (hidden 3584) decodes through the GEMM path
+        self.llm = QwenStack(sd, 'language_model.', self.config.llm, self.device, skinny=self.use_skinny)
         self._alloc_llm()
         return SimpleNamespace(missing_keys=missing, unexpected_keys=[])
 
@@ -123,8 +124,13 @@ class InternVLChatModel:
     def _head_last(self, h_last, partials, n_partials, M, greedy=True):
         """final RMSNorm + lm_head on M rows -> fp32 logits (+ argmax and next-token embedding gather)."""
         llm = self.config.llm
-        ops.skinny(L.PRO_NORM, L.SK_F32, h_last, self.llm.sk_head, M, partials=partials, n_partials=n_partials, norm_w=self.llm.norm,
-                   eps=llm.rms_norm_eps, out_f32=self.logits)
+        if self.use_skinny:
+            ops.skinny(L.PRO_NORM, L.SK_F32, h_last, self.llm.sk_head, M, partials=partials, n_partials=n_partials, norm_w=self.llm.norm,
+                       eps=llm.rms_norm_eps, out_f32=self.logits)
+        else:
+            assert partials is None
+            ops.rmsnorm(h_last, self.llm.norm, llm.rms_norm_eps, out=self.pbuf.x[:M])
+            ops.gemm(L.EPI_F32, self.pbuf.x[:M], self.llm.head, out=self.logits[:M])
         if greedy:
             ops.argmax(self.logits[:M], self.next_ids, self.llm.embed, self.next_h)
 
@@ -139,6 +145,17 @@ class InternVLChatModel:
         else:
             torch.add(lens, step, out=self.pos1[:B])
             slot, kv_len, mode, kw = L_cur + step, L_cur + step + 1, L.ATTN_PREFIX, dict(valid_len=lens, blk_start=L_cur)
+        if not self.use_skinny:
+            # MFMA GEMM path with one row per sequence: K/V appended at `slot`, PREFIX/CAUSAL visibility by descriptor
+            h, layers = self.next_h, self.llm.layers
+            prefill_begin(self.llm, self.pbuf, h, B)
+            for i, lw in enumerate(layers):
+                nxt = layers[i + 1].ln_in if i + 1 < len(layers) else None
+                prefill_layer(self.llm, lw, self.pbuf, h, self.cache, i, self.rope, self.pos1, B, 1,
+                              L.ATTN_PREFIX if lens is not None else L.ATTN_CAUSAL, causal_off=slot, kv_len=kv_len, next_norm_w=nxt,
+                              slot_base=slot, **kw)
+            self._head_last(h, None, 0, B)
+            return
         h, parts, npart = self.next_h, None, 0
         for i, lw in enumerate(self.llm.layers):
             h, parts, npart = skinny_layer(self.llm, lw, self.sbuf, h, parts, npart, self.cache, i, self.rope, self.pos1, B, 1, slot,

@@ -200,6 +200,17 @@ def pick_k_splits(K, N, target_blocks=72):
     return best
 
 
+def skinny_supported(llm):
+    """True when every matrix of a Qwen2 layer (+ lm_head) fits the weight-streaming kernel's 1..8 K-steps per wave
+    (K / (k_splits * 256)); Vlaser-2B and the 768-wide action expert do, the 3584-wide Vlaser-8B does not and decodes
+    through the MFMA GEMM path instead."""
+    H, I, nqd = llm.hidden_size, llm.intermediate_size, llm.num_attention_heads * llm.head_dim
+    for K, ks in ((H, 1), (nqd, pick_k_splits(nqd, H)), (I, pick_k_splits(I, H))):
+        if K % (ks * 256) or not 1 <= K // (ks * 256) <= 8:
+            return False
+    return True
+
+
 # ------------------------------------------------------------------------------------------------ helpers
 def layernorm(x, w, b, eps, out=None):
     out = torch.empty_like(x) if out is None else out
