@@ -286,6 +286,143 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- LDS-DMA variant
+// Same tiles, fragments and epilogues as gemm_kernel, but the operands go global -> LDS directly (global_load_lds_dwordx4:
+// no staging VGPRs, no ds_write pass -- the ablation of the register-staged loop attributes ~45 % of its time to that
+// path) into NST LDS stages, NST-1 K-tiles in flight, ONE raw s_barrier per K-step and a counted vmcnt (never 0 inside
+// the loop).  An LDS-DMA wave instruction writes 64 lanes x 16 B to CONSECUTIVE LDS addresses (M0 base + lane*16), i.e.
+// 8 rows x 128 B of the row-major tile image; the XOR swizzle of the image is therefore applied on the SOURCE side: lane l
+// of piece j fetches logical slot (l&7) ^ (row&7) of row 8j + (l>>3).  The DMA is issued from inline asm so that hipcc
+// neither counts it nor drains it at its own waits (guide §5.7); ordering is ours: vmcnt(N) -> s_barrier -> ds_read.
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int EPI, int BM, int NST>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) {
+  constexpr int WR = BM >= 64 ? 2 : 1, WC = 4 / WR;
+  constexpr int WTM = BM / WR, WTN = BN / WC;
+  constexpr int MT = WTM / 16, NT = WTN / 16;
+  constexpr int STAGE = BM * 128 + 16384;               // bytes: A tile | W tile
+  constexpr int PA = BM / 8 / 4, PW = 16 / 4;           // 1 KiB pieces per wave per K-tile (A, W)
+  constexpr int PIECES = PA + PW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const VlaserGemmArgs& a = p.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = bid % p.tiles_m, tile_n = bid / p.tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kc = a.K / (int)gridDim.y;
+  const int kbase = blockIdx.y * kc;
+  const int bz = blockIdx.z;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A) + (size_t)bz * a.a_bs;
+  const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W) + (size_t)(a.w_group > 1 ? bz / a.w_group : bz) * a.w_bs;
+  const int nk = kc / BK;
+
+  // per-lane source pointers of this wave's pieces (row clamped; the swizzle lives in the source slot)
+  const int prow = lane >> 3, pslot = lane & 7;
+  const bf16_t* srcA[PA];
+  const bf16_t* srcW[PW];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = (wave * PA + i) * 8 + prow;
+    srcA[i] = A + (size_t)min(m0 + row, a.M - 1) * a.lda + kbase + ((pslot ^ (row & 7)) << 3);
+  }
+#pragma unroll
+  for (int i = 0; i < PW; ++i) {
+    const int row = (wave * PW + i) * 8 + prow;
+    srcW[i] = W + (size_t)min(n0 + row, a.N - 1) * a.ldw + kbase + ((pslot ^ (row & 7)) << 3);
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;      // LDS byte address of the stage ring (low 32 bits of the generic pointer)
+  auto issue_tile = [&](int kt, int st) {
+    const int ko = min(kt, nk - 1) * BK;                 // tiles past the end re-fetch the last one (never read)
+    const uint32_t base = lds0 + st * STAGE;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) glds16(srcA[i] + ko, __builtin_amdgcn_readfirstlane(base + (wave * PA + i) * 1024));
+#pragma unroll
+    for (int i = 0; i < PW; ++i) glds16(srcW[i] + ko, __builtin_amdgcn_readfirstlane(base + BM * 128 + (wave * PW + i) * 1024));
+  };
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+#pragma unroll
+  for (int st = 0; st < NST - 1; ++st) issue_tile(st, st);
+  const int fr = lane & 15, fq = lane >> 4;
+  int st = 0;                                            // stage of tile kt
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt<PIECES * (NST - 2)>();                    // this wave's pieces of tile kt have landed (younger tiles may fly)
+    __builtin_amdgcn_s_barrier();                        // ... and everyone else's; also: all waves are done reading stage kt-1
+    int stn = st + NST - 1; if (stn >= NST) stn -= NST;  // = (kt-1) % NST: the stage read in the previous step
+    issue_tile(kt + NST - 1, stn);
+    const char* As = smem + st * STAGE;
+    const char* Ws = As + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[MT], fw[NT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+        fa[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + lds_off(wr * WTM + t * 16 + fr, ks * 4 + fq)));
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        fw[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ws + lds_off(wc * WTN + t * 16 + fr, ks * 4 + fq)));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(fw[nt], fa[mt], acc[nt][mt]);
+    }
+    if (++st == NST) st = 0;
+  }
+  wait_vmcnt<0>();                                       // drain the clamped look-ahead tiles before the block retires
+
+  VlaserGemmArgs ea = a;
+  if (bz > 0) {
+    if (ea.out) ea.out = reinterpret_cast<char*>(ea.out) + (size_t)bz * a.o_bs * (EPI == VL_EPI_F32 ? 4 : 2);
+    if (ea.out_f32) ea.out_f32 += (size_t)bz * a.o_bs;
+    if (ea.res) ea.res = reinterpret_cast<const char*>(ea.res) + (size_t)bz * a.o_bs * 2;
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + wr * WTM + mt * 16 + fr;
+    if constexpr (EPI == VL_EPI_SWIGLU || EPI == VL_EPI_QKV_ROPE) {
+#pragma unroll
+      for (int nt = 0; nt < NT; nt += 2) epilogue<EPI>(ea, m, n0 + wc * WTN + nt * 16 + fq * 4, acc[nt][mt], acc[nt + 1][mt]);
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) epilogue<EPI>(ea, m, n0 + wc * WTN + nt * 16 + fq * 4, acc[nt][mt], acc[nt][mt]);
+    }
+  }
+}
+
+template <int EPI, int BM, int NST>
+static int launch_glds(const VlaserGemmArgs* args, hipStream_t stream, int splits) {
+  GemmP p;
+  p.a = *args;
+  p.tiles_m = (args->M + BM - 1) / BM;
+  p.tiles_n = (args->N + BN - 1) / BN;
+  constexpr int lds = NST * (BM * 128 + 16384);
+  static bool attr_set = false;
+  if (!attr_set) {
+    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<EPI, BM, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BM, NST>), dim3(p.tiles_m * p.tiles_n, splits, args->batch > 1 ? args->batch : 1), dim3(256), lds, stream, p);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int EPI, int BM>
 static int launch_bm(const VlaserGemmArgs* args, hipStream_t stream, int splits) {
   GemmP p;
@@ -318,6 +455,12 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
     // the one measured exception: the prefill gate/up GEMM (SwiGLU epilogue, M a multiple of 128, >= 400 tiles): 36.5 vs 42.8 us
     if (EPI == VL_EPI_SWIGLU && args->M % 128 == 0 && blocks(128) >= 400) bm = 128;
   }
+  // LDS-DMA variant (gemm_glds_kernel, 2 stages): +3..17 % on bare GEMMs in tools/micro, but no gain inside the real
+  // chunk / SFT step (172 vs 132 VGPRs costs a workgroup of occupancy under the fused epilogues) -> opt-in until the
+  // deeper-pipelined structure it is the base for exists.
+  static const bool glds = getenv("VLASER_GEMM_GLDS") != nullptr;
+  if (glds && bm == 128) return launch_glds<EPI, 128, 2>(args, stream, splits);
+  if (glds && bm == 64) return launch_glds<EPI, 64, 2>(args, stream, splits);
   if (bm == 128) return launch_bm<EPI, 128>(args, stream, splits);
   if (bm == 64) return launch_bm<EPI, 64>(args, stream, splits);
   return launch_bm<EPI, 32>(args, stream, splits);
