@@ -129,10 +129,11 @@ def sft_bench(rank, world, local, dist, steps, warmup=2):
     assert loss == loss, 'SFT loss is NaN'
     del model
     torch.cuda.empty_cache()
-    # algorithmic work per rank-step: 7592 GFLOP for 560 tokens
+    # algorithmic work per rank-step: 6 x 1.695 G matmul params x 560 tokens = 5694 GFLOP (SURVEY 8d quotes 7592 with the
+    # reference's per-layer recompute, which this build does not do: activations are kept)
     return {'metric': 'sft_tokens_per_sec', 'value': round(world * steps * S / dt, 1), 'unit': 'tokens/s', 'ms_per_step': round(dt / steps * 1e3, 2),
             'steps': steps, 'tokens_per_rank_step': S, 'last_loss': round(loss, 4), 'parallelism': f'dp{world} (ZeRO-1 bucketed RCCL reduce-scatter + all-gather)',
-            'mfma_frac': round(7592e9 * world * steps / dt / (world * 2.5e15), 4)}
+            'mfma_frac': round(5694e9 * world * steps / dt / (world * 2.5e15), 4)}
 
 
 def main():
@@ -222,7 +223,46 @@ def main():
             line['cpu_baseline'] = cpu_baseline(vla)
         if sft_line is not None:
             line['sft'] = sft_line
+        if world == 1 and a.workload == 'both':
+            del model
+            torch.cuda.empty_cache()
+            line['qa'] = qa_bench(local)
     _finish(dist, line if rank == 0 else None)
+
+
+def qa_bench(local):
+    """BASELINE configs[1] side numbers ('report QA forward latency as prefill ms + decode tokens/s'): Vlaser-2B,
+    one 448 px tile + 256-token prompt (S = 560), greedy decode of 32 tokens, batch 1 and batch 8."""
+    from vlaser_amd import config as C, synth
+    from vlaser_amd.internvl_chat import InternVLChatModel
+    dev = f'cuda:{local}'
+    cfg = C.vlaser_2b()
+    sd = synth.vlm_state_dict(cfg, device=dev, dtype=torch.bfloat16)
+    m = InternVLChatModel(cfg, device=dev, max_seq_len=640, max_batch=8)
+    m.load_state_dict(sd)
+    del sd
+    m.img_context_token_id = cfg.img_context_token_id
+    out = {}
+    for B in (1, 8):
+        g = torch.Generator().manual_seed(7)
+        pv = torch.randn(B, 3, 448, 448, generator=g).to(dev).to(torch.bfloat16)
+        ids = torch.cat([torch.randint(0, 151643, (B, 41), generator=g), torch.full((B, 256), cfg.img_context_token_id),
+                         torch.randint(0, 151643, (B, 263), generator=g)], 1)
+        ts = []
+        for n_new in (1, 33):                      # time(33 tokens) - time(1 token) = 32 decode steps
+            m.generate(pv, ids, max_new_tokens=n_new, min_new_tokens=n_new)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                m.generate(pv, ids, max_new_tokens=n_new, min_new_tokens=n_new)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / 3)
+        out[f'batch{B}'] = {'prefill_ms': round(ts[0] * 1e3, 2), 'decode_tokens_per_s': round(B * 32 / (ts[1] - ts[0]), 1),
+                            'decode_ms_per_step': round((ts[1] - ts[0]) / 32 * 1e3, 3)}
+    out['config'] = 'Vlaser-2B, 1 tile + 256-token prompt (S=560), greedy, 32 new tokens; prefill_ms = ViT + prefill + first token; eager launches (no graph)'
+    del m
+    torch.cuda.empty_cache()
+    return out
 
 
 def _pmc_traffic():
