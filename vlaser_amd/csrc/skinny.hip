@@ -155,6 +155,9 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
   constexpr int RPU = TPU * 16;                 // rows per unit
   constexpr int NF = TPU * NS;                  // fragments (16-byte loads) per lane per unit
   constexpr bool NEED_EPI = (EPI == VL_SK_BIAS || EPI == VL_SK_BIAS_SILU || EPI == VL_SK_QKV_ROPE || EPI == VL_SK_F32);
+  // EARLY (gate/up: 2-3 units per block): units 1 and 2 are requested as soon as the prologue's own loads are back
+  // (first barrier) instead of one unit ahead of the MFMAs, so the HBM stream does not restart after the ~3 us prologue
+  constexpr bool EARLY = (PRO == VL_PRO_NORM && EPI == VL_SK_SWIGLU);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const VlaserSkinnyArgs& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -180,8 +183,8 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
   const u32x4* wp = reinterpret_cast<const u32x4*>(a.W) + ((size_t)ks * n_units * SKW + wave) * (NF * 64) + lane;
   constexpr size_t unit_stride = (size_t)SKW * NF * 64;
   const int m = fr;
-  u32x4 cw[NF], nw[NF];                      // current / next unit (both requested at entry)
-  EpiOps ce[NEED_EPI ? TPU / 2 : 1], ne[NEED_EPI ? TPU / 2 : 1];
+  u32x4 cw[NF], nw[NF], tw[EARLY ? NF : 1];  // current / next (/ third, EARLY) unit
+  EpiOps ce[NEED_EPI ? TPU / 2 : 1], ne[NEED_EPI ? TPU / 2 : 1], te[1];
   auto load_unit = [&](int ui, u32x4* dst, EpiOps* e) {
     const u32x4* src = wp + (size_t)(ustart + ui) * unit_stride;
 #pragma unroll
@@ -352,6 +355,10 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
     }  // SP < 0
     __syncthreads();
     STAMP(1);
+    if constexpr (EARLY) {                     // block-uniform conditions; hipcc then waits for all of them at the first use: fine,
+      if (ucount > 1) load_unit(1, nw, ne);    // they were requested ~2 us before anything consumes them
+      if (ucount > 2) load_unit(2, tw, te);
+    }
     // phase 2 (one wave per row, LDS only): sum of squares, normalise in place
     for (int mm = wave; mm < a.M; mm += SKW) {
       float ssq = 0.f;
@@ -420,8 +427,21 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
       }
     }
   };
+  int ui0 = 0;
+  if constexpr (EARLY) {
+    consume_finish(0, cw, ce);
+    if (ucount > 1) consume_finish(1, nw, ne);
+    if (ucount <= 3) {
+      if (ucount > 2) consume_finish(2, tw, te);
+      STAMP(5);
+      return;
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) cw[f] = tw[f];       // more than 3 units: continue one unit ahead from unit 2
+    ui0 = 2;
+  }
   // while unit ui is consumed, unit ui+1 is in flight; last unit peeled (no dangling prefetch)
-  for (int ui = 0; ui + 1 < ucount; ++ui) {
+  for (int ui = ui0; ui + 1 < ucount; ++ui) {
     load_unit(ui + 1, nw, ne);
     consume_finish(ui, cw, ce);
 #pragma unroll
