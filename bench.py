@@ -226,8 +226,38 @@ def main():
         if world == 1 and a.workload == 'both':
             del model
             torch.cuda.empty_cache()
+            line['batched'] = batched_chunks(vla, dev, a.steps)
             line['qa'] = qa_bench(local)
     _finish(dist, line if rank == 0 else None)
+
+
+def batched_chunks(vla, dev, steps):
+    """Side number (never `value`): the same chunk workload with 3 observations per infer_action call -- the largest batch
+    whose 3 x (1 proprio + 4 action) rows fit the 16-row weight-streaming kernels, i.e. the expert's weights are streamed
+    once for 3 chunks."""
+    from vlaser_amd import synth
+    from vlaser_amd.pizero import PiZeroInference
+    B = 3
+    sd = synth.vla_state_dict(vla, device=dev, dtype=torch.bfloat16)
+    model = PiZeroInference(vla, device=dev, max_batch=B)
+    model.load_state_dict(sd)
+    del sd
+    ids, pv, proprio, noise = make_inputs(vla.base, B, seed=100)
+    ids_d, pv_d, pro_d, noise_d = ids.to(dev), pv.to(dev).to(torch.bfloat16), proprio.to(dev), noise.to(dev)
+    valid = (ids != vla.base.pad_token_id).sum(-1).to(dev)
+    call = lambda: model.infer_action(ids_d, pv_d, proprios=pro_d, noise=noise_d, valid_len=valid)
+    for _ in range(3):
+        out = call()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = call()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    del model
+    torch.cuda.empty_cache()
+    return {'batch': B, 'action_chunks_per_sec': round(B * steps / dt, 2), 'ms_per_call': round(dt / steps * 1e3, 3)}
 
 
 def qa_bench(local):
