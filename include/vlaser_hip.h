@@ -143,6 +143,11 @@ typedef struct {
 
 int vlaser_skinny(int prologue, int epi, const VlaserSkinnyArgs* args, vl_stream_t stream);
 
+/* Weight-gradient GEMM: out[M,N] (bf16) = At^T @ Wt, At [K,M] and Wt [K,N] row-major bf16 (contraction along rows).
+ * dW = dY^T X of every nn.Linear on the SFT path (autograd of modeling_internvl_chat.py:194-203): At = dY [S,N_out],
+ * Wt = X [S,K_in].  Rows 16-byte aligned and readable up to M / N rounded up to 8 columns (ld >= that). */
+int vlaser_gemm_tn(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, vl_stream_t stream);
+
 /* ---- memory-bound helpers -------------------------------------------------------------------------------------- */
 /* nn.LayerNorm (NORM2FN['layer_norm'], modeling_intern_vit.py:127-130,275-276) and Qwen2RMSNorm. bf16 [rows, C]. */
 int vlaser_layernorm(const void* x, const void* w, const void* b, void* out, int rows, int C, float eps, vl_stream_t stream);

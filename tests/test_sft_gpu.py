@@ -172,3 +172,21 @@ def test_backward_kernels_oplevel():
     ops.gemm_raw(L.EPI_F32, A, W, o, 40, 50, 128, 128, 128, 64, batch=3, a_bs=40 * 128, w_bs=50 * 128, o_bs=40 * 64, w_group=1)
     rel, _ = _rel(o[:, :, :50], A.float() @ W.float().transpose(1, 2))
     assert rel < 5e-3
+
+
+@pytest.mark.parametrize('K,M,N', [(560, 1536, 2048), (313, 256, 1536), (64, 8, 136), (130, 17920, 1536), (48, 1002, 520)])
+def test_gemm_tn_weight_gradient(K, M, N):
+    """out = At^T @ Wt with the contraction along the rows of both operands (transposing LDS reads): ragged K (zero-filled
+    tail rows), edge tiles in M and N, strided operand views."""
+    from vlaser_amd import ops
+    g = torch.Generator().manual_seed(K + M)
+    big_a = torch.randn(K, (M + 7) // 8 * 8 + 16, generator=g).to(BF).cuda()
+    big_w = torch.randn(K + 3, N, generator=g).to(BF).cuda()
+    At, Wt = big_a[:, 8:8 + M], big_w[:K]                     # column-offset view (16-byte aligned) and a row-truncated view
+    out = torch.full((M, N), 7.0, dtype=BF, device='cuda')
+    ops.gemm_tn(At, Wt, out)
+    ref = At.float().t() @ Wt.float()
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 2e-2 * ref.abs().max().item() + 1e-3, err
+    rel, cos = _rel(out, ref)
+    assert rel < 5e-3 and cos > 0.9999

@@ -466,6 +466,167 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
   return launch_bm<EPI, 32>(args, stream, splits);
 }
 
+// ---------------------------------------------------------------------------------------------- TN GEMM (weight gradients)
+// out[M,N] = At^T @ Wt with At [K,M] and Wt [K,N] row-major, i.e. the contraction index is the SLOW axis of both operands:
+// dW[n_out, k_in] = sum_s dY[s, n_out] * X[s, k_in] straight from the activations as the forward/backward left them -- no
+// transposed copies (they cost 8 launches and ~0.1 ms per layer).  Tiles are staged as they lie in memory ([64 s][cols]
+// rows of 16-byte chunks) and the MFMA fragments (8 consecutive s for one column) are gathered by gfx950's transposing
+// LDS read: a 16-lane group passes 16 8-byte pieces, piece p = 4 consecutive columns of row p>>2, and lane i receives,
+// for j = 0..3, element (i&3) of piece 4j + (i>>2) = T[row j][col i] (probed: tools/micro/tr16_probe.hip).  Row pitches
+// of 160 B (64-column tile) / 288 B (128-column tile) put the 8 rows a 32-lane access touches on disjoint banks.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ bf16x8 tr_frag(const char* lds_tile, int pitch, int col0, int krow0, int fq, int fr) {
+  // fragment of 8 k-values for column col0 + fr.  The MFMA only needs A and B to agree on which k a (lane group fq, slot)
+  // pair means, so slot (h, j) of group fq is taken as row krow0 + 16 h + 4 fq + j: the two groups of a 32-lane LDS access
+  // then read 8 CONSECUTIVE rows, which the 160 B / 288 B pitches spread over disjoint banks (rows r and r + 8 would collide).
+  const char* p0 = lds_tile + (krow0 + 4 * fq + (fr >> 2)) * pitch + (col0 + 4 * (fr & 3)) * 2;
+  typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(uint32_t)(uintptr_t)p0);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(uint32_t)(uintptr_t)(p0 + 16 * pitch));
+  union { s16x4_t h[2]; bf16x8 b; } u;
+  u.h[0] = lo; u.h[1] = hi;
+  return u.b;
+}
+
+struct GemmTnP {
+  const bf16_t* At; const bf16_t* Wt; bf16_t* out;
+  int M, N, K, ldat, ldwt, ldo, tiles_m, tiles_n;
+};
+
+template <int BM>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnP p) {
+  constexpr int WR = 2, WC = 2;
+  constexpr int WTM = BM / WR, WTN = BN / WC;
+  constexpr int MT = WTM / 16, NT = WTN / 16;
+  constexpr int PA = BM * 2 + 32, PW = BN * 2 + 32;      // row pitches (bytes): 160 / 288 -> conflict-free transposing reads
+  constexpr int ACH = BM / 32;                           // 16-byte A chunks per thread per K-tile (64 rows x BM/8 chunks / 256)
+  constexpr int BUF = 64 * PA + 64 * PW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = bid % p.tiles_m, tile_n = bid / p.tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nk = (p.K + BK - 1) / BK;
+  // staging map: A: row = tid / (BM/8) + rows_per_pass * i, chunk = tid % (BM/8); W: row = tid / 16 + 16 * i, chunk = tid % 16
+  constexpr int ACPR = BM / 8, ARPP = 256 / ACPR;        // chunks per row, rows per pass
+  const int arow = tid / ACPR, achk = tid % ACPR;
+  const int wrow = tid >> 4, wchk = tid & 15;
+  const bf16_t* pa = p.At + min(m0 + achk * 8, ((p.M + 7) & ~7) - 8);   // column clamp (chunk-aligned): columns >= M only feed dropped outputs
+  const bf16_t* pw = p.Wt + min(n0 + wchk * 8, ((p.N + 7) & ~7) - 8);
+  u32x4 ra[2][ACH], rw[2][4];
+  auto load_tile = [&](int kt, int st) {
+    const int k0 = min(kt, nk - 1) * BK;
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+      const int s = k0 + arow + ARPP * i;
+      const u32x4 v = ld_global_16(pa + (size_t)min(s, p.K - 1) * p.ldat);
+      ra[st][i] = s < p.K ? v : u32x4{0, 0, 0, 0};               // rows past K must contribute zero (select on data, load unconditional)
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int s = k0 + wrow + 16 * i;
+      rw[st][i] = ld_global_16(pw + (size_t)min(s, p.K - 1) * p.ldwt);   // clamped (finite data): the zeroed A rows cancel it
+    }
+  };
+  auto store_tile = [&](int buf, int st) {
+    char* base = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) *reinterpret_cast<u32x4*>(base + (arow + ARPP * i) * PA + achk * 16) = ra[st][i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(base + 64 * PA + (wrow + 16 * i) * PW + wchk * 16) = rw[st][i];
+  };
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+  const int fr = lane & 15, fq = lane >> 4;
+  load_tile(0, 0);
+  load_tile(1, 1);
+  store_tile(0, 0);
+  __syncthreads();
+  auto kstep = [&](int kt, int nst) __attribute__((always_inline)) {
+    const int buf = kt & 1;
+    const char* As = smem + buf * BUF;
+    const char* Ws = As + 64 * PA;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[MT], fw[NT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) fa[t] = tr_frag(As, PA, wr * WTM + t * 16, ks * 32, fq, fr);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) fw[t] = tr_frag(Ws, PW, wc * WTN + t * 16, ks * 32, fq, fr);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(fw[nt], fa[mt], acc[nt][mt]);
+    }
+    store_tile(buf ^ 1, nst);
+    __builtin_amdgcn_sched_barrier(0);
+    load_tile(kt + 2, nst ^ 1);            // the stage just consumed two steps ago: tile kt went to LDS before this step
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  };
+  // register stages alternate: tile kt+1 sits in stage (kt+1)&1; after it is stored, stage kt&1 (tile kt, already in LDS) is refilled with kt+2
+  int kt = 0;
+  for (; kt + 2 <= nk; kt += 2) {
+    kstep(kt, 1);
+    kstep(kt + 1, 0);
+  }
+  if (kt < nk) kstep(kt, 1);
+
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + wr * WTM + mt * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wc * WTN + nt * 16 + fq * 4;
+      bf16_t* o = p.out + (size_t)m * p.ldo + n;
+      const f32x4 v = acc[nt][mt];
+      if (n + 3 < p.N && (p.ldo & 3) == 0) {
+        *reinterpret_cast<u32x2*>(o) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n + j < p.N) o[j] = f32_to_bf16(v[j]);
+      }
+    }
+  }
+}
+
+extern "C" int vlaser_gemm_tn(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, vl_stream_t s) {
+  VL_CHECK(At && Wt && out && M >= 8 && N >= 8 && K > 0, "vlaser_gemm_tn: bad arguments (M, N >= 8)");
+  VL_CHECK(ldat % 8 == 0 && ldwt % 8 == 0 && (((uintptr_t)At | (uintptr_t)Wt) & 15) == 0, "vlaser_gemm_tn: operands must be 16-byte aligned rows");
+  VL_CHECK(ldat >= ((M + 7) & ~7) && ldwt >= ((N + 7) & ~7), "vlaser_gemm_tn: operand rows must be readable up to M, N rounded up to 8 columns");
+  GemmTnP p{(const bf16_t*)At, (const bf16_t*)Wt, (bf16_t*)out, M, N, K, ldat, ldwt, ldo, 0, (N + BN - 1) / BN};
+  hipStream_t stream = reinterpret_cast<hipStream_t>(s);
+  constexpr int lds64 = 2 * (64 * (64 * 2 + 32) + 64 * (BN * 2 + 32)), lds128 = 2 * (64 * (128 * 2 + 32) + 64 * (BN * 2 + 32));
+  static bool attr_set = false;
+  if (!attr_set) {
+    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64));
+    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds128));
+    attr_set = true;
+  }
+  static const int force = getenv("VLASER_TN_BM") ? atoi(getenv("VLASER_TN_BM")) : 0;   // LAB
+  const bool big = force ? force == 128 : ((M + 127) / 128) * p.tiles_n >= 512;
+  if (big) {
+    p.tiles_m = (M + 127) / 128;
+    hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(p.tiles_m * p.tiles_n), dim3(256), lds128, stream, p);
+  } else {
+    p.tiles_m = (M + 63) / 64;
+    hipLaunchKernelGGL(gemm_tn_kernel<64>, dim3(p.tiles_m * p.tiles_n), dim3(256), lds64, stream, p);
+  }
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(s);
   VL_CHECK(a && a->A && a->W, "vlaser_gemm: null operand");

@@ -306,6 +306,15 @@ def cast_f32_bf16(x, y):
 
 
 # ------------------------------------------------------------------------------------------------ SFT (backward / optimizer)
+def gemm_tn(At, Wt, out, K=None):
+    """out[M,N] = At[:K]^T @ Wt[:K] (bf16): At [K,M], Wt [K,N] row-major views (row strides honoured)."""
+    K = At.shape[0] if K is None else K
+    M, N = At.shape[1], Wt.shape[1]
+    L.check(L.lib().vlaser_gemm_tn(At.data_ptr(), Wt.data_ptr(), out.data_ptr(), M, N, K, At.stride(0), Wt.stride(0), out.stride(0), _stream()),
+            'vlaser_gemm_tn')
+    return out
+
+
 def transpose(x, out, rows, cols, ld_in, ld_out, pad_rows=None, batch=1, in_bs=0, out_bs=0, inner=1, in_is=0, out_is=0):
     L.check(L.lib().vlaser_transpose(x.data_ptr(), out.data_ptr(), rows, cols, ld_in, ld_out, ld_out if pad_rows is None else pad_rows, batch,
                                      in_bs, out_bs, inner, in_is, out_is, _stream()), 'vlaser_transpose')

@@ -223,8 +223,6 @@ class SFTModel:
         self.dS_T, self.P_T = z(nkv, S, G * S), z(nkv, S, G * S)
         self.Vn, self.KT = z(nkv, S, hd), z(nkv, hd, S)
         self.QT, self.dOT = z(nkv, hd, G * S), z(nkv, hd, G * S)
-        self.tA = z(max(2 * I, NQ, H, C4) * S)      # transposed-activation scratch (dY^T)
-        self.tB = z(max(I, H, nq * hd, C4) * S)     # transposed-activation scratch (X^T)
         self.col = torch.zeros(max(2 * I, NQ, C4, H), dtype=F32, device=dev)
         self.rowstat = torch.zeros(2 * max(S, self.max_tiles * cfg.num_image_token) + 16 * max(2 * I, NQ, C4, H), dtype=F32, device=dev)   # colsum scratch
         self.sumsq_ws = torch.zeros(1024, dtype=F32, device=dev)
@@ -262,15 +260,11 @@ class SFTModel:
 
     # ------------------------------------------------------------------ small helpers
     def _wgrad(self, dY, X, out, S, bias_out=None):
-        """out[N,K] = dY[S,N]^T @ X[S,K] (bf16): both operands transposed to [*, Sp] (zero padded) then one NT GEMM."""
-        N, K = dY.shape[1], X.shape[1]
-        Sp = (S + 63) // 64 * 64
-        tA = self.tA[:N * Sp].view(N, Sp)
-        tB = self.tB[:K * Sp].view(K, Sp)
-        ops.transpose(dY, tA, S, N, dY.stride(0), Sp)
-        ops.transpose(X, tB, S, K, X.stride(0), Sp)
-        ops.gemm(L.EPI_NONE, tA, tB, out=out)
+        """out[N,K] = dY[S,N]^T @ X[S,K] (bf16) by the TN GEMM: both operands are read as they lie (contraction along their
+        rows, transposing LDS reads) -- no transposed activation copies."""
+        ops.gemm_tn(dY[:S], X[:S], out)
         if bias_out is not None:
+            N = dY.shape[1]
             ops.colsum_mul(dY, None, self.col, S, N, 0, ws=self.rowstat)
             bias_out.copy_(self.col[:N])
 
@@ -393,12 +387,7 @@ class SFTModel:
         ops.ce_dlogits(logits, lse, t_rows, dlog, 1.0 / R)
         dx_rows = torch.empty(R, H, dtype=BF, device=dev)
         ops.gemm(L.EPI_NONE, dlog, self.headT, out=dx_rows)          # dX = dlogits @ W_head
-        Rp = (R + 63) // 64 * 64
-        tA = torch.empty(V, Rp, dtype=BF, device=dev)
-        tB = torch.empty(H, Rp, dtype=BF, device=dev)
-        ops.transpose(dlog, tA, R, V, self.Vp, Rp)
-        ops.transpose(x_rows, tB, R, H, H, Rp)
-        ops.gemm(L.EPI_NONE, tA, tB, out=gv['head'])                 # dW_head = dlogits^T @ x
+        ops.gemm_tn(dlog[:, :V], x_rows, gv['head'])                # dW_head = dlogits^T @ x (dlogits rows are padded to Vp columns)
         dxn = self.dx[:S]
         dxn.zero_()
         dxn.index_copy_(0, rows, dx_rows)
