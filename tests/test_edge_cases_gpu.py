@@ -1,0 +1,142 @@
+"""Edge cases of the hot path on the GPU against the CPU oracle (depth-truncated true-width Vlaser-2B): the ragged / extreme
+inputs the reference's own code paths distinguish.
+
+  * infer_action: no padding at all (384 valid tokens), the shortest legal prompt (template + image, no instruction text),
+    and a batch mixing both (per-sequence valid lengths in one launch);
+  * generate: a batch in which one sequence hits eos first (finished rows emit pad, the other keeps decoding), and
+    min_new_tokens suppressing the stop;
+  * 13 tiles (dynamic high resolution, 3328 visual tokens) through extract_feature + prefill;
+  * SFT: image_flags dropping a tile, a step whose labels are all ignored, two tiles per sample.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _relmax(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().max() / b.abs().max()).item()
+
+
+def _vla_obs(cfg, n_text, seed):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.full((1, 384), cfg.pad_token_id)
+    ids[0, :10] = torch.randint(0, 151643, (10,), generator=g)
+    ids[0, 10:266] = cfg.img_context_token_id
+    ids[0, 266:266 + n_text] = torch.randint(0, 151643, (n_text,), generator=g)
+    return ids, torch.randn(1, 3, 448, 448, generator=g), torch.rand(1, 1, 7, generator=g) * 2 - 1, torch.randn(1, 4, 7, generator=g)
+
+
+def test_infer_action_valid_length_extremes(golden_model):
+    from oracle import vla as ovla
+    from vlaser_amd.pizero import PiZeroInference
+    cfg, vla, sd = golden_model
+    m = PiZeroInference(vla, max_batch=2)
+    m.load_state_dict(sd)
+    obs = [_vla_obs(cfg, 118, seed=31), _vla_obs(cfg, 0, seed=32)]           # 384 valid (no pad) / 266 valid (no instruction)
+    singles = []
+    for ids, pv, pro, noise in obs:
+        am = (ids != cfg.pad_token_id).long()
+        assert int(am.sum()) in (384, 266)
+        mask, vp, pp, ap = ovla.build_causal_mask_and_position_ids(am, torch.float32, vla)
+        m1, m2 = ovla.split_full_mask_into_submasks(mask, vla)
+        ref = ovla.infer_action(sd, vla, ids, pv, m1, m2, vp, pp, ap, pro, noise)
+        act = m.infer_action(ids, pv, m1, m2, vp, pp, ap, pro, noise=noise)
+        assert (act.cpu() - ref).abs().max().item() < 2.5e-2
+        singles.append(act.clone())
+    # both in one batch: per-sequence valid lengths inside one launch
+    cat = [torch.cat([a, b], 0) for a, b in zip(*obs)]
+    am = (cat[0] != cfg.pad_token_id).long()
+    mask, vp, pp, ap = ovla.build_causal_mask_and_position_ids(am, torch.float32, vla)
+    m1, m2 = ovla.split_full_mask_into_submasks(mask, vla)
+    both = m.infer_action(cat[0], cat[1], m1, m2, vp, pp, ap, cat[2], noise=cat[3])
+    for b in range(2):
+        assert (both[b] - singles[b][0]).abs().max().item() < 2.5e-2
+
+
+def test_generate_eos_in_batch_and_min_new_tokens(golden_model, golden_dir):
+    import os
+    from oracle import vlm as ovlm
+    from vlaser_amd.internvl_chat import InternVLChatModel
+    cfg, _, sd = golden_model
+    d = np.load(os.path.join(golden_dir, 'g6b_ragged.npz'))
+    m = InternVLChatModel(cfg, max_seq_len=512, max_batch=2)
+    m.load_state_dict(sd)
+    m.img_context_token_id = cfg.img_context_token_id
+    pv = torch.cat([torch.randn(1, 3, 448, 448, generator=torch.Generator().manual_seed(int(s))) for s in d['seeds']])
+    ids, am = torch.from_numpy(d['input_ids']), torch.from_numpy(d['attention_mask'])
+    gold = d['greedy_ids']                                   # [2, 6] from the reference's HF generate
+    eos = int(gold[1, 1])                                    # sequence 1 emits this at step 1; sequence 0 never does
+    assert eos not in gold[0].tolist()
+    out = m.generate(pv, ids, attention_mask=am, max_new_tokens=6, eos_token_id=eos, pad_token_id=151643).cpu()
+    assert out[0].tolist() == gold[0].tolist()               # the unfinished row is unaffected by its neighbour stopping
+    assert out[1, :2].tolist() == gold[1, :2].tolist() and (out[1, 2:] == 151643).all()      # finished row pads (HF semantics)
+    ref = ovlm.generate(sd, cfg, pv, ids, attention_mask=am, max_new_tokens=6, eos_token_id=eos)
+    assert ref[0].tolist() == gold[0].tolist()
+    # both rows finished -> generation stops early; min_new_tokens keeps it going past the eos
+    solo = m.generate(pv[1:], ids[1:, -int(am[1].sum()):], max_new_tokens=6, eos_token_id=eos).cpu()
+    assert solo.shape[1] == 2
+    forced = m.generate(pv[1:], ids[1:, -int(am[1].sum()):], max_new_tokens=6, min_new_tokens=4, eos_token_id=eos).cpu()
+    assert forced.shape[1] >= 4 and forced[0, :2].tolist() == gold[1, :2].tolist()
+
+
+def test_thirteen_tiles_dynamic_resolution():
+    from oracle import vlm as ovlm, vit as ovit
+    from vlaser_amd import config as C, synth
+    from vlaser_amd.internvl_chat import InternVLChatModel
+    cfg = C.truncated(C.vlaser_2b(), 1, 1)
+    sd = synth.vlm_state_dict(cfg)
+    m = InternVLChatModel(cfg, max_tiles=13, max_seq_len=3456)
+    m.load_state_dict(sd)
+    m.img_context_token_id = cfg.img_context_token_id
+    g = torch.Generator().manual_seed(13)
+    pv = torch.randn(13, 3, 448, 448, generator=g)
+    feat = m.extract_feature(pv)
+    assert feat.shape == (13, 256, cfg.llm.hidden_size)
+    assert _relmax(feat, ovit.extract_feature(sd, cfg, pv)) < 3e-2
+    ids = torch.cat([torch.randint(0, 151643, (41,), generator=g), torch.full((13 * 256,), cfg.img_context_token_id),
+                     torch.randint(0, 151643, (13,), generator=g)])[None]
+    assert ids.shape[1] == 3382                               # the reference's own 13-tile chat prompt length (golden G1)
+    out = m.forward(pv, ids, image_flags=torch.ones(13, 1, dtype=torch.long))
+    ref = ovlm.forward_logits(sd, cfg, pv, ids)
+    assert _relmax(out.logits[:, -8:], ref[:, -8:]) < 3e-2
+    t2 = ref[0, -1].topk(2).values
+    assert out.logits[0, -1].argmax().item() == ref[0, -1].argmax().item() or (t2[0] - t2[1]).item() < 0.05
+
+
+def test_sft_image_flags_ignored_labels_and_two_tiles(golden_model):
+    from oracle import vlm as ovlm
+    from vlaser_amd.sft import SFTModel
+    cfg, _, sd = golden_model
+    g = torch.Generator().manual_seed(77)
+    # two tiles in the batch, the second flagged off (image_flags = 0): only 256 <IMG_CONTEXT> tokens are filled (:166)
+    pv = torch.randn(2, 3, 448, 448, generator=g)
+    ids = torch.cat([torch.randint(0, 151643, (30,), generator=g), torch.full((256,), cfg.img_context_token_id),
+                     torch.randint(0, 151643, (20,), generator=g)])[None]
+    labels = torch.full_like(ids, -100)
+    labels[0, -10:] = ids[0, -10:]
+    flags = torch.tensor([[1], [0]])
+    m = SFTModel(cfg, max_seq_len=ids.shape[1], max_tiles=2, lr=1e-3)
+    m.load_state_dict(sd)
+    loss = m.forward_backward(pv, ids, labels, image_flags=flags)
+    ref = ovlm.sft_loss(ovlm.forward_logits(sd, cfg, pv, ids, image_flags=flags), labels)
+    assert abs(loss.item() - ref.item()) < 5e-3
+    # the dropped tile gets no gradient path; the kept one does (projector gradient is non-zero and finite)
+    gr = m.named_grads()
+    assert torch.isfinite(gr['mlp1.1.weight']).all() and gr['mlp1.1.weight'].abs().sum() > 0
+    # two tiles, both used (512 visual tokens)
+    ids2 = torch.cat([torch.randint(0, 151643, (30,), generator=g), torch.full((512,), cfg.img_context_token_id),
+                      torch.randint(0, 151643, (20,), generator=g)])[None]
+    lab2 = torch.full_like(ids2, -100)
+    lab2[0, -10:] = ids2[0, -10:]
+    m2 = SFTModel(cfg, max_seq_len=ids2.shape[1], max_tiles=2, lr=1e-3)
+    m2.load_state_dict(sd)
+    loss2 = m2.forward_backward(pv, ids2, lab2)
+    ref2 = ovlm.sft_loss(ovlm.forward_logits(sd, cfg, pv, ids2), lab2)
+    assert abs(loss2.item() - ref2.item()) < 5e-3
+    # a sample whose labels are all ignored: zero loss, optimizer step still well defined
+    loss3 = m2.forward_backward(pv, ids2, torch.full_like(ids2, -100))
+    assert loss3.item() == 0.0
