@@ -10,6 +10,7 @@ Weights are stored in HBM in the layouts the kernels want (packed once at load):
   * K cache [L][B,n_kv,S_max,128], V cache TRANSPOSED [L][B,n_kv,128,S_max] (MFMA A-fragment = one 16-byte load).
 """
 import torch
+from types import SimpleNamespace
 
 from . import _lib as L
 from . import ops
@@ -257,6 +258,7 @@ class SkinnyBuffers:
         self.attn_parts = ops.attn_partial_buffers(max_rows, stack.nkv, device)
         self.part_o = torch.zeros(stack.ks_o, max_rows, H, dtype=torch.float32, device=device)
         self.part_d = torch.zeros(stack.ks_down, max_rows, H, dtype=torch.float32, device=device)
+        self.plans = {}      # cached launch argument structs of skinny_layer
 
 
 def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in, partials, n_partials, cache: KVCache, layer, rope,
@@ -267,22 +269,42 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
     llm = stack.llm
     M = batch * tok_per_batch
     nq, nkv, hd = stack.nq, stack.nkv, llm.head_dim
-    H = llm.hidden_size
-    ops.skinny(L.PRO_NORM, L.SK_QKV_ROPE, h_in, lw.sk_qkv, M, partials=partials, n_partials=n_partials, norm_w=lw.ln_in,
-               eps=llm.rms_norm_eps, h_out=sb.hA, bias=lw.bqkv, q_out=sb.q, k_cache=cache.k[layer], vt_cache=cache.vt[layer],
-               rope_cos=rope[0], rope_sin=rope[1], pos_ids=pos_ids, n_q_heads=nq, n_kv_heads=nkv, s_max=cache.s_max,
-               tok_per_batch=tok_per_batch, slot_base=slot_base)
-    ks, vs = cache.strides()
+    # the five argument structs of this (layer, input buffers, geometry) are built once and re-launched: only the cache slot,
+    # the key count and its split factor change from step to step (greedy decode is otherwise host-bound on struct building)
+    key = (layer, M, tok_per_batch, attn_mode, h_in.data_ptr(), 0 if partials is None else partials.data_ptr(), n_partials,
+           0 if valid_len is None else valid_len.data_ptr(), pos_ids.data_ptr(), cache.k.data_ptr(), skip_post_attn)
+    plan = sb.plans.get(key)
+    if plan is None:
+        ks, vs = cache.strides()
+        plan = SimpleNamespace()
+        plan.qkv = ops.skinny_args(h_in, lw.sk_qkv, M, partials=partials, n_partials=n_partials, norm_w=lw.ln_in, eps=llm.rms_norm_eps,
+                                   h_out=sb.hA, bias=lw.bqkv, q_out=sb.q, k_cache=cache.k[layer], vt_cache=cache.vt[layer], rope_cos=rope[0],
+                                   rope_sin=rope[1], pos_ids=pos_ids, n_q_heads=nq, n_kv_heads=nkv, s_max=cache.s_max,
+                                   tok_per_batch=tok_per_batch, slot_base=slot_base)
+        plan.attn = ops.attn_skinny_args(sb.q, cache.k[layer], cache.vt[layer], sb.attn_parts, batch, tok_per_batch, kv_len, nq, nkv, hd,
+                                         (tok_per_batch * nq * hd, hd, nq * hd), ks, vs, cache.s_max, hd ** -0.5, attn_mode, 1,
+                                         valid_len=valid_len, blk_start=blk_start)
+        if not skip_post_attn:
+            plan.o = ops.skinny_args(None, lw.sk_o, M, out_f32=sb.part_o, attn_m=sb.attn_parts[0], attn_l=sb.attn_parts[1],
+                                     attn_o=sb.attn_parts[2], attn_splits=1, attn_group=nq // nkv, attn_nq=tok_per_batch)
+            plan.gu = ops.skinny_args(sb.hA, lw.sk_gu, M, partials=sb.part_o, n_partials=stack.ks_o, norm_w=lw.ln_post, eps=llm.rms_norm_eps,
+                                      h_out=sb.hB, out=sb.act, ldo=llm.intermediate_size)
+            plan.down = ops.skinny_args(sb.act, lw.sk_down, M, out_f32=sb.part_d)
+        if len(sb.plans) > 4096:         # keys hold buffer addresses of per-call tensors (ragged lengths): bound the cache
+            sb.plans.clear()
+        sb.plans[key] = plan
+    stream = torch.cuda.current_stream().cuda_stream
     nsp = ops.attn_splits(kv_len)
-    ops.attn_skinny(sb.q, cache.k[layer], cache.vt[layer], sb.attn_parts, batch, tok_per_batch, kv_len, nq, nkv, hd,
-                    (tok_per_batch * nq * hd, hd, nq * hd), ks, vs, cache.s_max, hd ** -0.5, attn_mode, nsp, valid_len=valid_len,
-                    blk_start=blk_start)
+    plan.qkv[0].slot_base = slot_base
+    ops.launch_skinny(L.PRO_NORM, L.SK_QKV_ROPE, plan.qkv[0], stream)
+    a = plan.attn
+    a.kv_len, a.n_splits, a.blk_start = kv_len, nsp, blk_start
+    ops.launch_attn_skinny(a, stream)
     if skip_post_attn:
         return sb.hA, None, 0
     # o_proj: the prologue merges the attention split partials (flash-decoding) straight into its activation tile
-    ops.skinny(L.PRO_ATTN, L.SK_PARTIAL, None, lw.sk_o, M, out_f32=sb.part_o, attn_m=sb.attn_parts[0],
-               attn_l=sb.attn_parts[1], attn_o=sb.attn_parts[2], attn_splits=nsp, attn_group=nq // nkv, attn_nq=tok_per_batch)
-    ops.skinny(L.PRO_NORM, L.SK_SWIGLU, sb.hA, lw.sk_gu, M, partials=sb.part_o, n_partials=stack.ks_o, norm_w=lw.ln_post,
-               eps=llm.rms_norm_eps, h_out=sb.hB, out=sb.act, ldo=llm.intermediate_size)
-    ops.skinny(L.PRO_PLAIN, L.SK_PARTIAL, sb.act, lw.sk_down, M, out_f32=sb.part_d)
+    plan.o[0].attn_splits = nsp
+    ops.launch_skinny(L.PRO_ATTN, L.SK_PARTIAL, plan.o[0], stream)
+    ops.launch_skinny(L.PRO_NORM, L.SK_SWIGLU, plan.gu[0], stream)
+    ops.launch_skinny(L.PRO_PLAIN, L.SK_PARTIAL, plan.down[0], stream)
     return sb.hB, sb.part_d, stack.ks_down

@@ -131,11 +131,19 @@ def attn_splits(kv_len):
     return max(1, min(8, (((kv_len + 31) // 32) + 1) // 2))
 
 
+def attn_skinny_args(q, k, vt, parts, batch, sq, kv_len, n_q, n_kv, hd, q_str, k_str, vt_str, ld_vt, scale, mode, n_splits, **kw):
+    return _attn_args(q, k, vt, None, batch, sq, kv_len, n_q, n_kv, hd, q_str, k_str, vt_str, (0, 0), ld_vt, scale, mode, parts=parts,
+                      n_splits=n_splits, **kw)
+
+
+def launch_attn_skinny(a, stream=None):
+    L.check(L.lib().vlaser_attn_skinny(C.byref(a), _stream() if stream is None else stream), 'vlaser_attn_skinny')
+
+
 def attn_skinny(q, k, vt, parts, batch, sq, kv_len, n_q, n_kv, hd, q_str, k_str, vt_str, ld_vt, scale, mode, n_splits, **kw):
     """Writes flash-decoding partials (m, l, o) per (b, kv head, split) into `parts`; merged by skinny(PRO_ATTN)."""
-    a = _attn_args(q, k, vt, None, batch, sq, kv_len, n_q, n_kv, hd, q_str, k_str, vt_str, (0, 0), ld_vt, scale, mode, parts=parts,
-                   n_splits=n_splits, **kw)
-    L.check(L.lib().vlaser_attn_skinny(C.byref(a), _stream()), 'vlaser_attn_skinny')
+    launch_attn_skinny(attn_skinny_args(q, k, vt, parts, batch, sq, kv_len, n_q, n_kv, hd, q_str, k_str, vt_str, ld_vt, scale, mode, n_splits,
+                                        **kw))
 
 
 def attn_partial_buffers(batch, n_kv, device, max_splits=8):
@@ -170,20 +178,30 @@ def pack_skinny(W, k_splits=1, tpu=2):
     return PackedW(v.reshape(-1), Np, N, K, k_splits, tpu)
 
 
-def skinny(pro, epi, x, W: PackedW, M, **kw):
+def skinny_args(x, W: PackedW, M, **kw):
+    """Filled VlaserSkinnyArgs (+ tensors it must keep alive).  Building the ctypes struct costs ~8 us of host time; callers
+    on a host-bound path (greedy decode: 141 launches per token) build it once and re-launch it (`launch_skinny`)."""
     a = L.SkinnyArgs()
     a.x, a.W = _p(x), W.t.data_ptr()
     a.M, a.N, a.K, a.ldw, a.n_valid, a.tiles_per_unit = M, W.N, W.K, W.K, W.n_valid, W.tpu
     a.k_splits = W.k_splits
     a.eps = kw.pop('eps', 1e-6)
+    keep = None
     b = kw.get('bias')
     if b is not None and b.numel() < W.N:       # the epilogue reads bias with unconditional vector loads over the padded N
-        kw['bias'] = torch.cat([b, torch.zeros(W.N - b.numel(), dtype=b.dtype, device=b.device)])
-        kw['_keep'] = kw['bias']
-    kw.pop('_keep', None)
+        keep = kw['bias'] = torch.cat([b, torch.zeros(W.N - b.numel(), dtype=b.dtype, device=b.device)])
     for k, v in kw.items():
         setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
-    L.check(L.lib().vlaser_skinny(pro, epi, C.byref(a), _stream()), 'vlaser_skinny')
+    return a, keep
+
+
+def launch_skinny(pro, epi, a, stream=None):
+    L.check(L.lib().vlaser_skinny(pro, epi, C.byref(a), _stream() if stream is None else stream), 'vlaser_skinny')
+
+
+def skinny(pro, epi, x, W: PackedW, M, **kw):
+    a, _keep = skinny_args(x, W, M, **kw)
+    launch_skinny(pro, epi, a)
 
 
 def pick_k_splits(K, N, target_blocks=72):
