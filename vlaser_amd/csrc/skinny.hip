@@ -504,6 +504,8 @@ static int launch_ns(const VlaserSkinnyArgs* a, hipStream_t stream) {
       case 2: return launch_sp<PRO, EPI, TPU, NS, 2>(a, stream, p, gx, lds);
       case 3: return launch_sp<PRO, EPI, TPU, NS, 3>(a, stream, p, gx, lds);
       case 5: return launch_sp<PRO, EPI, TPU, NS, 5>(a, stream, p, gx, lds);
+      case 6: return launch_sp<PRO, EPI, TPU, NS, 6>(a, stream, p, gx, lds);
+      case 7: return launch_sp<PRO, EPI, TPU, NS, 7>(a, stream, p, gx, lds);
       default: break;
     }
   }

@@ -2,6 +2,8 @@
 memory and the stream; every op below is a launch of a hand-written gfx950 kernel in libvlaser_hip.so."""
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -204,9 +206,11 @@ def skinny(pro, epi, x, W: PackedW, M, **kw):
     launch_skinny(pro, epi, a)
 
 
-def pick_k_splits(K, N, target_blocks=72):
+def pick_k_splits(K, N, target_blocks=None):
     """Smallest cross-block split-K factor that (a) keeps K/k_splits a multiple of 256 (8 waves x 32) and (b) gives
     about one block per CU (units = N/32)."""
+    if target_blocks is None:
+        target_blocks = int(os.environ.get('VLASER_SK_TARGET', '130'))
     units = (N + 31) // 32
     best = 1
     for s in range(1, 9):            # <= 8 slabs: the consumer's prologue sums them in ONE batch of loads
