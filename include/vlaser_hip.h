@@ -147,6 +147,10 @@ int vlaser_skinny(int prologue, int epi, const VlaserSkinnyArgs* args, vl_stream
  * dW = dY^T X of every nn.Linear on the SFT path (autograd of modeling_internvl_chat.py:194-203): At = dY [S,N_out],
  * Wt = X [S,K_in].  Rows 16-byte aligned and readable up to M / N rounded up to 8 columns (ld >= that). */
 int vlaser_gemm_tn(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, vl_stream_t stream);
+/* Grouped + batched form: out[b] = sum_{g < groups} At[b, g]^T @ Wt[b, g], run (b, g) starting at At + b*a_bs + g*a_gs (K rows each);
+ * grouped-query attention backward: dK[kvh] = sum_g dS[kvh*G+g]^T Q_g, dV[kvh] = sum_g P[kvh*G+g]^T dO_g (HF sdpa/eager autograd). */
+int vlaser_gemm_tn_grouped(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, int groups,
+                           long long a_gs, long long w_gs, int batch, long long a_bs, long long w_bs, long long o_bs, vl_stream_t stream);
 
 /* ---- memory-bound helpers -------------------------------------------------------------------------------------- */
 /* nn.LayerNorm (NORM2FN['layer_norm'], modeling_intern_vit.py:127-130,275-276) and Qwen2RMSNorm. bf16 [rows, C]. */
@@ -195,15 +199,20 @@ int vlaser_reduce_norm(const void* h_in /* may be null = 0 */, const float* part
  * strides: matrix (b, i), b < batch, i < inner (inner >= 1), starts at in + b*in_bs + i*in_is / out + b*out_bs + i*out_is */
 int vlaser_transpose(const void* in, void* out, int rows, int cols, int ld_in, int ld_out, int pad_rows, int batch, long long in_bs, long long out_bs,
                      int inner, long long in_is, long long out_is, vl_stream_t stream);
+/* fused causal softmax + dS: P = softmax(scale * scores) (bf16), dS = P o (dP - D) * scale with D[q] = sum_d dO[q,d] O[q,d];
+ * scores, dP fp32 [H, S, ld]; dO, O bf16 [S, H*hd]; P, dS bf16 [H, S, ld] (0 beyond the diagonal / beyond S) */
+int vlaser_attn_bwd_pds(const float* scores, const float* dP, const void* dO, const void* O, void* P, void* dS, int H, int S, int ld, int hd,
+                        float scale, vl_stream_t stream);
 /* causal softmax of fp32 scores [B, S, ld] * scale -> P bf16 [B, S, ld] (0 beyond the diagonal / beyond S) */
 int vlaser_softmax_causal(const float* scores, void* P, int batch, int S, int ld, float scale, vl_stream_t stream);
 /* dS = P o (dP - D) * scale with D[q] = sum_d dO[q,d] O[q,d]; writes dS [H,S,ld] and the grouped transposes
  * dS_T, P_T [n_kv, ld, G*ld] (key-major, contraction axis (g, q)) for the dK / dV GEMMs */
 int vlaser_attn_bwd_ds(const void* P, const float* dP, const void* dO, const void* O, void* dS, void* dS_T, void* P_T, int n_heads,
                        int n_kv, int S, int ld, int hd, float scale, vl_stream_t stream);
-/* inverse RoPE on dq/dk + pack [dq | dk | dv] (natural [S, heads*128]) into the packed q/k/v column order */
+/* inverse RoPE on dq/dk + pack [dq | dk | dv] (natural [S, heads*128]) into the packed q/k/v column order.
+ * kv_per_q_head != 0: dk / dv are [S, n_q*128] partials, one per Q head, summed here over the heads of each kv group */
 int vlaser_rope_bwd_pack(const void* dq, const void* dk, const void* dv, const float* rope_cos, const float* rope_sin, const int32_t* pos_ids,
-                         void* out_packed, int S, int n_q, int n_kv, vl_stream_t stream);
+                         void* out_packed, int S, int n_q, int n_kv, int kv_per_q_head, vl_stream_t stream);
 /* Qwen2RMSNorm backward: dx_out = dres + rmsnorm_bwd(dy, x, w); dw_rows (fp32 [S, C] scratch-free): column sums go to dw
  * through vlaser_colsum_mul.  x is the (bf16) norm input. */
 int vlaser_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* dres, void* dx_out, int S, int C, float eps, vl_stream_t stream);

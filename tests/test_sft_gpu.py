@@ -190,3 +190,32 @@ def test_gemm_tn_weight_gradient(K, M, N):
     assert err <= 2e-2 * ref.abs().max().item() + 1e-3, err
     rel, cos = _rel(out, ref)
     assert rel < 5e-3 and cos > 0.9999
+
+
+def test_attention_backward_fused_pds_and_grouped_tn():
+    """vlaser_attn_bwd_pds (softmax + dS in one pass) and the grouped TN GEMM (dK / dV summed over the q heads of a kv group)
+    against the closed forms, on a ragged S (not a multiple of 64)."""
+    from vlaser_amd import ops
+    g = torch.Generator().manual_seed(5)
+    H, nkv, S, hd = 4, 2, 83, 128
+    G, Sp = H // nkv, 128
+    scale = hd ** -0.5
+    sc = torch.zeros(H, S, Sp, device='cuda'); dP = torch.zeros(H, S, Sp, device='cuda')
+    sc[:, :, :S] = (torch.randn(H, S, S, generator=g) * 4).cuda(); dP[:, :, :S] = torch.randn(H, S, S, generator=g).cuda()
+    dO = torch.randn(S, H * hd, generator=g).to(BF).cuda(); O = torch.randn(S, H * hd, generator=g).to(BF).cuda()
+    P = torch.full((H, S, Sp), 7, dtype=BF, device='cuda'); dS = torch.full((H, S, Sp), 7, dtype=BF, device='cuda')
+    ops.attn_bwd_pds(sc, dP, dO, O, P, dS, H, S, Sp, hd, scale)
+    mask = torch.tril(torch.ones(S, S, dtype=torch.bool, device='cuda'))
+    Pref = (sc[:, :, :S] * scale).masked_fill(~mask, float('-inf')).softmax(-1)
+    D = (dO.float() * O.float()).view(S, H, hd).sum(-1).t()                      # [H, S]
+    dSref = Pref.to(BF).float() * (dP[:, :, :S] - D[:, :, None]) * scale
+    assert (P[:, :, :S].float() - Pref).abs().max().item() < 4e-3 and (P[:, :, S:] == 0).all()
+    assert (dS[:, :, :S].float() - dSref).abs().max().item() < 2e-2 * dSref.abs().max().item() and (dS[:, :, S:] == 0).all()
+    assert (dS[:, :, :S].float().masked_select(~mask) == 0).all()
+    # dK[kvh] = sum_g dS[kvh*G+g]^T Q_g
+    q = torch.randn(S, H * hd, generator=g).to(BF).cuda()
+    dk = torch.full((S, nkv * hd), 7, dtype=BF, device='cuda')
+    ops.gemm_tn_grouped(dS, q, dk, S, hd, S, Sp, H * hd, nkv * hd, G, S * Sp, hd, nkv, G * S * Sp, G * hd, hd)
+    ref = torch.einsum('hqk,qhd->khd', dS[:, :, :S].float(), q.float().view(S, H, hd)).view(S, nkv, G, hd).sum(2).reshape(S, nkv * hd)
+    rel, cos = _rel(dk, ref)
+    assert rel < 6e-3 and cos > 0.9999, (rel, cos)

@@ -491,6 +491,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lds_tile, int pitch, int c
 struct GemmTnP {
   const bf16_t* At; const bf16_t* Wt; bf16_t* out;
   int M, N, K, ldat, ldwt, ldo, tiles_m, tiles_n;
+  // grouped contraction: the K rows are `groups` runs of K rows each (run g starts at At + g*a_gs / Wt + g*w_gs), summed into
+  // one output -- dK / dV of grouped-query attention sum over the q heads of a kv group; batch (blockIdx.z) = kv heads
+  int groups; long long a_gs, w_gs, a_bs, w_bs, o_bs;
 };
 
 template <int BM>
@@ -512,26 +515,30 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnP p) {
   }
   const int tile_m = bid % p.tiles_m, tile_n = bid / p.tiles_m;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int nk = (p.K + BK - 1) / BK;
+  const int tpg = (p.K + BK - 1) / BK, nk = tpg * p.groups;      // K-tiles per group run, total
   // staging map: A: row = tid / (BM/8) + rows_per_pass * i, chunk = tid % (BM/8); W: row = tid / 16 + 16 * i, chunk = tid % 16
   constexpr int ACPR = BM / 8, ARPP = 256 / ACPR;        // chunks per row, rows per pass
   const int arow = tid / ACPR, achk = tid % ACPR;
   const int wrow = tid >> 4, wchk = tid & 15;
-  const bf16_t* pa = p.At + min(m0 + achk * 8, ((p.M + 7) & ~7) - 8);   // column clamp (chunk-aligned): columns >= M only feed dropped outputs
-  const bf16_t* pw = p.Wt + min(n0 + wchk * 8, ((p.N + 7) & ~7) - 8);
+  const bf16_t* pa = p.At + (size_t)blockIdx.z * p.a_bs + min(m0 + achk * 8, ((p.M + 7) & ~7) - 8);   // column clamp (chunk-aligned): columns >= M only feed dropped outputs
+  const bf16_t* pw = p.Wt + (size_t)blockIdx.z * p.w_bs + min(n0 + wchk * 8, ((p.N + 7) & ~7) - 8);
   u32x4 ra[2][ACH], rw[2][4];
   auto load_tile = [&](int kt, int st) {
-    const int k0 = min(kt, nk - 1) * BK;
+    const int ktc = min(kt, nk - 1);
+    const int grp = __builtin_amdgcn_readfirstlane((int)(((float)ktc + 0.5f) * __builtin_amdgcn_rcpf((float)tpg)));   // ktc / tpg (uniform)
+    const int k0 = (ktc - grp * tpg) * BK;
+    const bf16_t* ga = pa + (size_t)grp * p.a_gs;
+    const bf16_t* gw = pw + (size_t)grp * p.w_gs;
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
       const int s = k0 + arow + ARPP * i;
-      const u32x4 v = ld_global_16(pa + (size_t)min(s, p.K - 1) * p.ldat);
+      const u32x4 v = ld_global_16(ga + (size_t)min(s, p.K - 1) * p.ldat);
       ra[st][i] = s < p.K ? v : u32x4{0, 0, 0, 0};               // rows past K must contribute zero (select on data, load unconditional)
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int s = k0 + wrow + 16 * i;
-      rw[st][i] = ld_global_16(pw + (size_t)min(s, p.K - 1) * p.ldwt);   // clamped (finite data): the zeroed A rows cancel it
+      rw[st][i] = ld_global_16(gw + (size_t)min(s, p.K - 1) * p.ldwt);   // clamped (finite data): the zeroed A rows cancel it
     }
   };
   auto store_tile = [&](int buf, int st) {
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnP p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = n0 + wc * WTN + nt * 16 + fq * 4;
-      bf16_t* o = p.out + (size_t)m * p.ldo + n;
+      bf16_t* o = p.out + (size_t)blockIdx.z * p.o_bs + (size_t)m * p.ldo + n;
       const f32x4 v = acc[nt][mt];
       if (n + 3 < p.N && (p.ldo & 3) == 0) {
         *reinterpret_cast<u32x2*>(o) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -601,11 +608,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnP p) {
   }
 }
 
-extern "C" int vlaser_gemm_tn(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, vl_stream_t s) {
-  VL_CHECK(At && Wt && out && M >= 8 && N >= 8 && K > 0, "vlaser_gemm_tn: bad arguments (M, N >= 8)");
-  VL_CHECK(ldat % 8 == 0 && ldwt % 8 == 0 && (((uintptr_t)At | (uintptr_t)Wt) & 15) == 0, "vlaser_gemm_tn: operands must be 16-byte aligned rows");
+extern "C" int vlaser_gemm_tn_grouped(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, int groups,
+                                      long long a_gs, long long w_gs, int batch, long long a_bs, long long w_bs, long long o_bs, vl_stream_t s) {
+  VL_CHECK(At && Wt && out && M >= 8 && N >= 8 && K > 0 && groups >= 1 && batch >= 1, "vlaser_gemm_tn: bad arguments (M, N >= 8)");
+  VL_CHECK(ldat % 8 == 0 && ldwt % 8 == 0 && (((uintptr_t)At | (uintptr_t)Wt) & 15) == 0 && ((a_gs | w_gs | a_bs | w_bs) & 7) == 0,
+           "vlaser_gemm_tn: operands must be 16-byte aligned rows / group / batch strides");
   VL_CHECK(ldat >= ((M + 7) & ~7) && ldwt >= ((N + 7) & ~7), "vlaser_gemm_tn: operand rows must be readable up to M, N rounded up to 8 columns");
-  GemmTnP p{(const bf16_t*)At, (const bf16_t*)Wt, (bf16_t*)out, M, N, K, ldat, ldwt, ldo, 0, (N + BN - 1) / BN};
+  GemmTnP p{(const bf16_t*)At, (const bf16_t*)Wt, (bf16_t*)out, M, N, K, ldat, ldwt, ldo, 0, (N + BN - 1) / BN, groups, a_gs, w_gs, a_bs, w_bs, o_bs};
   hipStream_t stream = reinterpret_cast<hipStream_t>(s);
   constexpr int lds64 = 2 * (64 * (64 * 2 + 32) + 64 * (BN * 2 + 32)), lds128 = 2 * (64 * (128 * 2 + 32) + 64 * (BN * 2 + 32));
   static bool attr_set = false;
@@ -614,17 +623,20 @@ extern "C" int vlaser_gemm_tn(const void* At, const void* Wt, void* out, int M, 
     VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds128));
     attr_set = true;
   }
-  static const int force = getenv("VLASER_TN_BM") ? atoi(getenv("VLASER_TN_BM")) : 0;   // LAB
-  const bool big = force ? force == 128 : ((M + 127) / 128) * p.tiles_n >= 512;
+  const bool big = ((M + 127) / 128) * p.tiles_n * batch >= 512;      // measured: 128-row tiles win on the big weight gradients only
   if (big) {
     p.tiles_m = (M + 127) / 128;
-    hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(p.tiles_m * p.tiles_n), dim3(256), lds128, stream, p);
+    hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(p.tiles_m * p.tiles_n, 1, batch), dim3(256), lds128, stream, p);
   } else {
     p.tiles_m = (M + 63) / 64;
-    hipLaunchKernelGGL(gemm_tn_kernel<64>, dim3(p.tiles_m * p.tiles_n), dim3(256), lds64, stream, p);
+    hipLaunchKernelGGL(gemm_tn_kernel<64>, dim3(p.tiles_m * p.tiles_n, 1, batch), dim3(256), lds64, stream, p);
   }
   VL_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int vlaser_gemm_tn(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, vl_stream_t s) {
+  return vlaser_gemm_tn_grouped(At, Wt, out, M, N, K, ldat, ldwt, ldo, 1, 0, 0, 1, 0, 0, 0, s);
 }
 
 extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {

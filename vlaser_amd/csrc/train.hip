@@ -130,22 +130,90 @@ extern "C" int vlaser_attn_bwd_ds(const void* P, const float* dP, const void* dO
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------- fused softmax + dS
+// One wave per (h, q) row, the row (ld <= 1024 columns) stays in registers: P = softmax(scale * s) over k <= q, D = <dO, O>,
+// dS = P (dP - D) scale.  dK / dV then come from the grouped TN GEMM, so no transposed copies of P / dS are produced.
+__global__ __launch_bounds__(256) void attn_bwd_pds_kernel(const float* __restrict__ sc, const float* __restrict__ dP, const bf16_t* __restrict__ dO,
+                                                           const bf16_t* __restrict__ O, bf16_t* __restrict__ P, bf16_t* __restrict__ dS, int H, int S,
+                                                           int ld, int hd, float scale) {
+  const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y;
+  if (q >= S) return;
+  const bf16_t* dorow = dO + (size_t)q * H * hd + h * hd;
+  const bf16_t* orow = O + (size_t)q * H * hd + h * hd;
+  float d = 0.f;
+  for (int i = lane * 2; i < hd; i += 128) {
+    const uint32_t a = *reinterpret_cast<const uint32_t*>(dorow + i), b = *reinterpret_cast<const uint32_t*>(orow + i);
+    d += bf16lo_to_f32(a) * bf16lo_to_f32(b) + bf16hi_to_f32(a) * bf16hi_to_f32(b);
+  }
+  d = wave_sum(d);
+  const size_t ro = ((size_t)h * S + q) * ld;
+  float v[16];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int k = lane + 64 * j;
+    v[j] = (k <= q && k < ld) ? sc[ro + k] * scale : -INFINITY;
+    mx = fmaxf(mx, v[j]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { v[j] = __expf(v[j] - mx); sum += v[j]; }       // exp(-inf) = 0 outside the causal range
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int k = lane + 64 * j;
+    if (k < ld) {
+      const bf16_t pb = f32_to_bf16(v[j] * inv);
+      P[ro + k] = pb;
+      dS[ro + k] = (k <= q) ? f32_to_bf16(bf16_to_f32(pb) * (dP[ro + k] - d) * scale) : (bf16_t)0;
+    }
+  }
+}
+extern "C" int vlaser_attn_bwd_pds(const float* scores, const float* dP, const void* dO, const void* O, void* P, void* dS, int H, int S, int ld, int hd,
+                                   float scale, vl_stream_t s) {
+  VL_CHECK(scores && dP && dO && O && P && dS && ld >= S && ld <= 1024 && hd % 2 == 0, "vlaser_attn_bwd_pds: bad args (ld <= 1024)");
+  hipLaunchKernelGGL(attn_bwd_pds_kernel, dim3((S + 3) / 4, H), dim3(256), 0, (hipStream_t)s, scores, dP, (const bf16_t*)dO, (const bf16_t*)O,
+                     (bf16_t*)P, (bf16_t*)dS, H, S, ld, hd, scale);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- RoPE backward + pack
 // forward: o1 = x1 c - x2 s, o2 = x2 c + x1 s (x1 = d < 64, x2 = d + 64)  =>  dx1 = do1 c + do2 s, dx2 = do2 c - do1 s.
 // Output column order = packed q/k/v rows (ops.head_perm): col = head*128 + 32*(d/16) + 16*half + d%16, d in [0,64).
 __global__ __launch_bounds__(256) void rope_bwd_pack_kernel(const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dk, const bf16_t* __restrict__ dv,
                                                             const float* __restrict__ cosT, const float* __restrict__ sinT,
-                                                            const int32_t* __restrict__ pos_ids, bf16_t* __restrict__ out, int n_q, int n_kv) {
-  const int s = blockIdx.x, nh = n_q + 2 * n_kv;
+                                                            const int32_t* __restrict__ pos_ids, bf16_t* __restrict__ out, int n_q, int n_kv,
+                                                            int kv_per_q_head) {
+  // kv_per_q_head != 0: dk / dv hold one partial per Q head ([S, n_q*128], the per-head TN GEMMs of the attention backward);
+  // the kv gradient is their sum over the G = n_q / n_kv heads of the group (fp32, fixed order)
+  const int s = blockIdx.x, nh = n_q + 2 * n_kv, G = n_q / n_kv;
   const int pos = pos_ids[s];
   for (int i = threadIdx.x; i < nh * 64; i += 256) {
     const int head = i >> 6, d = i & 63;
-    const bf16_t* src;
+    float g1, g2;
     bool rot = true;
-    if (head < n_q) src = dq + (size_t)s * n_q * 128 + head * 128;
-    else if (head < n_q + n_kv) src = dk + (size_t)s * n_kv * 128 + (head - n_q) * 128;
-    else { src = dv + (size_t)s * n_kv * 128 + (head - n_q - n_kv) * 128; rot = false; }
-    const float g1 = bf16_to_f32(src[d]), g2 = bf16_to_f32(src[d + 64]);
+    if (head < n_q) {
+      const bf16_t* src = dq + (size_t)s * n_q * 128 + head * 128;
+      g1 = bf16_to_f32(src[d]); g2 = bf16_to_f32(src[d + 64]);
+    } else {
+      const bool isv = head >= n_q + n_kv;
+      const int kvh = head - n_q - (isv ? n_kv : 0);
+      const bf16_t* base = isv ? dv : dk;
+      rot = !isv;
+      if (kv_per_q_head) {
+        g1 = 0.f; g2 = 0.f;
+        for (int gi = 0; gi < G; ++gi) {
+          const bf16_t* src = base + (size_t)s * n_q * 128 + (kvh * G + gi) * 128;
+          g1 += bf16_to_f32(src[d]); g2 += bf16_to_f32(src[d + 64]);
+        }
+      } else {
+        const bf16_t* src = base + (size_t)s * n_kv * 128 + kvh * 128;
+        g1 = bf16_to_f32(src[d]); g2 = bf16_to_f32(src[d + 64]);
+      }
+    }
     float x1 = g1, x2 = g2;
     if (rot) {
       const float c = cosT[(size_t)pos * 64 + d], sn = sinT[(size_t)pos * 64 + d];
@@ -158,10 +226,10 @@ __global__ __launch_bounds__(256) void rope_bwd_pack_kernel(const bf16_t* __rest
   }
 }
 extern "C" int vlaser_rope_bwd_pack(const void* dq, const void* dk, const void* dv, const float* c, const float* sn, const int32_t* pos, void* out,
-                                    int S, int n_q, int n_kv, vl_stream_t s) {
-  VL_CHECK(dq && dk && dv && c && sn && pos && out && S > 0, "vlaser_rope_bwd_pack: bad args");
+                                    int S, int n_q, int n_kv, int kv_per_q_head, vl_stream_t s) {
+  VL_CHECK(dq && dk && dv && c && sn && pos && out && S > 0 && n_q % n_kv == 0, "vlaser_rope_bwd_pack: bad args");
   hipLaunchKernelGGL(rope_bwd_pack_kernel, dim3(S), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dq, (const bf16_t*)dk, (const bf16_t*)dv, c, sn, pos,
-                     (bf16_t*)out, n_q, n_kv);
+                     (bf16_t*)out, n_q, n_kv, kv_per_q_head);
   VL_LAUNCH_CHECK();
   return 0;
 }

@@ -337,6 +337,17 @@ def gemm_tn(At, Wt, out, K=None):
     return out
 
 
+def gemm_tn_grouped(At, Wt, out, M, N, K, ldat, ldwt, ldo, groups, a_gs, w_gs, batch, a_bs, w_bs, o_bs):
+    """out[b] = sum_g At[b,g]^T @ Wt[b,g] (raw pointers + element strides; see include/vlaser_hip.h)."""
+    L.check(L.lib().vlaser_gemm_tn_grouped(At.data_ptr(), Wt.data_ptr(), out.data_ptr(), M, N, K, ldat, ldwt, ldo, groups, a_gs, w_gs, batch,
+                                           a_bs, w_bs, o_bs, _stream()), 'vlaser_gemm_tn_grouped')
+
+
+def attn_bwd_pds(scores, dP, dO, O, P, dS, H, S, ld, hd, scale):
+    L.check(L.lib().vlaser_attn_bwd_pds(scores.data_ptr(), dP.data_ptr(), dO.data_ptr(), O.data_ptr(), P.data_ptr(), dS.data_ptr(), H, S, ld, hd,
+                                        scale, _stream()), 'vlaser_attn_bwd_pds')
+
+
 def transpose(x, out, rows, cols, ld_in, ld_out, pad_rows=None, batch=1, in_bs=0, out_bs=0, inner=1, in_is=0, out_is=0):
     L.check(L.lib().vlaser_transpose(x.data_ptr(), out.data_ptr(), rows, cols, ld_in, ld_out, ld_out if pad_rows is None else pad_rows, batch,
                                      in_bs, out_bs, inner, in_is, out_is, _stream()), 'vlaser_transpose')
@@ -351,9 +362,9 @@ def attn_bwd_ds(P, dP, dO, O, dS, dS_T, P_T, H, n_kv, S, ld, hd, scale):
                                        H, n_kv, S, ld, hd, scale, _stream()), 'vlaser_attn_bwd_ds')
 
 
-def rope_bwd_pack(dq, dk, dv, cos, sin, pos, out, S, n_q, n_kv):
+def rope_bwd_pack(dq, dk, dv, cos, sin, pos, out, S, n_q, n_kv, kv_per_q_head=False):
     L.check(L.lib().vlaser_rope_bwd_pack(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), cos.data_ptr(), sin.data_ptr(), pos.data_ptr(),
-                                         out.data_ptr(), S, n_q, n_kv, _stream()), 'vlaser_rope_bwd_pack')
+                                         out.data_ptr(), S, n_q, n_kv, 1 if kv_per_q_head else 0, _stream()), 'vlaser_rope_bwd_pack')
 
 
 def rmsnorm_bwd(dy, x, w, dres, dx, S, Cc, eps):

@@ -214,15 +214,13 @@ class SFTModel:
         # backward buffers
         self.dh, self.dh2, self.dx = z(S, H), z(S, H), z(S, H)
         self.dact, self.dgu = z(S, I), z(S, 2 * I)
-        self.dao, self.dq, self.dk, self.dv = z(S, nq * hd), z(S, nq * hd), z(S, nkv * hd), z(S, nkv * hd)
+        self.dao, self.dq, self.dk, self.dv = z(S, nq * hd), z(S, nq * hd), z(S, nq * hd), z(S, nq * hd)      # dk / dv: one partial per Q head
         self.dqkv = z(S, NQ)
         G = nq // nkv
         self.sc = torch.zeros(nq, S, S, dtype=F32, device=dev)
         self.dP = torch.zeros(nq, S, S, dtype=F32, device=dev)
         self.P, self.dS = z(nq, S, S), z(nq, S, S)
-        self.dS_T, self.P_T = z(nkv, S, G * S), z(nkv, S, G * S)
         self.Vn, self.KT = z(nkv, S, hd), z(nkv, hd, S)
-        self.QT, self.dOT = z(nkv, hd, G * S), z(nkv, hd, G * S)
         self.col = torch.zeros(max(2 * I, NQ, C4, H), dtype=F32, device=dev)
         self.rowstat = torch.zeros(2 * max(S, self.max_tiles * cfg.num_image_token) + 16 * max(2 * I, NQ, C4, H), dtype=F32, device=dev)   # colsum scratch
         self.sumsq_ws = torch.zeros(1024, dtype=F32, device=dev)
@@ -402,13 +400,8 @@ class SFTModel:
         dP = self.dP.view(-1)[:nq * S * Sp].view(nq, S, Sp)
         P = self.P.view(-1)[:nq * S * Sp].view(nq, S, Sp)
         dS = self.dS.view(-1)[:nq * S * Sp].view(nq, S, Sp)
-        dS_T = self.dS_T.view(-1)[:nkv * Sp * G * Sp].view(nkv, Sp, G * Sp)
-        P_T = self.P_T.view(-1)[:nkv * Sp * G * Sp].view(nkv, Sp, G * Sp)
-        dS_T.zero_(); P_T.zero_()
         Vn = self.Vn.view(-1)[:nkv * Sp * hd].view(nkv, Sp, hd)
         KT = self.KT.view(-1)[:nkv * hd * Sp].view(nkv, hd, Sp)
-        QT = self.QT.view(-1)[:nkv * hd * G * Sp].view(nkv, hd, G * Sp)
-        dOT = self.dOT.view(-1)[:nkv * hd * G * Sp].view(nkv, hd, G * Sp)
         sm = self.cache.s_max
         scale = hd ** -0.5
         bucket_of_layer = {}
@@ -435,21 +428,18 @@ class SFTModel:
             # attention backward through materialised per-head score matrices (S is small: 12 x S x S)
             Kc, VTc = self.cache.k[kslot, 0], self.cache.vt[kslot, 0]         # [nkv, s_max, hd], [nkv, hd, s_max]
             ops.gemm_raw(L.EPI_F32, q, Kc, sc, S, S, hd, nq * hd, hd, Sp, batch=nq, a_bs=hd, w_bs=sm * hd, o_bs=S * Sp, w_group=G)     # Q K^T
-            ops.softmax_causal(sc, P, nq, S, Sp, scale)
             ops.transpose(VTc, Vn, hd, S, sm, hd, hd, nkv, hd * sm, Sp * hd)        # V^T [hd, S] -> V [S, hd]
             ops.gemm_raw(L.EPI_F32, dao, Vn, dP, S, S, hd, nq * hd, hd, Sp, batch=nq, a_bs=hd, w_bs=Sp * hd, o_bs=S * Sp, w_group=G)   # dO V^T
-            ops.attn_bwd_ds(P, dP, dao, ao, dS, dS_T, P_T, nq, nkv, S, Sp, hd, scale)
+            ops.attn_bwd_pds(sc, dP, dao, ao, P, dS, nq, S, Sp, hd, scale)         # P = softmax(S), dS = P o (dP - D) * scale
             ops.transpose(Kc, KT, S, hd, hd, Sp, Sp, nkv, sm * hd, hd * Sp)         # K [S, hd] -> K^T [hd, Sp]
             ops.gemm_raw(L.EPI_NONE, dS, KT, self.dq, S, hd, Sp, Sp, Sp, nq * hd, batch=nq, a_bs=S * Sp, w_bs=hd * Sp, o_bs=hd, w_group=G)  # dQ = dS K
-            # grouped transposes [S, (kvh, g, d)] -> [kvh][d][g*Sp + q]: outer batch = kv head, inner = q head of the group
-            ops.transpose(q, QT, S, hd, nq * hd, G * Sp, Sp, nkv, G * hd, hd * G * Sp, inner=G, in_is=hd, out_is=Sp)
-            ops.transpose(dao, dOT, S, hd, nq * hd, G * Sp, Sp, nkv, G * hd, hd * G * Sp, inner=G, in_is=hd, out_is=Sp)
-            ops.gemm_raw(L.EPI_NONE, dS_T, QT, self.dk, S, hd, G * Sp, G * Sp, G * Sp, nkv * hd, batch=nkv, a_bs=Sp * G * Sp, w_bs=hd * G * Sp,
-                         o_bs=hd, w_group=1)                                                                                             # dK = dS^T Q
-            ops.gemm_raw(L.EPI_NONE, P_T, dOT, self.dv, S, hd, G * Sp, G * Sp, G * Sp, nkv * hd, batch=nkv, a_bs=Sp * G * Sp, w_bs=hd * G * Sp,
-                         o_bs=hd, w_group=1)                                                                                             # dV = P^T dO
+            # dK[kvh] = sum_g dS[kvh*G+g]^T Q_g, dV[kvh] = sum_g P[kvh*G+g]^T dO_g: contraction along the rows (q) of both operands,
+            # summed over the q heads of the kv group, straight from dS / P [head, q, k] and q / dO [q, head*hd]
+            # one TN GEMM per Q head (108 workgroups instead of 18 serial ones); the sum over the group happens in rope_bwd_pack
+            ops.gemm_tn_grouped(dS, q, self.dk, S, hd, S, Sp, nq * hd, nq * hd, 1, 0, 0, nq, S * Sp, hd, hd)
+            ops.gemm_tn_grouped(P, dao, self.dv, S, hd, S, Sp, nq * hd, nq * hd, 1, 0, 0, nq, S * Sp, hd, hd)
             dqkv = self.dqkv[:S]
-            ops.rope_bwd_pack(self.dq[:S], self.dk[:S], self.dv[:S], self.rope[0], self.rope[1], pos, dqkv, S, nq, nkv)
+            ops.rope_bwd_pack(self.dq[:S], self.dk[:S], self.dv[:S], self.rope[0], self.rope[1], pos, dqkv, S, nq, nkv, kv_per_q_head=True)
             self._dgrad(dqkv, wT['wqkv'], dx, S)
             self._wgrad(dqkv, x1, gv[f'l{i}.wqkv'], S, bias_out=gv[f'l{i}.bqkv'])
             ops.rmsnorm_bwd(dx, h_in, v[f'l{i}.ln_in'], dh2, dh, S, H, llm.rms_norm_eps)
