@@ -324,7 +324,9 @@ class SFTModel:
         Lyr = llm.num_hidden_layers
         ids = input_ids.to(dev).contiguous()
         pos = torch.arange(S, dtype=torch.int32, device=dev)
-        self.fp.g.zero_()
+        # every gradient tensor is fully overwritten by its wgrad / column-sum kernel each step, except the embedding rows
+        # (scatter-add over the text tokens): only that slice is cleared (466 MB instead of the whole 3.6 GB buffer)
+        gv['embed'].zero_()
         # ---- vision tower (frozen) + trainable projector (mlp1), with the intermediates mlp1's backward needs
         T = pixel_values.shape[0]
         pv = pixel_values.to(dev)
@@ -370,6 +372,7 @@ class SFTModel:
         xn = self.xn[:S]
         ops.rmsnorm(h_fin, v['norm'], llm.rms_norm_eps, out=xn)
         if R == 0:
+            self.fp.g.zero_()                                        # no supervised position: zero loss, zero gradients
             return torch.zeros((), device=dev)
         x_rows = xn.index_select(0, rows).contiguous()
         t_rows = tgt.index_select(0, rows).contiguous()
