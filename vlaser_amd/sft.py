@@ -69,6 +69,11 @@ class FlatParams:
         self.n += (numel + 127) // 128 * 128          # 256-byte aligned views
         return len(self.specs) - 1
 
+    def align(self, multiple):
+        """Pad so that the next tensor starts at a multiple of `multiple` elements (bucket boundaries: every ZeRO-1 bucket
+        then divides evenly over the ranks and the collectives run in place, without staging copies)."""
+        self.n = (self.n + multiple - 1) // multiple * multiple
+
     def finalize(self, pad_to=1):
         self.n = (self.n + pad_to - 1) // pad_to * pad_to
         self.p = torch.zeros(self.n, dtype=BF, device=self.device)
@@ -129,11 +134,13 @@ class SFTModel:
         fp = FlatParams(dev)
         fp.add('head', (V, H))
         fp.add('norm', (H,))
+        fp.align(128 * self.world)                # end of bucket 0 (head + final norm)
         self.bucket_bounds = [0]                  # flat offsets where a gradient bucket ends
         for i in reversed(range(llm.num_hidden_layers)):
             for nm, shp in [('wqkv', (NQ, H)), ('bqkv', (NQ,)), ('wo', (H, nq * hd)), ('wgu', (2 * I, H)), ('wdown', (H, I)), ('ln_in', (H,)),
                             ('ln_post', (H,))]:
                 fp.add(f'l{i}.{nm}', shp)
+        fp.align(128 * self.world)                # layer buckets are whole layers: already multiples for world <= 8, keep it explicit
         fp.add('embed', (V, H))
         C4 = cfg.vision.hidden_size * 4
         for nm, shp in [('m0w', (C4,)), ('m0b', (C4,)), ('m1w', (H, C4)), ('m1b', (H,)), ('m3w', (H, H)), ('m3b', (H,))]:
@@ -172,6 +179,7 @@ class SFTModel:
                 lo = hi
         # ZeRO-1: every rank owns the slice [lo + r*len/N, lo + (r+1)*len/N) of each bucket (bucket lengths are multiples of 128;
         # uneven division is handled by padding the reduce-scatter input)
+        assert all((hi - lo) % (128 * self.world) == 0 for lo, hi in self.buckets), 'ZeRO-1 buckets must divide evenly over the ranks'
         self.shards = dp.plan_shards(self.buckets, self.world, self.rank)
         n_shard = sum(hi - lo for lo, hi, _ in self.shards)
         self.master = torch.zeros(n_shard, dtype=F32, device=dev)
