@@ -232,12 +232,11 @@ def main():
 
 
 def batched_chunks(vla, dev, steps):
-    """Side number (never `value`): the same chunk workload with 3 observations per infer_action call -- the largest batch
-    whose 3 x (1 proprio + 4 action) rows fit the 16-row weight-streaming kernels, i.e. the expert's weights are streamed
-    once for 3 chunks."""
+    """Side number (never `value`): the same chunk workload with 4 observations per infer_action call -- the largest batch
+    whose 4 x 4 action rows fit the 16-row weight-streaming kernels, i.e. the expert's weights are streamed once for 4 chunks."""
     from vlaser_amd import synth
     from vlaser_amd.pizero import PiZeroInference
-    B = 3
+    B = 4
     sd = synth.vla_state_dict(vla, device=dev, dtype=torch.bfloat16)
     model = PiZeroInference(vla, device=dev, max_batch=B)
     model.load_state_dict(sd)

@@ -55,6 +55,13 @@ def test_infer_action_valid_length_extremes(golden_model):
     both = m.infer_action(cat[0], cat[1], m1, m2, vp, pp, ap, cat[2], noise=cat[3])
     for b in range(2):
         assert (both[b] - singles[b][0]).abs().max().item() < 2.5e-2
+    # a batch larger than max_batch runs as consecutive groups (the reference takes any batch size)
+    big = [torch.cat([c, c[:1]], 0) for c in cat]
+    am3 = (big[0] != cfg.pad_token_id).long()
+    mask3, vp3, pp3, ap3 = ovla.build_causal_mask_and_position_ids(am3, torch.float32, vla)
+    m13, m23 = ovla.split_full_mask_into_submasks(mask3, vla)
+    three = m.infer_action(big[0], big[1], m13, m23, vp3, pp3, ap3, big[2], noise=big[3])
+    assert three.shape == (3, 4, 7) and torch.equal(three[:2], both) and (three[2] - singles[0][0]).abs().max().item() < 2.5e-2
 
 
 def test_generate_eos_in_batch_and_min_new_tokens(golden_model, golden_dir):

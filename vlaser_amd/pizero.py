@@ -183,7 +183,16 @@ class PiZero:
         B = pixel_values.shape[0] // self.num_images
         T, na = self.max_image_text_tokens, self.num_action_tokens
         if B > self.max_batch:
-            raise ValueError(f'batch {B} > max_batch {self.max_batch}')
+            # larger batches run as consecutive groups of max_batch observations (<= 16 action rows per weight-streaming launch)
+            outs, mb, ni = [], self.max_batch, self.num_images
+            sl = lambda t, lo, hi, k=1: None if t is None else t[lo * k:hi * k]
+            for lo in range(0, B, mb):
+                hi = min(B, lo + mb)
+                outs.append(self.infer_action(input_ids[lo:hi], pixel_values[lo * ni:hi * ni], sl(image_text_proprio_mask, lo, hi),
+                                              sl(action_mask, lo, hi), sl(vlm_position_ids, lo, hi), sl(proprio_position_ids, lo, hi),
+                                              sl(action_position_ids, lo, hi), sl(proprios, lo, hi), sl(noise, lo, hi), generator,
+                                              sl(valid_len, lo, hi)))
+            return torch.cat(outs, 0)
         if input_ids.shape != (B, T):
             raise ValueError(f'input_ids must be [B,{T}] (right-padded with pad_token_id), got {tuple(input_ids.shape)}')
         # ---- stage inputs into the static buffers (host->device plumbing)
