@@ -90,6 +90,28 @@ def test_generate_eos_in_batch_and_min_new_tokens(golden_model, golden_dir):
     assert forced.shape[1] >= 4 and forced[0, :2].tolist() == gold[1, :2].tolist()
 
 
+def test_generate_more_than_sixteen_sequences(golden_model):
+    """generate() takes any batch size: 18 text-only prompts = a group of 16 + a group of 2, same ids as one-by-one decoding
+    wherever the one-by-one logit margin is clear."""
+    from vlaser_amd.internvl_chat import InternVLChatModel
+    cfg, _, sd = golden_model
+    m = InternVLChatModel(cfg, max_seq_len=128, max_batch=16)
+    m.load_state_dict(sd)
+    m.img_context_token_id = cfg.img_context_token_id
+    g = torch.Generator().manual_seed(99)
+    ids = torch.randint(0, 151643, (18, 24), generator=g)
+    out = m.generate(None, ids, max_new_tokens=3)
+    assert out.shape == (18, 3)
+    for b in (0, 15, 16, 17):
+        solo, lg = m.generate(None, ids[b:b + 1], max_new_tokens=3, return_logits=True)
+        t2 = lg[0].topk(2, dim=-1).values
+        margin = (t2[:, 0] - t2[:, 1]).cpu()
+        n_clear = 0
+        while n_clear < 3 and margin[n_clear] > 0.08:
+            n_clear += 1
+        assert out[b, :n_clear].tolist() == solo[0, :n_clear].tolist()
+
+
 def test_thirteen_tiles_dynamic_resolution():
     from oracle import vlm as ovlm, vit as ovit
     from vlaser_amd import config as C, synth

@@ -189,13 +189,27 @@ class InternVLChatModel:
             eos_token_id = eos_token_id if eos_token_id is not None else getattr(generation_config, 'eos_token_id', None)
         max_new_tokens = max_new_tokens or 20          # HF default max_length heritage
         B = input_ids.shape[0]
+        if B > 16:
+            # the weight-streaming decode takes <= 16 rows per launch: larger batches run as consecutive groups of 16 sequences
+            if return_logits or visual_features is not None:
+                raise NotImplementedError('return_logits / visual_features are per-group features: call generate() with <= 16 sequences')
+            tiles = ((input_ids == self.img_context_token_id).sum(1) // self.num_image_token).tolist() if pixel_values is not None else [0] * B
+            pad = pad_token_id if pad_token_id is not None else (eos_token_id[0] if isinstance(eos_token_id, (list, tuple)) else eos_token_id) or 0
+            outs, off = [], 0
+            for lo in range(0, B, 16):
+                hi = min(B, lo + 16)
+                nt = sum(tiles[lo:hi])
+                outs.append(self.generate(None if pixel_values is None else pixel_values[off:off + nt], input_ids[lo:hi],
+                                          None if attention_mask is None else attention_mask[lo:hi], max_new_tokens=max_new_tokens,
+                                          min_new_tokens=min_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id))
+                off += nt
+            n = max(o.shape[1] for o in outs)
+            return torch.cat([torch.nn.functional.pad(o, (0, n - o.shape[1]), value=pad) for o in outs], 0)
         lens = None
         if attention_mask is not None and not bool(attention_mask.bool().all()):
             input_ids, lens_cpu = self._compact_padded(input_ids, attention_mask, self.config.pad_token_id)
             lens = lens_cpu.to(self.device)
         S = input_ids.shape[1]
-        if B > 16:
-            raise ValueError('at most 16 sequences per generate() call')
         self._ensure(B, S + max_new_tokens)
         if pixel_values is not None:
             vit_embeds = visual_features if visual_features is not None else self.vit.forward(self._to_bf16(pixel_values))
