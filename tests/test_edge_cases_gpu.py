@@ -112,6 +112,23 @@ def test_generate_more_than_sixteen_sequences(golden_model):
         assert out[b, :n_clear].tolist() == solo[0, :n_clear].tolist()
 
 
+def test_do_sample_warpers(golden_model):
+    """do_sample=True: top_k=1 reproduces greedy, a seeded generator reproduces itself, samples stay inside the top-k set."""
+    from vlaser_amd.internvl_chat import InternVLChatModel
+    cfg, _, sd = golden_model
+    m = InternVLChatModel(cfg, max_seq_len=128, max_batch=2)
+    m.load_state_dict(sd)
+    m.img_context_token_id = cfg.img_context_token_id
+    ids = torch.randint(0, 151643, (2, 20), generator=torch.Generator().manual_seed(4))
+    greedy, lg = m.generate(None, ids, max_new_tokens=4, return_logits=True)
+    assert m.generate(None, ids, max_new_tokens=4, do_sample=True, top_k=1).tolist() == greedy.tolist()
+    gen = lambda seed: m.generate(None, ids, max_new_tokens=4, do_sample=True, temperature=0.8, top_k=5, top_p=0.9,
+                                  generator=torch.Generator(device='cuda').manual_seed(seed))
+    a, b = gen(1), gen(1)
+    assert a.tolist() == b.tolist()
+    assert all(int(a[r, 0]) in lg[r, 0].topk(5).indices.tolist() for r in range(2))      # first step: same distribution as greedy's logits
+
+
 def test_thirteen_tiles_dynamic_resolution():
     from oracle import vlm as ovlm, vit as ovit
     from vlaser_amd import config as C, synth

@@ -182,8 +182,10 @@ class InternVLChatModel:
                  output_hidden_states=None, max_new_tokens=None, min_new_tokens=0, do_sample=False, eos_token_id=None,
                  pad_token_id=None, return_logits=False, **generate_kwargs):
         assert self.img_context_token_id is not None
-        if do_sample:
-            raise NotImplementedError('only greedy decoding (do_sample=False) is implemented')
+        # do_sample: HF's logits warpers in their order (temperature -> top_k -> top_p) + multinomial on the fp32 logits the
+        # lm_head kernel leaves on the device; not on the hot path (the reference's eval configs decode greedily)
+        sample = dict(temperature=float(generate_kwargs.pop('temperature', 1.0) or 1.0), top_k=int(generate_kwargs.pop('top_k', 0) or 0),
+                      top_p=float(generate_kwargs.pop('top_p', 1.0) or 1.0), generator=generate_kwargs.pop('generator', None)) if do_sample else None
         if generation_config is not None:
             max_new_tokens = max_new_tokens or getattr(generation_config, 'max_new_tokens', None)
             eos_token_id = eos_token_id if eos_token_id is not None else getattr(generation_config, 'eos_token_id', None)
@@ -201,7 +203,8 @@ class InternVLChatModel:
                 nt = sum(tiles[lo:hi])
                 outs.append(self.generate(None if pixel_values is None else pixel_values[off:off + nt], input_ids[lo:hi],
                                           None if attention_mask is None else attention_mask[lo:hi], max_new_tokens=max_new_tokens,
-                                          min_new_tokens=min_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id))
+                                          min_new_tokens=min_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id,
+                                          do_sample=do_sample, **(dict(sample) if sample else {})))
                 off += nt
             n = max(o.shape[1] for o in outs)
             return torch.cat([torch.nn.functional.pad(o, (0, n - o.shape[1]), value=pad) for o in outs], 0)
@@ -234,6 +237,8 @@ class InternVLChatModel:
         for step in range(max_new_tokens):
             if return_logits:
                 logits_out.append(self.logits[:B].clone())
+            if sample is not None:
+                self._sample_next(B, **sample)
             nxt = self.next_ids[:B].cpu()
             nxt = torch.where(finished, torch.full_like(nxt, pad), nxt)
             out.append(nxt)
@@ -246,6 +251,22 @@ class InternVLChatModel:
         if return_logits:
             return ids, torch.stack(logits_out, dim=1)
         return ids
+
+    def _sample_next(self, B, temperature=1.0, top_k=0, top_p=1.0, generator=None):
+        """Replace the greedy pick in next_ids / next_h by a sample from the warped distribution (torch ops on device logits)."""
+        lg = self.logits[:B] / temperature
+        if top_k > 0:
+            kth = lg.topk(min(top_k, lg.shape[-1]), dim=-1).values[:, -1:]
+            lg = lg.masked_fill(lg < kth, float('-inf'))
+        if top_p < 1.0:
+            srt, idx = lg.sort(dim=-1, descending=False)
+            cum = srt.softmax(-1).cumsum(-1)
+            drop = cum <= (1.0 - top_p)
+            drop[:, -1] = False                                   # always keep the most likely token
+            lg = lg.masked_fill(drop.scatter(1, idx, drop), float('-inf'))
+        pick = torch.multinomial(lg.softmax(-1), 1, generator=generator).squeeze(1)
+        self.next_ids[:B].copy_(pick)
+        self.next_h[:B].copy_(self.llm.embed[pick])
 
     def chat(self, tokenizer, pixel_values, question, generation_config, history=None, return_history=False,
              num_patches_list=None, IMG_START_TOKEN='<img>', IMG_END_TOKEN='</img>', IMG_CONTEXT_TOKEN='<IMG_CONTEXT>',
