@@ -129,6 +129,36 @@ def test_do_sample_warpers(golden_model):
     assert all(int(a[r, 0]) in lg[r, 0].topk(5).indices.tolist() for r in range(2))      # first step: same distribution as greedy's logits
 
 
+def test_from_pretrained_and_sft_save_pretrained(golden_model, tmp_path):
+    """HF-layout checkpoints: InternVLChatModel.from_pretrained(dir) == load_state_dict(sd); one SFT step, save_pretrained,
+    reload: the saved weights are the trained ones under the HF key names."""
+    from vlaser_amd import config as C
+    from vlaser_amd.internvl_chat import InternVLChatModel
+    from vlaser_amd.sft import SFTModel
+    cfg, _, sd = golden_model
+    vsd = {k: v.to(BF) for k, v in sd.items() if k.startswith(('vision_model.', 'mlp1.', 'language_model.'))}
+    C.save_hf_checkpoint(str(tmp_path / 'a'), cfg, vsd, max_shard_bytes=1 << 30)
+    g = torch.Generator().manual_seed(8)
+    pv = torch.randn(1, 3, 448, 448, generator=g)
+    ids = torch.cat([torch.randint(0, 151643, (20,), generator=g), torch.full((256,), cfg.img_context_token_id),
+                     torch.randint(0, 151643, (12,), generator=g)])[None]
+    m0 = InternVLChatModel(cfg, max_seq_len=320); m0.load_state_dict(vsd); m0.img_context_token_id = cfg.img_context_token_id
+    m1 = InternVLChatModel.from_pretrained(str(tmp_path / 'a'), max_seq_len=320); m1.img_context_token_id = cfg.img_context_token_id
+    assert m1.config == cfg
+    l0 = m0.forward(pv, ids, image_flags=torch.ones(1, 1, dtype=torch.long)).logits
+    assert torch.equal(l0, m1.forward(pv, ids, image_flags=torch.ones(1, 1, dtype=torch.long)).logits)
+    labels = torch.full_like(ids, -100); labels[0, -8:] = ids[0, -8:]
+    t = SFTModel(cfg, max_seq_len=ids.shape[1], lr=1e-2); t.load_state_dict(vsd)
+    t.step(pv, ids, labels)
+    t.save_pretrained(str(tmp_path / 'b'))
+    m2 = InternVLChatModel.from_pretrained(str(tmp_path / 'b'), max_seq_len=320); m2.img_context_token_id = cfg.img_context_token_id
+    l2 = m2.forward(pv, ids, image_flags=torch.ones(1, 1, dtype=torch.long)).logits
+    assert not torch.equal(l2, l0)                                        # the step changed the weights ...
+    out = t.forward_backward(pv, ids, labels)                             # ... and the reloaded model is the trained one
+    ref = m2.forward(pv, ids, image_flags=torch.ones(1, 1, dtype=torch.long), labels=labels).loss
+    assert abs(out.item() - ref.item()) < 5e-3
+
+
 def test_thirteen_tiles_dynamic_resolution():
     from oracle import vlm as ovlm, vit as ovit
     from vlaser_amd import config as C, synth

@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from vlaser_amd import prep
@@ -84,3 +85,33 @@ def test_normalize_bound_roundtrip():
     y = prep.normalize_bound(x, lo, hi)
     assert y.min() >= -1 and y.max() <= 1
     torch.testing.assert_close(prep.denormalize_bound(y, lo, hi), x, rtol=0, atol=1e-6)
+
+
+def test_hf_config_and_checkpoint_round_trip(tmp_path):
+    """config.json in the layout of the reference's vendored InternVL3 config (keys as found there; sizes of Vlaser-2B) ->
+    VlaserConfig; sharded safetensors + index written and read back with the key names unchanged."""
+    from vlaser_amd import config as C
+    hf = {'architectures': ['InternVLChatModel'], 'downsample_ratio': 0.5, 'dynamic_image_size': True, 'force_image_size': 448,
+          'max_dynamic_patch': 12, 'min_dynamic_patch': 1, 'model_type': 'internvl_chat', 'ps_version': 'v2', 'select_layer': -1,
+          'system_message': None, 'template': 'internvl2_5', 'tie_word_embeddings': False, 'use_thumbnail': True,
+          'llm_config': {'architectures': ['Qwen2ForCausalLM'], 'hidden_size': 1536, 'intermediate_size': 8960, 'max_position_embeddings': 32768,
+                         'num_attention_heads': 12, 'num_hidden_layers': 28, 'num_key_value_heads': 2, 'rms_norm_eps': 1e-06,
+                         'rope_theta': 1000000.0, 'tie_word_embeddings': False, 'vocab_size': 151674},
+          'vision_config': {'hidden_act': 'gelu', 'hidden_size': 1024, 'image_size': 448, 'initializer_factor': 0.1, 'intermediate_size': 4096,
+                            'layer_norm_eps': 1e-06, 'norm_type': 'layer_norm', 'num_attention_heads': 16, 'num_hidden_layers': 24,
+                            'patch_size': 14, 'qk_normalization': False, 'qkv_bias': True}}
+    cfg = C.from_hf_config(hf)
+    assert cfg == C.vlaser_2b()
+    assert C.from_hf_config(C.to_hf_config(C.vlaser_8b())) == C.vlaser_8b()
+    bad = json.loads(json.dumps(hf)); bad['llm_config'].update(hidden_size=896, num_attention_heads=14)        # InternVL3-1B: head_dim 64
+    with pytest.raises(ValueError):
+        C.from_hf_config(bad)
+    bad = json.loads(json.dumps(hf)); bad['llm_config']['architectures'] = ['InternLM2ForCausalLM']
+    with pytest.raises(ValueError):
+        C.from_hf_config(bad)
+    sd = {'language_model.model.norm.weight': torch.arange(8, dtype=torch.bfloat16), 'mlp1.0.bias': torch.ones(5),
+          'vision_model.embeddings.class_embedding': torch.zeros(1, 1, 4, dtype=torch.bfloat16)}
+    C.save_hf_checkpoint(str(tmp_path), cfg, sd, max_shard_bytes=20)                 # forces several shards
+    assert len([f for f in os.listdir(tmp_path) if f.endswith('.safetensors')]) >= 2
+    hf2, sd2 = C.load_hf_checkpoint(str(tmp_path))
+    assert C.from_hf_config(hf2) == cfg and set(sd2) == set(sd) and all(torch.equal(sd2[k], sd[k]) for k in sd)

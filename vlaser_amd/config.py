@@ -112,3 +112,101 @@ def truncated(cfg: VlaserConfig, vit_layers: int, llm_layers: int, vocab_size: i
     l = replace(cfg.llm, num_hidden_layers=llm_layers,
                 vocab_size=cfg.llm.vocab_size if vocab_size is None else vocab_size)
     return replace(cfg, vision=v, llm=l)
+
+
+def from_hf_config(d: dict) -> VlaserConfig:
+    """VlaserConfig from the dict of an InternVL3 / Vlaser HF `config.json` (the format of the reference's vendored
+    InternVL3-1B/config.json: top-level template / ps_version / select_layer / downsample_ratio + `llm_config` + `vision_config`).
+    Raises ValueError for architectures the kernels do not cover instead of loading something that would run wrong."""
+    lc, vc = d.get('llm_config', {}), d.get('vision_config', {})
+    arch = (lc.get('architectures') or ['Qwen2ForCausalLM'])[0]
+    if arch != 'Qwen2ForCausalLM':
+        raise ValueError(f'LLM architecture {arch} is outside the hot path (Qwen2ForCausalLM only; SURVEY.md 8)')
+    nh = lc['num_attention_heads']
+    head_dim = lc.get('head_dim') or lc['hidden_size'] // nh
+    if head_dim != 128:
+        raise ValueError(f'head_dim {head_dim}: the attention / RoPE kernels are built for head_dim 128 (Vlaser-2B / 8B)')
+    if lc.get('tie_word_embeddings', d.get('tie_word_embeddings', False)):
+        raise ValueError('tie_word_embeddings=True is not supported (Vlaser checkpoints carry a separate lm_head)')
+    if vc.get('norm_type', 'layer_norm') != 'layer_norm' or vc.get('qk_normalization', False) or not vc.get('qkv_bias', True):
+        raise ValueError('vision tower variant outside InternViT-300M-448px (layer_norm, no qk-norm, qkv bias)')
+    if vc.get('hidden_act', 'gelu') != 'gelu':
+        raise ValueError('vision MLP activation must be gelu')
+    rope = lc.get('rope_theta') or (lc.get('rope_parameters') or {}).get('rope_theta') or 1e6      # transformers >= 5 moved it
+    llm = LLMConfig(hidden_size=lc['hidden_size'], num_hidden_layers=lc['num_hidden_layers'], num_attention_heads=nh,
+                    num_key_value_heads=lc.get('num_key_value_heads', nh), head_dim=head_dim, intermediate_size=lc['intermediate_size'],
+                    vocab_size=lc['vocab_size'], rms_norm_eps=lc.get('rms_norm_eps', 1e-6), rope_theta=float(rope))
+    img = d.get('force_image_size') or vc.get('image_size', 448)
+    vision = VisionConfig(hidden_size=vc.get('hidden_size', 1024), num_hidden_layers=vc.get('num_hidden_layers', 24),
+                          num_attention_heads=vc.get('num_attention_heads', 16), intermediate_size=vc.get('intermediate_size', 4096),
+                          image_size=img, patch_size=vc.get('patch_size', 14), layer_norm_eps=vc.get('layer_norm_eps', 1e-6),
+                          initializer_factor=vc.get('initializer_factor', 0.1))
+    return VlaserConfig(vision=vision, llm=llm, downsample_ratio=d.get('downsample_ratio', 0.5), ps_version=d.get('ps_version', 'v2'),
+                        select_layer=d.get('select_layer', -1), template=d.get('template', 'internvl2_5'))
+
+
+def to_hf_config(cfg: VlaserConfig) -> dict:
+    """The inverse of from_hf_config (what save_pretrained writes)."""
+    v, l = cfg.vision, cfg.llm
+    return {'architectures': ['InternVLChatModel'], 'model_type': 'internvl_chat', 'downsample_ratio': cfg.downsample_ratio,
+            'ps_version': cfg.ps_version, 'select_layer': cfg.select_layer, 'template': cfg.template, 'force_image_size': v.image_size,
+            'tie_word_embeddings': False, 'torch_dtype': 'bfloat16',
+            'llm_config': {'architectures': ['Qwen2ForCausalLM'], 'hidden_size': l.hidden_size, 'num_hidden_layers': l.num_hidden_layers,
+                           'num_attention_heads': l.num_attention_heads, 'num_key_value_heads': l.num_key_value_heads, 'head_dim': l.head_dim,
+                           'intermediate_size': l.intermediate_size, 'vocab_size': l.vocab_size, 'rms_norm_eps': l.rms_norm_eps,
+                           'rope_theta': l.rope_theta, 'tie_word_embeddings': False},
+            'vision_config': {'hidden_size': v.hidden_size, 'num_hidden_layers': v.num_hidden_layers, 'num_attention_heads': v.num_attention_heads,
+                              'intermediate_size': v.intermediate_size, 'image_size': v.image_size, 'patch_size': v.patch_size,
+                              'layer_norm_eps': v.layer_norm_eps, 'initializer_factor': v.initializer_factor, 'norm_type': 'layer_norm',
+                              'qk_normalization': False, 'qkv_bias': True, 'hidden_act': 'gelu'}}
+
+
+def load_hf_checkpoint(path: str):
+    """(config dict, state dict) of an HF-format checkpoint directory: config.json + model.safetensors, or
+    model.safetensors.index.json + shards, or pytorch_model.bin (InternVLChatModel.from_pretrained's formats)."""
+    import json
+    import os
+    with open(os.path.join(path, 'config.json')) as f:
+        cfg = json.load(f)
+    idx = os.path.join(path, 'model.safetensors.index.json')
+    one = os.path.join(path, 'model.safetensors')
+    sd = {}
+    if os.path.exists(idx):
+        from safetensors.torch import load_file
+        with open(idx) as f:
+            shards = sorted(set(json.load(f)['weight_map'].values()))
+        for sh in shards:
+            sd.update(load_file(os.path.join(path, sh)))
+    elif os.path.exists(one):
+        from safetensors.torch import load_file
+        sd = load_file(one)
+    elif os.path.exists(os.path.join(path, 'pytorch_model.bin')):
+        import torch
+        sd = torch.load(os.path.join(path, 'pytorch_model.bin'), map_location='cpu')
+    else:
+        raise FileNotFoundError(f'no model.safetensors(.index.json) / pytorch_model.bin under {path}')
+    return cfg, sd
+
+
+def save_hf_checkpoint(path: str, cfg: VlaserConfig, sd: dict, max_shard_bytes: int = 4 << 30):
+    """config.json + sharded safetensors with an index (HF layout; keys unchanged)."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, 'config.json'), 'w') as f:
+        json.dump(to_hf_config(cfg), f, indent=1)
+    shards, cur, size = [], {}, 0
+    for k, t in sd.items():
+        b = t.numel() * t.element_size()
+        if cur and size + b > max_shard_bytes:
+            shards.append(cur); cur, size = {}, 0
+        cur[k] = t.detach().cpu().contiguous(); size += b
+    shards.append(cur)
+    wm = {}
+    for i, sh in enumerate(shards):
+        name = f'model-{i + 1:05d}-of-{len(shards):05d}.safetensors'
+        save_file(sh, os.path.join(path, name), metadata={'format': 'pt'})
+        wm.update({k: name for k in sh})
+    with open(os.path.join(path, 'model.safetensors.index.json'), 'w') as f:
+        json.dump({'metadata': {'total_size': sum(t.numel() * t.element_size() for t in sd.values())}, 'weight_map': wm}, f, indent=1)

@@ -47,6 +47,18 @@ class InternVLChatModel:
             raise NotImplementedError('only select_layer == -1 (last hidden state) is implemented')
 
     # ------------------------------------------------------------------ weights
+    @classmethod
+    def from_pretrained(cls, path, device='cuda', **kw):
+        """HF-format checkpoint directory (config.json + safetensors shards / pytorch_model.bin), key names unchanged
+        (the reference: InternVLChatModel.from_pretrained, eval_example.py:112-122)."""
+        from .config import from_hf_config, load_hf_checkpoint
+        hf_cfg, sd = load_hf_checkpoint(path)
+        model = cls(from_hf_config(hf_cfg), device=device, **kw)
+        if hf_cfg.get('system_message'):
+            model.system_message = hf_cfg['system_message']
+        model.load_state_dict(sd)
+        return model
+
     def load_state_dict(self, sd, strict=True):
         need = ['vision_model.embeddings.class_embedding', 'mlp1.0.weight', 'language_model.model.embed_tokens.weight',
                 'language_model.lm_head.weight', 'language_model.model.norm.weight']

@@ -127,6 +127,7 @@ class SFTModel:
     def load_state_dict(self, sd):
         cfg, llm, dev = self.cfg, self.llm, self.device
         self.vit = VitEngine(sd, cfg, dev, max_tiles=self.max_tiles)     # frozen (freeze_backbone True)
+        self.frozen_sd = {k: v.detach().to('cpu') for k, v in sd.items() if k.startswith('vision_model.')}      # for save_pretrained
         H, I, V = llm.hidden_size, llm.intermediate_size, llm.vocab_size
         nq, nkv, hd = llm.num_attention_heads, llm.num_key_value_heads, llm.head_dim
         NQ = (nq + 2 * nkv) * hd
@@ -529,6 +530,14 @@ class SFTModel:
         loss = self.forward_backward(pixel_values, input_ids, labels, image_flags, on_bucket_ready=self._exchange_bucket)
         gnorm = self.optimizer_step(lr)
         return SimpleNamespace(loss=loss, grad_norm=gnorm)
+
+    def save_pretrained(self, path, max_shard_bytes=4 << 30):
+        """HF-layout checkpoint (config.json + sharded safetensors + index) of the current weights: trainable tensors from the flat
+        buffer (HF key names, un-packed), the frozen vision tower as loaded -- `InternVLChatModel.from_pretrained(path)` reads it."""
+        from .config import save_hf_checkpoint
+        sd = dict(self.frozen_sd)
+        sd.update(self.state_dict())
+        save_hf_checkpoint(path, self.cfg, sd, max_shard_bytes)
 
     # ------------------------------------------------------------------ export (HF key names, un-packed layouts)
     def state_dict(self):
