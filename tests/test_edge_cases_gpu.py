@@ -55,6 +55,23 @@ def test_infer_action_valid_length_extremes(golden_model):
     both = m.infer_action(cat[0], cat[1], m1, m2, vp, pp, ap, cat[2], noise=cat[3])
     for b in range(2):
         assert (both[b] - singles[b][0]).abs().max().item() < 2.5e-2
+    # the reference's .pt layout (`data["model"]`, aliased / `_orig_mod.`-prefixed keys) loads to the same policy
+    import os, tempfile
+    aliased = {}
+    for k, v in sd.items():
+        if k.startswith('action_expert.model.layers.'):
+            aliased['_orig_mod.joint_model.mixtures.action.layers.' + k[len('action_expert.model.layers.'):]] = v
+            aliased['_orig_mod.joint_model.mixtures.proprio.layers.' + k[len('action_expert.model.layers.'):]] = v
+        elif k.startswith('vision_model.'):
+            aliased['_orig_mod.vision_tower.' + k] = v
+        else:
+            aliased['_orig_mod.' + k] = v
+    with tempfile.TemporaryDirectory() as td:
+        torch.save({'model': aliased, 'step': 1}, os.path.join(td, 'ckpt.pt'))
+        m_ck = PiZeroInference(vla, max_batch=1)
+        m_ck.load_checkpoint(os.path.join(td, 'ckpt.pt'))
+    ids0, pv0, pro0, noise0 = obs[0]
+    assert torch.equal(m_ck.infer_action(ids0, pv0, proprios=pro0, noise=noise0), m.infer_action(ids0, pv0, proprios=pro0, noise=noise0))
     # a batch larger than max_batch runs as consecutive groups (the reference takes any batch size)
     big = [torch.cat([c, c[:1]], 0) for c in cat]
     am3 = (big[0] != cfg.pad_token_id).long()

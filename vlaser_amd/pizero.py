@@ -76,6 +76,12 @@ class PiZero:
             raise ValueError('the weight-streaming action path handles batch * horizon <= 16 rows')
 
     # ------------------------------------------------------------------ weights / workspace
+    def load_checkpoint(self, path):
+        """The reference's released `.pt` checkpoints: `torch.load(path)["model"]` (eval.py:196-212); aliases and `_orig_mod.`
+        prefixes are canonicalised by load_state_dict."""
+        data = torch.load(path, map_location='cpu', weights_only=True)
+        return self.load_state_dict(data['model'] if isinstance(data, dict) and 'model' in data else data)
+
     def load_state_dict(self, sd, strict=True):
         sd = canonicalize_vla_state_dict(sd)
         cfg, dev = self.cfg, self.device
