@@ -115,3 +115,28 @@ def test_hf_config_and_checkpoint_round_trip(tmp_path):
     assert len([f for f in os.listdir(tmp_path) if f.endswith('.safetensors')]) >= 2
     hf2, sd2 = C.load_hf_checkpoint(str(tmp_path))
     assert C.from_hf_config(hf2) == cfg and set(sd2) == set(sd) and all(torch.equal(sd2[k], sd[k]) for k in sd)
+
+
+def test_env_adapter_vs_reference(golden_dir):
+    """Bridge / WidowX adapter (proprio in, env actions out) and its rotation helpers against the reference's own functions
+    (tools/gen_golden_adapter.py), incl. the identity rotation and a gimbal-lock pitch."""
+    from vlaser_amd import adapter as A
+    d = np.load(os.path.join(golden_dir, 'g8_adapter.npz'))
+    for q, m, e in zip(d['quat'], d['quat2mat'], d['mat2euler']):
+        np.testing.assert_allclose(A.quat2mat(q), m, rtol=0, atol=1e-14)
+        np.testing.assert_allclose(A.mat2euler(m), e, rtol=0, atol=1e-12)
+    for e, ax, ang in zip(d['euler'], d['axangle_axis'], d['axangle_angle']):
+        axis, angle = A.euler2axangle(*e)
+        np.testing.assert_allclose(axis, ax, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(angle, ang, rtol=0, atol=1e-12)
+    stats = {k1: {k2: d[f'stats_{k1}_{k2}'].tolist() for k2 in ('p01', 'p99', 'mean', 'std')} for k1 in ('proprio', 'action')}
+    for kind in ('bound', 'gaussian'):
+        ad = A.BridgeSimplerAdapter(stats, action_normalization_type=kind, proprio_normalization_type=kind)
+        for eef, raw, nb in zip(d['eef_pos'], d['raw_proprio'], d[f'proprio_{kind}']):
+            r = ad.preprocess_proprio({'agent': {'eef_pos': eef}})
+            np.testing.assert_allclose(r, raw, rtol=0, atol=1e-12)
+            np.testing.assert_allclose(ad.normalize_proprio(r), nb, rtol=0, atol=1e-12)
+        for a, ref in zip(d['actions'], d[f'post_{kind}']):
+            out = ad.postprocess(a)
+            np.testing.assert_allclose(out, ref, rtol=0, atol=1e-12)
+            assert set(np.unique(out[:, -1])) <= {-1.0, 1.0}
