@@ -1,0 +1,89 @@
+"""The data-parallel SFT step with a REAL world size of 2 on the one-GPU box: two processes share the GPU and exchange CUDA
+tensors over gloo (the same dp.py / SFTModel code path that runs over RCCL on a multi-GPU node; only the backend differs).
+
+  * both ranks end every step with bit-identical parameters (ZeRO-1 shard ownership + all-gather),
+  * the result equals the single-process emulation "average the two samples' gradients, then one AdamW step" bit for bit when
+    clipping is off (same bf16 mean, same fused AdamW), and within fp32 reduction-order noise with the default clip at 1.0,
+  * the loss each rank reports is its own sample's loss.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BF = torch.bfloat16
+KEYS = ['language_model.model.layers.0.self_attn.q_proj.weight', 'language_model.model.layers.1.mlp.down_proj.weight',
+        'language_model.lm_head.weight', 'language_model.model.norm.weight', 'mlp1.1.weight', 'language_model.model.embed_tokens.weight']
+
+
+def _sample(cfg, rank):
+    g = torch.Generator().manual_seed(500 + rank)
+    pv = torch.randn(1, 3, 448, 448, generator=g)
+    ids = torch.cat([torch.randint(0, 151643, (20,), generator=g), torch.full((256,), cfg.img_context_token_id),
+                     torch.randint(0, 151643, (30,), generator=g)])[None]
+    labels = torch.full_like(ids, -100)
+    labels[0, -12:] = ids[0, -12:]
+    return pv, ids, labels
+
+
+def _model(clip, pg=None):
+    from vlaser_amd import config as C, synth
+    from vlaser_amd.sft import SFTModel
+    cfg = C.truncated(C.vlaser_2b(), 1, 2)
+    sd = synth.vlm_state_dict(cfg)
+    m = SFTModel(cfg, max_seq_len=320, lr=1e-3, max_grad_norm=clip, process_group=pg, bucket_layers=1)
+    m.load_state_dict(sd)
+    return cfg, m
+
+
+def _worker(rank, world, port, clip, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_grad_enabled(False)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    cfg, m = _model(clip, dist.group.WORLD)
+    assert m.world == 2 and m.dp_active and len(m.buckets) >= 3
+    pv, ids, labels = _sample(cfg, rank)
+    losses = []
+    for _ in range(2):
+        out = m.step(pv, ids, labels)
+        losses.append(float(out.loss))
+    sd = m.state_dict()
+    torch.save({'losses': losses, 'params': {k: sd[k].cpu() for k in KEYS}}, os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('clip', [0.0, 1.0])
+def test_world2_step_equals_gradient_averaging(tmp_path, clip):
+    import torch.multiprocessing as mp
+    port = 29600 + int(clip) + (os.getpid() % 50) * 2
+    mp.spawn(_worker, args=(2, port, clip, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'rank0.pt'), torch.load(tmp_path / 'rank1.pt')
+    for k in KEYS:
+        assert torch.equal(r0['params'][k], r1['params'][k]), k                 # every rank holds the same updated parameters
+    # single-process emulation: mean of the two samples' gradients, then the same optimizer step
+    torch.set_grad_enabled(False)
+    cfg, m = _model(clip)
+    samples = [_sample(cfg, r) for r in range(2)]
+    for step in range(2):
+        grads, losses = [], []
+        for pv, ids, labels in samples:
+            losses.append(float(m.forward_backward(pv, ids, labels)))
+            grads.append(m.fp.g.clone())
+        m.fp.g.copy_(((grads[0].float() + grads[1].float()) / 2).to(BF))
+        m.optimizer_step()
+        assert abs(losses[0] - r0['losses'][step]) < 1e-6 and abs(losses[1] - r1['losses'][step]) < 1e-6
+    ref = m.state_dict()
+    for k in KEYS:
+        a, b = r0['params'][k].float(), ref[k].float().cpu()
+        if clip == 0.0:
+            assert torch.equal(a, b), k
+        else:      # the clip factor comes from an fp32 norm summed in a different order (per-shard partials + all-reduce)
+            assert (a - b).abs().max().item() <= 3e-5, k               # lr = 1e-3: a few percent of one update at most
