@@ -117,6 +117,8 @@ class SFTModel:
         # activations are ~39 MB at S=560, 1.1 GB for 28 layers -- noise next to 288 GB, so they are kept by default and the
         # backward re-runs nothing.  recompute=True restores the per-layer recompute (same values either way).
         self.recompute = recompute
+        self.ag_events = {}                       # bucket -> event of its last parameter all-gather (data parallel only)
+        self.overlap_allgather = os.environ.get('VLASER_SFT_NO_AG_OVERLAP') != '1'
         self.step_count = 0
         self.img_context_token_id = cfg.img_context_token_id
         self.max_tiles = max_tiles
@@ -244,6 +246,12 @@ class SFTModel:
         self.aux_stream = torch.cuda.Stream(device=dev)        # weight transposes overlap the next step's forward
         self.wT_ready = None
 
+    def _wait_params(self, b):
+        """Block the compute stream until bucket b's parameters of the current step have been all-gathered."""
+        ev = self.ag_events.get(b)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
     def _refresh_transposes(self):
         """W^T copies used by the dgrad GEMMs (dX = dY @ W needs W with the contraction axis contiguous).  Issued on a side
         stream: only the backward needs them, so they overlap the next forward."""
@@ -251,6 +259,8 @@ class SFTModel:
         ev.record()
         with torch.cuda.stream(self.aux_stream):
             self.aux_stream.wait_event(ev)
+            if self.dp_active and self.ag_events.get(0) is not None:
+                self.aux_stream.wait_event(self.ag_events[0])          # bucket 0 is gathered last: all parameters are current
             self._refresh_transposes_now()
             self.wT_ready = torch.cuda.Event()
             self.wT_ready.record()
@@ -346,6 +356,7 @@ class SFTModel:
         vit_w = self.vit
         vit_w.m0w, vit_w.m0b = v['mlp1.m0w'], v['mlp1.m0b']       # the projector weights are the trainable views
         vit_w.m1w, vit_w.m1b, vit_w.m3w, vit_w.m3b = v['mlp1.m1w'], v['mlp1.m1b'], v['mlp1.m3w'], v['mlp1.m3b']
+        self._wait_params(len(self.buckets) - 1)                   # embed + projector bucket (the projector runs inside vit_w.forward)
         vit_w.forward(pv)                                          # leaves the last hidden state in vit_w.h
         nt = T * cfg.num_image_token
         C1 = cfg.vision.hidden_size
@@ -369,6 +380,7 @@ class SFTModel:
         ops.embed_merge(ids, v['embed'], feat_used, h0, self.img_context_token_id, cfg.pad_token_id, False, self.rank_ws)
         # ---- forward through the layers (saved activations per layer, or only the layer inputs when recompute=True)
         for i in range(Lyr):
+            self._wait_params(1 + (Lyr - 1 - i) // self.bucket_layers)     # layer buckets hold the layers in reverse order (bucket 1 = last layers)
             _, _, h2, _, _, _, act = self._layer_forward(i, self.h_in[i, :S], S, pos)
             self._layer_out(i, S, h2, act, self.h_in[i + 1, :S])
         h_fin = self.h_in[Lyr, :S]
@@ -379,6 +391,7 @@ class SFTModel:
         rows = (tgt != -100).nonzero().flatten()
         R = int(rows.numel())
         xn = self.xn[:S]
+        self._wait_params(0)                                         # lm_head + final norm
         ops.rmsnorm(h_fin, v['norm'], llm.rms_norm_eps, out=xn)
         if R == 0:
             self.fp.g.zero_()                                        # no supervised position: zero loss, zero gradients
@@ -517,9 +530,20 @@ class SFTModel:
                 n = s_hi - s_lo
                 ops.adamw(self.fp.p[s_lo:s_hi], self.master[o:o + n], self.m[o:o + n], self.v[o:o + n], self.fp.g[s_lo:s_hi], lr, self.betas[0],
                           self.betas[1], self.eps, self.wd, scale, self.step_count)
-        if self.dp_active:                                   # ZeRO-1: all-gather the updated bf16 parameters, bucket by bucket
-            for bkt, shd in zip(self.buckets, self.shards):
-                dp.all_gather_params(self.fp.p, bkt, shd, self.pg)
+        if self.dp_active:
+            # ZeRO-1: all-gather the updated bf16 parameters bucket by bucket on the comm stream, in the order the NEXT forward
+            # consumes them (embed + projector first, lm_head last); the forward waits per bucket (`_wait_params`), so the
+            # exchange overlaps the frozen ViT and the earlier layers instead of sitting between two steps
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                for b in reversed(range(len(self.buckets))):
+                    dp.all_gather_params(self.fp.p, self.buckets[b], self.shards[b], self.pg)
+                    self.ag_events[b] = torch.cuda.Event()
+                    self.ag_events[b].record()
+            if not self.overlap_allgather:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._refresh_transposes()
         return gnorm
 
@@ -541,6 +565,8 @@ class SFTModel:
 
     # ------------------------------------------------------------------ export (HF key names, un-packed layouts)
     def state_dict(self):
+        if self.dp_active:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)      # pending parameter all-gathers
         llm = self.llm
         v = self.fp.view
         nq, nkv, hd = llm.num_attention_heads, llm.num_key_value_heads, llm.head_dim
