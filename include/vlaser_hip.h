@@ -213,9 +213,10 @@ int vlaser_attn_bwd_ds(const void* P, const float* dP, const void* dO, const voi
  * kv_per_q_head != 0: dk / dv are [S, n_q*128] partials, one per Q head, summed here over the heads of each kv group */
 int vlaser_rope_bwd_pack(const void* dq, const void* dk, const void* dv, const float* rope_cos, const float* rope_sin, const int32_t* pos_ids,
                          void* out_packed, int S, int n_q, int n_kv, int kv_per_q_head, vl_stream_t stream);
-/* Qwen2RMSNorm backward: dx_out = dres + rmsnorm_bwd(dy, x, w); dw_rows (fp32 [S, C] scratch-free): column sums go to dw
- * through vlaser_colsum_mul.  x is the (bf16) norm input. */
-int vlaser_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* dres, void* dx_out, int S, int C, float eps, vl_stream_t stream);
+/* Qwen2RMSNorm backward: dx_out = dres + rmsnorm_bwd(dy, x, w).  dw_out (bf16 [C], nullable) = sum_s dy x rs, the weight
+ * gradient, accumulated in the same pass through dw_ws (fp32 [ceil(S/4)][C] scratch). */
+int vlaser_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* dres, void* dx_out, void* dw_out, float* dw_ws, int S, int C,
+                       float eps, vl_stream_t stream);
 /* out[c] = sum_s a[s,c] * f(b)[s,c]: mode 0: 1; 1: b; 2: rmsnorm-normalised b (b = norm input); 3: layernorm-normalised b */
 int vlaser_colsum_mul(const void* a, const void* b, float* out, int S, int C, int mode, float eps, float* ws /* float[2*S + 16*C] scratch */, vl_stream_t stream);
 /* SwiGLU on the packed [gate16|up16] layout: act[s, I] from gu[s, 2I]; backward: dgu from (gu, dact) */

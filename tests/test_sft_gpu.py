@@ -134,6 +134,12 @@ def test_backward_kernels_oplevel():
     ops.rmsnorm_bwd(dy, x, w, dres, dx, S, C, 1e-6)
     rel, cos = _rel(dx, xr.grad + dres.float())
     assert rel < 1e-2 and cos > 0.9999
+    # same call with the weight gradient fused into the pass
+    dx2 = torch.zeros_like(x); dw = torch.full((C,), 7.0, dtype=BF, device='cuda'); dw_ws = torch.zeros((S + 3) // 4 * C, device='cuda')
+    ops.rmsnorm_bwd(dy, x, w, dres, dx2, S, C, 1e-6, dw_out=dw, dw_ws=dw_ws)
+    assert torch.equal(dx2, dx)
+    rel, cos = _rel(dw, wr.grad)
+    assert rel < 1e-2 and cos > 0.9999
     col = torch.zeros(C, device='cuda'); ws = torch.zeros(2 * S + 16 * C, device='cuda')
     ops.colsum_mul(dy, x, col, S, C, 2, 1e-6, ws)
     rel, cos = _rel(col, wr.grad)

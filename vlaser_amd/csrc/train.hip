@@ -238,10 +238,14 @@ extern "C" int vlaser_rope_bwd_pack(const void* dq, const void* dk, const void* 
 // y = w * bf16(x rs), rs = rsqrt(mean(x^2) + eps).  dx = rs * (g - xhat * mean(g xhat)), g = w dy, xhat = x rs.
 // dx_out = dres + dx.  One wave per row.
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                          const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, int S, int C, float eps) {
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= S) return;
-  const size_t ro = (size_t)row * C;
+                                                          const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, float* __restrict__ dw_partial,
+                                                          int S, int C, float eps) {
+  // dw_partial (optional, fp32 [gridDim.x][C]): this block's share of the weight gradient dw[c] = sum_s dy[s,c] x[s,c] rs_s, so the
+  // norm-weight gradient needs no pass of its own over dy / x (finished by colsum_partials_kernel)
+  extern __shared__ float dw_lds[];            // [4][C] when dw_partial
+  const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6, row = blockIdx.x * 4 + wv_;
+  const bool live = row < S;
+  const size_t ro = (size_t)min(row, S - 1) * C;
   float ss = 0.f, dot = 0.f;
   for (int c = lane * 8; c < C; c += 512) {
     const u32x4 xv = ld_global_16(x + ro + c), gv = ld_global_16(dy + ro + c), wv = ld_global_16(w + c);
@@ -266,14 +270,40 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
       const float lo = bf16lo_to_f32(rv[j]) + rs * bf16lo_to_f32(gv[j]) * bf16lo_to_f32(wv[j]) - coef * bf16lo_to_f32(xv[j]);
       const float hi = bf16hi_to_f32(rv[j]) + rs * bf16hi_to_f32(gv[j]) * bf16hi_to_f32(wv[j]) - coef * bf16hi_to_f32(xv[j]);
       o[j] = pack_bf16x2(lo, hi);
+      if (dw_partial) {
+        dw_lds[wv_ * C + c + 2 * j] = live ? bf16lo_to_f32(gv[j]) * bf16lo_to_f32(xv[j]) * rs : 0.f;
+        dw_lds[wv_ * C + c + 2 * j + 1] = live ? bf16hi_to_f32(gv[j]) * bf16hi_to_f32(xv[j]) * rs : 0.f;
+      }
     }
-    st_global_16(dx + ro + c, o);
+    if (live) st_global_16(dx + ro + c, o);
+  }
+  if (dw_partial) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+      dw_partial[(size_t)blockIdx.x * C + c] = dw_lds[c] + dw_lds[C + c] + dw_lds[2 * C + c] + dw_lds[3 * C + c];
   }
 }
-extern "C" int vlaser_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* dres, void* dx, int S, int C, float eps, vl_stream_t s) {
+// out[c] (bf16) = sum_p partial[p][c], fixed order
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partial, int n_part, int C, bf16_t* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int pi = 0;
+  for (; pi + 4 <= n_part; pi += 4) {
+    a0 += partial[(size_t)pi * C + c]; a1 += partial[(size_t)(pi + 1) * C + c];
+    a2 += partial[(size_t)(pi + 2) * C + c]; a3 += partial[(size_t)(pi + 3) * C + c];
+  }
+  for (; pi < n_part; ++pi) a0 += partial[(size_t)pi * C + c];
+  out[c] = f32_to_bf16((a0 + a1) + (a2 + a3));
+}
+extern "C" int vlaser_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* dres, void* dx, void* dw_out, float* dw_ws, int S, int C,
+                                  float eps, vl_stream_t s) {
   VL_CHECK(dy && x && w && dx && S > 0 && C % 8 == 0, "vlaser_rmsnorm_bwd: bad args");
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((S + 3) / 4), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w,
-                     (const bf16_t*)dres, (bf16_t*)dx, S, C, eps);
+  VL_CHECK(!dw_out || (dw_ws && C * 16 <= 64 * 1024), "vlaser_rmsnorm_bwd: weight gradient needs the [ceil(S/4)][C] fp32 workspace and C <= 4096");
+  const int nb = (S + 3) / 4;
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nb), dim3(256), dw_out ? (size_t)C * 16 : 0, (hipStream_t)s, (const bf16_t*)dy, (const bf16_t*)x,
+                     (const bf16_t*)w, (const bf16_t*)dres, (bf16_t*)dx, dw_out ? dw_ws : nullptr, S, C, eps);
+  if (dw_out) hipLaunchKernelGGL(colsum_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)s, dw_ws, nb, C, (bf16_t*)dw_out);
   VL_LAUNCH_CHECK();
   return 0;
 }

@@ -235,6 +235,7 @@ class SFTModel:
         self.col = torch.zeros(max(2 * I, NQ, C4, H), dtype=F32, device=dev)
         self.rowstat = torch.zeros(2 * max(S, self.max_tiles * cfg.num_image_token) + 16 * max(2 * I, NQ, C4, H), dtype=F32, device=dev)   # colsum scratch
         self.sumsq_ws = torch.zeros(1024, dtype=F32, device=dev)
+        self.normw_ws = torch.zeros((S + 3) // 4 * H, dtype=F32, device=dev)      # norm-weight gradient partials of rmsnorm_bwd
         self.gnorm2 = torch.zeros(1, dtype=F32, device=dev)
         self.rank_ws = torch.zeros(S, dtype=torch.int32, device=dev)
         # mlp1
@@ -415,8 +416,7 @@ class SFTModel:
         dxn.zero_()
         dxn.index_copy_(0, rows, dx_rows)
         dh = self.dh[:S]
-        ops.rmsnorm_bwd(dxn, h_fin, v['norm'], None, dh, S, H, llm.rms_norm_eps)
-        self._norm_wgrad(dxn, h_fin, gv['norm'], S, H, 2, llm.rms_norm_eps)
+        ops.rmsnorm_bwd(dxn, h_fin, v['norm'], None, dh, S, H, llm.rms_norm_eps, dw_out=gv['norm'], dw_ws=self.normw_ws)
         if on_bucket_ready:
             on_bucket_ready(0)
         G = nq // nkv
@@ -445,8 +445,7 @@ class SFTModel:
             ops.swiglu_bwd(gu, dact, dgu, S, I)
             self._dgrad(dgu, wT['wgu'], dx, S)
             self._wgrad(dgu, x2, gv[f'l{i}.wgu'], S)
-            ops.rmsnorm_bwd(dx, h2, v[f'l{i}.ln_post'], dh, dh2, S, H, llm.rms_norm_eps)
-            self._norm_wgrad(dx, h2, gv[f'l{i}.ln_post'], S, H, 2, llm.rms_norm_eps)
+            ops.rmsnorm_bwd(dx, h2, v[f'l{i}.ln_post'], dh, dh2, S, H, llm.rms_norm_eps, dw_out=gv[f'l{i}.ln_post'], dw_ws=self.normw_ws)
             # attention block: h2 = h_in + ao Wo^T
             self._dgrad(dh2, wT['wo'], dao, S)
             self._wgrad(dh2, ao, gv[f'l{i}.wo'], S)
@@ -467,8 +466,7 @@ class SFTModel:
             ops.rope_bwd_pack(self.dq[:S], self.dk[:S], self.dv[:S], self.rope[0], self.rope[1], pos, dqkv, S, nq, nkv, kv_per_q_head=True)
             self._dgrad(dqkv, wT['wqkv'], dx, S)
             self._wgrad(dqkv, x1, gv[f'l{i}.wqkv'], S, bias_out=gv[f'l{i}.bqkv'])
-            ops.rmsnorm_bwd(dx, h_in, v[f'l{i}.ln_in'], dh2, dh, S, H, llm.rms_norm_eps)
-            self._norm_wgrad(dx, h_in, gv[f'l{i}.ln_in'], S, H, 2, llm.rms_norm_eps)
+            ops.rmsnorm_bwd(dx, h_in, v[f'l{i}.ln_in'], dh2, dh, S, H, llm.rms_norm_eps, dw_out=gv[f'l{i}.ln_in'], dw_ws=self.normw_ws)
             if on_bucket_ready and (i == 0 or bucket_of_layer[i - 1] != bucket_of_layer[i]):
                 on_bucket_ready(bucket_of_layer[i])
         # ---- embeddings (text rows) and projector (image rows)
