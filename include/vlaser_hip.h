@@ -218,6 +218,8 @@ int vlaser_rope_bwd_pack(const void* dq, const void* dk, const void* dv, const f
 int vlaser_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* dres, void* dx_out, void* dw_out, float* dw_ws, int S, int C,
                        float eps, vl_stream_t stream);
 /* out[c] = sum_s a[s,c] * f(b)[s,c]: mode 0: 1; 1: b; 2: rmsnorm-normalised b (b = norm input); 3: layernorm-normalised b */
+/* bias gradient of an nn.Linear: out[c] (bf16) = sum_s a[s, c], one launch */
+int vlaser_colsum_bf16(const void* a, void* out, int S, int C, int lda, vl_stream_t stream);
 int vlaser_colsum_mul(const void* a, const void* b, float* out, int S, int C, int mode, float eps, float* ws /* float[2*S + 16*C] scratch */, vl_stream_t stream);
 /* SwiGLU on the packed [gate16|up16] layout: act[s, I] from gu[s, 2I]; backward: dgu from (gu, dact) */
 int vlaser_swiglu(const void* gu, void* act, int S, int I, vl_stream_t stream);

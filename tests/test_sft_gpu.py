@@ -134,6 +134,9 @@ def test_backward_kernels_oplevel():
     ops.rmsnorm_bwd(dy, x, w, dres, dx, S, C, 1e-6)
     rel, cos = _rel(dx, xr.grad + dres.float())
     assert rel < 1e-2 and cos > 0.9999
+    bsum = torch.full((C,), 7.0, dtype=BF, device='cuda')
+    ops.colsum_bf16(dy, bsum, S, C)                                  # bias gradient of a Linear: column sum in one launch
+    assert _rel(bsum, dy.float().sum(0))[0] < 5e-3
     # same call with the weight gradient fused into the pass
     dx2 = torch.zeros_like(x); dw = torch.full((C,), 7.0, dtype=BF, device='cuda'); dw_ws = torch.zeros((S + 3) // 4 * C, device='cuda')
     ops.rmsnorm_bwd(dy, x, w, dres, dx2, S, C, 1e-6, dw_out=dw, dw_ws=dw_ws)

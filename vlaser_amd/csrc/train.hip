@@ -374,6 +374,36 @@ extern "C" int vlaser_colsum_mul(const void* a, const void* b, float* out, int S
   return 0;
 }
 
+// bias gradient: out[c] (bf16) = sum_s a[s,c] in ONE launch (64 columns x 4 row lanes per block, fixed order): the matrices here
+// are a few hundred rows, where the two-stage column sum's extra launches cost more than its parallelism buys
+__global__ __launch_bounds__(1024) void colsum_bf16_kernel(const bf16_t* __restrict__ a, bf16_t* __restrict__ out, int S, int C, int lda) {
+  __shared__ float red[16][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane_r = threadIdx.x >> 6;      // 16 row lanes x 64 columns
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < C) {
+    int s = lane_r;
+    for (; s + 48 < S; s += 64) {
+      a0 += bf16_to_f32(a[(size_t)s * lda + c]); a1 += bf16_to_f32(a[(size_t)(s + 16) * lda + c]);
+      a2 += bf16_to_f32(a[(size_t)(s + 32) * lda + c]); a3 += bf16_to_f32(a[(size_t)(s + 48) * lda + c]);
+    }
+    for (; s < S; s += 16) a0 += bf16_to_f32(a[(size_t)s * lda + c]);
+  }
+  red[lane_r][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (lane_r == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
+    out[c] = f32_to_bf16(t);
+  }
+}
+extern "C" int vlaser_colsum_bf16(const void* a, void* out, int S, int C, int lda, vl_stream_t s) {
+  VL_CHECK(a && out && S > 0 && C > 0 && lda >= C, "vlaser_colsum_bf16: bad args");
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)s, (const bf16_t*)a, (bf16_t*)out, S, C, lda);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- SwiGLU fwd / bwd
 // packed layout: columns [32j, 32j+16) = gate channels 16j.., [32j+16, 32j+32) = up channels 16j..
 __global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act, long long n, int I) {

@@ -377,6 +377,10 @@ def rmsnorm_bwd(dy, x, w, dres, dx, S, Cc, eps, dw_out=None, dw_ws=None):
                                        _stream()), 'vlaser_rmsnorm_bwd')
 
 
+def colsum_bf16(a, out, S, Cc):
+    L.check(L.lib().vlaser_colsum_bf16(a.data_ptr(), out.data_ptr(), S, Cc, a.stride(0), _stream()), 'vlaser_colsum_bf16')
+
+
 def colsum_mul(a, b, out, S, Cc, mode=0, eps=1e-6, ws=None):
     L.check(L.lib().vlaser_colsum_mul(a.data_ptr(), _p(b), out.data_ptr(), S, Cc, mode, eps, _p(ws), _stream()), 'vlaser_colsum_mul')
 

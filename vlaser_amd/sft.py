@@ -282,9 +282,7 @@ class SFTModel:
         rows, transposing LDS reads) -- no transposed activation copies."""
         ops.gemm_tn(dY[:S], X[:S], out)
         if bias_out is not None:
-            N = dY.shape[1]
-            ops.colsum_mul(dY, None, self.col, S, N, 0, ws=self.rowstat)
-            bias_out.copy_(self.col[:N])
+            ops.colsum_bf16(dY, bias_out, S, dY.shape[1])
 
     def _dgrad(self, dY, WT, out, S):
         """out[S,K] = dY[S,N] @ W[N,K] with W^T [K,N] resident; long contractions over few output tiles run split-K."""
