@@ -287,13 +287,15 @@ class SFTModel:
     def _dgrad(self, dY, WT, out, S):
         """out[S,K] = dY[S,N] @ W[N,K] with W^T [K,N] resident; long contractions over few output tiles run split-K."""
         Kout, Nin = WT.shape
-        sp = ops.gemm_splits(S, Kout, Nin)
+        # measured at S = 560, 1536 outputs (tools/micro/split_lab.py): contraction <= 2048 -> one pass on 32-row tiles (11-13 us) beats
+        # split-K slabs + their reduction (19-20 us); longer contractions (8960 / 17920) keep split-K (36 / 65 vs 42 / 100 us)
+        sp = 1 if Nin <= 2048 else ops.gemm_splits(S, Kout, Nin)
         if sp > 1:
             part = self.part[:sp * S * Kout]
             ops.gemm(L.EPI_PARTIAL, dY, WT, out_f32=part, k_splits=sp)
             ops.reduce_norm(None, part, sp, S, Kout, out)
         else:
-            ops.gemm(L.EPI_NONE, dY, WT, out=out)
+            ops.gemm(L.EPI_NONE, dY, WT, out=out, force_bm=32 if Nin <= 2048 and Kout <= 2048 else 0)
 
     def _norm_wgrad(self, dy, x, out, S, Cc, mode=2, eps=1e-6):
         ops.colsum_mul(dy, x, self.col, S, Cc, mode, eps, self.rowstat)
