@@ -17,6 +17,6 @@ for K in (1536, 2048, 8960, 17920):
     for S in (2, 3, 4, 5, 7, 8):
         if K % (S * 64): continue
         part = torch.zeros(S, M, N, device='cuda')
-        us = timeit([lambda w=w: (ops.gemm(L.EPI_PARTIAL, x, w, out_f32=part, k_splits=S), ops.reduce_norm(None, part, S, M, N, out)) for w in ws]) * 2
+        us = timeit([lambda w=w: (ops.gemm(L.EPI_PARTIAL, x, w, out_f32=part, k_splits=S), ops.reduce_norm(None, part, S, M, N, out)) for w in ws])   # per pair of launches
         res.append(f'S{S} {us:.1f}')
     print(f'M={M} N={N} K={K}: default splits {ops.gemm_splits(M, N, K)} |', '  '.join(res))
