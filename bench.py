@@ -142,7 +142,7 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='both', choices=['vla_chunk', 'sft', 'both'])
-    ap.add_argument('--sft-steps', type=int, default=6)
+    ap.add_argument('--sft-steps', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     a = ap.parse_args()
