@@ -7,7 +7,6 @@ joint_model.py:166,209,219,449-452,573-578,631-669,694).  Restated from the publ
   attention : repeat_kv; softmax(q k^T * d^-1/2 + mask) in fp32, cast to dtype; @ v
   MLP       : down(silu(gate(x)) * up(x))
 """
-import math
 
 import torch
 import torch.nn.functional as F

@@ -14,7 +14,7 @@ from types import SimpleNamespace
 
 from . import _lib as L
 from . import ops
-from .config import LLMConfig, VisionConfig, VlaserConfig, VLAConfig
+from .config import LLMConfig, VlaserConfig
 
 BF = torch.bfloat16
 

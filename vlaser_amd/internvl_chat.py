@@ -14,7 +14,6 @@ Attributes read by callers: num_image_token, template, system_message, img_conte
 There is no CPU path: constructing the model without the HIP library / a GPU raises.
 """
 from types import SimpleNamespace
-from typing import List, Optional
 
 import torch
 

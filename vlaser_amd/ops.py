@@ -2,7 +2,6 @@
 memory and the stream; every op below is a launch of a hand-written gfx950 kernel in libvlaser_hip.so."""
 import ctypes as C
 
-import os
 
 import torch
 

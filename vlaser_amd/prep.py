@@ -2,9 +2,8 @@
 <IMG_CONTEXT> expansion, dynamic tiling grid, ImageNet normalisation, VLA prompt / masks / position ids, WidowX
 proprio / action (de)normalisation.  Pure Python / torch-CPU integer and string logic, pinned bit-exactly by the
 golden fixtures in tests/golden (generated from the reference by tools/gen_golden.py)."""
-import math
 from dataclasses import dataclass, field
-from typing import List, Optional
+from typing import List
 
 import torch
 
