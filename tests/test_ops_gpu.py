@@ -245,6 +245,18 @@ def test_skinny_partial(ops, M, N, K, ks):
     close(part[ks - 1], x[:, -kb:].float() @ w[:, -kb:].float().t(), rtol=2e-3, atol=2e-3, name='last slab')
 
 
+@pytest.mark.parametrize('M,N,K,ks', [(4, 768, 8960, 5), (2, 1536, 8960, 7), (5, 784, 8960, 5)])
+def test_skinny_partial_16_row_units(ops, M, N, K, ks):
+    """tiles_per_unit = 1: 16-row units (twice the workgroups for the narrow down_proj), incl. an N that is no multiple of 32."""
+    from vlaser_amd import _lib as L
+    x, w = rnd(M, K), rnd(N, K, std=0.03)
+    part = torch.full((ks, M, N), 7.0, dtype=torch.float32, device='cuda')
+    pw = ops.pack_skinny(w, ks, 1)
+    assert pw.tpu == 1 and pw.N == (N + 15) // 16 * 16
+    ops.skinny(L.PRO_PLAIN, L.SK_PARTIAL, x, pw, M, out_f32=part)
+    close(part.sum(0), x.float() @ w.float().t(), rtol=2e-3, atol=2e-3, name='partial sum (16-row units)')
+
+
 def test_skinny_bias_silu_f32(ops):
     from vlaser_amd import _lib as L
     M, N, K = 4, 768, 1536

@@ -86,4 +86,6 @@ def test_world2_step_equals_gradient_averaging(tmp_path, clip):
         if clip == 0.0:
             assert torch.equal(a, b), k
         else:      # the clip factor comes from an fp32 norm summed in a different order (per-shard partials + all-reduce)
-            assert (a - b).abs().max().item() <= 3e-5, k               # lr = 1e-3: a few percent of one update at most
+            diff = (a - b).abs()
+            assert (diff <= b.abs() * 2.0 ** -7 + 1e-6).all(), k             # at most one bf16 ulp ...
+            assert (diff > 0).float().mean().item() < 1e-3, k                 # ... on a handful of elements

@@ -421,9 +421,14 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
         for (int t = 0; t < TPU; ++t) acc[t] += *reinterpret_cast<const f32x4*>(r + t * 64 * 4);
       }
       if (m < a.M) {
+        if constexpr (TPU == 1) {          // 16-row units (split-K partial only): one tile, columns (ustart+ui)*16 + g*4
+          const int n0 = (ustart + ui) * 16 + g * 4;
+          if (n0 + 3 < a.n_valid) *reinterpret_cast<f32x4*>(a.out_f32 + ((size_t)ks * a.M + m) * a.n_valid + n0) = acc[0];
+        } else {
 #pragma unroll
-        for (int pr = 0; pr < TPU / 2; ++pr)
-          skinny_epilogue<EPI>(a, ks, (ustart + ui) * (TPU / 2) + pr, m, g, acc[2 * pr], acc[2 * pr + 1], e[NEED_EPI ? pr : 0]);
+          for (int pr = 0; pr < TPU / 2; ++pr)
+            skinny_epilogue<EPI>(a, ks, (ustart + ui) * (TPU / 2) + pr, m, g, acc[2 * pr], acc[2 * pr + 1], e[NEED_EPI ? pr : 0]);
+        }
       }
     }
   };
@@ -515,6 +520,17 @@ static int launch_ns(const VlaserSkinnyArgs* a, hipStream_t stream) {
 template <int PRO, int EPI>
 static int launch(const VlaserSkinnyArgs* a, hipStream_t stream) {
   const int ns = a->K / a->k_splits / (32 * SKW);
+  if (a->tiles_per_unit == 1) {          // 16-row units: twice the workgroups of a narrow split-K GEMV (down_proj: 48 units x 5 splits)
+    if constexpr (PRO == VL_PRO_PLAIN && EPI == VL_SK_PARTIAL) {
+      switch (ns) {
+        case 5: return launch_ns<PRO, EPI, 1, 5>(a, stream);
+        case 7: return launch_ns<PRO, EPI, 1, 7>(a, stream);
+        default: break;
+      }
+    }
+    vlaser_set_error("vlaser_skinny: tiles_per_unit = 1 is only built for PLAIN + PARTIAL with 5 or 7 K-steps per wave");
+    return -1;
+  }
   if (a->tiles_per_unit == 6) {
     if constexpr (PRO == VL_PRO_NORM && EPI == VL_SK_SWIGLU) {
       if (ns == 3) return launch_ns<PRO, EPI, 6, 3>(a, stream);
@@ -547,10 +563,10 @@ extern "C" int vlaser_skinny(int pro, int epi, const VlaserSkinnyArgs* a, vl_str
   VL_CHECK(a->M >= 1 && a->M <= 16, "vlaser_skinny: M=%d must be in 1..16", a->M);
   VL_CHECK(a->k_splits >= 1 && a->K % (a->k_splits * 32 * SKW) == 0, "vlaser_skinny: K=%d not divisible by k_splits*%d (k_splits=%d)", a->K,
            32 * SKW, a->k_splits);
-  VL_CHECK(a->tiles_per_unit == 0 || a->tiles_per_unit == 2 || a->tiles_per_unit == 6, "vlaser_skinny: tiles_per_unit must be 2 or 6");
-  VL_CHECK(a->N % (a->tiles_per_unit == 6 ? 96 : 32) == 0,
+  VL_CHECK(a->tiles_per_unit == 0 || a->tiles_per_unit == 1 || a->tiles_per_unit == 2 || a->tiles_per_unit == 6, "vlaser_skinny: tiles_per_unit must be 1, 2 or 6");
+  VL_CHECK(a->N % (a->tiles_per_unit == 6 ? 96 : (a->tiles_per_unit == 1 ? 16 : 32)) == 0,
            "vlaser_skinny: N=%d must be a multiple of the unit height (pack_skinny pads the weight rows; pass n_valid)", a->N);
-  VL_CHECK(a->n_valid <= a->N && (a->n_valid <= 0 || a->n_valid > a->N - (a->tiles_per_unit == 6 ? 96 : 32)),
+  VL_CHECK(a->n_valid <= a->N && (a->n_valid <= 0 || a->n_valid > a->N - (a->tiles_per_unit == 6 ? 96 : (a->tiles_per_unit == 1 ? 16 : 32))),
            "vlaser_skinny: n_valid must lie in the last unit");
   VL_CHECK(((uintptr_t)a->W & 15) == 0 && ((uintptr_t)a->x & 15) == 0, "vlaser_skinny: alignment");
   VL_CHECK((size_t)a->M * (a->K / a->k_splits * 2 + 16) <= 120000, "vlaser_skinny: activation tile does not fit in LDS");

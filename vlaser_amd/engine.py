@@ -9,6 +9,7 @@ Weights are stored in HBM in the layouts the kernels want (packed once at load):
   * patch-embedding conv flattened to [1024, 640] (K zero-padded from 588 to a multiple of 64),
   * K cache [L][B,n_kv,S_max,128], V cache TRANSPOSED [L][B,n_kv,128,S_max] (MFMA A-fragment = one 16-byte load).
 """
+
 import torch
 from types import SimpleNamespace
 
@@ -27,7 +28,7 @@ class QwenLayerWeights:
     """One Qwen2DecoderLayer in kernel layout: row-major packed matrices for the MFMA GEMM (prefill) and/or
     fragment-major copies for the weight-streaming skinny kernel (decode / action tokens)."""
 
-    def __init__(self, sd, p, llm: LLMConfig, device, ks_o, ks_down, gemm=True, skinny=True):
+    def __init__(self, sd, p, llm: LLMConfig, device, ks_o, ks_down, gemm=True, skinny=True, tpu_down=2):
         g = lambda k: _dev(sd[p + k], device)
         wqkv, self.bqkv = ops.pack_qkv(g('self_attn.q_proj.weight'), g('self_attn.k_proj.weight'),
                                        g('self_attn.v_proj.weight'), g('self_attn.q_proj.bias'),
@@ -45,7 +46,7 @@ class QwenLayerWeights:
             # wide output + short K (action expert: 17920 x 768): 96-row units -> one unit per block, single load batch
             tpu = 2      # 96-row units (tpu = 6) measured slower on MI355X (12.3 vs 11.2 us): kept in the kernel, not used
             self.sk_gu = ops.pack_skinny(wgu, 1, tpu)
-            self.sk_down = ops.pack_skinny(wdown, ks_down)
+            self.sk_down = ops.pack_skinny(wdown, ks_down, tpu_down)
 
 
 class QwenStack:
@@ -56,9 +57,13 @@ class QwenStack:
         H, I = llm.hidden_size, llm.intermediate_size
         nqd = llm.num_attention_heads * llm.head_dim
         self.ks_o = ops.pick_k_splits(nqd, H)
-        self.ks_down = ops.pick_k_splits(I, H)
+        # down_proj (narrow output, long K): 16-row units double the workgroups that stream it (48 units x 5 splits = 240 for the expert)
+        # when the kernel has that variant (5 or 7 K-steps per wave); measured +0.9 % chunks/s over 32-row units x 7 splits
+        ks16 = ops.pick_k_splits(I, H, rows_per_unit=16)
+        self.tpu_down = 1 if I % (ks16 * 256) == 0 and I // (ks16 * 256) in (5, 7) else 2
+        self.ks_down = ks16 if self.tpu_down == 1 else ops.pick_k_splits(I, H)
         self.nqd = nqd
-        self.layers = [QwenLayerWeights(sd, f'{prefix}model.layers.{i}.', llm, device, self.ks_o, self.ks_down, gemm, skinny)
+        self.layers = [QwenLayerWeights(sd, f'{prefix}model.layers.{i}.', llm, device, self.ks_o, self.ks_down, gemm, skinny, self.tpu_down)
                        for i in range(llm.num_hidden_layers)]
         self.norm = _dev(sd[prefix + 'model.norm.weight'], device)
         self.embed = _dev(sd[prefix + 'model.embed_tokens.weight'], device) if with_embed else None

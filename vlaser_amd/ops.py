@@ -209,12 +209,12 @@ def skinny(pro, epi, x, W: PackedW, M, **kw):
 SK_TARGET_BLOCKS = 130
 
 
-def pick_k_splits(K, N, target_blocks=None):
+def pick_k_splits(K, N, target_blocks=None, rows_per_unit=32):
     """Smallest cross-block split-K factor that (a) keeps K/k_splits a multiple of 256 (8 waves x 32) and (b) gives
     about one block per CU (units = N/32)."""
     if target_blocks is None:
         target_blocks = SK_TARGET_BLOCKS
-    units = (N + 31) // 32
+    units = (N + rows_per_unit - 1) // rows_per_unit
     best = 1
     for s in range(1, 9):            # <= 8 slabs: the consumer's prologue sums them in ONE batch of loads
         if K % (s * 256):
