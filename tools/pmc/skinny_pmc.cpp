@@ -15,7 +15,7 @@ static unsigned short bf16(float f) { unsigned u; memcpy(&u, &f, 4); return (uns
 
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 4;
-  const int M = 4, K = 768, N = 17920, NL = 28, NP = 6;
+  const int M = 4, K = 768, N = 17920, NL = 28, NP = 3;
   const size_t wbytes = (size_t)N * K * 2;
   std::vector<unsigned short> hw((size_t)N * K);
   unsigned s = 12345u;

@@ -490,7 +490,7 @@ static int launch_ns(const VlaserSkinnyArgs* a, hipStream_t stream) {
   p.urem = n_units % gx;
   p.attn_nkv = PRO == VL_PRO_ATTN ? a->K / (128 * a->attn_group) : 0;
   // exact slab-count variants for the hidden sizes / split factors this path produces (engine.py: ks_o, ks_down)
-  if constexpr (PRO == VL_PRO_ATTN && TPU == 2 && (NS == 2 || NS == 3)) {   // exact attention-split count (o_proj of the expert / LLM)
+  if constexpr (PRO == VL_PRO_ATTN && (TPU == 2 || TPU == 1) && (NS == 2 || NS == 3)) {   // exact attention-split count (o_proj of the expert / LLM)
     switch (a->attn_splits) {
       case 1: return launch_sp<PRO, EPI, TPU, NS, 1>(a, stream, p, gx, lds);
       case 2: return launch_sp<PRO, EPI, TPU, NS, 2>(a, stream, p, gx, lds);
@@ -528,7 +528,14 @@ static int launch(const VlaserSkinnyArgs* a, hipStream_t stream) {
         default: break;
       }
     }
-    vlaser_set_error("vlaser_skinny: tiles_per_unit = 1 is only built for PLAIN + PARTIAL with 5 or 7 K-steps per wave");
+    if constexpr (PRO == VL_PRO_ATTN && EPI == VL_SK_PARTIAL) {
+      switch (ns) {
+        case 2: return launch_ns<PRO, EPI, 1, 2>(a, stream);
+        case 3: return launch_ns<PRO, EPI, 1, 3>(a, stream);
+        default: break;
+      }
+    }
+    vlaser_set_error("vlaser_skinny: tiles_per_unit = 1 is built for PLAIN + PARTIAL (5 / 7 K-steps per wave) and ATTN + PARTIAL (2 / 3)");
     return -1;
   }
   if (a->tiles_per_unit == 6) {

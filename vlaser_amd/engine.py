@@ -28,7 +28,7 @@ class QwenLayerWeights:
     """One Qwen2DecoderLayer in kernel layout: row-major packed matrices for the MFMA GEMM (prefill) and/or
     fragment-major copies for the weight-streaming skinny kernel (decode / action tokens)."""
 
-    def __init__(self, sd, p, llm: LLMConfig, device, ks_o, ks_down, gemm=True, skinny=True, tpu_down=2):
+    def __init__(self, sd, p, llm: LLMConfig, device, ks_o, ks_down, gemm=True, skinny=True, tpu_down=2, tpu_o=2):
         g = lambda k: _dev(sd[p + k], device)
         wqkv, self.bqkv = ops.pack_qkv(g('self_attn.q_proj.weight'), g('self_attn.k_proj.weight'),
                                        g('self_attn.v_proj.weight'), g('self_attn.q_proj.bias'),
@@ -42,7 +42,7 @@ class QwenLayerWeights:
             self.wqkv, self.wo, self.wgu, self.wdown = wqkv, wo, wgu, wdown
         if skinny:
             self.sk_qkv = ops.pack_skinny(wqkv, 1)
-            self.sk_o = ops.pack_skinny(wo, ks_o)
+            self.sk_o = ops.pack_skinny(wo, ks_o, tpu_o)
             # wide output + short K (action expert: 17920 x 768): 96-row units -> one unit per block, single load batch
             tpu = 2      # 96-row units (tpu = 6) measured slower on MI355X (12.3 vs 11.2 us): kept in the kernel, not used
             self.sk_gu = ops.pack_skinny(wgu, 1, tpu)
@@ -56,14 +56,18 @@ class QwenStack:
         self.llm = llm
         H, I = llm.hidden_size, llm.intermediate_size
         nqd = llm.num_attention_heads * llm.head_dim
-        self.ks_o = ops.pick_k_splits(nqd, H)
+        # o_proj on 16-row units where the kernel has the variant: the same ~144 workgroups with half the split-K slabs for the
+        # gate/up prologue to sum (chunk time unchanged, the dominant gate/up GEMV 8.9 -> 8.6 us; same-box A/B)
+        ks16o = ops.pick_k_splits(nqd, H, rows_per_unit=16)
+        self.tpu_o = 1 if (nqd % (ks16o * 256) == 0 and nqd // (ks16o * 256) in (2, 3)) else 2
+        self.ks_o = ks16o if self.tpu_o == 1 else ops.pick_k_splits(nqd, H)
         # down_proj (narrow output, long K): 16-row units double the workgroups that stream it (48 units x 5 splits = 240 for the expert)
         # when the kernel has that variant (5 or 7 K-steps per wave); measured +0.9 % chunks/s over 32-row units x 7 splits
         ks16 = ops.pick_k_splits(I, H, rows_per_unit=16)
         self.tpu_down = 1 if I % (ks16 * 256) == 0 and I // (ks16 * 256) in (5, 7) else 2
         self.ks_down = ks16 if self.tpu_down == 1 else ops.pick_k_splits(I, H)
         self.nqd = nqd
-        self.layers = [QwenLayerWeights(sd, f'{prefix}model.layers.{i}.', llm, device, self.ks_o, self.ks_down, gemm, skinny, self.tpu_down)
+        self.layers = [QwenLayerWeights(sd, f'{prefix}model.layers.{i}.', llm, device, self.ks_o, self.ks_down, gemm, skinny, self.tpu_down, self.tpu_o)
                        for i in range(llm.num_hidden_layers)]
         self.norm = _dev(sd[prefix + 'model.norm.weight'], device)
         self.embed = _dev(sd[prefix + 'model.embed_tokens.weight'], device) if with_embed else None
