@@ -127,7 +127,7 @@ typedef struct {
   const void* W;          /* bf16, FRAGMENT-MAJOR packed [k_splits][N/(16 T)][8 waves][K/(k_splits*256)][T tiles][64][8], T = tiles_per_unit (ops.pack_skinny) */
   int M, N, K, ldw;       /* N = padded row count (multiple of 32); ldw unused */
   int n_valid;            /* un-padded N (0 = N): logits / partial row length */
-  int tiles_per_unit;     /* 0/2: units of 32 rows; 6: units of 96 rows (packing must match) */
+  int tiles_per_unit;     /* 0/2: units of 32 rows; 6: units of 96 rows; 1: units of 16 rows (split-K partial outputs only); packing must match */
   int k_splits;           /* grid.y; K % (k_splits*256) == 0 */
   float* out_f32;
   void* out; int ldo;
