@@ -100,6 +100,27 @@ def test_ragged_batch_generate(golden_dir, golden_model):
     np.testing.assert_allclose(lg.topk(4, dim=-1).values.numpy(), d['greedy_top_vals'], rtol=1e-4, atol=2e-5)
 
 
+def test_sft_gradients_vs_reference_autograd(golden_dir, golden_model, g56):
+    """The oracle's loss differentiated by torch autograd against the gradients of the REFERENCE model itself (G8): pins the
+    checker that the HIP backward is compared with."""
+    cfg, _, sd = golden_model
+    d = np.load(os.path.join(golden_dir, 'g8_sft_grads.npz'))
+    pv, ids = _inputs(0, g56)
+    labels = torch.full_like(ids, -100)
+    labels[0, -16:] = ids[0, -16:]
+    names = [str(n) for n in d['names']]
+    with torch.enable_grad():
+        sdg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items() if k.startswith(('vision_model.', 'mlp1.', 'language_model.'))}
+        loss = ovlm.sft_loss(ovlm.forward_logits(sdg, cfg, pv, ids), labels)
+        loss.backward()
+    np.testing.assert_allclose(loss.item(), float(d['loss']), rtol=1e-5)
+    assert len(names) == 33
+    for n in names:
+        g = sdg[n].grad.double().flatten()
+        np.testing.assert_allclose(g.norm().item(), float(d[f'norm::{n}']), rtol=2e-4, err_msg=n)
+        np.testing.assert_allclose(g[torch.from_numpy(d[f'idx::{n}'])].numpy(), d[f'val::{n}'], rtol=2e-3, atol=1e-6 * float(d[f'norm::{n}']) + 1e-9, err_msg=n)
+
+
 def test_infer_action(golden_dir, golden_model):
     _, vla, sd = golden_model
     d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))

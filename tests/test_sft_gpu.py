@@ -73,6 +73,25 @@ def test_loss_and_grads_vs_oracle_autograd(setup):
     print('worst relative gradient error', worst)
 
 
+def test_grads_vs_reference_golden(setup, golden_dir):
+    """HIP backward against the gradients of the reference model itself (tests/golden/g8_sft_grads.npz, reference forward + torch
+    autograd in fp32): per-tensor norm within 3 %, sampled entries within 4e-2 of the tensor's scale."""
+    cfg, sd, m, pv, ids, labels, _ = setup
+    d = np.load(os.path.join(golden_dir, 'g8_sft_grads.npz'))
+    loss = m.forward_backward(pv, ids, labels)
+    assert abs(loss.item() - float(d['loss'])) < 5e-3
+    grads = m.named_grads()
+    names = [str(n) for n in d['names']]
+    assert set(names) == set(grads)
+    for n in names:
+        g = grads[n].double().flatten().cpu()
+        ref_norm = float(d[f'norm::{n}'])
+        assert abs(g.norm().item() - ref_norm) <= 3e-2 * ref_norm, (n, g.norm().item(), ref_norm)
+        idx, val = torch.from_numpy(d[f'idx::{n}']), torch.from_numpy(d[f'val::{n}'])
+        scale = max(val.abs().max().item(), ref_norm / g.numel() ** 0.5)
+        assert (g[idx] - val).abs().max().item() <= 4e-2 * scale + 1e-12, n
+
+
 def test_recompute_mode_gives_identical_grads(setup):
     """Per-layer recompute (the reference's grad_checkpoint) and the default keep-activations backward run the same
     kernels on the same values: gradients agree bit for bit."""

@@ -358,7 +358,42 @@ def g7_vla(vla, sd, ref_vlm):
     return fake
 
 
+def g8_sft_grads(cfg, ref_vlm):
+    """SFT step gradients from the REFERENCE's own forward + torch autograd (modeling_internvl_chat.py:143-255 with labels): the
+    same sample as G5's sft_loss (seed 0, labels on the last 16 positions), vision tower frozen (freeze_backbone), every LLM /
+    projector gradient summarised by its norm and a few sampled entries."""
+    ref_vlm.img_context_token_id = 151667
+    pv, ids = make_inputs(cfg, seed=0, n_tiles=1, n_text=32)
+    labels = torch.full_like(ids, -100); labels[0, -16:] = ids[0, -16:]
+    for n, p_ in ref_vlm.named_parameters():
+        p_.requires_grad_(not n.startswith('vision_model.'))
+    with torch.enable_grad():
+        out = ref_vlm(pixel_values=pv, input_ids=ids, attention_mask=torch.ones_like(ids), image_flags=torch.ones(1, 1, dtype=torch.long),
+                      labels=labels, return_dict=True)
+        out.loss.backward()
+    d = {'loss': np.array(out.loss.item())}
+    names = []
+    for n, p_ in ref_vlm.named_parameters():
+        if p_.grad is None:
+            continue
+        g = p_.grad.detach().double().flatten()
+        names.append(n)
+        d[f'norm::{n}'] = np.array(g.norm().item())
+        k = min(64, g.numel())
+        idx = (torch.arange(k, dtype=torch.int64) * (g.numel() - 1)) // max(1, k - 1)
+        d[f'idx::{n}'] = idx.numpy(); d[f'val::{n}'] = g[idx].numpy()
+        p_.grad = None
+    d['names'] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, 'g8_sft_grads.npz'), **d)
+    print('G8 ok', len(names), 'gradient tensors, loss', d['loss'])
+
+
 def main():
+    if '--only-g8grad' in sys.argv:
+        cfg = C.truncated(C.vlaser_2b(), VIT_L, LLM_L)
+        sd = synth.vla_state_dict(C.VLAConfig(base=cfg), with_head=True)
+        vlm_sd = {k: v for k, v in sd.items() if k.startswith(('vision_model.', 'mlp1.', 'language_model.'))}
+        return g8_sft_grads(cfg, build_ref_vlm(cfg, vlm_sd))
     if '--only-g6b' not in sys.argv:
         tok = ref_import.tokenizer()
         g1_prompts(tok)
@@ -374,6 +409,7 @@ def main():
     g3_g4(ref_vlm)
     g5_g6(cfg, sd, ref_vlm)
     g7_vla(vla, sd, ref_vlm)
+    g8_sft_grads(cfg, build_ref_vlm(cfg, vlm_sd))
     meta = dict(vit_layers=VIT_L, llm_layers=LLM_L, widths='vlaser-2b', weights='vlaser_amd.synth seed 0',
                 torch=torch.__version__, transformers=__import__('transformers').__version__,
                 generated_by='tools/gen_golden.py (imports /root/reference)')
