@@ -176,6 +176,40 @@ def test_from_pretrained_and_sft_save_pretrained(golden_model, tmp_path):
     assert abs(out.item() - ref.item()) < 5e-3
 
 
+def test_sft_long_multi_tile_sample():
+    """An SFT sample longer than 1024 tokens (4 tiles + text = 1100): loss and a few gradient tensors vs oracle autograd -- exercises
+    the long-row attention backward and the multi-tile projector backward."""
+    from oracle import vlm as ovlm
+    from vlaser_amd import config as C, synth
+    from vlaser_amd.sft import SFTModel
+    cfg = C.truncated(C.vlaser_2b(), 1, 1)
+    sd = synth.vlm_state_dict(cfg)
+    g = torch.Generator().manual_seed(41)
+    pv = torch.randn(4, 3, 448, 448, generator=g)
+    ids = torch.cat([torch.randint(0, 151643, (41,), generator=g), torch.full((1024,), cfg.img_context_token_id),
+                     torch.randint(0, 151643, (35,), generator=g)])[None]
+    labels = torch.full_like(ids, -100)
+    labels[0, -20:] = ids[0, -20:]
+    m = SFTModel(cfg, max_seq_len=ids.shape[1], max_tiles=4, lr=1e-3)
+    m.load_state_dict(sd)
+    loss = m.forward_backward(pv, ids, labels)
+    keys = ['language_model.model.layers.0.self_attn.q_proj.weight', 'language_model.model.layers.0.self_attn.k_proj.weight',
+            'language_model.model.layers.0.mlp.down_proj.weight', 'mlp1.1.weight', 'language_model.model.layers.0.input_layernorm.weight']
+    torch.set_grad_enabled(True)
+    try:
+        sdg = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
+        ref = ovlm.sft_loss(ovlm.forward_logits(sdg, cfg, pv, ids), labels)
+        ref.backward()
+    finally:
+        torch.set_grad_enabled(False)
+    assert abs(loss.item() - ref.item()) < 5e-3
+    grads = m.named_grads()
+    for k in keys:
+        a, b = grads[k].float().cpu().flatten(), sdg[k].grad.flatten()
+        rel = ((a - b).norm() / b.norm()).item()
+        assert rel < 4e-2, (k, rel)
+
+
 def test_thirteen_tiles_dynamic_resolution():
     from oracle import vlm as ovlm, vit as ovit
     from vlaser_amd import config as C, synth

@@ -171,11 +171,43 @@ __global__ __launch_bounds__(256) void attn_bwd_pds_kernel(const float* __restri
     }
   }
 }
+// rows longer than 1024 columns (multi-tile samples): same math with the row re-read from memory in three passes
+__global__ __launch_bounds__(256) void attn_bwd_pds_long_kernel(const float* __restrict__ sc, const float* __restrict__ dP, const bf16_t* __restrict__ dO,
+                                                                const bf16_t* __restrict__ O, bf16_t* __restrict__ P, bf16_t* __restrict__ dS, int H,
+                                                                int S, int ld, int hd, float scale) {
+  const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y;
+  if (q >= S) return;
+  const bf16_t* dorow = dO + (size_t)q * H * hd + h * hd;
+  const bf16_t* orow = O + (size_t)q * H * hd + h * hd;
+  float d = 0.f;
+  for (int i = lane * 2; i < hd; i += 128) {
+    const uint32_t a = *reinterpret_cast<const uint32_t*>(dorow + i), b = *reinterpret_cast<const uint32_t*>(orow + i);
+    d += bf16lo_to_f32(a) * bf16lo_to_f32(b) + bf16hi_to_f32(a) * bf16hi_to_f32(b);
+  }
+  d = wave_sum(d);
+  const size_t ro = ((size_t)h * S + q) * ld;
+  float mx = -INFINITY;
+  for (int k = lane; k <= q; k += 64) mx = fmaxf(mx, sc[ro + k] * scale);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int k = lane; k <= q; k += 64) sum += __expf(sc[ro + k] * scale - mx);
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int k = lane; k < ld; k += 64) {
+    const bf16_t pb = (k <= q) ? f32_to_bf16(__expf(sc[ro + k] * scale - mx) * inv) : (bf16_t)0;
+    P[ro + k] = pb;
+    dS[ro + k] = (k <= q) ? f32_to_bf16(bf16_to_f32(pb) * (dP[ro + k] - d) * scale) : (bf16_t)0;
+  }
+}
 extern "C" int vlaser_attn_bwd_pds(const float* scores, const float* dP, const void* dO, const void* O, void* P, void* dS, int H, int S, int ld, int hd,
                                    float scale, vl_stream_t s) {
-  VL_CHECK(scores && dP && dO && O && P && dS && ld >= S && ld <= 1024 && hd % 2 == 0, "vlaser_attn_bwd_pds: bad args (ld <= 1024)");
-  hipLaunchKernelGGL(attn_bwd_pds_kernel, dim3((S + 3) / 4, H), dim3(256), 0, (hipStream_t)s, scores, dP, (const bf16_t*)dO, (const bf16_t*)O,
-                     (bf16_t*)P, (bf16_t*)dS, H, S, ld, hd, scale);
+  VL_CHECK(scores && dP && dO && O && P && dS && ld >= S && hd % 2 == 0, "vlaser_attn_bwd_pds: bad args");
+  if (ld <= 1024)
+    hipLaunchKernelGGL(attn_bwd_pds_kernel, dim3((S + 3) / 4, H), dim3(256), 0, (hipStream_t)s, scores, dP, (const bf16_t*)dO, (const bf16_t*)O,
+                       (bf16_t*)P, (bf16_t*)dS, H, S, ld, hd, scale);
+  else
+    hipLaunchKernelGGL(attn_bwd_pds_long_kernel, dim3((S + 3) / 4, H), dim3(256), 0, (hipStream_t)s, scores, dP, (const bf16_t*)dO, (const bf16_t*)O,
+                       (bf16_t*)P, (bf16_t*)dS, H, S, ld, hd, scale);
   VL_LAUNCH_CHECK();
   return 0;
 }
