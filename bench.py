@@ -18,6 +18,8 @@ Extra objects on the JSON line (tier contract 4):
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -145,18 +147,27 @@ def main():
     ap.add_argument('--sft-steps', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+
+    ap.add_argument('--dry-run', action='store_true', help='rendezvous only (gloo, no GPU work): checks the N-rank launch path')
     a = ap.parse_args()
 
+    if a.gpus > 1 and 'RANK' not in os.environ:
+        # `python bench.py --gpus N`: this parent never touches the GPU; it starts N ranks (one process per GPU) and relays rank 0's line
+        sys.exit(_spawn_ranks(a.gpus))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != a.gpus:
+        raise SystemExit(f'bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or run `python bench.py --gpus N`)')
+    if a.dry_run:
+        return _dry_run(rank, world)
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or os.environ.get('VLASER_FORCE_DP') == '1':      # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         for k, v in (('MASTER_ADDR', '127.0.0.1'), ('MASTER_PORT', '29533'), ('RANK', '0'), ('WORLD_SIZE', '1')):
             os.environ.setdefault(k, v)
-        dist.init_process_group('nccl')      # RCCL on ROCm: used for the barrier and the max-over-ranks time only
+        dist.init_process_group('nccl')      # RCCL on ROCm: barrier, max-over-ranks time, and the SFT gradient exchange
 
     torch.set_grad_enabled(False)
     sft_line = None
@@ -229,6 +240,49 @@ def main():
             line['batched'] = batched_chunks(vla, dev, a.steps)
             line['qa'] = qa_bench(local)
     _finish(dist, line if rank == 0 else None)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _spawn_ranks(n):
+    """Parent of `python bench.py --gpus N` (N > 1, no RANK in the environment): start N worker ranks through
+    torch.distributed.run as a CHILD process (never an exec: see the GPU-box rules), relay rank 0's JSON line, and return
+    non-zero if any rank failed.  The parent itself makes no GPU call."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if p.returncode != 0 or line is None:
+        print(f'bench.py: {n}-rank run failed (rc {p.returncode})', file=sys.stderr)
+        return p.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
+def _dry_run(rank, world):
+    """No GPU: rendezvous over gloo, count the ranks, print the line's skeleton (tests/test_bench_launch.py)."""
+    n = world
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('gloo')
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        n = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({'metric': 'action_chunks_per_sec', 'value': 0.0, 'n_gpus': world, 'ranks_seen': n, 'dry_run': True}), flush=True)
 
 
 def batched_chunks(vla, dev, steps):

@@ -267,3 +267,24 @@ def test_sft_image_flags_ignored_labels_and_two_tiles(golden_model):
     # a sample whose labels are all ignored: zero loss, optimizer step still well defined
     loss3 = m2.forward_backward(pv, ids2, torch.full_like(ids2, -100))
     assert loss3.item() == 0.0
+
+
+def test_sft_workspaces_grow_with_tile_count(golden_model):
+    """a multi-tile sample on a model built with the default max_tiles = 1 must re-allocate the projector workspaces
+    (it used to write past them): same loss and projector gradient as a model sized for the sample."""
+    from vlaser_amd.sft import SFTModel
+    cfg, _, sd = golden_model
+    g = torch.Generator().manual_seed(78)
+    pv = torch.randn(3, 3, 448, 448, generator=g)
+    ids = torch.cat([torch.randint(0, 151643, (30,), generator=g), torch.full((768,), cfg.img_context_token_id),
+                     torch.randint(0, 151643, (20,), generator=g)])[None]
+    labels = torch.full_like(ids, -100)
+    labels[0, -10:] = ids[0, -10:]
+    out = []
+    for mt in (1, 3):
+        m = SFTModel(cfg, max_seq_len=ids.shape[1], max_tiles=mt, lr=1e-3)
+        m.load_state_dict(sd)
+        loss = m.forward_backward(pv, ids, labels)
+        out.append((loss.item(), m.named_grads()['mlp1.1.weight'].clone()))
+        assert m.max_tiles == 3
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])

@@ -39,7 +39,7 @@ def _model(clip, pg=None):
     return cfg, m
 
 
-def _worker(rank, world, port, clip, out_dir):
+def _worker(rank, world, port, clip, out_dir, mute_rank=-1):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -50,6 +50,8 @@ def _worker(rank, world, port, clip, out_dir):
     cfg, m = _model(clip, dist.group.WORLD)
     assert m.world == 2 and m.dp_active and len(m.buckets) >= 3
     pv, ids, labels = _sample(cfg, rank)
+    if rank == mute_rank:
+        labels = torch.full_like(labels, -100)          # no supervised position on this rank
     losses = []
     for _ in range(2):
         out = m.step(pv, ids, labels)
@@ -89,3 +91,26 @@ def test_world2_step_equals_gradient_averaging(tmp_path, clip):
             diff = (a - b).abs()
             assert (diff <= b.abs() * 2.0 ** -7 + 1e-6).all(), k             # at most one bf16 ulp ...
             assert (diff > 0).float().mean().item() < 1e-3, k                 # ... on a handful of elements
+
+
+def test_world2_rank_without_labels_issues_the_same_collectives(tmp_path):
+    """a rank whose sample has no supervised label must still issue one reduce-scatter per bucket (otherwise its
+    all_reduce(gnorm) meets the peers' reduce_scatter and the job hangs).  Rank 1 contributes zero gradients: the result equals
+    'half of rank 0's gradient, then one AdamW step'."""
+    import torch.multiprocessing as mp
+    port = 29700 + (os.getpid() % 50) * 2
+    mp.spawn(_worker, args=(2, port, 0.0, str(tmp_path), 1), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'rank0.pt'), torch.load(tmp_path / 'rank1.pt')
+    assert r1['losses'] == [0.0, 0.0] and r0['losses'][0] > 0
+    for k in KEYS:
+        assert torch.equal(r0['params'][k], r1['params'][k]), k
+    torch.set_grad_enabled(False)
+    cfg, m = _model(0.0)
+    pv, ids, labels = _sample(cfg, 0)
+    for step in range(2):
+        m.forward_backward(pv, ids, labels)
+        m.fp.g.copy_((m.fp.g.float() / 2).to(BF))
+        m.optimizer_step()
+    ref = m.state_dict()
+    for k in KEYS:
+        assert torch.equal(r0['params'][k].float(), ref[k].float().cpu()), k

@@ -261,11 +261,13 @@ def vit_assemble(patch, cls, pos, h, T, P, Cc):
 
 
 def pixel_shuffle_ln(x, w, b, out, T, G, Cc, eps, ps_v1=0):
+    assert out.numel() >= T * (G // 2) ** 2 * 4 * Cc and x.numel() >= T * (G * G + 1) * Cc, 'pixel_shuffle_ln: buffer smaller than T tiles'
     L.check(L.lib().vlaser_pixel_shuffle_ln(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), T, G, Cc, eps, ps_v1,
                                             _stream()), 'vlaser_pixel_shuffle_ln')
 
 
 def pixel_shuffle(x, out, T, G, Cc, ps_v1=0):
+    assert out.numel() >= T * (G // 2) ** 2 * 4 * Cc and x.numel() >= T * (G * G + 1) * Cc, 'pixel_shuffle: buffer smaller than T tiles'
     L.check(L.lib().vlaser_pixel_shuffle(x.data_ptr(), out.data_ptr(), T, G, Cc, ps_v1, _stream()), 'vlaser_pixel_shuffle')
 
 

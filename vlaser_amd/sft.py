@@ -233,19 +233,34 @@ class SFTModel:
         self.P, self.dS = z(nq, S, S), z(nq, S, S)
         self.Vn, self.KT = z(nkv, S, hd), z(nkv, hd, S)
         self.col = torch.zeros(max(2 * I, NQ, C4, H), dtype=F32, device=dev)
-        self.rowstat = torch.zeros(2 * max(S, self.max_tiles * cfg.num_image_token) + 16 * max(2 * I, NQ, C4, H), dtype=F32, device=dev)   # colsum scratch
         self.sumsq_ws = torch.zeros(1024, dtype=F32, device=dev)
         self.normw_ws = torch.zeros((S + 3) // 4 * H, dtype=F32, device=dev)      # norm-weight gradient partials of rmsnorm_bwd
         self.gnorm2 = torch.zeros(1, dtype=F32, device=dev)
         self.rank_ws = torch.zeros(S, dtype=torch.int32, device=dev)
-        # mlp1
+        self._alloc_projector_ws()
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.dp_active else None
+        self.aux_stream = torch.cuda.Stream(device=dev)        # weight transposes overlap the next step's forward
+        self.wT_ready = None
+
+    def _alloc_projector_ws(self):
+        """Projector (mlp1) workspaces, sized for `max_tiles` tiles x 256 visual tokens."""
+        cfg, dev = self.cfg, self.device
+        H, C4 = self.llm.hidden_size, cfg.vision.hidden_size * 4
+        z = lambda *s, dt=BF: torch.zeros(*s, dtype=dt, device=dev)
         nt = self.max_tiles * cfg.num_image_token
         self.ps_raw, self.ps_ln = z(nt, C4), z(nt, C4)
         self.z1, self.g1, self.feat = z(nt, H), z(nt, H), z(nt, H)
         self.dvit, self.dg1, self.dz1, self.dln = z(nt, H), z(nt, H), z(nt, H), z(nt, C4)
-        self.comm_stream = torch.cuda.Stream(device=dev) if self.dp_active else None
-        self.aux_stream = torch.cuda.Stream(device=dev)        # weight transposes overlap the next step's forward
-        self.wT_ready = None
+        I = self.llm.intermediate_size
+        NQ = (self.llm.num_attention_heads + 2 * self.llm.num_key_value_heads) * self.llm.head_dim
+        self.rowstat = torch.zeros(2 * max(self.S_max, nt) + 16 * max(2 * I, NQ, C4, H), dtype=F32, device=dev)   # colsum scratch
+
+    def _grow_tiles(self, T):
+        """A sample with more tiles than the workspaces were built for (dynamic-resolution SFT: up to 12 + thumbnail, plus dummy
+        `image_flags == 0` tiles): re-allocate the projector workspaces, as VitEngine._alloc does for the tower's own."""
+        if T > self.max_tiles:
+            self.max_tiles = T
+            self._alloc_projector_ws()
 
     def _wait_params(self, b):
         """Block the compute stream until bucket b's parameters of the current step have been all-gathered."""
@@ -349,6 +364,7 @@ class SFTModel:
         gv['embed'].zero_()
         # ---- vision tower (frozen) + trainable projector (mlp1), with the intermediates mlp1's backward needs
         T = pixel_values.shape[0]
+        self._grow_tiles(T)
         pv = pixel_values.to(dev)
         if pv.dtype != BF:
             pvb = torch.empty(pv.shape, dtype=BF, device=dev)
@@ -395,7 +411,15 @@ class SFTModel:
         self._wait_params(0)                                         # lm_head + final norm
         ops.rmsnorm(h_fin, v['norm'], llm.rms_norm_eps, out=xn)
         if R == 0:
-            self.fp.g.zero_()                                        # no supervised position: zero loss, zero gradients
+            # no supervised position on this rank: zero loss, zero gradients -- but the SAME collective sequence as every other
+            # rank (one reduce-scatter per bucket, in backward order), and the W^T refresh of the previous step must have finished
+            # reading fp.p before the optimizer writes it
+            if self.wT_ready is not None:
+                torch.cuda.current_stream().wait_event(self.wT_ready)
+            self.fp.g.zero_()
+            if on_bucket_ready:
+                for b in range(len(self.buckets)):
+                    on_bucket_ready(b)
             return torch.zeros((), device=dev)
         x_rows = xn.index_select(0, rows).contiguous()
         t_rows = tgt.index_select(0, rows).contiguous()
