@@ -59,7 +59,8 @@ typedef struct {
   void* vq; void* vk; void* vvt; int vit_heads, vit_seq, vit_seq_pad; float q_scale;
   /* VL_EPI_PARTIAL */
   float* out_f32; int k_splits;
-  int force_bm;             /* 0 = heuristic, else tile height 32 / 64 / 128 (tests) */
+  int force_bm;             /* 0 = heuristic; 32 / 64 / 128 = register-staged tile height; 1100 / 1200 / 1300 / 1500 = LDS-DMA pipeline
+                               128x128 / 128x256 / 256x256 / 64x128 (tests, tools/micro/gemm_lab) */
   /* batched GEMM (attention backward through materialised per-head matrices): blockIdx.z = batch index z;
    * A += z*a_bs, out += z*o_bs, W += (z / w_group)*w_bs  (element strides; batch 0/1 = plain GEMM) */
   int batch; long long a_bs, w_bs, o_bs; int w_group;

@@ -406,7 +406,7 @@ def test_vla_glue(ops):
     close(act, a0 + 0.1 * vel, rtol=1e-5, atol=1e-6, name='euler')
 
 
-@pytest.mark.parametrize('bm', [32, 64, 128])
+@pytest.mark.parametrize('bm', [32, 64, 128, 1100, 1200, 1300, 1500, 0])
 def test_gemm_tile_heights(ops, bm):
     from vlaser_amd import _lib as L
     M, N, K = 385, 1536, 1536
@@ -421,7 +421,7 @@ def test_gemm_tile_heights(ops, bm):
     close(o2, F.silu(gr).to(BF).float() * ur, name=f'swiglu bm{bm}')
 
 
-@pytest.mark.parametrize('bm', [32, 64])
+@pytest.mark.parametrize('bm', [32, 64, 1100, 1200, 1300, 1500])
 def test_gemm_qkv_rope_small_tiles(ops, bm):
     from vlaser_amd import _lib as L
     B, S, H, nq, nkv, smax = 1, 100, 1536, 12, 2, 128
@@ -471,3 +471,20 @@ def test_gemm_splitk_reduce_norm(ops, M, N, K, S):
     h3 = torch.zeros_like(h)
     ops.reduce_norm(h, part, S, M, N, h3)
     close(h3, href.float(), rtol=8e-3, name='h none')
+
+
+@pytest.mark.parametrize('bm', [1100, 1200, 1300, 1500])
+def test_gemm_glds_ragged_and_splitk(ops, bm):
+    """LDS-DMA pipelines on shapes that do not fill their tiles: ragged M and N (fp32 logits epilogue), K shorter than the stage
+    ring (look-ahead tiles are clamped re-fetches), and split-K partial slabs."""
+    from vlaser_amd import _lib as L
+    for (M, N, K) in [(130, 1000, 64), (257, 300, 128), (70, 520, 1536)]:
+        x, w = rnd(M, K), rnd(N, K, std=0.05, seed=M)
+        out = torch.zeros(M, N, dtype=torch.float32, device='cuda')
+        ops.gemm(L.EPI_F32, x, w, out=out, force_bm=bm)
+        close(out, x.float() @ w.float().t(), rtol=2e-3, atol=2e-3, name=f'f32 {M}x{N}x{K} cfg{bm}')
+    M, N, K, S = 385, 1024, 2048, 4
+    x, w = rnd(M, K), rnd(N, K, std=0.05, seed=9)
+    part = torch.zeros(S, M, N, dtype=torch.float32, device='cuda')
+    ops.gemm(L.EPI_PARTIAL, x, w, out_f32=part, k_splits=S, force_bm=bm)
+    close(part.sum(0), x.float() @ w.float().t(), rtol=2e-3, atol=2e-3, name=f'split-K cfg{bm}')

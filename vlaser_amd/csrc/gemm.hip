@@ -10,6 +10,8 @@
 // LDS: 2 x (A 16 KiB + W 16 KiB), 16-byte slots XOR-swizzled by (row & 7) (guide T2) -> <=2-way conflicts on
 // ds_read_b128.  Global->register prefetch of tile k+1 overlaps the MFMAs of tile k; one barrier per K-step.
 // blockIdx is remapped so each XCD owns a contiguous run of tiles that share the same weight panel (guide T1).
+#include <mutex>
+
 #include "common.h"
 #include "../../include/vlaser_hip.h"
 
@@ -286,14 +288,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------- LDS-DMA variant
-// Same tiles, fragments and epilogues as gemm_kernel, but the operands go global -> LDS directly (global_load_lds_dwordx4:
-// no staging VGPRs, no ds_write pass -- the ablation of the register-staged loop attributes ~45 % of its time to that
-// path) into NST LDS stages, NST-1 K-tiles in flight, ONE raw s_barrier per K-step and a counted vmcnt (never 0 inside
-// the loop).  An LDS-DMA wave instruction writes 64 lanes x 16 B to CONSECUTIVE LDS addresses (M0 base + lane*16), i.e.
-// 8 rows x 128 B of the row-major tile image; the XOR swizzle of the image is therefore applied on the SOURCE side: lane l
-// of piece j fetches logical slot (l&7) ^ (row&7) of row 8j + (l>>3).  The DMA is issued from inline asm so that hipcc
-// neither counts it nor drains it at its own waits (guide §5.7); ordering is ours: vmcnt(N) -> s_barrier -> ds_read.
+// ---------------------------------------------------------------------------------------------- LDS-DMA pipeline
+// Same fragments and epilogues as gemm_kernel, but the operands go global -> LDS directly (global_load_lds_dwordx4: no
+// staging VGPRs, no ds_write pass) into a ring of NST stages with NST-1 K-tiles in flight, ONE raw s_barrier per K-step and
+// a counted vmcnt (never 0 inside the loop): the L2/HBM latency of a K-tile is covered by the MFMAs of the NST-2 tiles
+// before it instead of by a second co-resident workgroup -- the path's GEMMs are single-round grids (M = 384..1025), so
+// there is no second workgroup to hide behind.  WM x WN waves (4 or 8) own a BM x BN tile; BN = 256 halves the activation
+// re-reads of the wide GEMMs (gate/up, fc1).
+// An LDS-DMA wave instruction writes 64 lanes x 16 B to CONSECUTIVE LDS addresses (M0 base + lane*16), i.e. 8 rows x 128 B
+// of the row-major tile image; the XOR swizzle of the image is therefore applied on the SOURCE side: lane l of a piece
+// fetches logical slot (l&7) ^ (row&7) of row 8*piece + (l>>3).  The DMA is issued from inline asm so that hipcc neither
+// counts it nor drains it at its own waits (guide 5.7); ordering is ours: vmcnt(N) -> s_barrier -> ds_read.
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -301,18 +306,20 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EPI, int BM, int NST>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) {
-  constexpr int WR = BM >= 64 ? 2 : 1, WC = 4 / WR;
-  constexpr int WTM = BM / WR, WTN = BN / WC;
+template <int EPI, int BM, int BNT, int WM, int WN, int NST>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
+  constexpr int NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BNT / WN;
   constexpr int MT = WTM / 16, NT = WTN / 16;
-  constexpr int STAGE = BM * 128 + 16384;               // bytes: A tile | W tile
-  constexpr int PA = BM / 8 / 4, PW = 16 / 4;           // 1 KiB pieces per wave per K-tile (A, W)
+  constexpr int STAGE = (BM + BNT) * 128;               // bytes: A tile | W tile (row-major, 128 B = 64 k per row)
+  constexpr int PA = BM / 8 / NW, PW = BNT / 8 / NW;     // 1 KiB pieces per wave per K-tile (A, W)
   constexpr int PIECES = PA + PW;
+  static_assert(PA >= 1 && PW >= 1 && PA * 8 * NW == BM && PW * 8 * NW == BNT, "tile rows must split evenly into 8-row pieces per wave");
+  static_assert(NT % 2 == 0, "fused pair epilogues need an even number of 16-column tiles per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const VlaserGemmArgs& a = p.a;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave / WC, wc = wave % WC;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wc = wave % WN;
   const int nwg = gridDim.x;
   int bid = blockIdx.x;
   {
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int tile_m = bid % p.tiles_m, tile_n = bid / p.tiles_m;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * BM, n0 = tile_n * BNT;
   const int kc = a.K / (int)gridDim.y;
   const int kbase = blockIdx.y * kc;
   const int bz = blockIdx.z;
@@ -406,19 +413,33 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmP p) {
   }
 }
 
-template <int EPI, int BM, int NST>
+// one attribute call per (kernel, device): the C ABI promises thread safety w.r.t. distinct streams, and a process may drive
+// several GPUs
+template <class K>
+static int set_max_lds_once(K kernel, int lds) {
+  static std::mutex mu;
+  static int done_lds[64] = {0};
+  int dev = 0;
+  VL_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> g(mu);
+  if (dev < 0 || dev >= 64 || done_lds[dev] < lds) {
+    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (dev >= 0 && dev < 64) done_lds[dev] = lds;
+  }
+  return 0;
+}
+
+template <int EPI, int BM, int BNT, int WM, int WN, int NST>
 static int launch_glds(const VlaserGemmArgs* args, hipStream_t stream, int splits) {
   GemmP p;
   p.a = *args;
   p.tiles_m = (args->M + BM - 1) / BM;
-  p.tiles_n = (args->N + BN - 1) / BN;
-  constexpr int lds = NST * (BM * 128 + 16384);
-  static bool attr_set = false;
-  if (!attr_set) {
-    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<EPI, BM, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BM, NST>), dim3(p.tiles_m * p.tiles_n, splits, args->batch > 1 ? args->batch : 1), dim3(256), lds, stream, p);
+  p.tiles_n = (args->N + BNT - 1) / BNT;
+  constexpr int lds = NST * (BM + BNT) * 128;
+  static_assert(lds <= 160 * 1024, "stage ring exceeds the 160 KiB LDS of a CU");
+  if (int rc = set_max_lds_once(gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST>, lds)) return rc;
+  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST>), dim3(p.tiles_m * p.tiles_n, splits, args->batch > 1 ? args->batch : 1),
+                     dim3(WM * WN * 64), lds, stream, p);
   VL_LAUNCH_CHECK();
   return 0;
 }
@@ -430,37 +451,53 @@ static int launch_bm(const VlaserGemmArgs* args, hipStream_t stream, int splits)
   p.tiles_m = (args->M + BM - 1) / BM;
   p.tiles_n = (args->N + BN - 1) / BN;
   constexpr int lds = 2 * (BM * 128 + 16384);
-  static bool attr_set = false;
-  if (!attr_set) {
-    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<EPI, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
-  }
+  if (int rc = set_max_lds_once(gemm_kernel<EPI, BM>, lds)) return rc;
   hipLaunchKernelGGL((gemm_kernel<EPI, BM>), dim3(p.tiles_m * p.tiles_n, splits, args->batch > 1 ? args->batch : 1), dim3(256), lds, stream, p);
   VL_LAUNCH_CHECK();
   return 0;
 }
 
-// tile-height heuristic: the largest BM that still yields >= ~one workgroup per CU (256 CUs)
+// Tile configuration.  Measured on the path's shapes (tools/micro/gemm_lab.cpp, profiles/r02b_gemm_lab.md): the LDS-DMA
+// pipelines beat the register-staged kernels whenever the grid is a single round of workgroups (<= one per CU), largest tile
+// first losing to smallest: 64x128 (8 waves, 4 stages) for the smallest problems, then 128x128 (4 stages), 128x256 (3 stages),
+// 256x256 (2 stages).  Multi-round grids take the configuration with the least modelled time (rounds x tile area / measured
+// rate); <= 32 activation rows stay on the 32-row register-staged kernel (a 64-row tile would be 50+ % padding).
 template <int EPI>
 static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
   const int splits = (EPI == VL_EPI_PARTIAL && args->k_splits > 1) ? args->k_splits : 1;
   const int tn = (args->N + BN - 1) / BN;
   const int nb = args->batch > 1 ? args->batch : 1;
-  auto blocks = [&](int bm) { return ((args->M + bm - 1) / bm) * tn * splits * nb; };
+  auto blocks = [&](int bm, int bn = BN) { return ((args->M + bm - 1) / bm) * ((args->N + bn - 1) / bn) * splits * nb; };
+  (void)tn;
   int bm = args->force_bm;
-  // measured on the path's shapes (tools/micro/kernel_lab.py): BM = 64 beats or ties BM = 128 everywhere up to ~1700
-  // tiles (two 64-row workgroups per CU overlap each other's staging); 128 only pays on far larger grids
   if (bm == 0) {
-    bm = blocks(128) >= 2048 ? 128 : (blocks(64) >= 192 ? 64 : 32);
-    // the one measured exception: the prefill gate/up GEMM (SwiGLU epilogue, M a multiple of 128, >= 400 tiles): 36.5 vs 42.8 us
-    if (EPI == VL_EPI_SWIGLU && args->M % 128 == 0 && blocks(128) >= 400) bm = 128;
+    if (args->M <= 32) {
+      bm = 32;
+    } else if (blocks(64, 128) <= 256) {
+      bm = 1500;
+    } else if (blocks(128, 128) <= 256) {
+      bm = 1100;
+    } else if (blocks(128, 256) <= 256) {
+      bm = 1200;
+    } else if (blocks(256, 256) <= 256) {
+      bm = 1300;
+    } else {
+      const struct { int code, bm, bn; float rate; } cand[4] = {{1500, 64, 128, 701.f}, {1100, 128, 128, 850.f}, {1200, 128, 256, 1040.f}, {1300, 256, 256, 1208.f}};
+      float best = 1e30f;
+      for (const auto& c : cand) {
+        const float t = (float)((blocks(c.bm, c.bn) + 255) / 256) * (float)(c.bm * c.bn) / c.rate;
+        if (t < best) { best = t; bm = c.code; }
+      }
+    }
   }
-  // LDS-DMA variant (gemm_glds_kernel, 2 stages): +3..17 % on bare GEMMs in tools/micro, but no gain inside the real
-  // chunk / SFT step (172 vs 132 VGPRs costs a workgroup of occupancy under the fused epilogues) -> opt-in until the
-  // deeper-pipelined structure it is the base for exists.
-  static const bool glds = getenv("VLASER_GEMM_GLDS") != nullptr;
-  if (glds && bm == 128) return launch_glds<EPI, 128, 2>(args, stream, splits);
-  if (glds && bm == 64) return launch_glds<EPI, 64, 2>(args, stream, splits);
+  // LDS-DMA pipeline configurations: 1100 = 128x128 / 4 stages, 1200 = 128x256 / 3, 1300 = 256x256 / 2, 1500 = 64x128 / 4 (8 waves each)
+  switch (bm) {
+    case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4>(args, stream, splits);
+    case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3>(args, stream, splits);
+    case 1300: return launch_glds<EPI, 256, 256, 2, 4, 2>(args, stream, splits);
+    case 1500: return launch_glds<EPI, 64, 128, 2, 4, 4>(args, stream, splits);
+    default: break;
+  }
   if (bm == 128) return launch_bm<EPI, 128>(args, stream, splits);
   if (bm == 64) return launch_bm<EPI, 64>(args, stream, splits);
   return launch_bm<EPI, 32>(args, stream, splits);
@@ -617,12 +654,8 @@ extern "C" int vlaser_gemm_tn_grouped(const void* At, const void* Wt, void* out,
   GemmTnP p{(const bf16_t*)At, (const bf16_t*)Wt, (bf16_t*)out, M, N, K, ldat, ldwt, ldo, 0, (N + BN - 1) / BN, groups, a_gs, w_gs, a_bs, w_bs, o_bs};
   hipStream_t stream = reinterpret_cast<hipStream_t>(s);
   constexpr int lds64 = 2 * (64 * (64 * 2 + 32) + 64 * (BN * 2 + 32)), lds128 = 2 * (64 * (128 * 2 + 32) + 64 * (BN * 2 + 32));
-  static bool attr_set = false;
-  if (!attr_set) {
-    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds64));
-    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds128));
-    attr_set = true;
-  }
+  if (int rc = set_max_lds_once(gemm_tn_kernel<64>, lds64)) return rc;
+  if (int rc = set_max_lds_once(gemm_tn_kernel<128>, lds128)) return rc;
   const bool big = ((M + 127) / 128) * p.tiles_n * batch >= 512;      // measured: 128-row tiles win on the big weight gradients only
   if (big) {
     p.tiles_m = (M + 127) / 128;
@@ -645,7 +678,8 @@ extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   VL_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "vlaser_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
   VL_CHECK(a->K % BK == 0, "vlaser_gemm: K=%d must be a multiple of %d", a->K, BK);
   VL_CHECK(a->batch <= 1 || (epi == VL_EPI_NONE || epi == VL_EPI_F32 || epi == VL_EPI_BIAS), "vlaser_gemm: batched mode supports NONE / F32 / BIAS epilogues");
-  VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128, "vlaser_gemm: force_bm must be 0/32/64/128");
+  VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1500,
+           "vlaser_gemm: force_bm must be 0/32/64/128 or an LDS-DMA configuration code 1100/1200/1300/1500");
   VL_CHECK(a->lda % 8 == 0 && a->ldw % 8 == 0, "vlaser_gemm: lda/ldw must be multiples of 8 (16-byte rows)");
   VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm: operands must be 16-byte aligned");
   switch (epi) {

@@ -223,7 +223,7 @@ def prefill_begin(stack: QwenStack, buf: PrefillBuffers, h, M):
 
 def prefill_layer(stack: QwenStack, lw: QwenLayerWeights, buf: PrefillBuffers, h, cache: KVCache, layer, rope, pos_ids, batch,
                   tok_per_batch, attn_mode, valid_len=None, blk_start=0, causal_off=0, kv_len=None, skip_post_attn=False,
-                  next_norm_w=None, slot_base=0):
+                  next_norm_w=None, slot_base=0, kv_ready=None):
     """One Qwen2DecoderLayer over M = batch*tok_per_batch rows with the big-GEMM kernels; K/V written to slots
     [slot_base, slot_base + tok_per_batch) of the cache (slot_base > 0: decode steps of models too wide for the
     weight-streaming kernels).  Expects buf.x = input_layernorm(h); leaves buf.x = next_norm(h_out) when
@@ -237,6 +237,8 @@ def prefill_layer(stack: QwenStack, lw: QwenLayerWeights, buf: PrefillBuffers, h
     x, q, ao, act = buf.x[:M], buf.q[:M], buf.ao[:M], buf.act[:M]
     ops.gemm(L.EPI_QKV_ROPE, x, lw.wqkv, bias=lw.bqkv, q_out=q, k_cache=cache.k[layer], vt_cache=cache.vt[layer], rope_cos=rope[0],
              rope_sin=rope[1], pos_ids=pos_ids, n_q_heads=nq, n_kv_heads=nkv, s_max=cache.s_max, tok_per_batch=tok_per_batch, slot_base=slot_base)
+    if kv_ready is not None:
+        kv_ready.record()                  # this layer's K / V^T rows are in the cache: a side stream may attend to them
     ks, vs = cache.strides()
     ops.attn_prefill(q, cache.k[layer], cache.vt[layer], ao, batch, tok_per_batch, tok_per_batch if kv_len is None else kv_len, nq, nkv, hd,
                      (tok_per_batch * nq * hd, hd, nq * hd), ks, vs, (tok_per_batch * nq * hd, nq * hd), cache.s_max, hd ** -0.5,
@@ -271,7 +273,8 @@ class SkinnyBuffers:
 
 
 def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in, partials, n_partials, cache: KVCache, layer, rope,
-                 pos_ids, batch, tok_per_batch, slot_base, kv_len, attn_mode, valid_len=None, blk_start=0, skip_post_attn=False):
+                 pos_ids, batch, tok_per_batch, slot_base, kv_len, attn_mode, valid_len=None, blk_start=0, skip_post_attn=False,
+                 wait_kv=None):
     """One decoder layer over M = batch*tok_per_batch <= 16 rows with the weight-streaming kernels (5 launches).
     Input residual = h_in + sum(partials) (partials = down_proj slabs of the previous layer).  Returns
     (h, partials, n_partials) describing this layer's output residual the same way."""
@@ -308,6 +311,8 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
     ops.launch_skinny(L.PRO_NORM, L.SK_QKV_ROPE, plan.qkv[0], stream)
     a = plan.attn
     a.kv_len, a.n_splits, a.blk_start = kv_len, nsp, blk_start
+    if wait_kv is not None:
+        torch.cuda.current_stream().wait_event(wait_kv)      # keys written by another stream (the VLM prefill of this layer)
     ops.launch_attn_skinny(a, stream)
     if skip_post_attn:
         return sb.hA, None, 0

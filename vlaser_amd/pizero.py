@@ -126,6 +126,7 @@ class PiZero:
         self.pos_vlm = z(B * T, dt=torch.int32)
         self.pos_pro = z(B, dt=torch.int32)
         self.pos_act = z(B * self.num_action_tokens, dt=torch.int32)
+        self.side_stream = torch.cuda.Stream(device=dev)
 
     # ------------------------------------------------------------------ reference helpers (API parity)
     def build_causal_mask_and_position_ids(self, attention_mask, dtype):
@@ -149,18 +150,27 @@ class PiZero:
         feats = self.vit.forward(self.in_pix[:B * self.num_images])
         h_vlm = self.h_vlm[:B * T]
         ops.embed_merge(self.in_ids[:B], self.vlm.embed, feats, h_vlm, self.image_token_index, self.pad_token_id, True, self.rank_ws)
-        ops.small_linear(self.in_proprio, self.pe_w, self.pe_b, self.h_pro, B, cfg.action_hidden_size, cfg.proprio_dim)
-        # a13: joint prefill over {vlm, proprio}; K/V of both mixtures cached (post-RoPE), last layer skips o_proj+MLP
+        # a13: joint prefill over {vlm, proprio}; K/V of both mixtures cached (post-RoPE), last layer skips o_proj+MLP.
+        # The proprio token's expert layers (5 weight-streaming launches each, ~30 us per layer of pure latency) only need the VLM
+        # keys of their own layer, and the VLM rows never look at the proprio token: the proprio chain runs on a side stream (a
+        # parallel branch of the HIP graph) underneath the VLM's MFMA GEMMs instead of between them.
+        main, side = torch.cuda.current_stream(), self.side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.small_linear(self.in_proprio, self.pe_w, self.pe_b, self.h_pro, B, cfg.action_hidden_size, cfg.proprio_dim)
         h_pro, parts, npart = self.h_pro, None, 0
         prefill_begin(self.vlm, self.pbuf, h_vlm, B * T)
         for i in range(nL):
             last = i == nL - 1
+            kv_ready = torch.cuda.Event()
             prefill_layer(self.vlm, self.vlm.layers[i], self.pbuf, h_vlm, self.cache, i, self.rope, self.pos_vlm, B, T,
                           L.ATTN_PREFIX, valid_len=self.valid_len, blk_start=T, skip_post_attn=last,
-                          next_norm_w=None if last else self.vlm.layers[i + 1].ln_in)
-            h_pro, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_pro, h_pro, parts, npart, self.cache, i,
-                                               self.rope, self.pos_pro, B, 1, T, T + 1, L.ATTN_PREFIX, valid_len=self.valid_len,
-                                               blk_start=T, skip_post_attn=last)
+                          next_norm_w=None if last else self.vlm.layers[i + 1].ln_in, kv_ready=kv_ready)
+            with torch.cuda.stream(side):
+                h_pro, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_pro, h_pro, parts, npart, self.cache, i,
+                                                   self.rope, self.pos_pro, B, 1, T, T + 1, L.ATTN_PREFIX, valid_len=self.valid_len,
+                                                   blk_start=T, skip_post_attn=last, wait_kv=kv_ready)
+        main.wait_stream(side)
         # a14: flow-matching Euler integration over the cached prefix
         M = B * na
         self.action[:M].copy_(self.in_noise[:M])
