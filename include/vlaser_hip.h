@@ -97,6 +97,8 @@ typedef struct {
   float* part_m; float* part_l; /* fp32 [B, n_kv, n_splits, 32] */
   float* part_o;                /* fp32 [B, n_kv, n_splits, 32, 128], unnormalised */
   int n_splits;                 /* 1..8 key splits (grid.y) */
+  int first_tok_kv_len;         /* > 0: query token 0 of each batch element sees the block keys [blk_start, first_tok_kv_len) only -- the
+                                   proprio row riding in front of the action rows (pizero_internvl.py:517-587: proprio sees prefix + self) */
 } VlaserAttnArgs;
 
 int vlaser_attn_prefill(const VlaserAttnArgs* args, vl_stream_t stream);

@@ -278,6 +278,24 @@ def test_graph_equals_eager(golden_model, golden_dir):
     assert torch.equal(e.infer_action(*args[:8], noise=args[8]), g.infer_action(*args[:8], noise=args[8]))
 
 
+def test_proprio_row_riding_with_step0_is_bit_identical(golden_model, golden_dir):
+    """Batch 1 runs the proprio token in front of the action rows of Euler step 0 (M = 5) instead of in its own pass through the
+    expert: actions and the cached proprio K / V^T (slot 384 of every layer) must equal the separate pass bit for bit."""
+    from vlaser_amd.pizero import PiZeroInference
+    _, vla, sd = golden_model
+    d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))
+    a = PiZeroInference(vla, max_batch=1, use_graph=False, ride_proprio=True); a.load_state_dict(sd)
+    b = PiZeroInference(vla, max_batch=1, use_graph=False, ride_proprio=False); b.load_state_dict(sd)
+    for case in ('a', 'b'):
+        args = _vla_inputs(d, case, a)
+        ra, rb = a.infer_action(*args[:8], noise=args[8]), b.infer_action(*args[:8], noise=args[8])
+        assert torch.equal(ra, rb)
+        T = a.max_image_text_tokens
+        assert torch.equal(a.cache.k[:, :, :, T:T + 5], b.cache.k[:, :, :, T:T + 5])
+        assert torch.equal(a.cache.vt[:, :, :, :, T:T + 5], b.cache.vt[:, :, :, :, T:T + 5])
+        assert a.cache.k[:, :, :, T].abs().sum() > 0
+
+
 def test_vlaser_8b_widths_multi_tile_generate():
     """BASELINE configs[3] geometry at true 8B widths (hidden 3584, 28 q / 4 kv heads, MLP 18944), depth-truncated, 2 tiles:
     prefill + greedy decode vs the fp32 CPU oracle.  The 3584-wide decoder does not fit the weight-streaming kernels'

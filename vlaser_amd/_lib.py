@@ -24,7 +24,8 @@ class AttnArgs(C.Structure):
                 ('n_q_heads', i32), ('n_kv_heads', i32), ('head_dim', i32), ('q_bs', i64), ('q_hs', i64), ('q_ss', i64),
                 ('k_bs', i64), ('k_hs', i64), ('vt_bs', i64), ('vt_hs', i64), ('o_bs', i64), ('o_ss', i64),
                 ('ld_vt', i32), ('scale', f32), ('mode', i32), ('causal_off', i32), ('valid_len', vp),
-                ('blk_start', i32), ('q_row_off', i32), ('part_m', vp), ('part_l', vp), ('part_o', vp), ('n_splits', i32)]
+                ('blk_start', i32), ('q_row_off', i32), ('part_m', vp), ('part_l', vp), ('part_o', vp), ('n_splits', i32),
+                ('first_tok_kv_len', i32)]
 
 
 class SkinnyArgs(C.Structure):

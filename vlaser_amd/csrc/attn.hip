@@ -239,10 +239,12 @@ __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
   const int c_begin = split * cps, c_end = min(n_chunks, c_begin + cps);
 
   bf16x8 qf[2][DC];
+  int row_hi2[2];                                      // per query row: end of the visible part of the [blk_start, kv_len) block
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     const int r = qt * 16 + fr;
     const int hg = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)nq)), tok = r - hg * nq;     // r / nq without an integer division
+    row_hi2[qt] = (tok == 0 && a.first_tok_kv_len > 0) ? a.first_tok_kv_len : 0x7fffffff;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (size_t)b * a.q_bs + (size_t)(kvh * G + hg) * a.q_hs + (size_t)tok * a.q_ss;
 #pragma unroll
     for (int dc = 0; dc < DC; ++dc) {
@@ -276,17 +278,25 @@ __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
     }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) vf[dt] = ld_global_16(VT + (size_t)(dt * 16 + fr) * a.ld_vt + key0 + g * 8);
-    bool vis[2][4];
+    bool visk[2][4];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = key0 + g * 8 + t * 4 + r;
-        vis[t][r] = (key < lim1) || (key >= lo2 && key < hi2);
+        visk[t][r] = (key < lim1) || (key >= lo2 && key < hi2);
       }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       if (qt * 16 >= nrows) continue;
+      bool vis[2][4];                                  // this lane's query row (fr of tile qt) x its 8 keys
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = key0 + g * 8 + t * 4 + r;
+          vis[t][r] = visk[t][r] && (key < lim1 || key < row_hi2[qt]);
+        }
       f32x4 s[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {

@@ -489,12 +489,15 @@ extern "C" int vlaser_ce_rows(const float* logits, const int64_t* labels, int R,
 // h = h_in + [ls *] (sum_s partials[s] [+ bias]); x_out = norm(h).  One wave per row, 4 rows per block; the row
 // (C <= 4096) stays in registers between the reduction and the normalisation; slab loads are issued 4 slabs at a
 // time (independent 16-byte loads) so the reduction costs ~ceil(S/4) L2 round trips.
-template <int NORM, int MAXC>  // NORM: 0 none, 1 RMS, 2 LayerNorm; MAXC: 16-byte chunks per lane (C <= 512*MAXC)
-__global__ __launch_bounds__(256) void reduce_norm_kernel(const bf16_t* __restrict__ h_in, const float* __restrict__ partials, int S,
+// One wave per row and ONE row per workgroup: the path's seams have M = 384..1025 rows, so 4-row workgroups left two thirds of
+// the CUs idle and made each busy CU pull 4 rows x S slabs through its own L1 (7.1-7.5 us per launch for 7-12 MB of traffic);
+// SX > 0 = exact slab count (no clamped duplicate loads), SX = 0 = runtime count in batches of 8.
+template <int NORM, int MAXC, int SX>  // NORM: 0 none, 1 RMS, 2 LayerNorm; MAXC: 16-byte chunks per lane (C <= 512*MAXC)
+__global__ __launch_bounds__(64) void reduce_norm_kernel(const bf16_t* __restrict__ h_in, const float* __restrict__ partials, int S,
                                                           const bf16_t* __restrict__ bias, const bf16_t* __restrict__ ls,
                                                           const bf16_t* __restrict__ nw, const bf16_t* __restrict__ nb, float eps,
                                                           bf16_t* __restrict__ h_out, bf16_t* __restrict__ x_out, int M, int C) {
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, row = blockIdx.x;
   if (row >= M) return;
   u32x4 hv[MAXC];
   const size_t slab = (size_t)M * C;
@@ -505,7 +508,19 @@ __global__ __launch_bounds__(256) void reduce_norm_kernel(const bf16_t* __restri
     if (c < C) {
       const size_t off = (size_t)row * C + c;
       float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (S > 0) {
+      if constexpr (SX > 0) {
+        f32x4 q[2 * SX];
+#pragma unroll
+        for (int u = 0; u < SX; ++u) {
+          const float* pp = partials + off + (size_t)u * slab;
+          q[2 * u] = *reinterpret_cast<const f32x4*>(pp);
+          q[2 * u + 1] = *reinterpret_cast<const f32x4*>(pp + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < SX; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] += q[2 * u][j]; v[4 + j] += q[2 * u + 1][j]; }
+      } else if (S > 0) {
         const float* pb = partials + off;
         int Sr = S;
         for (; Sr > 8; Sr -= 8, pb += 8 * slab) add_slabs_clamped<8>(v, pb, slab, 8);
@@ -576,18 +591,30 @@ extern "C" int vlaser_reduce_norm(const void* h_in, const float* partials, int S
                                   const void* nw, const void* nb, float eps, void* h_out, void* x_out, int M, int C, vl_stream_t s) {
   VL_CHECK(h_out && (S == 0 || partials) && M > 0 && C % 8 == 0 && C <= 4096, "vlaser_reduce_norm: bad args (C=%d)", C);
   VL_CHECK(norm_kind == 0 || (nw && x_out && (norm_kind == 1 || nb)), "vlaser_reduce_norm: norm weights / x_out missing");
-  dim3 grid((M + 3) / 4), blk(256);
+  dim3 grid(M), blk(64);
 #define RN_ARGS (const bf16_t*)h_in, partials, S, (const bf16_t*)bias, (const bf16_t*)ls, (const bf16_t*)nw, (const bf16_t*)nb, eps, \
                 (bf16_t*)h_out, (bf16_t*)x_out, M, C
-  if (C <= 2048) {
-    if (norm_kind == 0) hipLaunchKernelGGL((reduce_norm_kernel<0, 4>), grid, blk, 0, (hipStream_t)s, RN_ARGS);
-    else if (norm_kind == 1) hipLaunchKernelGGL((reduce_norm_kernel<1, 4>), grid, blk, 0, (hipStream_t)s, RN_ARGS);
-    else hipLaunchKernelGGL((reduce_norm_kernel<2, 4>), grid, blk, 0, (hipStream_t)s, RN_ARGS);
-  } else {
-    if (norm_kind == 0) hipLaunchKernelGGL((reduce_norm_kernel<0, 8>), grid, blk, 0, (hipStream_t)s, RN_ARGS);
-    else if (norm_kind == 1) hipLaunchKernelGGL((reduce_norm_kernel<1, 8>), grid, blk, 0, (hipStream_t)s, RN_ARGS);
-    else hipLaunchKernelGGL((reduce_norm_kernel<2, 8>), grid, blk, 0, (hipStream_t)s, RN_ARGS);
+#define RN_LAUNCH(MAXC, SX)                                                                                                   \
+  do {                                                                                                                        \
+    if (norm_kind == 0) hipLaunchKernelGGL((reduce_norm_kernel<0, MAXC, SX>), grid, blk, 0, (hipStream_t)s, RN_ARGS);         \
+    else if (norm_kind == 1) hipLaunchKernelGGL((reduce_norm_kernel<1, MAXC, SX>), grid, blk, 0, (hipStream_t)s, RN_ARGS);    \
+    else hipLaunchKernelGGL((reduce_norm_kernel<2, MAXC, SX>), grid, blk, 0, (hipStream_t)s, RN_ARGS);                        \
+  } while (0)
+#define RN_SWITCH(MAXC)                            \
+  switch (S) {                                     \
+    case 1: RN_LAUNCH(MAXC, 1); break;             \
+    case 2: RN_LAUNCH(MAXC, 2); break;             \
+    case 3: RN_LAUNCH(MAXC, 3); break;             \
+    case 4: RN_LAUNCH(MAXC, 4); break;             \
+    case 5: RN_LAUNCH(MAXC, 5); break;             \
+    case 6: RN_LAUNCH(MAXC, 6); break;             \
+    case 7: RN_LAUNCH(MAXC, 7); break;             \
+    case 8: RN_LAUNCH(MAXC, 8); break;             \
+    default: RN_LAUNCH(MAXC, 0); break;            \
   }
+  if (C <= 2048) { RN_SWITCH(4) } else { RN_SWITCH(8) }
+#undef RN_SWITCH
+#undef RN_LAUNCH
 #undef RN_ARGS
   VL_LAUNCH_CHECK();
   return 0;

@@ -223,7 +223,7 @@ def prefill_begin(stack: QwenStack, buf: PrefillBuffers, h, M):
 
 def prefill_layer(stack: QwenStack, lw: QwenLayerWeights, buf: PrefillBuffers, h, cache: KVCache, layer, rope, pos_ids, batch,
                   tok_per_batch, attn_mode, valid_len=None, blk_start=0, causal_off=0, kv_len=None, skip_post_attn=False,
-                  next_norm_w=None, slot_base=0, kv_ready=None):
+                  next_norm_w=None, slot_base=0):
     """One Qwen2DecoderLayer over M = batch*tok_per_batch rows with the big-GEMM kernels; K/V written to slots
     [slot_base, slot_base + tok_per_batch) of the cache (slot_base > 0: decode steps of models too wide for the
     weight-streaming kernels).  Expects buf.x = input_layernorm(h); leaves buf.x = next_norm(h_out) when
@@ -237,8 +237,6 @@ def prefill_layer(stack: QwenStack, lw: QwenLayerWeights, buf: PrefillBuffers, h
     x, q, ao, act = buf.x[:M], buf.q[:M], buf.ao[:M], buf.act[:M]
     ops.gemm(L.EPI_QKV_ROPE, x, lw.wqkv, bias=lw.bqkv, q_out=q, k_cache=cache.k[layer], vt_cache=cache.vt[layer], rope_cos=rope[0],
              rope_sin=rope[1], pos_ids=pos_ids, n_q_heads=nq, n_kv_heads=nkv, s_max=cache.s_max, tok_per_batch=tok_per_batch, slot_base=slot_base)
-    if kv_ready is not None:
-        kv_ready.record()                  # this layer's K / V^T rows are in the cache: a side stream may attend to them
     ks, vs = cache.strides()
     ops.attn_prefill(q, cache.k[layer], cache.vt[layer], ao, batch, tok_per_batch, tok_per_batch if kv_len is None else kv_len, nq, nkv, hd,
                      (tok_per_batch * nq * hd, hd, nq * hd), ks, vs, (tok_per_batch * nq * hd, nq * hd), cache.s_max, hd ** -0.5,
@@ -274,7 +272,7 @@ class SkinnyBuffers:
 
 def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in, partials, n_partials, cache: KVCache, layer, rope,
                  pos_ids, batch, tok_per_batch, slot_base, kv_len, attn_mode, valid_len=None, blk_start=0, skip_post_attn=False,
-                 wait_kv=None):
+                 first_tok_kv_len=0):
     """One decoder layer over M = batch*tok_per_batch <= 16 rows with the weight-streaming kernels (5 launches).
     Input residual = h_in + sum(partials) (partials = down_proj slabs of the previous layer).  Returns
     (h, partials, n_partials) describing this layer's output residual the same way."""
@@ -284,7 +282,7 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
     # the five argument structs of this (layer, input buffers, geometry) are built once and re-launched: only the cache slot,
     # the key count and its split factor change from step to step (greedy decode is otherwise host-bound on struct building)
     key = (layer, M, tok_per_batch, attn_mode, h_in.data_ptr(), 0 if partials is None else partials.data_ptr(), n_partials,
-           0 if valid_len is None else valid_len.data_ptr(), pos_ids.data_ptr(), cache.k.data_ptr(), skip_post_attn)
+           0 if valid_len is None else valid_len.data_ptr(), pos_ids.data_ptr(), cache.k.data_ptr(), skip_post_attn, first_tok_kv_len)
     plan = sb.plans.get(key)
     if plan is None:
         ks, vs = cache.strides()
@@ -295,7 +293,7 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
                                    tok_per_batch=tok_per_batch, slot_base=slot_base)
         plan.attn = ops.attn_skinny_args(sb.q, cache.k[layer], cache.vt[layer], sb.attn_parts, batch, tok_per_batch, kv_len, nq, nkv, hd,
                                          (tok_per_batch * nq * hd, hd, nq * hd), ks, vs, cache.s_max, hd ** -0.5, attn_mode, 1,
-                                         valid_len=valid_len, blk_start=blk_start)
+                                         valid_len=valid_len, blk_start=blk_start, first_tok_kv_len=first_tok_kv_len)
         if not skip_post_attn:
             plan.o = ops.skinny_args(None, lw.sk_o, M, out_f32=sb.part_o, attn_m=sb.attn_parts[0], attn_l=sb.attn_parts[1],
                                      attn_o=sb.attn_parts[2], attn_splits=1, attn_group=nq // nkv, attn_nq=tok_per_batch)
@@ -311,8 +309,6 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
     ops.launch_skinny(L.PRO_NORM, L.SK_QKV_ROPE, plan.qkv[0], stream)
     a = plan.attn
     a.kv_len, a.n_splits, a.blk_start = kv_len, nsp, blk_start
-    if wait_kv is not None:
-        torch.cuda.current_stream().wait_event(wait_kv)      # keys written by another stream (the VLM prefill of this layer)
     ops.launch_attn_skinny(a, stream)
     if skip_post_attn:
         return sb.hA, None, 0

@@ -104,7 +104,7 @@ def linear(x, W, bias=None, epi=None, res=None, ls=None, out=None, out_dtype=BF1
 
 # ------------------------------------------------------------------------------------------------ attention
 def _attn_args(q, k, vt, out, batch, sq, kv_len, n_q, n_kv, hd, q_str, k_str, vt_str, o_str, ld_vt, scale, mode,
-               causal_off=0, valid_len=None, blk_start=0, q_row_off=0, parts=None, n_splits=1):
+               causal_off=0, valid_len=None, blk_start=0, q_row_off=0, parts=None, n_splits=1, first_tok_kv_len=0):
     a = L.AttnArgs()
     a.q, a.k, a.vt, a.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), _p(out)
     a.batch, a.sq, a.kv_len, a.n_q_heads, a.n_kv_heads, a.head_dim = batch, sq, kv_len, n_q, n_kv, hd
@@ -118,6 +118,7 @@ def _attn_args(q, k, vt, out, batch, sq, kv_len, n_q, n_kv, hd, q_str, k_str, vt
     if parts is not None:
         a.part_m, a.part_l, a.part_o = parts[0].data_ptr(), parts[1].data_ptr(), parts[2].data_ptr()
     a.n_splits = n_splits
+    a.first_tok_kv_len = first_tok_kv_len
     return a
 
 

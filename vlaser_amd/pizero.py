@@ -52,7 +52,7 @@ def canonicalize_vla_state_dict(sd):
 
 
 class PiZero:
-    def __init__(self, cfg: VLAConfig, device='cuda', max_batch=1, use_graph=True):
+    def __init__(self, cfg: VLAConfig, device='cuda', max_batch=1, use_graph=True, ride_proprio=True):
         L.lib()
         if not torch.cuda.is_available():
             raise L.VlaserHipError('vlaser_amd needs an MI355X (gfx950) GPU: there is no CPU fallback')
@@ -71,6 +71,7 @@ class PiZero:
         self.num_images = cfg.cond_steps
         self.max_batch = max_batch
         self.use_graph = use_graph
+        self.ride_proprio = ride_proprio        # batch 1: proprio row processed with the action rows of Euler step 0 (see _run)
         self._graphs = {}
         if max_batch * cfg.num_action_tokens > 16:
             raise ValueError('the weight-streaming action path handles batch * horizon <= 16 rows')
@@ -115,6 +116,8 @@ class PiZero:
         self.xcat = z(16, 2 * W)
         self.e2 = z(16, W)
         self.h_act = z(16, W)
+        self.h5 = z(16, W)                      # batch 1: [proprio row | action rows] of Euler step 0
+        self.action5 = z(16, cfg.action_dim, dt=torch.float32)
         self.action = z(16, cfg.action_dim, dt=torch.float32)
         self.rank_ws = z(B * T, dt=torch.int32)
         self.valid_len = z(B, dt=torch.int32)
@@ -126,7 +129,7 @@ class PiZero:
         self.pos_vlm = z(B * T, dt=torch.int32)
         self.pos_pro = z(B, dt=torch.int32)
         self.pos_act = z(B * self.num_action_tokens, dt=torch.int32)
-        self.side_stream = torch.cuda.Stream(device=dev)
+        self.pos5 = z(16, dt=torch.int32)
 
     # ------------------------------------------------------------------ reference helpers (API parity)
     def build_causal_mask_and_position_ids(self, attention_mask, dtype):
@@ -151,43 +154,59 @@ class PiZero:
         h_vlm = self.h_vlm[:B * T]
         ops.embed_merge(self.in_ids[:B], self.vlm.embed, feats, h_vlm, self.image_token_index, self.pad_token_id, True, self.rank_ws)
         # a13: joint prefill over {vlm, proprio}; K/V of both mixtures cached (post-RoPE), last layer skips o_proj+MLP.
-        # The proprio token's expert layers (5 weight-streaming launches each, ~30 us per layer of pure latency) only need the VLM
-        # keys of their own layer, and the VLM rows never look at the proprio token: the proprio chain runs on a side stream (a
-        # parallel branch of the HIP graph) underneath the VLM's MFMA GEMMs instead of between them.
-        main, side = torch.cuda.current_stream(), self.side_stream
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
+        # Batch 1: the proprio token does NOT get its own pass through the expert (28 x 5 weight-streaming launches, ~0.85 ms of pure
+        # latency): it rides in front of the 4 action rows of Euler step 0 (M = 5).  Its rows of the block mask (prefix + itself,
+        # pizero_internvl.py:517-587) only differ from the action rows' in the block keys they see (first_tok_kv_len), no row looks at
+        # a later row's output, and the per-row arithmetic of the <= 16-row kernels does not depend on M -- so its K / V^T (slot T)
+        # and every action are bit-identical to the separate pass, and the expert's weights are streamed once for both.
+        # (An HIP-graph side branch was tried first: graph replay runs the branches back to back, 0.9 % kernel overlap in rocprof.)
+        ride = self.ride_proprio and B == 1
+        M = B * na
+        if ride:
+            ops.small_linear(self.in_proprio, self.pe_w, self.pe_b, self.h5, B, cfg.action_hidden_size, cfg.proprio_dim)      # row 0
+        else:
             ops.small_linear(self.in_proprio, self.pe_w, self.pe_b, self.h_pro, B, cfg.action_hidden_size, cfg.proprio_dim)
         h_pro, parts, npart = self.h_pro, None, 0
         prefill_begin(self.vlm, self.pbuf, h_vlm, B * T)
         for i in range(nL):
             last = i == nL - 1
-            kv_ready = torch.cuda.Event()
             prefill_layer(self.vlm, self.vlm.layers[i], self.pbuf, h_vlm, self.cache, i, self.rope, self.pos_vlm, B, T,
                           L.ATTN_PREFIX, valid_len=self.valid_len, blk_start=T, skip_post_attn=last,
-                          next_norm_w=None if last else self.vlm.layers[i + 1].ln_in, kv_ready=kv_ready)
-            with torch.cuda.stream(side):
+                          next_norm_w=None if last else self.vlm.layers[i + 1].ln_in)
+            if not ride:
                 h_pro, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_pro, h_pro, parts, npart, self.cache, i,
                                                    self.rope, self.pos_pro, B, 1, T, T + 1, L.ATTN_PREFIX, valid_len=self.valid_len,
-                                                   blk_start=T, skip_post_attn=last, wait_kv=kv_ready)
-        main.wait_stream(side)
+                                                   blk_start=T, skip_post_attn=last)
         # a14: flow-matching Euler integration over the cached prefix
-        M = B * na
-        self.action[:M].copy_(self.in_noise[:M])
         n = self.num_inference_steps
         dt = 1.0 / n
         W = cfg.action_hidden_size
+        clip = self.final_action_clip_value
+        if ride:
+            self.action5[1:1 + M].copy_(self.in_noise[:M])
+        else:
+            self.action[:M].copy_(self.in_noise[:M])
         for s in range(n):
             t = s * dt
-            ops.vla_prep(self.action, self.ae_w1, self.ae_b1, self.xcat, M, W, cfg.action_dim, t, cfg.time_max_period)
+            first = ride and s == 0
+            ops.vla_prep(self.action5[1:1 + M] if first else self.action, self.ae_w1, self.ae_b1, self.xcat, M, W, cfg.action_dim, t, cfg.time_max_period)
             ops.skinny(L.PRO_PLAIN, L.SK_BIAS_SILU, self.xcat, self.ae_w2, M, out=self.e2, ldo=W, bias=self.ae_b2)
-            ops.skinny(L.PRO_PLAIN, L.SK_BIAS, self.e2, self.ae_w3, M, out=self.h_act, ldo=W, bias=self.ae_b3)
+            ops.skinny(L.PRO_PLAIN, L.SK_BIAS, self.e2, self.ae_w3, M, out=self.h5[1:1 + M] if first else self.h_act, ldo=W, bias=self.ae_b3)
+            if first:
+                h, parts, npart = self.h5, None, 0
+                for i in range(nL):
+                    h, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_pro, h, parts, npart, self.cache, i, self.rope,
+                                                   self.pos5, B, na + 1, T, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len, blk_start=T,
+                                                   first_tok_kv_len=T + 1)
+                ops.vla_euler(h, parts, npart, M + 1, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action5, W, cfg.action_dim, dt,
+                              clip if clip is not None else 0.0, clip is not None and s == n - 1)
+                self.action[:M].copy_(self.action5[1:1 + M])          # row 0 of action5 (the proprio row's "velocity") is scratch
+                continue
             h, parts, npart = self.h_act, None, 0
             for i in range(nL):
                 h, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_act, h, parts, npart, self.cache, i, self.rope,
                                                self.pos_act, B, na, T + 1, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len,
                                                blk_start=T)
-            clip = self.final_action_clip_value
             ops.vla_euler(h, parts, npart, M, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action, W, cfg.action_dim, dt,
                           clip if clip is not None else 0.0, clip is not None and s == n - 1)
 
@@ -229,6 +248,9 @@ class PiZero:
         self.pos_vlm[:B * T].copy_(bpos(vlm_position_ids, torch.arange(1, T + 1).repeat(B, 1)))
         self.pos_pro[:B].copy_(bpos(proprio_position_ids, torch.ones(B, 1, dtype=torch.long)))
         self.pos_act[:B * na].copy_(bpos(action_position_ids, torch.arange(2, 2 + na).repeat(B, 1)))
+        if B == 1:
+            self.pos5[:1].copy_(self.pos_pro[:1])
+            self.pos5[1:1 + na].copy_(self.pos_act[:na])
         if noise is None:
             noise = torch.randn((B, na, cfg.action_dim), generator=generator)      # reference: torch.randn inside (:879-881)
         self.in_noise[:B * na].copy_(noise.reshape(B * na, -1).to(torch.float32))
