@@ -162,8 +162,36 @@ def infer_action(sd, vla, input_ids, pixel_values, image_text_proprio_mask, acti
         action = action + dt_step * vel
         t = t + dt_step
         if return_trace:
-            trace.append(action.clone())
+            trace.append((action.clone(), vel.clone()))
     if vla.final_action_clip_value is not None:
         action = torch.clamp(action, -vla.final_action_clip_value, vla.final_action_clip_value)
     action = action[:, -vla.horizon_steps:]
     return (action, caches, trace) if return_trace else action
+
+
+def infer_action_naive(sd, vla, input_ids, pixel_values, causal_mask, vlm_position_ids, proprio_position_ids, action_position_ids,
+                       proprios, noise, return_trace=False):
+    """PiZero.infer_action_naive (pizero_internvl.py:938-1003): no KV cache -- every Euler step runs ONE joint pass over all three
+    mixtures (cache_mode="no_append") under the full [B,1,389,389] block mask.  (The reference's method omits
+    `position_embeddings_all` and raises KeyError on the InternVL path; tools/gen_golden.py drives the same JointModel.forward
+    calls with that argument supplied -- golden G7b.)"""
+    dt = pixel_values.dtype
+    bsz = pixel_values.shape[0]
+    embeds = embed_image_text(sd, vla, input_ids, pixel_values)
+    pro = F.linear(proprios, sd['proprio_encoder.weight'], sd['proprio_encoder.bias'])
+    action = noise.clone().to(dt)
+    n = vla.num_inference_steps
+    t = torch.zeros(bsz, dtype=dt)
+    trace = []
+    for _ in range(n):
+        temb = sinusoidal_pos_emb(t, vla.action_hidden_size, vla.time_max_period)
+        ae = action_encoder(sd, action, temb)
+        out = joint_forward(sd, vla, {'vlm': embeds.clone(), 'proprio': pro.clone(), 'action': ae},
+                            {'vlm': vlm_position_ids, 'proprio': proprio_position_ids, 'action': action_position_ids}, causal_mask, {})['action']
+        vel = F.linear(out, sd['action_decoder.weight'], sd['action_decoder.bias'])
+        action = action + vel / n
+        t = t + 1.0 / n
+        trace.append(vel.clone())
+    if vla.final_action_clip_value is not None:
+        action = torch.clamp(action, -vla.final_action_clip_value, vla.final_action_clip_value)
+    return (action, trace) if return_trace else action

@@ -259,6 +259,83 @@ def test_infer_action_vs_golden(pz, golden_dir):
         assert torch.equal(act, act2)
 
 
+def test_infer_action_internals_vs_reference_trace(pz, golden_dir):
+    """VERDICT r01 #3a/b: the action chunk within 1e-2 (and relative to the model-dependent part of the signal, action - clip(noise)),
+    the decoder velocity of EVERY Euler step, and the cached K / V of the first and last layer (VLM positions + proprio token)
+    against what the reference's own infer_action produced internally (golden G7b)."""
+    d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))
+    t = np.load(os.path.join(golden_dir, 'g7b_vla_trace.npz'))
+    T = pz.max_image_text_tokens
+    for case in ('a', 'b'):
+        ids, pv, m1, m2, vp, pp, ap, pro, noise = _vla_inputs(d, case, pz)
+        act = pz.infer_action(ids, pv, m1, m2, vp, pp, ap, pro, noise=noise).cpu()
+        ref = torch.from_numpy(d[f'{case}_action'])
+        err = (act - ref).abs().max().item()
+        sig = (ref - noise.clamp(-1, 1))
+        live = ref.abs() < 1.0                                             # entries the final clip did not saturate
+        rel = ((act - ref)[live].norm() / sig[live].norm()).item()
+        print(f'case {case}: action max|err| {err:.3e}, rel to signal {rel:.3e}')
+        assert err < 1e-2 and rel < 2.5e-2
+        vel = pz.last_velocities()[:, 0].cpu()
+        rv = torch.from_numpy(t[f'{case}_vel'])
+        verr = (vel - rv).abs().amax(dim=(1, 2))
+        print('  per-step max|vel err|', [f'{x:.2e}' for x in verr.tolist()], 'ref max', rv.abs().max().item())
+        assert (verr < 1.5e-2 * max(1.0, rv.abs().max().item())).all()
+        pos = torch.from_numpy(t[f'{case}_kv_pos']).long()
+        for li in (0, int(t[f'{case}_n_layers']) - 1):
+            k = pz.cache.k[li, 0].float().cpu()                            # [n_kv, S_max, 128]
+            vt = pz.cache.vt[li, 0].float().cpu()                          # [n_kv, 128, S_max]
+            for name, got, want in [('k_vlm', k[:, pos], t[f'{case}_k_vlm_L{li}']), ('v_vlm', vt[:, :, pos].transpose(1, 2), t[f'{case}_v_vlm_L{li}']),
+                                    ('k_pro', k[:, T], t[f'{case}_k_pro_L{li}']), ('v_pro', vt[:, :, T], t[f'{case}_v_pro_L{li}'])]:
+                want = torch.from_numpy(want)
+                e = (got - want).abs().max().item()
+                assert e < 2e-2 * want.abs().max().item() + 1e-3, (case, li, name, e, want.abs().max().item())
+
+
+def test_infer_action_naive_equals_cached(golden_model, golden_dir):
+    """VERDICT r01 #3d: the cache-free surface (`infer_action_naive`: every step re-runs the joint pass; here on the MFMA GEMM +
+    prefill-attention kernels for the expert rows) against the cached path (weight-streaming kernels) and against the reference's
+    cache-free result (G7b)."""
+    from vlaser_amd.pizero import PiZeroInference
+    _, vla, sd = golden_model
+    d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))
+    t = np.load(os.path.join(golden_dir, 'g7b_vla_trace.npz'))
+    m = PiZeroInference(vla, max_batch=1, naive_support=True); m.load_state_dict(sd)
+    for case in ('a', 'b'):
+        ids, pv, m1, m2, vp, pp, ap, pro, noise = _vla_inputs(d, case, m)
+        cached = m.infer_action(ids, pv, m1, m2, vp, pp, ap, pro, noise=noise).cpu()
+        am = (ids != 151643).long()
+        mask, _, _, _ = m.build_causal_mask_and_position_ids(am, torch.float32)
+        naive = m.infer_action_naive(ids, pv, mask, vp, pp, ap, pro, noise=noise).cpu()
+        dn = (naive - cached).abs().max().item()
+        dr = (naive - torch.from_numpy(t[f'{case}_action_naive'])).abs().max().item()
+        print(f'case {case}: naive vs cached {dn:.3e}, naive vs reference naive {dr:.3e}')
+        assert dn < 5e-3 and dr < 1e-2
+
+
+def test_infer_text_equals_chat_model_logits(golden_model):
+    """VERDICT r01 #3d: `infer_text` (VLM mixture alone through the joint path + lm_head, pizero_internvl.py:1005-1046) must
+    reproduce InternVLChatModel's logits."""
+    from oracle import vlm as ovlm
+    from vlaser_amd.internvl_chat import InternVLChatModel
+    from vlaser_amd.pizero import PiZeroInference
+    cfg, vla, sd = golden_model
+    g = torch.Generator().manual_seed(3)
+    pv = torch.randn(1, 3, 448, 448, generator=g)
+    ids = torch.cat([torch.randint(0, 151643, (12,), generator=g), torch.full((256,), cfg.img_context_token_id),
+                     torch.randint(0, 151643, (20,), generator=g)])[None]
+    pz_ = PiZeroInference(vla, max_batch=1); pz_.load_state_dict(sd)
+    lt = pz_.infer_text(ids, pv, torch.ones_like(ids))['logits'].cpu()
+    chat = InternVLChatModel(cfg, max_seq_len=320); chat.load_state_dict({k: v for k, v in sd.items() if k.startswith(('vision_model.', 'mlp1.', 'language_model.'))})
+    chat.img_context_token_id = cfg.img_context_token_id
+    lc = chat.forward(pv, ids, image_flags=torch.ones(1, 1, dtype=torch.long)).logits.cpu()
+    assert lt.shape == lc.shape
+    assert (lt - lc).abs().max().item() < 2e-3 * lc.abs().max().item()          # same kernels, same weights
+    ref = ovlm.forward_logits(sd, cfg, pv, ids)
+    assert (lt[0, -4:] - ref[0, -4:]).abs().max().item() < 3e-2 * ref[0, -4:].abs().max().item()
+    assert lt[0, -1].argmax().item() == ref[0, -1].argmax().item()
+
+
 def test_infer_action_batch2_equals_singles(pz, golden_dir):
     d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))
     a, b = _vla_inputs(d, 'a', pz), _vla_inputs(d, 'b', pz)

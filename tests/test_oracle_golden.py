@@ -136,3 +136,36 @@ def test_infer_action(golden_dir, golden_model):
         act = ovla.infer_action(sd, vla, ids, pv, m1, m2, vp, pp, ap, torch.from_numpy(d[f'{case}_proprio']),
                                 torch.from_numpy(d[f'{case}_noise']))
         np.testing.assert_allclose(act.numpy(), d[f'{case}_action'], rtol=0, atol=2e-5)
+
+
+def test_infer_action_trace_kv_and_naive(golden_dir, golden_model):
+    """G7b: per-Euler-step velocities, K / V cache slices (first / last layer) and the cache-free path, all from the reference's
+    own infer_action / JointModel.forward (tools/gen_golden.py:g7b_trace)."""
+    _, vla, sd = golden_model
+    d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))
+    t = np.load(os.path.join(golden_dir, 'g7b_vla_trace.npz'))
+    for case in ('a', 'b'):
+        g = torch.Generator().manual_seed(int(d[f'{case}_seed']))
+        pv = torch.randn(1, 3, 448, 448, generator=g)
+        ids = torch.from_numpy(d[f'{case}_input_ids'])
+        am = (ids != vla.base.pad_token_id).long()
+        m, vp, pp, ap = ovla.build_causal_mask_and_position_ids(am, torch.float32, vla)
+        m1, m2 = ovla.split_full_mask_into_submasks(m, vla)
+        pro, noise = torch.from_numpy(d[f'{case}_proprio']), torch.from_numpy(d[f'{case}_noise'])
+        np.testing.assert_array_equal(t[f'{case}_action'], d[f'{case}_action'])          # same reference run as G7
+        act, caches, trace = ovla.infer_action(sd, vla, ids, pv, m1, m2, vp, pp, ap, pro, noise, return_trace=True)
+        vel = torch.stack([v for _, v in trace], 0)[:, 0]
+        np.testing.assert_allclose(vel.numpy(), t[f'{case}_vel'], rtol=0, atol=5e-5)
+        pos = torch.from_numpy(t[f'{case}_kv_pos'])
+        for li in (0, int(t[f'{case}_n_layers']) - 1):
+            k, v = caches['vlm'][li]
+            np.testing.assert_allclose(k[0][:, pos].numpy(), t[f'{case}_k_vlm_L{li}'], rtol=0, atol=2e-5)
+            np.testing.assert_allclose(v[0][:, pos].numpy(), t[f'{case}_v_vlm_L{li}'], rtol=0, atol=2e-5)
+            k, v = caches['proprio'][li]
+            np.testing.assert_allclose(k[0, :, 0].numpy(), t[f'{case}_k_pro_L{li}'], rtol=0, atol=2e-5)
+            np.testing.assert_allclose(v[0, :, 0].numpy(), t[f'{case}_v_pro_L{li}'], rtol=0, atol=2e-5)
+        naive, ntrace = ovla.infer_action_naive(sd, vla, ids, pv, m, vp, pp, ap, pro, noise, return_trace=True)
+        np.testing.assert_allclose(naive.numpy(), t[f'{case}_action_naive'], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(torch.stack(ntrace, 0)[:, 0].numpy(), t[f'{case}_vel_naive'], rtol=0, atol=5e-5)
+        # cached == naive in fp32 (the reference's own remark, eval.py:131-137)
+        assert (act - naive[:, -vla.horizon_steps:]).abs().max().item() < 1e-5

@@ -358,6 +358,98 @@ def g7_vla(vla, sd, ref_vlm):
     return fake
 
 
+def _g7_case(fake, seed, n_valid):
+    g = torch.Generator().manual_seed(seed)
+    pv = torch.randn(1, 3, 448, 448, generator=g)
+    ids = torch.full((1, 384), 151643)
+    n_text = n_valid - 10 - 256
+    ids[0, :10] = torch.randint(0, 151643, (10,), generator=g)
+    ids[0, 10:266] = 151667
+    ids[0, 266:266 + n_text] = torch.randint(0, 151643, (n_text,), generator=g)
+    am = (ids != 151643).long()
+    proprio = torch.rand(1, 1, 7, generator=g) * 2 - 1
+    mask, vp, pp, ap = RP.PiZero.build_causal_mask_and_position_ids(fake, am, torch.float32)
+    return pv, ids, am, proprio, mask, vp, pp, ap
+
+
+def _infer_action_naive(self, input_ids, pixel_values, causal_mask, vlm_position_ids, proprio_position_ids, action_position_ids, proprios):
+    """The reference's `infer_action_naive` (pizero_internvl.py:938-1003) cannot run on the InternVL path as shipped: it never
+    passes `position_embeddings_all`, which `forward_mixture_attn_internvl` indexes unconditionally (joint_model.py:549, KeyError
+    'vlm').  This driver makes the SAME calls in the same order -- the reference's own JointModel.forward with all three mixtures
+    active and cache_mode="no_append" every Euler step -- with that one argument supplied the way `infer_action` builds it
+    (:854-855,895)."""
+    bsz = pixel_values.size(0)
+    kv_caches = self.joint_model.build_mixture_caches()
+    inputs_embeds = self._forward_siglip_and_text_embedding(input_ids, pixel_values)
+    proprio_embeds = self.proprio_encoder(proprios)
+    rot_v = self.internvl_model.language_model.model.rotary_emb
+    rot_a = self.internvl_model.action_expert.model.rotary_emb
+    action = torch.randn((bsz, self.horizon_steps, self.action_dim))
+    delta_t = 1.0 / self.num_inference_steps
+    t = torch.zeros(bsz)
+    for _ in range(self.num_inference_steps):
+        time_cond = self.time_embedding(t)
+        action_embeds = self.action_encoder(action, time_cond)
+        pe = {'vlm': rot_v(inputs_embeds, vlm_position_ids), 'proprio': rot_a(proprio_embeds, proprio_position_ids),
+              'action': rot_a(action_embeds, action_position_ids)}
+        action_embeds = self.joint_model(
+            attention_mask=causal_mask,
+            position_ids_all={'vlm': vlm_position_ids, 'proprio': proprio_position_ids, 'action': action_position_ids},
+            embeds_all={'vlm': inputs_embeds.clone(), 'proprio': proprio_embeds.clone(), 'action': action_embeds},
+            time_cond=time_cond, kv_caches=kv_caches, position_embeddings_all=pe, cache_mode='no_append')['action']
+        action = action + delta_t * self.action_decoder(action_embeds)
+        t = t + delta_t
+    if self.final_action_clip_value is not None:
+        action = torch.clamp(action, -self.final_action_clip_value, self.final_action_clip_value)
+    return action
+
+
+def g7b_trace(fake, vla):
+    """G7b: what happens INSIDE the reference's infer_action for the two G7 cases -- the velocity the action decoder returns at every
+    Euler step (forward hook on `action_decoder`), slices of the K / V caches the joint prefill leaves behind (kv_cache.py:6-46;
+    first and last layer, a few VLM positions + the proprio token), and the cache-free path (`_infer_action_naive` above: the
+    reference's JointModel.forward with all three mixtures in one joint pass per step, pizero_internvl.py:938-1003)."""
+    d = {}
+    vels = []
+    hook = fake.action_decoder.register_forward_hook(lambda m, i, o: vels.append(o.detach().clone()))
+    orig_build = fake.joint_model.build_mixture_caches
+    for case, (seed, n_valid) in {'a': (0, 277), 'b': (1, 300)}.items():
+        pv, ids, am, proprio, mask, vp, pp, ap = _g7_case(fake, seed, n_valid)
+        m1, m2 = RP.PiZero.split_full_mask_into_submasks(fake, mask)
+        grabbed = {}
+
+        def build():
+            grabbed['c'] = orig_build()
+            return grabbed['c']
+        fake.joint_model.build_mixture_caches = build
+        vels.clear()
+        torch.manual_seed(1234 + seed)
+        act = RP.PiZero.infer_action(fake, ids, pv, m1, m2, vp, pp, ap, proprio)
+        d[f'{case}_action'] = act.numpy()
+        d[f'{case}_vel'] = torch.stack(vels, 0)[:, 0].numpy()                    # [n_steps, 4, 7]
+        kv = grabbed['c']
+        nl = len(kv['vlm'].key_cache)
+        pos = np.array([0, 9, 10, 137, 265, n_valid - 1])
+        d[f'{case}_kv_pos'] = pos
+        for li in (0, nl - 1):
+            kc, vc = kv['vlm'].get(li)                                            # [1, n_kv, 384, 128], K after RoPE
+            d[f'{case}_k_vlm_L{li}'] = kc[0][:, pos].numpy(); d[f'{case}_v_vlm_L{li}'] = vc[0][:, pos].numpy()
+            kp, vp_ = kv['proprio'].get(li)                                       # [1, n_kv, 1, 128]
+            d[f'{case}_k_pro_L{li}'] = kp[0, :, 0].numpy(); d[f'{case}_v_pro_L{li}'] = vp_[0, :, 0].numpy()
+        d[f'{case}_n_layers'] = np.array(nl)
+        # the reference's cache-free path on the same noise
+        fake.joint_model.build_mixture_caches = orig_build
+        vels.clear()
+        torch.manual_seed(1234 + seed)
+        naive = _infer_action_naive(fake, ids, pv, mask, vp, pp, ap, proprio)
+        d[f'{case}_action_naive'] = naive.numpy()
+        d[f'{case}_vel_naive'] = torch.stack(vels, 0)[:, 0].numpy()
+        print('G7b', case, 'cached vs naive max diff', (act - naive).abs().max().item())
+    hook.remove()
+    fake.joint_model.build_mixture_caches = orig_build
+    np.savez_compressed(os.path.join(OUT, 'g7b_vla_trace.npz'), **d)
+
+
 def g8_sft_grads(cfg, ref_vlm):
     """SFT step gradients from the REFERENCE's own forward + torch autograd (modeling_internvl_chat.py:143-255 with labels): the
     same sample as G5's sft_loss (seed 0, labels on the last 16 positions), vision tower frozen (freeze_backbone), every LLM /
@@ -394,6 +486,12 @@ def main():
         sd = synth.vla_state_dict(C.VLAConfig(base=cfg), with_head=True)
         vlm_sd = {k: v for k, v in sd.items() if k.startswith(('vision_model.', 'mlp1.', 'language_model.'))}
         return g8_sft_grads(cfg, build_ref_vlm(cfg, vlm_sd))
+    if '--only-g7' in sys.argv:
+        cfg = C.truncated(C.vlaser_2b(), VIT_L, LLM_L)
+        vla = C.VLAConfig(base=cfg)
+        sd = synth.vla_state_dict(vla, with_head=True)
+        vlm_sd = {k: v for k, v in sd.items() if k.startswith(('vision_model.', 'mlp1.', 'language_model.'))}
+        return g7b_trace(g7_vla(vla, sd, build_ref_vlm(cfg, vlm_sd)), vla)
     if '--only-g6b' not in sys.argv:
         tok = ref_import.tokenizer()
         g1_prompts(tok)
@@ -408,7 +506,7 @@ def main():
     g6b_ragged(cfg, ref_vlm)
     g3_g4(ref_vlm)
     g5_g6(cfg, sd, ref_vlm)
-    g7_vla(vla, sd, ref_vlm)
+    g7b_trace(g7_vla(vla, sd, ref_vlm), vla)
     g8_sft_grads(cfg, build_ref_vlm(cfg, vlm_sd))
     meta = dict(vit_layers=VIT_L, llm_layers=LLM_L, widths='vlaser-2b', weights='vlaser_amd.synth seed 0',
                 torch=torch.__version__, transformers=__import__('transformers').__version__,

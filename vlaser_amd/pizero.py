@@ -52,7 +52,7 @@ def canonicalize_vla_state_dict(sd):
 
 
 class PiZero:
-    def __init__(self, cfg: VLAConfig, device='cuda', max_batch=1, use_graph=True, ride_proprio=True):
+    def __init__(self, cfg: VLAConfig, device='cuda', max_batch=1, use_graph=True, ride_proprio=True, naive_support=False):
         L.lib()
         if not torch.cuda.is_available():
             raise L.VlaserHipError('vlaser_amd needs an MI355X (gfx950) GPU: there is no CPU fallback')
@@ -71,6 +71,7 @@ class PiZero:
         self.num_images = cfg.cond_steps
         self.max_batch = max_batch
         self.use_graph = use_graph
+        self.naive_support = naive_support      # keep the expert's un-packed weights for infer_action_naive (tests)
         self.ride_proprio = ride_proprio        # batch 1: proprio row processed with the action rows of Euler step 0 (see _run)
         self._graphs = {}
         if max_batch * cfg.num_action_tokens > 16:
@@ -88,7 +89,9 @@ class PiZero:
         cfg, dev = self.cfg, self.device
         base = cfg.base
         self.vit = VitEngine(sd, base, dev, max_tiles=self.max_batch * self.num_images)
-        self.vlm = QwenStack(sd, 'language_model.', base.llm, dev, with_embed=True, with_head=False, gemm=True, skinny=False)
+        self.vlm = QwenStack(sd, 'language_model.', base.llm, dev, with_embed=True, with_head=True, gemm=True, skinny=False)   # lm_head (if present): infer_text only
+        self._sd_expert = {k: v for k, v in sd.items() if k.startswith('action_expert.')} if self.naive_support else None
+        self.expert_gemm = None
         self.expert = QwenStack(sd, 'action_expert.', cfg.expert, dev, with_embed=False, with_head=False, gemm=False, skinny=True)
         g = lambda k: sd[k].to(device=dev, dtype=BF).contiguous()
         self.ae_w1, self.ae_b1 = g('action_encoder.linear_1.weight'), g('action_encoder.linear_1.bias')
@@ -118,6 +121,8 @@ class PiZero:
         self.h_act = z(16, W)
         self.h5 = z(16, W)                      # batch 1: [proprio row | action rows] of Euler step 0
         self.action5 = z(16, cfg.action_dim, dt=torch.float32)
+        self.vel5 = z(16, cfg.action_dim, dt=torch.float32)
+        self.vel_trace = z(cfg.num_inference_steps, 16, cfg.action_dim, dt=torch.float32)   # decoder output of every Euler step
         self.action = z(16, cfg.action_dim, dt=torch.float32)
         self.rank_ws = z(B * T, dt=torch.int32)
         self.valid_len = z(B, dt=torch.int32)
@@ -199,8 +204,9 @@ class PiZero:
                                                    self.pos5, B, na + 1, T, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len, blk_start=T,
                                                    first_tok_kv_len=T + 1)
                 ops.vla_euler(h, parts, npart, M + 1, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action5, W, cfg.action_dim, dt,
-                              clip if clip is not None else 0.0, clip is not None and s == n - 1)
+                              clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel5)
                 self.action[:M].copy_(self.action5[1:1 + M])          # row 0 of action5 (the proprio row's "velocity") is scratch
+                self.vel_trace[s, :M].copy_(self.vel5[1:1 + M])
                 continue
             h, parts, npart = self.h_act, None, 0
             for i in range(nL):
@@ -208,7 +214,7 @@ class PiZero:
                                                self.pos_act, B, na, T + 1, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len,
                                                blk_start=T)
             ops.vla_euler(h, parts, npart, M, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action, W, cfg.action_dim, dt,
-                          clip if clip is not None else 0.0, clip is not None and s == n - 1)
+                          clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel_trace[s])
 
     @torch.no_grad()
     def infer_action(self, input_ids, pixel_values, image_text_proprio_mask=None, action_mask=None, vlm_position_ids=None,
@@ -269,6 +275,116 @@ class PiZero:
             self._run(B)
         act = self.action[:B * na].view(B, na, cfg.action_dim)
         return act[:, -cfg.horizon_steps:].clone()
+
+    def last_velocities(self, B=1):
+        """Decoder output (velocity) of every Euler step of the last infer_action call: fp32 [n_steps, B, horizon, action_dim]
+        (the `action_vel` of pizero_internvl.py:911; golden G7b pins it per step)."""
+        na = self.num_action_tokens
+        return self.vel_trace[:, :B * na].view(self.num_inference_steps, B, na, -1).clone()
+
+    @torch.no_grad()
+    def infer_action_naive(self, input_ids, pixel_values, causal_mask=None, vlm_position_ids=None, proprio_position_ids=None,
+                           action_position_ids=None, proprios=None, noise=None, generator=None, valid_len=None):
+        """Mirror of `PiZero.infer_action_naive` (pizero_internvl.py:938-1003): no reuse of cached keys -- EVERY Euler step
+        re-runs the joint pass over {vlm, proprio, action} (`cache_mode="no_append"`).  It is a self-consistency surface, not a hot
+        path, and it deliberately takes the OTHER kernels: the 5 expert rows go through the MFMA GEMM kernels + the prefill
+        attention kernel (block mask as two PREFIX launches) instead of the weight-streaming <= 16-row kernels + the key-split
+        attention -- so `infer_action == infer_action_naive` cross-checks the two implementations (the reference remarks ~1e-3 in
+        bf16, none in fp32: eval.py:131-137).  Batch 1."""
+        cfg, dev = self.cfg, self.device
+        base, llm, ex = cfg.base, cfg.base.llm, cfg.expert
+        T, na, nL = self.max_image_text_tokens, self.num_action_tokens, llm.num_hidden_layers
+        B = pixel_values.shape[0] // self.num_images
+        if B != 1:
+            raise NotImplementedError('infer_action_naive: batch 1')
+        if self._sd_expert is None:
+            raise RuntimeError('construct PiZero(..., naive_support=True) to keep the weights infer_action_naive needs')
+        if self.expert_gemm is None:
+            self.expert_gemm = QwenStack(self._sd_expert, 'action_expert.', ex, dev, with_embed=False, with_head=False, gemm=True, skinny=False)
+            self.ebuf = PrefillBuffers(self.expert_gemm, 16, dev)
+        # inputs exactly as infer_action stages them
+        self.in_ids[:1].copy_(input_ids)
+        pv = pixel_values.to(dev)
+        if pv.dtype == torch.float32:
+            ops.cast_f32_bf16(pv.contiguous(), self.in_pix[:self.num_images])
+        else:
+            self.in_pix[:self.num_images].copy_(pv)
+        self.in_proprio[:1].copy_(proprios.reshape(1, -1).to(torch.float32))
+        if valid_len is None:
+            valid_len = prep.mask_to_descriptor(causal_mask[:, :, :T + 1, :T + 1].to('cpu'), T) if causal_mask is not None else (input_ids != self.pad_token_id).sum(-1)
+        self.valid_len[:1].copy_(valid_len.to(torch.int32))
+        bpos = lambda p, default: (default if p is None else p).to(torch.int32).reshape(-1)
+        self.pos_vlm[:T].copy_(bpos(vlm_position_ids, torch.arange(1, T + 1)[None]))
+        self.pos_pro[:1].copy_(bpos(proprio_position_ids, torch.ones(1, 1, dtype=torch.long)))
+        self.pos_act[:na].copy_(bpos(action_position_ids, torch.arange(2, 2 + na)[None]))
+        if noise is None:
+            noise = torch.randn((1, na, cfg.action_dim), generator=generator)
+        self.action[:na].copy_(noise.reshape(na, -1).to(torch.float32))
+        feats = self.vit.forward(self.in_pix[:self.num_images])
+        W, n = cfg.action_hidden_size, self.num_inference_steps
+        dt = 1.0 / n
+        clip = self.final_action_clip_value
+        eg, eb = self.expert_gemm, self.ebuf
+        for s in range(n):
+            h_vlm = self.h_vlm[:T]
+            ops.embed_merge(self.in_ids[:1], self.vlm.embed, feats, h_vlm, self.image_token_index, self.pad_token_id, True, self.rank_ws)
+            ops.small_linear(self.in_proprio, self.pe_w, self.pe_b, self.h_pro, 1, W, cfg.proprio_dim)
+            ops.vla_prep(self.action, self.ae_w1, self.ae_b1, self.xcat, na, W, cfg.action_dim, s * dt, cfg.time_max_period)
+            ops.skinny(L.PRO_PLAIN, L.SK_BIAS_SILU, self.xcat, self.ae_w2, na, out=self.e2, ldo=W, bias=self.ae_b2)
+            ops.skinny(L.PRO_PLAIN, L.SK_BIAS, self.e2, self.ae_w3, na, out=self.h_act, ldo=W, bias=self.ae_b3)
+            h_pro, h_act = self.h_pro[:1], self.h_act[:na]
+            prefill_begin(self.vlm, self.pbuf, h_vlm, T)
+            for i in range(nL):
+                last = i == nL - 1
+                prefill_layer(self.vlm, self.vlm.layers[i], self.pbuf, h_vlm, self.cache, i, self.rope, self.pos_vlm, 1, T, L.ATTN_PREFIX,
+                              valid_len=self.valid_len, blk_start=T, skip_post_attn=last, next_norm_w=None if last else self.vlm.layers[i + 1].ln_in)
+                lw = eg.layers[i]
+                # proprio row: prefix + itself (slot T); action rows: prefix + proprio + all action rows (slots T+1..T+na)
+                ops.rmsnorm(h_pro, lw.ln_in, ex.rms_norm_eps, out=eb.x[:1])
+                prefill_layer(eg, lw, eb, h_pro, self.cache, i, self.rope, self.pos_pro, 1, 1, L.ATTN_PREFIX, valid_len=self.valid_len, blk_start=T,
+                              kv_len=T + 1, skip_post_attn=last, slot_base=T)
+                ops.rmsnorm(h_act, lw.ln_in, ex.rms_norm_eps, out=eb.x[:na])
+                prefill_layer(eg, lw, eb, h_act, self.cache, i, self.rope, self.pos_act, 1, na, L.ATTN_PREFIX, valid_len=self.valid_len, blk_start=T,
+                              kv_len=T + 1 + na, slot_base=T + 1)
+            ops.vla_euler(h_act, None, 0, na, eg.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action, W, cfg.action_dim, dt,
+                          clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel_trace[s])
+        return self.action[:na].view(1, na, cfg.action_dim).clone()
+
+    @torch.no_grad()
+    def infer_text(self, input_ids, pixel_values, attention_mask=None, kv_cache=None):
+        """Mirror of `PiZero.infer_text` (pizero_internvl.py:1005-1046): the VLM mixture ALONE through the joint model (causal mask
+        of :645-702, 0-based positions `cumsum(mask) - 1`, `final_layer_post_attn_skip_names=[]`) + lm_head -> {'logits': fp32
+        [B, S, V]}; it must reproduce InternVLChatModel's logits (same weights, VLA-style embedding assembly with zeroed pad
+        rows).  Prefill only (kv_cache must be None), no padding inside the sequence (the reference assumes the same)."""
+        if kv_cache is not None:
+            raise NotImplementedError('infer_text: prefill only (kv_cache=None)')
+        if self.vlm.head is None:
+            raise ValueError('infer_text needs language_model.lm_head.weight in the checkpoint')
+        cfg, dev, llm = self.cfg, self.device, self.cfg.base.llm
+        B, S = input_ids.shape
+        if attention_mask is not None and not bool(attention_mask.bool().all()):
+            raise NotImplementedError('infer_text: padded prompts are not supported (the reference assumes no padding, :655)')
+        if B != 1 or S > self.max_image_text_tokens:
+            raise NotImplementedError(f'infer_text: batch 1, at most {self.max_image_text_tokens} tokens')
+        pv = pixel_values.to(dev)
+        pvb = torch.empty(pv.shape, dtype=BF, device=dev)
+        if pv.dtype == torch.float32:
+            ops.cast_f32_bf16(pv.contiguous(), pvb)
+        else:
+            pvb.copy_(pv)
+        feats = self.vit.forward(pvb)
+        ids = input_ids.to(dev).contiguous()
+        h = self.h_vlm[:S]
+        ops.embed_merge(ids, self.vlm.embed, feats, h, self.image_token_index, self.pad_token_id, True, self.rank_ws)
+        pos = torch.arange(S, dtype=torch.int32, device=dev)
+        layers = self.vlm.layers
+        prefill_begin(self.vlm, self.pbuf, h, S)
+        for i, lw in enumerate(layers):
+            nxt = layers[i + 1].ln_in if i + 1 < len(layers) else self.vlm.norm
+            prefill_layer(self.vlm, lw, self.pbuf, h, self.cache, i, self.rope, pos, 1, S, L.ATTN_CAUSAL, next_norm_w=nxt)
+        logits = torch.empty(S, llm.vocab_size, dtype=torch.float32, device=dev)
+        ops.gemm(L.EPI_F32, self.pbuf.x[:S], self.vlm.head, out=logits)
+        return {'logits': logits.view(1, S, -1)}
 
     def forward(self, *args, **kw):
         return self.infer_action(*args, **kw)
