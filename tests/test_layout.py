@@ -127,3 +127,44 @@ def test_weight_packing_roundtrip():
         v = pw.t.view(ks, 3, 8, ns, 2, 4, 16, 8)        # [ks, u, w, s, t, g, r, e]
         k0 = 1 * (512 // ks) * 0 + 3 * ns * 32 + 0 * 32 + 2 * 8      # ks=0, wave 3, step 0, g=2
         assert torch.equal(v[0, 1, 3, 0, 1, 2, 5], W[32 + 16 + 5, k0:k0 + 8])
+
+
+def test_vla_checkpoint_keys_of_the_reference_canonicalize():
+    """Golden G9 = the key names / shapes of the reference's own PiZero module tree (built on the meta device by
+    tools/gen_golden_vla_keys.py).  Every key must canonicalise onto a tensor the loader consumes (or onto the short list of
+    heads the inference path never reads), aliases of one module must agree in shape, and nothing the loader needs may be
+    missing -- the reference loads `strict=False` but asserts no missing keys (eval.py:196-212)."""
+    import json
+    import re
+    import torch
+    from vlaser_amd import config as C, synth
+    from vlaser_amd.pizero import canonicalize_vla_state_dict
+    keys = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'g9_vla_state_keys.json')))['keys']
+    assert len(keys) == 1713
+    # a checkpoint saved from a torch.compile'd module carries the `_orig_mod.` prefix on every key (eval.py:200-210)
+    sd = {('_orig_mod.' + k): torch.empty(shape, device='meta') for k, shape in keys.items()}
+    canon = canonicalize_vla_state_dict(sd)
+    # what the loader consumes: the synthetic checkpoint's key set, generalised from a 1+1-layer model to the full depth
+    full = C.VLAConfig(base=C.vlaser_2b())
+    small = synth.vla_state_dict(C.VLAConfig(base=C.truncated(C.vlaser_2b(), 1, 1)), with_head=True)
+    need = {}
+    for k, v in small.items():
+        if '.layers.0.' in k:
+            n = full.base.vision.num_hidden_layers if k.startswith('vision_model.') else full.base.llm.num_hidden_layers
+            for i in range(n):
+                need[k.replace('.layers.0.', f'.layers.{i}.')] = tuple(v.shape)
+        else:
+            need[k] = tuple(v.shape)
+    vocab_rows = {'language_model.model.embed_tokens.weight', 'language_model.lm_head.weight'}    # + 256 '<a i>' tokens (pizero_internvl.py:45-48,85)
+    for k, shape in need.items():
+        assert k in canon, f'the reference checkpoint has no tensor for {k}'
+        got = tuple(canon[k].shape)
+        if k in vocab_rows:
+            assert got[1:] == shape[1:] and got[0] == shape[0] + 256, (k, got, shape)
+        else:
+            assert got == shape, (k, got, shape)
+    extra = set(canon) - set(need)
+    assert extra == {'internvl_model.action_expert.lm_head.weight'}, sorted(extra)[:10]           # the expert's unused vocabulary head
+    # the proprio mixture IS the action mixture after tie_action_proprio_weights (pizero_internvl.py:508-510)
+    assert all(keys[k] == keys[k.replace('.proprio.', '.action.')] for k in keys if '.mixtures.proprio.' in k)
+    assert not any(re.search(r'mixtures\.(vlm|action|proprio)\.layers\.\d+\.(self_attn\.o_proj\.bias|mlp\..*bias)', k) for k in keys)
