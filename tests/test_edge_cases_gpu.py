@@ -88,7 +88,7 @@ def test_generate_eos_in_batch_and_min_new_tokens(golden_model, golden_dir):
     cfg, _, sd = golden_model
     d = np.load(os.path.join(golden_dir, 'g6b_ragged.npz'))
     m = InternVLChatModel(cfg, max_seq_len=512, max_batch=2)
-    m.load_state_dict(sd)
+    m.load_state_dict(sd, strict=False)      # VLA superset: action_expert.* etc. are unexpected keys for the chat model
     m.img_context_token_id = cfg.img_context_token_id
     pv = torch.cat([torch.randn(1, 3, 448, 448, generator=torch.Generator().manual_seed(int(s))) for s in d['seeds']])
     ids, am = torch.from_numpy(d['input_ids']), torch.from_numpy(d['attention_mask'])
@@ -113,7 +113,7 @@ def test_generate_more_than_sixteen_sequences(golden_model):
     from vlaser_amd.internvl_chat import InternVLChatModel
     cfg, _, sd = golden_model
     m = InternVLChatModel(cfg, max_seq_len=128, max_batch=16)
-    m.load_state_dict(sd)
+    m.load_state_dict(sd, strict=False)
     m.img_context_token_id = cfg.img_context_token_id
     g = torch.Generator().manual_seed(99)
     ids = torch.randint(0, 151643, (18, 24), generator=g)
@@ -134,7 +134,7 @@ def test_do_sample_warpers(golden_model):
     from vlaser_amd.internvl_chat import InternVLChatModel
     cfg, _, sd = golden_model
     m = InternVLChatModel(cfg, max_seq_len=128, max_batch=2)
-    m.load_state_dict(sd)
+    m.load_state_dict(sd, strict=False)
     m.img_context_token_id = cfg.img_context_token_id
     ids = torch.randint(0, 151643, (2, 20), generator=torch.Generator().manual_seed(4))
     greedy, lg = m.generate(None, ids, max_new_tokens=4, return_logits=True)
@@ -288,3 +288,33 @@ def test_sft_workspaces_grow_with_tile_count(golden_model):
         out.append((loss.item(), m.named_grads()['mlp1.1.weight'].clone()))
         assert m.max_tiles == 3
     assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
+
+
+def test_strict_state_dict_and_generate_kwargs(golden_model):
+    """Boundary behaviour of the drop-in surface: `load_state_dict(strict=True)` names every missing and
+    unexpected key like nn.Module does; `generate()` refuses HF features it does not implement instead of dropping them."""
+    from vlaser_amd.internvl_chat import InternVLChatModel
+    cfg, _, sd = golden_model
+    vsd = {k: v for k, v in sd.items() if k.startswith(('vision_model.', 'mlp1.', 'language_model.'))}
+    m = InternVLChatModel(cfg, max_seq_len=128)
+    with pytest.raises(RuntimeError, match='Unexpected key'):
+        m.load_state_dict(sd)                                   # the VLA superset carries action_expert.* / action_encoder.* ...
+    broken = dict(vsd)
+    broken.pop('language_model.model.layers.1.mlp.down_proj.weight'); broken.pop('vision_model.encoder.layers.0.ls1')
+    with pytest.raises(RuntimeError, match='Missing key') as ei:
+        m.load_state_dict(broken)
+    assert 'layers.1.mlp.down_proj.weight' in str(ei.value) and 'layers.0.ls1' in str(ei.value)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(broken, strict=False)                 # non-strict still cannot run without the tensors
+    r = m.load_state_dict(sd, strict=False)
+    assert not r.missing_keys and any(k.startswith('action_expert.') for k in r.unexpected_keys)
+    assert m.load_state_dict(vsd).unexpected_keys == []
+    m.img_context_token_id = cfg.img_context_token_id
+    ids = torch.randint(0, 151643, (1, 12))
+    for bad in (dict(num_beams=4), dict(repetition_penalty=1.2), dict(no_repeat_ngram_size=3)):
+        with pytest.raises(NotImplementedError):
+            m.generate(None, ids, max_new_tokens=2, **bad)
+    with pytest.raises(TypeError):
+        m.generate(None, ids, max_new_tokens=2, penalty_alpha=0.6)
+    out = m.generate(None, ids, max_new_tokens=2, num_beams=1, repetition_penalty=1.0, use_cache=True)
+    assert out.shape == (1, 2)

@@ -143,4 +143,4 @@ def test_full_depth_chunk_vs_fp32_oracle(full):
     e_k = ((k_last - rk).abs().max() / rk.abs().max()).item()
     print(f'full depth vs fp32 oracle: action max|err| {e_act:.3e}; per-step velocity max|err| {[f"{x:.2e}" for x in e_vel.tolist()]} (ref max {rvel.abs().max():.3f}); '
           f'last-layer K rel err {e_k:.3e}')
-    assert e_act < 2e-2 and (e_vel < 4e-2 * max(1.0, rvel.abs().max().item())).all() and e_k < 4e-2
+    assert e_act < 1e-2 and (e_vel < 2e-2).all() and e_k < 5e-2      # measured r02: 3.6e-3, 8.5e-3, 3.9e-2

@@ -27,7 +27,7 @@ def vlm(golden_model):
     from vlaser_amd.internvl_chat import InternVLChatModel
     cfg, _, sd = golden_model
     m = InternVLChatModel(cfg, max_seq_len=512)
-    m.load_state_dict(sd)
+    m.load_state_dict(sd, strict=False)      # VLA superset: action_expert.* etc. are unexpected keys for the chat model
     m.img_context_token_id = cfg.img_context_token_id
     return m
 

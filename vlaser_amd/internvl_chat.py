@@ -58,17 +58,48 @@ class InternVLChatModel:
         model.load_state_dict(sd)
         return model
 
+    def expected_keys(self):
+        """The HF key names this model consumes (module definitions: modeling_intern_vit.py:141-152,196-208,256-257,275-279,
+        modeling_internvl_chat.py:89-94, HF Qwen2ForCausalLM), i.e. `InternVLChatModel(config).state_dict().keys()` of the reference."""
+        v, llm = self.config.vision, self.config.llm
+        keys = ['vision_model.embeddings.class_embedding', 'vision_model.embeddings.patch_embedding.weight',
+                'vision_model.embeddings.patch_embedding.bias', 'vision_model.embeddings.position_embedding']
+        for i in range(v.num_hidden_layers):
+            p = f'vision_model.encoder.layers.{i}.'
+            keys += [p + n for n in ('attn.qkv.weight', 'attn.qkv.bias', 'attn.proj.weight', 'attn.proj.bias', 'mlp.fc1.weight', 'mlp.fc1.bias',
+                                     'mlp.fc2.weight', 'mlp.fc2.bias', 'norm1.weight', 'norm1.bias', 'norm2.weight', 'norm2.bias', 'ls1', 'ls2')]
+        keys += [f'mlp1.{i}.{n}' for i in (0, 1, 3) for n in ('weight', 'bias')]
+        keys += ['language_model.model.embed_tokens.weight', 'language_model.model.norm.weight', 'language_model.lm_head.weight']
+        for i in range(llm.num_hidden_layers):
+            p = f'language_model.model.layers.{i}.'
+            keys += [p + n for n in ('self_attn.q_proj.weight', 'self_attn.q_proj.bias', 'self_attn.k_proj.weight', 'self_attn.k_proj.bias',
+                                     'self_attn.v_proj.weight', 'self_attn.v_proj.bias', 'self_attn.o_proj.weight', 'mlp.gate_proj.weight',
+                                     'mlp.up_proj.weight', 'mlp.down_proj.weight', 'input_layernorm.weight', 'post_attention_layernorm.weight')]
+        return keys
+
     def load_state_dict(self, sd, strict=True):
-        need = ['vision_model.embeddings.class_embedding', 'mlp1.0.weight', 'language_model.model.embed_tokens.weight',
-                'language_model.lm_head.weight', 'language_model.model.norm.weight']
-        missing = [k for k in need if k not in sd]
-        if missing and strict:
-            raise KeyError(f'missing keys in state dict: {missing}')
+        """nn.Module.load_state_dict semantics: `strict=True` raises a RuntimeError naming every missing and unexpected key;
+        `strict=False` loads what is there (tensors the kernels need must still be present) and returns both lists.  Rotary
+        `inv_freq` buffers of older HF checkpoints are derived, not loaded, and are never reported."""
+        need = self.expected_keys()
+        have = set(sd.keys())
+        missing = [k for k in need if k not in have]
+        needset = set(need)
+        unexpected = sorted(k for k in have if k not in needset and not k.endswith('rotary_emb.inv_freq'))
+        if strict and (missing or unexpected):
+            msg = [f'Error(s) in loading state_dict for {type(self).__name__}:']
+            if missing:
+                msg.append('\tMissing key(s) in state_dict: ' + ', '.join(f'"{k}"' for k in missing[:20]) + (' ...' if len(missing) > 20 else '') + '.')
+            if unexpected:
+                msg.append('\tUnexpected key(s) in state_dict: ' + ', '.join(f'"{k}"' for k in unexpected[:20]) + (' ...' if len(unexpected) > 20 else '') + '.')
+            raise RuntimeError('\n'.join(msg))
+        if missing:
+            raise RuntimeError(f'state_dict lacks tensors the kernels need: {missing[:8]}{" ..." if len(missing) > 8 else ""}')
         self.vit = VitEngine(sd, self.config, self.device, max_tiles=self._max_tiles)
         self.use_skinny = ops.skinny_supported(self.config.llm)      # Vlaser-8B (hidden 3584) decodes through the GEMM path
         self.llm = QwenStack(sd, 'language_model.', self.config.llm, self.device, skinny=self.use_skinny)
         self._alloc_llm()
-        return SimpleNamespace(missing_keys=missing, unexpected_keys=[])
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
 
     def _alloc_llm(self):
         llm, dev = self.config.llm, self.device
@@ -193,6 +224,19 @@ class InternVLChatModel:
                  output_hidden_states=None, max_new_tokens=None, min_new_tokens=0, do_sample=False, eos_token_id=None,
                  pad_token_id=None, return_logits=False, **generate_kwargs):
         assert self.img_context_token_id is not None
+        # HF generation features this decoder does not implement must not be dropped silently
+        allowed = {'temperature', 'top_k', 'top_p', 'generator', 'use_cache', 'return_dict', 'return_dict_in_generate', 'output_scores',
+                   'output_attentions', 'num_return_sequences', 'num_beams', 'repetition_penalty', 'length_penalty', 'no_repeat_ngram_size',
+                   'early_stopping', 'do_sample', 'max_length'}
+        neutral = {'num_beams': 1, 'repetition_penalty': 1.0, 'length_penalty': 1.0, 'no_repeat_ngram_size': 0, 'num_return_sequences': 1,
+                   'early_stopping': False, 'output_scores': False, 'output_attentions': False, 'return_dict_in_generate': False, 'use_cache': True}
+        for k, v in generate_kwargs.items():
+            if k not in allowed:
+                raise TypeError(f'generate() got an unsupported generation argument {k!r}')
+            if k in neutral and v is not None and v != neutral[k]:
+                raise NotImplementedError(f'generate(): {k}={v!r} is not implemented (greedy / temperature / top-k / top-p sampling only)')
+        if generate_kwargs.get('max_length') is not None and max_new_tokens is None:
+            max_new_tokens = max(1, int(generate_kwargs['max_length']) - int(input_ids.shape[1]))
         # do_sample: HF's logits warpers in their order (temperature -> top_k -> top_p) + multinomial on the fp32 logits the
         # lm_head kernel leaves on the device; not on the hot path (the reference's eval configs decode greedily)
         sample = dict(temperature=float(generate_kwargs.pop('temperature', 1.0) or 1.0), top_k=int(generate_kwargs.pop('top_k', 0) or 0),
