@@ -88,9 +88,30 @@ def cpu_baseline(vla_full, seed=0):
                       f'(measured {tv:.2f}+{tp:.2f}+{te:.2f} s -> est. {full:.1f} s/chunk)'}
 
 
+def sft_flops(cfg, S, R, n_tiles):
+    """FLOPs one rank actually executes per optimizer step (1 MAC = 2 FLOP, full S x S attention counted): frozen ViT forward; projector
+    forward (its first Linear is evaluated twice: pre-activation kept for the GELU backward) + dgrad + wgrad on the 256 visual rows per
+    tile; every LLM matmul forward + dgrad + wgrad on S rows; attention forward + the five S x S products of its backward; lm_head
+    forward + dgrad + wgrad on the R supervised rows ONLY (the step never forms logits of unlabelled positions)."""
+    v, l = cfg.vision, cfg.llm
+    P = v.num_positions
+    vit = n_tiles * v.num_hidden_layers * (2 * P * v.hidden_size * (4 * v.hidden_size + 2 * v.intermediate_size) + 4 * P * P * v.hidden_size)
+    vit += n_tiles * 2 * v.num_patches * v.hidden_size * 3 * v.patch_size ** 2
+    nt, C4, H = n_tiles * cfg.num_image_token, 4 * v.hidden_size, l.hidden_size
+    proj = 2 * nt * (C4 * H * (2 + 2) + H * H * (1 + 2))
+    nqd, nkvd = l.num_attention_heads * l.head_dim, l.num_key_value_heads * l.head_dim
+    per_layer = H * (nqd + 2 * nkvd) + nqd * H + 3 * H * l.intermediate_size
+    llm = l.num_hidden_layers * 3 * 2 * S * per_layer
+    attn = l.num_hidden_layers * (4 + 10) * S * S * nqd
+    head = 3 * 2 * R * l.vocab_size * H
+    return float(vit + proj + llm + attn + head)
+
+
 def sft_bench(rank, world, local, dist, steps, warmup=2):
     """BASELINE configs[4]: Vlaser-2B SFT, data parallel, per-GPU micro-batch 1, T = 1 tile, S = 560 (48 + 256 image + 256 text),
-    labels on the last 128 positions, ViT frozen, per-layer recompute, bf16 params / fp32 AdamW, ZeRO-1 RCCL exchange."""
+    labels on the last 128 positions, ViT frozen, layer activations KEPT (1.1 GB; the reference recomputes them to fit 80 GB parts --
+    `SFTModel(recompute=True)` restores that policy), bf16 params / fp32 AdamW, ZeRO-1 RCCL exchange.  ids / labels are handed over
+    as CPU tensors, as the reference's collator produces them: the step then runs without a host<->device round trip."""
     from vlaser_amd import config as C, synth
     from vlaser_amd.sft import SFTModel
     dev = f'cuda:{local}'
@@ -101,23 +122,22 @@ def sft_bench(rank, world, local, dist, steps, warmup=2):
     del sd
     torch.cuda.empty_cache()
     g = torch.Generator().manual_seed(1000 + rank)
-    S = 560
-    ids = torch.cat([torch.randint(0, 151643, (41,), generator=g), torch.full((256,), cfg.img_context_token_id),
-                     torch.randint(0, 151643, (S - 41 - 256,), generator=g)])[None]
+    S, R = 560, 128
+    ids = torch.cat([torch.randint(1, 151643, (41,), generator=g), torch.full((256,), cfg.img_context_token_id),
+                     torch.randint(1, 151643, (S - 41 - 256,), generator=g)])[None]
     labels = torch.full_like(ids, -100)
-    labels[0, -128:] = ids[0, -128:]
+    labels[0, -R:] = ids[0, -R:]
     pv = torch.randn(1, 3, 448, 448, generator=g).to(dev).to(torch.bfloat16)
-    ids_d, lab_d = ids.to(dev), labels.to(dev)
     out = None
     for _ in range(warmup):
-        out = model.step(pv, ids_d, lab_d)
+        out = model.step(pv, ids, labels)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        out = model.step(pv, ids_d, lab_d)
+        out = model.step(pv, ids, labels)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -129,13 +149,16 @@ def sft_bench(rank, world, local, dist, steps, warmup=2):
         dt = t.item()
     loss = float(out.loss)
     assert loss == loss, 'SFT loss is NaN'
+    buckets_mb = [round((hi - lo) * 2 / 2 ** 20) for lo, hi in model.buckets]
     del model
     torch.cuda.empty_cache()
-    # algorithmic work per rank-step: 6 x 1.695 G matmul params x 560 tokens = 5694 GFLOP (SURVEY 8d quotes 7592 with the
-    # reference's per-layer recompute, which this build does not do: activations are kept)
+    fl = sft_flops(cfg, S, R - 1 + 1, 1)
     return {'metric': 'sft_tokens_per_sec', 'value': round(world * steps * S / dt, 1), 'unit': 'tokens/s', 'ms_per_step': round(dt / steps * 1e3, 2),
-            'steps': steps, 'tokens_per_rank_step': S, 'last_loss': round(loss, 4), 'parallelism': f'dp{world} (ZeRO-1 bucketed RCCL reduce-scatter + all-gather)',
-            'mfma_frac': round(5694e9 * world * steps / dt / (world * 2.5e15), 4)}
+            'steps': steps, 'tokens_per_rank_step': S, 'last_loss': round(loss, 4),
+            'parallelism': f'dp{world} (ZeRO-1: bucketed RCCL reduce-scatter(mean, bf16) issued from the backward + all-gather of updated params)',
+            'exchange': {'bucket_mib': buckets_mb, 'NCCL_ALGO': os.environ.get('NCCL_ALGO', 'default'), 'NCCL_PROTO': os.environ.get('NCCL_PROTO', 'default'),
+                         'gradient_bytes_per_rank': 3570e6 if world > 1 else 0},
+            'gflop_per_rank_step': round(fl / 1e9, 1), 'mfma_frac': round(fl * world * steps / dt / (world * 2.5e15), 4)}
 
 
 def main():

@@ -230,14 +230,23 @@ int vlaser_swiglu_bwd(const void* gu, const void* dact, void* dgu, int S, int I,
 /* dlogits[r, v] = (exp(logit - lse[r]) - [v == label]) * scale for label != ignore, else 0; bf16 [R, ld_out] zero padded */
 int vlaser_ce_dlogits(const float* logits, const float* lse, const int64_t* labels, void* out, int R, int V, long long ld_in, int ld_out,
                       float scale, long long ignore_index, vl_stream_t stream);
-/* dEmbed[ids[s], :] += dh[s, :] for positions whose rank < 0 (text tokens); deterministic (sequential over positions) */
-int vlaser_embed_scatter_add(const int64_t* ids, const int32_t* rank, const void* dh, void* dembed, int n, int H, vl_stream_t stream);
+/* dEmbed[id, :] += sum of dh[s, :] over the text positions s (rank < 0) with ids[s] == id: fp32 accumulation per id, rounded once
+ * (torch embedding backward).  order = int32 [n], the positions sorted by id (stable); ids outside [0, vocab) are skipped. */
+int vlaser_embed_scatter_add(const int64_t* ids, const int32_t* rank, const int32_t* order, const void* dh, void* dembed, int n, int H,
+                             long long vocab, vl_stream_t stream);
 /* GELU(erf) backward: dx = dy * gelu'(x)  (x = pre-activation, bf16) */
 int vlaser_gelu_bwd(const void* x, const void* dy, void* dx, long long n, vl_stream_t stream);
 /* fused AdamW on a flat shard: g bf16 -> fp32 (times grad_scale), m/v/master fp32 updated, bf16 param written.
  * DeepSpeed FusedAdam semantics (adam_w_mode): p = p*(1 - lr*wd) - lr * mhat / (sqrt(vhat) + eps). */
 int vlaser_adamw(void* param_bf16, float* master, float* m, float* v, const void* grad_bf16, long long n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, float grad_scale, int step, vl_stream_t stream);
+/* same update with global-norm clipping resolved on the device: grad_scale *= max_norm / (sqrt(gnorm2[0]) + 1e-6) when the norm exceeds
+ * max_norm > 0 (torch clip_grad_norm_; HF TrainingArguments.max_grad_norm) -- no host round trip between the norm and the update. */
+int vlaser_adamw_clipped(void* param_bf16, float* master, float* m, float* v, const void* grad_bf16, long long n, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, float grad_scale, const float* gnorm2, float max_norm, int step, vl_stream_t stream);
+/* acc (fp32) = (first ? 0 : acc) + w * g (bf16); finalize: g = bf16(acc).  Gradient accumulation over micro-batches / the samples of a
+ * per-device batch (…2nd_finetune_full.sh:5-6,49-50: PER_DEVICE_BATCH_SIZE, GRADIENT_ACC). */
+int vlaser_grad_accumulate(void* g_bf16, float* acc, long long n, float w, int first, int finalize, vl_stream_t stream);
 /* out[0] += sum of squares of a bf16 buffer (gradient norm); out must be zeroed by the caller */
 int vlaser_sumsq(const void* x, long long n, float* out, float* partial_ws /* float[1024] */, vl_stream_t stream);
 

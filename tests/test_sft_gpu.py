@@ -20,6 +20,12 @@ def _rel(a, b):
 
 
 @pytest.fixture(scope='module')
+def ops():
+    from vlaser_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope='module')
 def setup(golden_model, golden_dir):
     from vlaser_amd.sft import SFTModel
     cfg, _, sd = golden_model
@@ -247,3 +253,121 @@ def test_attention_backward_fused_pds_and_grouped_tn():
     ref = torch.einsum('hqk,qhd->khd', dS[:, :, :S].float(), q.float().view(S, H, hd)).view(S, nkv, G, hd).sum(2).reshape(S, nkv * hd)
     rel, cos = _rel(dk, ref)
     assert rel < 6e-3 and cos > 0.9999, (rel, cos)
+
+
+def _four_samples(cfg, seed=11):
+    """Four ragged samples as the collator batches them: ids right-padded with 0, labels with -100, tiles concatenated."""
+    g = torch.Generator().manual_seed(seed)
+    rows, labs, pvs = [], [], []
+    for n_text, n_lab in ((20, 6), (33, 12), (9, 4), (27, 9)):
+        ids = torch.cat([torch.randint(1, 151643, (12,), generator=g), torch.full((256,), cfg.img_context_token_id),
+                         torch.randint(1, 151643, (n_text,), generator=g)])
+        lab = torch.full_like(ids, -100); lab[-n_lab:] = ids[-n_lab:]
+        rows.append(ids); labs.append(lab); pvs.append(torch.randn(1, 3, 448, 448, generator=g))
+    S = max(len(r) for r in rows)
+    ids = torch.zeros(4, S, dtype=torch.long); lab = torch.full((4, S), -100)
+    for b, (r, l) in enumerate(zip(rows, labs)):
+        ids[b, :len(r)] = r; lab[b, :len(r)] = l
+    return torch.cat(pvs), ids, lab, rows, labs, pvs
+
+
+def test_batch4_equals_accumulation_of_4_and_oracle_batch_gradient(golden_model):
+    """per-device batch > 1 and gradient accumulation (…2nd_finetune_full.sh:5-6,49-50).  (a) one per-device batch
+    of 4 padded samples: loss and gradients vs torch autograd of the fp32 oracle's batch loss (mean over ALL supervised tokens);
+    (b) the same 4 samples as 4 accumulation micro-batches of 1 with HF's loss / GA scaling: every sample weighs 1/4 instead of
+    R_b / R -- checked against the oracle with those weights; both bit-reproducible."""
+    from oracle import vlm as ovlm
+    from vlaser_amd.sft import SFTModel
+    cfg, _, sd = golden_model
+    pv, ids, lab, rows, labs, pvs = _four_samples(cfg)
+    keys = ['language_model.model.layers.1.mlp.down_proj.weight', 'language_model.model.layers.0.self_attn.q_proj.weight', 'mlp1.3.weight',
+            'language_model.model.norm.weight', 'language_model.lm_head.weight']
+
+    def oracle(weights):
+        torch.set_grad_enabled(True)
+        try:
+            sdg = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
+            tot = 0
+            for b in range(4):
+                lg = ovlm.forward_logits(sdg, cfg, pvs[b], rows[b][None])
+                tot = tot + weights[b] * ovlm.sft_loss(lg, labs[b][None])
+            tot.backward()
+            return tot.item(), {k: sdg[k].grad for k in keys}
+        finally:
+            torch.set_grad_enabled(False)
+
+    R = torch.tensor([float((l[1:] != -100).sum()) for l in labs])
+    for mode, weights in (('batch', (R / R.sum()).tolist()), ('accum', [0.25] * 4)):
+        m = SFTModel(cfg, max_seq_len=ids.shape[1], max_grad_norm=0.0, lr=0.0, weight_decay=0.0)      # lr 0: the step leaves the weights alone
+        m.load_state_dict(sd)
+        if mode == 'batch':
+            out = m.train_step([(pv, ids, lab, torch.ones(4, 1, dtype=torch.long))])
+        else:
+            out = m.train_step([(pvs[b], rows[b][None], labs[b][None], None) for b in range(4)])
+        ref_loss, ref_g = oracle(weights)
+        assert abs(out.loss.item() - ref_loss) < 5e-3, (mode, out.loss.item(), ref_loss)
+        grads = m.named_grads()
+        for k in keys:
+            rel, cos = _rel(grads[k], ref_g[k])
+            assert rel < 4e-2 and cos > 0.999, (mode, k, rel, cos)
+        m2 = SFTModel(cfg, max_seq_len=ids.shape[1], max_grad_norm=0.0, lr=0.0, weight_decay=0.0); m2.load_state_dict(sd)
+        (m2.train_step([(pv, ids, lab, torch.ones(4, 1, dtype=torch.long))]) if mode == 'batch' else
+         m2.train_step([(pvs[b], rows[b][None], labs[b][None], None) for b in range(4)]))
+        assert torch.equal(m2.fp.g, m.fp.g)                                    # deterministic accumulation order
+
+
+def test_embedding_gradient_sums_duplicates_in_fp32(ops):
+    """a token that occurs hundreds of times must not lose its later contributions to bf16 re-rounding; ids out of range
+    are skipped, <IMG_CONTEXT> positions (rank >= 0) do not touch the table."""
+    n, H, V = 3000, 256, 500
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, V, (n,), generator=g)
+    ids[::3] = 7                                                               # one id on a third of the positions
+    rank = torch.full((n,), -1, dtype=torch.int32); rank[100:140] = torch.arange(40, dtype=torch.int32)
+    dh = (torch.randn(n, H, generator=g) * 0.01 + 0.01).to(BF)
+    base = (torch.randn(V, H, generator=g) * 0.01).to(BF)
+    demb = base.clone().cuda()
+    ops.embed_scatter_add(ids.cuda(), rank.cuda(), dh.cuda(), demb, n, H)
+    ref = base.float().clone()
+    keep = rank < 0
+    ref.index_add_(0, ids[keep], dh[keep].float())
+    ref = ref.to(BF).float()
+    got = demb.float().cpu()
+    assert (got - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item()      # one bf16 rounding of the fp32 sum
+    assert (got[7] - base[7].float()).abs().mean() > 5.0                                # ~1000 contributions of ~0.01 really arrived
+
+
+def test_checkpoint_resume_is_bit_identical(golden_model, tmp_path):
+    """Resumable training state (HF Trainer checkpoints / VLA step{N}.pt): 3 uninterrupted steps == 2 steps, save_checkpoint, a fresh
+    model's load_checkpoint, 1 more step -- weights, fp32 masters and AdamW moments bit for bit."""
+    from vlaser_amd.sft import SFTModel
+    cfg, _, sd = golden_model
+    pv, ids, lab, rows, labs, pvs = _four_samples(cfg, seed=21)
+    mk = lambda: SFTModel(cfg, max_seq_len=ids.shape[1], lr=1e-3, weight_decay=0.05)
+    a = mk(); a.load_state_dict(sd)
+    for s in range(3):
+        a.step(pvs[s], rows[s][None], labs[s][None], total_steps=10)
+    b = mk(); b.load_state_dict(sd)
+    for s in range(2):
+        b.step(pvs[s], rows[s][None], labs[s][None], total_steps=10)
+    b.save_checkpoint(str(tmp_path / 'ckpt'))
+    c = mk(); c.load_checkpoint(str(tmp_path / 'ckpt'))
+    assert c.step_count == 2
+    c.step(pvs[2], rows[2][None], labs[2][None], total_steps=10)
+    assert torch.equal(a.fp.p, c.fp.p) and torch.equal(a.master, c.master) and torch.equal(a.m, c.m) and torch.equal(a.v, c.v)
+
+
+def test_device_side_clip_matches_host_formula(ops):
+    n = 50_000
+    g = torch.Generator().manual_seed(8)
+    gr = (torch.randn(n, generator=g) * 0.05).to(BF).cuda()
+    p0 = (torch.randn(n, generator=g) * 0.05)
+    gn2 = gr.float().pow(2).sum().reshape(1)
+    for max_norm in (0.0, 1.0, 100.0):
+        a = [p0.to(BF).cuda(), p0.cuda().clone(), torch.zeros(n).cuda(), torch.zeros(n).cuda()]
+        b = [p0.to(BF).cuda(), p0.cuda().clone(), torch.zeros(n).cuda(), torch.zeros(n).cuda()]
+        gnorm = gn2.sqrt().item()
+        scale = max_norm / (gnorm + 1e-6) if (max_norm and gnorm > max_norm) else 1.0
+        ops.adamw(*a, gr, 1e-3, 0.9, 0.999, 1e-8, 0.05, scale, 1)
+        ops.adamw_clipped(*b, gr, 1e-3, 0.9, 0.999, 1e-8, 0.05, 1.0, gn2, max_norm, 1)
+        torch.testing.assert_close(a[1], b[1], rtol=1e-6, atol=1e-8)

@@ -76,10 +76,12 @@ _SIGS = {
     'vlaser_swiglu': [vp, vp, i32, i32, vp],
     'vlaser_swiglu_bwd': [vp, vp, vp, i32, i32, vp],
     'vlaser_ce_dlogits': [vp, vp, vp, vp, i32, i32, i64, i32, f32, i64, vp],
-    'vlaser_embed_scatter_add': [vp, vp, vp, vp, i32, i32, vp],
+    'vlaser_embed_scatter_add': [vp, vp, vp, vp, vp, i32, i32, i64, vp],
     'vlaser_gelu_bwd': [vp, vp, vp, i64, vp],
     'vlaser_adamw': [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, i32, vp],
     'vlaser_sumsq': [vp, i64, vp, vp, vp],
+    'vlaser_adamw_clipped': [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, i32, vp],
+    'vlaser_grad_accumulate': [vp, vp, i64, f32, i32, i32, vp],
 }
 
 

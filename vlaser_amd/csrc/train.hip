@@ -493,20 +493,45 @@ extern "C" int vlaser_ce_dlogits(const float* logits, const float* lse, const in
 }
 
 // ---------------------------------------------------------------------------------------------- embedding backward
-// dEmbed[ids[s]] += dh[s] for text positions (rank < 0); one block per 64-column slice walks the positions in order
-__global__ __launch_bounds__(64) void embed_scatter_add_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ rank,
-                                                               const bf16_t* __restrict__ dh, bf16_t* __restrict__ dembed, int n, int H) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
+// dEmbed[id] += sum over the text positions (rank < 0) holding that id of dh[position].  `order` lists the positions sorted by id
+// (stable), so equal ids are contiguous runs: every run is summed in fp32 in position order by exactly ONE workgroup (the one whose
+// chunk holds the run's first position -- a workgroup skips a leading run that started in the previous chunk and finishes its
+// last run past its own chunk end) and rounded to bf16 once, like torch's embedding backward; a token that occurs hundreds of times
+// in a 16k-token sample no longer loses its later contributions to bf16 re-rounding.  Ids outside [0, vocab) are skipped.
+#define ESA_CHUNK 64
+__global__ __launch_bounds__(256) void embed_scatter_add_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ rank, const int32_t* __restrict__ order,
+                                                                const bf16_t* __restrict__ dh, bf16_t* __restrict__ dembed, int n, int H, long long vocab) {
+  const int c = (blockIdx.y * 256 + threadIdx.x) * 2;               // two adjacent columns per thread (4-byte accesses)
   if (c >= H) return;
-  for (int s = 0; s < n; ++s) {
-    if (rank[s] >= 0) continue;
-    bf16_t* p = dembed + (size_t)ids[s] * H + c;
-    *p = f32_to_bf16(bf16_to_f32(*p) + bf16_to_f32(dh[(size_t)s * H + c]));
+  int i = blockIdx.x * ESA_CHUNK;
+  const int end = min(n, i + ESA_CHUNK);
+  if (i > 0) {                                                      // a run that began before this chunk belongs to the previous workgroup
+    const int64_t prev = ids[order[i - 1]];
+    while (i < n && ids[order[i]] == prev) ++i;
+  }
+  while (i < end) {                                                 // runs that START inside the chunk (may end beyond it)
+    const int64_t id = ids[order[i]];
+    float a0 = 0.f, a1 = 0.f;
+    bool any = false;
+    for (; i < n && ids[order[i]] == id; ++i) {
+      const int s = order[i];
+      if (rank[s] >= 0) continue;                                   // <IMG_CONTEXT> positions take the projector's gradient, not the table's
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(dh + (size_t)s * H + c);
+      a0 += bf16lo_to_f32(v); a1 += bf16hi_to_f32(v);
+      any = true;
+    }
+    if (any && id >= 0 && id < vocab) {
+      uint32_t* p = reinterpret_cast<uint32_t*>(dembed + (size_t)id * H + c);
+      const uint32_t o = *p;
+      *p = pack_bf16x2(bf16lo_to_f32(o) + a0, bf16hi_to_f32(o) + a1);
+    }
   }
 }
-extern "C" int vlaser_embed_scatter_add(const int64_t* ids, const int32_t* rank, const void* dh, void* dembed, int n, int H, vl_stream_t s) {
-  VL_CHECK(ids && rank && dh && dembed && n > 0, "vlaser_embed_scatter_add: bad args");
-  hipLaunchKernelGGL(embed_scatter_add_kernel, dim3((H + 63) / 64), dim3(64), 0, (hipStream_t)s, ids, rank, (const bf16_t*)dh, (bf16_t*)dembed, n, H);
+extern "C" int vlaser_embed_scatter_add(const int64_t* ids, const int32_t* rank, const int32_t* order, const void* dh, void* dembed, int n, int H,
+                                        long long vocab, vl_stream_t s) {
+  VL_CHECK(ids && rank && order && dh && dembed && n > 0 && H % 2 == 0 && vocab > 0, "vlaser_embed_scatter_add: bad args (order = positions sorted by id)");
+  hipLaunchKernelGGL(embed_scatter_add_kernel, dim3((n + ESA_CHUNK - 1) / ESA_CHUNK, (H / 2 + 255) / 256), dim3(256), 0, (hipStream_t)s, ids, rank, order,
+                     (const bf16_t*)dh, (bf16_t*)dembed, n, H, vocab);
   VL_LAUNCH_CHECK();
   return 0;
 }
@@ -531,8 +556,12 @@ extern "C" int vlaser_gelu_bwd(const void* x, const void* dy, void* dx, long lon
 // DeepSpeed FusedAdam (adam_w_mode=1, bias_correction=1) on fp32 master weights; bf16 params refreshed from the master.
 __global__ __launch_bounds__(256) void adamw_kernel(bf16_t* __restrict__ p, float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
                                                     const bf16_t* __restrict__ g, long long n, float lr, float b1, float b2, float eps, float wd,
-                                                    float gscale, float bc1, float bc2) {
+                                                    float gscale, float bc1, float bc2, const float* __restrict__ gnorm2, float max_norm) {
   const float rbc2 = rsqrtf(bc2), step = lr / bc1, decay = 1.0f - lr * wd;
+  if (gnorm2) {          // global-norm clipping with the norm left on the device (torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), applied when < 1)
+    const float gn = sqrtf(gnorm2[0]);
+    if (max_norm > 0.f && gn > max_norm) gscale *= max_norm / (gn + 1e-6f);
+  }
   const long long n4 = n >> 2;                 // 4 elements per thread per iteration (16-byte fp32 vectors, 8-byte bf16 vectors)
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const u32x2 gv = *reinterpret_cast<const u32x2*>(g + 4 * i);
@@ -567,7 +596,45 @@ extern "C" int vlaser_adamw(void* p, float* master, float* m, float* v, const vo
   const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (bf16_t*)p, master, m, v, (const bf16_t*)g, n, lr, b1, b2, eps, wd,
-                     gscale, bc1, bc2);
+                     gscale, bc1, bc2, (const float*)nullptr, 0.f);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vlaser_adamw_clipped(void* p, float* master, float* m, float* v, const void* g, long long n, float lr, float b1, float b2, float eps,
+                                    float wd, float gscale, const float* gnorm2, float max_norm, int step, vl_stream_t s) {
+  VL_CHECK(p && master && m && v && g && gnorm2 && n > 0 && step >= 1, "vlaser_adamw_clipped: bad args");
+  VL_CHECK((((uintptr_t)p | (uintptr_t)g) & 7) == 0 && (((uintptr_t)master | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "vlaser_adamw_clipped: alignment");
+  const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (bf16_t*)p, master, m, v, (const bf16_t*)g, n, lr, b1, b2, eps, wd,
+                     gscale, bc1, bc2, gnorm2, max_norm);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- gradient accumulation
+// acc (fp32) = [acc +] w * g (bf16); with `finalize` the bf16 buffer is overwritten by the rounded sum -- micro-batches of a
+// gradient-accumulation step / samples of a per-device batch > 1 (the SFT launcher's PER_DEVICE_BATCH_SIZE x GRADIENT_ACC).
+__global__ __launch_bounds__(256) void grad_accumulate_kernel(bf16_t* __restrict__ g, float* __restrict__ acc, long long n, float w, int first, int finalize) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const u32x2 gv = *reinterpret_cast<const u32x2*>(g + 4 * i);
+    f32x4 a = first ? f32x4{0, 0, 0, 0} : *reinterpret_cast<const f32x4*>(acc + 4 * i);
+    a[0] += w * bf16lo_to_f32(gv[0]); a[1] += w * bf16hi_to_f32(gv[0]); a[2] += w * bf16lo_to_f32(gv[1]); a[3] += w * bf16hi_to_f32(gv[1]);
+    *reinterpret_cast<f32x4*>(acc + 4 * i) = a;
+    if (finalize) *reinterpret_cast<u32x2*>(g + 4 * i) = u32x2{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
+  }
+  if (blockIdx.x == 0)
+    for (long long i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+      const float a = (first ? 0.f : acc[i]) + w * bf16_to_f32(g[i]);
+      acc[i] = a;
+      if (finalize) g[i] = f32_to_bf16(a);
+    }
+}
+extern "C" int vlaser_grad_accumulate(void* g, float* acc, long long n, float w, int first, int finalize, vl_stream_t s) {
+  VL_CHECK(g && acc && n > 0 && (((uintptr_t)g) & 7) == 0 && (((uintptr_t)acc) & 15) == 0, "vlaser_grad_accumulate: bad args / alignment");
+  const int blocks = (int)((n + 1023) / 1024 < 4096 ? (n + 1023) / 1024 : 4096);
+  hipLaunchKernelGGL(grad_accumulate_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (bf16_t*)g, acc, n, w, first, finalize);
   VL_LAUNCH_CHECK();
   return 0;
 }

@@ -408,8 +408,10 @@ def ce_dlogits(logits, lse, labels, out, scale, ignore_index=-100):
 
 
 def embed_scatter_add(ids, rank, dh, dembed, n, H):
-    L.check(L.lib().vlaser_embed_scatter_add(ids.data_ptr(), rank.data_ptr(), dh.data_ptr(), dembed.data_ptr(), n, H, _stream()),
-            'vlaser_embed_scatter_add')
+    """dEmbed[id] += fp32 sum of dh over the text positions holding id (duplicates summed before the single bf16 rounding)."""
+    order = torch.sort(ids.reshape(-1)[:n], stable=True).indices.to(torch.int32)          # index bookkeeping only: equal ids -> contiguous runs
+    L.check(L.lib().vlaser_embed_scatter_add(ids.data_ptr(), rank.data_ptr(), order.data_ptr(), dh.data_ptr(), dembed.data_ptr(), n, H,
+                                             dembed.shape[0], _stream()), 'vlaser_embed_scatter_add')
 
 
 def gelu_bwd(x, dy, dx):
@@ -419,6 +421,15 @@ def gelu_bwd(x, dy, dx):
 def adamw(param, master, m, v, grad, lr, beta1, beta2, eps, wd, gscale, step):
     L.check(L.lib().vlaser_adamw(param.data_ptr(), master.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), param.numel(), lr, beta1, beta2,
                                  eps, wd, gscale, step, _stream()), 'vlaser_adamw')
+
+
+def adamw_clipped(param, master, m, v, grad, lr, beta1, beta2, eps, wd, gscale, gnorm2, max_norm, step):
+    L.check(L.lib().vlaser_adamw_clipped(param.data_ptr(), master.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), param.numel(), lr, beta1,
+                                         beta2, eps, wd, gscale, gnorm2.data_ptr(), max_norm or 0.0, step, _stream()), 'vlaser_adamw_clipped')
+
+
+def grad_accumulate(g, acc, w, first, finalize):
+    L.check(L.lib().vlaser_grad_accumulate(g.data_ptr(), acc.data_ptr(), g.numel(), w, int(first), int(finalize), _stream()), 'vlaser_grad_accumulate')
 
 
 def sumsq(x, out, ws):

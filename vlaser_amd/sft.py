@@ -237,6 +237,8 @@ class SFTModel:
         self.normw_ws = torch.zeros((S + 3) // 4 * H, dtype=F32, device=dev)      # norm-weight gradient partials of rmsnorm_bwd
         self.gnorm2 = torch.zeros(1, dtype=F32, device=dev)
         self.rank_ws = torch.zeros(S, dtype=torch.int32, device=dev)
+        self.pos_all = torch.arange(S, dtype=torch.int32, device=dev)
+        self.gacc = None                                            # fp32 gradient accumulator (allocated by the first multi-sample step)
         self._alloc_projector_ws()
         self.comm_stream = torch.cuda.Stream(device=dev) if self.dp_active else None
         self.aux_stream = torch.cuda.Stream(device=dev)        # weight transposes overlap the next step's forward
@@ -261,6 +263,10 @@ class SFTModel:
         if T > self.max_tiles:
             self.max_tiles = T
             self._alloc_projector_ws()
+
+    def _h2d(self, t):
+        """Small host index tensor -> device through a pinned staging copy (`non_blocking`: the host does not wait for the stream)."""
+        return t.contiguous().pin_memory().to(self.device, non_blocking=True)
 
     def _wait_params(self, b):
         """Block the compute stream until bucket b's parameters of the current step have been all-gathered."""
@@ -353,12 +359,26 @@ class SFTModel:
         cfg, llm, dev = self.cfg, self.llm, self.device
         v, gv = self.fp.view, self.fp.gview
         B, S = input_ids.shape
-        assert B == 1 and S <= self.S_max, 'per-GPU micro-batch 1 (BASELINE config 5)'
+        if B != 1:
+            raise ValueError('forward_backward takes ONE sample; per-device batches / gradient accumulation go through train_step()')
+        if S > self.S_max:
+            raise ValueError(f'sequence of {S} tokens exceeds max_seq_len={self.S_max}')
+        # index bookkeeping on the HOST copy of the (tiny) id / label tensors -- the collator hands CPU tensors over; CUDA inputs cost
+        # one device->host copy here.  Nothing below reads a device value back, so the whole step is queued without a host sync.
+        ids_h = input_ids.detach().to('cpu', torch.int64).reshape(1, S)
+        lab_h = labels.detach().to('cpu', torch.int64).reshape(-1)
+        if int(ids_h.min()) < 0 or int(ids_h.max()) >= llm.vocab_size:
+            raise ValueError(f'input_ids outside [0, {llm.vocab_size})')
+        tgt_h = torch.full((S,), -100, dtype=torch.int64)
+        tgt_h[:S - 1] = lab_h[1:]                                      # shift: position t predicts token t+1
+        rows_h = (tgt_h != -100).nonzero().flatten()
+        R = int(rows_h.numel())
+        n_img = int((ids_h == self.img_context_token_id).sum())
         H, I, V = llm.hidden_size, llm.intermediate_size, llm.vocab_size
         nq, nkv, hd = llm.num_attention_heads, llm.num_key_value_heads, llm.head_dim
         Lyr = llm.num_hidden_layers
-        ids = input_ids.to(dev).contiguous()
-        pos = torch.arange(S, dtype=torch.int32, device=dev)
+        ids = self._h2d(ids_h)
+        pos = self.pos_all[:S]
         # every gradient tensor is fully overwritten by its wgrad / column-sum kernel each step, except the embedding rows
         # (scatter-add over the text tokens): only that slice is cleared (466 MB instead of the whole 3.6 GB buffer)
         gv['embed'].zero_()
@@ -385,11 +405,10 @@ class SFTModel:
         ops.gemm(L.EPI_BIAS_GELU, ps_ln, v['mlp1.m1w'], out=g1, bias=v['mlp1.m1b'])
         ops.gemm(L.EPI_BIAS, g1, v['mlp1.m3w'], out=feat, bias=v['mlp1.m3b'])
         if image_flags is not None:
-            keep = image_flags.reshape(-1).to(dev) == 1
-            feat_used = feat.view(T, cfg.num_image_token, H)[keep].reshape(-1, H).contiguous()
+            keep = self._h2d((image_flags.detach().to('cpu').reshape(-1) == 1).nonzero().flatten())          # indices of the real tiles
+            feat_used = feat.view(T, cfg.num_image_token, H).index_select(0, keep).reshape(-1, H)
         else:
             feat_used = feat
-        n_img = int((ids == self.img_context_token_id).sum())
         if n_img != feat_used.shape[0]:
             raise RuntimeError(f'shape mismatch: {n_img} <IMG_CONTEXT> tokens vs {feat_used.shape[0]} visual tokens')
         # ---- embeddings + visual-token scatter
@@ -402,11 +421,7 @@ class SFTModel:
             self._layer_out(i, S, h2, act, self.h_in[i + 1, :S])
         h_fin = self.h_in[Lyr, :S]
         # ---- loss head on the labelled rows only (rows with label -100 contribute neither loss nor gradient)
-        lab = labels.to(dev).reshape(-1)
-        tgt = torch.full((S,), -100, dtype=torch.int64, device=dev)
-        tgt[:S - 1] = lab[1:]                                        # shift: position t predicts token t+1
-        rows = (tgt != -100).nonzero().flatten()
-        R = int(rows.numel())
+        rows = self._h2d(rows_h) if R else None
         xn = self.xn[:S]
         self._wait_params(0)                                         # lm_head + final norm
         ops.rmsnorm(h_fin, v['norm'], llm.rms_norm_eps, out=xn)
@@ -422,7 +437,7 @@ class SFTModel:
                     on_bucket_ready(b)
             return torch.zeros((), device=dev)
         x_rows = xn.index_select(0, rows).contiguous()
-        t_rows = tgt.index_select(0, rows).contiguous()
+        t_rows = self._h2d(tgt_h.index_select(0, rows_h))
         logits = ops.linear(x_rows, v['head'], epi=L.EPI_F32)         # [R, V] fp32
         loss_rows = torch.empty(R, dtype=F32, device=dev)
         lse = torch.empty(R, dtype=F32, device=dev)
@@ -495,12 +510,12 @@ class SFTModel:
                 on_bucket_ready(bucket_of_layer[i])
         # ---- embeddings (text rows) and projector (image rows)
         ops.embed_scatter_add(ids, self.rank_ws, dh, gv['embed'], S, H)
-        img_rows = (ids.reshape(-1) == self.img_context_token_id).nonzero().flatten()
+        img_rows = self._h2d((ids_h.reshape(-1) == self.img_context_token_id).nonzero().flatten())
         dfeat_used = dh.index_select(0, img_rows).contiguous()
         dvit = self.dvit[:nt]
         if image_flags is not None:
             dvit.zero_()
-            dvit.view(T, cfg.num_image_token, H)[keep] = dfeat_used.view(-1, cfg.num_image_token, H)
+            dvit.view(T, cfg.num_image_token, H).index_copy_(0, keep, dfeat_used.view(-1, cfg.num_image_token, H))
         else:
             dvit.copy_(dfeat_used)
         dg1, dz1, dln = self.dg1[:nt], self.dz1[:nt], self.dln[:nt]
@@ -543,15 +558,13 @@ class SFTModel:
                 ops.sumsq(self.fp.g[s_lo:s_hi], self.gnorm2, self.sumsq_ws)
         if self.dp_active:
             torch.distributed.all_reduce(self.gnorm2, group=self.pg)
-        gnorm = float(self.gnorm2.sqrt())
-        scale = 1.0
-        if self.max_grad_norm and gnorm > self.max_grad_norm:
-            scale = self.max_grad_norm / (gnorm + 1e-6)
         for (s_lo, s_hi, per), o in zip(self.shards, self.shard_off):
             if s_hi > s_lo:
                 n = s_hi - s_lo
-                ops.adamw(self.fp.p[s_lo:s_hi], self.master[o:o + n], self.m[o:o + n], self.v[o:o + n], self.fp.g[s_lo:s_hi], lr, self.betas[0],
-                          self.betas[1], self.eps, self.wd, scale, self.step_count)
+                # clip factor max_norm / (||g|| + 1e-6) resolved inside the kernel from the device-resident squared norm
+                ops.adamw_clipped(self.fp.p[s_lo:s_hi], self.master[o:o + n], self.m[o:o + n], self.v[o:o + n], self.fp.g[s_lo:s_hi], lr, self.betas[0],
+                                  self.betas[1], self.eps, self.wd, 1.0, self.gnorm2, self.max_grad_norm, self.step_count)
+        gnorm = self.gnorm2.sqrt()                                  # device tensor: reading it is the caller's (only) sync
         if self.dp_active:
             # ZeRO-1: all-gather the updated bf16 parameters bucket by bucket on the comm stream, in the order the NEXT forward
             # consumes them (embed + projector first, lm_head last); the forward waits per bucket (`_wait_params`), so the
@@ -570,12 +583,114 @@ class SFTModel:
         return gnorm
 
     def step(self, pixel_values, input_ids, labels, image_flags=None, lr=None, total_steps=None):
-        """One optimizer step.  With `total_steps` the learning rate follows the launcher's cosine schedule."""
+        """One optimizer step on one per-device batch ([B, S] ids / labels as the collator pads them, B >= 1).  With `total_steps` the
+        learning rate follows the launcher's cosine schedule."""
+        return self.train_step([(pixel_values, input_ids, labels, image_flags)], lr=lr, total_steps=total_steps)
+
+    def _split_batch(self, pixel_values, input_ids, labels, image_flags):
+        """A collated per-device batch (pad_data_collator.py:57-116: ids right-padded with 0, labels with -100, tiles of all samples
+        concatenated, `image_flags` 0 for dummy tiles) -> its samples, each trimmed to its own length, with the number of supervised
+        positions R_b (CrossEntropyLoss averages over ALL supervised tokens of the batch: sample b weighs R_b / sum R)."""
+        ids_h = input_ids.detach().to('cpu', torch.int64)
+        lab_h = labels.detach().to('cpu', torch.int64)
+        B = ids_h.shape[0]
+        nt = self.cfg.num_image_token
+        flags = None if image_flags is None else image_flags.detach().to('cpu').reshape(-1)
+        T = pixel_values.shape[0]
+        out, t0 = [], 0
+        for b in range(B):
+            nz = (ids_h[b] != 0).nonzero().flatten()
+            Lb = int(nz[-1]) + 1 if nz.numel() else 1
+            need = int((ids_h[b, :Lb] == self.img_context_token_id).sum()) // nt          # real tiles of this sample
+            t1, got = t0, 0
+            while t1 < T and got < need:
+                got += 1 if (flags is None or flags[t1] == 1) else 0
+                t1 += 1
+            if need == 0:                           # text-only sample: the dataset attaches ONE dummy tile with image_flags 0 (pure_text_get_item)
+                if flags is None or t1 >= T or flags[t1] != 0:
+                    raise ValueError('a text-only sample must come with its dummy tile (image_flags == 0), as the reference dataset emits it')
+                t1 += 1
+            if got < need:
+                raise ValueError(f'sample {b} has {need * nt} <IMG_CONTEXT> tokens but only {got} real tiles are left in pixel_values')
+            if b == B - 1 and t1 != T:
+                raise ValueError(f'{T - t1} tiles of pixel_values belong to no sample')
+            R = int((lab_h[b, 1:Lb] != -100).sum())
+            out.append((pixel_values[t0:t1], ids_h[b:b + 1, :Lb], lab_h[b:b + 1, :Lb], None if flags is None else flags[t0:t1].reshape(-1, 1), R))
+            t0 = t1
+        return out
+
+    def _accumulate_bucket(self, b, w, first, last):
+        """Sample-wise gradient accumulation, bucket by bucket as the backward completes them: acc (fp32) += w * g; on the LAST sample
+        the bucket is rounded back to bf16 and handed to the exchange (one reduce-scatter per bucket per step, like DDP's no_sync /
+        DeepSpeed's gradient-accumulation boundary: train.py:470-482, zero_stage1_config.json)."""
+        lo, hi = self.buckets[b]
+        ops.grad_accumulate(self.fp.g[lo:hi], self.gacc[lo:hi], w, first, last)
+        if last:
+            self._exchange_bucket(b)
+
+    def train_step(self, micro_batches, lr=None, total_steps=None):
+        """One optimizer step over `len(micro_batches)` gradient-accumulation micro-batches, each a per-device batch
+        `(pixel_values, input_ids [B,S], labels [B,S], image_flags)` -- the reference launcher's PER_DEVICE_BATCH_SIZE x GRADIENT_ACC
+        (…2nd_finetune_full.sh:5-6,49-50).  HF Trainer semantics: each micro-batch's loss is the mean over its supervised tokens,
+        divided by the number of accumulation steps; gradients add up.  The kernels run one sample at a time, so sample b of a
+        micro-batch enters with weight (R_b / R_batch) / n_micro; partial sums live in an fp32 accumulator."""
         if lr is None and total_steps is not None:
             lr = cosine_lr(self.step_count, total_steps, self.lr)
-        loss = self.forward_backward(pixel_values, input_ids, labels, image_flags, on_bucket_ready=self._exchange_bucket)
+        GA = len(micro_batches)
+        work = []
+        for mb in micro_batches:
+            pv, ids, lab = mb[0], mb[1], mb[2]
+            fl = mb[3] if len(mb) > 3 else None
+            if ids.shape[0] == 1 and GA == 1:
+                work.append((pv, ids, lab, fl, 1.0))
+                continue
+            smp = self._split_batch(pv, ids, lab, fl)
+            Rt = sum(x[4] for x in smp)
+            for (pvb, idb, lbb, flb, Rb) in smp:
+                work.append((pvb, idb, lbb, flb, (Rb / Rt if Rt else 0.0) / GA))
+        if len(work) == 1:
+            loss = self.forward_backward(*work[0][:4], on_bucket_ready=self._exchange_bucket)
+        else:
+            if self.gacc is None:
+                self.gacc = torch.zeros(self.fp.n, dtype=F32, device=self.device)
+            loss = torch.zeros((), device=self.device)
+            for j, (pvb, idb, lbb, flb, w) in enumerate(work):
+                first, last = j == 0, j == len(work) - 1
+                lj = self.forward_backward(pvb, idb, lbb, flb, on_bucket_ready=lambda b, w=w, first=first, last=last: self._accumulate_bucket(b, w, first, last))
+                loss = loss + lj * w
         gnorm = self.optimizer_step(lr)
         return SimpleNamespace(loss=loss, grad_norm=gnorm)
+
+    # ------------------------------------------------------------------ resumable training state
+    def save_checkpoint(self, path):
+        """Everything a run needs to resume bit-identically (HF Trainer checkpoints, internvl_chat_finetune.py:847-860,1051-1068; VLA
+        `step{N}.pt`, train.py:639-672): rank 0 writes the HF-layout weights (`save_pretrained`), EVERY rank writes its ZeRO-1 shard
+        of the fp32 masters + AdamW moments and the step counter (DeepSpeed shards optimizer state per rank the same way)."""
+        os.makedirs(path, exist_ok=True)
+        if self.rank == 0:
+            self.save_pretrained(path)
+        if self.dp_active:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        torch.save({'step_count': self.step_count, 'world': self.world, 'rank': self.rank, 'shards': self.shards, 'lr': self.lr, 'betas': self.betas,
+                    'eps': self.eps, 'weight_decay': self.wd, 'master': self.master.cpu(), 'exp_avg': self.m.cpu(), 'exp_avg_sq': self.v.cpu()},
+                   os.path.join(path, f'optimizer_rank{self.rank:05d}_of_{self.world:05d}.pt'))
+
+    def load_checkpoint(self, path):
+        """Weights through `load_hf_checkpoint` (key names unchanged), then this rank's optimizer shard; the bf16 parameters are
+        re-derived from the fp32 masters so the resumed run continues bit for bit."""
+        from .config import load_hf_checkpoint
+        _, sd = load_hf_checkpoint(path)
+        self.load_state_dict(sd)
+        st = torch.load(os.path.join(path, f'optimizer_rank{self.rank:05d}_of_{self.world:05d}.pt'), map_location='cpu', weights_only=False)
+        if st['world'] != self.world or [tuple(x) for x in st['shards']] != [tuple(x) for x in self.shards]:
+            raise ValueError(f"optimizer shard was written for world size {st['world']} / another bucket layout")
+        self.step_count = st['step_count']
+        self.master.copy_(st['master']); self.m.copy_(st['exp_avg']); self.v.copy_(st['exp_avg_sq'])
+        for (lo, hi, _), o in zip(self.shards, self.shard_off):
+            if hi > lo:
+                self.fp.p[lo:hi].copy_(self.master[o:o + hi - lo].to(BF))
+        self._refresh_transposes()
+        return self
 
     def save_pretrained(self, path, max_shard_bytes=4 << 30):
         """HF-layout checkpoint (config.json + sharded safetensors + index) of the current weights: trainable tensors from the flat
