@@ -375,13 +375,13 @@ def test_proprio_row_riding_with_step0_is_bit_identical(golden_model, golden_dir
 
 def test_vlaser_8b_widths_multi_tile_generate():
     """BASELINE configs[3] geometry at true 8B widths (hidden 3584, 28 q / 4 kv heads, MLP 18944), depth-truncated, 2 tiles:
-    prefill + greedy decode vs the fp32 CPU oracle.  The 3584-wide decoder does not fit the weight-streaming kernels'
-    K-step budget, so its decode steps run on the MFMA GEMM path (still HIP, no fallback off the GPU)."""
+    prefill + greedy decode vs the fp32 CPU oracle.  The 3584-wide decoder decodes on the weight-streaming kernels through their
+    chunked-K variants (hidden 3584 = 2 x 7 steps per wave; MLP 18944 zero-padded to 20480)."""
     from oracle import vlm as ovlm
     from vlaser_amd import config as C, synth, ops
     from vlaser_amd.internvl_chat import InternVLChatModel
     cfg = C.truncated(C.vlaser_8b(), 1, 2)
-    assert not ops.skinny_supported(cfg.llm) and ops.skinny_supported(C.vlaser_2b().llm)
+    assert ops.skinny_supported(cfg.llm) and ops.skinny_supported(C.vlaser_2b().llm)
     sd = synth.vlm_state_dict(cfg)
     m = InternVLChatModel(cfg, max_tiles=2, max_seq_len=640)
     m.load_state_dict(sd)
@@ -401,5 +401,35 @@ def test_vlaser_8b_widths_multi_tile_generate():
     assert gen[0, :n_clear].cpu().tolist() == ogen[0, :n_clear].tolist()
     if n_clear == 4:       # teacher-forced agreement all the way: the decode-step logits match too
         assert (lg[0, 3].cpu() - olg[0, 3]).abs().max() < 3e-2 * olg[0, 3].abs().max()
+    del m
+    torch.cuda.empty_cache()
+
+
+def test_config4_shape_8b_widths_13_tiles_vs_oracle():
+    """BASELINE configs[3] at its real SHAPE: Vlaser-8B widths x 13 tiles (12 + thumbnail) -> S = 13*256 + 48 + 32 = 3408 prompt tokens,
+    depth-truncated (1 ViT layer, 2 LLM layers): prefill logits + greedy ids vs the fp32 oracle, decode on the chunked-K
+    weight-streaming kernels.  (r01 tested the widths at 2 tiles and 13 tiles at 2B widths, never together.)"""
+    from oracle import vlm as ovlm
+    from vlaser_amd import config as C, synth
+    from vlaser_amd.internvl_chat import InternVLChatModel
+    cfg = C.truncated(C.vlaser_8b(), 1, 2)
+    sd = synth.vlm_state_dict(cfg)
+    m = InternVLChatModel(cfg, max_tiles=13, max_seq_len=3456)
+    m.load_state_dict(sd)
+    assert m.use_skinny
+    m.img_context_token_id = cfg.img_context_token_id
+    g = torch.Generator().manual_seed(44)
+    pv = torch.randn(13, 3, 448, 448, generator=g)
+    ids = torch.cat([torch.randint(0, 151643, (41,), generator=g), torch.full((13 * 256,), cfg.img_context_token_id),
+                     torch.randint(0, 151643, (39,), generator=g)])[None]
+    assert ids.shape[1] == 3408
+    gen, lg = m.generate(pv, ids, max_new_tokens=3, return_logits=True)
+    ogen, olg = ovlm.generate(sd, cfg, pv, ids, max_new_tokens=3, eos_token_id=None, return_logits=True)
+    for t in range(3):
+        assert (lg[0, t].cpu() - olg[0, t]).abs().max() < 3e-2 * olg[0, t].abs().max(), t
+        t2 = olg[0, t].topk(2).values
+        if (t2[0] - t2[1]).item() < 0.08:
+            break
+        assert gen[0, t].item() == ogen[0, t].item()
     del m
     torch.cuda.empty_cache()

@@ -488,3 +488,40 @@ def test_gemm_glds_ragged_and_splitk(ops, bm):
     part = torch.zeros(S, M, N, dtype=torch.float32, device='cuda')
     ops.gemm(L.EPI_PARTIAL, x, w, out_f32=part, k_splits=S, force_bm=bm)
     close(part.sum(0), x.float() @ w.float().t(), rtol=2e-3, atol=2e-3, name=f'split-K cfg{bm}')
+
+
+def test_skinny_chunked_k_vlaser_8b_widths(ops):
+    """Chunked-K weight streaming: K / (k_splits * 256) = 14 or 16 steps per wave run as two chunks of 7 / 8 with
+    the accumulators carried across chunks -- Vlaser-8B's hidden 3584 (qkv / gate+up / lm_head, NORM prologue) and its MLP width
+    18944, zero-padded to 20480 = 5 splits x 16 steps (down projection)."""
+    from vlaser_amd import _lib as L
+    M, H, I = 5, 3584, 18944
+    assert ops.skinny_geometry(I, H) == (20480, 5) and ops.skinny_geometry(H, H)[0] == H
+    h = rnd(M, H); nw = (1 + 0.1 * rnd(H, seed=2).float()).to(BF)
+    parts = (torch.randn(2, M, H, generator=torch.Generator().manual_seed(1)) * 0.1).cuda()
+    hs = (h.float() + parts.sum(0)).to(BF)
+    xn = _rms_ref(hs, nw).to(BF).float()
+    # gate/up with the fused residual + RMSNorm prologue, K = 3584 (14 steps = 2 x 7)
+    g, u = rnd(512, H, std=0.03, seed=3), rnd(512, H, std=0.03, seed=4)
+    act = torch.zeros(M, 512, dtype=BF, device='cuda'); hout = torch.zeros(M, H, dtype=BF, device='cuda')
+    ops.skinny(L.PRO_NORM, L.SK_SWIGLU, h, ops.pack_skinny(ops.pack_gate_up(g, u)), M, partials=parts, n_partials=2, norm_w=nw, h_out=hout, out=act, ldo=512)
+    gr = (xn @ g.float().t()).to(BF).float(); ur = (xn @ u.float().t()).to(BF).float()
+    close(act, F.silu(gr).to(BF).float() * ur, name='chunked NORM+SWIGLU')
+    assert torch.equal(hout, hs)
+    # fp32 logits head, ragged N
+    wv = rnd(1000, H, std=0.03, seed=5)
+    lg = torch.zeros(M, 1000, dtype=torch.float32, device='cuda')
+    ops.skinny(L.PRO_NORM, L.SK_F32, h, ops.pack_skinny(wv), M, partials=parts, n_partials=2, norm_w=nw, out_f32=lg)
+    close(lg, xn @ wv.float().t(), rtol=2e-3, atol=2e-2, name='chunked NORM+F32')
+    # down projection: K = 18944 zero-padded to 20480, 5 split-K slabs of 16 steps (2 x 8)
+    kp, ks = ops.skinny_geometry(I, H)
+    x = torch.zeros(M, kp, dtype=BF, device='cuda'); x[:, :I] = rnd(M, I, seed=6)
+    wd = rnd(256, I, std=0.03, seed=7)
+    part = torch.zeros(ks, M, 256, dtype=torch.float32, device='cuda')
+    ops.skinny(L.PRO_PLAIN, L.SK_PARTIAL, x, ops.pack_skinny(wd, ks, k_pad=kp), M, out_f32=part)
+    close(part.sum(0), x[:, :I].float() @ wd.float().t(), rtol=2e-3, atol=2e-2, name='chunked padded down')
+    # plain bias epilogue, 16 rows, K = 3584
+    x16, wb, bb = rnd(16, H, seed=8), rnd(320, H, std=0.03, seed=9), rnd(320, std=0.3, seed=10)
+    o = torch.zeros(16, 320, dtype=BF, device='cuda')
+    ops.skinny(L.PRO_PLAIN, L.SK_BIAS, x16, ops.pack_skinny(wb), 16, out=o, ldo=320, bias=bb)
+    close(o, x16.float() @ wb.float().t() + bb.float(), name='chunked PLAIN+BIAS M=16')

@@ -25,6 +25,7 @@
 //   * one copy of K-loop / reduce / epilogue per peel: small code, a cold instruction cache is paid on every launch.
 // MFMA operands are swapped (W as A, x as B) so each lane owns 4 consecutive outputs n of one row m, sharing the
 // fused epilogues of the big GEMM (bias / SiLU / SwiGLU / RoPE + KV-cache scatter).
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -150,14 +151,18 @@ __device__ __forceinline__ void skinny_epilogue(const VlaserSkinnyArgs& a, int k
 // SP > 0 (ATTN prologue): exact attention-split count.  SP >= 0 (NORM prologue): the split-K slab count is a compile-time constant -> exactly 2 + 2*SP loads per chunk and no
 // clamped dummy loads / selects.  The prologue is instruction-issue bound (8 waves share 4 SIMDs, ~8 cycles per VALU op
 // per wave), so the generic runtime-count path (SP = -1) costs ~2 us more per launch at SP = 5.
-template <int PRO, int EPI, int TPU, int NS, int SP = -1>
+// NCH > 1 (chunked K): a wave's K range is NCH chunks of NS steps; the pipelined item is a (unit, chunk) pair and the accumulators
+// live across the chunks of a unit -- hidden sizes whose K / (k_splits * 256) exceeds the 8 steps a wave can hold in registers at
+// once (Vlaser-8B: 3584 = 14 x 256 -> 2 chunks of 7; its MLP width 18944 is zero-padded to 20480 = 5 splits x 2 chunks of 8).
+template <int PRO, int EPI, int TPU, int NS, int SP = -1, int NCH = 1>
 __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
   constexpr int RPU = TPU * 16;                 // rows per unit
-  constexpr int NF = TPU * NS;                  // fragments (16-byte loads) per lane per unit
+  constexpr int NF = TPU * NS;                  // fragments (16-byte loads) per lane per pipelined item (unit, or chunk of a unit)
+  constexpr int NST = NS * NCH;                 // K-steps per wave per unit
   constexpr bool NEED_EPI = (EPI == VL_SK_BIAS || EPI == VL_SK_BIAS_SILU || EPI == VL_SK_QKV_ROPE || EPI == VL_SK_F32);
   // EARLY (gate/up: 2-3 units per block): units 1 and 2 are requested as soon as the prologue's own loads are back
   // (first barrier) instead of one unit ahead of the MFMAs, so the HBM stream does not restart after the ~3 us prologue
-  constexpr bool EARLY = (PRO == VL_PRO_NORM && EPI == VL_SK_SWIGLU);
+  constexpr bool EARLY = (PRO == VL_PRO_NORM && EPI == VL_SK_SWIGLU && NCH == 1);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const VlaserSkinnyArgs& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -178,10 +183,10 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
   char* wn_lds = smem + xs_bytes + 2 * (SKW - 1) * TPU * 64 * 16;         // [K] bf16 norm weight (NORM prologue)
 
   // ------------------------------------------------------------------ weight stream (fragment-major packed weights)
-  const int kl0 = wave * (NS * 32);           // block-local k start of this wave
-  // 16-byte index of (ks, unit u, wave, step s, tile t, lane) = ((((ks*n_units + u)*SKW + wave)*NS + s)*TPU + t)*64 + lane
-  const u32x4* wp = reinterpret_cast<const u32x4*>(a.W) + ((size_t)ks * n_units * SKW + wave) * (NF * 64) + lane;
-  constexpr size_t unit_stride = (size_t)SKW * NF * 64;
+  const int kl0 = wave * (NST * 32);          // block-local k start of this wave
+  // 16-byte index of (ks, unit u, wave, step s, tile t, lane) = ((((ks*n_units + u)*SKW + wave)*NST + s)*TPU + t)*64 + lane
+  const u32x4* wp = reinterpret_cast<const u32x4*>(a.W) + ((size_t)ks * n_units * SKW + wave) * (NF * NCH * 64) + lane;
+  constexpr size_t unit_stride = (size_t)SKW * NF * NCH * 64;
   const int m = fr;
   u32x4 cw[NF], nw[NF], tw[EARLY ? NF : 1];  // current / next (/ third, EARLY) unit
   EpiOps ce[NEED_EPI ? TPU / 2 : 1], ne[NEED_EPI ? TPU / 2 : 1], te[1];
@@ -390,6 +395,75 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
   const char* xrow = xs + (fr < a.M ? fr : 0) * p.xs_stride + (kl0 + g * 8) * 2;
   const bool mok = fr < a.M;
   int par = 0;
+  if constexpr (NCH > 1) {
+    f32x4 acc[TPU];
+#pragma unroll
+    for (int t = 0; t < TPU; ++t) acc[t] = f32x4{0, 0, 0, 0};
+    auto load_item = [&](int ui, int c, u32x4* dst, EpiOps* e) {
+      const u32x4* src = wp + (size_t)(ustart + ui) * unit_stride + (size_t)c * (NF * 64);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) dst[f] = __builtin_nontemporal_load(src + f * 64);
+      if constexpr (NEED_EPI) {
+#pragma unroll
+        for (int pr = 0; pr < TPU / 2; ++pr) load_epi<EPI>(a, (ustart + ui) * (TPU / 2) + pr, m, g, e[pr]);
+      }
+    };
+    auto mma = [&](int c, const u32x4* w) {
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        u32x4 xv = {0, 0, 0, 0};
+        if (mok) xv = *reinterpret_cast<const u32x4*>(xrow + (c * NS + u) * 64);
+        const bf16x8 xf = as_bf16x8(xv);
+#pragma unroll
+        for (int t = 0; t < TPU; ++t) acc[t] = mfma16(as_bf16x8(w[TPU * u + t]), xf, acc[t]);
+      }
+    };
+    auto finish = [&](int ui, const EpiOps* e) {          // in-block split-K reduce + epilogue of one unit (as consume_finish below)
+      float* rb = red + par * (SKW - 1) * TPU * 64 * 4;
+      if (wave != 0) {
+        float* r = rb + ((wave - 1) * TPU * 64 + lane) * 4;
+#pragma unroll
+        for (int t = 0; t < TPU; ++t) *reinterpret_cast<f32x4*>(r + t * 64 * 4) = acc[t];
+      }
+      __syncthreads();
+      par ^= 1;
+      if (wave == 0) {
+#pragma unroll
+        for (int w2 = 0; w2 < SKW - 1; ++w2) {
+          const float* r = rb + (w2 * TPU * 64 + lane) * 4;
+#pragma unroll
+          for (int t = 0; t < TPU; ++t) acc[t] += *reinterpret_cast<const f32x4*>(r + t * 64 * 4);
+        }
+        if (m < a.M) {
+#pragma unroll
+          for (int pr = 0; pr < TPU / 2; ++pr)
+            skinny_epilogue<EPI>(a, ks, (ustart + ui) * (TPU / 2) + pr, m, g, acc[2 * pr], acc[2 * pr + 1], e[NEED_EPI ? pr : 0]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TPU; ++t) acc[t] = f32x4{0, 0, 0, 0};
+    };
+    // item 0 was requested by the prologue (load_unit(0) = chunk 0 of unit 0: the first NF fragments of the unit)
+    const int n_items = ucount * NCH;
+    int ui = 0, c = 0;
+    for (int it = 0; it + 1 < n_items; ++it) {             // item it+1 in flight while item it is consumed; last item peeled
+      int c2 = c + 1, ui2 = ui;
+      if (c2 == NCH) { c2 = 0; ++ui2; }
+      load_item(ui2, c2, nw, ne);
+      mma(c, cw);
+      if (c == NCH - 1) finish(ui, ce);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) cw[f] = nw[f];
+      if constexpr (NEED_EPI) {
+#pragma unroll
+        for (int pr = 0; pr < TPU / 2; ++pr) ce[pr] = ne[pr];
+      }
+      ui = ui2; c = c2;
+    }
+    mma(c, cw);
+    finish(ui, ce);
+    return;
+  }
   auto consume_finish = [&](int ui, const u32x4* w, const EpiOps* e) {
     f32x4 acc[TPU];
 #pragma unroll
@@ -461,19 +535,26 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
 #undef STAMP
 }
 
-template <int PRO, int EPI, int TPU, int NS, int SP>
+template <int PRO, int EPI, int TPU, int NS, int SP, int NCH = 1>
 static int launch_sp(const VlaserSkinnyArgs* a, hipStream_t stream, SkinnyP& p, int gx, int lds) {
-  static int attr_lds = 0;
-  if (lds > attr_lds) {
-    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel<PRO, EPI, TPU, NS, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_lds = lds;
+  // one attribute call per (kernel, device, size): the C ABI is used from several threads / GPUs
+  static std::mutex mu;
+  static int attr_lds[64] = {0};
+  int dev = 0;
+  VL_HIP(hipGetDevice(&dev));
+  {
+    std::lock_guard<std::mutex> g(mu);
+    if (dev < 0 || dev >= 64 || lds > attr_lds[dev]) {
+      VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel<PRO, EPI, TPU, NS, SP, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      if (dev >= 0 && dev < 64) attr_lds[dev] = lds;
+    }
   }
-  hipLaunchKernelGGL((skinny_kernel<PRO, EPI, TPU, NS, SP>), dim3(gx, a->k_splits), dim3(SKT), lds, stream, p);
+  hipLaunchKernelGGL((skinny_kernel<PRO, EPI, TPU, NS, SP, NCH>), dim3(gx, a->k_splits), dim3(SKT), lds, stream, p);
   VL_LAUNCH_CHECK();
   return 0;
 }
 
-template <int PRO, int EPI, int TPU, int NS>
+template <int PRO, int EPI, int TPU, int NS, int NCH = 1>
 static int launch_ns(const VlaserSkinnyArgs* a, hipStream_t stream) {
   SkinnyP p;
   p.a = *a;
@@ -489,6 +570,7 @@ static int launch_ns(const VlaserSkinnyArgs* a, hipStream_t stream) {
   p.ulo = n_units / gx;
   p.urem = n_units % gx;
   p.attn_nkv = PRO == VL_PRO_ATTN ? a->K / (128 * a->attn_group) : 0;
+  if constexpr (NCH > 1) return launch_sp<PRO, EPI, TPU, NS, -1, NCH>(a, stream, p, gx, lds);
   // exact slab-count variants for the hidden sizes / split factors this path produces (engine.py: ks_o, ks_down)
   if constexpr (PRO == VL_PRO_ATTN && (TPU == 2 || TPU == 1) && (NS == 2 || NS == 3)) {   // exact attention-split count (o_proj of the expert / LLM)
     switch (a->attn_splits) {
@@ -554,8 +636,10 @@ static int launch(const VlaserSkinnyArgs* a, hipStream_t stream) {
     case 6: return launch_ns<PRO, EPI, 2, 6>(a, stream);
     case 7: return launch_ns<PRO, EPI, 2, 7>(a, stream);
     case 8: return launch_ns<PRO, EPI, 2, 8>(a, stream);
+    case 14: return launch_ns<PRO, EPI, 2, 7, 2>(a, stream);        // chunked K: 2 x 7 steps (hidden 3584)
+    case 16: return launch_ns<PRO, EPI, 2, 8, 2>(a, stream);        // 2 x 8 steps (MLP 20480 / 5 splits)
     default:
-      vlaser_set_error("vlaser_skinny: K/(k_splits*256) = %d K-steps per wave unsupported (1..8): raise k_splits", ns);
+      vlaser_set_error("vlaser_skinny: K/(k_splits*256) = %d K-steps per wave unsupported (1..8, 14, 16): raise k_splits or pad K", ns);
       return -1;
   }
 }

@@ -28,7 +28,7 @@ class QwenLayerWeights:
     """One Qwen2DecoderLayer in kernel layout: row-major packed matrices for the MFMA GEMM (prefill) and/or
     fragment-major copies for the weight-streaming skinny kernel (decode / action tokens)."""
 
-    def __init__(self, sd, p, llm: LLMConfig, device, ks_o, ks_down, gemm=True, skinny=True, tpu_down=2, tpu_o=2):
+    def __init__(self, sd, p, llm: LLMConfig, device, ks_o, ks_down, gemm=True, skinny=True, tpu_down=2, tpu_o=2, i_pad=None):
         g = lambda k: _dev(sd[p + k], device)
         wqkv, self.bqkv = ops.pack_qkv(g('self_attn.q_proj.weight'), g('self_attn.k_proj.weight'),
                                        g('self_attn.v_proj.weight'), g('self_attn.q_proj.bias'),
@@ -46,7 +46,7 @@ class QwenLayerWeights:
             # wide output + short K (action expert: 17920 x 768): 96-row units -> one unit per block, single load batch
             tpu = 2      # 96-row units (tpu = 6) measured slower on MI355X (12.3 vs 11.2 us): kept in the kernel, not used
             self.sk_gu = ops.pack_skinny(wgu, 1, tpu)
-            self.sk_down = ops.pack_skinny(wdown, ks_down, tpu_down)
+            self.sk_down = ops.pack_skinny(wdown, ks_down, tpu_down, k_pad=i_pad)
 
 
 class QwenStack:
@@ -59,15 +59,16 @@ class QwenStack:
         # o_proj on 16-row units where the kernel has the variant: the same ~144 workgroups with half the split-K slabs for the
         # gate/up prologue to sum (chunk time unchanged, the dominant gate/up GEMV 8.9 -> 8.6 us; same-box A/B)
         ks16o = ops.pick_k_splits(nqd, H, rows_per_unit=16)
-        self.tpu_o = 1 if (nqd % (ks16o * 256) == 0 and nqd // (ks16o * 256) in (2, 3)) else 2
-        self.ks_o = ks16o if self.tpu_o == 1 else ops.pick_k_splits(nqd, H)
+        self.tpu_o = 1 if (ks16o is not None and nqd // (ks16o * 256) in (2, 3)) else 2
+        self.ks_o = ks16o if self.tpu_o == 1 else ops.skinny_geometry(nqd, H)[1]
         # down_proj (narrow output, long K): 16-row units double the workgroups that stream it (48 units x 5 splits = 240 for the expert)
         # when the kernel has that variant (5 or 7 K-steps per wave); measured +0.9 % chunks/s over 32-row units x 7 splits
         ks16 = ops.pick_k_splits(I, H, rows_per_unit=16)
-        self.tpu_down = 1 if I % (ks16 * 256) == 0 and I // (ks16 * 256) in (5, 7) else 2
-        self.ks_down = ks16 if self.tpu_down == 1 else ops.pick_k_splits(I, H)
+        self.tpu_down = 1 if (ks16 is not None and I // (ks16 * 256) in (5, 7)) else 2
+        self.I_pad, ks32 = ops.skinny_geometry(I, H)            # widths that do not factor (Vlaser-8B: 18944) are zero-padded: act buffer + down weight
+        self.ks_down = ks16 if self.tpu_down == 1 else ks32
         self.nqd = nqd
-        self.layers = [QwenLayerWeights(sd, f'{prefix}model.layers.{i}.', llm, device, self.ks_o, self.ks_down, gemm, skinny, self.tpu_down, self.tpu_o)
+        self.layers = [QwenLayerWeights(sd, f'{prefix}model.layers.{i}.', llm, device, self.ks_o, self.ks_down, gemm, skinny, self.tpu_down, self.tpu_o, self.I_pad)
                        for i in range(llm.num_hidden_layers)]
         self.norm = _dev(sd[prefix + 'model.norm.weight'], device)
         self.embed = _dev(sd[prefix + 'model.embed_tokens.weight'], device) if with_embed else None
@@ -263,7 +264,7 @@ class SkinnyBuffers:
         self.hA, self.hB = z(max_rows, H), z(max_rows, H)
         self.q = z(max_rows, stack.nq * llm.head_dim)
         self.ao = z(max_rows, stack.nq * llm.head_dim)
-        self.act = z(max_rows, I)
+        self.act = z(max_rows, getattr(stack, 'I_pad', I))      # zero padding columns (never written) feed the zero-padded down weight
         self.attn_parts = ops.attn_partial_buffers(max_rows, stack.nkv, device)
         self.part_o = torch.zeros(stack.ks_o, max_rows, H, dtype=torch.float32, device=device)
         self.part_d = torch.zeros(stack.ks_down, max_rows, H, dtype=torch.float32, device=device)
@@ -298,7 +299,7 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
             plan.o = ops.skinny_args(None, lw.sk_o, M, out_f32=sb.part_o, attn_m=sb.attn_parts[0], attn_l=sb.attn_parts[1],
                                      attn_o=sb.attn_parts[2], attn_splits=1, attn_group=nq // nkv, attn_nq=tok_per_batch)
             plan.gu = ops.skinny_args(sb.hA, lw.sk_gu, M, partials=sb.part_o, n_partials=stack.ks_o, norm_w=lw.ln_post, eps=llm.rms_norm_eps,
-                                      h_out=sb.hB, out=sb.act, ldo=llm.intermediate_size)
+                                      h_out=sb.hB, out=sb.act, ldo=sb.act.shape[1])
             plan.down = ops.skinny_args(sb.act, lw.sk_down, M, out_f32=sb.part_d)
         if len(sb.plans) > 4096:         # keys hold buffer addresses of per-call tensors (ragged lengths): bound the cache
             sb.plans.clear()

@@ -163,18 +163,24 @@ class PackedW:
 
 
 SK_WAVES = 8
+SK_STEPS = (1, 2, 3, 4, 5, 6, 7, 8, 14, 16)      # K-steps (of 32) per wave the kernel is built for; 14 / 16 = two chunks of 7 / 8
 
 
-def pack_skinny(W, k_splits=1, tpu=2):
+def pack_skinny(W, k_splits=1, tpu=2, k_pad=None):
     """Row-major [N,K] bf16 -> PackedW.  Lane (r = l&15, g = l>>4) of wave w, K-step s, tile t of unit u, split ks holds
-    W[u*32 + t*16 + r, ks*kb + w*kw + s*32 + g*8 : +8]; each wave-level load is a contiguous 1 KiB."""
+    W[u*32 + t*16 + r, ks*kb + w*kw + s*32 + g*8 : +8]; each wave-level load is a contiguous 1 KiB.  k_pad > K appends zero
+    columns (widths that do not factor into k_splits x 8 waves x an available step count; the activation is zero-padded alike)."""
     N, K = W.shape
+    if k_pad is not None and k_pad > K:
+        W = torch.cat([W, torch.zeros(N, k_pad - K, dtype=W.dtype, device=W.device)], 1)
+        K = k_pad
     assert K % (k_splits * 32 * SK_WAVES) == 0, (K, k_splits)
     rpu = 16 * tpu
     Np = (N + rpu - 1) // rpu * rpu
     if Np != N:
         W = torch.cat([W, torch.zeros(Np - N, K, dtype=W.dtype, device=W.device)], 0)
     ns = K // (k_splits * SK_WAVES * 32)
+    assert ns in SK_STEPS, f'{ns} K-steps per wave: not a kernel variant {SK_STEPS}'
     v = W.view(Np // rpu, tpu, 16, k_splits, SK_WAVES, ns, 4, 8)       # [u, t, r, ks, w, s, g, e]
     v = v.permute(3, 0, 4, 5, 1, 6, 2, 7).contiguous()                 # [ks, u, w, s, t, g, r, e]
     return PackedW(v.reshape(-1), Np, N, K, k_splits, tpu)
@@ -211,14 +217,14 @@ SK_TARGET_BLOCKS = 130
 
 
 def pick_k_splits(K, N, target_blocks=None, rows_per_unit=32):
-    """Smallest cross-block split-K factor that (a) keeps K/k_splits a multiple of 256 (8 waves x 32) and (b) gives
-    about one block per CU (units = N/32)."""
+    """Smallest cross-block split-K factor that (a) keeps K/k_splits a multiple of 256 (8 waves x 32) with a step count the kernel
+    has, and (b) gives about one block per CU (units = N/rows_per_unit); None when K does not factor that way (see skinny_geometry)."""
     if target_blocks is None:
         target_blocks = SK_TARGET_BLOCKS
     units = (N + rows_per_unit - 1) // rows_per_unit
-    best = 1
+    best = None
     for s in range(1, 9):            # <= 8 slabs: the consumer's prologue sums them in ONE batch of loads
-        if K % (s * 256):
+        if K % (s * 256) or K // (s * 256) not in SK_STEPS:
             continue
         best = s
         if units * s >= target_blocks:
@@ -226,15 +232,31 @@ def pick_k_splits(K, N, target_blocks=None, rows_per_unit=32):
     return best
 
 
+def skinny_geometry(K, N, target_blocks=None, rows_per_unit=32):
+    """(K_pad, k_splits) of a [N, K] weight for the weight-streaming kernel.  K_pad == K whenever K factors into
+    k_splits x 8 waves x an available step count; otherwise the least zero-padding that does (Vlaser-8B's MLP width
+    18944 = 2^9 x 37 -> 20480 = 5 splits x 16 steps, +8 % on the down projection only)."""
+    ks = pick_k_splits(K, N, target_blocks, rows_per_unit)
+    if ks is not None:
+        return K, ks
+    best = None
+    for s in range(1, 9):
+        for ns in SK_STEPS:
+            kp = s * ns * 256
+            if kp >= K:
+                if best is None or kp < best[0]:
+                    best = (kp, s)
+                break
+    return best
+
+
 def skinny_supported(llm):
-    """True when every matrix of a Qwen2 layer (+ lm_head) fits the weight-streaming kernel's 1..8 K-steps per wave
-    (K / (k_splits * 256)); Vlaser-2B and the 768-wide action expert do, the 3584-wide Vlaser-8B does not and decodes
-    through the MFMA GEMM path instead."""
+    """True when every matrix of a Qwen2 layer (+ lm_head) has a weight-streaming geometry: Vlaser-2B, the 768-wide action expert
+    and (with chunked K / a zero-padded MLP width) Vlaser-8B."""
     H, I, nqd = llm.hidden_size, llm.intermediate_size, llm.num_attention_heads * llm.head_dim
-    for K, ks in ((H, 1), (nqd, pick_k_splits(nqd, H)), (I, pick_k_splits(I, H))):
-        if K % (ks * 256) or not 1 <= K // (ks * 256) <= 8:
-            return False
-    return True
+    if H % 256 or H // 256 not in SK_STEPS:          # NORM-prologue kernels (qkv, gate/up, lm_head) cannot split or pad K
+        return False
+    return skinny_geometry(nqd, H)[0] == nqd and skinny_geometry(I, H) is not None
 
 
 # ------------------------------------------------------------------------------------------------ helpers
