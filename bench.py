@@ -142,8 +142,9 @@ def sft_cpu_baseline(cfg_full, S=560, R=128):
                 ovit.vision_forward(sd, cfg.vision, pv)
             t1 = time.perf_counter()
             opt.zero_grad(set_to_none=True)
-            loss = ovlm.sft_loss(ovlm.forward_logits(sd, cfg, pv, ids), labels)
-            loss.backward()
+            with torch.enable_grad():
+                loss = ovlm.sft_loss(ovlm.forward_logits(sd, cfg, pv, ids), labels)
+                loss.backward()
             t2 = time.perf_counter()
             opt.step()
             t3 = time.perf_counter()
@@ -248,6 +249,7 @@ def main():
     ap.add_argument('--sft-steps', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-8b', action='store_true', help='skip the Vlaser-8B x 13-tile side numbers (BASELINE configs[3])')
 
     ap.add_argument('--dry-run', action='store_true', help='rendezvous only (gloo, no GPU work): checks the N-rank launch path')
     a = ap.parse_args()
@@ -328,6 +330,12 @@ def main():
         if not a.no_roofline:
             avg_ms, byts, n = _probe(model)
             ach = byts / (avg_ms * 1e-3) / 1e9
+            # whole-chunk floor: 1 726 GFLOP of ViT + projector + joint prefill on MFMA (2.5 PFLOP/s dense bf16) + 10 Euler steps x
+            # 1.310 GB of expert weights (+ 11.2 MB of K/V each) over HBM (8 TB/s) = 0.690 + 1.652 ms
+            floor_ms = 1726e9 / 2.5e15 * 1e3 + 10 * (1.310e9 + 11.2e6) / 8e12 * 1e3
+            line['chunk_roofline'] = {'floor_ms': round(floor_ms, 3), 'ms_per_chunk': round(dt / a.steps * 1e3, 3), 'frac': round(floor_ms / (dt / a.steps * 1e3), 4),
+                                      'note': 'MFMA-bound part at 2.5 PFLOP/s + HBM-bound Euler part at 8 TB/s; the Euler phase is a chain of 1 400 dependent launches '
+                                              '(5 per layer-step), see DESIGN.md section 3'}
             line['roofline'] = {'bound': 'hbm', 'kernel': 'skinny_kernel<NORM,SWIGLU> (action-expert gate/up GEMV, N=17920 K=768, M=4; 307 launches per chunk)',
                                 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
                                 'traffic': _pmc_traffic(), 'bytes_per_launch': byts, 'us_per_launch': round(avg_ms * 1e3, 3), 'launches_timed': n}
@@ -342,6 +350,8 @@ def main():
             torch.cuda.empty_cache()
             line['batched'] = batched_chunks(vla, dev, a.steps)
             line['qa'] = qa_bench(local)
+            if not a.no_8b:
+                line['qa_8b'] = qa8b_bench(local)
     _finish(dist, line if rank == 0 else None)
 
 
@@ -449,6 +459,49 @@ def qa_bench(local):
     del m
     torch.cuda.empty_cache()
     return out
+
+
+def qa8b_bench(local):
+    """BASELINE configs[3]: Vlaser-8B dynamic-high-res grounding request -- 13 tiles (12 + thumbnail) of 448 px, S = 13*256 + 48 + 32 =
+    3408 prompt tokens, greedy decode of 32 tokens, batch 1, random-init weights of the true architecture.  Prefill is MFMA-bound
+    (58.7 TFLOP: ViT 9 407 + mlp1 183 + LLM 44 476 + attention 4 662 GFLOP), decode is HBM-bound (14.14 GB of weights
+    + 28 x 2 x S x 4 x 128 x 2 B of KV per token) on the chunked-K weight-streaming kernels."""
+    from vlaser_amd import config as C, synth
+    from vlaser_amd.internvl_chat import InternVLChatModel
+    dev = f'cuda:{local}'
+    cfg = C.vlaser_8b()
+    sd = synth.vlm_state_dict(cfg, device=dev, dtype=torch.bfloat16)
+    m = InternVLChatModel(cfg, device=dev, max_tiles=13, max_seq_len=3456, max_batch=1)
+    m.load_state_dict(sd)
+    del sd
+    torch.cuda.empty_cache()
+    m.img_context_token_id = cfg.img_context_token_id
+    g = torch.Generator().manual_seed(9)
+    pv = torch.randn(13, 3, 448, 448, generator=g).to(dev).to(torch.bfloat16)
+    ids = torch.cat([torch.randint(0, 151643, (1, 41), generator=g), torch.full((1, 13 * 256), cfg.img_context_token_id),
+                     torch.randint(0, 151643, (1, 39), generator=g)], 1)
+    S = ids.shape[1]
+    ts = []
+    for n_new in (1, 33):
+        m.generate(pv, ids, max_new_tokens=n_new, min_new_tokens=n_new)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            m.generate(pv, ids, max_new_tokens=n_new, min_new_tokens=n_new)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / 2)
+    del m
+    torch.cuda.empty_cache()
+    l = cfg.llm
+    per_tok = 2.0 * (l.num_hidden_layers * (l.hidden_size * (l.num_attention_heads + 2 * l.num_key_value_heads) * l.head_dim
+                                           + l.num_attention_heads * l.head_dim * l.hidden_size + 3 * l.hidden_size * l.intermediate_size))
+    pre_flop = 13 * 723.6e9 + 13 * 14.09e9 + per_tok * S + l.num_hidden_layers * 4.0 * S * S * l.num_attention_heads * l.head_dim + 2.0 * l.vocab_size * l.hidden_size
+    dec_bytes = per_tok + 2.0 * l.vocab_size * l.hidden_size + l.num_hidden_layers * 2 * (S + 16) * l.num_key_value_heads * l.head_dim * 2
+    step = (ts[1] - ts[0]) / 32
+    return {'config': f'Vlaser-8B, 13 tiles, S={S}, greedy, 32 new tokens, batch 1 (BASELINE configs[3]); prefill_ms = ViT + prefill + first token',
+            'prefill_ms': round(ts[0] * 1e3, 2), 'decode_tokens_per_s': round(1.0 / step, 1), 'decode_ms_per_step': round(step * 1e3, 3),
+            'roofline': {'prefill': {'bound': 'mfma', 'achieved': round(pre_flop / ts[0] / 1e12, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(pre_flop / ts[0] / 2.5e15, 4)},
+                         'decode': {'bound': 'hbm', 'achieved': round(dec_bytes / step / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(dec_bytes / step / 1e9 / HBM_PEAK_GBS, 4)}}}
 
 
 def _pmc_traffic():
