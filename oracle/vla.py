@@ -195,3 +195,22 @@ def infer_action_naive(sd, vla, input_ids, pixel_values, causal_mask, vlm_positi
     if vla.final_action_clip_value is not None:
         action = torch.clamp(action, -vla.final_action_clip_value, vla.final_action_clip_value)
     return (action, trace) if return_trace else action
+
+
+
+def flow_matching_loss(sd, vla, input_ids, pixel_values, causal_mask, vlm_position_ids, proprio_position_ids, action_position_ids, proprios,
+                       actions, t, x0):
+    """PiZero.forward (pizero_internvl.py:1064-1197), the flow-matching training loss, with x0 as an explicit input:
+    psi_t = (1 - (1 - sig_min) t) x0 + t x1 (:1050-1062); ONE joint pass over {vlm, proprio, action}, no cache, last-layer
+    post-attention skipped for proprio only; loss = mean((action_decoder(h_action) - (x1 - (1 - sig_min) x0))^2)."""
+    sig = vla.flow_sig_min
+    tt = t[:, None, None]
+    psi = (1 - (1 - sig) * tt) * x0 + tt * actions
+    embeds = embed_image_text(sd, vla, input_ids, pixel_values)
+    pro = F.linear(proprios, sd['proprio_encoder.weight'], sd['proprio_encoder.bias'])
+    temb = sinusoidal_pos_emb(t, vla.action_hidden_size, vla.time_max_period)
+    ae = action_encoder(sd, psi, temb)
+    out = joint_forward(sd, vla, {'vlm': embeds, 'proprio': pro, 'action': ae},
+                        {'vlm': vlm_position_ids, 'proprio': proprio_position_ids, 'action': action_position_ids}, causal_mask, {}, final_skip=('proprio',))['action']
+    v = F.linear(out, sd['action_decoder.weight'], sd['action_decoder.bias'])
+    return torch.mean((v - (actions - (1 - sig) * x0)) ** 2)

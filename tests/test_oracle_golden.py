@@ -169,3 +169,32 @@ def test_infer_action_trace_kv_and_naive(golden_dir, golden_model):
         np.testing.assert_allclose(torch.stack(ntrace, 0)[:, 0].numpy(), t[f'{case}_vel_naive'], rtol=0, atol=5e-5)
         # cached == naive in fp32 (the reference's own remark, eval.py:131-137)
         assert (act - naive[:, -vla.horizon_steps:]).abs().max().item() < 1e-5
+
+
+def test_flow_matching_loss_and_grads_vs_reference_autograd(golden_dir, golden_model):
+    """G10: loss and action-expert gradients of the reference's own flow-matching training forward (PiZero.forward) + autograd."""
+    _, vla, sd = golden_model
+    d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))
+    f = np.load(os.path.join(golden_dir, 'g10_flow_matching.npz'))
+    names = [str(n) for n in f['a_names']]
+    case = 'a'
+    g = torch.Generator().manual_seed(int(d[f'{case}_seed']))
+    pv = torch.randn(1, 3, 448, 448, generator=g)
+    ids = torch.from_numpy(d[f'{case}_input_ids'])
+    am = (ids != vla.base.pad_token_id).long()
+    m, vp, pp, ap = ovla.build_causal_mask_and_position_ids(am, torch.float32, vla)
+    torch.set_grad_enabled(True)
+    try:
+        sdg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+        loss = ovla.flow_matching_loss(sdg, vla, ids, pv, m, vp, pp, ap, torch.from_numpy(d[f'{case}_proprio']), torch.from_numpy(f[f'{case}_actions']),
+                                       torch.from_numpy(f[f'{case}_t']), torch.from_numpy(f[f'{case}_x0']))
+        loss.backward()
+    finally:
+        torch.set_grad_enabled(False)
+    np.testing.assert_allclose(loss.item(), float(f[f'{case}_loss']), rtol=2e-5)
+    assert len(names) == 35
+    for n in names:
+        gr = sdg[n].grad.double().flatten()
+        np.testing.assert_allclose(gr.norm().item(), float(f[f'{case}_norm::{n}']), rtol=5e-4, err_msg=n)
+        np.testing.assert_allclose(gr[torch.from_numpy(f[f'{case}_idx::{n}'])].numpy(), f[f'{case}_val::{n}'], rtol=5e-3,
+                                   atol=1e-6 * float(f[f'{case}_norm::{n}']) + 1e-10, err_msg=n)

@@ -450,6 +450,56 @@ def g7b_trace(fake, vla):
     np.savez_compressed(os.path.join(OUT, 'g7b_vla_trace.npz'), **d)
 
 
+def g10_flow_matching(fake, vla):
+    """G10: the flow-matching TRAINING step of the VLA from the reference's own `PiZero.forward` (pizero_internvl.py:1064-1197) +
+    torch autograd: loss and the gradients of the action-expert parameter group (`action_expert_parameters`, :358-374 -- action /
+    proprio encoders, action decoder, the expert's decoder layers and final norm; the reference's default `train_vlm=False`
+    optimises exactly this group, train.py:246-255).  x0 is drawn inside the method (`randn_like`): recorded by re-seeding."""
+    import types as _t
+    fake.flow_sig_min = 0.001
+    fake.psi_t = _t.MethodType(RP.PiZero.psi_t, fake)
+    expert = fake.internvl_model.action_expert
+    mods = {'action_expert.model.': expert.model, 'action_encoder.': fake.action_encoder, 'proprio_encoder.': fake.proprio_encoder,
+            'action_decoder.': fake.action_decoder}
+    params = {}
+    for pre, m in mods.items():
+        for n, p_ in m.named_parameters():
+            p_.requires_grad_(True); p_.grad = None
+            params[pre + n] = p_
+    for p_ in list(fake.internvl_model.language_model.parameters()) + list(fake.embed_tokens.parameters()) + list(fake.multi_modal_projector.parameters()):
+        p_.requires_grad_(False)
+    d = {}
+    for case, (seed, n_valid, tval) in {'a': (0, 277, 0.35), 'b': (1, 300, 0.8)}.items():
+        pv, ids, am, proprio, mask, vp, pp, ap = _g7_case(fake, seed, n_valid)
+        g = torch.Generator().manual_seed(100 + seed)
+        actions = torch.rand(1, 4, 7, generator=g) * 2 - 1
+        t = torch.tensor([tval])
+        torch.manual_seed(4321 + seed)
+        x0 = torch.randn_like(actions)
+        torch.manual_seed(4321 + seed)
+        for p_ in params.values():
+            p_.grad = None
+        with torch.enable_grad():
+            loss = RP.PiZero.forward(fake, ids, pv, mask, vp, pp, ap, proprio, actions, t)
+            loss.backward()
+        d[f'{case}_actions'] = actions.numpy(); d[f'{case}_t'] = t.numpy(); d[f'{case}_x0'] = x0.numpy(); d[f'{case}_loss'] = np.array(loss.item())
+        names = []
+        for n, p_ in params.items():
+            if p_.grad is None:
+                continue
+            gr = p_.grad.detach().double().flatten()
+            names.append(n)
+            d[f'{case}_norm::{n}'] = np.array(gr.norm().item())
+            k = min(32, gr.numel())
+            idx = (torch.arange(k, dtype=torch.int64) * (gr.numel() - 1)) // max(1, k - 1)
+            d[f'{case}_idx::{n}'] = idx.numpy(); d[f'{case}_val::{n}'] = gr[idx].numpy()
+        d[f'{case}_names'] = np.array(names)
+        print('G10', case, 'loss', loss.item(), len(names), 'gradient tensors')
+    for p_ in params.values():
+        p_.requires_grad_(False); p_.grad = None
+    np.savez_compressed(os.path.join(OUT, 'g10_flow_matching.npz'), **d)
+
+
 def g8_sft_grads(cfg, ref_vlm):
     """SFT step gradients from the REFERENCE's own forward + torch autograd (modeling_internvl_chat.py:143-255 with labels): the
     same sample as G5's sft_loss (seed 0, labels on the last 16 positions), vision tower frozen (freeze_backbone), every LLM /
@@ -491,7 +541,10 @@ def main():
         vla = C.VLAConfig(base=cfg)
         sd = synth.vla_state_dict(vla, with_head=True)
         vlm_sd = {k: v for k, v in sd.items() if k.startswith(('vision_model.', 'mlp1.', 'language_model.'))}
-        return g7b_trace(g7_vla(vla, sd, build_ref_vlm(cfg, vlm_sd)), vla)
+        fake = g7_vla(vla, sd, build_ref_vlm(cfg, vlm_sd))
+        if '--skip-g7b' not in sys.argv:
+            g7b_trace(fake, vla)
+        return g10_flow_matching(fake, vla)
     if '--only-g6b' not in sys.argv:
         tok = ref_import.tokenizer()
         g1_prompts(tok)
@@ -506,7 +559,9 @@ def main():
     g6b_ragged(cfg, ref_vlm)
     g3_g4(ref_vlm)
     g5_g6(cfg, sd, ref_vlm)
-    g7b_trace(g7_vla(vla, sd, ref_vlm), vla)
+    fake = g7_vla(vla, sd, ref_vlm)
+    g7b_trace(fake, vla)
+    g10_flow_matching(fake, vla)
     g8_sft_grads(cfg, build_ref_vlm(cfg, vlm_sd))
     meta = dict(vit_layers=VIT_L, llm_layers=LLM_L, widths='vlaser-2b', weights='vlaser_amd.synth seed 0',
                 torch=torch.__version__, transformers=__import__('transformers').__version__,
