@@ -250,6 +250,17 @@ int vlaser_grad_accumulate(void* g_bf16, float* acc, long long n, float w, int f
 /* out[0] += sum of squares of a bf16 buffer (gradient norm); out must be zeroed by the caller */
 int vlaser_sumsq(const void* x, long long n, float* out, float* partial_ws /* float[1024] */, vl_stream_t stream);
 
+/* ---- VLA flow-matching training step: PiZero.forward, pizero_internvl.py:1064-1197; train.py:470-513 -----------
+ * SiLU of ActionEncoder.linear_2 (modules.py:45-52) and its backward (x = pre-activation). */
+int vlaser_silu(const void* x, void* y, long long n, vl_stream_t stream);
+int vlaser_silu_bwd(const void* x, const void* dy, void* dx, long long n, vl_stream_t stream);
+/* Backward of the joint attention (joint_model.py:410-696) for the R <= 16 expert rows (proprio + action tokens, cache slots
+ * [blk_start, blk_start + R)) over the frozen VLM prefix [0, valid_len) + their own block; first_tok_self: row 0 sees only itself in
+ * the block (proprio row of the block mask, pizero_internvl.py:517-587).  q / dO / O / dq bf16 [R, n_q*128]; K [n_kv, s_max, 128]
+ * (post-RoPE), VT [n_kv, 128, s_max]; dk / dv bf16 [R, n_kv*128] (gradients of the block keys; dk still needs the inverse RoPE). */
+int vlaser_attn_rows_bwd(const void* q, const void* K, const void* VT, const void* dO, const void* O, void* dq, void* dk, void* dv, int R, int n_q,
+                         int n_kv, int s_max, int valid_len, int blk_start, int first_tok_self, float scale, vl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

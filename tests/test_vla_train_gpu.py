@@ -1,0 +1,100 @@
+"""VLA flow-matching training step on the GPU: loss and every action-expert gradient against (a) golden G10 =
+the reference's own `PiZero.forward` + torch autograd and (b) the fp32 oracle's autograd on the same inputs; optimizer step, gradient
+accumulation and determinism.  Tolerances as for the SFT step (bf16 storage vs fp32 reference): per-tensor relative Frobenius error
+<= 4e-2, cosine >= 0.999; loss |err| <= 1e-2."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _case(golden_dir, case):
+    d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))
+    f = np.load(os.path.join(golden_dir, 'g10_flow_matching.npz'))
+    pv = torch.randn(1, 3, 448, 448, generator=torch.Generator().manual_seed(int(d[f'{case}_seed'])))
+    smp = dict(input_ids=torch.from_numpy(d[f'{case}_input_ids']), pixel_values=pv, proprios=torch.from_numpy(d[f'{case}_proprio']),
+               actions=torch.from_numpy(f[f'{case}_actions']), t=torch.from_numpy(f[f'{case}_t']), x0=torch.from_numpy(f[f'{case}_x0']))
+    return smp, f
+
+
+@pytest.fixture(scope='module')
+def trainer(golden_model):
+    from vlaser_amd.vla_train import VLATrainer
+    _, vla, sd = golden_model
+    m = VLATrainer(vla, lr=1e-3, max_grad_norm=1.0, bucket_layers=1)
+    m.load_state_dict(sd)
+    return m
+
+
+@pytest.mark.parametrize('case', ['a', 'b'])
+def test_loss_and_grads_vs_reference_golden(trainer, golden_dir, case):
+    smp, f = _case(golden_dir, case)
+    loss = trainer.forward_backward(**smp)
+    assert abs(loss.item() - float(f[f'{case}_loss'])) < 1e-2, (loss.item(), float(f[f'{case}_loss']))
+    grads = trainer.named_grads()
+    names = [str(n) for n in f[f'{case}_names']]
+    assert set(names) == set(grads)                                          # exactly the reference's action_expert_parameters group
+    worst = (0.0, '')
+    for n in names:
+        g = grads[n].double().flatten().cpu()
+        ref_norm = float(f[f'{case}_norm::{n}'])
+        rel_norm = abs(g.norm().item() - ref_norm) / (ref_norm + 1e-12)
+        worst = max(worst, (rel_norm, n))
+        assert rel_norm < 4e-2, (n, g.norm().item(), ref_norm)
+        idx = torch.from_numpy(f[f'{case}_idx::{n}'])
+        np.testing.assert_allclose(g[idx].numpy(), f[f'{case}_val::{n}'], rtol=0, atol=6e-2 * ref_norm / max(1.0, g.numel() ** 0.5) * 8 + 1e-7, err_msg=n)
+    print('worst gradient-norm error', worst)
+
+
+def test_grads_vs_oracle_autograd_full_tensors(trainer, golden_model, golden_dir):
+    from oracle import vla as ovla
+    _, vla, sd = golden_model
+    smp, f = _case(golden_dir, 'a')
+    loss = trainer.forward_backward(**smp)
+    grads = trainer.named_grads()
+    am = (smp['input_ids'] != vla.base.pad_token_id).long()
+    mask, vp, pp, ap = ovla.build_causal_mask_and_position_ids(am, torch.float32, vla)
+    torch.set_grad_enabled(True)
+    try:
+        sdg = {k: (v.clone().requires_grad_(True) if k in grads else v) for k, v in sd.items()}
+        ref = ovla.flow_matching_loss(sdg, vla, smp['input_ids'], smp['pixel_values'], mask, vp, pp, ap, smp['proprios'], smp['actions'], smp['t'], smp['x0'])
+        ref.backward()
+    finally:
+        torch.set_grad_enabled(False)
+    assert abs(loss.item() - ref.item()) < 1e-2
+    for k, g in grads.items():
+        a, b = g.float().cpu().flatten(), sdg[k].grad.flatten()
+        rel = ((a - b).norm() / (b.norm() + 1e-30)).item()
+        cos = F.cosine_similarity(a, b, dim=0).item()
+        assert rel < 4e-2 and cos > 0.999, (k, rel, cos)
+
+
+def test_step_accumulation_and_determinism(golden_model, golden_dir):
+    from vlaser_amd.vla_train import VLATrainer, sample_fm_time, cosine_warmup_restarts_lr
+    _, vla, sd = golden_model
+    a, _ = _case(golden_dir, 'a')
+    b, _ = _case(golden_dir, 'b')
+    runs = []
+    for _ in range(2):
+        m = VLATrainer(vla, lr=1e-4, max_grad_norm=1.0); m.load_state_dict(sd)
+        l0 = m.forward_backward(**a).item()
+        outs = [m.step([a, b], lr=cosine_warmup_restarts_lr(s + 1, 100, 1e-4, 1e-6, 2)) for s in range(4)]
+        l1 = m.forward_backward(**a).item()
+        runs.append((l0, l1, [o.loss.item() for o in outs], m.fp.p.clone()))
+    assert runs[0][1] < runs[0][0], runs[0][:2]                               # four small updates on {a, b} lower the loss on a
+    assert runs[0][2] == runs[1][2] and torch.equal(runs[0][3], runs[1][3])   # bit-reproducible
+    # accumulation of two samples == mean of their gradients
+    m = VLATrainer(vla, lr=0.0, max_grad_norm=0.0); m.load_state_dict(sd)
+    m.forward_backward(**a); ga = m.fp.g.float().clone()
+    m.forward_backward(**b); gb = m.fp.g.float().clone()
+    m.step([a, b])
+    assert torch.equal(m.fp.g, ((ga + gb) * 0.5).to(BF))
+    t = sample_fm_time(4096, generator=torch.Generator().manual_seed(0))
+    assert t.min() >= 0 and t.max() <= 0.999 and abs(t.mean().item() - 0.999 * (1 - 1.5 / 2.5)) < 0.02     # E[1 - Beta(1.5, 1)] = 0.4
+    assert cosine_warmup_restarts_lr(0, 100, 1.0, 0.1, 10) == 0.1 and abs(cosine_warmup_restarts_lr(10, 100, 1.0, 0.1, 10) - 1.0) < 1e-12
+    assert abs(cosine_warmup_restarts_lr(100, 100, 1.0, 0.1, 10) - 0.1) < 1e-12      # restart

@@ -82,6 +82,9 @@ _SIGS = {
     'vlaser_sumsq': [vp, i64, vp, vp, vp],
     'vlaser_adamw_clipped': [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, i32, vp],
     'vlaser_grad_accumulate': [vp, vp, i64, f32, i32, i32, vp],
+    'vlaser_silu': [vp, vp, i64, vp],
+    'vlaser_silu_bwd': [vp, vp, vp, i64, vp],
+    'vlaser_attn_rows_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
 }
 
 

@@ -670,3 +670,144 @@ extern "C" int vlaser_sumsq(const void* x, long long n, float* out, float* parti
   VL_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------- SiLU (ActionEncoder.linear_2, modules.py:45-52)
+__global__ __launch_bounds__(256) void silu_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = f32_to_bf16(silu(bf16_to_f32(x[i])));
+}
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = bf16_to_f32(x[i]), sg = 1.0f / (1.0f + __expf(-v));
+    dx[i] = f32_to_bf16(bf16_to_f32(dy[i]) * sg * (1.0f + v * (1.0f - sg)));
+  }
+}
+extern "C" int vlaser_silu(const void* x, void* y, long long n, vl_stream_t s) {
+  VL_CHECK(x && y && n > 0, "vlaser_silu: bad args");
+  hipLaunchKernelGGL(silu_fwd_kernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (bf16_t*)y, n);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vlaser_silu_bwd(const void* x, const void* dy, void* dx, long long n, vl_stream_t s) {
+  VL_CHECK(x && dy && dx && n > 0, "vlaser_silu_bwd: bad args");
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)dy,
+                     (bf16_t*)dx, n);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- attention backward of a few query rows over a KV cache
+// The expert rows of the VLA flow-matching training step (pizero_internvl.py:1064-1197; joint attention of joint_model.py:410-696):
+// R <= 16 query rows (proprio + action tokens, cache slots [blk_start, blk_start + R)) attend to the frozen VLM prefix [0, valid_len)
+// and to their own block (row 0 -- the proprio token -- only to itself when first_tok_self is set).  One workgroup per kv head walks
+// its G query heads x R rows in a fixed order (deterministic, no atomics): scores -> softmax -> dP = dO V^T -> dS = P o (dP - <dO, O>)
+// -> dQ = dS K; dK / dV are accumulated for the block keys only (the prefix keys belong to the frozen VLM: no gradient is needed).
+// K [n_kv, S_max, 128] (post-RoPE), V^T [n_kv, 128, S_max]; q / dO / O / dq bf16 [R, n_q*128]; dk / dv bf16 [R, n_kv*128].
+#define ARB_MAXKEYS 2048
+__global__ __launch_bounds__(256) void attn_rows_bwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ VT,
+                                                            const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O, bf16_t* __restrict__ dq,
+                                                            bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int R, int n_q, int n_kv, int s_max,
+                                                            int valid_len, int blk_start, int first_tok_self, float scale) {
+  __shared__ float sc[ARB_MAXKEYS];       // p, then dS
+  __shared__ float qs[128], dos[128], red[8];
+  __shared__ float dk_acc[16 * 128], dv_acc[16 * 128];
+  const int kvh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = n_q / n_kv, kv_len = blk_start + R;
+  const bf16_t* Kh = K + (size_t)kvh * s_max * 128;
+  const bf16_t* Vh = VT + (size_t)kvh * 128 * s_max;
+  for (int i = tid; i < R * 128; i += 256) { dk_acc[i] = 0.f; dv_acc[i] = 0.f; }
+  __syncthreads();
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    const float t = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return t;
+  };
+  auto block_max = [&](float v) {
+    v = wave_max(v);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    const float t = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    return t;
+  };
+  for (int hg = 0; hg < G; ++hg) {
+    const int h = kvh * G + hg;
+    for (int r = 0; r < R; ++r) {
+      const size_t ro = (size_t)r * n_q * 128 + (size_t)h * 128;
+      if (tid < 128) { qs[tid] = bf16_to_f32(q[ro + tid]); dos[tid] = bf16_to_f32(dO[ro + tid]); }
+      __syncthreads();
+      const int hi2 = (r == 0 && first_tok_self) ? blk_start + 1 : kv_len;
+      float mx = -3.0e38f;
+      for (int j = tid; j < kv_len; j += 256) {
+        const bool vis = j < valid_len || (j >= blk_start && j < hi2);
+        float s = -3.0e38f;
+        if (vis) {
+          float a = 0.f;
+          const bf16_t* kr = Kh + (size_t)j * 128;
+#pragma unroll 8
+          for (int d = 0; d < 128; ++d) a += qs[d] * bf16_to_f32(kr[d]);
+          s = a * scale;
+        }
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+      }
+      mx = block_max(mx);
+      float sum = 0.f;
+      for (int j = tid; j < kv_len; j += 256) {
+        const float p = sc[j] > -1.0e38f ? __expf(sc[j] - mx) : 0.f;
+        sc[j] = p;
+        sum += p;
+      }
+      sum = block_sum(sum);
+      const float inv = 1.0f / sum;
+      // D = <dO, O>; dP_j = dO . V_j; dS_j = p_j (dP_j - D) * scale
+      float dd = 0.f;
+      if (tid < 128) dd = dos[tid] * bf16_to_f32(O[ro + tid]);
+      const float D = block_sum(dd);
+      for (int j = tid; j < kv_len; j += 256) {
+        const float p = sc[j] * inv;
+        float ds = 0.f;
+        if (p > 0.f) {
+          float dp = 0.f;
+#pragma unroll 8
+          for (int d = 0; d < 128; ++d) dp += dos[d] * bf16_to_f32(Vh[(size_t)d * s_max + j]);
+          ds = p * (dp - D) * scale;
+          if (j >= blk_start) {                          // block keys: dV_j += p dO, dK_j += dS q  (threads own distinct j: no race)
+            float* dvr = dv_acc + (j - blk_start) * 128;
+            float* dkr = dk_acc + (j - blk_start) * 128;
+            for (int d = 0; d < 128; ++d) { dvr[d] += p * dos[d]; dkr[d] += ds * qs[d]; }
+          }
+        }
+        sc[j] = ds;
+      }
+      __syncthreads();
+      // dQ[d] = sum_j dS_j K_j[d]: two threads per d, each half of the keys
+      {
+        const int d = tid & 127, half = tid >> 7;
+        float a = 0.f;
+        for (int j = half; j < kv_len; j += 2) a += sc[j] * bf16_to_f32(Kh[(size_t)j * 128 + d]);
+        if (half == 1) qs[d] = a;                       // qs is free now
+        __syncthreads();
+        if (half == 0) dq[ro + d] = f32_to_bf16(a + qs[d]);
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < R * 128; i += 256) {
+    const int r = i >> 7, d = i & 127;
+    dk[(size_t)r * n_kv * 128 + kvh * 128 + d] = f32_to_bf16(dk_acc[i]);
+    dv[(size_t)r * n_kv * 128 + kvh * 128 + d] = f32_to_bf16(dv_acc[i]);
+  }
+}
+extern "C" int vlaser_attn_rows_bwd(const void* q, const void* K, const void* VT, const void* dO, const void* O, void* dq, void* dk, void* dv, int R, int n_q,
+                                    int n_kv, int s_max, int valid_len, int blk_start, int first_tok_self, float scale, vl_stream_t s) {
+  VL_CHECK(q && K && VT && dO && O && dq && dk && dv, "vlaser_attn_rows_bwd: null pointer");
+  VL_CHECK(R >= 1 && R <= 16 && n_q % n_kv == 0 && blk_start + R <= s_max && blk_start + R <= ARB_MAXKEYS && valid_len <= blk_start,
+           "vlaser_attn_rows_bwd: bad geometry (R <= 16, kv_len <= %d)", ARB_MAXKEYS);
+  hipLaunchKernelGGL(attn_rows_bwd_kernel, dim3(n_kv), dim3(256), 0, (hipStream_t)s, (const bf16_t*)q, (const bf16_t*)K, (const bf16_t*)VT, (const bf16_t*)dO,
+                     (const bf16_t*)O, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, R, n_q, n_kv, s_max, valid_len, blk_start, first_tok_self, scale);
+  VL_LAUNCH_CHECK();
+  return 0;
+}

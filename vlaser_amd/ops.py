@@ -456,3 +456,17 @@ def grad_accumulate(g, acc, w, first, finalize):
 
 def sumsq(x, out, ws):
     L.check(L.lib().vlaser_sumsq(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), _stream()), 'vlaser_sumsq')
+
+
+# ------------------------------------------------------------------------------------------------ VLA flow-matching training step
+def silu(x, y):
+    L.check(L.lib().vlaser_silu(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), 'vlaser_silu')
+
+
+def silu_bwd(x, dy, dx):
+    L.check(L.lib().vlaser_silu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _stream()), 'vlaser_silu_bwd')
+
+
+def attn_rows_bwd(q, K, VT, dO, O, dq, dk, dv, R, n_q, n_kv, s_max, valid_len, blk_start, first_tok_self, scale):
+    L.check(L.lib().vlaser_attn_rows_bwd(q.data_ptr(), K.data_ptr(), VT.data_ptr(), dO.data_ptr(), O.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                         dv.data_ptr(), R, n_q, n_kv, s_max, valid_len, blk_start, int(first_tok_self), scale, _stream()), 'vlaser_attn_rows_bwd')
