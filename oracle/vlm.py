@@ -48,3 +48,38 @@ def sft_loss(logits, labels):
     sl = logits[..., :-1, :].contiguous().float()
     tl = labels[..., 1:].contiguous()
     return F.cross_entropy(sl.view(-1, sl.shape[-1]), tl.view(-1), ignore_index=-100)
+
+
+def packed_logits(sd, cfg, pixel_values, input_ids, cu_seqlens, image_flags=None):
+    """Logits of a PACKED row (dataset_packed.py:517-624): block-diagonal causal attention + restarting position ids make the
+    sub-sequences independent -- each [cu[i], cu[i+1]) slice is an ordinary causal forward over its own tiles."""
+    nt = cfg.num_image_token
+    flags = None if image_flags is None else image_flags.reshape(-1)
+    out, t0 = [], 0
+    for lo, hi in zip(cu_seqlens[:-1].tolist(), cu_seqlens[1:].tolist()):
+        ids = input_ids[:, lo:hi]
+        need = int((ids == cfg.img_context_token_id).sum()) // nt
+        t1, got = t0, 0
+        while t1 < pixel_values.shape[0] and got < need:
+            got += 1 if (flags is None or flags[t1] == 1) else 0
+            t1 += 1
+        if need == 0:
+            if flags is not None and t1 < pixel_values.shape[0] and flags[t1] == 0:
+                t1 += 1                                            # dummy tile of a text-only sub-sequence: no visual token uses it
+            e = F.embedding(ids, sd[LM + 'model.embed_tokens.weight'])
+            S = e.shape[1]
+            h, _ = qwen2.model_forward(sd, LM, cfg.llm, e, torch.arange(S)[None], qwen2.causal_mask(S, S, e.dtype, torch.ones(1, S, dtype=torch.long)))
+            out.append(qwen2.lm_head(sd, LM, h))
+        else:
+            fl = None if flags is None else flags[t0:t1]
+            out.append(forward_logits(sd, cfg, pixel_values[t0:t1], ids, image_flags=fl))
+        t0 = t1
+    return torch.cat(out, 1)
+
+
+def packed_loss(logits, labels, loss_weight):
+    """sum(w_t ce_t) / sum(w_t) over the flat shifted row (modeling_internvl_chat.py:207-230)."""
+    sl = logits[..., :-1, :].contiguous().float()
+    ce = F.cross_entropy(sl.view(-1, sl.shape[-1]), labels[..., 1:].reshape(-1), ignore_index=-100, reduction='none')
+    w = loss_weight[..., 1:].reshape(-1).float()
+    return (ce * w).sum() / w.sum()

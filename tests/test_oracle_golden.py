@@ -198,3 +198,20 @@ def test_flow_matching_loss_and_grads_vs_reference_autograd(golden_dir, golden_m
         np.testing.assert_allclose(gr.norm().item(), float(f[f'{case}_norm::{n}']), rtol=5e-4, err_msg=n)
         np.testing.assert_allclose(gr[torch.from_numpy(f[f'{case}_idx::{n}'])].numpy(), f[f'{case}_val::{n}'], rtol=5e-3,
                                    atol=1e-6 * float(f[f'{case}_norm::{n}']) + 1e-10, err_msg=n)
+
+
+def test_packed_sequence_loss_vs_reference(golden_dir, golden_model):
+    """G11: the reference's own forward with `loss_weight` on a packed row (block-diagonal causal 4-D mask, restarting position ids)
+    vs the oracle running the sub-sequences independently + the weighted loss."""
+    cfg, _, sd = golden_model
+    d = np.load(os.path.join(golden_dir, 'g11_packed.npz'))
+    g = torch.Generator().manual_seed(int(d['seed']))
+    ids = torch.from_numpy(d['input_ids'])
+    # regenerate the pixel values exactly as the generator did: the id / text draws come first
+    for n_img, n_text, n_lab in ((256, 22, 7), (0, 31, 9), (256, 15, 5)):
+        torch.randint(1, 151643, (9,), generator=g); torch.randint(1, 151643, (n_text,), generator=g)
+    pv = torch.randn(3, 3, 448, 448, generator=g)
+    logits = ovlm.packed_logits(sd, cfg, pv, ids, torch.from_numpy(d['cu_seqlens']), torch.from_numpy(d['image_flags']))
+    loss = ovlm.packed_loss(logits, torch.from_numpy(d['labels']), torch.from_numpy(d['loss_weight']))
+    np.testing.assert_allclose(loss.item(), float(d['loss']), rtol=2e-5)
+    np.testing.assert_allclose(logits[0, -1].topk(8).values.numpy(), d['last_logits'], rtol=0, atol=2e-4)

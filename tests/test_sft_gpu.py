@@ -371,3 +371,39 @@ def test_device_side_clip_matches_host_formula(ops):
         ops.adamw(*a, gr, 1e-3, 0.9, 0.999, 1e-8, 0.05, scale, 1)
         ops.adamw_clipped(*b, gr, 1e-3, 0.9, 0.999, 1e-8, 0.05, 1.0, gn2, max_norm, 1)
         torch.testing.assert_close(a[1], b[1], rtol=1e-6, atol=1e-8)
+
+
+def _packed_inputs(golden_dir):
+    d = np.load(os.path.join(golden_dir, 'g11_packed.npz'))
+    g = torch.Generator().manual_seed(int(d['seed']))
+    for n_img, n_text, n_lab in ((256, 22, 7), (0, 31, 9), (256, 15, 5)):
+        torch.randint(1, 151643, (9,), generator=g); torch.randint(1, 151643, (n_text,), generator=g)
+    pv = torch.randn(3, 3, 448, 448, generator=g)
+    return d, pv, torch.from_numpy(d['input_ids']), torch.from_numpy(d['labels']), torch.from_numpy(d['loss_weight']), torch.from_numpy(d['cu_seqlens'])[None], \
+        torch.from_numpy(d['image_flags'])
+
+
+def test_packed_sequence_forward_and_sft_step(golden_model, golden_dir):
+    """SURVEY 8f-4 / VERDICT r01 missing #5: packed-sequence SFT.  (a) InternVLChatModel.forward with loss_weight + cu_seqlens vs the
+    reference's own packed loss (golden G11); (b) SFTModel.train_step_packed: loss vs G11 and every gradient norm vs the reference
+    model's autograd on the packed row."""
+    from vlaser_amd.internvl_chat import InternVLChatModel
+    from vlaser_amd.sft import SFTModel
+    cfg, _, sd = golden_model
+    d, pv, ids, labels, w, cu, flags = _packed_inputs(golden_dir)
+    vsd = {k: v for k, v in sd.items() if k.startswith(('vision_model.', 'mlp1.', 'language_model.'))}
+    chat = InternVLChatModel(cfg, max_seq_len=640, max_tiles=3); chat.load_state_dict(vsd)
+    chat.img_context_token_id = cfg.img_context_token_id
+    out = chat.forward(pv, ids, attention_mask=cu, image_flags=flags, labels=labels, loss_weight=w.tolist())
+    assert abs(out.loss.item() - float(d['loss'])) < 1e-2, (out.loss.item(), float(d['loss']))
+    assert (out.logits[0, -1].topk(8).values.cpu() - torch.from_numpy(d['last_logits'])).abs().max() < 3e-2 * abs(d['last_logits']).max()
+    del chat
+    m = SFTModel(cfg, max_seq_len=320, max_tiles=1, lr=0.0, weight_decay=0.0, max_grad_norm=0.0); m.load_state_dict(sd)
+    res = m.train_step_packed(pv, ids, labels, w, cu, image_flags=flags)
+    assert abs(res.loss.item() - float(d['loss'])) < 1e-2
+    grads = m.named_grads()
+    names = [str(n) for n in d['names']]
+    assert set(names) == set(grads)
+    for n in names:
+        ref = float(d[f'norm::{n}'])
+        assert abs(grads[n].double().norm().item() - ref) < 4e-2 * ref + 1e-9, (n, grads[n].double().norm().item(), ref)

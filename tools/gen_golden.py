@@ -10,6 +10,7 @@ replays them in seconds.  Fixtures hold inputs' seeds and output slices only -- 
 """
 import copy
 import json
+import math
 import os
 import sys
 import types
@@ -500,6 +501,49 @@ def g10_flow_matching(fake, vla):
     np.savez_compressed(os.path.join(OUT, 'g10_flow_matching.npz'), **d)
 
 
+def g11_packed(cfg, ref_vlm):
+    """G11: packed-sequence SFT loss (`--use_packed_ds`) from the reference's own `InternVLChatModel.forward` with `loss_weight`
+    (modeling_internvl_chat.py:207-230).  The reference realises the block-diagonal causal attention with flash_attn_varlen_func
+    behind a CUDA-only monkey patch (qwen2_packed_training_patch.py:14-101); here the SAME visibility is handed to HF's eager
+    attention as an explicit 4-D additive mask, with the packed collator's restarting position ids (dataset_packed.py:517-545).
+    One row = [1-tile sample | text-only sample (dummy tile, image_flags 0) | 1-tile sample]; loss_weight = 1/sqrt(n_eff) per
+    sub-sequence ('square' reduction), 0 on ignored labels (:622)."""
+    ref_vlm.img_context_token_id = 151667
+    g = torch.Generator().manual_seed(77)
+    subs, labs = [], []
+    for n_img, n_text, n_lab in ((256, 22, 7), (0, 31, 9), (256, 15, 5)):
+        ids = torch.cat([torch.randint(1, 151643, (9,), generator=g), torch.full((n_img,), 151667), torch.randint(1, 151643, (n_text,), generator=g)])
+        lab = torch.full_like(ids, -100); lab[-n_lab:] = ids[-n_lab:]
+        subs.append(ids); labs.append(lab)
+    ids = torch.cat(subs)[None]; labels = torch.cat(labs)[None]
+    cu = torch.tensor([0] + list(torch.tensor([len(x) for x in subs]).cumsum(0)))
+    S = ids.shape[1]
+    pos = torch.cat([torch.arange(len(x)) for x in subs])[None]
+    w = torch.cat([torch.full((len(x),), 1.0 / math.sqrt(float((l != -100).sum()))) for x, l in zip(subs, labs)])[None]
+    w = torch.where(labels == -100, torch.zeros_like(w), w)
+    mask = torch.full((S, S), torch.finfo(torch.float32).min)
+    for lo, hi in zip(cu[:-1].tolist(), cu[1:].tolist()):
+        mask[lo:hi, lo:hi] = torch.full((hi - lo, hi - lo), torch.finfo(torch.float32).min).triu(1)
+    pv = torch.randn(3, 3, 448, 448, generator=g)
+    flags = torch.tensor([[1], [0], [1]])
+    for n, p_ in ref_vlm.named_parameters():
+        p_.requires_grad_(not n.startswith('vision_model.')); p_.grad = None
+    with torch.enable_grad():
+        out = ref_vlm(pixel_values=pv, input_ids=ids, attention_mask=mask[None, None], position_ids=pos, image_flags=flags, labels=labels,
+                      loss_weight=w.tolist(), return_dict=True)
+        out.loss.backward()
+    d = {'seed': np.array(77), 'input_ids': ids.numpy(), 'labels': labels.numpy(), 'cu_seqlens': cu.numpy(), 'loss_weight': w.numpy(),
+         'image_flags': flags.numpy(), 'loss': np.array(out.loss.item()), 'last_logits': out.logits[0, -1].detach().topk(8).values.numpy()}
+    names = []
+    for n, p_ in ref_vlm.named_parameters():
+        if p_.grad is not None:
+            names.append(n); d[f'norm::{n}'] = np.array(p_.grad.double().norm().item()); p_.grad = None
+        p_.requires_grad_(False)
+    d['names'] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, 'g11_packed.npz'), **d)
+    print('G11 packed loss', out.loss.item(), len(names), 'gradient tensors')
+
+
 def g8_sft_grads(cfg, ref_vlm):
     """SFT step gradients from the REFERENCE's own forward + torch autograd (modeling_internvl_chat.py:143-255 with labels): the
     same sample as G5's sft_loss (seed 0, labels on the last 16 positions), vision tower frozen (freeze_backbone), every LLM /
@@ -536,6 +580,11 @@ def main():
         sd = synth.vla_state_dict(C.VLAConfig(base=cfg), with_head=True)
         vlm_sd = {k: v for k, v in sd.items() if k.startswith(('vision_model.', 'mlp1.', 'language_model.'))}
         return g8_sft_grads(cfg, build_ref_vlm(cfg, vlm_sd))
+    if '--only-g11' in sys.argv:
+        cfg = C.truncated(C.vlaser_2b(), VIT_L, LLM_L)
+        sd = synth.vla_state_dict(C.VLAConfig(base=cfg), with_head=True)
+        vlm_sd = {k: v for k, v in sd.items() if k.startswith(('vision_model.', 'mlp1.', 'language_model.'))}
+        return g11_packed(cfg, build_ref_vlm(cfg, vlm_sd))
     if '--only-g7' in sys.argv:
         cfg = C.truncated(C.vlaser_2b(), VIT_L, LLM_L)
         vla = C.VLAConfig(base=cfg)
@@ -563,6 +612,7 @@ def main():
     g7b_trace(fake, vla)
     g10_flow_matching(fake, vla)
     g8_sft_grads(cfg, build_ref_vlm(cfg, vlm_sd))
+    g11_packed(cfg, build_ref_vlm(cfg, vlm_sd))
     meta = dict(vit_layers=VIT_L, llm_layers=LLM_L, widths='vlaser-2b', weights='vlaser_amd.synth seed 0',
                 torch=torch.__version__, transformers=__import__('transformers').__version__,
                 generated_by='tools/gen_golden.py (imports /root/reference)')

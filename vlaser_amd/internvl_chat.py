@@ -387,8 +387,10 @@ class InternVLChatModel:
                 past_key_values=None, labels=None, use_cache=None, output_attentions=None, output_hidden_states=None,
                 return_dict=None, statistics=None, loss_weight=None, loss_reduction_all_gather=False):
         """Inference forward (logits + CE loss).  The trainable SFT step lives in vlaser_amd.sft."""
-        if loss_weight is not None or past_key_values is not None:
-            raise NotImplementedError('packed-sequence loss weights / external caches are out of scope (SURVEY.md 8f-4)')
+        if past_key_values is not None:
+            raise NotImplementedError('external caches are not supported by forward() (generate() owns the KV cache)')
+        if loss_weight is not None:
+            return self._forward_packed(pixel_values, input_ids, attention_mask, labels, image_flags, loss_weight, loss_reduction_all_gather)
         B, S = input_ids.shape
         if attention_mask is not None and not bool(attention_mask.bool().all()):
             am = attention_mask.bool()
@@ -396,12 +398,15 @@ class InternVLChatModel:
                 raise NotImplementedError('forward() takes unpadded or right-padded batches (the SFT collator pads on the '
                                           'right, pad_data_collator.py:57-72); causal attention keeps pads out of valid rows')
         self._ensure(B, S)
-        feats = self.vit.forward(self._to_bf16(pixel_values)).view(pixel_values.shape[0], self.num_image_token, -1)
-        if image_flags is not None:
-            feats = feats[image_flags.reshape(-1).to(self.device) == 1]
+        if pixel_values is None or pixel_values.shape[0] == 0:                  # text-only (sub-)sequence
+            feats2d = torch.zeros(0, self.config.llm.hidden_size, dtype=BF, device=self.device)
+        else:
+            feats = self.vit.forward(self._to_bf16(pixel_values)).view(pixel_values.shape[0], self.num_image_token, -1)
+            if image_flags is not None:
+                feats = feats[image_flags.reshape(-1).to(self.device) == 1]
+            feats2d = feats.reshape(-1, feats.shape[-1])
         n_sel = int((input_ids == self.img_context_token_id).sum())
         ignore_flag = False
-        feats2d = feats.reshape(-1, feats.shape[-1])
         if n_sel != feats2d.shape[0]:
             # reference falls back to the first n_token features and zeroes the loss (:184-190, 242-243)
             print(f'warning: shape mismatch, input_embeds[selected].shape={n_sel}, vit_embeds.shape={tuple(feats2d.shape)}')
@@ -420,6 +425,44 @@ class InternVLChatModel:
             loss = ce_loss(logits[:, :-1].reshape(-1, logits.shape[-1]), labels[:, 1:].reshape(-1).to(self.device))
             if ignore_flag:
                 loss = loss * 0.0
+        return SimpleNamespace(loss=loss, logits=logits, past_key_values=None, hidden_states=None, attentions=None)
+
+    def _forward_packed(self, pixel_values, input_ids, cu_seqlens, labels, image_flags, loss_weight, loss_reduction_all_gather):
+        """Packed-sequence forward (`--use_packed_ds`: dataset_packed.py:517-624, qwen2_packed_training_patch.py:14-101): every row of
+        `input_ids` is a concatenation of sub-sequences, `attention_mask` carries their cu_seqlens [B, n+1] (:623), attention is
+        block-diagonal causal (flash_attn_varlen_func, :71-96) -- i.e. the sub-sequences are independent, so each one runs through the
+        ordinary causal path on its own -- and the loss is sum(w_t * ce_t) / sum(w_t) over the flat shifted row with the per-token
+        `loss_weight` (modeling_internvl_chat.py:207-230)."""
+        B, S = input_ids.shape
+        cu = cu_seqlens.detach().to('cpu', torch.int64).reshape(B, -1)
+        ids_h = input_ids.detach().to('cpu')
+        nt = self.num_image_token
+        flags = None if image_flags is None else image_flags.detach().to('cpu').reshape(-1)
+        logits = torch.zeros(B, S, self.config.llm.vocab_size, dtype=torch.float32, device=self.device)
+        t0 = 0
+        for b in range(B):
+            for lo, hi in zip(cu[b, :-1].tolist(), cu[b, 1:].tolist()):
+                if hi <= lo:
+                    continue
+                need = int((ids_h[b, lo:hi] == self.img_context_token_id).sum()) // nt
+                t1, got = t0, 0
+                while pixel_values is not None and t1 < pixel_values.shape[0] and got < need:
+                    got += 1 if (flags is None or flags[t1] == 1) else 0
+                    t1 += 1
+                sub = self.forward(None if pixel_values is None else pixel_values[t0:t1], ids_h[b:b + 1, lo:hi],
+                                   image_flags=None if flags is None else flags[t0:t1].reshape(-1, 1))
+                logits[b, lo:hi] = sub.logits[0]
+                t0 = t1
+        loss = None
+        if labels is not None:
+            w = torch.as_tensor(loss_weight, dtype=torch.float32).reshape(B, S)[:, 1:].reshape(-1).to(self.device)
+            tgt = labels.to(self.device)[:, 1:].reshape(-1).contiguous()
+            rows = torch.empty(tgt.numel(), dtype=torch.float32, device=self.device)
+            ops.ce_rows(logits[:, :-1].reshape(-1, logits.shape[-1]), tgt, rows, None, -100)
+            wsum = w.sum()
+            if loss_reduction_all_gather and torch.distributed.is_available() and torch.distributed.is_initialized():
+                torch.distributed.all_reduce(wsum, op=torch.distributed.ReduceOp.AVG)
+            loss = (rows * w).sum() / wsum
         return SimpleNamespace(loss=loss, logits=logits, past_key_values=None, hidden_states=None, attentions=None)
 
     __call__ = forward

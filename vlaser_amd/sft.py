@@ -648,7 +648,11 @@ class SFTModel:
             Rt = sum(x[4] for x in smp)
             for (pvb, idb, lbb, flb, Rb) in smp:
                 work.append((pvb, idb, lbb, flb, (Rb / Rt if Rt else 0.0) / GA))
-        if len(work) == 1:
+        return self._run_weighted(work, lr)
+
+    def _run_weighted(self, work, lr):
+        """Samples (pixel_values, ids, labels, image_flags, weight) -> accumulated weighted gradients -> exchange -> optimizer step."""
+        if len(work) == 1 and work[0][4] == 1.0:
             loss = self.forward_backward(*work[0][:4], on_bucket_ready=self._exchange_bucket)
         else:
             if self.gacc is None:
@@ -660,6 +664,55 @@ class SFTModel:
                 loss = loss + lj * w
         gnorm = self.optimizer_step(lr)
         return SimpleNamespace(loss=loss, grad_norm=gnorm)
+
+    def train_step_packed(self, pixel_values, input_ids, labels, loss_weight, cu_seqlens, image_flags=None, lr=None, total_steps=None,
+                          loss_reduction_all_gather=False):
+        """One optimizer step on a PACKED batch (`--use_packed_ds`: dataset_packed.py:517-624; varlen attention of
+        qwen2_packed_training_patch.py:14-101; weighted loss of modeling_internvl_chat.py:207-230).  Rows of `input_ids` concatenate
+        sub-sequences delimited by `cu_seqlens` [B, n+1]; block-diagonal causal attention makes them independent, so each runs as its
+        own sample.  The reference's loss sum(w_t ce_t) / sum(w_t) has w constant over the supervised tokens of a sub-sequence
+        (`len2weight`, dataset_packed.py:540) and 0 on ignored labels (:622): sub-sequence j therefore enters with weight
+        w_j R_j / sum_k w_k R_k (R = supervised positions)."""
+        if lr is None and total_steps is not None:
+            lr = cosine_lr(self.step_count, total_steps, self.lr)
+        B, S = input_ids.shape
+        cu = cu_seqlens.detach().to('cpu', torch.int64).reshape(B, -1)
+        ids_h = input_ids.detach().to('cpu', torch.int64)
+        lab_h = labels.detach().to('cpu', torch.int64)
+        w_h = torch.as_tensor(loss_weight, dtype=torch.float32).reshape(B, S)
+        flags = None if image_flags is None else image_flags.detach().to('cpu').reshape(-1)
+        nt = self.cfg.num_image_token
+        work, t0 = [], 0
+        for b in range(B):
+            for lo, hi in zip(cu[b, :-1].tolist(), cu[b, 1:].tolist()):
+                if hi <= lo:
+                    continue
+                if lo > 0 and lab_h[b, lo] != -100 and w_h[b, lo] != 0:
+                    raise NotImplementedError('a supervised FIRST token of a packed sub-sequence would be predicted from the previous sub-sequence')
+                sup = lab_h[b, lo + 1:hi] != -100
+                ws = w_h[b, lo + 1:hi][sup]
+                if ws.numel() and not bool((ws == ws[0]).all()):
+                    raise NotImplementedError('loss_weight must be constant over the supervised tokens of a sub-sequence (dataset_packed.py:540)')
+                need = int((ids_h[b, lo:hi] == self.img_context_token_id).sum()) // nt
+                t1, got = t0, 0
+                while t1 < pixel_values.shape[0] and got < need:
+                    got += 1 if (flags is None or flags[t1] == 1) else 0
+                    t1 += 1
+                if need == 0 and flags is not None and t1 < pixel_values.shape[0] and flags[t1] == 0:
+                    t1 += 1                                            # the dummy tile of a text-only sub-sequence
+                if t1 == t0:
+                    raise ValueError('every packed sub-sequence needs at least its (dummy) tile, as the reference dataset emits it')
+                wj = float(ws[0]) * int(sup.sum()) if ws.numel() else 0.0
+                work.append([pixel_values[t0:t1], ids_h[b:b + 1, lo:hi], lab_h[b:b + 1, lo:hi], None if flags is None else flags[t0:t1].reshape(-1, 1), wj])
+                t0 = t1
+        wsum = sum(x[4] for x in work)
+        if loss_reduction_all_gather and self.dp_active:
+            tw = torch.tensor([wsum], dtype=torch.float64, device=self.device)
+            torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.AVG, group=self.pg)
+            wsum = float(tw.item())
+        for x in work:
+            x[4] = x[4] / wsum if wsum else 0.0
+        return self._run_weighted(work, lr)
 
     # ------------------------------------------------------------------ resumable training state
     def save_checkpoint(self, path):
