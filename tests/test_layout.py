@@ -168,3 +168,51 @@ def test_vla_checkpoint_keys_of_the_reference_canonicalize():
     # the proprio mixture IS the action mixture after tie_action_proprio_weights (pizero_internvl.py:508-510)
     assert all(keys[k] == keys[k.replace('.proprio.', '.action.')] for k in keys if '.mixtures.proprio.' in k)
     assert not any(re.search(r'mixtures\.(vlm|action|proprio)\.layers\.\d+\.(self_attn\.o_proj\.bias|mlp\..*bias)', k) for k in keys)
+
+
+def test_vla_checkpoint_writer_emits_every_reference_key():
+    """`reference_vla_state_dict` (the VLA `.pt` writer) must produce exactly the key set of the reference's PiZero.state_dict()
+    (golden G9, aliases included) so that the reference's loader finds no missing key; round trip through the canonicaliser is the
+    identity on the canonical tensors."""
+    import json
+    import torch
+    from vlaser_amd import config as C, synth
+    from vlaser_amd.pizero import canonicalize_vla_state_dict, reference_vla_state_dict
+    keys = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'g9_vla_state_keys.json')))['keys']
+    small = synth.vla_state_dict(C.VLAConfig(base=C.truncated(C.vlaser_2b(), 1, 1)), with_head=True)
+    ref = reference_vla_state_dict(small)
+    want = {k for k in keys if '.layers.' not in k or '.layers.0.' in k}          # the 1 + 1-layer slice of the full key list
+    assert set(ref) == want, (sorted(set(ref) - want)[:5], sorted(want - set(ref))[:5])
+    back = canonicalize_vla_state_dict(ref)
+    for k, v in small.items():
+        assert torch.equal(back[k], v), k
+
+
+def test_internvla_processor_matches_reference_contract():
+    """InternVLAProcessor mirror: prompt ids equal golden G1's VLA prompt (the reference's processor output), pixel normalisation is
+    the ImageNet affine map on uint8 input, padding to max_seq_len on the right."""
+    import json
+    import torch
+    from vlaser_amd import prep
+
+    class Tok:                                     # records the query string; the real Qwen2 tokenizer is not on the GPU box
+        model_max_length = 0
+
+        def convert_tokens_to_ids(self, t):
+            return 151665
+
+        def __call__(self, query, **kw):
+            self.query, self.kw = query, kw
+            return {'input_ids': torch.zeros(len(query), kw['max_length'], dtype=torch.long), 'attention_mask': torch.ones(len(query), kw['max_length'], dtype=torch.long)}
+    tok = Tok()
+    proc = prep.InternVLAProcessor(tok, num_image_tokens=256, max_seq_len=384, tokenizer_padding='max_length')
+    img = torch.randint(0, 256, (2, 1, 3, 448, 448), dtype=torch.uint8)          # [B, n_images, 3, H, W] as simpler.py:82-92 builds it
+    out = proc(['put the spoon on the towel', 'pick up the carrot'], img)
+    assert tok.kw == {'return_tensors': 'pt', 'max_length': 384, 'padding': 'max_length', 'truncation': True} and tok.model_max_length == 384
+    assert tok.query[0] == prep.build_vla_query('put the spoon on the towel', 256) and tok.query[0].count('<IMG_CONTEXT>') == 256
+    assert tok.query[0].startswith('<|im_start|>system\nNone<|im_end|>\n<|im_start|>user\n<img>')
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    ref = (img[:, 0].float() / 255.0 - mean[None, :, None, None]) / std[None, :, None, None]
+    assert torch.allclose(out['pixel_values'].float(), ref, atol=1e-6) and out['input_ids'].shape == (2, 384)
+    with pytest.raises(AssertionError):
+        proc(['x'], img.float())

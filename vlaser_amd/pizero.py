@@ -51,6 +51,46 @@ def canonicalize_vla_state_dict(sd):
     return out
 
 
+def reference_vla_state_dict(sd, action_vocab_rows=None):
+    """Inverse of `canonicalize_vla_state_dict`: canonical tensors -> the key names of the reference's `PiZero.state_dict()` INCLUDING
+    every alias under which the reference registers the same module (vision_tower.vision_model == internvl_model.vision_model,
+    proprio mixture == action mixture, embed_tokens, ... -- golden G9 lists all 1713 names), so that the reference's
+    `load_checkpoint` (strict=False + "no missing keys", eval.py:196-212) accepts the file.  The action expert's vocabulary head
+    (`internvl_model.action_expert.lm_head.weight`, never used) is written as zeros when the canonical dict has none."""
+    rules = [('vision_model.', ['vision_tower.vision_model.', 'internvl_model.vision_model.']),
+             ('mlp1.', ['multi_modal_projector.']),
+             ('language_model.model.layers.', ['joint_model.mixtures.vlm.layers.']),
+             ('language_model.model.norm.', ['joint_model.mixtures.vlm.norm.', 'internvl_model.language_model.model.norm.']),
+             ('language_model.model.embed_tokens.', ['embed_tokens.', 'internvl_model.language_model.model.embed_tokens.']),
+             ('language_model.lm_head.', ['internvl_model.language_model.lm_head.']),
+             ('action_expert.model.layers.', ['joint_model.mixtures.action.layers.', 'joint_model.mixtures.proprio.layers.']),
+             ('action_expert.model.norm.', ['joint_model.mixtures.action.norm.', 'joint_model.mixtures.proprio.norm.', 'internvl_model.action_expert.model.norm.']),
+             ('action_expert.lm_head.', ['internvl_model.action_expert.lm_head.']),
+             ('action_encoder.', ['action_encoder.']), ('proprio_encoder.', ['proprio_encoder.']), ('action_decoder.', ['action_decoder.'])]
+    out = {}
+    for k, v in sd.items():
+        for a, bs in rules:
+            if k.startswith(a):
+                for b in bs:
+                    out[b + k[len(a):]] = v
+                break
+        else:
+            raise KeyError(f'no reference name for canonical key {k}')
+    if 'internvl_model.action_expert.lm_head.weight' not in out:
+        emb = sd['language_model.model.embed_tokens.weight']
+        rows = emb.shape[0] if action_vocab_rows is None else action_vocab_rows
+        out['internvl_model.action_expert.lm_head.weight'] = torch.zeros(rows, sd['action_expert.model.norm.weight'].shape[0], dtype=emb.dtype)
+    return out
+
+
+def save_vla_checkpoint(path, sd, cnt_update=0, cnt_batch=0, extra=None):
+    """Write a VLA checkpoint in the reference's `step{N}.pt` layout (train.py:639-672): `{"cnt_update", "cnt_batch", "model": state_dict,
+    ...}` with the reference's key names; `PiZero.load_checkpoint` / the reference's `EvalAgent.load_checkpoint` read `data["model"]`."""
+    data = {'cnt_update': cnt_update, 'cnt_batch': cnt_batch, 'model': {k: v.detach().cpu() for k, v in reference_vla_state_dict(sd).items()}}
+    data.update(extra or {})
+    torch.save(data, path)
+
+
 class PiZero:
     def __init__(self, cfg: VLAConfig, device='cuda', max_batch=1, use_graph=True, ride_proprio=True, naive_support=False):
         L.lib()

@@ -144,6 +144,31 @@ def vla_normalize_images(images_u8):
 
 
 # ------------------------------------------------------------------------------------------------ VLA masks
+class InternVLAProcessor:
+    """Mirror of the reference's `InternVLAProcessor` (Vlaser_VLA/Simpler/src/model/vla/processing.py:250-366): same constructor,
+    same `__call__(text, images uint8 [B,3,H,W]) -> {pixel_values, input_ids, attention_mask}` contract (ImageNet normalisation
+    :303-311, the hard-coded chat string with system message "None" :358, right padding to `max_seq_len` :360-363).  The number of
+    <IMG_CONTEXT> tokens comes from the constructor (`num_image_tokens`), not from the IMAGE_448 environment variable."""
+    IMAGE_TOKEN = '<image>'
+
+    def __init__(self, tokenizer, num_image_tokens, max_seq_len, actions=None, tokenizer_padding='max_length', num_images=1):
+        self.image_seq_length = num_image_tokens
+        self.max_seq_len = max_seq_len
+        self.tokenizer_padding = tokenizer_padding
+        self.image_token_id = tokenizer.convert_tokens_to_ids(self.IMAGE_TOKEN)
+        self.tokenizer = tokenizer
+        self.num_images = num_images
+
+    def __call__(self, text, images, truncation=True, actions=None):
+        assert len(images) == len(text), f'Received {len(images)} images for {len(text)} prompts.'
+        assert images.dtype == torch.uint8, f'Expected uint8 tensor for images, got {images.dtype}.'
+        pixel_values = vla_normalize_images(images)
+        self.tokenizer.model_max_length = self.max_seq_len
+        query = [build_vla_query(prompt, self.image_seq_length * self.num_images) for prompt in text]
+        inputs = self.tokenizer(query, return_tensors='pt', max_length=self.max_seq_len, padding=self.tokenizer_padding, truncation=truncation)
+        return {'pixel_values': pixel_values, **inputs}
+
+
 def build_causal_mask_and_position_ids(attention_mask, dtype, max_image_text_tokens=384, num_proprio_tokens=1,
                                        num_action_tokens=4):
     """Dense block mask + position ids of PiZero.build_causal_mask_and_position_ids (pizero_internvl.py:517-587).

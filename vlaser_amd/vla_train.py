@@ -424,3 +424,28 @@ class VLATrainer:
 
     def named_grads(self):
         return self.state_dict(grads=True)
+
+    def save_checkpoint(self, path, frozen_sd, cnt_batch=0):
+        """`step{N}.pt` of the reference trainer (train.py:639-672): the full model under the reference's key names (trained expert group
+        from the flat buffer + the frozen VLM tensors `frozen_sd` as loaded) + this rank's optimizer shard for a bit-identical resume."""
+        from .pizero import save_vla_checkpoint
+        sd = {k: v for k, v in canonicalize_vla_state_dict(frozen_sd).items() if not k.startswith(('action_expert.model.', 'action_encoder.', 'proprio_encoder.', 'action_decoder.'))}
+        sd.update(self.state_dict())
+        if self.dp_active:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        save_vla_checkpoint(path, sd, cnt_update=self.step_count, cnt_batch=cnt_batch,
+                            extra={'vlaser_amd_optimizer': {'rank': self.rank, 'world': self.world, 'step_count': self.step_count, 'master': self.master.cpu(),
+                                                            'exp_avg': self.m.cpu(), 'exp_avg_sq': self.v.cpu()}})
+
+    def load_checkpoint(self, path):
+        data = torch.load(path, map_location='cpu', weights_only=False)
+        self.load_state_dict(data['model'])
+        st = data.get('vlaser_amd_optimizer')
+        if st is not None and st['world'] == self.world and st['rank'] == self.rank:
+            self.step_count = st['step_count']
+            self.master.copy_(st['master']); self.m.copy_(st['exp_avg']); self.v.copy_(st['exp_avg_sq'])
+            for (lo, hi, _), o in zip(self.shards, self.shard_off):
+                if hi > lo:
+                    self.fp.p[lo:hi].copy_(self.master[o:o + hi - lo].to(BF))
+            self._refresh_transposes()
+        return self
