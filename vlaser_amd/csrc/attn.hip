@@ -35,16 +35,12 @@ __device__ __forceinline__ int k_lds_off(int row, int slot) {
 }
 __device__ __forceinline__ int vt_lds_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
 
-// QT = 16-row query tiles per wave: a workgroup owns 64 * QT query rows.  QT = 2 reads every K / V^T fragment from LDS once for two
-// query tiles (half the LDS traffic and barriers per FLOP) and turns the ViT's 17 x 16 = 272 workgroups (a second, nearly empty round
-// on 256 CUs) into 9 x 16 = 144 of one round; small grids (LLM prefill at S = 384: 36 workgroups with QT = 2) stay on QT = 1.
-template <int HD, int QT>
+template <int HD>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnP p) {
   constexpr int DC = HD / 32;   // d-chunks of 32 for S^T
   constexpr int DT = HD / 16;   // d-tiles of 16 for O^T
   constexpr int KCH = HD / 32;  // 16-byte chunks per thread for the K tile (64*HD*2/16/256)
   constexpr int VCH = HD / 32;  // same for V^T tile
-  constexpr int BR = 64 * QT;   // query rows per workgroup
   __shared__ __attribute__((aligned(16))) char smem[64 * HD * 2 + HD * 128];
   char* Ks = smem;
   char* Vs = smem + 64 * HD * 2;
@@ -53,60 +49,43 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnP p) {
   const int fr = lane & 15, g = lane >> 4;
   const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int kvh = h / (a.n_q_heads / a.n_kv_heads);
-  int q_row[QT];                 // this lane's query rows (within the batch element)
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) q_row[qt] = qb * BR + wave * (16 * QT) + qt * 16 + fr;
+  const int q_row = qb * 64 + wave * 16 + fr;  // this lane's query row (within the batch element)
 
   const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (size_t)b * a.q_bs + (size_t)h * a.q_hs;
   const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (size_t)b * a.k_bs + (size_t)kvh * a.k_hs;
   const bf16_t* VT = reinterpret_cast<const bf16_t*>(a.vt) + (size_t)b * a.vt_bs + (size_t)kvh * a.vt_hs;
 
   // visibility
-  int lim1[QT], lo2[QT], hi2[QT];
+  int lim1, lo2 = 0x7fffffff, hi2 = 0;
   int blk_lim1, blk_has2 = 0;
   {
-    const int q_last = min(a.sq, qb * BR + BR) - 1;
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) { lo2[qt] = 0x7fffffff; hi2[qt] = 0; }
+    const int q_last = min(a.sq, qb * 64 + 64) - 1;
     if (a.mode == VL_ATTN_FULL) {
-      blk_lim1 = a.kv_len;
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) lim1[qt] = a.kv_len;
+      lim1 = blk_lim1 = a.kv_len;
     } else if (a.mode == VL_ATTN_CAUSAL) {
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) lim1[qt] = min(a.kv_len, q_row[qt] + 1 + a.causal_off);
+      lim1 = min(a.kv_len, q_row + 1 + a.causal_off);
       blk_lim1 = min(a.kv_len, q_last + 1 + a.causal_off);
     } else {
       const int vl = a.valid_len ? a.valid_len[b] : a.kv_len;
-      blk_lim1 = min(vl, a.kv_len);
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) {
-        lim1[qt] = blk_lim1;
-        if (q_row[qt] + a.q_row_off >= a.blk_start) { lo2[qt] = a.blk_start; hi2[qt] = a.kv_len; }
-      }
+      lim1 = blk_lim1 = min(vl, a.kv_len);
+      if (q_row + a.q_row_off >= a.blk_start) { lo2 = a.blk_start; hi2 = a.kv_len; }
       blk_has2 = (q_last + a.q_row_off >= a.blk_start);
     }
   }
 
   // Q fragments (MFMA-B: col = query fr, k = d)
-  bf16x8 qf[QT][DC];
+  bf16x8 qf[DC];
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-    for (int dc = 0; dc < DC; ++dc) {
-      u32x4 v = {0, 0, 0, 0};
-      if (q_row[qt] < a.sq) v = ld_global_16(Q + (size_t)q_row[qt] * a.q_ss + dc * 32 + g * 8);
-      qf[qt][dc] = as_bf16x8(v);
-    }
-
-  f32x4 o[QT][DT];
-  float m_run[QT], l_run[QT];
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    m_run[qt] = NEG_BIG; l_run[qt] = 0.f;
-#pragma unroll
-    for (int i = 0; i < DT; ++i) o[qt][i] = f32x4{0, 0, 0, 0};
+  for (int dc = 0; dc < DC; ++dc) {
+    u32x4 v = {0, 0, 0, 0};
+    if (q_row < a.sq) v = ld_global_16(Q + (size_t)q_row * a.q_ss + dc * 32 + g * 8);
+    qf[dc] = as_bf16x8(v);
   }
+
+  f32x4 o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) o[i] = f32x4{0, 0, 0, 0};
+  float m_run = NEG_BIG, l_run = 0.f;
   const float sc = a.scale * 1.4426950408889634f;  // softmax in base 2
 
   // key-tile schedule: [0, n1) then tiles overlapping [blk_start, kv_len)
@@ -153,98 +132,82 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnP p) {
     __syncthreads();
     if (it + 1 < n_tiles) load_tile(it + 1);
     const int key0 = tile_key0(it);
-    // S^T tiles: s[qt][c][t], key(c,t,reg) = key0 + c*32 + g*8 + t*4 + reg; every K fragment feeds all QT query tiles
-    f32x4 s[QT][2][2];
+
+    // S^T tiles: s[c][t], key(c,t,reg) = key0 + c*32 + g*8 + t*4 + reg
+    f32x4 s[2][2];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        f32x4 acc[QT];
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) acc[qt] = f32x4{0, 0, 0, 0};
+        f32x4 acc = {0, 0, 0, 0};
         const int krow = c * 32 + (fr >> 2) * 8 + t * 4 + (fr & 3);
 #pragma unroll
         for (int dc = 0; dc < DC; ++dc) {
           bf16x8 kf = as_bf16x8(*reinterpret_cast<const u32x4*>(Ks + k_lds_off<HD>(krow, dc * 4 + g)));
-#pragma unroll
-          for (int qt = 0; qt < QT; ++qt) acc[qt] = mfma16(kf, qf[qt][dc], acc[qt]);
+          acc = mfma16(kf, qf[dc], acc);
         }
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) s[qt][c][t] = acc[qt];
+        s[c][t] = acc;
       }
     // mask + online softmax (lane-local per query; max all-reduced over the 4 lane groups)
-    bf16x8 pf[QT][2];
-    float alpha[QT];
+    float mx = NEG_BIG;
+    bool vis[2][2][4];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-      float mx = NEG_BIG;
-      bool vis[2][2][4];
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int r = 0; r < 4; ++r) {
+          const int key = key0 + c * 32 + g * 8 + t * 4 + r;
+          const bool v = (key < lim1) || (key >= lo2 && key < hi2);
+          vis[c][t][r] = v;
+          const float x = s[c][t][r] * sc;
+          s[c][t][r] = x;
+          if (v) mx = fmaxf(mx, x);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = fast_exp2(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8 pf[2];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = key0 + c * 32 + g * 8 + t * 4 + r;
-            const bool v = (key < lim1[qt]) || (key >= lo2[qt] && key < hi2[qt]);
-            vis[c][t][r] = v;
-            const float x = s[qt][c][t][r] * sc;
-            s[qt][c][t][r] = x;
-            if (v) mx = fmaxf(mx, x);
-          }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[qt], mx);
-      alpha[qt] = fast_exp2(m_run[qt] - m_new);
-      m_run[qt] = m_new;
-      float psum = 0.f;
+    for (int c = 0; c < 2; ++c) {
+      float pv[8];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        float pv[8];
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pe = vis[c][t][r] ? fast_exp2(s[qt][c][t][r] - m_new) : 0.f;
-            psum += pe;
-            pv[t * 4 + r] = pe;
-          }
-        u32x4 pk = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]), pack_bf16x2(pv[4], pv[5]), pack_bf16x2(pv[6], pv[7])};
-        pf[qt][c] = as_bf16x8(pk);
-      }
-      l_run[qt] = l_run[qt] * alpha[qt] + psum;
+        for (int r = 0; r < 4; ++r) {
+          const float pe = vis[c][t][r] ? fast_exp2(s[c][t][r] - m_new) : 0.f;
+          psum += pe;
+          pv[t * 4 + r] = pe;
+        }
+      u32x4 pk = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]), pack_bf16x2(pv[4], pv[5]), pack_bf16x2(pv[6], pv[7])};
+      pf[c] = as_bf16x8(pk);
     }
+    l_run = l_run * alpha + psum;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-      f32x4 acc[QT];
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) {
-        acc[qt] = o[qt][dt];
-        acc[qt][0] *= alpha[qt]; acc[qt][1] *= alpha[qt]; acc[qt][2] *= alpha[qt]; acc[qt][3] *= alpha[qt];
-      }
+      f32x4 acc = o[dt];
+      acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         bf16x8 vf = as_bf16x8(*reinterpret_cast<const u32x4*>(Vs + vt_lds_off(dt * 16 + fr, c * 4 + g)));
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) acc[qt] = mfma16(vf, pf[qt][c], acc[qt]);
+        acc = mfma16(vf, pf[c], acc);
       }
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) o[qt][dt] = acc[qt];
+      o[dt] = acc;
     }
   }
 
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  if (q_row < a.sq) {
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    bf16_t* O = reinterpret_cast<bf16_t*>(a.out) + (size_t)b * a.o_bs + (size_t)q_row * a.o_ss + h * HD;
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    float l_tot = l_run[qt] + __shfl_xor(l_run[qt], 16, 64);
-    l_tot += __shfl_xor(l_tot, 32, 64);
-    if (q_row[qt] < a.sq) {
-      const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-      bf16_t* O = reinterpret_cast<bf16_t*>(a.out) + (size_t)b * a.o_bs + (size_t)q_row[qt] * a.o_ss + h * HD;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        u32x2 pk = {pack_bf16x2(o[qt][dt][0] * inv, o[qt][dt][1] * inv), pack_bf16x2(o[qt][dt][2] * inv, o[qt][dt][3] * inv)};
-        *reinterpret_cast<u32x2*>(O + dt * 16 + g * 4) = pk;
-      }
+    for (int dt = 0; dt < DT; ++dt) {
+      u32x2 pk = {pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
+      *reinterpret_cast<u32x2*>(O + dt * 16 + g * 4) = pk;
     }
   }
 }
@@ -434,17 +397,9 @@ extern "C" int vlaser_attn_prefill(const VlaserAttnArgs* a, vl_stream_t s) {
   VL_CHECK(a->kv_len <= a->ld_vt, "vlaser_attn_prefill: kv_len exceeds cache");
   VL_CHECK(a->sq > 0 && a->batch > 0, "vlaser_attn_prefill: empty");
   AttnP p; p.a = *a;
-  // two query tiles per wave (128-row workgroups) whenever that still leaves about half a chip of workgroups
-  const int qt2_blocks = ((a->sq + 127) / 128) * a->n_q_heads * a->batch;
-  const bool qt2 = getenv("VLASER_ATTN_QT1") == nullptr && qt2_blocks >= 128;
-  dim3 grid((a->sq + (qt2 ? 127 : 63)) / (qt2 ? 128 : 64), a->n_q_heads, a->batch);
-  if (a->head_dim == 128) {
-    if (qt2) hipLaunchKernelGGL((attn_prefill_kernel<128, 2>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((attn_prefill_kernel<128, 1>), grid, dim3(256), 0, stream, p);
-  } else {
-    if (qt2) hipLaunchKernelGGL((attn_prefill_kernel<64, 2>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((attn_prefill_kernel<64, 1>), grid, dim3(256), 0, stream, p);
-  }
+  dim3 grid((a->sq + 63) / 64, a->n_q_heads, a->batch);
+  if (a->head_dim == 128) hipLaunchKernelGGL(attn_prefill_kernel<128>, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(attn_prefill_kernel<64>, grid, dim3(256), 0, stream, p);
   VL_LAUNCH_CHECK();
   return 0;
 }
