@@ -216,3 +216,16 @@ def test_internvla_processor_matches_reference_contract():
     assert torch.allclose(out['pixel_values'].float(), ref, atol=1e-6) and out['input_ids'].shape == (2, 384)
     with pytest.raises(AssertionError):
         proc(['x'], img.float())
+
+
+def test_split_k_choice_respects_kernel_constraints():
+    """ops.gemm_splits: K/splits must stay a multiple of 64 and >= 256 (csrc/gemm.hip checks both), splits never exceed what the consumers'
+    slab buffers hold, and an output that already fills the chip is not split."""
+    from vlaser_amd import ops
+    shapes = [(1025, 1024, 1024), (1025, 1024, 4096), (272, 1536, 1536), (272, 1536, 8960), (560, 1536, 8960), (560, 1536, 17920),
+              (3400, 3584, 18944), (5, 1536, 1536), (5, 1536, 8960), (64, 128, 256), (33, 4096, 320)]
+    for M, N, K in shapes:
+        s = ops.gemm_splits(M, N, K)
+        assert 1 <= s <= 32 and K % (s * 64) == 0 and (K // s >= 256 or s == 1), (M, N, K, s)
+    assert ops.gemm_splits(4096, 4096, 4096) == 1
+    assert ops.gemm_tile_config(1025, 4096)[0] == 1440 and ops.gemm_tile_config(16, 4096)[0] == 32

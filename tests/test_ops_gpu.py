@@ -406,7 +406,7 @@ def test_vla_glue(ops):
     close(act, a0 + 0.1 * vel, rtol=1e-5, atol=1e-6, name='euler')
 
 
-@pytest.mark.parametrize('bm', [32, 64, 128, 1100, 1200, 1300, 1500, 0])
+@pytest.mark.parametrize('bm', [32, 64, 128, 1100, 1200, 1300, 1440, 1500, 0])
 def test_gemm_tile_heights(ops, bm):
     from vlaser_amd import _lib as L
     M, N, K = 385, 1536, 1536
@@ -421,7 +421,7 @@ def test_gemm_tile_heights(ops, bm):
     close(o2, F.silu(gr).to(BF).float() * ur, name=f'swiglu bm{bm}')
 
 
-@pytest.mark.parametrize('bm', [32, 64, 1100, 1200, 1300, 1500])
+@pytest.mark.parametrize('bm', [32, 64, 1100, 1200, 1300, 1440, 1500])
 def test_gemm_qkv_rope_small_tiles(ops, bm):
     from vlaser_amd import _lib as L
     B, S, H, nq, nkv, smax = 1, 100, 1536, 12, 2, 128
@@ -473,7 +473,7 @@ def test_gemm_splitk_reduce_norm(ops, M, N, K, S):
     close(h3, href.float(), rtol=8e-3, name='h none')
 
 
-@pytest.mark.parametrize('bm', [1100, 1200, 1300, 1500])
+@pytest.mark.parametrize('bm', [1100, 1200, 1300, 1440, 1500])
 def test_gemm_glds_ragged_and_splitk(ops, bm):
     """LDS-DMA pipelines on shapes that do not fill their tiles: ragged M and N (fp32 logits epilogue), K shorter than the stage
     ring (look-ahead tiles are clamped re-fetches), and split-K partial slabs."""

@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
       {3408, 37888, 3584, "8B gate/up", VL_EPI_SWIGLU}};
   std::vector<Shape> pshapes = {{1025, 1024, 1024, "vit proj", 4}, {1025, 1024, 4096, "vit fc2", 4}, {384, 1536, 1536, "llm o", 3}, {384, 1536, 8960, "llm down", 7},
                                 {560, 1536, 8960, "sft down", 5}, {560, 1536, 17920, "sft dgrad gu", 10}};
-  const int cfgs[] = {64, 128, 1100, 1200, 1300, 1500, 0};
+  const int cfgs[] = {64, 128, 1100, 1200, 1300, 1440, 1500, 0};
   const int NL = 8;
   float* dmax; CK(hipMalloc(&dmax, 4));
   auto run = [&](const Shape& sh, int splits) {

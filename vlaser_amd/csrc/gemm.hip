@@ -312,9 +312,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
   constexpr int WTM = BM / WM, WTN = BNT / WN;
   constexpr int MT = WTM / 16, NT = WTN / 16;
   constexpr int STAGE = (BM + BNT) * 128;               // bytes: A tile | W tile (row-major, 128 B = 64 k per row)
-  constexpr int PA = BM / 8 / NW, PW = BNT / 8 / NW;     // 1 KiB pieces per wave per K-tile (A, W)
-  constexpr int PIECES = PA + PW;
-  static_assert(PA >= 1 && PW >= 1 && PA * 8 * NW == BM && PW * 8 * NW == BNT, "tile rows must split evenly into 8-row pieces per wave");
+  constexpr int NPA = BM / 8, NPW = BNT / 8;             // 1 KiB (8-row) pieces of the A / W tile
+  constexpr int PA = (NPA + NW - 1) / NW, PW = (NPW + NW - 1) / NW;     // pieces per wave per K-tile; an uneven split re-issues the last piece
+  constexpr int PIECES = PA + PW;                        // (same bytes to the same LDS address: benign) so every wave's vmcnt arithmetic is identical
+  static_assert(NPA * 8 == BM && NPW * 8 == BNT, "tile rows must be multiples of 8");
   static_assert(NT % 2 == 0, "fused pair epilogues need an even number of 16-column tiles per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const VlaserGemmArgs& a = p.a;
@@ -341,12 +342,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
   const bf16_t* srcW[PW];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
-    const int row = (wave * PA + i) * 8 + prow;
+    const int row = min(wave * PA + i, NPA - 1) * 8 + prow;
     srcA[i] = A + (size_t)min(m0 + row, a.M - 1) * a.lda + kbase + ((pslot ^ (row & 7)) << 3);
   }
 #pragma unroll
   for (int i = 0; i < PW; ++i) {
-    const int row = (wave * PW + i) * 8 + prow;
+    const int row = min(wave * PW + i, NPW - 1) * 8 + prow;
     srcW[i] = W + (size_t)min(n0 + row, a.N - 1) * a.ldw + kbase + ((pslot ^ (row & 7)) << 3);
   }
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;      // LDS byte address of the stage ring (low 32 bits of the generic pointer)
@@ -354,9 +355,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
     const int ko = min(kt, nk - 1) * BK;                 // tiles past the end re-fetch the last one (never read)
     const uint32_t base = lds0 + st * STAGE;
 #pragma unroll
-    for (int i = 0; i < PA; ++i) glds16(srcA[i] + ko, __builtin_amdgcn_readfirstlane(base + (wave * PA + i) * 1024));
+    for (int i = 0; i < PA; ++i) glds16(srcA[i] + ko, __builtin_amdgcn_readfirstlane(base + min(wave * PA + i, NPA - 1) * 1024));
 #pragma unroll
-    for (int i = 0; i < PW; ++i) glds16(srcW[i] + ko, __builtin_amdgcn_readfirstlane(base + BM * 128 + (wave * PW + i) * 1024));
+    for (int i = 0; i < PW; ++i) glds16(srcW[i] + ko, __builtin_amdgcn_readfirstlane(base + BM * 128 + min(wave * PW + i, NPW - 1) * 1024));
   };
 
   f32x4 acc[NT][MT];
@@ -477,6 +478,8 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
       bm = 1500;
     } else if (blocks(128, 128) <= 256) {
       bm = 1100;
+    } else if (blocks(144, 128) <= 256) {
+      bm = 1440;                       // M = 8 x 128 + a few rows (the ViT's 1025 tokens): 144-row tiles cover it in 8 instead of 9 tile rows
     } else if (blocks(128, 256) <= 256) {
       bm = 1200;
     } else if (blocks(256, 256) <= 256) {
@@ -490,12 +493,13 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
       }
     }
   }
-  // LDS-DMA pipeline configurations: 1100 = 128x128 / 4 stages, 1200 = 128x256 / 3, 1300 = 256x256 / 2, 1500 = 64x128 / 4 (8 waves each)
+  // LDS-DMA pipeline configurations: 1100 = 128x128 / 4 stages, 1200 = 128x256 / 3, 1300 = 256x256 / 2, 1500 = 64x128 / 4 (8 waves each), 1440 = 144x128 / 4 (6 waves)
   switch (bm) {
     case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4>(args, stream, splits);
     case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3>(args, stream, splits);
     case 1300: return launch_glds<EPI, 256, 256, 2, 4, 2>(args, stream, splits);
     case 1500: return launch_glds<EPI, 64, 128, 2, 4, 4>(args, stream, splits);
+    case 1440: return launch_glds<EPI, 144, 128, 3, 2, 4>(args, stream, splits);
     default: break;
   }
   if (bm == 128) return launch_bm<EPI, 128>(args, stream, splits);
@@ -678,8 +682,8 @@ extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   VL_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "vlaser_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
   VL_CHECK(a->K % BK == 0, "vlaser_gemm: K=%d must be a multiple of %d", a->K, BK);
   VL_CHECK(a->batch <= 1 || (epi == VL_EPI_NONE || epi == VL_EPI_F32 || epi == VL_EPI_BIAS), "vlaser_gemm: batched mode supports NONE / F32 / BIAS epilogues");
-  VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1500,
-           "vlaser_gemm: force_bm must be 0/32/64/128 or an LDS-DMA configuration code 1100/1200/1300/1500");
+  VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1440 || a->force_bm == 1500,
+           "vlaser_gemm: force_bm must be 0/32/64/128 or an LDS-DMA configuration code 1100/1200/1300/1440/1500");
   VL_CHECK(a->lda % 8 == 0 && a->ldw % 8 == 0, "vlaser_gemm: lda/ldw must be multiples of 8 (16-byte rows)");
   VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm: operands must be 16-byte aligned");
   switch (epi) {

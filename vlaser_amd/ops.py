@@ -71,6 +71,9 @@ def gemm(epi, A, W, out=None, bias=None, res=None, ls=None, N=None, **kw):
     if out is not None:
         a.out, a.ldo = out.data_ptr(), out.stride(0)
     a.bias, a.res, a.ls = _p(bias), _p(res), _p(ls)
+    part = kw.get('out_f32')
+    if epi == L.EPI_PARTIAL and isinstance(part, torch.Tensor) and part.numel() < kw.get('k_splits', 1) * M * a.N:
+        raise ValueError(f'vlaser_gemm: {kw.get("k_splits", 1)} fp32 slabs of [{M},{a.N}] do not fit the {part.numel()}-element partial buffer')
     for k, v in kw.items():
         setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
     L.check(L.lib().vlaser_gemm(epi, C.byref(a), _stream()), 'vlaser_gemm')
@@ -335,20 +338,34 @@ def reduce_norm(h_in, partials, n_partials, M, C, h_out, x_out=None, bias=None, 
                                        h_out.data_ptr(), _p(x_out), M, C, _stream()), 'vlaser_reduce_norm')
 
 
+_GEMM_CFGS = ((1500, 64, 128, 701.0), (1100, 128, 128, 850.0), (1440, 144, 128, 900.0), (1200, 128, 256, 1040.0), (1300, 256, 256, 1208.0))
+
+
+def gemm_tile_config(M, N, splits=1, batch=1):
+    """Mirror of the tile choice in csrc/gemm.hip `launch<EPI>` (single-round rule, then least modelled time): (code, BM, BN, rate)."""
+    blocks = lambda bm, bn: -(-M // bm) * -(-N // bn) * splits * batch
+    if M <= 32:
+        return (32, 32, 128, 500.0)
+    for c in _GEMM_CFGS:
+        if blocks(c[1], c[2]) <= 256:
+            return c
+    return min((c for c in _GEMM_CFGS if c[0] != 1440), key=lambda c: -(-blocks(c[1], c[2]) // 256) * c[1] * c[2] / c[3])
+
+
 def gemm_splits(M, N, K, target_blocks=256):
-    """Split-K factor for a [M,N] output so that tiles * splits ~ one workgroup per CU; K/splits stays a multiple of 64
-    and >= 256."""
-    def tiles(bm):
-        return ((M + bm - 1) // bm) * ((N + 127) // 128)
-    t = tiles(64)
-    best = 1
+    """Split-K factor for a [M,N] output whose tiles alone cannot fill 256 CUs: the factor (K/splits a multiple of 64 and >= 256) with
+    the least modelled time = rounds x tile FLOPs / measured tile rate (profiles/r02b_gemm_lab.md) + the consumer's cost of summing
+    the extra fp32 slabs."""
+    best = (None, 1)
     for s in range(1, 33):
         if K % (s * 64) or K // s < 256:
             continue
-        best = s
-        if t * s >= target_blocks:
-            break
-    return best
+        code, bm, bn, rate = gemm_tile_config(M, N, s)
+        blocks = -(-M // bm) * -(-N // bn) * s
+        t = -(-blocks // 256) * (2.0 * bm * bn * (K // s) * 256 / (rate * 1e12) * 1e6 + 2.0) + (s > 1) * (0.35 * s + M * N * 4.0 * s / 4e6)
+        if best[0] is None or t < best[0] - 1e-9:
+            best = (t, s)
+    return best[1]
 
 
 def cast_f32_bf16(x, y):
