@@ -226,6 +226,10 @@ def test_split_k_choice_respects_kernel_constraints():
               (3400, 3584, 18944), (5, 1536, 1536), (5, 1536, 8960), (64, 128, 256), (33, 4096, 320)]
     for M, N, K in shapes:
         s = ops.gemm_splits(M, N, K)
-        assert 1 <= s <= 32 and K % (s * 64) == 0 and (K // s >= 256 or s == 1), (M, N, K, s)
+        assert 1 <= s <= 8 and K % (s * 64) == 0 and (K // s >= 256 or s == 1), (M, N, K, s)
+        budget = ops.split_slab_elems(M, N)          # a workspace sized for M rows always holds the factor chosen for <= M rows
+        for m in (M, max(1, M // 2), max(1, M // 7)):
+            assert ops.gemm_splits(m, N, K, budget) * m * N <= budget
+    assert ops.gemm_splits(4096, 1536, 8960, ops.split_slab_elems(4096, 1536)) <= 2
     assert ops.gemm_splits(4096, 4096, 4096) == 1
     assert ops.gemm_tile_config(1025, 4096)[0] == 1440 and ops.gemm_tile_config(16, 4096)[0] == 32

@@ -490,6 +490,27 @@ def test_gemm_glds_ragged_and_splitk(ops, bm):
     close(part.sum(0), x.float() @ w.float().t(), rtol=2e-3, atol=2e-3, name=f'split-K cfg{bm}')
 
 
+def test_gemm_lds_attribute_is_set_per_kernel_in_any_order():
+    """The dynamic-LDS limit is raised once per (kernel instantiation, device).  In a fresh process, run the LDS-DMA configurations
+    from the largest stage ring to the smallest: every one must launch (a table shared by all instantiations let the first, largest
+    request mask the later ones -- an order the model code did not hit until the 144-row configuration existed)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import torch\n"
+        "from vlaser_amd import ops, _lib as L\n"
+        "x = torch.randn(300, 512, device='cuda').bfloat16(); w = (0.05 * torch.randn(640, 512, device='cuda')).bfloat16()\n"
+        "ref = x.float() @ w.float().t()\n"
+        "for bm in (1200, 1440, 1100, 1300, 1500, 128, 64, 32):\n"
+        "    out = torch.zeros(300, 640, dtype=torch.float32, device='cuda')\n"
+        "    ops.gemm(L.EPI_F32, x, w, out=out, force_bm=bm)\n"
+        "    torch.cuda.synchronize()\n"
+        "    assert (out - ref).abs().max().item() < 2e-2, bm\n"
+        "print('ok')\n")
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
+
+
 def test_skinny_chunked_k_vlaser_8b_widths(ops):
     """Chunked-K weight streaming: K / (k_splits * 256) = 14 or 16 steps per wave run as two chunks of 7 / 8 with
     the accumulators carried across chunks -- Vlaser-8B's hidden 3584 (qkv / gate+up / lm_head, NORM prologue) and its MLP width

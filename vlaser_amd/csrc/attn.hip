@@ -416,11 +416,7 @@ extern "C" int vlaser_attn_skinny(const VlaserAttnArgs* a, vl_stream_t s) {
   VL_CHECK(a->mode == VL_ATTN_FULL || a->mode == VL_ATTN_PREFIX, "vlaser_attn_skinny: mode must be FULL or PREFIX");
   AttnP p; p.a = *a;
   const int lds = SKA_WAVES * (64 + 32 * 128) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_skinny_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
-  }
+  if (int rc = set_max_lds_once(attn_skinny_kernel, lds)) return rc;
   hipLaunchKernelGGL(attn_skinny_kernel, dim3(a->n_kv_heads, a->n_splits, a->batch), dim3(64 * SKA_WAVES), lds, stream, p);
   VL_LAUNCH_CHECK();
   return 0;

@@ -4,6 +4,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
+#include <mutex>
+#include <utility>
 
 typedef uint16_t bf16_t;  // raw bf16 bits in memory
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -103,3 +106,23 @@ void vlaser_set_error(const char* fmt, ...);
     }                                                                       \
   } while (0)
 #define VL_LAUNCH_CHECK() VL_HIP(hipGetLastError())
+
+// one attribute call per (kernel, device): the C ABI promises thread safety w.r.t. distinct streams, and a process may drive
+// several GPUs
+template <class K>
+static int set_max_lds_once(K kernel, int lds) {
+  // keyed by the kernel's ADDRESS: every instantiation of a kernel template has the same function-pointer type, so a table per
+  // type would let the first (largest) instantiation mask all the others
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> done;
+  int dev = 0;
+  VL_HIP(hipGetDevice(&dev));
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  std::lock_guard<std::mutex> g(mu);
+  int& have = done[{fn, dev}];
+  if (have < lds) {
+    VL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    have = lds;
+  }
+  return 0;
+}

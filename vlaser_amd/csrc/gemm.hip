@@ -10,7 +10,6 @@
 // LDS: 2 x (A 16 KiB + W 16 KiB), 16-byte slots XOR-swizzled by (row & 7) (guide T2) -> <=2-way conflicts on
 // ds_read_b128.  Global->register prefetch of tile k+1 overlaps the MFMAs of tile k; one barrier per K-step.
 // blockIdx is remapped so each XCD owns a contiguous run of tiles that share the same weight panel (guide T1).
-#include <mutex>
 
 #include "common.h"
 #include "../../include/vlaser_hip.h"
@@ -412,22 +411,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
       for (int nt = 0; nt < NT; ++nt) epilogue<EPI>(ea, m, n0 + wc * WTN + nt * 16 + fq * 4, acc[nt][mt], acc[nt][mt]);
     }
   }
-}
-
-// one attribute call per (kernel, device): the C ABI promises thread safety w.r.t. distinct streams, and a process may drive
-// several GPUs
-template <class K>
-static int set_max_lds_once(K kernel, int lds) {
-  static std::mutex mu;
-  static int done_lds[64] = {0};
-  int dev = 0;
-  VL_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> g(mu);
-  if (dev < 0 || dev >= 64 || done_lds[dev] < lds) {
-    VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    if (dev >= 0 && dev < 64) done_lds[dev] = lds;
-  }
-  return 0;
 }
 
 template <int EPI, int BM, int BNT, int WM, int WN, int NST>

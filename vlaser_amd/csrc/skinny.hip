@@ -25,7 +25,6 @@
 //   * one copy of K-loop / reduce / epilogue per peel: small code, a cold instruction cache is paid on every launch.
 // MFMA operands are swapped (W as A, x as B) so each lane owns 4 consecutive outputs n of one row m, sharing the
 // fused epilogues of the big GEMM (bias / SiLU / SwiGLU / RoPE + KV-cache scatter).
-#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -537,18 +536,7 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
 
 template <int PRO, int EPI, int TPU, int NS, int SP, int NCH = 1>
 static int launch_sp(const VlaserSkinnyArgs* a, hipStream_t stream, SkinnyP& p, int gx, int lds) {
-  // one attribute call per (kernel, device, size): the C ABI is used from several threads / GPUs
-  static std::mutex mu;
-  static int attr_lds[64] = {0};
-  int dev = 0;
-  VL_HIP(hipGetDevice(&dev));
-  {
-    std::lock_guard<std::mutex> g(mu);
-    if (dev < 0 || dev >= 64 || lds > attr_lds[dev]) {
-      VL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel<PRO, EPI, TPU, NS, SP, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      if (dev >= 0 && dev < 64) attr_lds[dev] = lds;
-    }
-  }
+  if (int rc = set_max_lds_once(skinny_kernel<PRO, EPI, TPU, NS, SP, NCH>, lds)) return rc;
   hipLaunchKernelGGL((skinny_kernel<PRO, EPI, TPU, NS, SP, NCH>), dim3(gx, a->k_splits), dim3(SKT), lds, stream, p);
   VL_LAUNCH_CHECK();
   return 0;

@@ -124,7 +124,6 @@ class VitEngine:
         self.m1w, self.m1b = g('mlp1.1.weight'), g('mlp1.1.bias')
         self.m3w, self.m3b = g('mlp1.3.weight'), g('mlp1.3.bias')
         self.max_tiles = 0
-        self.part = None
         self._alloc(max_tiles)
 
     def _alloc(self, T):
@@ -147,6 +146,7 @@ class VitEngine:
         self.psln = z(n_tok, 4 * C)
         self.g = z(n_tok, self.cfg.llm.hidden_size)
         self.feat = z(n_tok, self.cfg.llm.hidden_size)
+        self.part = torch.zeros(ops.split_slab_elems(T * S, C), dtype=torch.float32, device=dev)      # split-K slabs of proj / fc2
         self.max_tiles = T
 
     def forward(self, pixel_values, return_layers=False):
@@ -165,10 +165,7 @@ class VitEngine:
         if return_layers:
             layers_out.append(h.clone())
         # split-K factors for the two N = C outputs (proj, fc2): M*C/128^2 tiles alone cannot fill 256 CUs
-        sp_proj, sp_fc2 = ops.gemm_splits(M, C, C), ops.gemm_splits(M, C, v.intermediate_size)
-        need = max(sp_proj, sp_fc2) * M * C
-        if self.part is None or self.part.numel() < need:
-            self.part = torch.zeros(need, dtype=torch.float32, device=self.device)
+        sp_proj, sp_fc2 = ops.gemm_splits(M, C, C, self.part.numel()), ops.gemm_splits(M, C, v.intermediate_size, self.part.numel())
         nl = len(self.layers)
         ops.layernorm(h, self.layers[0]['n1w'], self.layers[0]['n1b'], v.layer_norm_eps, out=x)
         for li, lw in enumerate(self.layers):
@@ -208,13 +205,9 @@ class PrefillBuffers:
         self.ao = z(max_rows, stack.nq * llm.head_dim)
         self.act = z(max_rows, llm.intermediate_size)
         self.max_rows = max_rows
-        self._part = None
+        # split-K slabs of o_proj / down_proj: sized once (a HIP graph may have captured the address)
+        self.part = torch.zeros(ops.split_slab_elems(max_rows, llm.hidden_size), dtype=torch.float32, device=device)
         self.device = device
-
-    def partials(self, n):
-        if self._part is None or self._part.numel() < n:
-            self._part = torch.zeros(n, dtype=torch.float32, device=self.device)
-        return self._part
 
 
 def prefill_begin(stack: QwenStack, buf: PrefillBuffers, h, M):
@@ -244,8 +237,8 @@ def prefill_layer(stack: QwenStack, lw: QwenLayerWeights, buf: PrefillBuffers, h
                      attn_mode, causal_off=causal_off, valid_len=valid_len, blk_start=blk_start, q_row_off=slot_base)
     if skip_post_attn:
         return
-    sp_o, sp_d = ops.gemm_splits(M, H, nq * hd), ops.gemm_splits(M, H, I)
-    part = buf.partials(max(sp_o, sp_d) * M * H)
+    part = buf.part
+    sp_o, sp_d = ops.gemm_splits(M, H, nq * hd, part.numel()), ops.gemm_splits(M, H, I, part.numel())
     ops.gemm(L.EPI_PARTIAL, ao, lw.wo, out_f32=part, k_splits=sp_o)
     ops.reduce_norm(h, part, sp_o, M, H, h, x, norm=1, norm_w=lw.ln_post, eps=llm.rms_norm_eps)
     ops.gemm(L.EPI_SWIGLU, x, lw.wgu, out=act)

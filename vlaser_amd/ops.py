@@ -352,13 +352,20 @@ def gemm_tile_config(M, N, splits=1, batch=1):
     return min((c for c in _GEMM_CFGS if c[0] != 1440), key=lambda c: -(-blocks(c[1], c[2]) // 256) * c[1] * c[2] / c[3])
 
 
-def gemm_splits(M, N, K, target_blocks=256):
-    """Split-K factor for a [M,N] output whose tiles alone cannot fill 256 CUs: the factor (K/splits a multiple of 64 and >= 256) with
-    the least modelled time = rounds x tile FLOPs / measured tile rate (profiles/r02b_gemm_lab.md) + the consumer's cost of summing
-    the extra fp32 slabs."""
+def split_slab_elems(max_rows, N):
+    """fp32 elements of a split-K slab workspace sized ONCE for up to max_rows output rows of width N: 8 slabs for outputs of up to
+    1024 rows, at least 2 for any size.  Workspaces must not be re-allocated after a HIP graph has captured their address, so the
+    callers allocate this at construction and pass it to `gemm_splits` as the budget."""
+    return max(8 * min(max_rows, 1024), 2 * max_rows) * N
+
+
+def gemm_splits(M, N, K, max_elems=None, max_splits=8):
+    """Split-K factor for a [M,N] output whose tiles alone cannot fill 256 CUs: the factor (K/splits a multiple of 64 and >= 256, at
+    most max_splits, splits*M*N fp32 slab elements within max_elems) with the least modelled time = rounds x tile FLOPs / measured
+    tile rate (profiles/r02b_gemm_lab.md) + the consumer's cost of summing the extra fp32 slabs."""
     best = (None, 1)
-    for s in range(1, 33):
-        if K % (s * 64) or K // s < 256:
+    for s in range(1, max_splits + 1):
+        if K % (s * 64) or K // s < 256 or (s > 1 and max_elems is not None and s * M * N > max_elems):
             continue
         code, bm, bn, rate = gemm_tile_config(M, N, s)
         blocks = -(-M // bm) * -(-N // bn) * s
