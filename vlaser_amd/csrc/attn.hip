@@ -17,6 +17,7 @@
 //   FULL   : lim1 = kv_len                         (ViT, modeling_intern_vit.py:220-224: no mask)
 //   CAUSAL : lim1 = min(kv_len, i + 1 + causal_off)
 //   PREFIX : lim1 = valid_len[b]; rows >= blk_start additionally see [blk_start, kv_len)
+#include <type_traits>
 #include "common.h"
 #include "../../include/vlaser_hip.h"
 
@@ -28,24 +29,48 @@ struct AttnP {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// LDS images of the K tile [64 keys][HD] and the V^T tile [HD][64 keys], 16-byte slots XOR-swizzled per row.  A ds_read_b128 is served
+// 16 lanes per cycle over 64 banks, so the 16 rows one lane group touches must land on 16 different 16-byte columns of the 256-byte
+// bank row: the S^T fragment's 16 lanes read key rows {0-3, 8-11, 16-19, 24-27} (+4 t) at one slot, the O^T fragment's read 16
+// consecutive d rows.  With 128-byte rows two rows share a bank row (row parity picks the half), so the swizzle key must separate
+// the 8 rows of equal parity; with 256-byte rows (head_dim 128) all 16.  (r01/r02 used row & 7 / row & 15: 4-way conflicts on K at
+// head_dim 64, 2-way on V^T and on K at head_dim 128.)
 template <int HD>
 __device__ __forceinline__ int k_lds_off(int row, int slot) {
-  if constexpr (HD == 128) return row * 256 + ((slot ^ (row & 15)) << 4);
-  else return row * 128 + ((slot ^ (row & 7)) << 4);
+  if constexpr (HD == 128) return row * 256 + ((slot ^ ((row & 3) | (((row >> 3) & 3) << 2))) << 4);
+  else return row * 128 + ((slot ^ (((row >> 1) & 1) | (((row >> 3) & 3) << 1))) << 4);
 }
-__device__ __forceinline__ int vt_lds_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
+template <int TK>
+__device__ __forceinline__ int vt_lds_off(int row, int slot) {
+  if constexpr (TK == 128) return row * 256 + ((slot ^ (row & 15)) << 4);
+  else return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
+}
 
-template <int HD>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnP p) {
+// KS = key splits INSIDE the workgroup: KS groups of 4 waves share the 64 query rows, group j walks key tiles j, j+KS, ... through
+// its own K / V^T staging buffers, and group 0 merges the (m, l, o) triples through LDS at the end (fixed order: deterministic).
+// The path's prefill grids are about one 4-wave workgroup per CU (ViT: 17 x 16 = 272, joint prefill 6 x 12 = 72), i.e. one wave
+// per SIMD walking a serial chain of key tiles with nothing to hide a tile's load latency behind; the split shortens the chain KS
+// times and puts KS waves on every SIMD.
+// TK = keys per tile (64 / 128): with about one workgroup per CU a wave is alone on its SIMD and every tile is a serial chain
+// barrier -> LDS store -> barrier -> S^T -> max (two cross-lane hops) -> exp -> P V; 128-key tiles halve the number of chains
+// per key and give each one twice the independent MFMA / exp work to overlap.
+template <int HD, int KS, int TK>
+__global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
   constexpr int DC = HD / 32;   // d-chunks of 32 for S^T
   constexpr int DT = HD / 16;   // d-tiles of 16 for O^T
-  constexpr int KCH = HD / 32;  // 16-byte chunks per thread for the K tile (64*HD*2/16/256)
-  constexpr int VCH = HD / 32;  // same for V^T tile
-  __shared__ __attribute__((aligned(16))) char smem[64 * HD * 2 + HD * 128];
-  char* Ks = smem;
-  char* Vs = smem + 64 * HD * 2;
+  constexpr int NC = TK / 32;   // 32-key chunks per tile
+  constexpr int KCH = TK * HD / 2048;  // 16-byte chunks per thread for the K tile (TK*HD*2/16/256)
+  constexpr int VCH = TK * HD / 2048;  // same for V^T tile
+  constexpr int TILE_BYTES = 2 * TK * HD * 2;
+  constexpr int MERGE_WAVE = (DT * 4 + 2) * 256;                 // one wave's (o[DT][4], m, l) as [slot][lane] fp32
+  constexpr int MERGE_BYTES = (KS - 1) * 4 * MERGE_WAVE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // max(KS * TILE_BYTES, MERGE_BYTES)
   const VlaserAttnArgs& a = p.a;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x & 63;
+  const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);      // key-split group of this wave
+  const int tid = threadIdx.x & 255, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // thread / wave index inside the group
+  char* Ks = smem + grp * TILE_BYTES;
+  char* Vs = Ks + TK * HD * 2;
   const int fr = lane & 15, g = lane >> 4;
   const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int kvh = h / (a.n_q_heads / a.n_kv_heads);
@@ -89,27 +114,27 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnP p) {
   const float sc = a.scale * 1.4426950408889634f;  // softmax in base 2
 
   // key-tile schedule: [0, n1) then tiles overlapping [blk_start, kv_len)
-  const int n1 = (blk_lim1 + 63) >> 6;
+  const int n1 = (blk_lim1 + TK - 1) / TK;
   int t2_lo = 0, t2_hi = 0;
-  if (blk_has2) { t2_lo = max(n1, a.blk_start >> 6); t2_hi = (a.kv_len + 63) >> 6; }
+  if (blk_has2) { t2_lo = max(n1, a.blk_start / TK); t2_hi = (a.kv_len + TK - 1) / TK; }
   const int n_tiles = n1 + max(0, t2_hi - t2_lo);
 
   u32x4 rk[KCH], rv[VCH];
-  auto tile_key0 = [&](int it) { return (it < n1 ? it : t2_lo + (it - n1)) << 6; };
+  auto tile_key0 = [&](int it) { return (it < n1 ? it : t2_lo + (it - n1)) * TK; };
   auto load_tile = [&](int it) {
     const int key0 = tile_key0(it);
 #pragma unroll
     for (int i = 0; i < KCH; ++i) {
       const int c = tid + i * 256;              // chunk id: row = c / (HD/8), slot = c % (HD/8)
       const int row = c / (HD / 8), slot = c % (HD / 8);
-      const int key = key0 + row;
-      rk[i] = (key < a.kv_len) ? ld_global_16(K + (size_t)key * HD + slot * 8) : u32x4{0, 0, 0, 0};
+      const int key = min(key0 + row, a.kv_len - 1);      // clamped, unconditional: keys >= kv_len are never visible
+      rk[i] = ld_global_16(K + (size_t)key * HD + slot * 8);
     }
 #pragma unroll
     for (int i = 0; i < VCH; ++i) {
-      const int c = tid + i * 256;              // row = d = c / 8, slot = c % 8 (8 keys each)
-      const int row = c >> 3, slot = c & 7;
-      rv[i] = ld_global_16(VT + (size_t)row * a.ld_vt + key0 + slot * 8);  // cache is padded to a multiple of 64 keys
+      const int c = tid + i * 256;              // row = d = c / (TK/8), slot = c % (TK/8) (8 keys each)
+      const int row = c / (TK / 8), slot = c % (TK / 8);
+      rv[i] = ld_global_16(VT + (size_t)row * a.ld_vt + min(key0 + slot * 8, a.ld_vt - 8));  // rows are padded to a multiple of 64 keys; clamped beyond
     }
   };
   auto store_tile = [&]() {
@@ -121,22 +146,16 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnP p) {
 #pragma unroll
     for (int i = 0; i < VCH; ++i) {
       const int c = tid + i * 256;
-      *reinterpret_cast<u32x4*>(Vs + vt_lds_off(c >> 3, c & 7)) = rv[i];
+      *reinterpret_cast<u32x4*>(Vs + vt_lds_off<TK>(c / (TK / 8), c % (TK / 8))) = rv[i];
     }
   };
 
-  if (n_tiles > 0) load_tile(0);
-  for (int it = 0; it < n_tiles; ++it) {
-    __syncthreads();  // previous tile's LDS reads are done
-    store_tile();
-    __syncthreads();
-    if (it + 1 < n_tiles) load_tile(it + 1);
-    const int key0 = tile_key0(it);
-
-    // S^T tiles: s[c][t], key(c,t,reg) = key0 + c*32 + g*8 + t*4 + reg
-    f32x4 s[2][2];
+  // one TK-key tile against this wave's 16 query rows; S^T tiles s[c][t], key(c,t,reg) = key0 + c*32 + g*8 + t*4 + reg
+  auto tile_body = [&](int key0, auto masked_c) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(masked_c)::value;
+    f32x4 s[NC][2];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         f32x4 acc = {0, 0, 0, 0};
@@ -148,37 +167,42 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnP p) {
         }
         s[c][t] = acc;
       }
-    // mask + online softmax (lane-local per query; max all-reduced over the 4 lane groups)
+    // online softmax in base 2 (lane-local per query; max all-reduced over the 4 lane groups); the scale is applied inside the
+    // exponent's FMA: max(s) * sc == max(s * sc) for sc > 0
     float mx = NEG_BIG;
-    bool vis[2][2][4];
+    bool vis[NC][2][4];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = key0 + c * 32 + g * 8 + t * 4 + r;
-          const bool v = (key < lim1) || (key >= lo2 && key < hi2);
-          vis[c][t][r] = v;
-          const float x = s[c][t][r] * sc;
-          s[c][t][r] = x;
-          if (v) mx = fmaxf(mx, x);
+          if constexpr (MASKED) {
+            const int key = key0 + c * 32 + g * 8 + t * 4 + r;
+            const bool v = (key < lim1) || (key >= lo2 && key < hi2);
+            vis[c][t][r] = v;
+            if (v) mx = fmaxf(mx, s[c][t][r]);
+          } else {
+            vis[c][t][r] = true;
+            mx = fmaxf(mx, s[c][t][r]);
+          }
         }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
+    const float m_new = fmaxf(m_run, mx * sc);
     const float alpha = fast_exp2(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
-    bf16x8 pf[2];
+    bf16x8 pf[NC];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NC; ++c) {
       float pv[8];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pe = vis[c][t][r] ? fast_exp2(s[c][t][r] - m_new) : 0.f;
+          float pe = fast_exp2(__builtin_fmaf(s[c][t][r], sc, -m_new));
+          if constexpr (MASKED) pe = vis[c][t][r] ? pe : 0.f;
           psum += pe;
           pv[t * 4 + r] = pe;
         }
@@ -191,14 +215,62 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnP p) {
       f32x4 acc = o[dt];
       acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        bf16x8 vf = as_bf16x8(*reinterpret_cast<const u32x4*>(Vs + vt_lds_off(dt * 16 + fr, c * 4 + g)));
+      for (int c = 0; c < NC; ++c) {
+        bf16x8 vf = as_bf16x8(*reinterpret_cast<const u32x4*>(Vs + vt_lds_off<TK>(dt * 16 + fr, c * 4 + g)));
         acc = mfma16(vf, pf[c], acc);
       }
       o[dt] = acc;
     }
+  };
+  // smallest prefix limit among this wave's 16 rows (wave-uniform): a tile ending at or below it needs no masks
+  const int wave_lim1 = a.mode == VL_ATTN_CAUSAL ? min(a.kv_len, qb * 64 + wave * 16 + 1 + a.causal_off) : blk_lim1;
+
+  const int n_it = (n_tiles + KS - 1) / KS;                   // block-uniform trip count; a group past its last tile idles at the barriers
+  if (n_tiles > 0) load_tile(min(grp, n_tiles - 1));
+  for (int itg = 0; itg < n_it; ++itg) {
+    const int it = itg * KS + grp;
+    __syncthreads();  // previous tile's LDS reads are done
+    store_tile();
+    __syncthreads();
+    load_tile(min(it + KS, n_tiles - 1));                      // unconditional (clamped): a conditional load costs a full vmcnt drain
+    if (it >= n_tiles) continue;
+    const int key0 = tile_key0(it);
+
+    // a tile every row of this wave sees in full (all interior tiles of FULL / PREFIX, the tiles left of the diagonal of CAUSAL)
+    // skips the visibility arithmetic: the loop is VALU-issue bound (about 230 VALU + 17 transcendental instructions per tile
+    // against 16 MFMAs at head_dim 64), and the masks were 40 % of it
+    if (key0 + TK <= wave_lim1) tile_body(key0, std::false_type{});
+    else tile_body(key0, std::true_type{});
   }
 
+  if constexpr (KS > 1) {
+    // merge the groups' partial softmax states: lane-for-lane (every group holds the same (row, d) elements in the same registers)
+    __syncthreads();                                           // all tile reads done: the staging area becomes the merge area
+    if (grp > 0) {
+      float* mw = reinterpret_cast<float*>(smem + ((grp - 1) * 4 + wave) * MERGE_WAVE) + lane;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mw[(dt * 4 + r) * 64] = o[dt][r];
+      mw[DT * 4 * 64] = m_run;
+      mw[(DT * 4 + 1) * 64] = l_run;
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int j = 1; j < KS; ++j) {
+      const float* rw = reinterpret_cast<const float*>(smem + ((j - 1) * 4 + wave) * MERGE_WAVE) + lane;
+      const float m_o = rw[DT * 4 * 64], l_o = rw[(DT * 4 + 1) * 64];
+      const float m_new = fmaxf(m_run, m_o);
+      const float fa = fast_exp2(m_run - m_new), fb = fast_exp2(m_o - m_new);
+      m_run = m_new;
+      l_run = l_run * fa + l_o * fb;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[dt][r] = o[dt][r] * fa + rw[(dt * 4 + r) * 64] * fb;
+    }
+  }
   float l_tot = l_run + __shfl_xor(l_run, 16, 64);
   l_tot += __shfl_xor(l_tot, 32, 64);
   if (q_row < a.sq) {
@@ -398,8 +470,30 @@ extern "C" int vlaser_attn_prefill(const VlaserAttnArgs* a, vl_stream_t s) {
   VL_CHECK(a->sq > 0 && a->batch > 0, "vlaser_attn_prefill: empty");
   AttnP p; p.a = *a;
   dim3 grid((a->sq + 63) / 64, a->n_q_heads, a->batch);
-  if (a->head_dim == 128) hipLaunchKernelGGL(attn_prefill_kernel<128>, grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL(attn_prefill_kernel<64>, grid, dim3(256), 0, stream, p);
+  // tile / split choice, measured (tools/micro/attn_lab.py, profiles/r02k_attn.md): a 2-way in-workgroup key split pays only when
+  // the grid does not even reach one workgroup per CU (joint prefill: 72 workgroups, 11.4 -> 10.8 us); 128-key tiles only for the
+  // unmasked head_dim-64 case around one workgroup per CU (ViT, 1 tile: 23.9 -> 22.8 us); more registers per wave (a forced
+  // 4 waves / SIMD) and a 4-way split both lose everywhere
+  const long blocks = (long)grid.x * grid.y * grid.z;
+  int ks = blocks <= 192 ? 2 : 1;
+  const int tk = (a->head_dim == 64 && a->mode == VL_ATTN_FULL && blocks <= 512 && ks == 1) ? 128 : 64;
+  if (a->kv_len <= tk) ks = 1;
+#define VL_ATTN_LAUNCH(HD_, KS_, TK_)                                                                                       \
+  do {                                                                                                                      \
+    constexpr int tile = 2 * TK_ * HD_ * 2, merge = (KS_ - 1) * 4 * (HD_ / 16 * 4 + 2) * 256;                                \
+    constexpr int lds = KS_ * tile > merge ? KS_ * tile : merge;                                                            \
+    if (int rc = set_max_lds_once(attn_prefill_kernel<HD_, KS_, TK_>, lds)) return rc;                                      \
+    hipLaunchKernelGGL((attn_prefill_kernel<HD_, KS_, TK_>), grid, dim3(256 * KS_), lds, stream, p);                        \
+  } while (0)
+#define VL_ATTN_PICK(HD_)                                                                                                   \
+  do {                                                                                                                      \
+    if (ks == 2) VL_ATTN_LAUNCH(HD_, 2, 64);                                                                           \
+    else if (tk == 128) VL_ATTN_LAUNCH(HD_, 1, 128);                                                                        \
+    else VL_ATTN_LAUNCH(HD_, 1, 64);                                                                                        \
+  } while (0)
+  if (a->head_dim == 128) VL_ATTN_PICK(128); else VL_ATTN_PICK(64);
+#undef VL_ATTN_PICK
+#undef VL_ATTN_LAUNCH
   VL_LAUNCH_CHECK();
   return 0;
 }
