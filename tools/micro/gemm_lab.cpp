@@ -35,7 +35,11 @@ int main(int argc, char** argv) {
       {384, 2048, 1536, "llm qkv", VL_EPI_NONE}, {384, 17920, 1536, "llm gate/up", VL_EPI_SWIGLU}, {1025, 3072, 1024, "vit qkv", VL_EPI_NONE},
       {1025, 4096, 1024, "vit fc1", VL_EPI_BIAS_GELU}, {560, 17920, 1536, "sft gate/up", VL_EPI_NONE}, {560, 2048, 1536, "sft qkv", VL_EPI_NONE},
       {560, 8960, 1536, "sft dgrad wdown", VL_EPI_NONE}, {560, 1536, 2048, "sft dgrad qkv", VL_EPI_NONE}, {13 * 1025, 4096, 1024, "vit fc1 x13", VL_EPI_BIAS_GELU},
-      {3408, 37888, 3584, "8B gate/up", VL_EPI_SWIGLU}};
+      {3408, 37888, 3584, "8B gate/up", VL_EPI_SWIGLU},
+      // fixed cost vs per-K-step cost vs epilogue cost of a single-round grid (run with the filter "ksw")
+      {1025, 4096, 256, "ksw fc1 none", VL_EPI_NONE}, {1025, 4096, 512, "ksw fc1 none", VL_EPI_NONE}, {1025, 4096, 1024, "ksw fc1 none", VL_EPI_NONE},
+      {1025, 4096, 2048, "ksw fc1 none", VL_EPI_NONE}, {1025, 4096, 256, "ksw fc1 gelu", VL_EPI_BIAS_GELU}, {1025, 4096, 1024, "ksw fc1 gelu", VL_EPI_BIAS_GELU},
+      {1025, 4096, 1024, "ksw fc1 f32", VL_EPI_F32}};
   std::vector<Shape> pshapes = {{1025, 1024, 1024, "vit proj", 4}, {1025, 1024, 4096, "vit fc2", 4}, {384, 1536, 1536, "llm o", 3}, {384, 1536, 8960, "llm down", 7},
                                 {560, 1536, 8960, "sft down", 5}, {560, 1536, 17920, "sft dgrad gu", 10}};
   const int cfgs[] = {64, 128, 1100, 1200, 1300, 1440, 1500, 0};
@@ -44,7 +48,7 @@ int main(int argc, char** argv) {
   auto run = [&](const Shape& sh, int splits) {
     const int M = sh.M, N = sh.N, K = sh.K;
     unsigned short *x, *w[NL], *out, *ref, *bias; float* part = nullptr;
-    CK(hipMalloc(&x, (size_t)M * K * 2)); CK(hipMalloc(&out, (size_t)M * N * 2 + 64)); CK(hipMalloc(&ref, (size_t)M * N * 2 + 64)); CK(hipMalloc(&bias, (size_t)N * 2));
+    CK(hipMalloc(&x, (size_t)M * K * 2)); CK(hipMalloc(&out, (size_t)M * N * 4 + 64)); CK(hipMalloc(&ref, (size_t)M * N * 4 + 64)); CK(hipMalloc(&bias, (size_t)N * 2));
     if (splits) CK(hipMalloc(&part, (size_t)splits * M * N * 4 * 2));
     fill_bf16<<<1024, 256, 0, s>>>(x, (size_t)M * K, 1, 1.0f);
     fill_bf16<<<64, 256, 0, s>>>(bias, (size_t)N, 77, 0.5f);
@@ -84,7 +88,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < NL; ++i) CK(hipFree(w[i]));
   };
   const char* only = argc > 1 ? argv[1] : nullptr;
-  for (auto& sh : shapes) if (!only || strstr(sh.name, only)) run(sh, 0);
+  for (auto& sh : shapes) if (only ? strstr(sh.name, only) != nullptr : strncmp(sh.name, "ksw", 3) != 0) run(sh, 0);
   for (auto& sh : pshapes) if (!only || strstr(sh.name, only)) run(sh, sh.epi);
   return 0;
 }

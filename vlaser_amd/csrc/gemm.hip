@@ -37,6 +37,11 @@ __device__ __forceinline__ void epilogue(const VlaserGemmArgs& a, int m, int n0,
   }
   if constexpr (EPI == VL_EPI_F32) {
     float* o = reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n0;
+    if (n0 + 3 < a.N && (a.ldo & 1) == 0 && ((uintptr_t)a.out & 7) == 0) {      // 8-byte stores (the lm_head's N = 151674 rows are only 8-byte aligned)
+      *reinterpret_cast<f32x2_t*>(o) = f32x2_t{v[0], v[1]};
+      *reinterpret_cast<f32x2_t*>(o + 2) = f32x2_t{v[2], v[3]};
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (n0 + j < a.N) o[j] = v[j];
@@ -158,6 +163,190 @@ __device__ __forceinline__ void epilogue(const VlaserGemmArgs& a, int m, int n0,
   }
 }
 
+// QKV_ROPE for a whole wave tile: position ids, bias vectors and the cos / sin rows are requested as straight-line vector loads on
+// clamped rows (the per-fragment version pays two dependent L2 round trips per fragment behind the `m < M` branch: +4.5 us on the
+// joint prefill's 11 us qkv GEMM); only the stores are predicated.  Fragment pair (nt, nt+1) = RoPE halves d and d + 64.
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue_tile_rope(const VlaserGemmArgs& a, int m_w, int n_w, int fr, int fq, f32x4 (&acc)[NT][MT]) {
+  const bf16_t* bias = reinterpret_cast<const bf16_t*>(a.bias);
+  const bool fast = (n_w + NT * 16 <= a.N) && (((uintptr_t)bias & 7) == 0) && (((uintptr_t)a.rope_cos & 15) == 0) && (((uintptr_t)a.rope_sin & 15) == 0);
+  if (!fast) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt += 2) epilogue<VL_EPI_QKV_ROPE>(a, m_w + mt * 16 + fr, n_w + nt * 16 + fq * 4, acc[nt][mt], acc[nt + 1][mt]);
+    return;
+  }
+  constexpr int NP = NT / 2;
+  u32x2 b1[NP], b2[NP];
+  int pos[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) pos[mt] = a.pos_ids[min(m_w + mt * 16 + fr, a.M - 1)];
+#pragma unroll
+  for (int np = 0; np < NP; ++np) {
+    const int n0 = n_w + np * 32 + fq * 4;
+    b1[np] = *reinterpret_cast<const u32x2*>(bias + n0);
+    b2[np] = *reinterpret_cast<const u32x2*>(bias + n0 + 16);
+  }
+  const int nq = a.n_q_heads, nkv = a.n_kv_heads;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m_w + mt * 16 + fr;
+    const int mc = min(m, a.M - 1);
+    const int b = mc / a.tok_per_batch;
+    const int slot = a.slot_base + (mc - b * a.tok_per_batch);
+    f32x4 cs[NP], sn[NP];
+#pragma unroll
+    for (int np = 0; np < NP; ++np) {
+      const int p = (n_w + np * 32 + fq * 4) & 127, d = ((p >> 5) << 4) + (p & 15);
+      cs[np] = *reinterpret_cast<const f32x4*>(a.rope_cos + (size_t)pos[mt] * 64 + d);
+      sn[np] = *reinterpret_cast<const f32x4*>(a.rope_sin + (size_t)pos[mt] * 64 + d);
+    }
+#pragma unroll
+    for (int np = 0; np < NP; ++np) {
+      const int n0 = n_w + np * 32 + fq * 4;
+      const int head = n0 >> 7, p = n0 & 127, d = ((p >> 5) << 4) + (p & 15);
+      float x1[4], x2[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // q/k/v projections are bf16 Linear outputs in the reference: round once after bias
+        x1[j] = round_bf16(acc[2 * np][mt][j] + ((j & 1) ? bf16hi_to_f32(b1[np][j >> 1]) : bf16lo_to_f32(b1[np][j >> 1])));
+        x2[j] = round_bf16(acc[2 * np + 1][mt][j] + ((j & 1) ? bf16hi_to_f32(b2[np][j >> 1]) : bf16lo_to_f32(b2[np][j >> 1])));
+      }
+      if (head < nq + nkv) {
+        float o1[4], o2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o1[j] = x1[j] * cs[np][j] - x2[j] * sn[np][j];
+          o2[j] = x2[j] * cs[np][j] + x1[j] * sn[np][j];
+        }
+        bf16_t* dst = head < nq ? reinterpret_cast<bf16_t*>(a.q_out) + (size_t)mc * nq * 128 + head * 128
+                                : reinterpret_cast<bf16_t*>(a.k_cache) + (((size_t)b * nkv + (head - nq)) * a.s_max + slot) * 128;
+        if (m < a.M) {
+          *reinterpret_cast<u32x2*>(dst + d) = u32x2{pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3])};
+          *reinterpret_cast<u32x2*>(dst + d + 64) = u32x2{pack_bf16x2(o2[0], o2[1]), pack_bf16x2(o2[2], o2[3])};
+        }
+      } else if (m < a.M) {
+        bf16_t* vt = reinterpret_cast<bf16_t*>(a.vt_cache) + ((size_t)b * nkv + (head - nq - nkv)) * 128 * a.s_max + slot;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vt[(size_t)(d + j) * a.s_max] = f32_to_bf16(x1[j]);
+          vt[(size_t)(d + 64 + j) * a.s_max] = f32_to_bf16(x2[j]);
+        }
+      }
+    }
+  }
+}
+
+// VIT_QKV for a whole wave tile: bias vectors up front, branch-free math, predicated stores (see epilogue_tile).
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue_tile_vit_qkv(const VlaserGemmArgs& a, int m_w, int n_w, int fr, int fq, f32x4 (&acc)[NT][MT]) {
+  const bf16_t* bias = reinterpret_cast<const bf16_t*>(a.bias);
+  const bool fast = (n_w + NT * 16 <= a.N) && (((uintptr_t)bias & 7) == 0);
+  if (!fast) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) epilogue<VL_EPI_VIT_QKV>(a, m_w + mt * 16 + fr, n_w + nt * 16 + fq * 4, acc[nt][mt], acc[nt][mt]);
+    return;
+  }
+  u32x2 bv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const u32x2*>(bias + n_w + nt * 16 + fq * 4);
+  const int C = a.vit_heads * 64;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m_w + mt * 16 + fr;
+    const int mc = min(m, a.M - 1);
+    const int t = mc / a.vit_seq, sq = mc - t * a.vit_seq;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n0 = n_w + nt * 16 + fq * 4;
+      const int which = n0 / C, c = n0 - which * C, h = c >> 6, d = c & 63;
+      float r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r[j] = round_bf16(acc[nt][mt][j] + ((j & 1) ? bf16hi_to_f32(bv[nt][j >> 1]) : bf16lo_to_f32(bv[nt][j >> 1])));
+        if (which == 0) r[j] *= a.q_scale;
+      }
+      if (m >= a.M) continue;
+      if (which < 2) {
+        bf16_t* dst = reinterpret_cast<bf16_t*>(which == 0 ? a.vq : a.vk) + (((size_t)t * a.vit_heads + h) * a.vit_seq_pad + sq) * 64 + d;
+        *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+      } else {
+        bf16_t* vt = reinterpret_cast<bf16_t*>(a.vvt) + (((size_t)t * a.vit_heads + h) * 64 + d) * a.vit_seq_pad + sq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vt[(size_t)j * a.vit_seq_pad] = f32_to_bf16(r[j]);
+      }
+    }
+  }
+}
+
+// Whole wave tile at once for the bf16-row epilogues (NONE / BIAS / BIAS_GELU / BIAS_LS_RES / RES).  The per-fragment epilogue
+// above sits behind lane-divergent `m < M` / `n < N` branches with its bias / residual loads inside them: hipcc turns every
+// fragment into its own basic block with a load and a full `s_waitcnt` (measured on the ViT fc1 shape: the BIAS_GELU epilogue cost
+// 7.7 us of a 24.5 us launch, one L2 round trip per fragment).  Here the common case -- the tile's columns all inside N, rows
+// clamped instead of branched on -- is straight-line: NT bias / layer-scale vectors and MT x NT residual vectors are requested
+// up front as 8-byte loads, the math is branch-free, only the stores are predicated.
+template <int EPI, int MT, int NT>
+__device__ __forceinline__ void epilogue_tile(const VlaserGemmArgs& a, int m_w, int n_w, int fr, int fq, f32x4 (&acc)[NT][MT]) {
+  constexpr bool HAS_BIAS = (EPI == VL_EPI_BIAS || EPI == VL_EPI_BIAS_GELU || EPI == VL_EPI_BIAS_LS_RES);
+  constexpr bool HAS_RES = (EPI == VL_EPI_BIAS_LS_RES || EPI == VL_EPI_RES);
+  const bf16_t* bias = reinterpret_cast<const bf16_t*>(a.bias);
+  const bf16_t* ls = reinterpret_cast<const bf16_t*>(a.ls);
+  const bf16_t* res = reinterpret_cast<const bf16_t*>(a.res);
+  bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
+  bool fast = (n_w + NT * 16 <= a.N) && ((a.ldo & 3) == 0) && (((uintptr_t)out & 7) == 0);
+  if constexpr (HAS_BIAS) fast = fast && (((uintptr_t)bias & 7) == 0);
+  if constexpr (EPI == VL_EPI_BIAS_LS_RES) fast = fast && (((uintptr_t)ls & 7) == 0);
+  if constexpr (HAS_RES) fast = fast && (((uintptr_t)res & 7) == 0);
+  if (!fast) {                                             // ragged right edge / unaligned operands: per-fragment path
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) epilogue<EPI>(a, m_w + mt * 16 + fr, n_w + nt * 16 + fq * 4, acc[nt][mt], acc[nt][mt]);
+    return;
+  }
+  u32x2 bv[NT], lv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n_w + nt * 16 + fq * 4;
+    if constexpr (HAS_BIAS) bv[nt] = *reinterpret_cast<const u32x2*>(bias + n);
+    if constexpr (EPI == VL_EPI_BIAS_LS_RES) lv[nt] = *reinterpret_cast<const u32x2*>(ls + n);
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m_w + mt * 16 + fr;
+    const size_t row = (size_t)min(m, a.M - 1) * a.ldo;     // clamped: rows past M compute on the last row and are not stored
+    u32x2 rv[NT];
+    if constexpr (HAS_RES) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) rv[nt] = *reinterpret_cast<const u32x2*>(res + row + n_w + nt * 16 + fq * 4);
+    }
+    u32x2 pk[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = acc[nt][mt][j];
+        if constexpr (HAS_BIAS) x += (j & 1) ? bf16hi_to_f32(bv[nt][j >> 1]) : bf16lo_to_f32(bv[nt][j >> 1]);
+        if constexpr (EPI == VL_EPI_BIAS_GELU) x = gelu_erf(x);
+        if constexpr (EPI == VL_EPI_BIAS_LS_RES)
+          x = ((j & 1) ? bf16hi_to_f32(rv[nt][j >> 1]) : bf16lo_to_f32(rv[nt][j >> 1])) +
+              ((j & 1) ? bf16hi_to_f32(lv[nt][j >> 1]) : bf16lo_to_f32(lv[nt][j >> 1])) * x;
+        if constexpr (EPI == VL_EPI_RES) x += (j & 1) ? bf16hi_to_f32(rv[nt][j >> 1]) : bf16lo_to_f32(rv[nt][j >> 1]);
+        r[j] = x;
+      }
+      pk[nt] = u32x2{pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+    }
+    if (m < a.M) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<u32x2*>(out + row + n_w + nt * 16 + fq * 4) = pk[nt];
+    }
+  }
+}
+
 template <int EPI, int BM>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   constexpr int PD = GEMM_PD;                           // K-tiles in flight (register stages)
@@ -273,6 +462,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     if (ea.out) ea.out = reinterpret_cast<char*>(ea.out) + (size_t)bz * a.o_bs * (EPI == VL_EPI_F32 ? 4 : 2);
     if (ea.out_f32) ea.out_f32 += (size_t)bz * a.o_bs;
     if (ea.res) ea.res = reinterpret_cast<const char*>(ea.res) + (size_t)bz * a.o_bs * 2;
+  }
+  if constexpr (EPI == VL_EPI_NONE || EPI == VL_EPI_BIAS || EPI == VL_EPI_BIAS_GELU || EPI == VL_EPI_BIAS_LS_RES || EPI == VL_EPI_RES) {
+    epilogue_tile<EPI, MT, NT>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc);
+    return;
+  }
+  if constexpr (EPI == VL_EPI_QKV_ROPE) {
+    epilogue_tile_rope<MT, NT>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc);
+    return;
+  }
+  if constexpr (EPI == VL_EPI_VIT_QKV) {
+    epilogue_tile_vit_qkv<MT, NT>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc);
+    return;
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -399,6 +600,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
     if (ea.out) ea.out = reinterpret_cast<char*>(ea.out) + (size_t)bz * a.o_bs * (EPI == VL_EPI_F32 ? 4 : 2);
     if (ea.out_f32) ea.out_f32 += (size_t)bz * a.o_bs;
     if (ea.res) ea.res = reinterpret_cast<const char*>(ea.res) + (size_t)bz * a.o_bs * 2;
+  }
+  if constexpr (EPI == VL_EPI_NONE || EPI == VL_EPI_BIAS || EPI == VL_EPI_BIAS_GELU || EPI == VL_EPI_BIAS_LS_RES || EPI == VL_EPI_RES) {
+    epilogue_tile<EPI, MT, NT>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc);
+    return;
+  }
+  if constexpr (EPI == VL_EPI_QKV_ROPE) {
+    epilogue_tile_rope<MT, NT>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc);
+    return;
+  }
+  if constexpr (EPI == VL_EPI_VIT_QKV) {
+    epilogue_tile_vit_qkv<MT, NT>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc);
+    return;
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
