@@ -354,6 +354,7 @@ def test_checkpoint_resume_is_bit_identical(golden_model, tmp_path):
     c = mk(); c.load_checkpoint(str(tmp_path / 'ckpt'))
     assert c.step_count == 2
     c.step(pvs[2], rows[2][None], labs[2][None], total_steps=10)
+    a.wait_optimizer(); c.wait_optimizer()          # the last AdamW is still in flight on the optimizer stream
     assert torch.equal(a.fp.p, c.fp.p) and torch.equal(a.master, c.master) and torch.equal(a.m, c.m) and torch.equal(a.v, c.v)
 
 

@@ -563,10 +563,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(bf16_t* __restrict__ p, floa
     if (max_norm > 0.f && gn > max_norm) gscale *= max_norm / (gn + 1e-6f);
   }
   const long long n4 = n >> 2;                 // 4 elements per thread per iteration (16-byte fp32 vectors, 8-byte bf16 vectors)
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    const u32x2 gv = *reinterpret_cast<const u32x2*>(g + 4 * i);
-    f32x4 mv = *reinterpret_cast<const f32x4*>(m + 4 * i), vv = *reinterpret_cast<const f32x4*>(v + 4 * i),
-          wv = *reinterpret_cast<const f32x4*>(master + 4 * i);
+  // every byte is touched exactly once per step: non-temporal loads / stores keep the 28 B/parameter stream out of L2's way
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const u32x2 gv = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(g + 4 * i));
+    f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + 4 * i)), vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + 4 * i)),
+          wv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(master + 4 * i));
     const float gr[4] = {bf16lo_to_f32(gv[0]) * gscale, bf16hi_to_f32(gv[0]) * gscale, bf16lo_to_f32(gv[1]) * gscale, bf16hi_to_f32(gv[1]) * gscale};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -574,13 +575,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(bf16_t* __restrict__ p, floa
       vv[j] = b2 * vv[j] + (1.0f - b2) * gr[j] * gr[j];
       wv[j] = wv[j] * decay - step * (mv[j] / (sqrtf(vv[j]) * rbc2 + eps));
     }
-    *reinterpret_cast<f32x4*>(m + 4 * i) = mv;
-    *reinterpret_cast<f32x4*>(v + 4 * i) = vv;
-    *reinterpret_cast<f32x4*>(master + 4 * i) = wv;
-    *reinterpret_cast<u32x2*>(p + 4 * i) = u32x2{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3])};
+    __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(m + 4 * i));
+    __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v + 4 * i));
+    __builtin_nontemporal_store(wv, reinterpret_cast<f32x4*>(master + 4 * i));
+    *reinterpret_cast<u32x2*>(p + 4 * i) = u32x2{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3])};      // the next forward reads these: default policy
   }
   if (blockIdx.x == 0)
-    for (long long i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+    for (long long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {
       const float gr = bf16_to_f32(g[i]) * gscale;
       const float mi = b1 * m[i] + (1.0f - b1) * gr, vi = b2 * v[i] + (1.0f - b2) * gr * gr;
       m[i] = mi; v[i] = vi;
@@ -589,12 +590,26 @@ __global__ __launch_bounds__(256) void adamw_kernel(bf16_t* __restrict__ p, floa
       p[i] = f32_to_bf16(w);
     }
 }
+// Grid: ONE 256-thread workgroup per CU walking the arrays grid-stride.  Measured on a 198 M-parameter bucket (tools/micro/adamw_lab.py):
+// 4096 workgroups 4.4-4.5 TB/s, 1024 4.4, 512 5.2, 256 5.5-5.7 (= 0.9 of the 6.3 TB/s a copy reaches), 192 5.1, 128 3.7; 512- and
+// 1024-thread workgroups lose; the seven streams thrash less with a narrow window of addresses in flight.
+static int adamw_grid_cap() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    int n = 0;
+    cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cus[dev];
+}
 extern "C" int vlaser_adamw(void* p, float* master, float* m, float* v, const void* g, long long n, float lr, float b1, float b2, float eps, float wd,
                             float gscale, int step, vl_stream_t s) {
   VL_CHECK(p && master && m && v && g && n > 0 && step >= 1, "vlaser_adamw: bad args");
   VL_CHECK((((uintptr_t)p | (uintptr_t)g) & 7) == 0 && (((uintptr_t)master | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "vlaser_adamw: alignment");
   const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
-  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  const int cap = adamw_grid_cap();
+  const int blocks = (int)((n + 1023) / 1024 < cap ? (n + 1023) / 1024 : cap);
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (bf16_t*)p, master, m, v, (const bf16_t*)g, n, lr, b1, b2, eps, wd,
                      gscale, bc1, bc2, (const float*)nullptr, 0.f);
   VL_LAUNCH_CHECK();
@@ -605,7 +620,8 @@ extern "C" int vlaser_adamw_clipped(void* p, float* master, float* m, float* v, 
   VL_CHECK(p && master && m && v && g && gnorm2 && n > 0 && step >= 1, "vlaser_adamw_clipped: bad args");
   VL_CHECK((((uintptr_t)p | (uintptr_t)g) & 7) == 0 && (((uintptr_t)master | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "vlaser_adamw_clipped: alignment");
   const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
-  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  const int cap = adamw_grid_cap();
+  const int blocks = (int)((n + 1023) / 1024 < cap ? (n + 1023) / 1024 : cap);
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (bf16_t*)p, master, m, v, (const bf16_t*)g, n, lr, b1, b2, eps, wd,
                      gscale, bc1, bc2, gnorm2, max_norm);
   VL_LAUNCH_CHECK();

@@ -119,6 +119,7 @@ class SFTModel:
         self.recompute = recompute
         self.ag_events = {}                       # bucket -> event of its last parameter all-gather (data parallel only)
         self.overlap_allgather = os.environ.get('VLASER_SFT_NO_AG_OVERLAP') != '1'
+        self.overlap_optimizer = os.environ.get('VLASER_SFT_NO_OPT_OVERLAP') != '1'
         self.step_count = 0
         self.img_context_token_id = cfg.img_context_token_id
         self.max_tiles = max_tiles
@@ -128,6 +129,7 @@ class SFTModel:
     # ------------------------------------------------------------------ parameters
     def load_state_dict(self, sd):
         cfg, llm, dev = self.cfg, self.llm, self.device
+        self.wait_optimizer()
         self.vit = VitEngine(sd, cfg, dev, max_tiles=self.max_tiles)     # frozen (freeze_backbone True)
         self.frozen_sd = {k: v.detach().to('cpu') for k, v in sd.items() if k.startswith('vision_model.')}      # for save_pretrained
         H, I, V = llm.hidden_size, llm.intermediate_size, llm.vocab_size
@@ -242,6 +244,9 @@ class SFTModel:
         self._alloc_projector_ws()
         self.comm_stream = torch.cuda.Stream(device=dev) if self.dp_active else None
         self.aux_stream = torch.cuda.Stream(device=dev)        # weight transposes overlap the next step's forward
+        # single rank: AdamW (HBM-bound, a third of a step) runs on its own stream bucket by bucket in the order the next forward
+        # consumes the parameters, so the next step's frozen-ViT / early-layer GEMMs (MFMA-bound) overlap it
+        self.opt_stream = torch.cuda.Stream(device=dev)
         self.wT_ready = None
 
     def _alloc_projector_ws(self):
@@ -267,6 +272,13 @@ class SFTModel:
     def _h2d(self, t):
         """Small host index tensor -> device through a pinned staging copy (`non_blocking`: the host does not wait for the stream)."""
         return t.contiguous().pin_memory().to(self.device, non_blocking=True)
+
+    def wait_optimizer(self):
+        """Make the current stream wait for parameter updates / all-gathers still in flight on the side streams."""
+        if getattr(self, 'opt_stream', None) is not None:
+            torch.cuda.current_stream().wait_stream(self.opt_stream)
+        if self.dp_active and getattr(self, 'comm_stream', None) is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     def _wait_params(self, b):
         """Block the compute stream until bucket b's parameters of the current step have been all-gathered."""
@@ -379,9 +391,6 @@ class SFTModel:
         Lyr = llm.num_hidden_layers
         ids = self._h2d(ids_h)
         pos = self.pos_all[:S]
-        # every gradient tensor is fully overwritten by its wgrad / column-sum kernel each step, except the embedding rows
-        # (scatter-add over the text tokens): only that slice is cleared (466 MB instead of the whole 3.6 GB buffer)
-        gv['embed'].zero_()
         # ---- vision tower (frozen) + trainable projector (mlp1), with the intermediates mlp1's backward needs
         T = pixel_values.shape[0]
         self._grow_tiles(T)
@@ -394,6 +403,10 @@ class SFTModel:
         vit_w.m0w, vit_w.m0b = v['mlp1.m0w'], v['mlp1.m0b']       # the projector weights are the trainable views
         vit_w.m1w, vit_w.m1b, vit_w.m3w, vit_w.m3b = v['mlp1.m1w'], v['mlp1.m1b'], v['mlp1.m3w'], v['mlp1.m3b']
         self._wait_params(len(self.buckets) - 1)                   # embed + projector bucket (the projector runs inside vit_w.forward)
+        # every gradient tensor is fully overwritten by its wgrad / column-sum kernel each step, except the embedding rows
+        # (scatter-add over the text tokens): only that slice is cleared (466 MB instead of the whole 3.6 GB buffer) -- after the
+        # wait above: the previous step's AdamW may still be reading this bucket's gradients on the optimizer stream
+        gv['embed'].zero_()
         vit_w.forward(pv)                                          # leaves the last hidden state in vit_w.h
         nt = T * cfg.num_image_token
         C1 = cfg.vision.hidden_size
@@ -558,13 +571,34 @@ class SFTModel:
                 ops.sumsq(self.fp.g[s_lo:s_hi], self.gnorm2, self.sumsq_ws)
         if self.dp_active:
             torch.distributed.all_reduce(self.gnorm2, group=self.pg)
-        for (s_lo, s_hi, per), o in zip(self.shards, self.shard_off):
+        gnorm = self.gnorm2.sqrt()                                  # device tensor: reading it is the caller's (only) sync
+
+        def adamw_bucket(b):
+            (s_lo, s_hi, per), o = self.shards[b], self.shard_off[b]
             if s_hi > s_lo:
                 n = s_hi - s_lo
                 # clip factor max_norm / (||g|| + 1e-6) resolved inside the kernel from the device-resident squared norm
                 ops.adamw_clipped(self.fp.p[s_lo:s_hi], self.master[o:o + n], self.m[o:o + n], self.v[o:o + n], self.fp.g[s_lo:s_hi], lr, self.betas[0],
                                   self.betas[1], self.eps, self.wd, 1.0, self.gnorm2, self.max_grad_norm, self.step_count)
-        gnorm = self.gnorm2.sqrt()                                  # device tensor: reading it is the caller's (only) sync
+
+        if not self.dp_active and self.overlap_optimizer:
+            # pipelined with the NEXT step: bucket by bucket on `opt_stream`, embed + projector first, lm_head last; the next forward
+            # waits per bucket (`_wait_params`), its backward for the W^T refresh queued behind the last bucket (`wT_ready`).  The
+            # update is therefore still in flight when this returns: `wait_optimizer()` before touching parameter buffers directly.
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.opt_stream):
+                self.opt_stream.wait_event(ev)
+                for b in reversed(range(len(self.buckets))):
+                    adamw_bucket(b)
+                    self.ag_events[b] = torch.cuda.Event()
+                    self.ag_events[b].record()
+                self._refresh_transposes_now()
+                self.wT_ready = torch.cuda.Event()
+                self.wT_ready.record()
+            return gnorm
+        for b in range(len(self.buckets)):
+            adamw_bucket(b)
         if self.dp_active:
             # ZeRO-1: all-gather the updated bf16 parameters bucket by bucket on the comm stream, in the order the NEXT forward
             # consumes them (embed + projector first, lm_head last); the forward waits per bucket (`_wait_params`), so the
@@ -722,8 +756,7 @@ class SFTModel:
         os.makedirs(path, exist_ok=True)
         if self.rank == 0:
             self.save_pretrained(path)
-        if self.dp_active:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.wait_optimizer()
         torch.save({'step_count': self.step_count, 'world': self.world, 'rank': self.rank, 'shards': self.shards, 'lr': self.lr, 'betas': self.betas,
                     'eps': self.eps, 'weight_decay': self.wd, 'master': self.master.cpu(), 'exp_avg': self.m.cpu(), 'exp_avg_sq': self.v.cpu()},
                    os.path.join(path, f'optimizer_rank{self.rank:05d}_of_{self.world:05d}.pt'))
@@ -732,6 +765,7 @@ class SFTModel:
         """Weights through `load_hf_checkpoint` (key names unchanged), then this rank's optimizer shard; the bf16 parameters are
         re-derived from the fp32 masters so the resumed run continues bit for bit."""
         from .config import load_hf_checkpoint
+        self.wait_optimizer()
         _, sd = load_hf_checkpoint(path)
         self.load_state_dict(sd)
         st = torch.load(os.path.join(path, f'optimizer_rank{self.rank:05d}_of_{self.world:05d}.pt'), map_location='cpu', weights_only=False)
@@ -755,8 +789,7 @@ class SFTModel:
 
     # ------------------------------------------------------------------ export (HF key names, un-packed layouts)
     def state_dict(self):
-        if self.dp_active:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)      # pending parameter all-gathers
+        self.wait_optimizer()                                              # pending parameter updates / all-gathers
         llm = self.llm
         v = self.fp.view
         nq, nkv, hd = llm.num_attention_heads, llm.num_key_value_heads, llm.head_dim
