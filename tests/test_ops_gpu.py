@@ -445,8 +445,10 @@ def test_gemm_qkv_rope_small_tiles(ops, bm):
     close(vtc[:, :, :, :S], v.view(B, S, nkv, 128).permute(0, 2, 3, 1), name='vT')
 
 
-@pytest.mark.parametrize('M,N,K,S', [(385, 1536, 8960, 7), (1025, 1024, 4096, 4), (100, 1024, 1024, 1)])
+@pytest.mark.parametrize('M,N,K,S', [(385, 1536, 8960, 7), (1025, 1024, 4096, 4), (100, 1024, 1024, 1), (130, 3584, 3584, 2), (64, 1536, 1536, 3),
+                                     (50, 2048, 1024, 2), (33, 3584, 3584, 7)])
 def test_gemm_splitk_reduce_norm(ops, M, N, K, S):
+    # widths 1024 / 1536 / 3584 take the exact-shape seam kernels (all loads up front), 2048 and 3584 x 7 slabs the generic one
     from vlaser_amd import _lib as L
     x, w = rnd(M, K), rnd(N, K, std=0.03)
     part = torch.zeros(S, M, N, dtype=torch.float32, device='cuda')
