@@ -357,60 +357,89 @@ extern "C" int vlaser_small_linear(const float* x, const void* w, const void* b,
 // vla_euler: h = bf16(h_in + sum partials); y = rmsnorm(h) (expert final norm, joint_model.py:804-808);
 // vel = Wd y + bd (pizero_internvl.py:911); action += dt * vel (:912); optional clamp on the last step (:927-932).
 // One block per row m (<=16 rows); 256 threads.
+// One thread = 8 consecutive columns; every load of the row (residual, up to 8 slabs, norm weight, the adim decoder rows) is issued
+// up front in straight-line code, then two block reductions (sum of squares; the adim dot products).  The first version walked the
+// row 256 columns at a time with scalar loads behind a runtime slab count: 6 dependent round trips + a scalar decoder loop = 11.6 us
+// per Euler step for a few KB of work.
+template <int ADIM, bool HASP>
 __global__ __launch_bounds__(256) void vla_euler_kernel(const bf16_t* __restrict__ h_in, const float* __restrict__ partials, int n_partials,
                                                         int M, const bf16_t* __restrict__ norm_w, float eps, const bf16_t* __restrict__ wd,
                                                         const bf16_t* __restrict__ bd, float* __restrict__ action, int Wd, int adim, float dt,
                                                         float clip, int do_clip, float* __restrict__ vel_out) {
-  __shared__ float ybuf[2048];
-  __shared__ float red[4];
+  __shared__ float red[4][ADIM + 1];
   const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float ssq = 0.f;
-  for (int c = threadIdx.x; c < Wd; c += 256) {
-    float v = bf16_to_f32(h_in[(size_t)m * Wd + c]);
-    {
-      float t[12];
-      int s = 0;
-      for (; s + 12 <= n_partials; s += 12) {
+  const bool on = (int)threadIdx.x * 8 < Wd;
+  const int c = on ? threadIdx.x * 8 : 0;                  // idle threads (Wd < 2048) shadow column 0 and contribute zeros
+  const size_t off = (size_t)m * Wd + c, slab = (size_t)M * Wd;
+  const u32x4 hv = ld_global_16(h_in + off);
+  const u32x4 nw = ld_global_16(norm_w + c);
+  f32x4 q[16];
+  if constexpr (HASP) {
 #pragma unroll
-        for (int u = 0; u < 12; ++u) t[u] = partials[((size_t)(s + u) * M + m) * Wd + c];
-#pragma unroll
-        for (int u = 0; u < 12; ++u) v += t[u];
-      }
-#pragma unroll
-      for (int u = 0; u < 12; ++u) t[u] = (s + u < n_partials) ? partials[((size_t)(s + u) * M + m) * Wd + c] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 12; ++u) v += t[u];
+    for (int u = 0; u < 8; ++u) {
+      const float* pp = partials + off + (size_t)min(u, n_partials - 1) * slab;       // clamped, unconditional (n_partials >= 1 here)
+      q[2 * u] = *reinterpret_cast<const f32x4*>(pp);
+      q[2 * u + 1] = *reinterpret_cast<const f32x4*>(pp + 4);
     }
-    v = round_bf16(v);
-    ybuf[c] = v;
-    ssq += v * v;
   }
-  ssq = wave_sum(ssq);
-  if (lane == 0) red[wave] = ssq;
-  __syncthreads();
-  const float rs = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)Wd + eps);
-  for (int c = threadIdx.x; c < Wd; c += 256) ybuf[c] = round_bf16(round_bf16(ybuf[c] * rs) * bf16_to_f32(norm_w[c]));
-  __syncthreads();
-  // decoder: adim (<= 16) outputs, one wave-strided dot each
-  for (int j = wave; j < adim; j += 4) {
-    float acc = 0.f;
-    for (int c = lane; c < Wd; c += 64) acc += ybuf[c] * bf16_to_f32(wd[j * Wd + c]);
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      const float vel = round_bf16(acc + bf16_to_f32(bd[j]));
-      float av = action[m * adim + j] + dt * vel;
-      if (do_clip) av = fminf(fmaxf(av, -clip), clip);
-      action[m * adim + j] = av;
-      if (vel_out) vel_out[m * adim + j] = vel;
+  u32x4 wv[ADIM];
+#pragma unroll
+  for (int j = 0; j < ADIM; ++j) wv[j] = ld_global_16(wd + (size_t)min(j, adim - 1) * Wd + c);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[2 * j] = bf16lo_to_f32(hv[j]); v[2 * j + 1] = bf16hi_to_f32(hv[j]); }
+  float sl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (HASP) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool use = u < n_partials;                     // select, not multiply: clamped duplicates must not count
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { sl[j] += use ? q[2 * u][j] : 0.f; sl[4 + j] += use ? q[2 * u + 1][j] : 0.f; }
     }
+  }
+  float ssq = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { v[j] = on ? round_bf16(v[j] + sl[j]) : 0.f; ssq += v[j] * v[j]; }
+  ssq = wave_sum(ssq);
+  if (lane == 0) red[wave][ADIM] = ssq;
+  __syncthreads();
+  const float rs = rsqrtf((red[0][ADIM] + red[1][ADIM] + red[2][ADIM] + red[3][ADIM]) / (float)Wd + eps);
+  float y[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    y[2 * j] = round_bf16(round_bf16(v[2 * j] * rs) * bf16lo_to_f32(nw[j]));
+    y[2 * j + 1] = round_bf16(round_bf16(v[2 * j + 1] * rs) * bf16hi_to_f32(nw[j]));
+  }
+#pragma unroll
+  for (int j = 0; j < ADIM; ++j) {
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc += y[2 * e] * bf16lo_to_f32(wv[j][e]) + y[2 * e + 1] * bf16hi_to_f32(wv[j][e]);
+    acc = wave_sum(acc);
+    if (lane == 0) red[wave][j] = acc;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < adim) {
+    const int j = threadIdx.x;
+    const float vel = round_bf16(red[0][j] + red[1][j] + red[2][j] + red[3][j] + bf16_to_f32(bd[j]));
+    float av = action[m * adim + j] + dt * vel;
+    if (do_clip) av = fminf(fmaxf(av, -clip), clip);
+    action[m * adim + j] = av;
+    if (vel_out) vel_out[m * adim + j] = vel;
   }
 }
 extern "C" int vlaser_vla_euler(const void* h_in, const float* partials, int n_partials, int M, const void* norm_w, float eps,
                                 const void* wd, const void* bd, float* action, int Wd, int adim, float dt, float clip, int do_clip,
                                 float* vel_out, vl_stream_t s) {
-  VL_CHECK(h_in && norm_w && wd && bd && action && M > 0 && Wd <= 2048, "vlaser_vla_euler: bad args");
-  hipLaunchKernelGGL(vla_euler_kernel, dim3(M), dim3(256), 0, (hipStream_t)s, (const bf16_t*)h_in, partials, n_partials, M,
-                     (const bf16_t*)norm_w, eps, (const bf16_t*)wd, (const bf16_t*)bd, action, Wd, adim, dt, clip, do_clip, vel_out);
+  VL_CHECK(h_in && norm_w && wd && bd && action && M > 0 && Wd <= 2048 && Wd % 8 == 0, "vlaser_vla_euler: bad args");
+  VL_CHECK(n_partials >= 0 && n_partials <= 8 && (n_partials == 0 || partials) && adim >= 1 && adim <= 16,
+           "vlaser_vla_euler: 0..8 partial slabs, action_dim <= 16 (got %d, %d)", n_partials, adim);
+#define VL_EULER(AD_, HP_)                                                                                                          \
+  hipLaunchKernelGGL((vla_euler_kernel<AD_, HP_>), dim3(M), dim3(256), 0, (hipStream_t)s, (const bf16_t*)h_in, partials, n_partials, M, \
+                     (const bf16_t*)norm_w, eps, (const bf16_t*)wd, (const bf16_t*)bd, action, Wd, adim, dt, clip, do_clip, vel_out)
+  if (adim <= 8) { if (n_partials > 0) VL_EULER(8, true); else VL_EULER(8, false); }
+  else { if (n_partials > 0) VL_EULER(16, true); else VL_EULER(16, false); }
+#undef VL_EULER
   VL_LAUNCH_CHECK();
   return 0;
 }
