@@ -39,7 +39,8 @@ int main(int argc, char** argv) {
       // fixed cost vs per-K-step cost vs epilogue cost of a single-round grid (run with the filter "ksw")
       {1025, 4096, 256, "ksw fc1 none", VL_EPI_NONE}, {1025, 4096, 512, "ksw fc1 none", VL_EPI_NONE}, {1025, 4096, 1024, "ksw fc1 none", VL_EPI_NONE},
       {1025, 4096, 2048, "ksw fc1 none", VL_EPI_NONE}, {1025, 4096, 256, "ksw fc1 gelu", VL_EPI_BIAS_GELU}, {1025, 4096, 1024, "ksw fc1 gelu", VL_EPI_BIAS_GELU},
-      {1025, 4096, 1024, "ksw fc1 f32", VL_EPI_F32}};
+      {1025, 4096, 1024, "ksw fc1 f32", VL_EPI_F32}, {384, 17920, 1536, "ksw gu none", VL_EPI_NONE}, {384, 17920, 1536, "ksw gu swiglu", VL_EPI_SWIGLU},
+      {384, 17920, 512, "ksw gu none", VL_EPI_NONE}, {384, 17920, 512, "ksw gu swiglu", VL_EPI_SWIGLU}};
   std::vector<Shape> pshapes = {{1025, 1024, 1024, "vit proj", 4}, {1025, 1024, 4096, "vit fc2", 4}, {384, 1536, 1536, "llm o", 3}, {384, 1536, 8960, "llm down", 7},
                                 {560, 1536, 8960, "sft down", 5}, {560, 1536, 17920, "sft dgrad gu", 10}};
   const int cfgs[] = {64, 128, 1100, 1200, 1300, 1440, 1500, 0};
