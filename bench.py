@@ -507,8 +507,9 @@ def qa8b_bench(local):
 def _pmc_traffic():
     """HBM bytes per launch of the dominant kernel from hardware counters.  rocprofv3 --pmc cannot run under torch on this
     image, so the counters are collected by the torch-free harness tools/pmc/skinny_pmc.cpp on the same kernel and shape
-    (profiles/r01g_pmc_dominant_kernel.md has the commands and the gfx950 FETCH_SIZE correction); None if absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01g_pmc_dominant_kernel.json')
+    (profiles/r02o_pmc_dominant_kernel.md has the commands and the gfx950 FETCH_SIZE correction; re-collected whenever skinny.hip
+    changes); None if absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02o_pmc_dominant_kernel.json')
     try:
         return json.load(open(path))['traffic_bytes_per_launch']
     except (OSError, KeyError, ValueError):
