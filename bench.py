@@ -455,7 +455,7 @@ def qa_bench(local):
             ts.append((time.perf_counter() - t0) / 3)
         out[f'batch{B}'] = {'prefill_ms': round(ts[0] * 1e3, 2), 'decode_tokens_per_s': round(B * 32 / (ts[1] - ts[0]), 1),
                             'decode_ms_per_step': round((ts[1] - ts[0]) / 32 * 1e3, 3)}
-    out['config'] = 'Vlaser-2B, 1 tile + 256-token prompt (S=560), greedy, 32 new tokens; prefill_ms = ViT + prefill + first token; eager launches (no graph)'
+    out['config'] = 'Vlaser-2B, 1 tile + 256-token prompt (S=560), greedy, 32 new tokens; prefill_ms = ViT + prefill + first token; decode steps replayed from one HIP graph (device-resident slot / key-count state)'
     del m
     torch.cuda.empty_cache()
     return out

@@ -138,7 +138,7 @@ typedef struct {
   /* VL_SK_QKV_ROPE (same meaning as in VlaserGemmArgs) */
   void* q_out; void* k_cache; void* vt_cache;
   const float* rope_cos; const float* rope_sin; const int32_t* pos_ids;
-  int n_q_heads, n_kv_heads, s_max, tok_per_batch, slot_base;
+  int n_q_heads, n_kv_heads, s_max, tok_per_batch, slot_base;   /* slot_base < 0: cache slot of row m = pos_ids[m] (read on the device: graph-replayable decode) */
   /* VL_PRO_ATTN: x[m = b*nq+tok][h*128+d] = sum_s o_s e^(m_s-M) / sum_s l_s e^(m_s-M) */
   const float* attn_m; const float* attn_l; const float* attn_o; int attn_splits, attn_group, attn_nq;
   unsigned long long* dbg; /* optional: per-block timestamps [grid][8] (wall_clock64, 100 MHz) for kernel tuning */

@@ -91,6 +91,26 @@ def test_logits_loss_topk(vlm, g56, golden_model):
     assert abs(out2.loss.item() - float(g56['sft_loss'])) < 5e-3
 
 
+def test_graph_decode_equals_eager_decode(vlm, g56, golden_model):
+    """Uniform batches replay one captured decode step (device-resident slot / visible-key state): the ids must equal the eager step-by-step
+    decode's, the logits agree to bf16 noise (the key-chunk schedule is sized for the final length instead of the current one), a second
+    call replays the cached graph, and a batch of two equal prompts gives two equal rows."""
+    from vlaser_amd.internvl_chat import InternVLChatModel
+    cfg, _, sd = golden_model
+    pv, ids = _pv(0), torch.from_numpy(g56['input_ids'])
+    eager = InternVLChatModel(cfg, max_seq_len=512, max_batch=2, decode_graph=False)
+    eager.load_state_dict(sd, strict=False)
+    eager.img_context_token_id = cfg.img_context_token_id
+    ge, le = eager.generate(pv, ids, max_new_tokens=12, return_logits=True)
+    for rep in range(2):                                        # second pass: graph cached from the first
+        gg, lg = vlm.generate(pv, ids, max_new_tokens=12, return_logits=True)
+        assert gg.cpu().tolist() == ge.cpu().tolist()
+        assert (lg - le).abs().max().item() < 2e-2 * le.abs().max().item()
+    assert any(not isinstance(g, str) for g in vlm._dec_graphs.values())      # a graph was really captured and replayed
+    two = vlm.generate(torch.cat([pv, pv]), torch.cat([ids, ids]), max_new_tokens=12)
+    assert two[0].tolist() == two[1].tolist() == ge[0].tolist()
+
+
 def test_greedy_ids_bit_exact(vlm, g56):
     pv, ids = _pv(0), torch.from_numpy(g56['input_ids'])
     assert float(g56['greedy_margin'].min()) > 0.05           # golden margins are far above bf16 logit noise

@@ -48,6 +48,7 @@ __device__ __forceinline__ int fdiv(int x, float inv_d) { return (int)(((float)x
 struct EpiOps {  // epilogue operands of one tile pair
   u32x2 b0, b1;  // 4 bf16 bias values of tile 0 / tile 1
   f32x4 cs, sn;  // RoPE cos / sin
+  int pos;       // position id of the row (cache slot when slot_base < 0)
 };
 
 template <int EPI>
@@ -67,6 +68,7 @@ __device__ __forceinline__ void load_epi(const VlaserSkinnyArgs& a, int pair, in
   if constexpr (EPI == VL_SK_QKV_ROPE) {
     const int pp = n0 & 127, d = ((pp >> 5) << 4) + (pp & 15);
     const int pos = a.pos_ids[min(m, a.M - 1)];
+    e.pos = pos;
     e.cs = *reinterpret_cast<const f32x4*>(a.rope_cos + (size_t)pos * 64 + d);
     e.sn = *reinterpret_cast<const f32x4*>(a.rope_sin + (size_t)pos * 64 + d);
   }
@@ -123,7 +125,9 @@ __device__ __forceinline__ void skinny_epilogue(const VlaserSkinnyArgs& a, int k
       x2[j] = round_bf16(acc1[j] + b1[j]);
     }
     const int b = fdiv(m, __builtin_amdgcn_rcpf((float)a.tok_per_batch));
-    const int slot = a.slot_base + (m - b * a.tok_per_batch);
+    // slot_base < 0: the cache slot is the row's position id (device-resident), so a captured decode step can be replayed while the
+    // sequence grows (uniform decode: one new token per sequence, slot == position)
+    const int slot = a.slot_base >= 0 ? a.slot_base + (m - b * a.tok_per_batch) : e.pos;
     const int nq = a.n_q_heads, nkv = a.n_kv_heads;
     if (head < nq + nkv) {
       float o1[4], o2[4];
