@@ -59,14 +59,20 @@ typedef struct {
   void* vq; void* vk; void* vvt; int vit_heads, vit_seq, vit_seq_pad; float q_scale;
   /* VL_EPI_PARTIAL */
   float* out_f32; int k_splits;
-  int force_bm;             /* 0 = heuristic; 32 / 64 / 128 = register-staged tile height; 1100 / 1200 / 1300 / 1500 = LDS-DMA pipeline
-                               128x128 / 128x256 / 256x256 / 64x128 (tests, tools/micro/gemm_lab) */
+  int force_bm;             /* 0 = heuristic; 32 / 64 / 128 = register-staged tile height; 1100 / 1200 / 1300 / 1440 / 1500 = LDS-DMA pipeline
+                               128x128 / 128x256 / 256x256 / 144x128 / 64x128 (tests, tools/micro/gemm_lab) */
   /* batched GEMM (attention backward through materialised per-head matrices): blockIdx.z = batch index z;
    * A += z*a_bs, out += z*o_bs, W += (z / w_group)*w_bs  (element strides; batch 0/1 = plain GEMM) */
   int batch; long long a_bs, w_bs, o_bs; int w_group;
 } VlaserGemmArgs;
 
 int vlaser_gemm(int epi, const VlaserGemmArgs* args, vl_stream_t stream);
+
+/* NN form: out[M,N] = A[M,K] @ B[K,N], B = args->W row-major with row stride args->ldw ("k-major").  The dgrad of an nn.Linear
+ * (dX = dY @ W, autograd of modeling_internvl_chat.py:194-203 / joint_model.py:410-696) reads the forward weight [N_out, K_in] as it
+ * is stored: no transposed copy.  Epilogues VL_EPI_NONE (bf16 out) and VL_EPI_PARTIAL (split-K fp32 slabs); K % 64 == 0, N % 8 == 0;
+ * force_bm: 0 or an LDS-DMA configuration code. */
+int vlaser_gemm_nn(int epi, const VlaserGemmArgs* args, vl_stream_t stream);
 
 /* ---- attention ------------------------------------------------------------------------------------------------
  * vlaser_attn_prefill replaces FlashAttention.forward / InternAttention._naive_attn (modeling_intern_vit.py:51-96,

@@ -513,6 +513,32 @@ def test_gemm_lds_attribute_is_set_per_kernel_in_any_order():
     assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
 
 
+@pytest.mark.parametrize('bm', [0, 1100, 1200, 1300, 1440, 1500])
+def test_gemm_nn_reads_the_weight_as_stored(ops, bm):
+    """NN form (dgrad dX = dY @ W with W [N_out, K_in] as the forward stores it): every LDS-DMA configuration against fp32 matmul on
+    ragged M / N, a short contraction (K shorter than the stage ring), a strided B (a slice of a wider matrix), and split-K slabs."""
+    from vlaser_amd import _lib as L
+    for (M, N, K) in [(130, 1000, 64), (257, 304, 128), (70, 520, 1536), (560, 1536, 2048)]:
+        x, w = rnd(M, K), rnd(K, N, std=0.05, seed=M)
+        out = torch.zeros(M, N, dtype=BF, device='cuda')
+        ops.gemm_nn(L.EPI_NONE, x, w, out=out, force_bm=bm)
+        close(out, x.float() @ w.float(), rtol=1e-2, atol=1e-2, name=f'nn {M}x{N}x{K} cfg{bm}')
+    # B = columns [256, 256 + 520) of a wider row-major matrix
+    x, wide = rnd(96, 320), rnd(320, 1024, std=0.05, seed=5)
+    b = wide[:, 256:776]
+    out = torch.zeros(96, 520, dtype=BF, device='cuda')
+    a = L.GemmArgs(); a.A, a.W, a.out = x.data_ptr(), b.data_ptr(), out.data_ptr()
+    a.M, a.N, a.K, a.lda, a.ldw, a.ldo, a.force_bm = 96, 520, 320, 320, 1024, 520, bm
+    import ctypes
+    L.check(L.lib().vlaser_gemm_nn(L.EPI_NONE, ctypes.byref(a), torch.cuda.current_stream().cuda_stream), 'vlaser_gemm_nn')
+    close(out, x.float() @ b.float(), rtol=1e-2, atol=1e-2, name=f'nn strided cfg{bm}')
+    M, N, K, S = 385, 1024, 2048, 4
+    x, w = rnd(M, K), rnd(K, N, std=0.05, seed=9)
+    part = torch.zeros(S, M, N, dtype=torch.float32, device='cuda')
+    ops.gemm_nn(L.EPI_PARTIAL, x, w, out_f32=part, k_splits=S, force_bm=bm)
+    close(part.sum(0), x.float() @ w.float(), rtol=2e-3, atol=2e-3, name=f'nn split-K cfg{bm}')
+
+
 def test_skinny_chunked_k_vlaser_8b_widths(ops):
     """Chunked-K weight streaming: K / (k_splits * 256) = 14 or 16 steps per wave run as two chunks of 7 / 8 with
     the accumulators carried across chunks -- Vlaser-8B's hidden 3584 (qkv / gate+up / lm_head, NORM prologue) and its MLP width

@@ -45,6 +45,7 @@ SK_PARTIAL, SK_QKV_ROPE, SK_SWIGLU, SK_F32, SK_BIAS, SK_BIAS_SILU = range(6)
 
 _SIGS = {
     'vlaser_gemm': [i32, C.POINTER(GemmArgs), vp],
+    'vlaser_gemm_nn': [i32, C.POINTER(GemmArgs), vp],
     'vlaser_attn_prefill': [C.POINTER(AttnArgs), vp],
     'vlaser_attn_skinny': [C.POINTER(AttnArgs), vp],
     'vlaser_skinny': [i32, i32, C.POINTER(SkinnyArgs), vp],

@@ -499,6 +499,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 // of the row-major tile image; the XOR swizzle of the image is therefore applied on the SOURCE side: lane l of a piece
 // fetches logical slot (l&7) ^ (row&7) of row 8*piece + (l>>3).  The DMA is issued from inline asm so that hipcc neither
 // counts it nor drains it at its own waits (guide 5.7); ordering is ours: vmcnt(N) -> s_barrier -> ds_read.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -506,13 +507,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EPI, int BM, int BNT, int WM, int WN, int NST>
+// WKM ("W k-major", the NN form out = A @ B): the second operand is stored [K][N] row-major -- a weight matrix exactly as the
+// forward keeps it, seen from its dgrad (dX = dY @ W).  Its K-tile is staged as [64 k][BNT n] (1 KiB pieces = 1024 / (2 BNT)
+// whole k-rows; XOR swizzle of the 16-byte slots on the source side again) and the MFMA fragments come out of LDS through the
+// transposing `ds_read_tr16_b64`: lane (fr, fq) reads 8 bytes of k-row 8 fq + (fr >> 2) (+4 for the upper half) at columns
+// 4 (fr & 3) .. +3 and receives column fr's four k-values, i.e. operand element e <-> k = 8 fq + e, the same order the
+// row-major A fragment has.  A 32-lane phase of that read touches k-rows {0-3, 8-11} (+4), 32 bytes each, at the same two
+// logical slots: the swizzle key 2 ((k & 3) | ((k >> 3) & 1) << 2) sends them to eight different slot pairs of the 256-byte bank row.
+template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BNT / WN;
   constexpr int MT = WTM / 16, NT = WTN / 16;
   constexpr int STAGE = (BM + BNT) * 128;               // bytes: A tile | W tile (row-major, 128 B = 64 k per row)
-  constexpr int NPA = BM / 8, NPW = BNT / 8;             // 1 KiB (8-row) pieces of the A / W tile
+  constexpr int NPA = BM / 8, NPW = BNT / 8;             // 1 KiB (8-row) pieces of the A / W tile (WKM: 64 k-rows x 2 BNT bytes = the same count)
+  constexpr int WROWB = BNT * 2, WRPP = 1024 / WROWB, WSPR = BNT / 8;      // WKM: bytes per k-row, k-rows per piece, 16-byte slots per k-row
   constexpr int PA = (NPA + NW - 1) / NW, PW = (NPW + NW - 1) / NW;     // pieces per wave per K-tile; an uneven split re-issues the last piece
   constexpr int PIECES = PA + PW;                        // (same bytes to the same LDS address: benign) so every wave's vmcnt arithmetic is identical
   static_assert(NPA * 8 == BM && NPW * 8 == BNT, "tile rows must be multiples of 8");
@@ -547,8 +556,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
   }
 #pragma unroll
   for (int i = 0; i < PW; ++i) {
-    const int row = min(wave * PW + i, NPW - 1) * 8 + prow;
-    srcW[i] = W + (size_t)min(n0 + row, a.N - 1) * a.ldw + kbase + ((pslot ^ (row & 7)) << 3);
+    if constexpr (WKM) {
+      const int krow = min(wave * PW + i, NPW - 1) * WRPP + lane / WSPR;              // k-row of this lane inside the tile
+      const int slot = (lane % WSPR) ^ (2 * ((krow & 3) | (((krow >> 3) & 1) << 2)));    // logical 16-byte slot fetched into physical slot lane % WSPR
+      srcW[i] = W + (size_t)(kbase + krow) * a.ldw + min(n0 + slot * 8, ((a.N + 7) & ~7) - 8);   // columns past N (chunk-aligned clamp) only feed dropped outputs
+    } else {
+      const int row = min(wave * PW + i, NPW - 1) * 8 + prow;
+      srcW[i] = W + (size_t)min(n0 + row, a.N - 1) * a.ldw + kbase + ((pslot ^ (row & 7)) << 3);
+    }
   }
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;      // LDS byte address of the stage ring (low 32 bits of the generic pointer)
   auto issue_tile = [&](int kt, int st) {
@@ -557,7 +572,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
 #pragma unroll
     for (int i = 0; i < PA; ++i) glds16(srcA[i] + ko, __builtin_amdgcn_readfirstlane(base + min(wave * PA + i, NPA - 1) * 1024));
 #pragma unroll
-    for (int i = 0; i < PW; ++i) glds16(srcW[i] + ko, __builtin_amdgcn_readfirstlane(base + BM * 128 + min(wave * PW + i, NPW - 1) * 1024));
+    for (int i = 0; i < PW; ++i) glds16(srcW[i] + (WKM ? (size_t)ko * a.ldw : (size_t)ko), __builtin_amdgcn_readfirstlane(base + BM * 128 + min(wave * PW + i, NPW - 1) * 1024));
   };
 
   f32x4 acc[NT][MT];
@@ -584,8 +599,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
       for (int t = 0; t < MT; ++t)
         fa[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + lds_off(wr * WTM + t * 16 + fr, ks * 4 + fq)));
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        fw[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ws + lds_off(wc * WTN + t * 16 + fr, ks * 4 + fq)));
+      for (int t = 0; t < NT; ++t) {
+        if constexpr (WKM) {
+          const int kr = ks * 32 + 8 * fq + (fr >> 2), c0 = wc * WTN + t * 16;      // lower half: k-rows kr, upper: kr + 4 (same swizzle bits 0-1, 3)
+          const int sl = (c0 >> 3) + ((fr & 3) >> 1), hb = (fr & 1) * 8;
+          const int key_lo = 2 * ((kr & 3) | (((kr >> 3) & 1) << 2)), key_hi = 2 * (((kr + 4) & 3) | ((((kr + 4) >> 3) & 1) << 2));
+          typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+          const char* plo = Ws + kr * WROWB + (((sl & ~15) | ((sl & 15) ^ key_lo)) << 4) + hb;
+          const char* phi = Ws + (kr + 4) * WROWB + (((sl & ~15) | ((sl & 15) ^ key_hi)) << 4) + hb;
+          union { s16x4_t h[2]; bf16x8 b; } u;
+          u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(uint32_t)(uintptr_t)plo);
+          u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(uint32_t)(uintptr_t)phi);
+          fw[t] = u.b;
+        } else {
+          fw[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ws + lds_off(wc * WTN + t * 16 + fr, ks * 4 + fq)));
+        }
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -626,7 +655,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
   }
 }
 
-template <int EPI, int BM, int BNT, int WM, int WN, int NST>
+template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false>
 static int launch_glds(const VlaserGemmArgs* args, hipStream_t stream, int splits) {
   GemmP p;
   p.a = *args;
@@ -634,8 +663,8 @@ static int launch_glds(const VlaserGemmArgs* args, hipStream_t stream, int split
   p.tiles_n = (args->N + BNT - 1) / BNT;
   constexpr int lds = NST * (BM + BNT) * 128;
   static_assert(lds <= 160 * 1024, "stage ring exceeds the 160 KiB LDS of a CU");
-  if (int rc = set_max_lds_once(gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST>, lds)) return rc;
-  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST>), dim3(p.tiles_m * p.tiles_n, splits, args->batch > 1 ? args->batch : 1),
+  if (int rc = set_max_lds_once(gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM>, lds)) return rc;
+  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM>), dim3(p.tiles_m * p.tiles_n, splits, args->batch > 1 ? args->batch : 1),
                      dim3(WM * WN * 64), lds, stream, p);
   VL_LAUNCH_CHECK();
   return 0;
@@ -659,7 +688,7 @@ static int launch_bm(const VlaserGemmArgs* args, hipStream_t stream, int splits)
 // first losing to smallest: 64x128 (8 waves, 4 stages) for the smallest problems, then 128x128 (4 stages), 128x256 (3 stages),
 // 256x256 (2 stages).  Multi-round grids take the configuration with the least modelled time (rounds x tile area / measured
 // rate); <= 32 activation rows stay on the 32-row register-staged kernel (a 64-row tile would be 50+ % padding).
-template <int EPI>
+template <int EPI, bool WKM = false>
 static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
   const int splits = (EPI == VL_EPI_PARTIAL && args->k_splits > 1) ? args->k_splits : 1;
   const int tn = (args->N + BN - 1) / BN;
@@ -668,7 +697,7 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
   (void)tn;
   int bm = args->force_bm;
   if (bm == 0) {
-    if (args->M <= 32) {
+    if (args->M <= 32 && !WKM) {
       bm = 32;
     } else if (blocks(64, 128) <= 256) {
       bm = 1500;
@@ -691,12 +720,16 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
   }
   // LDS-DMA pipeline configurations: 1100 = 128x128 / 4 stages, 1200 = 128x256 / 3, 1300 = 256x256 / 2, 1500 = 64x128 / 4 (8 waves each), 1440 = 144x128 / 4 (6 waves)
   switch (bm) {
-    case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4>(args, stream, splits);
-    case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3>(args, stream, splits);
-    case 1300: return launch_glds<EPI, 256, 256, 2, 4, 2>(args, stream, splits);
-    case 1500: return launch_glds<EPI, 64, 128, 2, 4, 4>(args, stream, splits);
-    case 1440: return launch_glds<EPI, 144, 128, 3, 2, 4>(args, stream, splits);
+    case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM>(args, stream, splits);
+    case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3, WKM>(args, stream, splits);
+    case 1300: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM>(args, stream, splits);
+    case 1500: return launch_glds<EPI, 64, 128, 2, 4, 4, WKM>(args, stream, splits);
+    case 1440: return launch_glds<EPI, 144, 128, 3, 2, 4, WKM>(args, stream, splits);
     default: break;
+  }
+  if constexpr (WKM) {
+    vlaser_set_error("vlaser_gemm_nn: force_bm must be 0 or an LDS-DMA configuration code (got %d)", bm);
+    return -1;
   }
   if (bm == 128) return launch_bm<EPI, 128>(args, stream, splits);
   if (bm == 64) return launch_bm<EPI, 64>(args, stream, splits);
@@ -711,7 +744,6 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
 // LDS read: a 16-lane group passes 16 8-byte pieces, piece p = 4 consecutive columns of row p>>2, and lane i receives,
 // for j = 0..3, element (i&3) of piece 4j + (i>>2) = T[row j][col i] (probed: tools/micro/tr16_probe.hip).  Row pitches
 // of 160 B (64-column tile) / 288 B (128-column tile) put the 8 rows a 32-lane access touches on disjoint banks.
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 __device__ __forceinline__ bf16x8 tr_frag(const char* lds_tile, int pitch, int col0, int krow0, int fq, int fr) {
   // fragment of 8 k-values for column col0 + fr.  The MFMA only needs A and B to agree on which k a (lane group fq, slot)
   // pair means, so slot (h, j) of group fq is taken as row krow0 + 16 h + 4 fq + j: the two groups of a 32-lane LDS access
@@ -909,4 +941,27 @@ extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
       return launch<VL_EPI_VIT_QKV>(a, stream);
     default: vlaser_set_error("vlaser_gemm: unknown epilogue %d", epi); return -1;
   }
+}
+
+// out[M,N] = A[M,K] @ B[K,N] with B row-major ("k-major": a forward weight [N_out, K_in] read as the B of its own dgrad dX = dY @ W);
+// ldw = row stride of B.  NONE (bf16 out) and PARTIAL (split-K fp32 slabs) epilogues.
+extern "C" int vlaser_gemm_nn(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(s);
+  VL_CHECK(a && a->A && a->W, "vlaser_gemm_nn: null operand");
+  VL_CHECK(a->M > 0 && a->N > 0 && a->K > 0 && a->K % BK == 0, "vlaser_gemm_nn: bad shape M=%d N=%d K=%d (K must be a multiple of %d)", a->M, a->N, a->K, BK);
+  VL_CHECK(a->N % 8 == 0 && a->lda % 8 == 0 && a->ldw % 8 == 0 && a->ldw >= a->N, "vlaser_gemm_nn: N, lda, ldw must be multiples of 8 and ldw >= N");
+  VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm_nn: operands must be 16-byte aligned");
+  VL_CHECK(a->batch <= 1, "vlaser_gemm_nn: batched mode is not supported");
+  VL_CHECK(a->force_bm == 0 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1440 || a->force_bm == 1500,
+           "vlaser_gemm_nn: force_bm must be 0 or an LDS-DMA configuration code 1100/1200/1300/1440/1500");
+  switch (epi) {
+    case VL_EPI_NONE: VL_CHECK(a->out, "out null"); return launch<VL_EPI_NONE, true>(a, stream);
+    case VL_EPI_PARTIAL:
+      VL_CHECK(a->out_f32 && a->N % 4 == 0, "partial: out_f32 null or N %% 4 != 0");
+      VL_CHECK(a->k_splits >= 1 && a->K % (a->k_splits * BK) == 0, "partial: K=%d not divisible by k_splits*64 (k_splits=%d)", a->K, a->k_splits);
+      return launch<VL_EPI_PARTIAL, true>(a, stream);
+    default: break;
+  }
+  vlaser_set_error("vlaser_gemm_nn: epilogue %d is not available in the NN form (NONE / PARTIAL)", epi);
+  return -1;
 }

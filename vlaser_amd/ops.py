@@ -80,6 +80,27 @@ def gemm(epi, A, W, out=None, bias=None, res=None, ls=None, N=None, **kw):
     return out
 
 
+def gemm_nn(epi, A, B, out=None, **kw):
+    """out[M,N] = A[M,K] @ B[K,N] with B row-major as stored (a forward weight seen from its dgrad): NONE (bf16 `out`) or PARTIAL
+    (`out_f32` slabs, `k_splits`)."""
+    _chk(A); _chk(B)
+    a = L.GemmArgs()
+    M, K = A.shape
+    assert B.shape[0] == K, (A.shape, B.shape)
+    a.A, a.W = A.data_ptr(), B.data_ptr()
+    a.M, a.N, a.K = M, B.shape[1], K
+    a.lda, a.ldw = A.stride(0), B.stride(0)
+    if out is not None:
+        a.out, a.ldo = out.data_ptr(), out.stride(0)
+    part = kw.get('out_f32')
+    if epi == L.EPI_PARTIAL and isinstance(part, torch.Tensor) and part.numel() < kw.get('k_splits', 1) * M * a.N:
+        raise ValueError(f'vlaser_gemm_nn: {kw.get("k_splits", 1)} fp32 slabs of [{M},{a.N}] do not fit the {part.numel()}-element partial buffer')
+    for k, v in kw.items():
+        setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    L.check(L.lib().vlaser_gemm_nn(epi, C.byref(a), _stream()), 'vlaser_gemm_nn')
+    return out
+
+
 def gemm_raw(epi, A, W, out, M, N, K, lda, ldw, ldo, **kw):
     """Fully explicit GEMM call (views / batched operands): pointers from the tensors, geometry from the arguments."""
     a = L.GemmArgs()

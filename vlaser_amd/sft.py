@@ -138,6 +138,8 @@ class SFTModel:
         self.Vp = (V + 63) // 64 * 64
         fp = FlatParams(dev)
         fp.add('head', (V, H))
+        if self.Vp > V:
+            fp.add('head_pad', (self.Vp - V, H))   # zero rows (zero gradients, so AdamW keeps them zero): the head's dgrad contracts over Vp = V rounded up to 64
         fp.add('norm', (H,))
         fp.align(128 * self.world)                # end of bucket 0 (head + final norm)
         self.bucket_bounds = [0]                  # flat offsets where a gradient bucket ends
@@ -152,6 +154,8 @@ class SFTModel:
             fp.add('mlp1.' + nm, shp)
         fp.finalize(pad_to=128 * self.world * 8)
         self.fp = fp
+        o_head = fp.offset_of('head')
+        self.head_full = fp.p[o_head:o_head + self.Vp * H].view(self.Vp, H)      # [Vp, H]: lm_head rows + the zero pad rows
         g = lambda k: sd[k].to(device=dev, dtype=BF)
         fp.view['head'].copy_(g('language_model.lm_head.weight'))
         fp.view['norm'].copy_(g('language_model.model.norm.weight'))
@@ -197,7 +201,6 @@ class SFTModel:
             self.shard_off.append(o)
             o += hi - lo
         self._alloc_workspace()
-        self._refresh_transposes()
         return self
 
     def _alloc_workspace(self):
@@ -208,12 +211,8 @@ class SFTModel:
         S, Lyr = self.S_max, llm.num_hidden_layers
         z = lambda *s, dt=BF: torch.zeros(*s, dtype=dt, device=dev)
         C4 = cfg.vision.hidden_size * 4
-        # derived (non-parameter) transposed weights for the dgrad GEMMs
-        self.wT = {}
-        for i in range(Lyr):
-            self.wT[i] = dict(wqkv=z(H, NQ), wo=z(nq * hd, H), wgu=z(H, 2 * I), wdown=z(I, H))
-        self.headT = z(H, self.Vp)
-        self.m1wT, self.m3wT = z(C4, H), z(H, H)
+        # the dgrad GEMMs read the forward weights as stored (vlaser_gemm_nn): no transposed copies (r01/r02 kept 3.5 GB of W^T and
+        # rebuilt it after every optimizer step: 170 launches, 1.8 ms)
         # activations
         self.h_in = z(Lyr + 1, S, H)               # layer inputs (checkpoints) + final hidden
         Lk = 1 if self.recompute else Lyr          # saved-activation slots: one (reused) or one per layer
@@ -243,11 +242,9 @@ class SFTModel:
         self.gacc = None                                            # fp32 gradient accumulator (allocated by the first multi-sample step)
         self._alloc_projector_ws()
         self.comm_stream = torch.cuda.Stream(device=dev) if self.dp_active else None
-        self.aux_stream = torch.cuda.Stream(device=dev)        # weight transposes overlap the next step's forward
         # single rank: AdamW (HBM-bound, a third of a step) runs on its own stream bucket by bucket in the order the next forward
         # consumes the parameters, so the next step's frozen-ViT / early-layer GEMMs (MFMA-bound) overlap it
         self.opt_stream = torch.cuda.Stream(device=dev)
-        self.wT_ready = None
 
     def _alloc_projector_ws(self):
         """Projector (mlp1) workspaces, sized for `max_tiles` tiles x 256 visual tokens."""
@@ -286,29 +283,6 @@ class SFTModel:
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
-    def _refresh_transposes(self):
-        """W^T copies used by the dgrad GEMMs (dX = dY @ W needs W with the contraction axis contiguous).  Issued on a side
-        stream: only the backward needs them, so they overlap the next forward."""
-        ev = torch.cuda.Event()
-        ev.record()
-        with torch.cuda.stream(self.aux_stream):
-            self.aux_stream.wait_event(ev)
-            if self.dp_active and self.ag_events.get(0) is not None:
-                self.aux_stream.wait_event(self.ag_events[0])          # bucket 0 is gathered last: all parameters are current
-            self._refresh_transposes_now()
-            self.wT_ready = torch.cuda.Event()
-            self.wT_ready.record()
-
-    def _refresh_transposes_now(self):
-        v = self.fp.view
-        for i in range(self.llm.num_hidden_layers):
-            for nm in ('wqkv', 'wo', 'wgu', 'wdown'):
-                w = v[f'l{i}.{nm}']
-                ops.transpose(w, self.wT[i][nm], w.shape[0], w.shape[1], w.shape[1], w.shape[0])
-        ops.transpose(v['head'], self.headT, v['head'].shape[0], v['head'].shape[1], v['head'].shape[1], self.Vp)
-        ops.transpose(v['mlp1.m1w'], self.m1wT, *v['mlp1.m1w'].shape, v['mlp1.m1w'].shape[1], v['mlp1.m1w'].shape[0])
-        ops.transpose(v['mlp1.m3w'], self.m3wT, *v['mlp1.m3w'].shape, v['mlp1.m3w'].shape[1], v['mlp1.m3w'].shape[0])
-
     # ------------------------------------------------------------------ small helpers
     def _wgrad(self, dY, X, out, S, bias_out=None):
         """out[N,K] = dY[S,N]^T @ X[S,K] (bf16) by the TN GEMM: both operands are read as they lie (contraction along their
@@ -317,18 +291,18 @@ class SFTModel:
         if bias_out is not None:
             ops.colsum_bf16(dY, bias_out, S, dY.shape[1])
 
-    def _dgrad(self, dY, WT, out, S):
-        """out[S,K] = dY[S,N] @ W[N,K] with W^T [K,N] resident; long contractions over few output tiles run split-K."""
-        Kout, Nin = WT.shape
-        # measured at S = 560, 1536 outputs (tools/micro/split_lab.py): contraction <= 2048 -> one pass on 32-row tiles (11-13 us) beats
-        # split-K slabs + their reduction (19-20 us); longer contractions (8960 / 17920) keep split-K (36 / 65 vs 42 / 100 us)
+    def _dgrad(self, dY, W, out, S):
+        """out[S,K] = dY[S,N] @ W[N,K], W as the forward stores it (NN GEMM); long contractions over few output tiles run split-K."""
+        Nin, Kout = W.shape
+        # measured at S = 560, 1536 outputs (tools/micro/nn_lab.py): contraction <= 2048 -> one pass (11.5-14.6 us) beats split-K slabs +
+        # their reduction (9-11 + 5 us); longer contractions (8960 / 17920) keep split-K
         sp = 1 if Nin <= 2048 else ops.gemm_splits(S, Kout, Nin)
         if sp > 1:
             part = self.part[:sp * S * Kout]
-            ops.gemm(L.EPI_PARTIAL, dY, WT, out_f32=part, k_splits=sp)
+            ops.gemm_nn(L.EPI_PARTIAL, dY, W, out_f32=part, k_splits=sp)
             ops.reduce_norm(None, part, sp, S, Kout, out)
         else:
-            ops.gemm(L.EPI_NONE, dY, WT, out=out, force_bm=32 if Nin <= 2048 and Kout <= 2048 else 0)
+            ops.gemm_nn(L.EPI_NONE, dY, W, out=out)
 
     def _norm_wgrad(self, dy, x, out, S, Cc, mode=2, eps=1e-6):
         ops.colsum_mul(dy, x, self.col, S, Cc, mode, eps, self.rowstat)
@@ -440,10 +414,7 @@ class SFTModel:
         ops.rmsnorm(h_fin, v['norm'], llm.rms_norm_eps, out=xn)
         if R == 0:
             # no supervised position on this rank: zero loss, zero gradients -- but the SAME collective sequence as every other
-            # rank (one reduce-scatter per bucket, in backward order), and the W^T refresh of the previous step must have finished
-            # reading fp.p before the optimizer writes it
-            if self.wT_ready is not None:
-                torch.cuda.current_stream().wait_event(self.wT_ready)
+            # rank (one reduce-scatter per bucket, in backward order)
             self.fp.g.zero_()
             if on_bucket_ready:
                 for b in range(len(self.buckets)):
@@ -457,12 +428,11 @@ class SFTModel:
         ops.ce_rows(logits, t_rows, loss_rows, lse)
         loss = loss_rows.sum() / R
         # ================================================================ backward
-        if self.wT_ready is not None:
-            torch.cuda.current_stream().wait_event(self.wT_ready)
+        # (every bucket's `_wait_params` has been issued by now: the previous step's AdamW / all-gathers no longer touch fp.p or fp.g)
         dlog = torch.zeros(R, self.Vp, dtype=BF, device=dev)
         ops.ce_dlogits(logits, lse, t_rows, dlog, 1.0 / R)
         dx_rows = torch.empty(R, H, dtype=BF, device=dev)
-        ops.gemm(L.EPI_NONE, dlog, self.headT, out=dx_rows)          # dX = dlogits @ W_head
+        self._dgrad(dlog, self.head_full, dx_rows, R)               # dX = dlogits @ W_head (contraction over Vp: dlogits and the pad rows are zero there)
         ops.gemm_tn(dlog[:, :V], x_rows, gv['head'])                # dW_head = dlogits^T @ x (dlogits rows are padded to Vp columns)
         dxn = self.dx[:S]
         dxn.zero_()
@@ -489,17 +459,16 @@ class SFTModel:
             h_in = self.h_in[i, :S]
             x1, x2, h2, q, ao, gu, act = self._layer_forward(i, h_in, S, pos) if self.recompute else self._saved(i, S)
             kslot = 0 if self.recompute else i
-            wT = self.wT[i]
             dact, dgu, dx, dh2, dao = self.dact[:S], self.dgu[:S], self.dx[:S], self.dh2[:S], self.dao[:S]
             # MLP: h3 = h2 + act Wd^T ; act = silu(g) u ; [g|u] = x2 Wgu^T ; x2 = rms(h2) w_post
-            self._dgrad(dh, wT['wdown'], dact, S)
+            self._dgrad(dh, v[f'l{i}.wdown'], dact, S)
             self._wgrad(dh, act, gv[f'l{i}.wdown'], S)
             ops.swiglu_bwd(gu, dact, dgu, S, I)
-            self._dgrad(dgu, wT['wgu'], dx, S)
+            self._dgrad(dgu, v[f'l{i}.wgu'], dx, S)
             self._wgrad(dgu, x2, gv[f'l{i}.wgu'], S)
             ops.rmsnorm_bwd(dx, h2, v[f'l{i}.ln_post'], dh, dh2, S, H, llm.rms_norm_eps, dw_out=gv[f'l{i}.ln_post'], dw_ws=self.normw_ws)
             # attention block: h2 = h_in + ao Wo^T
-            self._dgrad(dh2, wT['wo'], dao, S)
+            self._dgrad(dh2, v[f'l{i}.wo'], dao, S)
             self._wgrad(dh2, ao, gv[f'l{i}.wo'], S)
             # attention backward through materialised per-head score matrices (S is small: 12 x S x S)
             Kc, VTc = self.cache.k[kslot, 0], self.cache.vt[kslot, 0]         # [nkv, s_max, hd], [nkv, hd, s_max]
@@ -516,7 +485,7 @@ class SFTModel:
             ops.gemm_tn_grouped(P, dao, self.dv, S, hd, S, Sp, nq * hd, nq * hd, 1, 0, 0, nq, S * Sp, hd, hd)
             dqkv = self.dqkv[:S]
             ops.rope_bwd_pack(self.dq[:S], self.dk[:S], self.dv[:S], self.rope[0], self.rope[1], pos, dqkv, S, nq, nkv, kv_per_q_head=True)
-            self._dgrad(dqkv, wT['wqkv'], dx, S)
+            self._dgrad(dqkv, v[f'l{i}.wqkv'], dx, S)
             self._wgrad(dqkv, x1, gv[f'l{i}.wqkv'], S, bias_out=gv[f'l{i}.bqkv'])
             ops.rmsnorm_bwd(dx, h_in, v[f'l{i}.ln_in'], dh2, dh, S, H, llm.rms_norm_eps, dw_out=gv[f'l{i}.ln_in'], dw_ws=self.normw_ws)
             if on_bucket_ready and (i == 0 or bucket_of_layer[i - 1] != bucket_of_layer[i]):
@@ -532,11 +501,11 @@ class SFTModel:
         else:
             dvit.copy_(dfeat_used)
         dg1, dz1, dln = self.dg1[:nt], self.dz1[:nt], self.dln[:nt]
-        ops.gemm(L.EPI_NONE, dvit, self.m3wT, out=dg1)
+        ops.gemm_nn(L.EPI_NONE, dvit, v['mlp1.m3w'], out=dg1)
         self._wgrad(dvit, g1, gv['mlp1.m3w'], nt, bias_out=gv['mlp1.m3b'])
         ops.gelu_bwd(z1, dg1, dz1)
         self._wgrad(dz1, ps_ln, gv['mlp1.m1w'], nt, bias_out=gv['mlp1.m1b'])
-        ops.gemm(L.EPI_NONE, dz1, self.m1wT, out=dln)
+        ops.gemm_nn(L.EPI_NONE, dz1, v['mlp1.m1w'], out=dln)
         C4 = C1 * 4
         ops.colsum_mul(dln, ps_raw, self.col, nt, C4, 3, 1e-5, self.rowstat)
         gv['mlp1.m0w'].copy_(self.col[:C4])
@@ -583,7 +552,7 @@ class SFTModel:
 
         if not self.dp_active and self.overlap_optimizer:
             # pipelined with the NEXT step: bucket by bucket on `opt_stream`, embed + projector first, lm_head last; the next forward
-            # waits per bucket (`_wait_params`), its backward for the W^T refresh queued behind the last bucket (`wT_ready`).  The
+            # waits per bucket (`_wait_params`); by the time its backward starts every bucket has been waited for.  The
             # update is therefore still in flight when this returns: `wait_optimizer()` before touching parameter buffers directly.
             ev = torch.cuda.Event()
             ev.record()
@@ -593,9 +562,6 @@ class SFTModel:
                     adamw_bucket(b)
                     self.ag_events[b] = torch.cuda.Event()
                     self.ag_events[b].record()
-                self._refresh_transposes_now()
-                self.wT_ready = torch.cuda.Event()
-                self.wT_ready.record()
             return gnorm
         for b in range(len(self.buckets)):
             adamw_bucket(b)
@@ -613,7 +579,6 @@ class SFTModel:
                     self.ag_events[b].record()
             if not self.overlap_allgather:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
-        self._refresh_transposes()
         return gnorm
 
     def step(self, pixel_values, input_ids, labels, image_flags=None, lr=None, total_steps=None):
@@ -776,7 +741,6 @@ class SFTModel:
         for (lo, hi, _), o in zip(self.shards, self.shard_off):
             if hi > lo:
                 self.fp.p[lo:hi].copy_(self.master[o:o + hi - lo].to(BF))
-        self._refresh_transposes()
         return self
 
     def save_pretrained(self, path, max_shard_bytes=4 << 30):
