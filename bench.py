@@ -274,9 +274,8 @@ def main():
 
     torch.set_grad_enabled(False)
     sft_line = None
-    if a.workload in ('sft', 'both'):
-        sft_line = sft_bench(rank, world, local, dist, a.sft_steps)
     if a.workload == 'sft':
+        sft_line = sft_bench(rank, world, local, dist, a.sft_steps)
         if rank == 0:
             sft_line.update({'n_gpus': world, 'warmup': 2, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
                              'data': 'synthetic', 'config': {'workload': 'Vlaser-2B SFT, per-GPU micro-batch 1, S=560 (BASELINE configs[4])'}})
@@ -341,13 +340,36 @@ def main():
                                 'traffic': _pmc_traffic(), 'bytes_per_launch': byts, 'us_per_launch': round(avg_ms * 1e3, 3), 'launches_timed': n}
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(vla)
+    # ---- SFT line (BASELINE configs[4]) AFTER the headline has been timed: the gradient exchange is the only part of this file that
+    # has never run on more than one physical GPU, so it must not be able to take the headline down with it.  Any rank that fails
+    # skips ahead; rank 0 runs a watchdog that prints the headline line and leaves if the exchange hangs on a missing peer.
+    if a.workload == 'both':
+        del model
+        torch.cuda.empty_cache()
+        watchdog = None
+        if world > 1:
+            import threading
+
+            def _bail():
+                if rank == 0:
+                    line['sft'] = {'error': 'SFT sub-bench did not finish within 420 s (a rank failed or the exchange hung); headline line printed by the watchdog'}
+                    print(json.dumps(line), flush=True)
+                os._exit(0)                                      # every rank leaves, so the launcher sees a clean exit
+            watchdog = threading.Timer(420.0 if rank == 0 else 450.0, _bail)
+            watchdog.daemon = True
+            watchdog.start()
+        try:
+            sft_line = sft_bench(rank, world, local, dist, a.sft_steps)
+        except Exception as e:                                   # noqa: BLE001  (reported in the line, never fatal for the headline)
+            sft_line = {'error': f'{type(e).__name__}: {e}'[:400]}
+        if watchdog is not None:
+            watchdog.cancel()
+    if rank == 0:
         if sft_line is not None:
-            if world == 1 and not a.no_cpu_baseline:
+            if world == 1 and not a.no_cpu_baseline and 'error' not in sft_line:
                 sft_line['cpu_baseline'] = sft_cpu_baseline(vla.base)
             line['sft'] = sft_line
         if world == 1 and a.workload == 'both':
-            del model
-            torch.cuda.empty_cache()
             line['batched'] = batched_chunks(vla, dev, a.steps)
             line['qa'] = qa_bench(local)
             if not a.no_8b:
@@ -369,17 +391,21 @@ def _spawn_ranks(n):
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
-    for ln in p.stdout.splitlines():
+    for ln in p.stdout:                                           # streamed: the line is relayed the moment rank 0 prints it
+        ln = ln.rstrip('\n')
         if ln.startswith('{') and '"metric"' in ln:
             line = ln
+            print(line, flush=True)
         else:
             print(ln, file=sys.stderr)
-    if p.returncode != 0 or line is None:
-        print(f'bench.py: {n}-rank run failed (rc {p.returncode})', file=sys.stderr)
-        return p.returncode or 1
-    print(line, flush=True)
+    rc = p.wait()
+    if line is None:
+        print(f'bench.py: {n}-rank run failed (rc {rc})', file=sys.stderr)
+        return rc or 1
+    if rc != 0:
+        print(f'bench.py: {n}-rank run printed its line but exited with rc {rc}', file=sys.stderr)
     return 0
 
 
