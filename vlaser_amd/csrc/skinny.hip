@@ -269,6 +269,15 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
     const int cpr = a.K >> 3, nch = a.M * cpr;
     const size_t slab = (size_t)a.M * a.K;
     const int S = a.n_partials;
+    // One-pass rows (M * K / 8 <= 512 chunks, rows aligned to 16-lane groups): each thread keeps its 8 rounded residual values and its
+    // norm-weight chunk in registers, the sum of squares goes 16-lane group -> LDS -> fixed-order row total, and the thread normalises
+    // its own values -- phase 2 then costs one short LDS round trip for all 8 waves instead of "one wave per row" walking the row
+    // through LDS twice (1.2 us of the 3.4 us prologue in the in-kernel timeline, tools/micro/skinny_timeline.py).
+    const bool fast2 = SP >= 0 && nch <= SKT && (cpr & 15) == 0 && (cpr >> 4) <= 12;
+    u32x4 hr0 = {0, 0, 0, 0}, wv0 = {0, 0, 0, 0};
+    int mm0 = 0, c0 = 0;
+    float* gs = red;                              // group sums [M][gstride] (the unit-reduce buffer is idle during the prologue)
+    const int ngr = cpr >> 4, gstride = (ngr + 3) & ~3;
     if constexpr (SP >= 0) {
       auto norm_pass_exact = [&](int cbase, auto issue_tag) {
         const int ch = min(cbase + tid, nch - 1);
@@ -296,7 +305,19 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
         u32x4 hr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) hr[j] = pack_bf16x2(sl[2 * j] + v[2 * j], sl[2 * j + 1] + v[2 * j + 1]);
-        if (cbase + tid < nch) {
+        if (fast2) {
+          hr0 = hr; wv0 = wv; mm0 = mm; c0 = c;
+          float ssq = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const float lo = bf16lo_to_f32(hr[j]), hi = bf16hi_to_f32(hr[j]); ssq += lo * lo + hi * hi; }
+          if (tid >= nch) ssq = 0.f;               // clamped duplicate chunk
+          ssq += __shfl_xor(ssq, 1, 64); ssq += __shfl_xor(ssq, 2, 64); ssq += __shfl_xor(ssq, 4, 64); ssq += __shfl_xor(ssq, 8, 64);
+          if ((lane & 15) == 0 && tid < nch) gs[mm * gstride + ((tid - mm * cpr) >> 4)] = ssq;
+          if (tid < nch && write_h) st_global_16(reinterpret_cast<bf16_t*>(a.h_out) + off, hr);
+          // pin the norm-weight chunk's vmcnt wait HERE: its first real use is after the (conditional) early weight requests below, where
+          // hipcc can no longer count and would drain the whole weight stream (vmcnt(0)) before phase 2
+          asm volatile("" ::"v"(wv0[0]), "v"(wv0[1]), "v"(wv0[2]), "v"(wv0[3]));
+        } else if (cbase + tid < nch) {
           *reinterpret_cast<u32x4*>(xs + mm * p.xs_stride + c * 2) = hr;
           if (mm == 0) *reinterpret_cast<u32x4*>(wn_lds + c * 2) = wv;
           if (write_h) st_global_16(reinterpret_cast<bf16_t*>(a.h_out) + off, hr);
@@ -367,6 +388,24 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
       if (ucount > 1) load_unit(1, nw, ne);    // they were requested ~2 us before anything consumes them
       if (ucount > 2) load_unit(2, tw, te);
     }
+    if (fast2) {
+      float tot = 0.f;
+      const float* gr = gs + mm0 * gstride;
+      for (int i = 0; i < ngr; i += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(gr + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tot += (i + j < ngr) ? t[j] : 0.f;      // fixed order: deterministic
+      }
+      const float rs = rsqrtf(tot / (float)a.K + a.eps);
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = round_bf16(bf16lo_to_f32(hr0[j]) * rs) * bf16lo_to_f32(wv0[j]);
+        const float hi = round_bf16(bf16hi_to_f32(hr0[j]) * rs) * bf16hi_to_f32(wv0[j]);
+        o[j] = pack_bf16x2(lo, hi);
+      }
+      if (tid < nch) *reinterpret_cast<u32x4*>(xs + mm0 * p.xs_stride + c0 * 2) = o;
+    } else
     // phase 2 (one wave per row, LDS only): sum of squares, normalise in place
     for (int mm = wave; mm < a.M; mm += SKW) {
       float ssq = 0.f;
