@@ -314,16 +314,15 @@ __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
   int row_hi2[2];                                      // per query row: end of the visible part of the [blk_start, kv_len) block
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    const int r = qt * 16 + fr;
+    // rows past nrows shadow the last real row: their loads are unconditional (a load behind `if (r < nrows)` is its own basic block
+    // and made hipcc drain ALL of Q with vmcnt(0) before the first K / V^T request: one extra memory round trip per launch) and
+    // their results are never stored
+    const int r = min(qt * 16 + fr, nrows - 1);
     const int hg = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)nq)), tok = r - hg * nq;     // r / nq without an integer division
     row_hi2[qt] = (tok == 0 && a.first_tok_kv_len > 0) ? a.first_tok_kv_len : 0x7fffffff;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (size_t)b * a.q_bs + (size_t)(kvh * G + hg) * a.q_hs + (size_t)tok * a.q_ss;
 #pragma unroll
-    for (int dc = 0; dc < DC; ++dc) {
-      u32x4 v = {0, 0, 0, 0};
-      if (r < nrows) v = ld_global_16(Q + dc * 32 + g * 8);
-      qf[qt][dc] = as_bf16x8(v);
-    }
+    for (int dc = 0; dc < DC; ++dc) qf[qt][dc] = as_bf16x8(ld_global_16(Q + dc * 32 + g * 8));      // unconditional (row clamped above)
   }
   int lim1 = a.kv_len, lo2 = 0x7fffffff, hi2 = 0;
   if (a.mode == VL_ATTN_PREFIX) {
@@ -338,9 +337,9 @@ __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
   float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f};
   const float sc = a.scale * 1.4426950408889634f;
 
-  for (int ci = c_begin + wave; ci < c_end; ci += SKA_WAVES) {
-    const int key0 = ci << 5;
-    u32x4 kf[2][DC], vf[DT];
+  // The wave's FIRST chunk is requested unconditionally (clamped for waves without one) in straight-line code right behind the Q
+  // loads: a load inside the chunk loop sits behind hipcc's loop-header `vmcnt(0)`, i.e. K / V^T used to wait for Q's round trip.
+  auto load_chunk = [&](int key0, u32x4 (&kf)[2][DC], u32x4 (&vf)[DT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int key = key0 + (fr >> 2) * 8 + t * 4 + (fr & 3);
@@ -350,6 +349,8 @@ __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
     }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) vf[dt] = ld_global_16(VT + (size_t)(dt * 16 + fr) * a.ld_vt + key0 + g * 8);
+  };
+  auto process_chunk = [&](int key0, u32x4 (&kf)[2][DC], u32x4 (&vf)[DT]) __attribute__((always_inline)) {
     bool visk[2][4];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -408,6 +409,16 @@ __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
         acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
         o[qt][dt] = mfma16(as_bf16x8(vf[dt]), pf, acc);
       }
+    }
+  };
+  {
+    u32x4 kf[2][DC], vf[DT];
+    const int ci0 = c_begin + wave;
+    load_chunk(min(ci0, n_chunks - 1) << 5, kf, vf);          // n_chunks >= 1; the chunk's keys lie inside the padded cache row
+    if (ci0 < c_end) process_chunk(ci0 << 5, kf, vf);
+    for (int ci = ci0 + SKA_WAVES; ci < c_end; ci += SKA_WAVES) {
+      load_chunk(ci << 5, kf, vf);
+      process_chunk(ci << 5, kf, vf);
     }
   }
 
