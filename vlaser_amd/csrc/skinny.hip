@@ -52,7 +52,7 @@ struct EpiOps {  // epilogue operands of one tile pair
 };
 
 template <int EPI>
-__device__ __forceinline__ void load_epi(const VlaserSkinnyArgs& a, int pair, int m, int g, EpiOps& e) {
+__device__ __forceinline__ void load_epi(const VlaserSkinnyArgs& a, int pair, int m, int g, EpiOps& e, int pos) {
   // unconditional (clamped) vector loads; pair = index of the 32-row group
   const int n0 = min(pair, (a.N >> 5) - 1) * 32 + g * 4;
   if constexpr (EPI == VL_SK_BIAS || EPI == VL_SK_BIAS_SILU || EPI == VL_SK_QKV_ROPE || EPI == VL_SK_F32) {
@@ -67,8 +67,7 @@ __device__ __forceinline__ void load_epi(const VlaserSkinnyArgs& a, int pair, in
   }
   if constexpr (EPI == VL_SK_QKV_ROPE) {
     const int pp = n0 & 127, d = ((pp >> 5) << 4) + (pp & 15);
-    const int pos = a.pos_ids[min(m, a.M - 1)];
-    e.pos = pos;
+    e.pos = pos;            // position id of row m, loaded at kernel start (see skinny_kernel): cos / sin no longer hang off a load issued behind the weights
     e.cs = *reinterpret_cast<const f32x4*>(a.rope_cos + (size_t)pos * 64 + d);
     e.sn = *reinterpret_cast<const f32x4*>(a.rope_sin + (size_t)pos * 64 + d);
   }
@@ -191,6 +190,10 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
   const u32x4* wp = reinterpret_cast<const u32x4*>(a.W) + ((size_t)ks * n_units * SKW + wave) * (NF * NCH * 64) + lane;
   constexpr size_t unit_stride = (size_t)SKW * NF * NCH * 64;
   const int m = fr;
+  // RoPE position of this lane's row, requested before anything else: the cos / sin loads depend on it, and a dependent load issued
+  // behind the unit's weight fragments made hipcc drain the whole weight stream (vmcnt(0)) in the middle of the prologue
+  int pos_m = 0;
+  if constexpr (EPI == VL_SK_QKV_ROPE) pos_m = a.pos_ids[min(m, a.M - 1)];
   u32x4 cw[NF], nw[NF], tw[EARLY ? NF : 1];  // current / next (/ third, EARLY) unit
   EpiOps ce[NEED_EPI ? TPU / 2 : 1], ne[NEED_EPI ? TPU / 2 : 1], te[1];
   auto load_unit = [&](int ui, u32x4* dst, EpiOps* e) {
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
     for (int f = 0; f < NF; ++f) dst[f] = __builtin_nontemporal_load(src + f * 64);
     if constexpr (NEED_EPI) {
 #pragma unroll
-      for (int pr = 0; pr < TPU / 2; ++pr) load_epi<EPI>(a, (ustart + ui) * (TPU / 2) + pr, m, g, e[pr]);
+      for (int pr = 0; pr < TPU / 2; ++pr) load_epi<EPI>(a, (ustart + ui) * (TPU / 2) + pr, m, g, e[pr], pos_m);
     }
   };
 
@@ -211,9 +214,15 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
     const int c0 = min(tid, nch - 1);
     const int r0 = fdiv(c0, p.inv_cpr), j0 = c0 - r0 * cpr;
     const u32x4 x0 = ld_global_16(X + (size_t)r0 * a.K + kb0 + j0 * 8);
+    // second chunk (M*K/8 in (512, 1024]: the expert's down projection has 640-800) requested up front as well, clamped instead of
+    // conditional: behind the weight fragments a conditional load is waited for with vmcnt(0), i.e. the prologue drained unit 0's weights
+    const int c1 = min(tid + SKT, nch - 1);
+    const int r1 = fdiv(c1, p.inv_cpr), j1 = c1 - r1 * cpr;
+    const u32x4 x1 = ld_global_16(X + (size_t)r1 * a.K + kb0 + j1 * 8);
     load_unit(0, cw, ce);
     if (tid < nch) *reinterpret_cast<u32x4*>(xs + r0 * p.xs_stride + j0 * 16) = x0;
-    for (int c = tid + SKT; c < nch; c += SKT)
+    if (tid + SKT < nch) *reinterpret_cast<u32x4*>(xs + r1 * p.xs_stride + j1 * 16) = x1;
+    for (int c = tid + 2 * SKT; c < nch; c += SKT)
       *reinterpret_cast<u32x4*>(xs + (c / cpr) * p.xs_stride + (c % cpr) * 16) = ld_global_16(X + (size_t)(c / cpr) * a.K + kb0 + (c % cpr) * 8);
   } else if constexpr (PRO == VL_PRO_ATTN) {
     // x[m][k] (k = h*128 + d) = flash-decoding merge of the attention partials of vlaser_attn_skinny
@@ -238,7 +247,14 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
         o0[sp] = *reinterpret_cast<const f32x4*>(po);
         o1[sp] = *reinterpret_cast<const f32x4*>(po + 4);
       }
-      if constexpr (decltype(issue_tag)::value) load_unit(0, cw, ce);
+      if constexpr (decltype(issue_tag)::value) {
+        // vmcnt retires in issue order: the weight fragments must be requested BEHIND the (L2-resident) attention partials, or every
+        // counted wait on a partial also waits for HBM.  hipcc hoisted these two loads to the top of the kernel (their addresses are
+        // ready first) until the order was pinned.
+        __builtin_amdgcn_sched_barrier(0);
+        load_unit(0, cw, ce);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       float Mx = -1.0e30f;
 #pragma unroll
       for (int sp = 0; sp < NSPL; ++sp) Mx = fmaxf(Mx, ms[sp]);
@@ -447,7 +463,7 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
       for (int f = 0; f < NF; ++f) dst[f] = __builtin_nontemporal_load(src + f * 64);
       if constexpr (NEED_EPI) {
 #pragma unroll
-        for (int pr = 0; pr < TPU / 2; ++pr) load_epi<EPI>(a, (ustart + ui) * (TPU / 2) + pr, m, g, e[pr]);
+        for (int pr = 0; pr < TPU / 2; ++pr) load_epi<EPI>(a, (ustart + ui) * (TPU / 2) + pr, m, g, e[pr], pos_m);
       }
     };
     auto mma = [&](int c, const u32x4* w) {
