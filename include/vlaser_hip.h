@@ -70,7 +70,8 @@ int vlaser_gemm(int epi, const VlaserGemmArgs* args, vl_stream_t stream);
 
 /* NN form: out[M,N] = A[M,K] @ B[K,N], B = args->W row-major with row stride args->ldw ("k-major").  The dgrad of an nn.Linear
  * (dX = dY @ W, autograd of modeling_internvl_chat.py:194-203 / joint_model.py:410-696) reads the forward weight [N_out, K_in] as it
- * is stored: no transposed copy.  Epilogues VL_EPI_NONE (bf16 out) and VL_EPI_PARTIAL (split-K fp32 slabs); K % 64 == 0, N % 8 == 0;
+ * is stored: no transposed copy.  Epilogues VL_EPI_NONE (bf16 out), VL_EPI_F32 and VL_EPI_PARTIAL (split-K fp32 slabs); batched like
+ * vlaser_gemm for NONE / F32 (the attention backward's dP = dO V^T and dQ = dS K read V^T / K as the cache holds them); K % 64 == 0, N % 8 == 0;
  * force_bm: 0 or an LDS-DMA configuration code. */
 int vlaser_gemm_nn(int epi, const VlaserGemmArgs* args, vl_stream_t stream);
 

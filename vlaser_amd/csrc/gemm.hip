@@ -944,24 +944,25 @@ extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
 }
 
 // out[M,N] = A[M,K] @ B[K,N] with B row-major ("k-major": a forward weight [N_out, K_in] read as the B of its own dgrad dX = dY @ W);
-// ldw = row stride of B.  NONE (bf16 out) and PARTIAL (split-K fp32 slabs) epilogues.
+// ldw = row stride of B.  NONE (bf16 out), F32 and PARTIAL (split-K fp32 slabs) epilogues; batched like vlaser_gemm (NONE / F32).
 extern "C" int vlaser_gemm_nn(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(s);
   VL_CHECK(a && a->A && a->W, "vlaser_gemm_nn: null operand");
   VL_CHECK(a->M > 0 && a->N > 0 && a->K > 0 && a->K % BK == 0, "vlaser_gemm_nn: bad shape M=%d N=%d K=%d (K must be a multiple of %d)", a->M, a->N, a->K, BK);
   VL_CHECK(a->N % 8 == 0 && a->lda % 8 == 0 && a->ldw % 8 == 0 && a->ldw >= a->N, "vlaser_gemm_nn: N, lda, ldw must be multiples of 8 and ldw >= N");
   VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm_nn: operands must be 16-byte aligned");
-  VL_CHECK(a->batch <= 1, "vlaser_gemm_nn: batched mode is not supported");
   VL_CHECK(a->force_bm == 0 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1440 || a->force_bm == 1500,
            "vlaser_gemm_nn: force_bm must be 0 or an LDS-DMA configuration code 1100/1200/1300/1440/1500");
+  VL_CHECK(a->batch <= 1 || epi == VL_EPI_NONE || epi == VL_EPI_F32, "vlaser_gemm_nn: batched mode supports the NONE / F32 epilogues");
   switch (epi) {
     case VL_EPI_NONE: VL_CHECK(a->out, "out null"); return launch<VL_EPI_NONE, true>(a, stream);
+    case VL_EPI_F32: VL_CHECK(a->out, "out null"); return launch<VL_EPI_F32, true>(a, stream);
     case VL_EPI_PARTIAL:
       VL_CHECK(a->out_f32 && a->N % 4 == 0, "partial: out_f32 null or N %% 4 != 0");
       VL_CHECK(a->k_splits >= 1 && a->K % (a->k_splits * BK) == 0, "partial: K=%d not divisible by k_splits*64 (k_splits=%d)", a->K, a->k_splits);
       return launch<VL_EPI_PARTIAL, true>(a, stream);
     default: break;
   }
-  vlaser_set_error("vlaser_gemm_nn: epilogue %d is not available in the NN form (NONE / PARTIAL)", epi);
+  vlaser_set_error("vlaser_gemm_nn: epilogue %d is not available in the NN form (NONE / F32 / PARTIAL)", epi);
   return -1;
 }

@@ -101,6 +101,16 @@ def gemm_nn(epi, A, B, out=None, **kw):
     return out
 
 
+def gemm_raw_nn(epi, A, B, out, M, N, K, lda, ldb, ldo, **kw):
+    """Fully explicit NN GEMM call (views / batched operands): out[M,N] = A[M,K] @ B[K,N], B row-major with row stride ldb."""
+    a = L.GemmArgs()
+    a.A, a.W, a.out = A.data_ptr(), B.data_ptr(), out.data_ptr()
+    a.M, a.N, a.K, a.lda, a.ldw, a.ldo = M, N, K, lda, ldb, ldo
+    for k, v in kw.items():
+        setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    L.check(L.lib().vlaser_gemm_nn(epi, C.byref(a), _stream()), 'vlaser_gemm_nn')
+
+
 def gemm_raw(epi, A, W, out, M, N, K, lda, ldw, ldo, **kw):
     """Fully explicit GEMM call (views / batched operands): pointers from the tensors, geometry from the arguments."""
     a = L.GemmArgs()

@@ -232,7 +232,6 @@ class SFTModel:
         self.sc = torch.zeros(nq, S, S, dtype=F32, device=dev)
         self.dP = torch.zeros(nq, S, S, dtype=F32, device=dev)
         self.P, self.dS = z(nq, S, S), z(nq, S, S)
-        self.Vn, self.KT = z(nkv, S, hd), z(nkv, hd, S)
         self.col = torch.zeros(max(2 * I, NQ, C4, H), dtype=F32, device=dev)
         self.sumsq_ws = torch.zeros(1024, dtype=F32, device=dev)
         self.normw_ws = torch.zeros((S + 3) // 4 * H, dtype=F32, device=dev)      # norm-weight gradient partials of rmsnorm_bwd
@@ -447,8 +446,6 @@ class SFTModel:
         dP = self.dP.view(-1)[:nq * S * Sp].view(nq, S, Sp)
         P = self.P.view(-1)[:nq * S * Sp].view(nq, S, Sp)
         dS = self.dS.view(-1)[:nq * S * Sp].view(nq, S, Sp)
-        Vn = self.Vn.view(-1)[:nkv * Sp * hd].view(nkv, Sp, hd)
-        KT = self.KT.view(-1)[:nkv * hd * Sp].view(nkv, hd, Sp)
         sm = self.cache.s_max
         scale = hd ** -0.5
         bucket_of_layer = {}
@@ -473,11 +470,11 @@ class SFTModel:
             # attention backward through materialised per-head score matrices (S is small: 12 x S x S)
             Kc, VTc = self.cache.k[kslot, 0], self.cache.vt[kslot, 0]         # [nkv, s_max, hd], [nkv, hd, s_max]
             ops.gemm_raw(L.EPI_F32, q, Kc, sc, S, S, hd, nq * hd, hd, Sp, batch=nq, a_bs=hd, w_bs=sm * hd, o_bs=S * Sp, w_group=G)     # Q K^T
-            ops.transpose(VTc, Vn, hd, S, sm, hd, hd, nkv, hd * sm, Sp * hd)        # V^T [hd, S] -> V [S, hd]
-            ops.gemm_raw(L.EPI_F32, dao, Vn, dP, S, S, hd, nq * hd, hd, Sp, batch=nq, a_bs=hd, w_bs=Sp * hd, o_bs=S * Sp, w_group=G)   # dO V^T
+            # dP = dO V^T and (below) dQ = dS K in the NN form: V^T [hd, keys] and K [keys, hd] are read as the cache holds them (r01/r02
+            # transposed both per layer); dS is zero beyond the causal range, so cache rows past S only need to be finite
+            ops.gemm_raw_nn(L.EPI_F32, dao, VTc, dP, S, Sp, hd, nq * hd, sm, Sp, batch=nq, a_bs=hd, w_bs=hd * sm, o_bs=S * Sp, w_group=G)   # dO V^T
             ops.attn_bwd_pds(sc, dP, dao, ao, P, dS, nq, S, Sp, hd, scale)         # P = softmax(S), dS = P o (dP - D) * scale
-            ops.transpose(Kc, KT, S, hd, hd, Sp, Sp, nkv, sm * hd, hd * Sp)         # K [S, hd] -> K^T [hd, Sp]
-            ops.gemm_raw(L.EPI_NONE, dS, KT, self.dq, S, hd, Sp, Sp, Sp, nq * hd, batch=nq, a_bs=S * Sp, w_bs=hd * Sp, o_bs=hd, w_group=G)  # dQ = dS K
+            ops.gemm_raw_nn(L.EPI_NONE, dS, Kc, self.dq, S, hd, Sp, Sp, hd, nq * hd, batch=nq, a_bs=S * Sp, w_bs=sm * hd, o_bs=hd, w_group=G)  # dQ = dS K
             # dK[kvh] = sum_g dS[kvh*G+g]^T Q_g, dV[kvh] = sum_g P[kvh*G+g]^T dO_g: contraction along the rows (q) of both operands,
             # summed over the q heads of the kv group, straight from dS / P [head, q, k] and q / dO [q, head*hd]
             # one TN GEMM per Q head (108 workgroups instead of 18 serial ones); the sum over the group happens in rope_bwd_pack
