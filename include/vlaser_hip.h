@@ -64,6 +64,9 @@ typedef struct {
   /* batched GEMM (attention backward through materialised per-head matrices): blockIdx.z = batch index z;
    * A += z*a_bs, out += z*o_bs, W += (z / w_group)*w_bs  (element strides; batch 0/1 = plain GEMM) */
   int batch; long long a_bs, w_bs, o_bs; int w_group;
+  /* VL_EPI_SWIGLU, optional: also keep the bf16 pre-activations [M, N] (gate / up in the packed 16-row interleave, exactly what
+   * VL_EPI_NONE would write) -- the SFT forward saves them for swiglu's backward instead of running the GEMM unfused + a swiglu pass */
+  void* aux_out; int ld_aux;
 } VlaserGemmArgs;
 
 int vlaser_gemm(int epi, const VlaserGemmArgs* args, vl_stream_t stream);

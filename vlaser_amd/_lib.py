@@ -16,7 +16,7 @@ class GemmArgs(C.Structure):
                 ('rope_cos', vp), ('rope_sin', vp), ('pos_ids', vp), ('n_q_heads', i32), ('n_kv_heads', i32),
                 ('s_max', i32), ('tok_per_batch', i32), ('slot_base', i32), ('vq', vp), ('vk', vp), ('vvt', vp),
                 ('vit_heads', i32), ('vit_seq', i32), ('vit_seq_pad', i32), ('q_scale', f32), ('out_f32', vp), ('k_splits', i32),
-                ('force_bm', i32), ('batch', i32), ('a_bs', i64), ('w_bs', i64), ('o_bs', i64), ('w_group', i32)]
+                ('force_bm', i32), ('batch', i32), ('a_bs', i64), ('w_bs', i64), ('o_bs', i64), ('w_group', i32), ('aux_out', vp), ('ld_aux', i32)]
 
 
 class AttnArgs(C.Structure):

@@ -87,6 +87,11 @@ __device__ __forceinline__ void epilogue(const VlaserGemmArgs& a, int m, int n0,
     for (int j = 0; j < 4; ++j) r[j] = round_bf16(silu(round_bf16(v[j]))) * round_bf16(v2[j]);
     u32x2 pk = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
     *reinterpret_cast<u32x2*>(o) = pk;
+    if (a.aux_out) {                             // training forward: the rounded pre-activations, packed [gate16 | up16] like VL_EPI_NONE's output
+      bf16_t* g = reinterpret_cast<bf16_t*>(a.aux_out) + (size_t)m * a.ld_aux + n0;
+      *reinterpret_cast<u32x2*>(g) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(g + 16) = u32x2{pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3])};
+    }
     return;
   }
   if constexpr (EPI == VL_EPI_QKV_ROPE) {

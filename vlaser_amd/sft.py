@@ -325,8 +325,7 @@ class SFTModel:
         sp = ops.gemm_splits(S, H, nq * hd)
         ops.gemm(L.EPI_PARTIAL, ao, v[f'l{i}.wo'], out_f32=self.part, k_splits=sp)
         ops.reduce_norm(h_in, self.part, sp, S, H, h2, x2, norm=1, norm_w=v[f'l{i}.ln_post'], eps=llm.rms_norm_eps)
-        ops.gemm(L.EPI_NONE, x2, v[f'l{i}.wgu'], out=gu)
-        ops.swiglu(gu, act, S, I)
+        ops.gemm(L.EPI_SWIGLU, x2, v[f'l{i}.wgu'], out=act, aux_out=gu, ld_aux=gu.stride(0))      # act + the pre-activations swiglu's backward needs
         return x1, x2, h2, q, ao, gu, act
 
     def _saved(self, i, S):
