@@ -13,6 +13,15 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run on the GPU box with -m gpu)')
 
 
+def pytest_collection_modifyitems(config, items):
+    """A hung kernel or rendezvous must fail ONE test, not eat the whole run: every test gets a generous wall-clock limit
+    (pytest-timeout; the slowest test -- two SFT processes on one GPU -- takes about 80 s)."""
+    if config.pluginmanager.hasplugin('timeout'):
+        for it in items:
+            if it.get_closest_marker('timeout') is None:
+                it.add_marker(pytest.mark.timeout(900))
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN

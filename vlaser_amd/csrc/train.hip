@@ -686,8 +686,10 @@ __global__ void sumsq_final_kernel(const float* __restrict__ partial, int n, flo
 }
 extern "C" int vlaser_sumsq(const void* x, long long n, float* out, float* partial_ws, vl_stream_t s) {
   VL_CHECK(x && out && partial_ws && n > 0 && ((uintptr_t)x & 15) == 0, "vlaser_sumsq: bad args (partial_ws = float[1024] workspace; x 16-byte aligned)");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, n, partial_ws);
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partial_ws, 1024, out);
+  // one workgroup per CU (like AdamW: a narrow window of addresses streams faster, and the launch leaves room for a GEMM on another stream)
+  const int nb = adamw_grid_cap() < 1024 ? adamw_grid_cap() : 1024;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, n, partial_ws);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partial_ws, nb, out);
   VL_LAUNCH_CHECK();
   return 0;
 }
