@@ -100,6 +100,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise VlaserHipError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                                  f'or `make -C vlaser_amd/csrc` -- there is no CPU fallback')
+        # torch first: it ships its own libamdhip64 / libhsa-runtime64, and whichever copy of that soname is mapped first serves the whole
+        # process.  Loading this library before torch maps /opt/rocm's runtime instead, and torch's later device initialisation then ends in
+        # "no ROCm-capable device is detected" (seen with build() followed by smoke() in one process on the GPU box).
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         l.vlaser_last_error.restype = C.c_char_p
         l.vlaser_abi_version.restype = i32
