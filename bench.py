@@ -337,7 +337,9 @@ def main():
                                               '(5 per layer-step), see DESIGN.md section 3'}
             line['roofline'] = {'bound': 'hbm', 'kernel': 'skinny_kernel<NORM,SWIGLU> (action-expert gate/up GEMV, N=17920 K=768, M=4; 307 launches per chunk)',
                                 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                                'traffic': _pmc_traffic(), 'bytes_per_launch': byts, 'us_per_launch': round(avg_ms * 1e3, 3), 'launches_timed': n}
+                                'traffic': _pmc_traffic(), 'traffic_source': {'file': 'profiles/r02o_pmc_dominant_kernel.json', 'measured_in_run': False,
+                                                                        'how': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on tools/pmc/skinny_pmc (torch-free harness, same kernel and shape)'},
+                                'bytes_per_launch': byts, 'us_per_launch': round(avg_ms * 1e3, 3), 'launches_timed': n}
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(vla)
     # ---- SFT line (BASELINE configs[4]) AFTER the headline has been timed: the gradient exchange is the only part of this file that
