@@ -37,7 +37,9 @@ enum {
   VL_EPI_QKV_ROPE = 6,   /* fused q/k/v projection + bias + RoPE + KV-cache write (Qwen2, head_dim 128) */
   VL_EPI_VIT_QKV = 7,    /* fused ViT qkv + bias, q*scale; writes Q,K [T,H,S,64] and V^T [T,H,64,Spad] */
   VL_EPI_F32 = 8,        /* out (float32) = acc   (full-vocab logits) */
-  VL_EPI_PARTIAL = 9     /* split-K: out_f32[ks, m, n] = partial over K slice ks (reduced by vlaser_reduce_norm) */
+  VL_EPI_PARTIAL = 9,    /* split-K: out_f32[ks, m, n] = partial over K slice ks (reduced by vlaser_reduce_norm) */
+  VL_EPI_SWIGLU_BWD = 10 /* vlaser_gemm_nn only: acc = d(act) [M, I]; res = the forward's bf16 pre-activations [M, 2I] (packed [gate16|up16], row
+                            stride ldo); out [M, 2I] = d(gate), d(up) in the same packing -- the dgrad of down_proj with swiglu's backward as its epilogue */
 };
 
 typedef struct {
@@ -73,7 +75,7 @@ int vlaser_gemm(int epi, const VlaserGemmArgs* args, vl_stream_t stream);
 
 /* NN form: out[M,N] = A[M,K] @ B[K,N], B = args->W row-major with row stride args->ldw ("k-major").  The dgrad of an nn.Linear
  * (dX = dY @ W, autograd of modeling_internvl_chat.py:194-203 / joint_model.py:410-696) reads the forward weight [N_out, K_in] as it
- * is stored: no transposed copy.  Epilogues VL_EPI_NONE (bf16 out), VL_EPI_F32 and VL_EPI_PARTIAL (split-K fp32 slabs); batched like
+ * is stored: no transposed copy.  Epilogues VL_EPI_NONE (bf16 out), VL_EPI_F32, VL_EPI_PARTIAL (split-K fp32 slabs) and VL_EPI_SWIGLU_BWD; batched like
  * vlaser_gemm for NONE / F32 (the attention backward's dP = dO V^T and dQ = dS K read V^T / K as the cache holds them); K % 64 == 0, N % 8 == 0;
  * force_bm: 0 or an LDS-DMA configuration code. */
 int vlaser_gemm_nn(int epi, const VlaserGemmArgs* args, vl_stream_t stream);

@@ -38,7 +38,7 @@ class SkinnyArgs(C.Structure):
 
 
 # enums (include/vlaser_hip.h)
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_LS_RES, EPI_RES, EPI_SWIGLU, EPI_QKV_ROPE, EPI_VIT_QKV, EPI_F32, EPI_PARTIAL = range(10)
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_LS_RES, EPI_RES, EPI_SWIGLU, EPI_QKV_ROPE, EPI_VIT_QKV, EPI_F32, EPI_PARTIAL, EPI_SWIGLU_BWD = range(11)
 ATTN_FULL, ATTN_CAUSAL, ATTN_PREFIX = range(3)
 PRO_PLAIN, PRO_NORM, PRO_ATTN = range(3)
 SK_PARTIAL, SK_QKV_ROPE, SK_SWIGLU, SK_F32, SK_BIAS, SK_BIAS_SILU = range(6)

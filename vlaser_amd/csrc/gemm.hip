@@ -287,6 +287,46 @@ __device__ __forceinline__ void epilogue_tile_vit_qkv(const VlaserGemmArgs& a, i
   }
 }
 
+// SWIGLU_BWD for a whole wave tile (NN dgrad of down_proj): acc = d(act); the forward's rounded gate / up pre-activations are read from
+// `res` (packed [gate16 | up16], row stride ldo) up front as 8-byte vectors; d(gate) = d u sig (1 + g (1 - sig)), d(up) = d g sig with
+// d rounded to bf16 first -- the same expressions, in the same order, as the stand-alone swiglu_bwd kernel this epilogue replaces.
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue_tile_swiglu_bwd(const VlaserGemmArgs& a, int m_w, int n_w, int fr, int fq, f32x4 (&acc)[NT][MT]) {
+  const bf16_t* gu = reinterpret_cast<const bf16_t*>(a.res);
+  bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
+  const bool in_range = n_w + NT * 16 <= a.N;              // wave-uniform; a ragged right edge takes the guarded path per fragment
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m_w + mt * 16 + fr;
+    const size_t row = (size_t)min(m, a.M - 1) * a.ldo;
+    u32x2 gv[NT], uv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = min(n_w + nt * 16 + fq * 4, a.N - 4), pg = (n >> 4) * 32 + (n & 15);
+      gv[nt] = *reinterpret_cast<const u32x2*>(gu + row + pg);
+      uv[nt] = *reinterpret_cast<const u32x2*>(gu + row + pg + 16);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n_w + nt * 16 + fq * 4, pg = (n >> 4) * 32 + (n & 15);
+      float dg[4], du[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float g = (j & 1) ? bf16hi_to_f32(gv[nt][j >> 1]) : bf16lo_to_f32(gv[nt][j >> 1]);
+        const float u = (j & 1) ? bf16hi_to_f32(uv[nt][j >> 1]) : bf16lo_to_f32(uv[nt][j >> 1]);
+        const float d = round_bf16(acc[nt][mt][j]);
+        const float sig = 1.0f / (1.0f + __expf(-g));
+        dg[j] = d * u * sig * (1.0f + g * (1.0f - sig));
+        du[j] = d * g * sig;
+      }
+      if (m < a.M && (in_range || n + 3 < a.N)) {
+        *reinterpret_cast<u32x2*>(out + row + pg) = u32x2{pack_bf16x2(dg[0], dg[1]), pack_bf16x2(dg[2], dg[3])};
+        *reinterpret_cast<u32x2*>(out + row + pg + 16) = u32x2{pack_bf16x2(du[0], du[1]), pack_bf16x2(du[2], du[3])};
+      }
+    }
+  }
+}
+
 // Whole wave tile at once for the bf16-row epilogues (NONE / BIAS / BIAS_GELU / BIAS_LS_RES / RES).  The per-fragment epilogue
 // above sits behind lane-divergent `m < M` / `n < N` branches with its bias / residual loads inside them: hipcc turns every
 // fragment into its own basic block with a load and a full `s_waitcnt` (measured on the ViT fc1 shape: the BIAS_GELU epilogue cost
@@ -480,6 +520,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     epilogue_tile_vit_qkv<MT, NT>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc);
     return;
   }
+  if constexpr (EPI == VL_EPI_SWIGLU_BWD) {
+    epilogue_tile_swiglu_bwd<MT, NT>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc);
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m0 + wr * WTM + mt * 16 + fr;
@@ -645,6 +689,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
   }
   if constexpr (EPI == VL_EPI_VIT_QKV) {
     epilogue_tile_vit_qkv<MT, NT>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc);
+    return;
+  }
+  if constexpr (EPI == VL_EPI_SWIGLU_BWD) {
+    epilogue_tile_swiglu_bwd<MT, NT>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc);
     return;
   }
 #pragma unroll
@@ -962,12 +1010,16 @@ extern "C" int vlaser_gemm_nn(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   switch (epi) {
     case VL_EPI_NONE: VL_CHECK(a->out, "out null"); return launch<VL_EPI_NONE, true>(a, stream);
     case VL_EPI_F32: VL_CHECK(a->out, "out null"); return launch<VL_EPI_F32, true>(a, stream);
+    case VL_EPI_SWIGLU_BWD:
+      VL_CHECK(a->out && a->res && a->N % 16 == 0 && a->ldo % 4 == 0 && a->ldo >= 2 * a->N, "swiglu_bwd: out / res null, N %% 16 != 0 or ldo < 2 N");
+      VL_CHECK((((uintptr_t)a->out | (uintptr_t)a->res) & 7) == 0, "swiglu_bwd: out / res must be 8-byte aligned");
+      return launch<VL_EPI_SWIGLU_BWD, true>(a, stream);
     case VL_EPI_PARTIAL:
       VL_CHECK(a->out_f32 && a->N % 4 == 0, "partial: out_f32 null or N %% 4 != 0");
       VL_CHECK(a->k_splits >= 1 && a->K % (a->k_splits * BK) == 0, "partial: K=%d not divisible by k_splits*64 (k_splits=%d)", a->K, a->k_splits);
       return launch<VL_EPI_PARTIAL, true>(a, stream);
     default: break;
   }
-  vlaser_set_error("vlaser_gemm_nn: epilogue %d is not available in the NN form (NONE / F32 / PARTIAL)", epi);
+  vlaser_set_error("vlaser_gemm_nn: epilogue %d is not available in the NN form (NONE / F32 / PARTIAL / SWIGLU_BWD)", epi);
   return -1;
 }

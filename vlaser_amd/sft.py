@@ -457,9 +457,14 @@ class SFTModel:
             kslot = 0 if self.recompute else i
             dact, dgu, dx, dh2, dao = self.dact[:S], self.dgu[:S], self.dx[:S], self.dh2[:S], self.dao[:S]
             # MLP: h3 = h2 + act Wd^T ; act = silu(g) u ; [g|u] = x2 Wgu^T ; x2 = rms(h2) w_post
-            self._dgrad(dh, v[f'l{i}.wdown'], dact, S)
+            if H <= 2048 and os.environ.get('VLASER_SFT_NO_FUSED_SWIGLU_BWD') != '1':
+                # d(act) = dh @ W_down with swiglu's backward as the GEMM epilogue: d(gate), d(up) straight from the accumulators
+                # (the stand-alone pass read d(act) and the pre-activations back and wrote 2 I columns per row)
+                ops.gemm_nn(L.EPI_SWIGLU_BWD, dh, v[f'l{i}.wdown'], out=dgu, res=gu)
+            else:
+                self._dgrad(dh, v[f'l{i}.wdown'], dact, S)
+                ops.swiglu_bwd(gu, dact, dgu, S, I)
             self._wgrad(dh, act, gv[f'l{i}.wdown'], S)
-            ops.swiglu_bwd(gu, dact, dgu, S, I)
             self._dgrad(dgu, v[f'l{i}.wgu'], dx, S)
             self._wgrad(dgu, x2, gv[f'l{i}.wgu'], S)
             ops.rmsnorm_bwd(dx, h2, v[f'l{i}.ln_post'], dh, dh2, S, H, llm.rms_norm_eps, dw_out=gv[f'l{i}.ln_post'], dw_ws=self.normw_ws)
