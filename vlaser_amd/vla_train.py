@@ -154,9 +154,7 @@ class VLATrainer:
         self.rank_ws = z(T, dt=torch.int32)
         self.valid_len = z(1, dt=torch.int32)
         self.pos_vlm, self.pos5 = z(T, dt=torch.int32), z(16, dt=torch.int32)
-        # transposed copies for the dgrad GEMMs (dX = dY @ W)
-        self.wT = {i: dict(wqkv=z(H, NQ), wo=z(nq * hd, H), wgu=z(H, 2 * I), wdown=z(I, H)) for i in range(Lyr)}
-        self.ae2T, self.ae3T = z(2 * H, H), z(H, H)
+        # the dgrad GEMMs read the weights as stored (vlaser_gemm_nn); only the 7-row action decoder keeps a zero-padded transposed copy
         # saved activations of the R expert rows (tiny: R x width per layer)
         self.h_in = z(Lyr + 1, 16, H)
         self.x1, self.x2, self.h2 = z(Lyr, 16, H), z(Lyr, 16, H), z(Lyr, 16, H)
@@ -184,20 +182,14 @@ class VLATrainer:
 
     def _refresh_transposes(self):
         v = self.fp.view
-        for i in range(self.cfg.expert.num_hidden_layers):
-            for nm in ('wqkv', 'wo', 'wgu', 'wdown'):
-                w = v[f'l{i}.{nm}']
-                ops.transpose(w, self.wT[i][nm], w.shape[0], w.shape[1], w.shape[1], w.shape[0])
-        for w, wt in ((v['ae2.w'], self.ae2T), (v['ae3.w'], self.ae3T)):
-            ops.transpose(w, wt, w.shape[0], w.shape[1], w.shape[1], w.shape[0])
         # action decoder [A, H] -> [H, 64] zero padded (contraction axis of the dgrad GEMM must be a multiple of 64)
         self.decT.zero_()
         ops.transpose(v['dec.w'], self.decT, v['dec.w'].shape[0], v['dec.w'].shape[1], v['dec.w'].shape[1], 64)
 
     # ------------------------------------------------------------------ small helpers
-    def _dgrad(self, dY, WT, out, M):
-        """out[M,K] = dY[M,N] @ W[N,K] with W^T [K,N] resident."""
-        ops.gemm(L.EPI_NONE, dY[:M], WT, out=out[:M])
+    def _dgrad(self, dY, W, out, M):
+        """out[M,K] = dY[M,N] @ W[N,K], W as the forward stores it (NN GEMM)."""
+        ops.gemm_nn(L.EPI_NONE, dY[:M], W, out=out[:M])
 
     def _wgrad(self, dY, X, out, M, bias_out=None):
         """out[N,K] = dY[:M]^T @ X[:M] (contraction over the M <= 16 rows)."""
@@ -300,20 +292,19 @@ class VLATrainer:
         ops.rmsnorm_bwd(dhn, h_fin, v['norm'], None, dh[1:R], na, H, ex.rms_norm_eps, dw_out=gv['norm'], dw_ws=self.normw_ws)
         for i in reversed(range(Lyr)):
             h_in, x1, x2, h2, q, ao, gu, act = self.h_in[i, :R], self.x1[i, :R], self.x2[i, :R], self.h2[i, :R], self.q[i, :R], self.ao[i, :R], self.gu[i, :R], self.act[i, :R]
-            wT = self.wT[i]
             dact, dgu, dx, dh2, dao = self.dact, self.dgu, self.dx, self.dh2, self.dao
-            self._dgrad(dh, wT['wdown'], dact, R)
+            self._dgrad(dh, v[f'l{i}.wdown'], dact, R)
             self._wgrad(dh, act, gv[f'l{i}.wdown'], R)
             ops.swiglu_bwd(gu, dact[:R], dgu[:R], R, I)
-            self._dgrad(dgu, wT['wgu'], dx, R)
+            self._dgrad(dgu, v[f'l{i}.wgu'], dx, R)
             self._wgrad(dgu, x2, gv[f'l{i}.wgu'], R)
             ops.rmsnorm_bwd(dx[:R], h2, v[f'l{i}.ln_post'], dh[:R], dh2[:R], R, H, ex.rms_norm_eps, dw_out=gv[f'l{i}.ln_post'], dw_ws=self.normw_ws)
-            self._dgrad(dh2, wT['wo'], dao, R)
+            self._dgrad(dh2, v[f'l{i}.wo'], dao, R)
             self._wgrad(dh2, ao, gv[f'l{i}.wo'], R)
             ops.attn_rows_bwd(q, self.cache.k[i, 0], self.cache.vt[i, 0], dao[:R], ao, self.dq[:R], self.dk[:R], self.dv[:R], R, nq, nkv, self.s_max,
                               n_valid, T, True, scale)
             ops.rope_bwd_pack(self.dq[:R], self.dk[:R], self.dv[:R], self.rope[0], self.rope[1], self.pos5, self.dqkv[:R], R, nq, nkv, kv_per_q_head=False)
-            self._dgrad(self.dqkv, wT['wqkv'], dx, R)
+            self._dgrad(self.dqkv, v[f'l{i}.wqkv'], dx, R)
             self._wgrad(self.dqkv, x1, gv[f'l{i}.wqkv'], R, bias_out=gv[f'l{i}.bqkv'])
             ops.rmsnorm_bwd(dx[:R], h_in, v[f'l{i}.ln_in'], dh2[:R], dh[:R], R, H, ex.rms_norm_eps, dw_out=gv[f'l{i}.ln_in'], dw_ws=self.normw_ws)
             if on_bucket_ready and (i == 0 or self.bucket_of_layer[i - 1] != self.bucket_of_layer[i]):
@@ -327,12 +318,12 @@ class VLATrainer:
         da = dh[1:R]
         self._wgrad(da, self.e2, gv['ae3.w'], na, bias_out=gv['ae3.b'])
         de2 = self.dx
-        self._dgrad(da, self.ae3T, de2, na)
+        self._dgrad(da, v['ae3.w'], de2, na)
         dz2 = self.dh2
         ops.silu_bwd(self.z2[:na], de2[:na], dz2[:na])
         self._wgrad(dz2, self.xcat, gv['ae2.w'], na, bias_out=gv['ae2.b'])
         dxc = torch.zeros(16, 2 * H, dtype=BF, device=dev)
-        self._dgrad(dz2, self.ae2T, dxc, na)
+        self._dgrad(dz2, v['ae2.w'], dxc, na)
         dl1 = dxc[:na, H:].contiguous()                                     # gradient of linear_1's output (the time half has no parameters)
         a8 = torch.zeros(8, 8, dtype=BF, device=dev); a8[:na, :A] = self.psi[:na].to(BF)
         l8 = torch.zeros(8, H, dtype=BF, device=dev); l8[:na] = dl1
