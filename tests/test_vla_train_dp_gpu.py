@@ -1,0 +1,69 @@
+"""Data-parallel VLA flow-matching training step (the reference trains with DDP: train.py:470-482): two processes on one GPU over gloo,
+one sample each.  The bucketed exchange averages the bf16 gradients in fp32 -- exactly what a single process does when it accumulates the
+two samples -- so after two optimizer steps both ranks must hold bit-identical parameters, equal to the single-process `step([a, b])`.
+Clipping is off here: with it the squared norm is summed per shard and all-reduced, i.e. in another order than on one rank, and the clip
+factor may differ in its last bit (the clipped exchange itself is covered by tests/test_sft_dp_gpu.py on the same dp code)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def _case(case):
+    d = np.load(os.path.join(GOLDEN, 'g7_vla.npz'))
+    f = np.load(os.path.join(GOLDEN, 'g10_flow_matching.npz'))
+    pv = torch.randn(1, 3, 448, 448, generator=torch.Generator().manual_seed(int(d[f'{case}_seed'])))
+    return dict(input_ids=torch.from_numpy(d[f'{case}_input_ids']), pixel_values=pv, proprios=torch.from_numpy(d[f'{case}_proprio']),
+                actions=torch.from_numpy(f[f'{case}_actions']), t=torch.from_numpy(f[f'{case}_t']), x0=torch.from_numpy(f[f'{case}_x0']))
+
+
+def _trainer(pg=None):
+    from vlaser_amd import config as C, synth
+    from vlaser_amd.vla_train import VLATrainer
+    torch.set_grad_enabled(False)
+    vla = C.VLAConfig(base=C.truncated(C.vlaser_2b(), 2, 2))
+    sd = synth.vla_state_dict(vla, with_head=True)
+    m = VLATrainer(vla, lr=1e-3, max_grad_norm=0.0, bucket_layers=1, process_group=pg)
+    m.load_state_dict(sd)
+    return m
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    m = _trainer(dist.group.WORLD)
+    assert m.world == 2 and m.dp_active and len(m.buckets) >= 2
+    smp = _case('ab'[rank])
+    losses = [float(m.step([smp]).loss) for _ in range(2)]
+    torch.cuda.synchronize()
+    torch.save({'losses': losses, 'p': {k: v.cpu() for k, v in m.state_dict().items()}}, os.path.join(out_dir, f'rank{rank}.pt'))      # (the flat buffer's padding depends on the world size)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_equals_single_process_accumulation(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29800 + (os.getpid() % 50) * 2
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'rank0.pt'), torch.load(tmp_path / 'rank1.pt')
+    assert r0['p'].keys() == r1['p'].keys() and all(torch.equal(r0['p'][k], r1['p'][k]) for k in r0['p']), 'ranks differ'      # ZeRO-1 shards all-gathered
+    m = _trainer()
+    a, b = _case('a'), _case('b')
+    outs = [m.step([a, b]) for _ in range(2)]
+    torch.cuda.synchronize()
+    ref = {k: v.cpu() for k, v in m.state_dict().items()}
+    for k in ref:                                                 # mean of two ranks' gradients == accumulation of the two samples
+        assert torch.equal(ref[k], r0['p'][k]), (k, float((ref[k].float() - r0['p'][k].float()).abs().max()))
+    # each rank reported its own sample's loss; the single process reports their mean
+    for s in range(2):
+        assert abs(0.5 * (r0['losses'][s] + r1['losses'][s]) - float(outs[s].loss)) < 1e-5
