@@ -356,7 +356,7 @@ def main():
                 if rank == 0:
                     line['sft'] = {'error': 'SFT sub-bench did not finish within 420 s (a rank failed or the exchange hung); headline line printed by the watchdog'}
                     print(json.dumps(line), flush=True)
-                os._exit(0)                                      # every rank leaves, so the launcher sees a clean exit
+                os._exit(3)                                      # the headline is out, but a hung exchange / dead peer is a FAILED run: non-zero on every rank
             watchdog = threading.Timer(420.0 if rank == 0 else 450.0, _bail)
             watchdog.daemon = True
             watchdog.start()
@@ -377,6 +377,8 @@ def main():
             if not a.no_8b:
                 line['qa_8b'] = qa8b_bench(local)
     _finish(dist, line if rank == 0 else None)
+    if isinstance(sft_line, dict) and 'error' in sft_line:
+        sys.exit(3)                                              # the headline line is out; a failed SFT sub-bench is still a failed run
 
 
 def _free_port():
@@ -388,7 +390,7 @@ def _free_port():
 def _spawn_ranks(n):
     """Parent of `python bench.py --gpus N` (N > 1, no RANK in the environment): start N worker ranks through
     torch.distributed.run as a CHILD process (never an exec: see the GPU-box rules), relay rank 0's JSON line, and return
-    non-zero if any rank failed.  The parent itself makes no GPU call."""
+    the launcher's exit code (non-zero if any rank failed or the SFT watchdog fired, even when the line was printed).  The parent itself makes no GPU call."""
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
@@ -408,7 +410,7 @@ def _spawn_ranks(n):
         return rc or 1
     if rc != 0:
         print(f'bench.py: {n}-rank run printed its line but exited with rc {rc}', file=sys.stderr)
-    return 0
+    return rc
 
 
 def _dry_run(rank, world):
@@ -424,6 +426,9 @@ def _dry_run(rank, world):
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({'metric': 'action_chunks_per_sec', 'value': 0.0, 'n_gpus': world, 'ranks_seen': n, 'dry_run': True}), flush=True)
+    rc = int(os.environ.get('VLASER_BENCH_DRYRUN_EXIT', '0'))      # test hook: a rank that fails AFTER the line was printed
+    if rc and rank == world - 1:
+        sys.exit(rc)
 
 
 def batched_chunks(vla, dev, steps):

@@ -39,3 +39,12 @@ def test_world_mismatch_fails_loudly():
     e.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     p = subprocess.run([sys.executable, BENCH, '--gpus', '4', '--dry-run'], env=e, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0 and 'WORLD_SIZE=1' in (p.stderr + p.stdout)
+
+
+def test_failed_rank_after_the_line_is_a_failed_run():
+    """a rank that dies (or the SFT watchdog firing) after rank 0 printed its line must not be reported as success."""
+    e = _env()
+    e['VLASER_BENCH_DRYRUN_EXIT'] = '3'
+    p = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--dry-run'], env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert _last_json(p.stdout)['n_gpus'] == 2          # the line is still relayed

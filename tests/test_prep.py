@@ -140,3 +140,40 @@ def test_env_adapter_vs_reference(golden_dir):
             out = ad.postprocess(a)
             np.testing.assert_allclose(out, ref, rtol=0, atol=1e-12)
             assert set(np.unique(out[:, -1])) <= {-1.0, 1.0}
+
+
+def test_check_block_mask_accepts_only_the_descriptor_pattern():
+    """VLATrainer.forward_backward validates a dense causal_mask instead of ignoring it."""
+    from vlaser_amd import prep
+    am = torch.zeros(2, 384, dtype=torch.long)
+    am[0, :277] = 1
+    am[1, :] = 1
+    m, _, _, _ = prep.build_causal_mask_and_position_ids(am, torch.float32)
+    prep.check_block_mask(m, [277, 384])
+    bad = m.clone()
+    bad[0, 0, 385, 100] = torch.finfo(torch.float32).min          # an action row that cannot see a valid prefix key
+    with pytest.raises(ValueError):
+        prep.check_block_mask(bad, [277, 384])
+    with pytest.raises(ValueError):
+        prep.check_block_mask(m, [276, 384])                      # disagrees with the pad count
+    dc = m.clone()
+    dc[0, 0, 300, 5] = 0                                          # rows of padded positions are "don't care"
+    prep.check_block_mask(dc, [277, 384])
+
+
+def test_split_batch_length_from_labels_and_mask():
+    """id 0 is a real Qwen token; a sample that ENDS in it keeps its trailing supervised positions."""
+    from vlaser_amd import config as C
+    from vlaser_amd.sft import SFTModel
+    m = object.__new__(SFTModel)                                  # host-side logic only: no GPU needed
+    m.cfg = C.truncated(C.vlaser_2b(), 1, 1)
+    m.img_context_token_id = m.cfg.img_context_token_id
+    ids = torch.tensor([[5, 6, 7, 0], [5, 6, 0, 0]])
+    lab = torch.tensor([[-100, 6, 7, 0], [-100, 6, -100, -100]])
+    pv = torch.zeros(2, 3, 448, 448)
+    flags = torch.zeros(2, 1, dtype=torch.long)                   # text-only samples: one dummy tile each
+    out = m._split_batch(pv, ids, lab, flags)
+    assert [o[1].shape[1] for o in out] == [4, 2] and [o[4] for o in out] == [3, 1]
+    am = torch.tensor([[1, 1, 1, 1], [1, 1, 1, 0]])               # the collator's mask wins when given
+    out = m._split_batch(pv, ids, lab, flags, am)
+    assert [o[1].shape[1] for o in out] == [4, 3]

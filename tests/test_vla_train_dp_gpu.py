@@ -47,6 +47,33 @@ def _worker(rank, world, port, out_dir):
     losses = [float(m.step([smp]).loss) for _ in range(2)]
     torch.cuda.synchronize()
     torch.save({'losses': losses, 'p': {k: v.cpu() for k, v in m.state_dict().items()}}, os.path.join(out_dir, f'rank{rank}.pt'))      # (the flat buffer's padding depends on the world size)
+    # ---- resume at world 2: rank 0 writes the reference-layout step file, EVERY rank its own optimizer shard; a fresh trainer
+    # that loads them continues bit for bit (third step == the uninterrupted third step), and a shard of another rank / world is refused
+    from vlaser_amd import config as C, synth
+    frozen = synth.vla_state_dict(C.VLAConfig(base=C.truncated(C.vlaser_2b(), 2, 2)), with_head=True)
+    ck = os.path.join(out_dir, 'step2.pt')
+    m.save_checkpoint(ck, frozen)
+    dist.barrier()
+    assert os.path.exists(ck) and all(os.path.exists(f'{ck}.optimizer_rank{r:05d}_of_00002.pt') for r in range(2))
+    m.step([smp])
+    torch.cuda.synchronize()
+    want = {k: v.cpu() for k, v in m.state_dict().items()}
+    want_m, want_v, want_master = m.m.cpu(), m.v.cpu(), m.master.cpu()
+    r = _trainer(dist.group.WORLD)
+    r.load_checkpoint(ck)
+    assert r.step_count == 2
+    r.step([smp])
+    torch.cuda.synchronize()
+    got = r.state_dict()
+    assert all(torch.equal(want[k], got[k].cpu()) for k in want), 'resumed run diverged'
+    assert torch.equal(want_m, r.m.cpu()) and torch.equal(want_v, r.v.cpu()) and torch.equal(want_master, r.master.cpu())
+    os.replace(f'{ck}.optimizer_rank{rank:05d}_of_00002.pt', f'{ck}.keep{rank}')
+    dist.barrier()
+    try:
+        _trainer(dist.group.WORLD).load_checkpoint(ck)
+        raise AssertionError('a missing optimizer shard must raise')
+    except FileNotFoundError:
+        pass
     dist.barrier()
     dist.destroy_process_group()
 

@@ -205,6 +205,26 @@ def mask_to_descriptor(image_text_proprio_mask, max_image_text_tokens=384):
     return valid
 
 
+def check_block_mask(causal_mask, valid_len, max_image_text_tokens=384, num_proprio_tokens=1, num_action_tokens=4):
+    """Raise unless the dense mask [B,1,L,L] (L = T + proprio + action) has EXACTLY the visibility pattern that
+    `build_causal_mask_and_position_ids` derives from `valid_len` -- the only pattern the (valid_len, blk_start) descriptors of the
+    kernels can express (pizero_internvl.py:517-587).  Rows of padded image/text positions are "don't care" (nobody attends to them)."""
+    B = causal_mask.shape[0]
+    vl = [int(x) for x in torch.as_tensor(valid_len).reshape(-1).tolist()]
+    am = torch.zeros(B, max_image_text_tokens, dtype=torch.long)
+    for b, c in enumerate(vl):
+        am[b, :c] = 1
+    want, _, _, _ = build_causal_mask_and_position_ids(am, torch.float32, max_image_text_tokens, num_proprio_tokens, num_action_tokens)
+    got = causal_mask.detach().to('cpu')
+    if got.shape != want.shape:
+        raise ValueError(f'causal_mask has shape {tuple(got.shape)}, expected {tuple(want.shape)}')
+    for b, c in enumerate(vl):
+        rows = torch.cat([torch.arange(c), torch.arange(max_image_text_tokens, want.shape[-1])])      # valid prefix rows + proprio / action rows
+        if not torch.equal(got[b, 0, rows] == 0, want[b, 0, rows] == 0):
+            raise ValueError('causal_mask is not the prefix + trailing-block mask of build_causal_mask_and_position_ids for this pad count: '
+                             'the kernels express visibility as (valid_len, blk_start) descriptors and cannot honour it')
+
+
 # ------------------------------------------------------------------------------------------------ WidowX adapter
 def normalize_bound(x, lo, hi, clip_min=-1.0, clip_max=1.0, eps=1e-8):
     """env_adapter/base.py:8-31: map [p01, p99] -> [-1, 1] and clip."""

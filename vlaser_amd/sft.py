@@ -521,6 +521,7 @@ class SFTModel:
         """Single rank: bucket b's share of the squared gradient norm as soon as its gradients are complete, on the optimizer stream
         (a one-workgroup-per-CU streaming kernel under the backward's GEMMs) instead of a 0.6 ms pass between backward and AdamW.
         Buckets complete in index order, so the partial sums are added in the same order as the loop in optimizer_step."""
+        self._norm_buckets_seen = getattr(self, '_norm_buckets_seen', 0) + 1
         ev = torch.cuda.Event()
         ev.record()
         with torch.cuda.stream(self.opt_stream):
@@ -605,19 +606,22 @@ class SFTModel:
         learning rate follows the launcher's cosine schedule."""
         return self.train_step([(pixel_values, input_ids, labels, image_flags)], lr=lr, total_steps=total_steps)
 
-    def _split_batch(self, pixel_values, input_ids, labels, image_flags):
+    def _split_batch(self, pixel_values, input_ids, labels, image_flags, attention_mask=None):
         """A collated per-device batch (pad_data_collator.py:57-116: ids right-padded with 0, labels with -100, tiles of all samples
         concatenated, `image_flags` 0 for dummy tiles) -> its samples, each trimmed to its own length, with the number of supervised
-        positions R_b (CrossEntropyLoss averages over ALL supervised tokens of the batch: sample b weighs R_b / sum R)."""
+        positions R_b (CrossEntropyLoss averages over ALL supervised tokens of the batch: sample b weighs R_b / sum R).
+        A sample's length is the collator's `attention_mask` when given; otherwise the last position that holds a non-pad id OR a
+        supervised label (id 0 is a real Qwen token, "!": a sample ending in it must keep its trailing labels)."""
         ids_h = input_ids.detach().to('cpu', torch.int64)
         lab_h = labels.detach().to('cpu', torch.int64)
+        am_h = None if attention_mask is None else attention_mask.detach().to('cpu').reshape(ids_h.shape) != 0
         B = ids_h.shape[0]
         nt = self.cfg.num_image_token
         flags = None if image_flags is None else image_flags.detach().to('cpu').reshape(-1)
         T = pixel_values.shape[0]
         out, t0 = [], 0
         for b in range(B):
-            nz = (ids_h[b] != 0).nonzero().flatten()
+            nz = (am_h[b] if am_h is not None else ((ids_h[b] != 0) | (lab_h[b] != -100))).nonzero().flatten()
             Lb = int(nz[-1]) + 1 if nz.numel() else 1
             need = int((ids_h[b, :Lb] == self.img_context_token_id).sum()) // nt          # real tiles of this sample
             t1, got = t0, 0
@@ -648,7 +652,7 @@ class SFTModel:
 
     def train_step(self, micro_batches, lr=None, total_steps=None):
         """One optimizer step over `len(micro_batches)` gradient-accumulation micro-batches, each a per-device batch
-        `(pixel_values, input_ids [B,S], labels [B,S], image_flags)` -- the reference launcher's PER_DEVICE_BATCH_SIZE x GRADIENT_ACC
+        `(pixel_values, input_ids [B,S], labels [B,S], image_flags[, attention_mask])` -- the reference launcher's PER_DEVICE_BATCH_SIZE x GRADIENT_ACC
         (…2nd_finetune_full.sh:5-6,49-50).  HF Trainer semantics: each micro-batch's loss is the mean over its supervised tokens,
         divided by the number of accumulation steps; gradients add up.  The kernels run one sample at a time, so sample b of a
         micro-batch enters with weight (R_b / R_batch) / n_micro; partial sums live in an fp32 accumulator."""
@@ -662,7 +666,7 @@ class SFTModel:
             if ids.shape[0] == 1 and GA == 1:
                 work.append((pv, ids, lab, fl, 1.0))
                 continue
-            smp = self._split_batch(pv, ids, lab, fl)
+            smp = self._split_batch(pv, ids, lab, fl, mb[4] if len(mb) > 4 else None)
             Rt = sum(x[4] for x in smp)
             for (pvb, idb, lbb, flb, Rb) in smp:
                 work.append((pvb, idb, lbb, flb, (Rb / Rt if Rt else 0.0) / GA))
@@ -670,9 +674,13 @@ class SFTModel:
 
     def _run_weighted(self, work, lr):
         """Samples (pixel_values, ids, labels, image_flags, weight) -> accumulated weighted gradients -> exchange -> optimizer step."""
+        self._norm_early = False                   # only trusted when THIS step's backward queued every bucket's partial norm (below)
         if len(work) == 1 and work[0][4] == 1.0:
-            self._norm_early = not self.dp_active and self.overlap_optimizer and os.environ.get('VLASER_SFT_NO_EARLY_NORM') != '1'
-            loss = self.forward_backward(*work[0][:4], on_bucket_ready=self._norm_bucket if self._norm_early else self._exchange_bucket)
+            early = not self.dp_active and self.overlap_optimizer and os.environ.get('VLASER_SFT_NO_EARLY_NORM') != '1'
+            self._norm_buckets_seen = 0
+            loss = self.forward_backward(*work[0][:4], on_bucket_ready=self._norm_bucket if early else self._exchange_bucket)
+            # a forward_backward that raised never gets here, and one that returned must have signalled every bucket
+            self._norm_early = early and self._norm_buckets_seen == len(self.buckets)
         else:
             if self.gacc is None:
                 self.gacc = torch.zeros(self.fp.n, dtype=F32, device=self.device)

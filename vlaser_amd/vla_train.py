@@ -26,7 +26,7 @@ from types import SimpleNamespace
 import torch
 
 from . import _lib as L
-from . import dp, ops
+from . import dp, ops, prep
 from .config import VLAConfig
 from .engine import BF, KVCache, PrefillBuffers, QwenStack, VitEngine, prefill_begin, prefill_layer
 from .pizero import canonicalize_vla_state_dict
@@ -213,6 +213,12 @@ class VLATrainer:
         v, gv = self.fp.view, self.fp.gview
         ids_h = input_ids.detach().to('cpu', torch.int64).reshape(1, T)
         n_valid = int((ids_h != cfg.base.pad_token_id).sum())
+        # visibility is expressed as (valid_len, blk_start) descriptors: the prompt must be strictly right-padded, and a dense mask, when
+        # given, must be exactly the block mask of that pad count (`PiZero.forward` would honour any mask; this build refuses the others)
+        if n_valid < T and bool((ids_h[0, :n_valid] == cfg.base.pad_token_id).any()):
+            raise ValueError('input_ids must be right-padded: pad tokens inside the valid prefix are not supported')
+        if causal_mask is not None:
+            prep.check_block_mask(causal_mask, [n_valid], T, 1, na)
         tval = float(t.reshape(-1)[0])
         sig = cfg.flow_sig_min
         # ---- frozen prefix: ViT -> projector -> embeddings -> VLM layers (inference kernels), K / V^T of every layer cached
@@ -416,27 +422,43 @@ class VLATrainer:
     def named_grads(self):
         return self.state_dict(grads=True)
 
+    def _opt_shard_path(self, path):
+        return f'{path}.optimizer_rank{self.rank:05d}_of_{self.world:05d}.pt'
+
     def save_checkpoint(self, path, frozen_sd, cnt_batch=0):
-        """`step{N}.pt` of the reference trainer (train.py:639-672): the full model under the reference's key names (trained expert group
-        from the flat buffer + the frozen VLM tensors `frozen_sd` as loaded) + this rank's optimizer shard for a bit-identical resume."""
+        """`step{N}.pt` of the reference trainer (train.py:639-672): RANK 0 writes the full model under the reference's key names (trained
+        expert group from the flat buffer + the frozen VLM tensors `frozen_sd` as loaded); EVERY rank writes its ZeRO-1 shard of the fp32
+        masters + AdamW moments next to it (`<path>.optimizer_rank{r}_of_{w}.pt`, as SFTModel.save_checkpoint does) for a bit-identical
+        resume.  Call it on all ranks."""
         from .pizero import save_vla_checkpoint
-        sd = {k: v for k, v in canonicalize_vla_state_dict(frozen_sd).items() if not k.startswith(('action_expert.model.', 'action_encoder.', 'proprio_encoder.', 'action_decoder.'))}
-        sd.update(self.state_dict())
         if self.dp_active:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
-        save_vla_checkpoint(path, sd, cnt_update=self.step_count, cnt_batch=cnt_batch,
-                            extra={'vlaser_amd_optimizer': {'rank': self.rank, 'world': self.world, 'step_count': self.step_count, 'master': self.master.cpu(),
-                                                            'exp_avg': self.m.cpu(), 'exp_avg_sq': self.v.cpu()}})
+        if self.rank == 0:
+            sd = {k: v for k, v in canonicalize_vla_state_dict(frozen_sd).items() if not k.startswith(('action_expert.model.', 'action_encoder.', 'proprio_encoder.', 'action_decoder.'))}
+            sd.update(self.state_dict())
+            save_vla_checkpoint(path, sd, cnt_update=self.step_count, cnt_batch=cnt_batch)
+        torch.save({'rank': self.rank, 'world': self.world, 'shards': self.shards, 'step_count': self.step_count, 'master': self.master.cpu(),
+                    'exp_avg': self.m.cpu(), 'exp_avg_sq': self.v.cpu()}, self._opt_shard_path(path))
 
-    def load_checkpoint(self, path):
+    def load_checkpoint(self, path, resume_optimizer=True):
+        """Weights from the reference-layout `.pt`; with `resume_optimizer` also this rank's optimizer shard -- a missing shard file or one
+        written for another world size / bucket layout raises (resuming with zero moments would silently change the run).  Pass
+        `resume_optimizer=False` to start a fresh optimizer from released weights."""
         data = torch.load(path, map_location='cpu', weights_only=False)
         self.load_state_dict(data['model'])
-        st = data.get('vlaser_amd_optimizer')
-        if st is not None and st['world'] == self.world and st['rank'] == self.rank:
-            self.step_count = st['step_count']
-            self.master.copy_(st['master']); self.m.copy_(st['exp_avg']); self.v.copy_(st['exp_avg_sq'])
-            for (lo, hi, _), o in zip(self.shards, self.shard_off):
-                if hi > lo:
-                    self.fp.p[lo:hi].copy_(self.master[o:o + hi - lo].to(BF))
-            self._refresh_transposes()
+        if not resume_optimizer:
+            return self
+        sp = self._opt_shard_path(path)
+        if not os.path.exists(sp):
+            raise FileNotFoundError(f'{sp}: no optimizer shard for rank {self.rank} of {self.world} (resume_optimizer=False loads the weights only)')
+        st = torch.load(sp, map_location='cpu', weights_only=False)
+        if st['world'] != self.world or st['rank'] != self.rank or [tuple(x) for x in st['shards']] != [tuple(x) for x in self.shards]:
+            raise ValueError(f"optimizer shard was written for rank {st['rank']} of {st['world']} / another bucket layout")
+        self.step_count = st['step_count']
+        self.master.copy_(st['master']); self.m.copy_(st['exp_avg']); self.v.copy_(st['exp_avg_sq'])
+        for (lo, hi, _), o in zip(self.shards, self.shard_off):
+            if hi > lo:
+                self.fp.p[lo:hi].copy_(self.master[o:o + hi - lo].to(BF))
+        # (the other ranks' slices of fp.p are the checkpoint's bf16 weights = bf16(their masters): rank 0 saved them after the all-gather)
+        self._refresh_transposes()
         return self
