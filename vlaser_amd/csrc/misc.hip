@@ -475,6 +475,81 @@ extern "C" int vlaser_cast_f32_bf16(const float* x, void* y, long long n, vl_str
   return 0;
 }
 
+// uint8 image -> normalised bf16 pixel_values [N,3,H,W] on the device: the host hands over 1 byte per sample instead of a
+// 4-byte fp32 tensor that then goes through cast_f32_bf16.  Arithmetic = the reference's, in its order, in fp32 (IEEE division), rounded once:
+//   mode 0  InternVLAProcessor (processing.py:51-63,303-311): (u8 * (1/255) - mean) / std
+//   mode 1  torchvision ToTensor + Normalize (dataset.py:293-300): (u8 / 255 - mean) / std
+// layout 0: planar [N,3,H,W] (the VLA processor's input); 1: interleaved [N,H,W,3] (PIL / numpy tiles).  Four pixels per thread.
+__global__ __launch_bounds__(256) void normalize_u8_kernel(const uint8_t* __restrict__ in, bf16_t* __restrict__ out, int hw, int layout, int mode,
+                                                           float m0, float m1, float m2, float s0, float s1, float s2, size_t total4) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  const int hw4 = hw >> 2;
+  const float r255 = (float)(1.0 / 255.0);
+  for (; i < total4; i += stride) {
+    const size_t plane = i / hw4;                  // (n, c)
+    const int p4 = (int)(i - plane * hw4);         // group of 4 pixels inside the plane
+    const int c = (int)(plane % 3);
+    const size_t n = plane / 3;
+    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    uint8_t px[4];
+    if (layout == 0) {
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(in + plane * hw + (size_t)p4 * 4);
+      px[0] = w & 255; px[1] = (w >> 8) & 255; px[2] = (w >> 16) & 255; px[3] = w >> 24;
+    } else {
+      const uint8_t* src = in + (n * hw + (size_t)p4 * 4) * 3 + c;
+      px[0] = src[0]; px[1] = src[3]; px[2] = src[6]; px[3] = src[9];
+    }
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x = mode == 0 ? (float)px[j] * r255 : (float)px[j] / 255.0f;
+      v[j] = (x - mean) / sd;
+    }
+    *reinterpret_cast<u32x2*>(out + plane * hw + (size_t)p4 * 4) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  }
+}
+extern "C" int vlaser_normalize_u8(const void* in_u8, void* out_bf16, int n_img, int hw, int layout, int mode, const float* mean3, const float* std3,
+                                   vl_stream_t s) {
+  VL_CHECK(in_u8 && out_bf16 && mean3 && std3 && n_img > 0 && hw > 0 && hw % 4 == 0, "vlaser_normalize_u8: bad args (H*W must be a multiple of 4)");
+  VL_CHECK((layout == 0 || layout == 1) && (mode == 0 || mode == 1), "vlaser_normalize_u8: layout / mode must be 0 or 1");
+  VL_CHECK(((uintptr_t)in_u8 & 3) == 0 && ((uintptr_t)out_bf16 & 7) == 0, "vlaser_normalize_u8: alignment");
+  const size_t total4 = (size_t)n_img * 3 * (hw / 4);
+  const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(normalize_u8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const uint8_t*)in_u8, (bf16_t*)out_bf16, hw, layout, mode,
+                     mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], total4);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// EMA / SWA of the trained parameters (train.py:524-528, model_averaging.py:8-72 = torch.optim.swa_utils.AveragedModel): one streaming pass
+// over the rank's fp32 master shard.  first: avg = p (AveragedModel copies on its first update); else avg += (p - avg) * c with
+// c = 1 - decay (EMA, get_ema_multi_avg_fn: lerp) or 1 / (n_averaged + 1) (SWA).  One workgroup per CU, grid-stride (lesson 22).
+__global__ __launch_bounds__(256) void avg_update_kernel(float* __restrict__ avg, const float* __restrict__ p, size_t n4, size_t n, float c, int first) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (; i < n4; i += stride) {
+    const f32x4 pv = reinterpret_cast<const f32x4*>(p)[i];
+    f32x4 av = reinterpret_cast<f32x4*>(avg)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) av[j] = first ? pv[j] : fmaf(c, pv[j] - av[j], av[j]);
+    reinterpret_cast<f32x4*>(avg)[i] = av;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t k = (n4 << 2) + threadIdx.x;
+    avg[k] = first ? p[k] : fmaf(c, p[k] - avg[k], avg[k]);
+  }
+}
+extern "C" int vlaser_avg_update(float* avg, const float* p, long long n, float c, int first, vl_stream_t s) {
+  VL_CHECK(avg && p && n > 0, "vlaser_avg_update: bad args");
+  VL_CHECK(((uintptr_t)avg & 15) == 0 && ((uintptr_t)p & 15) == 0, "vlaser_avg_update: alignment");
+  const size_t n4 = (size_t)n >> 2;
+  const int blocks = (int)((n4 + 255) / 256 < 256 ? (n4 + 255) / 256 + 1 : 256);
+  hipLaunchKernelGGL(avg_update_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, avg, p, n4, (size_t)n, c, first);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- cross entropy rows
 // loss_row[r] = logsumexp(logits[r,:]) - logits[r,label]  (0 when label == ignore_index); one block per row.
 // CrossEntropyLoss of modeling_internvl_chat.py:231-243 = sum(loss_row) / count(label != -100).

@@ -410,6 +410,34 @@ def cast_f32_bf16(x, y):
     L.check(L.lib().vlaser_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), 'vlaser_cast_f32_bf16')
 
 
+_NORM_CONST = {}
+
+
+def normalize_u8(img_u8, out, mean, std, layout='chw', mode='vla'):
+    """uint8 images -> normalised bf16 pixel_values on the device.  img_u8: [N,3,H,W] (layout 'chw') or [N,H,W,3] ('hwc'), contiguous,
+    on the GPU; out: bf16 [N,3,H,W].  mode 'vla' = InternVLAProcessor's (u8 * (1/255) - mean) / std, 'totensor' = torchvision's
+    (u8 / 255 - mean) / std (see include/vlaser_hip.h)."""
+    assert img_u8.dtype == torch.uint8 and img_u8.is_cuda and img_u8.is_contiguous() and img_u8.dim() == 4
+    N = img_u8.shape[0]
+    H, W = (img_u8.shape[2], img_u8.shape[3]) if layout == 'chw' else (img_u8.shape[1], img_u8.shape[2])
+    assert (img_u8.shape[1] if layout == 'chw' else img_u8.shape[3]) == 3
+    _chk(out)
+    assert out.numel() == N * 3 * H * W
+    key = (tuple(mean), tuple(std))
+    if key not in _NORM_CONST:
+        _NORM_CONST[key] = ((C.c_float * 3)(*mean), (C.c_float * 3)(*std))
+    m3, s3 = _NORM_CONST[key]
+    L.check(L.lib().vlaser_normalize_u8(img_u8.data_ptr(), out.data_ptr(), N, H * W, 0 if layout == 'chw' else 1, 0 if mode == 'vla' else 1, m3, s3,
+                                        _stream()), 'vlaser_normalize_u8')
+    return out
+
+
+def avg_update(avg, p, c, first):
+    """avg (fp32) = p on the first update, else avg += (p - avg) * c (EMA / SWA of the fp32 master shard)."""
+    assert avg.dtype == torch.float32 and p.dtype == torch.float32 and avg.numel() == p.numel()
+    L.check(L.lib().vlaser_avg_update(avg.data_ptr(), p.data_ptr(), avg.numel(), c, int(first), _stream()), 'vlaser_avg_update')
+
+
 # ------------------------------------------------------------------------------------------------ SFT (backward / optimizer)
 def gemm_tn(At, Wt, out, K=None):
     """out[M,N] = At[:K]^T @ Wt[:K] (bf16): At [K,M], Wt [K,N] row-major views (row strides honoured)."""

@@ -4,6 +4,7 @@
   infer_action(input_ids[B,384] i64, pixel_values[B*n,3,448,448], image_text_proprio_mask[B,1,385,385],
                action_mask[B,1,4,389], vlm_position_ids[B,384], proprio_position_ids[B,1],
                action_position_ids[B,4], proprios[B,1,7], noise=None, generator=None) -> [B,4,7]
+               (pixel_values: normalised fp32 / bf16 as the reference passes them, or the raw uint8 observation -- normalised on the device)
   build_causal_mask_and_position_ids(attention_mask, dtype), split_full_mask_into_submasks(mask)
 
 Extensions over the reference: an explicit `noise` / `generator` argument (the reference draws torch.randn inside
@@ -89,6 +90,20 @@ def save_vla_checkpoint(path, sd, cnt_update=0, cnt_batch=0, extra=None):
     data = {'cnt_update': cnt_update, 'cnt_batch': cnt_batch, 'model': {k: v.detach().cpu() for k, v in reference_vla_state_dict(sd).items()}}
     data.update(extra or {})
     torch.save(data, path)
+
+
+def stage_pixels(pixel_values, out, dev):
+    """Host/device plumbing of the image input: bf16 -> copy; fp32 -> `vlaser_cast_f32_bf16`; **uint8 [N,3,H,W]** (the raw observation the
+    reference's InternVLAProcessor normalises on the host, processing.py:303-311) -> `vlaser_normalize_u8` on the device: 1 byte per
+    sample over PCIe instead of 4, no fp32 intermediate."""
+    pv = pixel_values.to(dev)
+    if pv.dtype == torch.uint8:
+        ops.normalize_u8(pv.contiguous(), out, prep.VLA_MEAN, prep.VLA_STD, layout='chw', mode='vla')
+    elif pv.dtype == torch.float32:
+        ops.cast_f32_bf16(pv.contiguous(), out)
+    else:
+        out.copy_(pv)
+    return out
 
 
 class PiZero:
@@ -278,11 +293,7 @@ class PiZero:
             raise ValueError(f'input_ids must be [B,{T}] (right-padded with pad_token_id), got {tuple(input_ids.shape)}')
         # ---- stage inputs into the static buffers (host->device plumbing)
         self.in_ids[:B].copy_(input_ids)
-        pv = pixel_values.to(dev)
-        if pv.dtype == torch.float32:
-            ops.cast_f32_bf16(pv.contiguous(), self.in_pix[:B * self.num_images])
-        else:
-            self.in_pix[:B * self.num_images].copy_(pv)
+        stage_pixels(pixel_values, self.in_pix[:B * self.num_images], dev)
         self.in_proprio[:B].copy_(proprios.reshape(B, -1).to(torch.float32))
         if valid_len is None:
             if image_text_proprio_mask is not None:
@@ -344,11 +355,7 @@ class PiZero:
             self.ebuf = PrefillBuffers(self.expert_gemm, 16, dev)
         # inputs exactly as infer_action stages them
         self.in_ids[:1].copy_(input_ids)
-        pv = pixel_values.to(dev)
-        if pv.dtype == torch.float32:
-            ops.cast_f32_bf16(pv.contiguous(), self.in_pix[:self.num_images])
-        else:
-            self.in_pix[:self.num_images].copy_(pv)
+        stage_pixels(pixel_values, self.in_pix[:self.num_images], dev)
         self.in_proprio[:1].copy_(proprios.reshape(1, -1).to(torch.float32))
         if valid_len is None:
             valid_len = prep.mask_to_descriptor(causal_mask[:, :, :T + 1, :T + 1].to('cpu'), T) if causal_mask is not None else (input_ids != self.pad_token_id).sum(-1)
@@ -406,12 +413,7 @@ class PiZero:
             raise NotImplementedError('infer_text: padded prompts are not supported (the reference assumes no padding, :655)')
         if B != 1 or S > self.max_image_text_tokens:
             raise NotImplementedError(f'infer_text: batch 1, at most {self.max_image_text_tokens} tokens')
-        pv = pixel_values.to(dev)
-        pvb = torch.empty(pv.shape, dtype=BF, device=dev)
-        if pv.dtype == torch.float32:
-            ops.cast_f32_bf16(pv.contiguous(), pvb)
-        else:
-            pvb.copy_(pv)
+        pvb = stage_pixels(pixel_values, torch.empty(pixel_values.shape, dtype=BF, device=dev), dev)
         feats = self.vit.forward(pvb)
         ids = input_ids.to(dev).contiguous()
         h = self.h_vlm[:S]

@@ -12,6 +12,7 @@ IMG_END_TOKEN = '</img>'
 IMG_CONTEXT_TOKEN = '<IMG_CONTEXT>'
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
+VLA_MEAN, VLA_STD = (0.4850, 0.4560, 0.4060), (0.2290, 0.2240, 0.2250)      # InternVLAProcessor's constants (processing.py:303-304)
 
 
 # ------------------------------------------------------------------------------------------------ conversation

@@ -29,7 +29,7 @@ from . import _lib as L
 from . import dp, ops, prep
 from .config import VLAConfig
 from .engine import BF, KVCache, PrefillBuffers, QwenStack, VitEngine, prefill_begin, prefill_layer
-from .pizero import canonicalize_vla_state_dict
+from .pizero import canonicalize_vla_state_dict, stage_pixels
 from .sft import FlatParams
 
 F32 = torch.float32
@@ -59,6 +59,53 @@ def cosine_warmup_restarts_lr(step, first_cycle_steps, max_lr, min_lr=0.0, warmu
     if in_cycle < warmup_steps:
         return (mx - min_lr) * in_cycle / warmup_steps + min_lr
     return min_lr + (mx - min_lr) * (1 + math.cos(math.pi * (in_cycle - warmup_steps) / (cur - warmup_steps))) / 2
+
+
+class ModelAveraging:
+    """EMA / SWA of the trained parameters -- mirror of `ModelAveraging` (src/agent/model_averaging.py:8-72; driven from `TrainAgent.run`,
+    train.py:524-528: `maybe_initialize(cnt_update)` then `maybe_update(cnt_update)` after every optimizer step).  The reference wraps the
+    model in torch's `AveragedModel` (first update copies, later ones lerp with 1 - ema_decay or average with 1 / (n + 1)); here the
+    average lives in fp32 next to the rank's ZeRO-1 master shard and is updated by ONE streaming kernel (`vlaser_avg_update`).  Like the
+    reference's, it does not support resuming."""
+
+    def __init__(self, trainer, use_ema=False, use_swa=False, ema_start=0, ema_decay=0.99, ema_freq=1, swa_start=0, swa_freq=1):
+        assert not (use_ema and use_swa), 'Cannot use both EMA and SWA at once'
+        self.trainer, self.use_ema, self.use_swa = trainer, use_ema, use_swa
+        self.ema_start, self.ema_decay, self.ema_freq = ema_start, ema_decay, ema_freq
+        self.swa_start, self.swa_freq = swa_start, swa_freq
+        self.avg = None
+        self.n_averaged = 0
+
+    def maybe_initialize(self, cnt_update):
+        if (self.use_swa and cnt_update == self.swa_start) or (self.use_ema and cnt_update == self.ema_start):
+            self.avg = torch.zeros_like(self.trainer.master)
+            self.n_averaged = 0
+
+    def maybe_update(self, cnt_update):
+        if self.avg is None:
+            return
+        if (self.use_ema and cnt_update % self.ema_freq == 0) or (self.use_swa and cnt_update % self.swa_freq == 0):
+            c = (1.0 - self.ema_decay) if self.use_ema else 1.0 / (self.n_averaged + 1)
+            ops.avg_update(self.avg, self.trainer.master, c, self.n_averaged == 0)
+            self.n_averaged += 1
+
+    def state_dict(self):
+        """{'state_dict': averaged weights under the canonical VLA key names (bf16), 'n_averaged', 'model_type'} -- {} before the start step."""
+        if self.avg is None:
+            return {}
+        tr = self.trainer
+        keep = tr.fp.p.clone()
+        try:
+            for (lo, hi, _), o in zip(tr.shards, tr.shard_off):
+                if hi > lo:
+                    tr.fp.p[lo:hi].copy_(self.avg[o:o + hi - lo].to(BF))
+            if tr.dp_active:
+                for b in range(len(tr.buckets)):
+                    dp.all_gather_params(tr.fp.p, tr.buckets[b], tr.shards[b], tr.pg)
+            sd = tr.state_dict()
+        finally:
+            tr.fp.p.copy_(keep)
+        return {'state_dict': sd, 'n_averaged': self.n_averaged, 'model_type': 'ema' if self.use_ema else 'swa'}
 
 
 class VLATrainer:
@@ -222,12 +269,7 @@ class VLATrainer:
         tval = float(t.reshape(-1)[0])
         sig = cfg.flow_sig_min
         # ---- frozen prefix: ViT -> projector -> embeddings -> VLM layers (inference kernels), K / V^T of every layer cached
-        pv = pixel_values.to(dev)
-        pvb = torch.empty(pv.shape, dtype=BF, device=dev)
-        if pv.dtype == torch.float32:
-            ops.cast_f32_bf16(pv.contiguous(), pvb)
-        else:
-            pvb.copy_(pv)
+        pvb = stage_pixels(pixel_values, torch.empty(pixel_values.shape, dtype=BF, device=dev), dev)
         feats = self.vit.forward(pvb)
         ids = ids_h.pin_memory().to(dev, non_blocking=True)
         ops.embed_merge(ids, self.vlm.embed, feats, self.h_vlm, cfg.base.img_context_token_id, cfg.base.pad_token_id, True, self.rank_ws)
