@@ -158,6 +158,33 @@ typedef struct {
 
 int vlaser_skinny(int prologue, int epi, const VlaserSkinnyArgs* args, vl_stream_t stream);
 
+/* ---- fused layer-step launches (ABI 4, r03): one launch instead of two of the five of a <= 5-row decoder layer-step -------------------------
+ * vlaser_fused_ogu = vlaser_skinny(VL_PRO_ATTN, VL_SK_PARTIAL) [o_proj: flash-decoding merge of the vlaser_attn_skinny partials + split-K GEMV]
+ *                  + vlaser_skinny(VL_PRO_NORM, VL_SK_SWIGLU)  [residual + split-K reduce + Qwen2RMSNorm + gate/up GEMV + SwiGLU],
+ * bit-identical to the pair (16-row units), replacing the same reference call sites (joint_model.py:140-232,410-696 for the action mixture of
+ * every Euler step, pizero_internvl.py:884-924).  The first H/16 * ks_o workgroups compute the o_proj partial tiles and hand them to all 256
+ * workgroups INSIDE the launch (write-through stores + arrival counters), while every workgroup's share of the gate/up weights is already in
+ * flight.  sync: device uint32[VL_FUSED_SYNC_WORDS], ZEROED BY THE CALLER on the stream before every launch (one memset over all launch
+ * slots of a HIP graph); sync[VL_FUSED_SYNC_ERR] != 0 afterwards = a bounded wait expired (result invalid, nothing hangs). */
+#define VL_FUSED_SYNC_WORDS 160
+#define VL_FUSED_SYNC_ERR 128
+typedef struct {
+  /* o_proj: as VlaserSkinnyArgs' VL_PRO_ATTN prologue */
+  const float* attn_m; const float* attn_l; const float* attn_o; int attn_splits, attn_group, attn_nq;
+  const void* Wo;      /* ops.pack_skinny(o_proj.weight, ks_o, tiles_per_unit = 1) */
+  int K_o, ks_o;       /* n_q_heads * 128; cross-workgroup K splits */
+  float* part_o;       /* fp32 [ks_o][M][H] split-K slabs (written write-through, read by every workgroup) */
+  /* gate/up: as VlaserSkinnyArgs' VL_PRO_NORM prologue + VL_SK_SWIGLU on 16-row lane-local units */
+  const void* h_in;    /* bf16 [M,H] residual stream */
+  const void* norm_w; float eps;
+  void* h_out;         /* bf16 [M,H] = bf16(h_in + o_proj), written by workgroup 0 (may be null) */
+  const void* Wgu;     /* ops.pack_skinny(ops.pack_gate_up8(gate, up), 1, 1) */
+  int M, H, N_gu, n_valid_gu;   /* rows; hidden; packed gate/up rows (2 I) and their un-padded count */
+  void* act; int ld_act;        /* bf16 [M, ld_act]: silu(gate) * up */
+  unsigned int* sync;
+} VlaserFusedOguArgs;
+int vlaser_fused_ogu(const VlaserFusedOguArgs* args, vl_stream_t stream);
+
 /* Weight-gradient GEMM: out[M,N] (bf16) = At^T @ Wt, At [K,M] and Wt [K,N] row-major bf16 (contraction along rows).
  * dW = dY^T X of every nn.Linear on the SFT path (autograd of modeling_internvl_chat.py:194-203): At = dY [S,N_out],
  * Wt = X [S,K_in].  Rows 16-byte aligned and readable up to M / N rounded up to 8 columns (ld >= that). */

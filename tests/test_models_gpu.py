@@ -453,3 +453,26 @@ def test_config4_shape_8b_widths_13_tiles_vs_oracle():
         assert gen[0, t].item() == ogen[0, t].item()
     del m
     torch.cuda.empty_cache()
+
+
+def test_euler_kernel_options_are_bit_identical(golden_model, golden_dir):
+    """r03 Euler-phase kernels: 16-row lane-local units ('gu16', 'qkv16') and the fused o_proj -> gate/up launch ('fuse_ogu') compute the same
+    arithmetic in the same order as the r02 kernels -- the whole chunk (10 Euler steps, proprio riding) is bit-identical, eager and graph,
+    and no in-launch wait expires."""
+    from vlaser_amd.pizero import PiZeroInference
+    _, vla, sd = golden_model
+    d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))
+    ids = torch.from_numpy(d['a_input_ids'])
+    pv = torch.randn(1, 3, 448, 448, generator=torch.Generator().manual_seed(int(d['a_seed'])))
+    pro, noise = torch.from_numpy(d['a_proprio']), torch.from_numpy(d['a_noise'])
+    outs = {}
+    for opts in ('none', 'gu16', 'qkv16', 'gu16,qkv16', 'gu16,qkv16,fuse_ogu'):
+        for graph in (False, True):
+            m = PiZeroInference(vla, max_batch=1, use_graph=graph, euler_opts=opts); m.load_state_dict(sd)
+            for _ in range(3):
+                a = m.infer_action(ids, pv, proprios=pro, noise=noise)
+            assert m.sync_errors() == 0
+            outs[(opts, graph)] = (a.clone(), m.last_velocities().clone())
+    ref = outs[('none', False)]
+    for k, v in outs.items():
+        assert torch.equal(v[0], ref[0]) and torch.equal(v[1], ref[1]), k

@@ -293,6 +293,12 @@ def test_skinny_norm_swiglu(ops, M, H, I, npart):
     close(out, F.silu(gr).to(BF).float() * ur, name='norm swiglu')
     if H == 768:
         assert torch.equal(out6, out)
+    if H in (768, 1536):      # 16-row lane-local units (tiles_per_unit = 1, r03): same K order per output -> bit-identical
+        out16 = torch.zeros(M, I, dtype=BF, device='cuda'); h16 = torch.zeros(M, H, dtype=BF, device='cuda')
+        pw = ops.pack_skinny(ops.pack_gate_up8(g, u), 1, 1)
+        assert pw.tpu == 1 and pw.N == 2 * I
+        ops.skinny(L.PRO_NORM, L.SK_SWIGLU, h, pw, M, partials=parts, n_partials=npart, norm_w=nw, h_out=h16, out=out16, ldo=I)
+        assert torch.equal(out16, out) and torch.equal(h16, h_out)
 
 
 def test_skinny_norm_qkv_rope(ops):
@@ -316,6 +322,12 @@ def test_skinny_norm_qkv_rope(ops):
     close(q_out.view(M, nq, 128), _rope_ref(q, pos), name='q')
     close(kc[:, :, 385:389], _rope_ref(k, pos).view(B, tok, nkv, 128).permute(0, 2, 1, 3), name='k')
     close(vtc[:, :, :, 385:389], v.view(B, tok, nkv, 128).permute(0, 2, 3, 1), name='vT')
+    # 16-row lane-local units (tiles_per_unit = 1, r03): 128 instead of 64 units, bit-identical outputs
+    W16, B16 = ops.pack_qkv16(qw, kw, vw, qb, kb, vb)
+    q16 = torch.zeros_like(q_out); kc16 = torch.zeros_like(kc); vtc16 = torch.zeros_like(vtc)
+    ops.skinny(L.PRO_NORM, L.SK_QKV_ROPE, h, ops.pack_skinny(W16, 1, 1), M, n_partials=0, norm_w=nw, bias=B16, q_out=q16, k_cache=kc16, vt_cache=vtc16,
+               rope_cos=cos, rope_sin=sin, pos_ids=pos, n_q_heads=nq, n_kv_heads=nkv, s_max=smax, tok_per_batch=tok, slot_base=385)
+    assert torch.equal(q16, q_out) and torch.equal(kc16, kc) and torch.equal(vtc16, vtc)
 
 
 def test_norms(ops):
@@ -637,3 +649,39 @@ def test_avg_update_ema_swa(ops):
             else:
                 assert ma.avg is None and ma.state_dict() == {}
         assert ma.n_averaged == 4
+
+
+@pytest.mark.parametrize('M', [4, 5])
+def test_fused_ogu_equals_the_two_launches_bit_for_bit(ops, M):
+    """csrc/euler.hip (r03): o_proj -> gate/up as ONE launch with an in-launch hand-off == vlaser_skinny(ATTN, PARTIAL) + vlaser_skinny(NORM, SWIGLU)
+    on 16-row units, bit for bit (same arithmetic, same order), on fresh data every iteration (the hand-off buffers keep their addresses, so a
+    stale line in any cache would show), with the arrival counters checked and the error word clear."""
+    from vlaser_amd import _lib as L
+    H, I, nq, nkv, S = 768, 8960, 12, 2, 7
+    G = nq // nkv
+    wo, gw, uw = rnd(H, nq * 128, std=0.03, seed=1), rnd(I, H, std=0.03, seed=2), rnd(I, H, std=0.03, seed=3)
+    pwo, pgu = ops.pack_skinny(wo, 3, 1), ops.pack_skinny(ops.pack_gate_up8(gw, uw), 1, 1)
+    nw = (1 + 0.1 * rnd(H, seed=5).float()).to(BF)
+    parts = ops.attn_partial_buffers(1, nkv, 'cuda')
+    part_a = torch.zeros(3, M, H, dtype=torch.float32, device='cuda'); part_b = torch.zeros_like(part_a)
+    act_a = torch.zeros(M, I, dtype=BF, device='cuda'); act_b = torch.zeros_like(act_a)
+    h_a = torch.zeros(M, H, dtype=BF, device='cuda'); h_b = torch.zeros_like(h_a)
+    sync = torch.zeros(L.FUSED_SYNC_WORDS, dtype=torch.int32, device='cuda')
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    for it in range(60):
+        parts[0][:, :, :S].copy_(torch.randn(1, nkv, S, 32, generator=gen, device='cuda') * 3)
+        parts[1][:, :, :S].copy_(torch.rand(1, nkv, S, 32, generator=gen, device='cuda') * 50 + 1)
+        parts[2][:, :, :S].copy_(torch.randn(1, nkv, S, 32, 128, generator=gen, device='cuda') * 20)
+        h = (torch.randn(M, H, generator=gen, device='cuda')).to(BF)
+        ops.skinny(L.PRO_ATTN, L.SK_PARTIAL, None, pwo, M, out_f32=part_a, attn_m=parts[0], attn_l=parts[1], attn_o=parts[2], attn_splits=S, attn_group=G, attn_nq=M)
+        ops.skinny(L.PRO_NORM, L.SK_SWIGLU, h, pgu, M, partials=part_a, n_partials=3, norm_w=nw, h_out=h_a, out=act_a, ldo=I)
+        sync.zero_()
+        a = ops.fused_ogu_args(parts, pwo, part_b, h, nw, 1e-6, h_b, pgu, M, act_b, sync, S, G, M)
+        ops.launch_fused_ogu(a)
+        torch.cuda.synchronize()
+        assert int(sync[L.FUSED_SYNC_ERR]) == 0, 'bounded wait expired'
+        assert sync[[0, 32, 64, 96]].tolist() == [36, 36, 36, 36]
+        assert torch.equal(part_a, part_b), it
+        assert torch.equal(h_a, h_b), it
+        assert torch.equal(act_a, act_b), (it, int((act_a != act_b).sum()))
+    assert act_a.float().abs().max() > 0

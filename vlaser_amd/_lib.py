@@ -37,6 +37,14 @@ class SkinnyArgs(C.Structure):
                 ('attn_splits', i32), ('attn_group', i32), ('attn_nq', i32), ('dbg', vp)]
 
 
+class FusedOguArgs(C.Structure):
+    _fields_ = [('attn_m', vp), ('attn_l', vp), ('attn_o', vp), ('attn_splits', i32), ('attn_group', i32), ('attn_nq', i32), ('Wo', vp), ('K_o', i32),
+                ('ks_o', i32), ('part_o', vp), ('h_in', vp), ('norm_w', vp), ('eps', f32), ('h_out', vp), ('Wgu', vp), ('M', i32), ('H', i32),
+                ('N_gu', i32), ('n_valid_gu', i32), ('act', vp), ('ld_act', i32), ('sync', vp)]
+
+
+FUSED_SYNC_WORDS, FUSED_SYNC_ERR = 160, 128
+
 # enums (include/vlaser_hip.h)
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_LS_RES, EPI_RES, EPI_SWIGLU, EPI_QKV_ROPE, EPI_VIT_QKV, EPI_F32, EPI_PARTIAL, EPI_SWIGLU_BWD = range(11)
 ATTN_FULL, ATTN_CAUSAL, ATTN_PREFIX = range(3)
@@ -49,6 +57,7 @@ _SIGS = {
     'vlaser_attn_prefill': [C.POINTER(AttnArgs), vp],
     'vlaser_attn_skinny': [C.POINTER(AttnArgs), vp],
     'vlaser_skinny': [i32, i32, C.POINTER(SkinnyArgs), vp],
+    'vlaser_fused_ogu': [C.POINTER(FusedOguArgs), vp],
     'vlaser_layernorm': [vp, vp, vp, vp, i32, i32, f32, vp],
     'vlaser_rmsnorm': [vp, vp, vp, i32, i32, f32, vp],
     'vlaser_im2col': [vp, vp, i32, i32, i32, vp],

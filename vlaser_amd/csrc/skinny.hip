@@ -150,6 +150,68 @@ __device__ __forceinline__ void skinny_epilogue(const VlaserSkinnyArgs& a, int k
   }
 }
 
+// ---- 16-row units (TPU = 1) with lane-local epilogues (r03): a unit = ONE MFMA tile whose rows are packed so that lane group g (rows 4g .. 4g+3) holds
+//   SWIGLU:   [gate 2g, gate 2g+1, up 2g, up 2g+1] of the unit's 8 activation columns  (ops.pack_gate_up8),
+//   QKV_ROPE: [d, d+1, d+64, d+65], d = 8*(unit % 8) + 2g, of head unit / 8            (ops.head_perm16),
+// i.e. the SwiGLU partner / the RoPE partner of every value sits in the same lane, exactly as with the 32-row units, at half the unit
+// size: 1120 instead of 560 gate/up units over 256 workgroups (longest workgroup 80 instead of 96 rows), 128 instead of 64 q/k/v units.
+struct EpiOps16 {
+  u32x2 b;            // 4 bf16 bias values of the lane's rows
+  float cs[2], sn[2]; // RoPE cos / sin of d, d+1
+};
+
+template <int EPI>
+__device__ __forceinline__ void load_epi16(const VlaserSkinnyArgs& a, int unit, int g, EpiOps16& e, int pos) {
+  const int u = min(unit, (a.N >> 4) - 1);
+  if constexpr (EPI == VL_SK_QKV_ROPE) {
+    e.b = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(a.bias) + u * 16 + g * 4);
+    const int d = ((u & 7) << 3) + 2 * g;
+    const f32x2_t c = *reinterpret_cast<const f32x2_t*>(a.rope_cos + (size_t)pos * 64 + d);
+    const f32x2_t s = *reinterpret_cast<const f32x2_t*>(a.rope_sin + (size_t)pos * 64 + d);
+    e.cs[0] = c[0]; e.cs[1] = c[1]; e.sn[0] = s[0]; e.sn[1] = s[1];
+  }
+}
+
+template <int EPI>
+__device__ __forceinline__ void skinny_epilogue16(const VlaserSkinnyArgs& a, int ks, int unit, int m, int g, f32x4 acc, const EpiOps16& e, int pos) {
+  if constexpr (EPI == VL_SK_PARTIAL) {
+    const int n0 = unit * 16 + g * 4;
+    if (n0 + 3 < a.n_valid) *reinterpret_cast<f32x4*>(a.out_f32 + ((size_t)ks * a.M + m) * a.n_valid + n0) = acc;
+  } else if constexpr (EPI == VL_SK_SWIGLU) {
+    if (unit * 16 >= a.n_valid) return;      // zero-padded tail
+    bf16_t* o = reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + unit * 8 + g * 2;
+    const float r0 = round_bf16(silu(round_bf16(acc[0]))) * round_bf16(acc[2]);
+    const float r1 = round_bf16(silu(round_bf16(acc[1]))) * round_bf16(acc[3]);
+    *reinterpret_cast<uint32_t*>(o) = pack_bf16x2(r0, r1);
+  } else if constexpr (EPI == VL_SK_QKV_ROPE) {
+    const int head = unit >> 3, d = ((unit & 7) << 3) + 2 * g;
+    const float b0 = bf16lo_to_f32(e.b[0]), b1 = bf16hi_to_f32(e.b[0]), b2 = bf16lo_to_f32(e.b[1]), b3 = bf16hi_to_f32(e.b[1]);
+    const float x1[2] = {round_bf16(acc[0] + b0), round_bf16(acc[1] + b1)}, x2[2] = {round_bf16(acc[2] + b2), round_bf16(acc[3] + b3)};
+    const int b = fdiv(m, __builtin_amdgcn_rcpf((float)a.tok_per_batch));
+    const int slot = a.slot_base >= 0 ? a.slot_base + (m - b * a.tok_per_batch) : pos;
+    const int nq = a.n_q_heads, nkv = a.n_kv_heads;
+    if (head < nq + nkv) {
+      float o1[2], o2[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        o1[j] = x1[j] * e.cs[j] - x2[j] * e.sn[j];
+        o2[j] = x2[j] * e.cs[j] + x1[j] * e.sn[j];
+      }
+      bf16_t* dst = head < nq ? reinterpret_cast<bf16_t*>(a.q_out) + (size_t)m * nq * 128 + head * 128
+                              : reinterpret_cast<bf16_t*>(a.k_cache) + (((size_t)b * nkv + (head - nq)) * a.s_max + slot) * 128;
+      *reinterpret_cast<uint32_t*>(dst + d) = pack_bf16x2(o1[0], o1[1]);
+      *reinterpret_cast<uint32_t*>(dst + d + 64) = pack_bf16x2(o2[0], o2[1]);
+    } else {
+      bf16_t* vt = reinterpret_cast<bf16_t*>(a.vt_cache) + ((size_t)b * nkv + (head - nq - nkv)) * 128 * a.s_max + slot;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        vt[(size_t)(d + j) * a.s_max] = f32_to_bf16(x1[j]);
+        vt[(size_t)(d + 64 + j) * a.s_max] = f32_to_bf16(x2[j]);
+      }
+    }
+  }
+}
+
 // SP > 0 (ATTN prologue): exact attention-split count.  SP >= 0 (NORM prologue): the split-K slab count is a compile-time constant -> exactly 2 + 2*SP loads per chunk and no
 // clamped dummy loads / selects.  The prologue is instruction-issue bound (8 waves share 4 SIMDs, ~8 cycles per VALU op
 // per wave), so the generic runtime-count path (SP = -1) costs ~2 us more per launch at SP = 5.
@@ -165,6 +227,8 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
   // EARLY (gate/up: 2-3 units per block): units 1 and 2 are requested as soon as the prologue's own loads are back
   // (first barrier) instead of one unit ahead of the MFMAs, so the HBM stream does not restart after the ~3 us prologue
   constexpr bool EARLY = (PRO == VL_PRO_NORM && EPI == VL_SK_SWIGLU && NCH == 1);
+  constexpr int UE = TPU == 1 ? 5 : 3;          // EARLY: units held in registers at once (16-row units: 1120 / 256 -> 4 or 5 per workgroup)
+  constexpr bool EPI16 = (TPU == 1 && EPI == VL_SK_QKV_ROPE);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const VlaserSkinnyArgs& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -194,13 +258,16 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
   // behind the unit's weight fragments made hipcc drain the whole weight stream (vmcnt(0)) in the middle of the prologue
   int pos_m = 0;
   if constexpr (EPI == VL_SK_QKV_ROPE) pos_m = a.pos_ids[min(m, a.M - 1)];
-  u32x4 cw[NF], nw[NF], tw[EARLY ? NF : 1];  // current / next (/ third, EARLY) unit
-  EpiOps ce[NEED_EPI ? TPU / 2 : 1], ne[NEED_EPI ? TPU / 2 : 1], te[1];
-  auto load_unit = [&](int ui, u32x4* dst, EpiOps* e) {
+  u32x4 cw[NF], nw[NF], ew[EARLY ? UE - 2 : 1][EARLY ? NF : 1];  // current / next unit (/ units 2 .. UE-1, EARLY)
+  EpiOps ce[NEED_EPI && TPU > 1 ? TPU / 2 : 1], ne[NEED_EPI && TPU > 1 ? TPU / 2 : 1], te[1];
+  EpiOps16 ce16, ne16;
+  auto load_unit = [&](int ui, u32x4* dst, EpiOps* e, EpiOps16* e16 = nullptr) {
     const u32x4* src = wp + (size_t)(ustart + ui) * unit_stride;
 #pragma unroll
     for (int f = 0; f < NF; ++f) dst[f] = __builtin_nontemporal_load(src + f * 64);
-    if constexpr (NEED_EPI) {
+    if constexpr (EPI16) {
+      load_epi16<EPI>(a, ustart + ui, g, *e16, pos_m);
+    } else if constexpr (NEED_EPI) {
 #pragma unroll
       for (int pr = 0; pr < TPU / 2; ++pr) load_epi<EPI>(a, (ustart + ui) * (TPU / 2) + pr, m, g, e[pr], pos_m);
     }
@@ -219,7 +286,7 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
     const int c1 = min(tid + SKT, nch - 1);
     const int r1 = fdiv(c1, p.inv_cpr), j1 = c1 - r1 * cpr;
     const u32x4 x1 = ld_global_16(X + (size_t)r1 * a.K + kb0 + j1 * 8);
-    load_unit(0, cw, ce);
+    load_unit(0, cw, ce, &ce16);
     if (tid < nch) *reinterpret_cast<u32x4*>(xs + r0 * p.xs_stride + j0 * 16) = x0;
     if (tid + SKT < nch) *reinterpret_cast<u32x4*>(xs + r1 * p.xs_stride + j1 * 16) = x1;
     for (int c = tid + 2 * SKT; c < nch; c += SKT)
@@ -252,7 +319,7 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
         // counted wait on a partial also waits for HBM.  hipcc hoisted these two loads to the top of the kernel (their addresses are
         // ready first) until the order was pinned.
         __builtin_amdgcn_sched_barrier(0);
-        load_unit(0, cw, ce);
+        load_unit(0, cw, ce, &ce16);
         __builtin_amdgcn_sched_barrier(0);
       }
       float Mx = -1.0e30f;
@@ -308,7 +375,7 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
           q[2 * u] = *reinterpret_cast<const f32x4*>(pp);
           q[2 * u + 1] = *reinterpret_cast<const f32x4*>(pp + 4);
         }
-        if constexpr (decltype(issue_tag)::value) load_unit(0, cw, ce);       // weight stream right behind the prologue requests
+        if constexpr (decltype(issue_tag)::value) load_unit(0, cw, ce, &ce16);       // weight stream right behind the prologue requests
         float v[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[2 * j] = bf16lo_to_f32(hv[j]); v[2 * j + 1] = bf16hi_to_f32(hv[j]); }
@@ -360,7 +427,7 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
           q[2 * u] = *reinterpret_cast<const f32x4*>(pp);
           q[2 * u + 1] = *reinterpret_cast<const f32x4*>(pp + 4);
         }
-        if constexpr (decltype(issue_tag)::value) load_unit(0, cw, ce);       // weight stream right behind the prologue requests
+        if constexpr (decltype(issue_tag)::value) load_unit(0, cw, ce, &ce16);       // weight stream right behind the prologue requests
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const bool on = u < S;     // select, not multiply: the clamped dummy loads may hold non-finite bit patterns
@@ -375,7 +442,7 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
           q[2 * u] = *reinterpret_cast<const f32x4*>(pp);
           q[2 * u + 1] = *reinterpret_cast<const f32x4*>(pp + 4);
         }
-        if constexpr (decltype(issue_tag)::value) load_unit(0, cw, ce);
+        if constexpr (decltype(issue_tag)::value) load_unit(0, cw, ce, &ce16);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const bool on = u < S;
@@ -402,7 +469,9 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
     STAMP(1);
     if constexpr (EARLY) {                     // block-uniform conditions; hipcc then waits for all of them at the first use: fine,
       if (ucount > 1) load_unit(1, nw, ne);    // they were requested ~2 us before anything consumes them
-      if (ucount > 2) load_unit(2, tw, te);
+#pragma unroll
+      for (int u = 2; u < UE; ++u)
+        if (ucount > u) load_unit(u, ew[u - 2], te);
     }
     if (fast2) {
       float tot = 0.f;
@@ -522,7 +591,7 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
     finish(ui, ce);
     return;
   }
-  auto consume_finish = [&](int ui, const u32x4* w, const EpiOps* e) {
+  auto consume_finish = [&](int ui, const u32x4* w, const EpiOps* e, const EpiOps16* e16 = nullptr) {
     f32x4 acc[TPU];
 #pragma unroll
     for (int t = 0; t < TPU; ++t) acc[t] = f32x4{0, 0, 0, 0};
@@ -553,9 +622,9 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
         for (int t = 0; t < TPU; ++t) acc[t] += *reinterpret_cast<const f32x4*>(r + t * 64 * 4);
       }
       if (m < a.M) {
-        if constexpr (TPU == 1) {          // 16-row units (split-K partial only): one tile, columns (ustart+ui)*16 + g*4
-          const int n0 = (ustart + ui) * 16 + g * 4;
-          if (n0 + 3 < a.n_valid) *reinterpret_cast<f32x4*>(a.out_f32 + ((size_t)ks * a.M + m) * a.n_valid + n0) = acc[0];
+        if constexpr (TPU == 1) {          // 16-row units: one tile, lane-local epilogue (partial slab / SwiGLU / bias + RoPE + cache scatter)
+          EpiOps16 e0 = {};
+          skinny_epilogue16<EPI>(a, ks, ustart + ui, m, g, acc[0], EPI16 ? *e16 : e0, pos_m);
         } else {
 #pragma unroll
           for (int pr = 0; pr < TPU / 2; ++pr)
@@ -568,27 +637,30 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
   if constexpr (EARLY) {
     consume_finish(0, cw, ce);
     if (ucount > 1) consume_finish(1, nw, ne);
-    if (ucount <= 3) {
-      if (ucount > 2) consume_finish(2, tw, te);
+#pragma unroll
+    for (int u = 2; u < UE; ++u)
+      if (ucount > u) consume_finish(u, ew[u - 2], te);
+    if (ucount <= UE) {
       STAMP(5);
       return;
     }
-#pragma unroll
-    for (int f = 0; f < NF; ++f) cw[f] = tw[f];       // more than 3 units: continue one unit ahead from unit 2
-    ui0 = 2;
+    load_unit(UE, cw, ce);                            // more than UE units (grids far below the unit count): continue one unit ahead
+    ui0 = UE;
   }
   // while unit ui is consumed, unit ui+1 is in flight; last unit peeled (no dangling prefetch)
   for (int ui = ui0; ui + 1 < ucount; ++ui) {
-    load_unit(ui + 1, nw, ne);
-    consume_finish(ui, cw, ce);
+    load_unit(ui + 1, nw, ne, &ne16);
+    consume_finish(ui, cw, ce, &ce16);
 #pragma unroll
     for (int f = 0; f < NF; ++f) cw[f] = nw[f];
-    if constexpr (NEED_EPI) {
+    if constexpr (EPI16) {
+      ce16 = ne16;
+    } else if constexpr (NEED_EPI) {
 #pragma unroll
       for (int pr = 0; pr < TPU / 2; ++pr) ce[pr] = ne[pr];
     }
   }
-  consume_finish(ucount - 1, cw, ce);
+  consume_finish(ucount - 1, cw, ce, &ce16);
   STAMP(5);
 #undef STAMP
 }
@@ -632,7 +704,7 @@ static int launch_ns(const VlaserSkinnyArgs* a, hipStream_t stream) {
       default: break;
     }
   }
-  if constexpr (PRO == VL_PRO_NORM && TPU == 2 && (NS == 3 || NS == 6)) {
+  if constexpr (PRO == VL_PRO_NORM && (TPU == 2 || TPU == 1) && (NS == 3 || NS == 6)) {
     switch (a->n_partials) {
       case 0: return launch_sp<PRO, EPI, TPU, NS, 0>(a, stream, p, gx, lds);
       case 2: return launch_sp<PRO, EPI, TPU, NS, 2>(a, stream, p, gx, lds);
@@ -664,7 +736,14 @@ static int launch(const VlaserSkinnyArgs* a, hipStream_t stream) {
         default: break;
       }
     }
-    vlaser_set_error("vlaser_skinny: tiles_per_unit = 1 is built for PLAIN + PARTIAL (5 / 7 K-steps per wave) and ATTN + PARTIAL (2 / 3)");
+    if constexpr (PRO == VL_PRO_NORM && (EPI == VL_SK_SWIGLU || EPI == VL_SK_QKV_ROPE)) {      // lane-local 16-row units (r03), hidden 768 / 1536
+      switch (ns) {
+        case 3: return launch_ns<PRO, EPI, 1, 3>(a, stream);
+        case 6: return launch_ns<PRO, EPI, 1, 6>(a, stream);
+        default: break;
+      }
+    }
+    vlaser_set_error("vlaser_skinny: tiles_per_unit = 1 is built for PLAIN + PARTIAL (5 / 7 K-steps per wave), ATTN + PARTIAL (2 / 3) and NORM + SWIGLU / QKV_ROPE (3 / 6)");
     return -1;
   }
   if (a->tiles_per_unit == 6) {
@@ -716,7 +795,8 @@ extern "C" int vlaser_skinny(int pro, int epi, const VlaserSkinnyArgs* a, vl_str
   if (epi != VL_SK_PARTIAL) VL_CHECK(a->k_splits == 1, "vlaser_skinny: only VL_SK_PARTIAL may split K across blocks");
   if (epi != VL_SK_F32 && epi != VL_SK_PARTIAL && epi != VL_SK_SWIGLU)
     VL_CHECK(a->n_valid <= 0 || a->n_valid == a->N, "vlaser_skinny: only F32/PARTIAL/SWIGLU epilogues support a padded N");
-  if (epi == VL_SK_SWIGLU) VL_CHECK(a->n_valid <= 0 || a->n_valid % 32 == 0, "vlaser_skinny: SWIGLU needs whole [gate16|up16] groups");
+  if (epi == VL_SK_SWIGLU) VL_CHECK(a->n_valid <= 0 || a->n_valid % (a->tiles_per_unit == 1 ? 16 : 32) == 0, "vlaser_skinny: SWIGLU needs whole [gate|up] groups");
+  if (epi == VL_SK_QKV_ROPE && a->tiles_per_unit == 1) VL_CHECK(a->N % 128 == 0, "vlaser_skinny: QKV_ROPE on 16-row units needs whole heads");
   if (epi == VL_SK_BIAS || epi == VL_SK_BIAS_SILU || epi == VL_SK_QKV_ROPE) VL_CHECK(a->bias, "vlaser_skinny: bias null");
   if (epi == VL_SK_F32) VL_CHECK(a->bias == nullptr || a->n_valid <= 0 || a->n_valid == a->N, "vlaser_skinny: F32 bias needs an un-padded N");
 #define SK_CASE(P, E)                                   \

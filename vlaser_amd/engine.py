@@ -28,7 +28,7 @@ class QwenLayerWeights:
     """One Qwen2DecoderLayer in kernel layout: row-major packed matrices for the MFMA GEMM (prefill) and/or
     fragment-major copies for the weight-streaming skinny kernel (decode / action tokens)."""
 
-    def __init__(self, sd, p, llm: LLMConfig, device, ks_o, ks_down, gemm=True, skinny=True, tpu_down=2, tpu_o=2, i_pad=None):
+    def __init__(self, sd, p, llm: LLMConfig, device, ks_o, ks_down, gemm=True, skinny=True, tpu_down=2, tpu_o=2, i_pad=None, opts=()):
         g = lambda k: _dev(sd[p + k], device)
         wqkv, self.bqkv = ops.pack_qkv(g('self_attn.q_proj.weight'), g('self_attn.k_proj.weight'),
                                        g('self_attn.v_proj.weight'), g('self_attn.q_proj.bias'),
@@ -41,19 +41,29 @@ class QwenLayerWeights:
         if gemm:
             self.wqkv, self.wo, self.wgu, self.wdown = wqkv, wo, wgu, wdown
         if skinny:
-            self.sk_qkv = ops.pack_skinny(wqkv, 1)
+            self.bqkv_sk = self.bqkv
+            if 'qkv16' in opts:           # 16-row lane-local units (r03): 2x the workgroups on the q/k/v GEMV
+                w16, self.bqkv_sk = ops.pack_qkv16(g('self_attn.q_proj.weight'), g('self_attn.k_proj.weight'), g('self_attn.v_proj.weight'),
+                                                   g('self_attn.q_proj.bias'), g('self_attn.k_proj.bias'), g('self_attn.v_proj.bias'), llm.head_dim)
+                self.sk_qkv = ops.pack_skinny(w16, 1, 1)
+            else:
+                self.sk_qkv = ops.pack_skinny(wqkv, 1)
             self.sk_o = ops.pack_skinny(wo, ks_o, tpu_o)
-            # wide output + short K (action expert: 17920 x 768): 96-row units -> one unit per block, single load batch
-            tpu = 2      # 96-row units (tpu = 6) measured slower on MI355X (12.3 vs 11.2 us): kept in the kernel, not used
-            self.sk_gu = ops.pack_skinny(wgu, 1, tpu)
+            # wide output + short K (action expert: 17920 x 768): 96-row units (tpu = 6) measured slower on MI355X (12.3 vs 11.2 us): kept in
+            # the kernel, not used; 16-row lane-local units ('gu16', r03) balance 1120 units over 256 workgroups (80 vs 96 rows on the longest)
+            if 'gu16' in opts:
+                self.sk_gu = ops.pack_skinny(ops.pack_gate_up8(g('mlp.gate_proj.weight'), g('mlp.up_proj.weight')), 1, 1)
+            else:
+                self.sk_gu = ops.pack_skinny(wgu, 1, 2)
             self.sk_down = ops.pack_skinny(wdown, ks_down, tpu_down, k_pad=i_pad)
 
 
 class QwenStack:
     """Weights + geometry of one Qwen2 decoder stack (the VLM LLM or the action expert)."""
 
-    def __init__(self, sd, prefix, llm: LLMConfig, device, with_embed=True, with_head=True, gemm=True, skinny=True):
+    def __init__(self, sd, prefix, llm: LLMConfig, device, with_embed=True, with_head=True, gemm=True, skinny=True, opts=()):
         self.llm = llm
+        self.opts = tuple(opts)
         H, I = llm.hidden_size, llm.intermediate_size
         nqd = llm.num_attention_heads * llm.head_dim
         # o_proj on 16-row units where the kernel has the variant: the same ~144 workgroups with half the split-K slabs for the
@@ -68,7 +78,7 @@ class QwenStack:
         self.I_pad, ks32 = ops.skinny_geometry(I, H)            # widths that do not factor (Vlaser-8B: 18944) are zero-padded: act buffer + down weight
         self.ks_down = ks16 if self.tpu_down == 1 else ks32
         self.nqd = nqd
-        self.layers = [QwenLayerWeights(sd, f'{prefix}model.layers.{i}.', llm, device, self.ks_o, self.ks_down, gemm, skinny, self.tpu_down, self.tpu_o, self.I_pad)
+        self.layers = [QwenLayerWeights(sd, f'{prefix}model.layers.{i}.', llm, device, self.ks_o, self.ks_down, gemm, skinny, self.tpu_down, self.tpu_o, self.I_pad, self.opts)
                        for i in range(llm.num_hidden_layers)]
         self.norm = _dev(sd[prefix + 'model.norm.weight'], device)
         self.embed = _dev(sd[prefix + 'model.embed_tokens.weight'], device) if with_embed else None
@@ -262,11 +272,12 @@ class SkinnyBuffers:
         self.part_o = torch.zeros(stack.ks_o, max_rows, H, dtype=torch.float32, device=device)
         self.part_d = torch.zeros(stack.ks_down, max_rows, H, dtype=torch.float32, device=device)
         self.plans = {}      # cached launch argument structs of skinny_layer
+        self.sync = None     # [slots, VL_FUSED_SYNC_WORDS] int32: arrival counters of the fused launches (set + zeroed by the caller)
 
 
 def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in, partials, n_partials, cache: KVCache, layer, rope,
                  pos_ids, batch, tok_per_batch, slot_base, kv_len, attn_mode, valid_len=None, blk_start=0, skip_post_attn=False,
-                 first_tok_kv_len=0):
+                 first_tok_kv_len=0, skip=(), sync=None):
     """One decoder layer over M = batch*tok_per_batch <= 16 rows with the weight-streaming kernels (5 launches).
     Input residual = h_in + sum(partials) (partials = down_proj slabs of the previous layer).  Returns
     (h, partials, n_partials) describing this layer's output residual the same way."""
@@ -275,14 +286,20 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
     nq, nkv, hd = stack.nq, stack.nkv, llm.head_dim
     # the five argument structs of this (layer, input buffers, geometry) are built once and re-launched: only the cache slot,
     # the key count and its split factor change from step to step (greedy decode is otherwise host-bound on struct building)
+    # 'fuse_ogu' (r03): o_proj -> gate/up as ONE launch with an in-launch hand-off (csrc/euler.hip); needs its arrival-counter slot `sync`
+    # (zeroed by the caller before the launch) and the geometry the fused kernel is built for -- anything else takes the two launches
+    nsp = ops.attn_splits(kv_len)
+    fuse = (sync is not None and 'fuse_ogu' in stack.opts and 'gu16' in stack.opts and not skip_post_attn and stack.tpu_o == 1 and stack.ks_o == 3
+            and llm.hidden_size == 768 and nq * hd == 1536 and nsp == 7 and M * (llm.hidden_size // 8) <= 512)
     key = (layer, M, tok_per_batch, attn_mode, h_in.data_ptr(), 0 if partials is None else partials.data_ptr(), n_partials,
-           0 if valid_len is None else valid_len.data_ptr(), pos_ids.data_ptr(), cache.k.data_ptr(), skip_post_attn, first_tok_kv_len)
+           0 if valid_len is None else valid_len.data_ptr(), pos_ids.data_ptr(), cache.k.data_ptr(), skip_post_attn, first_tok_kv_len,
+           sync.data_ptr() if fuse else 0)
     plan = sb.plans.get(key)
     if plan is None:
         ks, vs = cache.strides()
         plan = SimpleNamespace()
         plan.qkv = ops.skinny_args(h_in, lw.sk_qkv, M, partials=partials, n_partials=n_partials, norm_w=lw.ln_in, eps=llm.rms_norm_eps,
-                                   h_out=sb.hA, bias=lw.bqkv, q_out=sb.q, k_cache=cache.k[layer], vt_cache=cache.vt[layer], rope_cos=rope[0],
+                                   h_out=sb.hA, bias=lw.bqkv_sk, q_out=sb.q, k_cache=cache.k[layer], vt_cache=cache.vt[layer], rope_cos=rope[0],
                                    rope_sin=rope[1], pos_ids=pos_ids, n_q_heads=nq, n_kv_heads=nkv, s_max=cache.s_max,
                                    tok_per_batch=tok_per_batch, slot_base=slot_base)
         plan.attn = ops.attn_skinny_args(sb.q, cache.k[layer], cache.vt[layer], sb.attn_parts, batch, tok_per_batch, kv_len, nq, nkv, hd,
@@ -294,21 +311,32 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
             plan.gu = ops.skinny_args(sb.hA, lw.sk_gu, M, partials=sb.part_o, n_partials=stack.ks_o, norm_w=lw.ln_post, eps=llm.rms_norm_eps,
                                       h_out=sb.hB, out=sb.act, ldo=sb.act.shape[1])
             plan.down = ops.skinny_args(sb.act, lw.sk_down, M, out_f32=sb.part_d)
+            if fuse:
+                plan.ogu = ops.fused_ogu_args(sb.attn_parts, lw.sk_o, sb.part_o, sb.hA, lw.ln_post, llm.rms_norm_eps, sb.hB, lw.sk_gu, M, sb.act, sync,
+                                              nsp, nq // nkv, tok_per_batch)
         if len(sb.plans) > 4096:         # keys hold buffer addresses of per-call tensors (ragged lengths): bound the cache
             sb.plans.clear()
         sb.plans[key] = plan
     stream = torch.cuda.current_stream().cuda_stream
-    nsp = ops.attn_splits(kv_len)
     plan.qkv[0].slot_base = slot_base
-    ops.launch_skinny(L.PRO_NORM, L.SK_QKV_ROPE, plan.qkv[0], stream)
+    if 'qkv' not in skip:                 # `skip` (bench.py only): in-chain timing of one launch = chain with it - chain without it
+        ops.launch_skinny(L.PRO_NORM, L.SK_QKV_ROPE, plan.qkv[0], stream)
     a = plan.attn
     a.kv_len, a.n_splits, a.blk_start = kv_len, nsp, blk_start
-    ops.launch_attn_skinny(a, stream)
+    if 'attn' not in skip:
+        ops.launch_attn_skinny(a, stream)
     if skip_post_attn:
         return sb.hA, None, 0
     # o_proj: the prologue merges the attention split partials (flash-decoding) straight into its activation tile
-    plan.o[0].attn_splits = nsp
-    ops.launch_skinny(L.PRO_ATTN, L.SK_PARTIAL, plan.o[0], stream)
-    ops.launch_skinny(L.PRO_NORM, L.SK_SWIGLU, plan.gu[0], stream)
-    ops.launch_skinny(L.PRO_PLAIN, L.SK_PARTIAL, plan.down[0], stream)
+    if fuse:
+        if 'gu' not in skip and 'o' not in skip:
+            ops.launch_fused_ogu(plan.ogu, stream)
+    else:
+        plan.o[0].attn_splits = nsp
+        if 'o' not in skip:
+            ops.launch_skinny(L.PRO_ATTN, L.SK_PARTIAL, plan.o[0], stream)
+        if 'gu' not in skip:
+            ops.launch_skinny(L.PRO_NORM, L.SK_SWIGLU, plan.gu[0], stream)
+    if 'down' not in skip:
+        ops.launch_skinny(L.PRO_PLAIN, L.SK_PARTIAL, plan.down[0], stream)
     return sb.hB, sb.part_d, stack.ks_down

@@ -46,6 +46,32 @@ def pack_gate_up(gw, uw):
     return torch.stack([gw.view(I // 16, 16, K), uw.view(I // 16, 16, K)], dim=1).reshape(2 * I, K).contiguous()
 
 
+def head_perm16(head_dim=128):
+    """16-row lane-local units (skinny.hip, TPU = 1): packed row p of a head <-> natural d = 8*(p//16) + 2*((p%16)//4) + (p%4)%2 + 64*((p%4)//2):
+    lane group g of tile t holds [d, d+1, d+64, d+65], d = 8t + 2g -- the RoPE pair (d, d+64) in one lane."""
+    p = torch.arange(head_dim)
+    q = p % 16
+    return 8 * (p // 16) + 2 * (q // 4) + (q % 4) % 2 + 64 * ((q % 4) // 2)
+
+
+def pack_qkv16(qw, kw, vw, qb, kb, vb, head_dim=128):
+    """q/k/v fused for the 16-row-unit weight-streaming kernel: rows permuted inside each head by head_perm16."""
+    w = torch.cat([qw, kw, vw], dim=0)
+    b = torch.cat([qb, kb, vb], dim=0)
+    nh = w.shape[0] // head_dim
+    idx = (torch.arange(nh)[:, None] * head_dim + head_perm16(head_dim)[None, :]).reshape(-1).to(w.device)
+    return w[idx].contiguous(), b[idx].contiguous()
+
+
+def pack_gate_up8(gw, uw):
+    """16-row lane-local units: rows [16j + 4g, +4) = [gate 8j+2g, gate 8j+2g+1, up 8j+2g, up 8j+2g+1] -> unit j yields activation columns 8j .. 8j+7."""
+    I, K = gw.shape
+    assert I % 8 == 0
+    g4 = gw.view(I // 8, 4, 2, K)          # [unit, lane group, pair, K]
+    u4 = uw.view(I // 8, 4, 2, K)
+    return torch.cat([g4, u4], dim=2).reshape(2 * I, K).contiguous()
+
+
 def pack_patch_embed(w, kpad=640):
     C_, k = w.shape[0], w[0].numel()
     out = torch.zeros(C_, kpad, dtype=w.dtype, device=w.device)
@@ -244,6 +270,24 @@ def launch_skinny(pro, epi, a, stream=None):
 def skinny(pro, epi, x, W: PackedW, M, **kw):
     a, _keep = skinny_args(x, W, M, **kw)
     launch_skinny(pro, epi, a)
+
+
+def fused_ogu_args(attn_parts, Wo: PackedW, part_o, h_in, norm_w, eps, h_out, Wgu: PackedW, M, act, sync, attn_splits, attn_group, attn_nq):
+    """Filled VlaserFusedOguArgs: o_proj (attention-split merge + split-K partial tiles) handed to gate/up (+ residual, RMSNorm, SwiGLU) inside ONE
+    launch (csrc/euler.hip).  `sync`: int32 view of VL_FUSED_SYNC_WORDS words, zeroed by the caller on the stream before every launch."""
+    assert Wo.tpu == 1 and Wgu.tpu == 1 and Wgu.k_splits == 1 and sync.numel() >= L.FUSED_SYNC_WORDS and sync.dtype == torch.int32
+    a = L.FusedOguArgs()
+    a.attn_m, a.attn_l, a.attn_o = attn_parts[0].data_ptr(), attn_parts[1].data_ptr(), attn_parts[2].data_ptr()
+    a.attn_splits, a.attn_group, a.attn_nq = attn_splits, attn_group, attn_nq
+    a.Wo, a.K_o, a.ks_o, a.part_o = Wo.t.data_ptr(), Wo.K, Wo.k_splits, part_o.data_ptr()
+    a.h_in, a.norm_w, a.eps, a.h_out = h_in.data_ptr(), norm_w.data_ptr(), eps, _p(h_out)
+    a.Wgu, a.M, a.H, a.N_gu, a.n_valid_gu = Wgu.t.data_ptr(), M, Wgu.K, Wgu.N, Wgu.n_valid
+    a.act, a.ld_act, a.sync = act.data_ptr(), act.stride(0), sync.data_ptr()
+    return a
+
+
+def launch_fused_ogu(a, stream=None):
+    L.check(L.lib().vlaser_fused_ogu(C.byref(a), _stream() if stream is None else stream), 'vlaser_fused_ogu')
 
 
 # measured on the action-expert chunk: 72 / 100 / 130 / 160 target blocks -> 16.63 / 16.52 / 16.48 / 16.50 ms

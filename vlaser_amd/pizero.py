@@ -15,6 +15,8 @@ replayed from ONE HIP graph after the first call of a given batch size.
 Checkpoint: canonical (de-aliased) VLA state dict -- the InternVLChatModel keys plus action_expert.model.*,
 action_encoder.*, proprio_encoder.*, action_decoder.* (see `canonicalize_vla_state_dict`).
 """
+import os
+
 import torch
 
 from . import _lib as L
@@ -107,7 +109,11 @@ def stage_pixels(pixel_values, out, dev):
 
 
 class PiZero:
-    def __init__(self, cfg: VLAConfig, device='cuda', max_batch=1, use_graph=True, ride_proprio=True, naive_support=False):
+    # Euler-phase kernel options of the action expert (VLASER_EULER overrides: comma list, "none" = the r02 kernels):
+    #   gu16 / qkv16: 16-row lane-local units for the gate/up and q/k/v weight-streaming GEMVs (r03a)
+    EULER_DEFAULT = 'gu16,qkv16'
+
+    def __init__(self, cfg: VLAConfig, device='cuda', max_batch=1, use_graph=True, ride_proprio=True, naive_support=False, euler_opts=None):
         L.lib()
         if not torch.cuda.is_available():
             raise L.VlaserHipError('vlaser_amd needs an MI355X (gfx950) GPU: there is no CPU fallback')
@@ -128,6 +134,8 @@ class PiZero:
         self.use_graph = use_graph
         self.naive_support = naive_support      # keep the expert's un-packed weights for infer_action_naive (tests)
         self.ride_proprio = ride_proprio        # batch 1: proprio row processed with the action rows of Euler step 0 (see _run)
+        eo = os.environ.get('VLASER_EULER', self.EULER_DEFAULT) if euler_opts is None else euler_opts
+        self.euler_opts = tuple(x for x in eo.split(',') if x and x != 'none')
         self._graphs = {}
         if max_batch * cfg.num_action_tokens > 16:
             raise ValueError('the weight-streaming action path handles batch * horizon <= 16 rows')
@@ -147,7 +155,7 @@ class PiZero:
         self.vlm = QwenStack(sd, 'language_model.', base.llm, dev, with_embed=True, with_head=True, gemm=True, skinny=False)   # lm_head (if present): infer_text only
         self._sd_expert = {k: v for k, v in sd.items() if k.startswith('action_expert.')} if self.naive_support else None
         self.expert_gemm = None
-        self.expert = QwenStack(sd, 'action_expert.', cfg.expert, dev, with_embed=False, with_head=False, gemm=False, skinny=True)
+        self.expert = QwenStack(sd, 'action_expert.', cfg.expert, dev, with_embed=False, with_head=False, gemm=False, skinny=True, opts=self.euler_opts)
         g = lambda k: sd[k].to(device=dev, dtype=BF).contiguous()
         self.ae_w1, self.ae_b1 = g('action_encoder.linear_1.weight'), g('action_encoder.linear_1.bias')
         self.ae_w2, self.ae_b2 = ops.pack_skinny(g('action_encoder.linear_2.weight')), g('action_encoder.linear_2.bias')
@@ -167,6 +175,8 @@ class PiZero:
         self.sb_pro = SkinnyBuffers(self.expert, 16, dev)
         self.sb_act = SkinnyBuffers(self.expert, 16, dev)
         self.rope = ops.rope_table(T + 16, llm.head_dim, llm.rope_theta, dev)
+        # arrival counters of the fused Euler launches: one slot per (Euler step, layer), zeroed once per chunk at the start of the Euler phase
+        self.euler_sync = torch.zeros(cfg.num_inference_steps * llm.num_hidden_layers, L.FUSED_SYNC_WORDS, dtype=torch.int32, device=dev)
         W = cfg.action_hidden_size
         z = lambda *s, dt=BF: torch.zeros(*s, dtype=dt, device=dev)
         self.h_vlm = z(B * T, llm.hidden_size)
@@ -205,14 +215,24 @@ class PiZero:
 
     # ------------------------------------------------------------------ the hot path (all kernel launches)
     def _run(self, B):
+        """ViT + projector + scatter -> joint prefill -> Euler loop: three phases, separately callable so that bench.py can time each
+        one from its own HIP graph (per-phase ms on the JSON line)."""
+        self._run_vit(B)
+        self._run_prefill(B)
+        self._run_euler(B)
+
+    def _run_vit(self, B):
+        # a1-a7, a12: ViT tiles -> projector -> scatter into the (zero-padded) text embeddings
+        T = self.max_image_text_tokens
+        feats = self.vit.forward(self.in_pix[:B * self.num_images])
+        ops.embed_merge(self.in_ids[:B], self.vlm.embed, feats, self.h_vlm[:B * T], self.image_token_index, self.pad_token_id, True, self.rank_ws)
+
+    def _run_prefill(self, B):
         cfg = self.cfg
-        base, llm, ex = cfg.base, cfg.base.llm, cfg.expert
+        llm = cfg.base.llm
         T, na = self.max_image_text_tokens, self.num_action_tokens
         nL = llm.num_hidden_layers
-        # a1-a7, a12: ViT tiles -> projector -> scatter into the (zero-padded) text embeddings
-        feats = self.vit.forward(self.in_pix[:B * self.num_images])
         h_vlm = self.h_vlm[:B * T]
-        ops.embed_merge(self.in_ids[:B], self.vlm.embed, feats, h_vlm, self.image_token_index, self.pad_token_id, True, self.rank_ws)
         # a13: joint prefill over {vlm, proprio}; K/V of both mixtures cached (post-RoPE), last layer skips o_proj+MLP.
         # Batch 1: the proprio token does NOT get its own pass through the expert (28 x 5 weight-streaming launches, ~0.85 ms of pure
         # latency): it rides in front of the 4 action rows of Euler step 0 (M = 5).  Its rows of the block mask (prefix + itself,
@@ -221,7 +241,6 @@ class PiZero:
         # and every action are bit-identical to the separate pass, and the expert's weights are streamed once for both.
         # (An HIP-graph side branch was tried first: graph replay runs the branches back to back, 0.9 % kernel overlap in rocprof.)
         ride = self.ride_proprio and B == 1
-        M = B * na
         if ride:
             ops.small_linear(self.in_proprio, self.pe_w, self.pe_b, self.h5, B, cfg.action_hidden_size, cfg.proprio_dim)      # row 0
         else:
@@ -237,7 +256,16 @@ class PiZero:
                 h_pro, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_pro, h_pro, parts, npart, self.cache, i,
                                                    self.rope, self.pos_pro, B, 1, T, T + 1, L.ATTN_PREFIX, valid_len=self.valid_len,
                                                    blk_start=T, skip_post_attn=last)
-        # a14: flow-matching Euler integration over the cached prefix
+
+    def _run_euler(self, B, skip=()):
+        """a14: flow-matching Euler integration over the cached prefix.  `skip`: names of per-layer launches left out (bench.py's in-chain
+        timing of one kernel = chain with it minus chain without it; the values are garbage then)."""
+        cfg = self.cfg
+        llm, ex = cfg.base.llm, cfg.expert
+        T, na = self.max_image_text_tokens, self.num_action_tokens
+        nL = llm.num_hidden_layers
+        ride = self.ride_proprio and B == 1
+        M = B * na
         n = self.num_inference_steps
         dt = 1.0 / n
         W = cfg.action_hidden_size
@@ -246,6 +274,10 @@ class PiZero:
             self.action5[1:1 + M].copy_(self.in_noise[:M])
         else:
             self.action[:M].copy_(self.in_noise[:M])
+        fused = any(o.startswith('fuse_') for o in self.euler_opts)
+        if fused:
+            self.euler_sync.zero_()               # ONE memset node per chunk: every fused launch below owns its own counter slot
+        sync = lambda s_, i_: self.euler_sync[s_ * nL + i_] if fused else None
         for s in range(n):
             t = s * dt
             first = ride and s == 0
@@ -257,7 +289,7 @@ class PiZero:
                 for i in range(nL):
                     h, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_pro, h, parts, npart, self.cache, i, self.rope,
                                                    self.pos5, B, na + 1, T, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len, blk_start=T,
-                                                   first_tok_kv_len=T + 1)
+                                                   first_tok_kv_len=T + 1, skip=skip, sync=sync(s, i))
                 ops.vla_euler(h, parts, npart, M + 1, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action5, W, cfg.action_dim, dt,
                               clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel5)
                 self.action[:M].copy_(self.action5[1:1 + M])          # row 0 of action5 (the proprio row's "velocity") is scratch
@@ -267,7 +299,7 @@ class PiZero:
             for i in range(nL):
                 h, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_act, h, parts, npart, self.cache, i, self.rope,
                                                self.pos_act, B, na, T + 1, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len,
-                                               blk_start=T)
+                                               blk_start=T, skip=skip, sync=sync(s, i))
             ops.vla_euler(h, parts, npart, M, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action, W, cfg.action_dim, dt,
                           clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel_trace[s])
 
@@ -326,6 +358,11 @@ class PiZero:
             self._run(B)
         act = self.action[:B * na].view(B, na, cfg.action_dim)
         return act[:, -cfg.horizon_steps:].clone()
+
+    def sync_errors(self):
+        """Number of fused-launch slots whose bounded in-launch wait expired during the last chunk (0 on a healthy run; the result is
+        invalid otherwise -- csrc/euler.hip never hangs, it flags)."""
+        return int((self.euler_sync[:, L.FUSED_SYNC_ERR] != 0).sum())
 
     def last_velocities(self, B=1):
         """Decoder output (velocity) of every Euler step of the last infer_action call: fp32 [n_steps, B, horizon, action_dim]
