@@ -169,7 +169,7 @@ def sft_cpu_baseline(cfg_full, S=560, R=128):
 
 def sft_flops(cfg, S, R, n_tiles):
     """FLOPs one rank actually executes per optimizer step (1 MAC = 2 FLOP, full S x S attention counted): frozen ViT forward; projector
-    forward (its first Linear is evaluated twice: pre-activation kept for the GELU backward) + dgrad + wgrad on the 256 visual rows per
+    forward (the GELU epilogue also keeps the pre-activation for its backward: ONE evaluation of the first Linear, r03) + dgrad + wgrad on the 256 visual rows per
     tile; every LLM matmul forward + dgrad + wgrad on S rows; attention forward + the five S x S products of its backward; lm_head
     forward + dgrad + wgrad on the R supervised rows ONLY (the step never forms logits of unlabelled positions)."""
     v, l = cfg.vision, cfg.llm
@@ -177,7 +177,7 @@ def sft_flops(cfg, S, R, n_tiles):
     vit = n_tiles * v.num_hidden_layers * (2 * P * v.hidden_size * (4 * v.hidden_size + 2 * v.intermediate_size) + 4 * P * P * v.hidden_size)
     vit += n_tiles * 2 * v.num_patches * v.hidden_size * 3 * v.patch_size ** 2
     nt, C4, H = n_tiles * cfg.num_image_token, 4 * v.hidden_size, l.hidden_size
-    proj = 2 * nt * (C4 * H * (2 + 2) + H * H * (1 + 2))
+    proj = 2 * nt * (C4 * H * (1 + 2) + H * H * (1 + 2))
     nqd, nkvd = l.num_attention_heads * l.head_dim, l.num_key_value_heads * l.head_dim
     per_layer = H * (nqd + 2 * nkvd) + nqd * H + 3 * H * l.intermediate_size
     llm = l.num_hidden_layers * 3 * 2 * S * per_layer

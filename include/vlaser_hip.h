@@ -67,7 +67,9 @@ typedef struct {
    * A += z*a_bs, out += z*o_bs, W += (z / w_group)*w_bs  (element strides; batch 0/1 = plain GEMM) */
   int batch; long long a_bs, w_bs, o_bs; int w_group;
   /* VL_EPI_SWIGLU, optional: also keep the bf16 pre-activations [M, N] (gate / up in the packed 16-row interleave, exactly what
-   * VL_EPI_NONE would write) -- the SFT forward saves them for swiglu's backward instead of running the GEMM unfused + a swiglu pass */
+   * VL_EPI_NONE would write) -- the SFT forward saves them for swiglu's backward instead of running the GEMM unfused + a swiglu pass.
+   * VL_EPI_BIAS_GELU, optional (ABI 4): aux_out [M, N] = bf16(acc + bias), the pre-activation GELU's backward needs (the projector's first
+   * Linear, modeling_internvl_chat.py:89-94, was evaluated twice in r02: once with BIAS, once with BIAS_GELU); ld_aux % 4 == 0, 8-byte aligned */
   void* aux_out; int ld_aux;
 } VlaserGemmArgs;
 
@@ -182,6 +184,8 @@ typedef struct {
   int M, H, N_gu, n_valid_gu;   /* rows; hidden; packed gate/up rows (2 I) and their un-padded count */
   void* act; int ld_act;        /* bf16 [M, ld_act]: silu(gate) * up */
   unsigned int* sync;
+  int cons_delay;               /* tuning: consumer-only workgroups start their weight stream this many 10-ns ticks after their start (0 = at once) */
+  unsigned long long* dbg;      /* optional: per-workgroup timestamps [256][8] (wall_clock64, 100 MHz) for kernel tuning */
 } VlaserFusedOguArgs;
 int vlaser_fused_ogu(const VlaserFusedOguArgs* args, vl_stream_t stream);
 

@@ -40,6 +40,10 @@ def test_gemm_plain_bias_gelu(ops, M, N, K):
     close(ops.linear(x, w), ref, name='none')
     close(ops.linear(x, w, b), ref + b.float(), name='bias')
     close(ops.linear(x, w, b, epi=L.EPI_BIAS_GELU), F.gelu(ref + b.float()), name='gelu')
+    if N % 4 == 0:      # aux_out (ABI 4): the same launch also keeps the rounded pre-activation == what EPI_BIAS writes, and leaves `out` unchanged
+        z, g2 = torch.zeros(M, N, dtype=BF, device='cuda'), torch.zeros(M, N, dtype=BF, device='cuda')
+        ops.gemm(L.EPI_BIAS_GELU, x, w, out=g2, bias=b, aux_out=z, ld_aux=N)
+        assert torch.equal(z, ops.linear(x, w, b)) and torch.equal(g2, ops.linear(x, w, b, epi=L.EPI_BIAS_GELU))
     res, ls = rnd(M, N, seed=3), rnd(N, std=0.1, seed=4)
     close(ops.linear(x, w, b, epi=L.EPI_BIAS_LS_RES, res=res, ls=ls), res.float() + ls.float() * (ref + b.float()), name='ls_res')
     close(ops.linear(x, w, epi=L.EPI_RES, res=res), res.float() + ref, name='res')

@@ -10,7 +10,7 @@ M, H, I = 4, 768, 8960
 h = rnd(M, H, std=1.0); nw = torch.ones(H, dtype=BF, device=dev)
 parts = torch.randn(8, M, H, device=dev) * 0.1
 out = torch.zeros(M, I, dtype=BF, device=dev); hout = torch.zeros(M, H, dtype=BF, device=dev)
-for tpu in (2,):
+for tpu in (2, 1):
     ws = [ops.pack_skinny(rnd(2 * I, H), 1, tpu) for _ in range(6)]
     dbg = torch.zeros(256 * 8, dtype=torch.int64, device=dev)
     for w in ws:   # last launch is HBM-cold for its own weights, I-cache warm-ish

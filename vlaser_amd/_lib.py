@@ -40,7 +40,7 @@ class SkinnyArgs(C.Structure):
 class FusedOguArgs(C.Structure):
     _fields_ = [('attn_m', vp), ('attn_l', vp), ('attn_o', vp), ('attn_splits', i32), ('attn_group', i32), ('attn_nq', i32), ('Wo', vp), ('K_o', i32),
                 ('ks_o', i32), ('part_o', vp), ('h_in', vp), ('norm_w', vp), ('eps', f32), ('h_out', vp), ('Wgu', vp), ('M', i32), ('H', i32),
-                ('N_gu', i32), ('n_valid_gu', i32), ('act', vp), ('ld_act', i32), ('sync', vp)]
+                ('N_gu', i32), ('n_valid_gu', i32), ('act', vp), ('ld_act', i32), ('sync', vp), ('cons_delay', i32), ('dbg', vp)]
 
 
 FUSED_SYNC_WORDS, FUSED_SYNC_ERR = 160, 128

@@ -47,6 +47,7 @@ struct FusedOguP {
 
 __device__ __forceinline__ int eu_fdiv(int x, float inv_d) { return (int)(((float)x + 0.5f) * inv_d); }
 __device__ __forceinline__ unsigned long long eu_clock() { return wall_clock64(); }      // 100 MHz, constant rate
+#define EU_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 
 // ---- consumer half: wait for the producers, gather the o_proj slabs, residual + RMSNorm, gate/up on NU register-resident units, SwiGLU ------------------
 // w[u][s]: fragments of unit (ustart + u), K-step s of this wave (u >= ucount: clamped duplicates, never stored).
@@ -73,6 +74,7 @@ __device__ __forceinline__ void ogu_tail(const FusedOguP& p, char* smem, const u
       __builtin_amdgcn_s_sleep(2);
     }
     if (!all_ok && lane == 0) __hip_atomic_store(ctr + EU_ERR, 1u, EU_RLX_AGENT);
+    EU_STAMP(3);
   }
   __syncthreads();
   // ---- 2. gather the KSO fp32 slabs of this thread's 8 columns (write-through by the producers -> sc1 loads, no fence) + residual -> bf16 h'
@@ -99,6 +101,7 @@ __device__ __forceinline__ void ogu_tail(const FusedOguP& p, char* smem, const u
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) hv[j] = pack_bf16x2(sl[2 * j] + v[2 * j], sl[2 * j + 1] + v[2 * j + 1]);
+    if (a.dbg) { asm volatile("" ::"v"(hv[0])); EU_STAMP(4); }
   }
   // ---- 3. RMSNorm: sum of squares 16-lane group -> LDS -> fixed-order row total; every thread normalises its own 8 values
   const int ngr = cpr >> 4, gstride = (ngr + 3) & ~3;
@@ -131,6 +134,7 @@ __device__ __forceinline__ void ogu_tail(const FusedOguP& p, char* smem, const u
     if (tid < nch) *reinterpret_cast<u32x4*>(xs + mm * p.xs_stride_h + c * 2) = o;
   }
   __syncthreads();
+  EU_STAMP(5);
   // ---- 4. gate/up: every wave its K slice of all NU units, partials through LDS, ONE barrier, wave u finishes unit u
   const char* xrow = xs + (fr < a.M ? fr : 0) * p.xs_stride_h + (wave * (NSG * 32) + g * 8) * 2;
   const bool mok = fr < a.M;
@@ -161,6 +165,7 @@ __device__ __forceinline__ void ogu_tail(const FusedOguP& p, char* smem, const u
       *reinterpret_cast<uint32_t*>(o) = pack_bf16x2(r0, r1);
     }
   }
+  EU_STAMP(6);
 }
 
 template <int NSO, int NSG, int SPL, int KSO, int NUP, int NUC>
@@ -170,6 +175,7 @@ __global__ __launch_bounds__(EU_T) void fused_ogu_kernel(FusedOguP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
   const int bid = blockIdx.x;
   const int H = a.H, cpr = H >> 3, nch = a.M * cpr;
+  EU_STAMP(0);
   // residual chunk + norm-weight chunk of this thread (both roles), requested first: small and L2 / fabric resident
   const int ch = min(tid, nch - 1);
   const int mm = eu_fdiv(ch, p.inv_cpr_h), c = (ch - mm * cpr) << 3;
@@ -233,6 +239,7 @@ __global__ __launch_bounds__(EU_T) void fused_ogu_kernel(FusedOguP p) {
       if (tid < nch_o) *reinterpret_cast<u32x4*>(xo + mo * p.xs_stride_o + jo * 16) = xr;
     }
     __syncthreads();
+    EU_STAMP(1);
     // ---- o_proj MFMA on this wave's K slice, partials through LDS
     const int xo_bytes = (a.M * p.xs_stride_o + 15) & ~15;
     float* redo = reinterpret_cast<float*>(smem + xo_bytes);                     // [EU_W - 1][64][4]
@@ -257,6 +264,7 @@ __global__ __launch_bounds__(EU_T) void fused_ogu_kernel(FusedOguP p) {
         if (fr < a.M) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rs, ((ks * a.M + fr) * H + n0) * 4, 0, 16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add((eu_gu32*)(a.sync) + (bid & 3) * EU_CTR_STRIDE, 1u, EU_RLX_AGENT);
+        EU_STAMP(2);
       }
     }
     // ---- gate/up weights of this workgroup's units, requested only NOW: vmcnt counts loads and stores in one in-order queue, so with these in flight
@@ -275,6 +283,10 @@ __global__ __launch_bounds__(EU_T) void fused_ogu_kernel(FusedOguP p) {
     const int cb = bid - p.n_prod;
     const int ucount = p.uc_lo + (cb < p.uc_rem ? 1 : 0);
     const int ustart = p.n_prod * p.up_lo + p.up_rem + cb * p.uc_lo + min(cb, p.uc_rem);
+    if (a.cons_delay > 0) {        // tuning knob: hold the bulk weight stream back so that the producers' small dependent requests do not queue behind 27 MB
+      const unsigned long long t0 = eu_clock();
+      while (eu_clock() - t0 < (unsigned long long)a.cons_delay) __builtin_amdgcn_s_sleep(1);
+    }
     u32x4 w[NUC][NSG];
 #pragma unroll
     for (int u = 0; u < NUC; ++u) {

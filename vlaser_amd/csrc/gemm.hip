@@ -57,7 +57,10 @@ __device__ __forceinline__ void epilogue(const VlaserGemmArgs& a, int m, int n0,
       if (n < a.N) {
         if constexpr (EPI == VL_EPI_BIAS || EPI == VL_EPI_BIAS_GELU || EPI == VL_EPI_BIAS_LS_RES)
           x += bf16_to_f32(reinterpret_cast<const bf16_t*>(a.bias)[n]);
-        if constexpr (EPI == VL_EPI_BIAS_GELU) x = gelu_erf(x);
+        if constexpr (EPI == VL_EPI_BIAS_GELU) {
+          if (a.aux_out) reinterpret_cast<bf16_t*>(a.aux_out)[(size_t)m * a.ld_aux + n] = f32_to_bf16(x);      // pre-activation kept for GELU's backward
+          x = gelu_erf(x);
+        }
         if constexpr (EPI == VL_EPI_BIAS_LS_RES)
           x = bf16_to_f32(reinterpret_cast<const bf16_t*>(a.res)[(size_t)m * a.ldo + n]) +
               bf16_to_f32(reinterpret_cast<const bf16_t*>(a.ls)[n]) * x;
@@ -368,15 +371,16 @@ __device__ __forceinline__ void epilogue_tile(const VlaserGemmArgs& a, int m_w, 
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) rv[nt] = *reinterpret_cast<const u32x2*>(res + row + n_w + nt * 16 + fq * 4);
     }
-    u32x2 pk[NT];
+    u32x2 pk[NT], pa[EPI == VL_EPI_BIAS_GELU ? NT : 1];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float r[4];
+      [[maybe_unused]] float z[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float x = acc[nt][mt][j];
         if constexpr (HAS_BIAS) x += (j & 1) ? bf16hi_to_f32(bv[nt][j >> 1]) : bf16lo_to_f32(bv[nt][j >> 1]);
-        if constexpr (EPI == VL_EPI_BIAS_GELU) x = gelu_erf(x);
+        if constexpr (EPI == VL_EPI_BIAS_GELU) { z[j] = x; x = gelu_erf(x); }
         if constexpr (EPI == VL_EPI_BIAS_LS_RES)
           x = ((j & 1) ? bf16hi_to_f32(rv[nt][j >> 1]) : bf16lo_to_f32(rv[nt][j >> 1])) +
               ((j & 1) ? bf16hi_to_f32(lv[nt][j >> 1]) : bf16lo_to_f32(lv[nt][j >> 1])) * x;
@@ -384,10 +388,18 @@ __device__ __forceinline__ void epilogue_tile(const VlaserGemmArgs& a, int m_w, 
         r[j] = x;
       }
       pk[nt] = u32x2{pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+      if constexpr (EPI == VL_EPI_BIAS_GELU) pa[nt] = u32x2{pack_bf16x2(z[0], z[1]), pack_bf16x2(z[2], z[3])};
     }
     if (m < a.M) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<u32x2*>(out + row + n_w + nt * 16 + fq * 4) = pk[nt];
+      if constexpr (EPI == VL_EPI_BIAS_GELU) {
+        if (a.aux_out) {                                   // SFT forward of the projector: the rounded pre-activations for GELU's backward (aux rows 8-byte aligned)
+          bf16_t* aux = reinterpret_cast<bf16_t*>(a.aux_out) + (size_t)m * a.ld_aux + n_w + fq * 4;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<u32x2*>(aux + nt * 16) = pa[nt];
+        }
+      }
     }
   }
 }

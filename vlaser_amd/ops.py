@@ -1,6 +1,7 @@
 """Thin torch-tensor wrappers over the C ABI (include/vlaser_hip.h).  PyTorch is plumbing here: it owns device
 memory and the stream; every op below is a launch of a hand-written gfx950 kernel in libvlaser_hip.so."""
 import ctypes as C
+import os
 
 
 import torch
@@ -272,7 +273,7 @@ def skinny(pro, epi, x, W: PackedW, M, **kw):
     launch_skinny(pro, epi, a)
 
 
-def fused_ogu_args(attn_parts, Wo: PackedW, part_o, h_in, norm_w, eps, h_out, Wgu: PackedW, M, act, sync, attn_splits, attn_group, attn_nq):
+def fused_ogu_args(attn_parts, Wo: PackedW, part_o, h_in, norm_w, eps, h_out, Wgu: PackedW, M, act, sync, attn_splits, attn_group, attn_nq, cons_delay=None, dbg=None):
     """Filled VlaserFusedOguArgs: o_proj (attention-split merge + split-K partial tiles) handed to gate/up (+ residual, RMSNorm, SwiGLU) inside ONE
     launch (csrc/euler.hip).  `sync`: int32 view of VL_FUSED_SYNC_WORDS words, zeroed by the caller on the stream before every launch."""
     assert Wo.tpu == 1 and Wgu.tpu == 1 and Wgu.k_splits == 1 and sync.numel() >= L.FUSED_SYNC_WORDS and sync.dtype == torch.int32
@@ -283,6 +284,8 @@ def fused_ogu_args(attn_parts, Wo: PackedW, part_o, h_in, norm_w, eps, h_out, Wg
     a.h_in, a.norm_w, a.eps, a.h_out = h_in.data_ptr(), norm_w.data_ptr(), eps, _p(h_out)
     a.Wgu, a.M, a.H, a.N_gu, a.n_valid_gu = Wgu.t.data_ptr(), M, Wgu.K, Wgu.N, Wgu.n_valid
     a.act, a.ld_act, a.sync = act.data_ptr(), act.stride(0), sync.data_ptr()
+    a.cons_delay = int(os.environ.get('VLASER_OGU_DELAY', '0')) if cons_delay is None else cons_delay
+    a.dbg = _p(dbg)
     return a
 
 

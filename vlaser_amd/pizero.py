@@ -110,8 +110,11 @@ def stage_pixels(pixel_values, out, dev):
 
 class PiZero:
     # Euler-phase kernel options of the action expert (VLASER_EULER overrides: comma list, "none" = the r02 kernels):
-    #   gu16 / qkv16: 16-row lane-local units for the gate/up and q/k/v weight-streaming GEMVs (r03a)
-    EULER_DEFAULT = 'gu16,qkv16'
+    #   qkv16: 16-row lane-local units for the q/k/v weight-streaming GEMV (128 instead of 64 workgroups): -0.88 us per layer-step in-chain
+    #   gu16: the same for gate/up (1120 units): +0.6 us in-chain (five serial unit-reduce rounds per workgroup) -- off
+    #   fuse_ogu (needs gu16): o_proj -> gate/up as one launch with an in-launch hand-off (csrc/euler.hip): +2.0 us in-chain -- off
+    # measurements + in-kernel timelines: profiles/r03c_euler_fusion.md
+    EULER_DEFAULT = 'qkv16'
 
     def __init__(self, cfg: VLAConfig, device='cuda', max_batch=1, use_graph=True, ride_proprio=True, naive_support=False, euler_opts=None):
         L.lib()
@@ -137,6 +140,7 @@ class PiZero:
         eo = os.environ.get('VLASER_EULER', self.EULER_DEFAULT) if euler_opts is None else euler_opts
         self.euler_opts = tuple(x for x in eo.split(',') if x and x != 'none')
         self._graphs = {}
+        self._pos_state = None
         if max_batch * cfg.num_action_tokens > 16:
             raise ValueError('the weight-streaming action path handles batch * horizon <= 16 rows')
 
@@ -167,6 +171,7 @@ class PiZero:
 
     def _alloc(self):
         cfg, dev, B = self.cfg, self.device, self.max_batch
+        self._pos_state = None                  # fresh (zeroed) position-id buffers
         llm = cfg.base.llm
         T = self.max_image_text_tokens
         self.s_max = (self.total_num_tokens + 63) // 64 * 64
@@ -200,6 +205,23 @@ class PiZero:
         self.pos_pro = z(B, dt=torch.int32)
         self.pos_act = z(B * self.num_action_tokens, dt=torch.int32)
         self.pos5 = z(16, dt=torch.int32)
+
+    def _stage_positions(self, B, vlm_position_ids, proprio_position_ids, action_position_ids):
+        """Position ids into the static buffers of the captured graph.  The reference's defaults (1..T, 1, 2..1+na; pizero_internvl.py:576-585)
+        are written ONCE per batch size: a per-call host tensor -> device copy from pageable memory makes the host wait for the previous
+        chunk, so every call started its ~10 small staging launches on an idle GPU (0.5 ms per chunk in r02's bench loop)."""
+        T, na = self.max_image_text_tokens, self.num_action_tokens
+        custom = not (vlm_position_ids is None and proprio_position_ids is None and action_position_ids is None)
+        if not custom and self._pos_state == ('default', B):
+            return
+        bpos = lambda p, default: (default if p is None else p).to(torch.int32).reshape(-1)
+        self.pos_vlm[:B * T].copy_(bpos(vlm_position_ids, torch.arange(1, T + 1).repeat(B, 1)))
+        self.pos_pro[:B].copy_(bpos(proprio_position_ids, torch.ones(B, 1, dtype=torch.long)))
+        self.pos_act[:B * na].copy_(bpos(action_position_ids, torch.arange(2, 2 + na).repeat(B, 1)))
+        if B == 1:
+            self.pos5[:1].copy_(self.pos_pro[:1])
+            self.pos5[1:1 + na].copy_(self.pos_act[:na])
+        self._pos_state = ('custom', B) if custom else ('default', B)
 
     # ------------------------------------------------------------------ reference helpers (API parity)
     def build_causal_mask_and_position_ids(self, attention_mask, dtype):
@@ -326,23 +348,17 @@ class PiZero:
         # ---- stage inputs into the static buffers (host->device plumbing)
         self.in_ids[:B].copy_(input_ids)
         stage_pixels(pixel_values, self.in_pix[:B * self.num_images], dev)
-        self.in_proprio[:B].copy_(proprios.reshape(B, -1).to(torch.float32))
+        self.in_proprio[:B].copy_(proprios.reshape(B, -1))
         if valid_len is None:
             if image_text_proprio_mask is not None:
                 valid_len = prep.mask_to_descriptor(image_text_proprio_mask.to('cpu'), T)
             else:
                 valid_len = (input_ids != self.pad_token_id).sum(-1)
-        self.valid_len[:B].copy_(valid_len.to(torch.int32))
-        bpos = lambda p, default: (default if p is None else p).to(torch.int32).reshape(-1)
-        self.pos_vlm[:B * T].copy_(bpos(vlm_position_ids, torch.arange(1, T + 1).repeat(B, 1)))
-        self.pos_pro[:B].copy_(bpos(proprio_position_ids, torch.ones(B, 1, dtype=torch.long)))
-        self.pos_act[:B * na].copy_(bpos(action_position_ids, torch.arange(2, 2 + na).repeat(B, 1)))
-        if B == 1:
-            self.pos5[:1].copy_(self.pos_pro[:1])
-            self.pos5[1:1 + na].copy_(self.pos_act[:na])
+        self.valid_len[:B].copy_(valid_len)                      # copy_ converts dtype and crosses devices in one op
+        self._stage_positions(B, vlm_position_ids, proprio_position_ids, action_position_ids)
         if noise is None:
             noise = torch.randn((B, na, cfg.action_dim), generator=generator)      # reference: torch.randn inside (:879-881)
-        self.in_noise[:B * na].copy_(noise.reshape(B * na, -1).to(torch.float32))
+        self.in_noise[:B * na].copy_(noise.reshape(B * na, -1))
         # ---- run (HIP graph replay after the first call per batch size)
         if self.use_graph:
             g = self._graphs.get(B)
@@ -397,10 +413,7 @@ class PiZero:
         if valid_len is None:
             valid_len = prep.mask_to_descriptor(causal_mask[:, :, :T + 1, :T + 1].to('cpu'), T) if causal_mask is not None else (input_ids != self.pad_token_id).sum(-1)
         self.valid_len[:1].copy_(valid_len.to(torch.int32))
-        bpos = lambda p, default: (default if p is None else p).to(torch.int32).reshape(-1)
-        self.pos_vlm[:T].copy_(bpos(vlm_position_ids, torch.arange(1, T + 1)[None]))
-        self.pos_pro[:1].copy_(bpos(proprio_position_ids, torch.ones(1, 1, dtype=torch.long)))
-        self.pos_act[:na].copy_(bpos(action_position_ids, torch.arange(2, 2 + na)[None]))
+        self._stage_positions(1, vlm_position_ids, proprio_position_ids, action_position_ids)
         if noise is None:
             noise = torch.randn((1, na, cfg.action_dim), generator=generator)
         self.action[:na].copy_(noise.reshape(na, -1).to(torch.float32))

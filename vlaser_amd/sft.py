@@ -386,8 +386,7 @@ class SFTModel:
         ps_raw, ps_ln, z1, g1, feat = self.ps_raw[:nt], self.ps_ln[:nt], self.z1[:nt], self.g1[:nt], self.feat[:nt]
         ops.pixel_shuffle(vit_w.h, ps_raw, T, G_, C1, 1 if cfg.ps_version == 'v1' else 0)
         ops.pixel_shuffle_ln(vit_w.h, v['mlp1.m0w'], v['mlp1.m0b'], ps_ln, T, G_, C1, 1e-5, 1 if cfg.ps_version == 'v1' else 0)
-        ops.gemm(L.EPI_BIAS, ps_ln, v['mlp1.m1w'], out=z1, bias=v['mlp1.m1b'])
-        ops.gemm(L.EPI_BIAS_GELU, ps_ln, v['mlp1.m1w'], out=g1, bias=v['mlp1.m1b'])
+        ops.gemm(L.EPI_BIAS_GELU, ps_ln, v['mlp1.m1w'], out=g1, bias=v['mlp1.m1b'], aux_out=z1, ld_aux=z1.stride(0))      # g1 + the pre-activation z1 (GELU backward)
         ops.gemm(L.EPI_BIAS, g1, v['mlp1.m3w'], out=feat, bias=v['mlp1.m3b'])
         if image_flags is not None:
             keep = self._h2d((image_flags.detach().to('cpu').reshape(-1) == 1).nonzero().flatten())          # indices of the real tiles
