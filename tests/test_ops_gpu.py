@@ -491,7 +491,7 @@ def test_gemm_splitk_reduce_norm(ops, M, N, K, S):
     close(h3, href.float(), rtol=8e-3, name='h none')
 
 
-@pytest.mark.parametrize('bm', [1100, 1200, 1300, 1440, 1500])
+@pytest.mark.parametrize('bm', [1100, 1105, 1200, 1300, 1440, 1500, 1506, 1532, 1564])
 def test_gemm_glds_ragged_and_splitk(ops, bm):
     """LDS-DMA pipelines on shapes that do not fill their tiles: ragged M and N (fp32 logits epilogue), K shorter than the stage
     ring (look-ahead tiles are clamped re-fetches), and split-K partial slabs."""

@@ -561,11 +561,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 // fetches logical slot (l&7) ^ (row&7) of row 8*piece + (l>>3).  The DMA is issued from inline asm so that hipcc neither
 // counts it nor drains it at its own waits (guide 5.7); ordering is ours: vmcnt(N) -> s_barrier -> ds_read.
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+// M0 is written and read inside ONE statement and NOT saved / restored (r03): hipcc reserves m0 but emits no use of it anywhere in this file (checked
+// in the ISA: every `m0` of gemm.s sits between #ASMSTART / #ASMEND), and the save + restore pair was 2 of the 5 issue slots of every 1-KiB piece
+// (3.1 SALU per MFMA on the 64x128 tile, profiles/r02t_pmc_gemm.md).
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+#ifndef GLDS_ISSUE_FIRST
+#define GLDS_ISSUE_FIRST 0        // 1 = r02 order (refill issued right behind the barrier, in front of the fragment reads)
+#endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // WKM ("W k-major", the NN form out = A @ B): the second operand is stored [K][N] row-major -- a weight matrix exactly as the
@@ -650,12 +654,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
     wait_vmcnt<PIECES * (NST - 2)>();                    // this wave's pieces of tile kt have landed (younger tiles may fly)
     __builtin_amdgcn_s_barrier();                        // ... and everyone else's; also: all waves are done reading stage kt-1
     int stn = st + NST - 1; if (stn >= NST) stn -= NST;  // = (kt-1) % NST: the stage read in the previous step
-    issue_tile(kt + NST - 1, stn);
     const char* As = smem + st * STAGE;
     const char* Ws = As + BM * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 fa[MT], fw[NT];
+      // (r03) the refill of stage kt-1 is issued BEHIND the first half's fragment reads: an LDS-DMA piece costs ~100-185 issue cycles
+      // (MI355X_MICROARCH.md), and in front of the reads the whole K-step sat behind PIECES of them before its first ds_read went out
+      if (ks == 1 && !GLDS_ISSUE_FIRST) issue_tile(kt + NST - 1, stn);
+      if (ks == 0 && GLDS_ISSUE_FIRST) issue_tile(kt + NST - 1, stn);
 #pragma unroll
       for (int t = 0; t < MT; ++t)
         fa[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + lds_off(wr * WTM + t * 16 + fr, ks * 4 + fq)));
@@ -764,6 +771,8 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
   if (bm == 0) {
     if (args->M <= 32 && !WKM) {
       bm = 32;
+    } else if (!WKM && blocks(64, 64) <= 256) {      // (the NN form's transposing reads need >= 16 slots per staged k-row: BNT >= 128)
+      bm = 1564;                       // r03: a K-step costs the same ~0.4 us whatever the tile, so the smallest problems want the most workgroups (profiles/r03e_gemm_lab.md)
     } else if (blocks(64, 128) <= 256) {
       bm = 1500;
     } else if (blocks(128, 128) <= 256) {
@@ -790,6 +799,12 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
     case 1300: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM>(args, stream, splits);
     case 1500: return launch_glds<EPI, 64, 128, 2, 4, 4, WKM>(args, stream, splits);
     case 1440: return launch_glds<EPI, 144, 128, 3, 2, 4, WKM>(args, stream, splits);
+    // r03: deeper rings / smaller tiles for the latency-bound single-round shapes (a K-step of the 64x128 tile takes ~0.38 us with 3 tiles in flight:
+    // the LDS-DMA round trip under load is ~1.1 us, so the bytes in flight per CU, not the MFMA pipe, set the rate)
+    case 1506: return launch_glds<EPI, 64, 128, 2, 4, 6, WKM>(args, stream, splits);
+    case 1105: return launch_glds<EPI, 128, 128, 2, 4, 5, WKM>(args, stream, splits);
+    case 1564: if constexpr (!WKM) return launch_glds<EPI, 64, 64, 2, 2, 8, false>(args, stream, splits); break;
+    case 1532: return launch_glds<EPI, 32, 128, 1, 4, 7, WKM>(args, stream, splits);
     default: break;
   }
   if constexpr (WKM) {
@@ -975,8 +990,8 @@ extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   VL_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "vlaser_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
   VL_CHECK(a->K % BK == 0, "vlaser_gemm: K=%d must be a multiple of %d", a->K, BK);
   VL_CHECK(a->batch <= 1 || (epi == VL_EPI_NONE || epi == VL_EPI_F32 || epi == VL_EPI_BIAS), "vlaser_gemm: batched mode supports NONE / F32 / BIAS epilogues");
-  VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1440 || a->force_bm == 1500,
-           "vlaser_gemm: force_bm must be 0/32/64/128 or an LDS-DMA configuration code 1100/1200/1300/1440/1500");
+  VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 || a->force_bm == 1564 || a->force_bm == 1532,
+           "vlaser_gemm: force_bm must be 0/32/64/128 or an LDS-DMA configuration code 1100/1105/1200/1300/1440/1500/1506/1532/1564");
   VL_CHECK(a->lda % 8 == 0 && a->ldw % 8 == 0, "vlaser_gemm: lda/ldw must be multiples of 8 (16-byte rows)");
   VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm: operands must be 16-byte aligned");
   switch (epi) {
@@ -1016,8 +1031,9 @@ extern "C" int vlaser_gemm_nn(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   VL_CHECK(a->M > 0 && a->N > 0 && a->K > 0 && a->K % BK == 0, "vlaser_gemm_nn: bad shape M=%d N=%d K=%d (K must be a multiple of %d)", a->M, a->N, a->K, BK);
   VL_CHECK(a->N % 8 == 0 && a->lda % 8 == 0 && a->ldw % 8 == 0 && a->ldw >= a->N, "vlaser_gemm_nn: N, lda, ldw must be multiples of 8 and ldw >= N");
   VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm_nn: operands must be 16-byte aligned");
-  VL_CHECK(a->force_bm == 0 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1440 || a->force_bm == 1500,
-           "vlaser_gemm_nn: force_bm must be 0 or an LDS-DMA configuration code 1100/1200/1300/1440/1500");
+  VL_CHECK(a->force_bm == 0 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 ||
+               a->force_bm == 1532,
+           "vlaser_gemm_nn: force_bm must be 0 or an LDS-DMA configuration code 1100/1105/1200/1300/1440/1500/1506/1532");
   VL_CHECK(a->batch <= 1 || epi == VL_EPI_NONE || epi == VL_EPI_F32, "vlaser_gemm_nn: batched mode supports the NONE / F32 epilogues");
   switch (epi) {
     case VL_EPI_NONE: VL_CHECK(a->out, "out null"); return launch<VL_EPI_NONE, true>(a, stream);

@@ -2,6 +2,8 @@
 // 16-byte vector accesses where the layout allows, fp32 statistics, deterministic reductions (no atomics).
 // GEMM-shaped backward work (dgrad, wgrad, attention backward through materialised per-head score matrices) goes
 // through vlaser_gemm on transposed operands produced by transpose_kernel.
+#include <stdlib.h>
+
 #include "common.h"
 #include "../../include/vlaser_hip.h"
 
@@ -599,6 +601,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(bf16_t* __restrict__ p, floa
 // 4096 workgroups 4.4-4.5 TB/s, 1024 4.4, 512 5.2, 256 5.5-5.7 (= 0.9 of the 6.3 TB/s a copy reaches), 192 5.1, 128 3.7; 512- and
 // 1024-thread workgroups lose; the seven streams thrash less with a narrow window of addresses in flight.
 static int adamw_grid_cap() {
+  static int forced = -1;                       // tuning: VLASER_ADAMW_BLOCKS caps the grid (fewer workgroups = less HBM pressure on kernels of other streams)
+  if (forced < 0) { const char* e = getenv("VLASER_ADAMW_BLOCKS"); forced = e ? atoi(e) : 0; }
+  if (forced > 0) return forced;
   static int cus[64] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;

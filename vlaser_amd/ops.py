@@ -416,18 +416,19 @@ def reduce_norm(h_in, partials, n_partials, M, C, h_out, x_out=None, bias=None, 
                                        h_out.data_ptr(), _p(x_out), M, C, _stream()), 'vlaser_reduce_norm')
 
 
-_GEMM_CFGS = ((1500, 64, 128, 701.0), (1100, 128, 128, 850.0), (1440, 144, 128, 900.0), (1200, 128, 256, 1040.0), (1300, 256, 256, 1208.0))
+_GEMM_CFGS = ((1564, 64, 64, 420.0), (1500, 64, 128, 701.0), (1100, 128, 128, 850.0), (1440, 144, 128, 900.0), (1200, 128, 256, 1040.0), (1300, 256, 256, 1208.0))
 
 
-def gemm_tile_config(M, N, splits=1, batch=1):
-    """Mirror of the tile choice in csrc/gemm.hip `launch<EPI>` (single-round rule, then least modelled time): (code, BM, BN, rate)."""
+def gemm_tile_config(M, N, splits=1, batch=1, nn=False):
+    """Mirror of the tile choice in csrc/gemm.hip `launch<EPI, WKM>` (single-round rule, then least modelled time): (code, BM, BN, rate);
+    nn: the NN form (vlaser_gemm_nn), which has no 64x64 and no 32-row configuration."""
     blocks = lambda bm, bn: -(-M // bm) * -(-N // bn) * splits * batch
-    if M <= 32:
+    if M <= 32 and not nn:
         return (32, 32, 128, 500.0)
     for c in _GEMM_CFGS:
-        if blocks(c[1], c[2]) <= 256:
+        if blocks(c[1], c[2]) <= 256 and not (nn and c[0] == 1564):
             return c
-    return min((c for c in _GEMM_CFGS if c[0] != 1440), key=lambda c: -(-blocks(c[1], c[2]) // 256) * c[1] * c[2] / c[3])
+    return min((c for c in _GEMM_CFGS if c[0] not in (1440, 1564)), key=lambda c: -(-blocks(c[1], c[2]) // 256) * c[1] * c[2] / c[3])
 
 
 def split_slab_elems(max_rows, N):
@@ -437,17 +438,23 @@ def split_slab_elems(max_rows, N):
     return max(8 * min(max_rows, 1024), 2 * max_rows) * N
 
 
-def gemm_splits(M, N, K, max_elems=None, max_splits=8):
+# per-launch time model of the LDS-DMA pipelines, fitted on MI355X (profiles/r03e_gemm_lab.md: 24 vs 64 K-steps per configuration):
+# a launch costs a fixed ~5-7 us (launch, cold first tiles, epilogue) + a per-K-step time that grows with the tile area
+_GEMM_STEP_US = {32: (5.0, 0.30), 1564: (4.9, 0.177), 1500: (5.1, 0.263), 1100: (5.3, 0.377), 1440: (5.6, 0.509), 1200: (7.0, 0.62), 1300: (9.0, 1.55)}
+
+
+def gemm_splits(M, N, K, max_elems=None, max_splits=8, nn=False):
     """Split-K factor for a [M,N] output whose tiles alone cannot fill 256 CUs: the factor (K/splits a multiple of 64 and >= 256, at
-    most max_splits, splits*M*N fp32 slab elements within max_elems) with the least modelled time = rounds x tile FLOPs / measured
-    tile rate (profiles/r02b_gemm_lab.md) + the consumer's cost of summing the extra fp32 slabs."""
+    most max_splits, splits*M*N fp32 slab elements within max_elems) with the least modelled time = rounds x (fixed + K-steps x step time
+    of the tile configuration the kernel will pick) + the consumer's cost of summing the extra fp32 slabs."""
     best = (None, 1)
     for s in range(1, max_splits + 1):
         if K % (s * 64) or K // s < 256 or (s > 1 and max_elems is not None and s * M * N > max_elems):
             continue
-        code, bm, bn, rate = gemm_tile_config(M, N, s)
+        code, bm, bn, _ = gemm_tile_config(M, N, s, nn=nn)
         blocks = -(-M // bm) * -(-N // bn) * s
-        t = -(-blocks // 256) * (2.0 * bm * bn * (K // s) * 256 / (rate * 1e12) * 1e6 + 2.0) + (s > 1) * (0.35 * s + M * N * 4.0 * s / 4e6)
+        fixed, step = _GEMM_STEP_US[code]
+        t = -(-blocks // 256) * (fixed + (K // s // 64) * step) + (s > 1) * (0.35 * s + M * N * 4.0 * s / 4e6)
         if best[0] is None or t < best[0] - 1e-9:
             best = (t, s)
     return best[1]

@@ -243,7 +243,7 @@ class SFTModel:
         self.comm_stream = torch.cuda.Stream(device=dev) if self.dp_active else None
         # single rank: AdamW (HBM-bound, a third of a step) runs on its own stream bucket by bucket in the order the next forward
         # consumes the parameters, so the next step's frozen-ViT / early-layer GEMMs (MFMA-bound) overlap it
-        self.opt_stream = torch.cuda.Stream(device=dev)
+        self.opt_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get('VLASER_SFT_OPT_PRIORITY', '0')))
 
     def _alloc_projector_ws(self):
         """Projector (mlp1) workspaces, sized for `max_tiles` tiles x 256 visual tokens."""
@@ -295,7 +295,7 @@ class SFTModel:
         Nin, Kout = W.shape
         # measured at S = 560, 1536 outputs (tools/micro/nn_lab.py): contraction <= 2048 -> one pass (11.5-14.6 us) beats split-K slabs +
         # their reduction (9-11 + 5 us); longer contractions (8960 / 17920) keep split-K
-        sp = 1 if Nin <= 2048 else ops.gemm_splits(S, Kout, Nin)
+        sp = 1 if Nin <= 2048 else ops.gemm_splits(S, Kout, Nin, nn=True)
         if sp > 1:
             part = self.part[:sp * S * Kout]
             ops.gemm_nn(L.EPI_PARTIAL, dY, W, out_f32=part, k_splits=sp)
