@@ -310,6 +310,28 @@ int vlaser_silu_bwd(const void* x, const void* dy, void* dx, long long n, vl_str
 int vlaser_attn_rows_bwd(const void* q, const void* K, const void* VT, const void* dO, const void* O, void* dq, void* dk, void* dv, int R, int n_q,
                          int n_kv, int s_max, int valid_len, int blk_start, int first_tok_self, float scale, vl_stream_t stream);
 
+/* ---- f1 with `train_vlm: True` (ABI 4, r03): the reference's second parameter group `trainable_vlm_parameters` (pizero_internvl.py:405-411 =
+ * vision tower + projector + the VLM mixture's decoder layers; optimiser + schedule train.py:270-295, stepped :509-520).  The gradient reaches the
+ * VLM through the keys / values its rows hand to the proprio / action rows, then runs back through the Qwen2 layers (bidirectional valid-prefix
+ * mask), mlp1, pixel_shuffle and the 24 InternViT blocks (modeling_intern_vit.py:177-295: LayerNorm, full attention, GELU MLP, layer scale). */
+/* vlaser_attn_bwd_pds with an explicit mask: key k is visible to query q iff k < kv_valid and (k <= q when causal != 0) */
+int vlaser_attn_bwd_pds_masked(const float* scores, const float* dP, const void* dO, const void* O, void* P, void* dS, int n_heads, int S, int ld, int hd,
+                               float scale, int causal, int kv_valid, vl_stream_t stream);
+/* vlaser_attn_rows_bwd that also stores P and dS of EVERY key, bf16 [n_q][16][s_max] (row r of head h at (h*16 + r)*s_max): the prefix keys' dK / dV
+ * then come from vlaser_gemm_tn_grouped (contraction over the R rows, summed over the q heads of a kv group) */
+int vlaser_attn_rows_bwd_ex(const void* q, const void* K, const void* VT, const void* dO, const void* O, void* dq, void* dk, void* dv, int R, int n_q,
+                            int n_kv, int s_max, int valid_len, int blk_start, int first_tok_self, float scale, void* p_out, void* ds_out, vl_stream_t stream);
+/* vlaser_rope_bwd_pack with a second source of key / value gradients for the same rows (bf16 [S, n_kv*128], nullable), added in fp32 before the rotation */
+int vlaser_rope_bwd_pack_ex(const void* dq, const void* dk, const void* dv, const float* rope_cos, const float* rope_sin, const int32_t* pos_ids,
+                            void* out_packed, int S, int n_q, int n_kv, int kv_per_q_head, const void* dk_extra, const void* dv_extra, vl_stream_t stream);
+/* nn.LayerNorm backward (NORM2FN['layer_norm'], modeling_intern_vit.py:127-130): dx_out = dres + LN'(dy); the affine gradients are column sums
+ * (vlaser_colsum_mul mode 3 / mode 0) */
+int vlaser_layernorm_bwd(const void* dy, const void* x, const void* w, const void* dres /* nullable */, void* dx_out, int S, int C, float eps, vl_stream_t stream);
+/* out[s,c] = x[s,c] * alpha * (vec ? vec[c] : 1) (bf16; row strides ldx / ldo): layer-scale factor in the backward of a ViT residual branch */
+int vlaser_scale_cols(const void* x, const void* vec /* nullable */, void* out, int S, int C, int ldx, int ldo, float alpha, vl_stream_t stream);
+/* backward of vlaser_pixel_shuffle: dx bf16 [T, G*G+1, C] (CLS rows zero) from dout [T*(G/2)^2, 4C] */
+int vlaser_pixel_unshuffle(const void* dout, void* dx, int T, int G, int C, int ps_v1, vl_stream_t stream);
+
 /* EMA / SWA of the trained parameters (ABI 4): `ModelAveraging.maybe_update` (Vlaser_VLA/Simpler/src/agent/model_averaging.py:8-72, called at
  * train.py:524-528) = torch.optim.swa_utils.AveragedModel.update_parameters on the rank's fp32 shard: first != 0: avg = p; else
  * avg += (p - avg) * c, c = 1 - ema_decay (EMA) or 1 / (n_averaged + 1) (SWA). */

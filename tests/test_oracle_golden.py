@@ -215,3 +215,38 @@ def test_packed_sequence_loss_vs_reference(golden_dir, golden_model):
     loss = ovlm.packed_loss(logits, torch.from_numpy(d['labels']), torch.from_numpy(d['loss_weight']))
     np.testing.assert_allclose(loss.item(), float(d['loss']), rtol=2e-5)
     np.testing.assert_allclose(logits[0, -1].topk(8).values.numpy(), d['last_logits'], rtol=0, atol=2e-4)
+
+
+def test_flow_matching_vlm_group_grads_vs_reference(golden_dir, golden_model):
+    """G10b: `train_vlm: True` -- the reference's `PiZero.forward` + autograd with `trainable_vlm_parameters` (pizero_internvl.py:405-411: vision
+    tower, projector, the VLM mixture's decoder layers) unfrozen next to the action-expert group: same loss as G10, 90 gradient tensors; the
+    VLM's last-layer post-attention parameters, its q projection there and its final norm receive none."""
+    _, vla, sd = golden_model
+    d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))
+    f = np.load(os.path.join(golden_dir, 'g10b_flow_matching_vlm.npz'))
+    f10 = np.load(os.path.join(golden_dir, 'g10_flow_matching.npz'))
+    for case in ('a', 'b'):
+        names, nograd = [str(n) for n in f[f'{case}_names']], [str(n) for n in f[f'{case}_nograd']]
+        assert float(f[f'{case}_loss']) == float(f10[f'{case}_loss']) and set(str(n) for n in f10[f'{case}_names']) <= set(names) and len(names) == 90
+        g = torch.Generator().manual_seed(int(d[f'{case}_seed']))
+        pv = torch.randn(1, 3, 448, 448, generator=g)
+        ids = torch.from_numpy(d[f'{case}_input_ids'])
+        am = (ids != vla.base.pad_token_id).long()
+        m, vp, pp, ap = ovla.build_causal_mask_and_position_ids(am, torch.float32, vla)
+        torch.set_grad_enabled(True)
+        try:
+            sdg = {k: (v.clone().requires_grad_(True) if (k in names or k in nograd) and k in sd else v) for k, v in sd.items()}
+            loss = ovla.flow_matching_loss(sdg, vla, ids, pv, m, vp, pp, ap, torch.from_numpy(d[f'{case}_proprio']), torch.from_numpy(f[f'{case}_actions']),
+                                           torch.from_numpy(f[f'{case}_t']), torch.from_numpy(f[f'{case}_x0']))
+            loss.backward()
+        finally:
+            torch.set_grad_enabled(False)
+        np.testing.assert_allclose(loss.item(), float(f[f'{case}_loss']), rtol=2e-5)
+        for n in names:
+            gr = sdg[n].grad.double().flatten()
+            np.testing.assert_allclose(gr.norm().item(), float(f[f'{case}_norm::{n}']), rtol=1e-3, err_msg=n)
+            np.testing.assert_allclose(gr[torch.from_numpy(f[f'{case}_idx::{n}'])].numpy(), f[f'{case}_val::{n}'], rtol=1e-2,
+                                       atol=2e-6 * float(f[f'{case}_norm::{n}']) + 1e-10, err_msg=n)
+        for n in nograd:
+            if n in sdg and sdg[n].requires_grad:
+                assert sdg[n].grad is None or float(sdg[n].grad.abs().max()) == 0.0, n

@@ -98,3 +98,106 @@ def test_step_accumulation_and_determinism(golden_model, golden_dir):
     assert t.min() >= 0 and t.max() <= 0.999 and abs(t.mean().item() - 0.999 * (1 - 1.5 / 2.5)) < 0.02     # E[1 - Beta(1.5, 1)] = 0.4
     assert cosine_warmup_restarts_lr(0, 100, 1.0, 0.1, 10) == 0.1 and abs(cosine_warmup_restarts_lr(10, 100, 1.0, 0.1, 10) - 1.0) < 1e-12
     assert abs(cosine_warmup_restarts_lr(100, 100, 1.0, 0.1, 10) - 0.1) < 1e-12      # restart
+
+
+# ------------------------------------------------------------------------------------------------ train_vlm: True (the reference's second parameter group)
+@pytest.fixture(scope='module')
+def trainer_vlm(golden_model):
+    from vlaser_amd.vla_train import VLATrainer
+    _, vla, sd = golden_model
+    m = VLATrainer(vla, lr=1e-3, max_grad_norm=1.0, bucket_layers=1, train_vlm=True, vlm_lr=1e-4)
+    m.load_state_dict(sd)
+    return m
+
+
+@pytest.mark.parametrize('case', ['a', 'b'])
+def test_vlm_group_loss_and_grads_vs_reference_golden(trainer_vlm, golden_dir, case):
+    """G10b: `train_vlm: True` -- loss and all 90 gradient tensors (action expert + vision tower + projector + the VLM's decoder layers) against the
+    reference's own `PiZero.forward` + autograd with `trainable_vlm_parameters` unfrozen; the tensors the reference leaves without a gradient
+    (the VLM's last-layer q projection / post-attention half, its final norm) are exactly zero here."""
+    smp, _ = _case(golden_dir, case)
+    f = np.load(os.path.join(golden_dir, 'g10b_flow_matching_vlm.npz'))
+    loss = trainer_vlm.forward_backward(**smp)
+    assert abs(loss.item() - float(f[f'{case}_loss'])) < 1e-2, (loss.item(), float(f[f'{case}_loss']))
+    grads = trainer_vlm.named_grads()
+    names = [str(n) for n in f[f'{case}_names']]
+    assert set(names) <= set(grads)
+    worst = []
+    for n in names:
+        g = grads[n].double().flatten().cpu()
+        ref_norm = float(f[f'{case}_norm::{n}'])
+        rel_norm = abs(g.norm().item() - ref_norm) / (ref_norm + 1e-12)
+        worst.append((round(rel_norm, 4), n))
+        idx = torch.from_numpy(f[f'{case}_idx::{n}'])
+        np.testing.assert_allclose(g[idx].numpy(), f[f'{case}_val::{n}'], rtol=0, atol=8e-2 * ref_norm / max(1.0, g.numel() ** 0.5) * 8 + 1e-7, err_msg=n)
+    worst.sort(reverse=True)
+    print('worst gradient-norm errors', worst[:8])
+    for rel_norm, n in worst:
+        assert rel_norm < 6e-2, (n, rel_norm)
+    for n in (str(x) for x in f[f'{case}_nograd']):
+        if n in grads:
+            assert float(grads[n].float().abs().max()) == 0.0, n
+
+
+def test_vlm_group_grads_vs_oracle_autograd_full_tensors(trainer_vlm, golden_model, golden_dir):
+    """Every element of every VLM-group gradient against torch autograd through the fp32 oracle (pinned to G10b on CPU): relative Frobenius
+    error and cosine per tensor."""
+    from oracle import vla as ovla
+    _, vla, sd = golden_model
+    smp, f = _case(golden_dir, 'a')
+    loss = trainer_vlm.forward_backward(**smp)
+    grads = trainer_vlm.named_grads()
+    am = (smp['input_ids'] != vla.base.pad_token_id).long()
+    mask, vp, pp, ap = ovla.build_causal_mask_and_position_ids(am, torch.float32, vla)
+    torch.set_grad_enabled(True)
+    try:
+        sdg = {k: (v.clone().requires_grad_(True) if k in grads else v) for k, v in sd.items()}
+        ref = ovla.flow_matching_loss(sdg, vla, smp['input_ids'], smp['pixel_values'], mask, vp, pp, ap, smp['proprios'], smp['actions'], smp['t'], smp['x0'])
+        ref.backward()
+    finally:
+        torch.set_grad_enabled(False)
+    assert abs(loss.item() - ref.item()) < 1e-2
+    rows = []
+    for k, g in grads.items():
+        b = sdg[k].grad
+        a = g.float().cpu().flatten()
+        if b is None or float(b.abs().max()) == 0.0:
+            assert float(a.abs().max()) == 0.0, k
+            continue
+        b = b.flatten()
+        rel = ((a - b).norm() / (b.norm() + 1e-30)).item()
+        cos = F.cosine_similarity(a, b, dim=0).item()
+        rows.append((round(rel, 4), round(cos, 5), k))
+    rows.sort(reverse=True)
+    print('worst tensors (rel Frobenius, cosine):', rows[:10])
+    for rel, cos, k in rows:
+        assert rel < 8e-2 and cos > 0.997, (k, rel, cos)
+
+
+def test_vlm_group_step_two_optimisers_and_accumulation(golden_model, golden_dir):
+    """One clip over both groups, two AdamW updates with their own learning rates (train.py:504-520): the loss on the sample goes down, a zero
+    vlm_lr leaves the VLM untouched while the expert moves, two runs are bit-identical, and accumulation of two samples == the mean gradient."""
+    from vlaser_amd.vla_train import VLATrainer
+    _, vla, sd = golden_model
+    a, _ = _case(golden_dir, 'a')
+    b, _ = _case(golden_dir, 'b')
+    runs = []
+    for _ in range(2):
+        m = VLATrainer(vla, lr=1e-4, max_grad_norm=1.0, train_vlm=True, vlm_lr=2e-5); m.load_state_dict(sd)
+        l0 = m.forward_backward(**a).item()
+        outs = [m.step([a, b]) for _ in range(3)]
+        l1 = m.forward_backward(**a).item()
+        runs.append((l0, l1, [o.loss.item() for o in outs], m.fp.p.clone(), m.vg.fp.p.clone()))
+    assert runs[0][1] < runs[0][0], runs[0][:2]
+    assert runs[0][2] == runs[1][2] and torch.equal(runs[0][3], runs[1][3]) and torch.equal(runs[0][4], runs[1][4])
+    m = VLATrainer(vla, lr=1e-4, max_grad_norm=0.0, train_vlm=True, vlm_lr=0.0); m.load_state_dict(sd)
+    p0, e0 = m.vg.fp.p.clone(), m.fp.p.clone()
+    m.forward_backward(**a); ga = m.vg.fp.g.float().clone()
+    m.forward_backward(**b); gb = m.vg.fp.g.float().clone()
+    m.step([a, b])
+    assert torch.equal(m.vg.fp.g, ((ga + gb) * 0.5).to(BF))
+    assert torch.equal(m.vg.fp.p, p0) and not torch.equal(m.fp.p, e0)
+    # the trained weights leave through the reference's key names: every VLM tensor of the checkpoint comes from the flat buffer
+    out = m.state_dict()
+    assert 'vision_model.embeddings.patch_embedding.weight' in out and out['vision_model.embeddings.patch_embedding.weight'].shape == (1024, 3, 14, 14)
+    assert torch.equal(out['mlp1.1.weight'].cpu(), sd['mlp1.1.weight'].to(BF)) and torch.equal(out['vision_model.encoder.layers.0.ls1'].cpu(), sd['vision_model.encoder.layers.0.ls1'].to(BF))

@@ -356,6 +356,7 @@ def g7_vla(vla, sd, ref_vlm):
         d[f'{case}_noise'] = noise.numpy(); d[f'{case}_action'] = act.numpy()
         print('G7', case, act)
     np.savez_compressed(os.path.join(OUT, 'g7_vla.npz'), **d)
+    fake._ref_vlm = ref_vlm
     return fake
 
 
@@ -501,6 +502,60 @@ def g10_flow_matching(fake, vla):
     np.savez_compressed(os.path.join(OUT, 'g10_flow_matching.npz'), **d)
 
 
+def g10b_flow_matching_vlm(fake, vla, ref_vlm):
+    """G10b: the same flow-matching training loss with the reference's SECOND parameter group unfrozen --
+    `trainable_vlm_parameters` (pizero_internvl.py:405-411) = vision_tower + multi_modal_projector + joint_model.mixtures["vlm"] (the LLM's
+    decoder layers and final norm; embed_tokens is NOT in the group) -- on top of `action_expert_parameters`, i.e. `train_vlm: True`
+    (train.py:270-295).  Loss (identical to G10's) and every gradient `PiZero.forward` + autograd produces: the gradient reaches the VLM
+    only through the K / V the image/text rows hand to the proprio / action rows (block mask, :517-587); the last layer's post-attention
+    parameters and the final norm of the VLM mixture get none (`final_layer_post_attn_skip_names`)."""
+    import types as _t
+    fake.flow_sig_min = 0.001
+    fake.psi_t = _t.MethodType(RP.PiZero.psi_t, fake)
+    expert = fake.internvl_model.action_expert
+    mods = {'action_expert.model.': expert.model, 'action_encoder.': fake.action_encoder, 'proprio_encoder.': fake.proprio_encoder,
+            'action_decoder.': fake.action_decoder, 'vision_model.': ref_vlm.vision_model, 'mlp1.': ref_vlm.mlp1,
+            'language_model.model.layers.': ref_vlm.language_model.model.layers, 'language_model.model.norm.': ref_vlm.language_model.model.norm}
+    params = {}
+    for pre, m in mods.items():
+        for n, p_ in m.named_parameters():
+            p_.requires_grad_(True); p_.grad = None
+            params[pre + n] = p_
+    for p_ in list(fake.embed_tokens.parameters()) + list(ref_vlm.language_model.lm_head.parameters()):
+        p_.requires_grad_(False)
+    d = {}
+    for case, (seed, n_valid, tval) in {'a': (0, 277, 0.35), 'b': (1, 300, 0.8)}.items():
+        pv, ids, am, proprio, mask, vp, pp, ap = _g7_case(fake, seed, n_valid)
+        g = torch.Generator().manual_seed(100 + seed)
+        actions = torch.rand(1, 4, 7, generator=g) * 2 - 1
+        t = torch.tensor([tval])
+        torch.manual_seed(4321 + seed)
+        x0 = torch.randn_like(actions)
+        torch.manual_seed(4321 + seed)
+        for p_ in params.values():
+            p_.grad = None
+        with torch.enable_grad():
+            loss = RP.PiZero.forward(fake, ids, pv, mask, vp, pp, ap, proprio, actions, t)
+            loss.backward()
+        d[f'{case}_actions'] = actions.numpy(); d[f'{case}_t'] = t.numpy(); d[f'{case}_x0'] = x0.numpy(); d[f'{case}_loss'] = np.array(loss.item())
+        names, nograd = [], []
+        for n, p_ in params.items():
+            if p_.grad is None or float(p_.grad.abs().max()) == 0.0:
+                nograd.append(n)
+                continue
+            gr = p_.grad.detach().double().flatten()
+            names.append(n)
+            d[f'{case}_norm::{n}'] = np.array(gr.norm().item())
+            k = min(32, gr.numel())
+            idx = (torch.arange(k, dtype=torch.int64) * (gr.numel() - 1)) // max(1, k - 1)
+            d[f'{case}_idx::{n}'] = idx.numpy(); d[f'{case}_val::{n}'] = gr[idx].numpy()
+        d[f'{case}_names'] = np.array(names); d[f'{case}_nograd'] = np.array(nograd)
+        print('G10b', case, 'loss', loss.item(), len(names), 'gradient tensors;', len(nograd), 'without gradient:', nograd[:6])
+    for p_ in params.values():
+        p_.requires_grad_(False); p_.grad = None
+    np.savez_compressed(os.path.join(OUT, 'g10b_flow_matching_vlm.npz'), **d)
+
+
 def g11_packed(cfg, ref_vlm):
     """G11: packed-sequence SFT loss (`--use_packed_ds`) from the reference's own `InternVLChatModel.forward` with `loss_weight`
     (modeling_internvl_chat.py:207-230).  The reference realises the block-diagonal causal attention with flash_attn_varlen_func
@@ -591,9 +646,12 @@ def main():
         sd = synth.vla_state_dict(vla, with_head=True)
         vlm_sd = {k: v for k, v in sd.items() if k.startswith(('vision_model.', 'mlp1.', 'language_model.'))}
         fake = g7_vla(vla, sd, build_ref_vlm(cfg, vlm_sd))
+        if '--only-g10b' in sys.argv:
+            return g10b_flow_matching_vlm(fake, vla, fake._ref_vlm)
         if '--skip-g7b' not in sys.argv:
             g7b_trace(fake, vla)
-        return g10_flow_matching(fake, vla)
+        g10_flow_matching(fake, vla)
+        return g10b_flow_matching_vlm(fake, vla, fake._ref_vlm)
     if '--only-g6b' not in sys.argv:
         tok = ref_import.tokenizer()
         g1_prompts(tok)

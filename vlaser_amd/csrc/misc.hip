@@ -206,6 +206,29 @@ extern "C" int vlaser_pixel_shuffle(const void* x, void* out, int T, int G, int 
   return 0;
 }
 
+// backward of pixel_shuffle(x[:, 1:]) (f1, train_vlm): the same permutation run the other way, dx [T, G*G+1, C] (CLS row zero) from dout [T*(G/2)^2, 4C]
+__global__ __launch_bounds__(256) void pixel_unshuffle_kernel(const bf16_t* __restrict__ dout, bf16_t* __restrict__ dx, int T, int G, int C, int transpose_v1) {
+  const int G2 = G / 2;
+  const int tok = blockIdx.x;
+  const int t = tok / (G2 * G2), r = tok - t * G2 * G2;
+  int i = r / G2, j = r - i * G2;
+  if (transpose_v1) { const int tmp = i; i = j; j = tmp; }
+  bf16_t* base = dx + (size_t)t * (G * G + 1) * C;
+  if (r == 0)
+    for (int c = threadIdx.x * 8; c < C; c += 256 * 8) st_global_16(base + c, u32x4{0, 0, 0, 0});       // CLS token: dropped by extract_feature (:284)
+  for (int c = threadIdx.x * 8; c < 4 * C; c += 256 * 8) {
+    const int ab = c / C;
+    bf16_t* dst = base + (size_t)(1 + (2 * i + (ab >> 1)) * G + (2 * j + (ab & 1))) * C + (c % C);
+    st_global_16(dst, ld_global_16(dout + (size_t)tok * 4 * C + c));
+  }
+}
+extern "C" int vlaser_pixel_unshuffle(const void* dout, void* dx, int T, int G, int C, int ps_v1, vl_stream_t s) {
+  VL_CHECK(dout && dx && G % 2 == 0 && C % 8 == 0, "vlaser_pixel_unshuffle: bad args");
+  hipLaunchKernelGGL(pixel_unshuffle_kernel, dim3(T * (G / 2) * (G / 2)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dout, (bf16_t*)dx, T, G, C, ps_v1);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- embedding + scatter
 // rank[s] = number of <IMG_CONTEXT> tokens before position s (row-major over [B,S]) if ids[s] is one, else -1.
 // Single block exclusive scan (n <= 2^20).  modeling_internvl_chat.py:422-425 / pizero_internvl.py:764-791.

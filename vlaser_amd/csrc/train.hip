@@ -137,9 +137,12 @@ extern "C" int vlaser_attn_bwd_ds(const void* P, const float* dP, const void* dO
 // dS = P (dP - D) scale.  dK / dV then come from the grouped TN GEMM, so no transposed copies of P / dS are produced.
 __global__ __launch_bounds__(256) void attn_bwd_pds_kernel(const float* __restrict__ sc, const float* __restrict__ dP, const bf16_t* __restrict__ dO,
                                                            const bf16_t* __restrict__ O, bf16_t* __restrict__ P, bf16_t* __restrict__ dS, int H, int S,
-                                                           int ld, int hd, float scale) {
+                                                           int ld, int hd, float scale, int causal, int kv_valid) {
+  // visibility of key k for query q: k < kv_valid and (k <= q when causal).  causal = 1, kv_valid = ld: the SFT step's causal mask; causal = 0:
+  // the bidirectional valid prefix of the VLA block mask (pizero_internvl.py:517-587) and the ViT's full attention (r03, f1)
   const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y;
   if (q >= S) return;
+  const int klim = causal ? min(q + 1, kv_valid) : kv_valid;
   const bf16_t* dorow = dO + (size_t)q * H * hd + h * hd;
   const bf16_t* orow = O + (size_t)q * H * hd + h * hd;
   float d = 0.f;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void attn_bwd_pds_kernel(const float* __restri
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int k = lane + 64 * j;
-    v[j] = (k <= q && k < ld) ? sc[ro + k] * scale : -INFINITY;
+    v[j] = (k < klim && k < ld) ? sc[ro + k] * scale : -INFINITY;
     mx = fmaxf(mx, v[j]);
   }
   mx = wave_max(mx);
@@ -169,16 +172,17 @@ __global__ __launch_bounds__(256) void attn_bwd_pds_kernel(const float* __restri
     if (k < ld) {
       const bf16_t pb = f32_to_bf16(v[j] * inv);
       P[ro + k] = pb;
-      dS[ro + k] = (k <= q) ? f32_to_bf16(bf16_to_f32(pb) * (dP[ro + k] - d) * scale) : (bf16_t)0;
+      dS[ro + k] = (k < klim) ? f32_to_bf16(bf16_to_f32(pb) * (dP[ro + k] - d) * scale) : (bf16_t)0;
     }
   }
 }
 // rows longer than 1024 columns (multi-tile samples): same math with the row re-read from memory in three passes
 __global__ __launch_bounds__(256) void attn_bwd_pds_long_kernel(const float* __restrict__ sc, const float* __restrict__ dP, const bf16_t* __restrict__ dO,
                                                                 const bf16_t* __restrict__ O, bf16_t* __restrict__ P, bf16_t* __restrict__ dS, int H,
-                                                                int S, int ld, int hd, float scale) {
+                                                                int S, int ld, int hd, float scale, int causal, int kv_valid) {
   const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y;
   if (q >= S) return;
+  const int klim = causal ? min(q + 1, kv_valid) : kv_valid;
   const bf16_t* dorow = dO + (size_t)q * H * hd + h * hd;
   const bf16_t* orow = O + (size_t)q * H * hd + h * hd;
   float d = 0.f;
@@ -189,29 +193,33 @@ __global__ __launch_bounds__(256) void attn_bwd_pds_long_kernel(const float* __r
   d = wave_sum(d);
   const size_t ro = ((size_t)h * S + q) * ld;
   float mx = -INFINITY;
-  for (int k = lane; k <= q; k += 64) mx = fmaxf(mx, sc[ro + k] * scale);
+  for (int k = lane; k < klim; k += 64) mx = fmaxf(mx, sc[ro + k] * scale);
   mx = wave_max(mx);
   float sum = 0.f;
-  for (int k = lane; k <= q; k += 64) sum += __expf(sc[ro + k] * scale - mx);
+  for (int k = lane; k < klim; k += 64) sum += __expf(sc[ro + k] * scale - mx);
   sum = wave_sum(sum);
   const float inv = 1.0f / sum;
   for (int k = lane; k < ld; k += 64) {
-    const bf16_t pb = (k <= q) ? f32_to_bf16(__expf(sc[ro + k] * scale - mx) * inv) : (bf16_t)0;
+    const bf16_t pb = (k < klim) ? f32_to_bf16(__expf(sc[ro + k] * scale - mx) * inv) : (bf16_t)0;
     P[ro + k] = pb;
-    dS[ro + k] = (k <= q) ? f32_to_bf16(bf16_to_f32(pb) * (dP[ro + k] - d) * scale) : (bf16_t)0;
+    dS[ro + k] = (k < klim) ? f32_to_bf16(bf16_to_f32(pb) * (dP[ro + k] - d) * scale) : (bf16_t)0;
   }
+}
+extern "C" int vlaser_attn_bwd_pds_masked(const float* scores, const float* dP, const void* dO, const void* O, void* P, void* dS, int H, int S, int ld, int hd,
+                                          float scale, int causal, int kv_valid, vl_stream_t s) {
+  VL_CHECK(scores && dP && dO && O && P && dS && ld >= S && hd % 2 == 0 && kv_valid >= 1 && kv_valid <= ld, "vlaser_attn_bwd_pds: bad args");
+  if (ld <= 1024)
+    hipLaunchKernelGGL(attn_bwd_pds_kernel, dim3((S + 3) / 4, H), dim3(256), 0, (hipStream_t)s, scores, dP, (const bf16_t*)dO, (const bf16_t*)O,
+                       (bf16_t*)P, (bf16_t*)dS, H, S, ld, hd, scale, causal, kv_valid);
+  else
+    hipLaunchKernelGGL(attn_bwd_pds_long_kernel, dim3((S + 3) / 4, H), dim3(256), 0, (hipStream_t)s, scores, dP, (const bf16_t*)dO, (const bf16_t*)O,
+                       (bf16_t*)P, (bf16_t*)dS, H, S, ld, hd, scale, causal, kv_valid);
+  VL_LAUNCH_CHECK();
+  return 0;
 }
 extern "C" int vlaser_attn_bwd_pds(const float* scores, const float* dP, const void* dO, const void* O, void* P, void* dS, int H, int S, int ld, int hd,
                                    float scale, vl_stream_t s) {
-  VL_CHECK(scores && dP && dO && O && P && dS && ld >= S && hd % 2 == 0, "vlaser_attn_bwd_pds: bad args");
-  if (ld <= 1024)
-    hipLaunchKernelGGL(attn_bwd_pds_kernel, dim3((S + 3) / 4, H), dim3(256), 0, (hipStream_t)s, scores, dP, (const bf16_t*)dO, (const bf16_t*)O,
-                       (bf16_t*)P, (bf16_t*)dS, H, S, ld, hd, scale);
-  else
-    hipLaunchKernelGGL(attn_bwd_pds_long_kernel, dim3((S + 3) / 4, H), dim3(256), 0, (hipStream_t)s, scores, dP, (const bf16_t*)dO, (const bf16_t*)O,
-                       (bf16_t*)P, (bf16_t*)dS, H, S, ld, hd, scale);
-  VL_LAUNCH_CHECK();
-  return 0;
+  return vlaser_attn_bwd_pds_masked(scores, dP, dO, O, P, dS, H, S, ld, hd, scale, 1, ld, s);
 }
 
 // ---------------------------------------------------------------------------------------------- RoPE backward + pack
@@ -220,7 +228,9 @@ extern "C" int vlaser_attn_bwd_pds(const float* scores, const float* dP, const v
 __global__ __launch_bounds__(256) void rope_bwd_pack_kernel(const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dk, const bf16_t* __restrict__ dv,
                                                             const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                             const int32_t* __restrict__ pos_ids, bf16_t* __restrict__ out, int n_q, int n_kv,
-                                                            int kv_per_q_head) {
+                                                            int kv_per_q_head, const bf16_t* __restrict__ dk_extra, const bf16_t* __restrict__ dv_extra) {
+  // dk_extra / dv_extra (optional, [S, n_kv*128]): a second source of key / value gradients for the same rows, added in fp32 before the rotation --
+  // the keys of the VLM rows are also read by the proprio / action rows of the joint attention (f1, train_vlm: True)
   // kv_per_q_head != 0: dk / dv hold one partial per Q head ([S, n_q*128], the per-head TN GEMMs of the attention backward);
   // the kv gradient is their sum over the G = n_q / n_kv heads of the group (fp32, fixed order)
   const int s = blockIdx.x, nh = n_q + 2 * n_kv, G = n_q / n_kv;
@@ -247,6 +257,11 @@ __global__ __launch_bounds__(256) void rope_bwd_pack_kernel(const bf16_t* __rest
         const bf16_t* src = base + (size_t)s * n_kv * 128 + kvh * 128;
         g1 = bf16_to_f32(src[d]); g2 = bf16_to_f32(src[d + 64]);
       }
+      const bf16_t* ex = isv ? dv_extra : dk_extra;
+      if (ex) {
+        const bf16_t* src = ex + (size_t)s * n_kv * 128 + kvh * 128;
+        g1 += bf16_to_f32(src[d]); g2 += bf16_to_f32(src[d + 64]);
+      }
     }
     float x1 = g1, x2 = g2;
     if (rot) {
@@ -259,13 +274,17 @@ __global__ __launch_bounds__(256) void rope_bwd_pack_kernel(const bf16_t* __rest
     o[16] = f32_to_bf16(x2);
   }
 }
-extern "C" int vlaser_rope_bwd_pack(const void* dq, const void* dk, const void* dv, const float* c, const float* sn, const int32_t* pos, void* out,
-                                    int S, int n_q, int n_kv, int kv_per_q_head, vl_stream_t s) {
-  VL_CHECK(dq && dk && dv && c && sn && pos && out && S > 0 && n_q % n_kv == 0, "vlaser_rope_bwd_pack: bad args");
+extern "C" int vlaser_rope_bwd_pack_ex(const void* dq, const void* dk, const void* dv, const float* c, const float* sn, const int32_t* pos, void* out,
+                                       int S, int n_q, int n_kv, int kv_per_q_head, const void* dk_extra, const void* dv_extra, vl_stream_t s) {
+  VL_CHECK(dq && dk && dv && c && sn && pos && out && S > 0 && n_q % n_kv == 0 && (!dk_extra == !dv_extra), "vlaser_rope_bwd_pack: bad args");
   hipLaunchKernelGGL(rope_bwd_pack_kernel, dim3(S), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dq, (const bf16_t*)dk, (const bf16_t*)dv, c, sn, pos,
-                     (bf16_t*)out, n_q, n_kv, kv_per_q_head);
+                     (bf16_t*)out, n_q, n_kv, kv_per_q_head, (const bf16_t*)dk_extra, (const bf16_t*)dv_extra);
   VL_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int vlaser_rope_bwd_pack(const void* dq, const void* dk, const void* dv, const float* c, const float* sn, const int32_t* pos, void* out,
+                                    int S, int n_q, int n_kv, int kv_per_q_head, vl_stream_t s) {
+  return vlaser_rope_bwd_pack_ex(dq, dk, dv, c, sn, pos, out, S, n_q, n_kv, kv_per_q_head, nullptr, nullptr, s);
 }
 
 // ---------------------------------------------------------------------------------------------- RMSNorm backward
@@ -734,7 +753,10 @@ extern "C" int vlaser_silu_bwd(const void* x, const void* dy, void* dx, long lon
 __global__ __launch_bounds__(256) void attn_rows_bwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ VT,
                                                             const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O, bf16_t* __restrict__ dq,
                                                             bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int R, int n_q, int n_kv, int s_max,
-                                                            int valid_len, int blk_start, int first_tok_self, float scale) {
+                                                            int valid_len, int blk_start, int first_tok_self, float scale,
+                                                            bf16_t* __restrict__ p_out, bf16_t* __restrict__ ds_out) {
+  // p_out / ds_out (optional, bf16 [n_q][16][s_max]): softmax probabilities and dS of every key, for the dK / dV of the PREFIX keys when the VLM
+  // is trained too (train_vlm: True): dK[kvh] = sum_{g, r} dS[kvh G + g][r]^T q[r, head], dV likewise from P and dO (vlaser_gemm_tn_grouped)
   __shared__ float sc[ARB_MAXKEYS];       // p, then dS
   __shared__ float qs[128], dos[128], red[8];
   __shared__ float dk_acc[16 * 128], dv_acc[16 * 128];
@@ -809,6 +831,10 @@ __global__ __launch_bounds__(256) void attn_rows_bwd_kernel(const bf16_t* __rest
           }
         }
         sc[j] = ds;
+        if (p_out) {
+          p_out[((size_t)h * 16 + r) * s_max + j] = f32_to_bf16(p);
+          ds_out[((size_t)h * 16 + r) * s_max + j] = f32_to_bf16(ds);
+        }
       }
       __syncthreads();
       // dQ[d] = sum_j dS_j K_j[d]: two threads per d, each half of the keys
@@ -829,13 +855,99 @@ __global__ __launch_bounds__(256) void attn_rows_bwd_kernel(const bf16_t* __rest
     dv[(size_t)r * n_kv * 128 + kvh * 128 + d] = f32_to_bf16(dv_acc[i]);
   }
 }
+extern "C" int vlaser_attn_rows_bwd_ex(const void* q, const void* K, const void* VT, const void* dO, const void* O, void* dq, void* dk, void* dv, int R, int n_q,
+                                       int n_kv, int s_max, int valid_len, int blk_start, int first_tok_self, float scale, void* p_out, void* ds_out,
+                                       vl_stream_t s);
 extern "C" int vlaser_attn_rows_bwd(const void* q, const void* K, const void* VT, const void* dO, const void* O, void* dq, void* dk, void* dv, int R, int n_q,
                                     int n_kv, int s_max, int valid_len, int blk_start, int first_tok_self, float scale, vl_stream_t s) {
-  VL_CHECK(q && K && VT && dO && O && dq && dk && dv, "vlaser_attn_rows_bwd: null pointer");
+  return vlaser_attn_rows_bwd_ex(q, K, VT, dO, O, dq, dk, dv, R, n_q, n_kv, s_max, valid_len, blk_start, first_tok_self, scale, nullptr, nullptr, s);
+}
+extern "C" int vlaser_attn_rows_bwd_ex(const void* q, const void* K, const void* VT, const void* dO, const void* O, void* dq, void* dk, void* dv, int R, int n_q,
+                                       int n_kv, int s_max, int valid_len, int blk_start, int first_tok_self, float scale, void* p_out, void* ds_out,
+                                       vl_stream_t s) {
+  VL_CHECK(q && K && VT && dO && O && dq && dk && dv && (!p_out == !ds_out), "vlaser_attn_rows_bwd: null pointer");
   VL_CHECK(R >= 1 && R <= 16 && n_q % n_kv == 0 && blk_start + R <= s_max && blk_start + R <= ARB_MAXKEYS && valid_len <= blk_start,
            "vlaser_attn_rows_bwd: bad geometry (R <= 16, kv_len <= %d)", ARB_MAXKEYS);
   hipLaunchKernelGGL(attn_rows_bwd_kernel, dim3(n_kv), dim3(256), 0, (hipStream_t)s, (const bf16_t*)q, (const bf16_t*)K, (const bf16_t*)VT, (const bf16_t*)dO,
-                     (const bf16_t*)O, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, R, n_q, n_kv, s_max, valid_len, blk_start, first_tok_self, scale);
+                     (const bf16_t*)O, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, R, n_q, n_kv, s_max, valid_len, blk_start, first_tok_self, scale, (bf16_t*)p_out,
+                     (bf16_t*)ds_out);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- LayerNorm backward (ViT blocks, f1: train_vlm)
+// y = gamma * xhat + beta, xhat = (x - mean) rs.  g = gamma dy;  dx = rs * (g - mean(g) - xhat * mean(g xhat));  dx_out = dres + dx.
+// One wave per row (C <= 8192).  The affine gradients are column sums over the rows: vlaser_colsum_mul mode 3 (gamma) and mode 0 (beta).
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                            const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, int S, int C, float eps) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= S) return;
+  const size_t ro = (size_t)row * C;
+  float sx = 0.f, sxx = 0.f;
+  for (int c = lane * 8; c < C; c += 512) {
+    const u32x4 xv = ld_global_16(x + ro + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float a = bf16lo_to_f32(xv[j]), b = bf16hi_to_f32(xv[j]); sx += a + b; sxx += a * a + b * b; }
+  }
+  sx = wave_sum(sx); sxx = wave_sum(sxx);
+  const float mean = sx / (float)C;
+  const float rs = rsqrtf(fmaxf(sxx / (float)C - mean * mean, 0.f) + eps);
+  float sg = 0.f, sgx = 0.f;
+  for (int c = lane * 8; c < C; c += 512) {
+    const u32x4 xv = ld_global_16(x + ro + c), gv = ld_global_16(dy + ro + c), wv = ld_global_16(w + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g0 = bf16lo_to_f32(gv[j]) * bf16lo_to_f32(wv[j]), g1 = bf16hi_to_f32(gv[j]) * bf16hi_to_f32(wv[j]);
+      sg += g0 + g1;
+      sgx += g0 * (bf16lo_to_f32(xv[j]) - mean) * rs + g1 * (bf16hi_to_f32(xv[j]) - mean) * rs;
+    }
+  }
+  sg = wave_sum(sg) / (float)C; sgx = wave_sum(sgx) / (float)C;
+  for (int c = lane * 8; c < C; c += 512) {
+    const u32x4 xv = ld_global_16(x + ro + c), gv = ld_global_16(dy + ro + c), wv = ld_global_16(w + c);
+    u32x4 rv = {0, 0, 0, 0};
+    if (dres) rv = ld_global_16(dres + ro + c);
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g0 = bf16lo_to_f32(gv[j]) * bf16lo_to_f32(wv[j]), g1 = bf16hi_to_f32(gv[j]) * bf16hi_to_f32(wv[j]);
+      const float lo = bf16lo_to_f32(rv[j]) + rs * (g0 - sg - (bf16lo_to_f32(xv[j]) - mean) * rs * sgx);
+      const float hi = bf16hi_to_f32(rv[j]) + rs * (g1 - sg - (bf16hi_to_f32(xv[j]) - mean) * rs * sgx);
+      o[j] = pack_bf16x2(lo, hi);
+    }
+    st_global_16(dx + ro + c, o);
+  }
+}
+extern "C" int vlaser_layernorm_bwd(const void* dy, const void* x, const void* w, const void* dres, void* dx_out, int S, int C, float eps, vl_stream_t s) {
+  VL_CHECK(dy && x && w && dx_out && S > 0 && C % 8 == 0, "vlaser_layernorm_bwd: bad args");
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((S + 3) / 4), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w,
+                     (const bf16_t*)dres, (bf16_t*)dx_out, S, C, eps);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[s, c] = x[s, c] * alpha * (vec ? vec[c] : 1): the layer-scale factor of a ViT residual branch in its backward (dy = ls o dh,
+// modeling_intern_vit.py:291-293) and the 1 / 8 the ViT's q carries (VL_EPI_VIT_QKV stores q * scale).  In place allowed.
+__global__ __launch_bounds__(256) void scale_cols_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ vec, bf16_t* __restrict__ out, size_t n8, int C,
+                                                         int ldx, int ldo, float alpha) {
+  const int c8 = C >> 3;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / c8;
+    const int c = (int)(i - row * c8) << 3;
+    const u32x4 xv = ld_global_16(x + row * ldx + c);
+    u32x4 vv = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};       // bf16 1.0 pairs
+    if (vec) vv = ld_global_16(vec + c);
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(bf16lo_to_f32(xv[j]) * bf16lo_to_f32(vv[j]) * alpha, bf16hi_to_f32(xv[j]) * bf16hi_to_f32(vv[j]) * alpha);
+    st_global_16(out + row * ldo + c, o);
+  }
+}
+extern "C" int vlaser_scale_cols(const void* x, const void* vec, void* out, int S, int C, int ldx, int ldo, float alpha, vl_stream_t s) {
+  VL_CHECK(x && out && S > 0 && C % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "vlaser_scale_cols: bad args");
+  const size_t n8 = (size_t)S * (C >> 3);
+  const int blocks = (int)((n8 + 255) / 256 < 2048 ? (n8 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(scale_cols_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)vec, (bf16_t*)out, n8, C, ldx, ldo, alpha);
   VL_LAUNCH_CHECK();
   return 0;
 }

@@ -604,6 +604,32 @@ def silu_bwd(x, dy, dx):
     L.check(L.lib().vlaser_silu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _stream()), 'vlaser_silu_bwd')
 
 
-def attn_rows_bwd(q, K, VT, dO, O, dq, dk, dv, R, n_q, n_kv, s_max, valid_len, blk_start, first_tok_self, scale):
-    L.check(L.lib().vlaser_attn_rows_bwd(q.data_ptr(), K.data_ptr(), VT.data_ptr(), dO.data_ptr(), O.data_ptr(), dq.data_ptr(), dk.data_ptr(),
-                                         dv.data_ptr(), R, n_q, n_kv, s_max, valid_len, blk_start, int(first_tok_self), scale, _stream()), 'vlaser_attn_rows_bwd')
+def attn_rows_bwd(q, K, VT, dO, O, dq, dk, dv, R, n_q, n_kv, s_max, valid_len, blk_start, first_tok_self, scale, p_out=None, ds_out=None):
+    L.check(L.lib().vlaser_attn_rows_bwd_ex(q.data_ptr(), K.data_ptr(), VT.data_ptr(), dO.data_ptr(), O.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                            dv.data_ptr(), R, n_q, n_kv, s_max, valid_len, blk_start, int(first_tok_self), scale, _p(p_out), _p(ds_out),
+                                            _stream()), 'vlaser_attn_rows_bwd')
+
+
+# ------------------------------------------------------------------------------------------------ f1 with train_vlm: VLM-side backward
+def attn_bwd_pds_masked(scores, dP, dO, O, P, dS, H, S, ld, hd, scale, causal, kv_valid):
+    L.check(L.lib().vlaser_attn_bwd_pds_masked(scores.data_ptr(), dP.data_ptr(), dO.data_ptr(), O.data_ptr(), P.data_ptr(), dS.data_ptr(), H, S, ld, hd,
+                                               scale, int(causal), kv_valid, _stream()), 'vlaser_attn_bwd_pds_masked')
+
+
+def rope_bwd_pack_ex(dq, dk, dv, cos, sin, pos, out, S, n_q, n_kv, kv_per_q_head=False, dk_extra=None, dv_extra=None):
+    L.check(L.lib().vlaser_rope_bwd_pack_ex(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), cos.data_ptr(), sin.data_ptr(), pos.data_ptr(), out.data_ptr(), S,
+                                            n_q, n_kv, 1 if kv_per_q_head else 0, _p(dk_extra), _p(dv_extra), _stream()), 'vlaser_rope_bwd_pack_ex')
+
+
+def layernorm_bwd(dy, x, w, dres, dx, S, Cc, eps):
+    L.check(L.lib().vlaser_layernorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), _p(dres), dx.data_ptr(), S, Cc, eps, _stream()), 'vlaser_layernorm_bwd')
+
+
+def scale_cols(x, vec, out, S, Cc, alpha=1.0, ldx=None, ldo=None):
+    L.check(L.lib().vlaser_scale_cols(x.data_ptr(), _p(vec), out.data_ptr(), S, Cc, x.stride(0) if ldx is None else ldx, out.stride(0) if ldo is None else ldo,
+                                      alpha, _stream()), 'vlaser_scale_cols')
+
+
+def pixel_unshuffle(dout, dx, T, G, Cc, ps_v1=0):
+    assert dout.numel() >= T * (G // 2) ** 2 * 4 * Cc and dx.numel() >= T * (G * G + 1) * Cc
+    L.check(L.lib().vlaser_pixel_unshuffle(dout.data_ptr(), dx.data_ptr(), T, G, Cc, ps_v1, _stream()), 'vlaser_pixel_unshuffle')

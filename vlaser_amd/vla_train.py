@@ -112,7 +112,7 @@ class VLATrainer:
     """`step(batch...)` = one optimizer update of the action expert on flow-matching samples (per-device batch B >= 1, sample by sample)."""
 
     def __init__(self, cfg: VLAConfig, device='cuda', lr=5e-5, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
-                 process_group=None, bucket_layers=8):
+                 process_group=None, bucket_layers=8, train_vlm=False, vlm_lr=5e-5, vlm_weight_decay=0.0):
         L.lib()
         if not torch.cuda.is_available():
             raise L.VlaserHipError('vlaser_amd needs an MI355X (gfx950) GPU: there is no CPU fallback')
@@ -123,6 +123,10 @@ class VLATrainer:
         self.rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
         self.dp_active = self.world > 1 or (process_group is not None and os.environ.get('VLASER_FORCE_DP') == '1')
         self.bucket_layers = bucket_layers
+        # `train_vlm: True` (train.py:270-295): the reference's second parameter group `trainable_vlm_parameters` (pizero_internvl.py:405-411) with its
+        # own learning rate / weight decay (`vlm_lr`, `vlm_weight_decay`); vlaser_amd/vla_vlm_group.py
+        self.train_vlm, self.vlm_lr, self.vlm_wd = train_vlm, vlm_lr, vlm_weight_decay
+        self.vg = None
         self.step_count = 0
         self.T, self.na = cfg.max_image_text_tokens, cfg.num_action_tokens
         self.R = 1 + self.na                       # expert rows: proprio + action tokens
@@ -185,6 +189,10 @@ class VLATrainer:
             self.shard_off.append(o); o += hi - lo
         self._alloc()
         self._refresh_transposes()
+        if self.train_vlm:
+            from .vla_vlm_group import VLMGroup
+            self.vg = VLMGroup(self, sd, self.bucket_layers)
+            self.gacc_v = None
         return self
 
     def _alloc(self):
@@ -270,20 +278,23 @@ class VLATrainer:
         sig = cfg.flow_sig_min
         # ---- frozen prefix: ViT -> projector -> embeddings -> VLM layers (inference kernels), K / V^T of every layer cached
         pvb = stage_pixels(pixel_values, torch.empty(pixel_values.shape, dtype=BF, device=dev), dev)
-        feats = self.vit.forward(pvb)
         ids = ids_h.pin_memory().to(dev, non_blocking=True)
-        ops.embed_merge(ids, self.vlm.embed, feats, self.h_vlm, cfg.base.img_context_token_id, cfg.base.pad_token_id, True, self.rank_ws)
         self.valid_len.fill_(n_valid)
         bpos = lambda p, default: (default if p is None else p).to(torch.int32).reshape(-1)
         self.pos_vlm.copy_(bpos(vlm_position_ids, torch.arange(1, T + 1)))
         self.pos5[:1].copy_(bpos(proprio_position_ids, torch.ones(1, dtype=torch.long)))
         self.pos5[1:R].copy_(bpos(action_position_ids, torch.arange(2, 2 + na)))
-        nLv = llm.num_hidden_layers
-        prefill_begin(self.vlm, self.pbuf, self.h_vlm, T)
-        for i in range(nLv):
-            last = i == nLv - 1
-            prefill_layer(self.vlm, self.vlm.layers[i], self.pbuf, self.h_vlm, self.cache, i, self.rope, self.pos_vlm, 1, T, L.ATTN_PREFIX,
-                          valid_len=self.valid_len, blk_start=T, skip_post_attn=last, next_norm_w=None if last else self.vlm.layers[i + 1].ln_in)
+        if self.vg is not None:
+            self.vg.forward(pvb, ids)                   # train_vlm: the same rows with every intermediate kept (vla_vlm_group.py)
+        else:
+            feats = self.vit.forward(pvb)
+            ops.embed_merge(ids, self.vlm.embed, feats, self.h_vlm, cfg.base.img_context_token_id, cfg.base.pad_token_id, True, self.rank_ws)
+            nLv = llm.num_hidden_layers
+            prefill_begin(self.vlm, self.pbuf, self.h_vlm, T)
+            for i in range(nLv):
+                last = i == nLv - 1
+                prefill_layer(self.vlm, self.vlm.layers[i], self.pbuf, self.h_vlm, self.cache, i, self.rope, self.pos_vlm, 1, T, L.ATTN_PREFIX,
+                              valid_len=self.valid_len, blk_start=T, skip_post_attn=last, next_norm_w=None if last else self.vlm.layers[i + 1].ln_in)
         # ---- inputs of the expert rows: proprio encoder (row 0), action encoder on psi_t (rows 1..na)
         x1a = actions.reshape(na, A).to(dev, F32)
         x0a = x0.reshape(na, A).to(dev, F32)
@@ -337,6 +348,8 @@ class VLATrainer:
         ops.gemm(L.EPI_NONE, dv[:na], self.decT, out=dhn)
         dh = self.dh
         dh.zero_()
+        if self.vg is not None:
+            self.vg.begin_backward()
         ops.rmsnorm_bwd(dhn, h_fin, v['norm'], None, dh[1:R], na, H, ex.rms_norm_eps, dw_out=gv['norm'], dw_ws=self.normw_ws)
         for i in reversed(range(Lyr)):
             h_in, x1, x2, h2, q, ao, gu, act = self.h_in[i, :R], self.x1[i, :R], self.x2[i, :R], self.h2[i, :R], self.q[i, :R], self.ao[i, :R], self.gu[i, :R], self.act[i, :R]
@@ -349,8 +362,12 @@ class VLATrainer:
             ops.rmsnorm_bwd(dx[:R], h2, v[f'l{i}.ln_post'], dh[:R], dh2[:R], R, H, ex.rms_norm_eps, dw_out=gv[f'l{i}.ln_post'], dw_ws=self.normw_ws)
             self._dgrad(dh2, v[f'l{i}.wo'], dao, R)
             self._wgrad(dh2, ao, gv[f'l{i}.wo'], R)
+            vg = self.vg
             ops.attn_rows_bwd(q, self.cache.k[i, 0], self.cache.vt[i, 0], dao[:R], ao, self.dq[:R], self.dk[:R], self.dv[:R], R, nq, nkv, self.s_max,
-                              n_valid, T, True, scale)
+                              n_valid, T, True, scale, p_out=None if vg is None else vg.p_rows, ds_out=None if vg is None else vg.ds_rows)
+            if vg is not None:                          # train_vlm: the prefix keys' dK / dV of this layer, then the VLM rows' own layer backward
+                vg.prefix_kv_grads((q, dao[:R]), R, nq, nkv)
+                vg.backward_layer(i, n_valid)
             ops.rope_bwd_pack(self.dq[:R], self.dk[:R], self.dv[:R], self.rope[0], self.rope[1], self.pos5, self.dqkv[:R], R, nq, nkv, kv_per_q_head=False)
             self._dgrad(self.dqkv, v[f'l{i}.wqkv'], dx, R)
             self._wgrad(self.dqkv, x1, gv[f'l{i}.wqkv'], R, bias_out=gv[f'l{i}.bqkv'])
@@ -381,6 +398,8 @@ class VLATrainer:
         ops.colsum_bf16(dl1, gv['ae1.b'], na, H)
         if on_bucket_ready:
             on_bucket_ready(len(self.buckets) - 1)
+        if self.vg is not None:
+            self.vg.backward_tail(ids_h)                # mlp1, pixel_shuffle, the vision tower and its embeddings
         return loss
 
     # ------------------------------------------------------------------ optimizer / data parallel (same machinery as the SFT step)
@@ -398,41 +417,66 @@ class VLATrainer:
         if last:
             self._exchange_bucket(b)
 
-    def optimizer_step(self, lr=None):
+    def _vlm_grads_ready(self, w, first, last, accumulate):
+        """VLM group after one sample's backward: accumulate (fp32) when the step has several samples, and hand every bucket to the exchange after
+        the last one (no overlap with the backward here: the vision tower finishes last and owns most of the group's buckets anyway)."""
+        vg = self.vg
+        for b, (lo, hi) in enumerate(vg.buckets):
+            if accumulate:
+                ops.grad_accumulate(vg.fp.g[lo:hi], self.gacc_v[lo:hi], w, first, last)
+            if last and self.dp_active:
+                ev = torch.cuda.Event(); ev.record()
+                with torch.cuda.stream(self.comm_stream):
+                    self.comm_stream.wait_event(ev)
+                    dp.reduce_scatter_mean(vg.fp.g, vg.buckets[b], vg.shards[b], self.pg)
+
+    def optimizer_step(self, lr=None, vlm_lr=None):
+        """clip_grad_norm_ over BOTH groups (train.py:504-507), then one AdamW per group with its own learning rate / weight decay (:509-520)."""
         lr = self.lr if lr is None else lr
         self.step_count += 1
         if self.dp_active:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        groups = [(self.fp, self.shards, self.shard_off, self.master, self.m, self.v, lr, self.wd, self.buckets)]
+        if self.vg is not None:
+            vg = self.vg
+            groups.append((vg.fp, vg.shards, vg.shard_off, vg.master, vg.m, vg.v, self.vlm_lr if vlm_lr is None else vlm_lr, self.vlm_wd, vg.buckets))
         self.gnorm2.zero_()
-        for (s_lo, s_hi, _) in self.shards:
-            if s_hi > s_lo:
-                ops.sumsq(self.fp.g[s_lo:s_hi], self.gnorm2, self.sumsq_ws)
+        for fp, shards, _, _, _, _, _, _, _ in groups:
+            for (s_lo, s_hi, _) in shards:
+                if s_hi > s_lo:
+                    ops.sumsq(fp.g[s_lo:s_hi], self.gnorm2, self.sumsq_ws)
         if self.dp_active:
             torch.distributed.all_reduce(self.gnorm2, group=self.pg)
-        for (s_lo, s_hi, _), o in zip(self.shards, self.shard_off):
-            if s_hi > s_lo:
-                n = s_hi - s_lo
-                ops.adamw_clipped(self.fp.p[s_lo:s_hi], self.master[o:o + n], self.m[o:o + n], self.v[o:o + n], self.fp.g[s_lo:s_hi], lr, self.betas[0],
-                                  self.betas[1], self.eps, self.wd, 1.0, self.gnorm2, self.max_grad_norm, self.step_count)
+        for fp, shards, offs, master, m, v_, glr, gwd, _ in groups:
+            for (s_lo, s_hi, _), o in zip(shards, offs):
+                if s_hi > s_lo:
+                    n = s_hi - s_lo
+                    ops.adamw_clipped(fp.p[s_lo:s_hi], master[o:o + n], m[o:o + n], v_[o:o + n], fp.g[s_lo:s_hi], glr, self.betas[0],
+                                      self.betas[1], self.eps, gwd, 1.0, self.gnorm2, self.max_grad_norm, self.step_count)
         if self.dp_active:
-            for b in range(len(self.buckets)):
-                dp.all_gather_params(self.fp.p, self.buckets[b], self.shards[b], self.pg)
+            for fp, shards, _, _, _, _, _, _, buckets in groups:
+                for b in range(len(buckets)):
+                    dp.all_gather_params(fp.p, buckets[b], shards[b], self.pg)
         self._refresh_transposes()
         return self.gnorm2.sqrt()
 
-    def step(self, samples, lr=None, grad_accumulation_steps=1):
+    def step(self, samples, lr=None, grad_accumulation_steps=1, vlm_lr=None):
         """One optimizer update over `samples` = list of dicts (input_ids, pixel_values, proprios, actions, t, x0 [, position ids]):
         the per-device batch of every accumulation micro-batch, flattened; each sample weighs 1 / len(samples) (the loss is a batch
         mean, `normalized_loss = loss / grad_accumulation_steps`, train.py:479-498)."""
         n = len(samples)
         if n > 1 and self.gacc is None:
             self.gacc = torch.zeros(self.fp.n, dtype=F32, device=self.device)
+        if n > 1 and self.vg is not None and self.gacc_v is None:
+            self.gacc_v = torch.zeros(self.vg.fp.n, dtype=F32, device=self.device)
         loss = torch.zeros((), device=self.device)
         for j, smp in enumerate(samples):
             first, last = j == 0, j == n - 1
             hook = self._exchange_bucket if n == 1 else (lambda b, first=first, last=last: self._accumulate_bucket(b, 1.0 / n, first, last))
             loss = loss + self.forward_backward(on_bucket_ready=hook, **smp) / n
-        gnorm = self.optimizer_step(lr)
+            if self.vg is not None:
+                self._vlm_grads_ready(1.0 / n, first, last, n > 1)
+        gnorm = self.optimizer_step(lr, vlm_lr)
         return SimpleNamespace(loss=loss, grad_norm=gnorm)
 
     # ------------------------------------------------------------------ export (canonical VLA key names, un-packed layouts)
@@ -459,6 +503,8 @@ class VLATrainer:
             out[p + 'mlp.down_proj.weight'] = v[f'l{i}.wdown'].clone()
             out[p + 'input_layernorm.weight'] = v[f'l{i}.ln_in'].clone()
             out[p + 'post_attention_layernorm.weight'] = v[f'l{i}.ln_post'].clone()
+        if self.vg is not None:
+            out.update(self.vg.state_dict(grads))
         return out
 
     def named_grads(self):
@@ -479,8 +525,11 @@ class VLATrainer:
             sd = {k: v for k, v in canonicalize_vla_state_dict(frozen_sd).items() if not k.startswith(('action_expert.model.', 'action_encoder.', 'proprio_encoder.', 'action_decoder.'))}
             sd.update(self.state_dict())
             save_vla_checkpoint(path, sd, cnt_update=self.step_count, cnt_batch=cnt_batch)
-        torch.save({'rank': self.rank, 'world': self.world, 'shards': self.shards, 'step_count': self.step_count, 'master': self.master.cpu(),
-                    'exp_avg': self.m.cpu(), 'exp_avg_sq': self.v.cpu()}, self._opt_shard_path(path))
+        st = {'rank': self.rank, 'world': self.world, 'shards': self.shards, 'step_count': self.step_count, 'master': self.master.cpu(),
+              'exp_avg': self.m.cpu(), 'exp_avg_sq': self.v.cpu()}
+        if self.vg is not None:                      # the VLM group's shard of the second optimiser (train_vlm)
+            st.update({'vlm_shards': self.vg.shards, 'vlm_master': self.vg.master.cpu(), 'vlm_exp_avg': self.vg.m.cpu(), 'vlm_exp_avg_sq': self.vg.v.cpu()})
+        torch.save(st, self._opt_shard_path(path))
 
     def load_checkpoint(self, path, resume_optimizer=True):
         """Weights from the reference-layout `.pt`; with `resume_optimizer` also this rank's optimizer shard -- a missing shard file or one
@@ -501,6 +550,14 @@ class VLATrainer:
         for (lo, hi, _), o in zip(self.shards, self.shard_off):
             if hi > lo:
                 self.fp.p[lo:hi].copy_(self.master[o:o + hi - lo].to(BF))
+        if self.vg is not None:
+            vg = self.vg
+            if 'vlm_master' not in st or [tuple(x) for x in st['vlm_shards']] != [tuple(x) for x in vg.shards]:
+                raise ValueError('the optimizer shard holds no (matching) state for the VLM parameter group (train_vlm)')
+            vg.master.copy_(st['vlm_master']); vg.m.copy_(st['vlm_exp_avg']); vg.v.copy_(st['vlm_exp_avg_sq'])
+            for (lo, hi, _), o in zip(vg.shards, vg.shard_off):
+                if hi > lo:
+                    vg.fp.p[lo:hi].copy_(vg.master[o:o + hi - lo].to(BF))
         # (the other ranks' slices of fp.p are the checkpoint's bf16 weights = bf16(their masters): rank 0 saved them after the all-gather)
         self._refresh_transposes()
         return self
