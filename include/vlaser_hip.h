@@ -314,9 +314,11 @@ int vlaser_attn_rows_bwd(const void* q, const void* K, const void* VT, const voi
  * vision tower + projector + the VLM mixture's decoder layers; optimiser + schedule train.py:270-295, stepped :509-520).  The gradient reaches the
  * VLM through the keys / values its rows hand to the proprio / action rows, then runs back through the Qwen2 layers (bidirectional valid-prefix
  * mask), mlp1, pixel_shuffle and the 24 InternViT blocks (modeling_intern_vit.py:177-295: LayerNorm, full attention, GELU MLP, layer scale). */
-/* vlaser_attn_bwd_pds with an explicit mask: key k is visible to query q iff k < kv_valid and (k <= q when causal != 0) */
+/* vlaser_attn_bwd_pds with an explicit mask: key k is visible to query row q iff k < kv_valid and (k <= q + q_off when causal != 0); q_off = global
+ * index of row 0 when the S rows are a block of a longer sequence (long-sequence SFT walks the queries in blocks: the score matrices stay
+ * [heads, block, keys] instead of [heads, S, S]) */
 int vlaser_attn_bwd_pds_masked(const float* scores, const float* dP, const void* dO, const void* O, void* P, void* dS, int n_heads, int S, int ld, int hd,
-                               float scale, int causal, int kv_valid, vl_stream_t stream);
+                               float scale, int causal, int kv_valid, int q_off, vl_stream_t stream);
 /* vlaser_attn_rows_bwd that also stores P and dS of EVERY key, bf16 [n_q][16][s_max] (row r of head h at (h*16 + r)*s_max): the prefix keys' dK / dV
  * then come from vlaser_gemm_tn_grouped (contraction over the R rows, summed over the q heads of a kv group) */
 int vlaser_attn_rows_bwd_ex(const void* q, const void* K, const void* VT, const void* dO, const void* O, void* dq, void* dk, void* dv, int R, int n_q,

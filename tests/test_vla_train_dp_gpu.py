@@ -23,15 +23,51 @@ def _case(case):
                 actions=torch.from_numpy(f[f'{case}_actions']), t=torch.from_numpy(f[f'{case}_t']), x0=torch.from_numpy(f[f'{case}_x0']))
 
 
-def _trainer(pg=None):
+def _trainer(pg=None, train_vlm=False):
     from vlaser_amd import config as C, synth
     from vlaser_amd.vla_train import VLATrainer
     torch.set_grad_enabled(False)
     vla = C.VLAConfig(base=C.truncated(C.vlaser_2b(), 2, 2))
     sd = synth.vla_state_dict(vla, with_head=True)
-    m = VLATrainer(vla, lr=1e-3, max_grad_norm=0.0, bucket_layers=1, process_group=pg)
+    m = VLATrainer(vla, lr=1e-3, max_grad_norm=0.0, bucket_layers=1, process_group=pg, train_vlm=train_vlm, vlm_lr=2e-4)
     m.load_state_dict(sd)
     return m
+
+
+def _worker_vlm(rank, world, port, out_dir):
+    """train_vlm: True at world 2 -- both parameter groups exchanged (ZeRO-1 shards of each), one sample per rank, two steps."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    m = _trainer(dist.group.WORLD, train_vlm=True)
+    assert m.world == 2 and m.dp_active and len(m.vg.buckets) >= 3
+    smp = _case('ab'[rank])
+    losses = [float(m.step([smp]).loss) for _ in range(2)]
+    torch.cuda.synchronize()
+    torch.save({'losses': losses, 'p': {k: v.cpu() for k, v in m.state_dict().items()}}, os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_train_vlm_equals_single_process_accumulation(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29860 + (os.getpid() % 50) * 2
+    mp.spawn(_worker_vlm, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'rank0.pt'), torch.load(tmp_path / 'rank1.pt')
+    assert r0['p'].keys() == r1['p'].keys() and all(torch.equal(r0['p'][k], r1['p'][k]) for k in r0['p']), 'ranks differ'
+    m = _trainer(train_vlm=True)
+    a, b = _case('a'), _case('b')
+    outs = [m.step([a, b]) for _ in range(2)]
+    torch.cuda.synchronize()
+    ref = {k: v.cpu() for k, v in m.state_dict().items()}
+    assert any(k.startswith('vision_model.') for k in ref) and any(k.startswith('language_model.model.layers.') for k in ref)
+    for k in ref:
+        assert torch.equal(ref[k], r0['p'][k]), (k, float((ref[k].float() - r0['p'][k].float()).abs().max()))
+    for s in range(2):
+        assert abs(0.5 * (r0['losses'][s] + r1['losses'][s]) - float(outs[s].loss)) < 1e-5
 
 
 def _worker(rank, world, port, out_dir):

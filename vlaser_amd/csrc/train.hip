@@ -137,12 +137,12 @@ extern "C" int vlaser_attn_bwd_ds(const void* P, const float* dP, const void* dO
 // dS = P (dP - D) scale.  dK / dV then come from the grouped TN GEMM, so no transposed copies of P / dS are produced.
 __global__ __launch_bounds__(256) void attn_bwd_pds_kernel(const float* __restrict__ sc, const float* __restrict__ dP, const bf16_t* __restrict__ dO,
                                                            const bf16_t* __restrict__ O, bf16_t* __restrict__ P, bf16_t* __restrict__ dS, int H, int S,
-                                                           int ld, int hd, float scale, int causal, int kv_valid) {
+                                                           int ld, int hd, float scale, int causal, int kv_valid, int q_off) {
   // visibility of key k for query q: k < kv_valid and (k <= q when causal).  causal = 1, kv_valid = ld: the SFT step's causal mask; causal = 0:
   // the bidirectional valid prefix of the VLA block mask (pizero_internvl.py:517-587) and the ViT's full attention (r03, f1)
   const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y;
   if (q >= S) return;
-  const int klim = causal ? min(q + 1, kv_valid) : kv_valid;
+  const int klim = causal ? min(q + q_off + 1, kv_valid) : kv_valid;      // q_off: global index of query row 0 (a block of rows of a longer sequence)
   const bf16_t* dorow = dO + (size_t)q * H * hd + h * hd;
   const bf16_t* orow = O + (size_t)q * H * hd + h * hd;
   float d = 0.f;
@@ -179,10 +179,10 @@ __global__ __launch_bounds__(256) void attn_bwd_pds_kernel(const float* __restri
 // rows longer than 1024 columns (multi-tile samples): same math with the row re-read from memory in three passes
 __global__ __launch_bounds__(256) void attn_bwd_pds_long_kernel(const float* __restrict__ sc, const float* __restrict__ dP, const bf16_t* __restrict__ dO,
                                                                 const bf16_t* __restrict__ O, bf16_t* __restrict__ P, bf16_t* __restrict__ dS, int H,
-                                                                int S, int ld, int hd, float scale, int causal, int kv_valid) {
+                                                                int S, int ld, int hd, float scale, int causal, int kv_valid, int q_off) {
   const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y;
   if (q >= S) return;
-  const int klim = causal ? min(q + 1, kv_valid) : kv_valid;
+  const int klim = causal ? min(q + q_off + 1, kv_valid) : kv_valid;
   const bf16_t* dorow = dO + (size_t)q * H * hd + h * hd;
   const bf16_t* orow = O + (size_t)q * H * hd + h * hd;
   float d = 0.f;
@@ -206,20 +206,21 @@ __global__ __launch_bounds__(256) void attn_bwd_pds_long_kernel(const float* __r
   }
 }
 extern "C" int vlaser_attn_bwd_pds_masked(const float* scores, const float* dP, const void* dO, const void* O, void* P, void* dS, int H, int S, int ld, int hd,
-                                          float scale, int causal, int kv_valid, vl_stream_t s) {
-  VL_CHECK(scores && dP && dO && O && P && dS && ld >= S && hd % 2 == 0 && kv_valid >= 1 && kv_valid <= ld, "vlaser_attn_bwd_pds: bad args");
+                                          float scale, int causal, int kv_valid, int q_off, vl_stream_t s) {
+  VL_CHECK(scores && dP && dO && O && P && dS && hd % 2 == 0 && kv_valid >= 1 && kv_valid <= ld && q_off >= 0, "vlaser_attn_bwd_pds: bad args");
   if (ld <= 1024)
     hipLaunchKernelGGL(attn_bwd_pds_kernel, dim3((S + 3) / 4, H), dim3(256), 0, (hipStream_t)s, scores, dP, (const bf16_t*)dO, (const bf16_t*)O,
-                       (bf16_t*)P, (bf16_t*)dS, H, S, ld, hd, scale, causal, kv_valid);
+                       (bf16_t*)P, (bf16_t*)dS, H, S, ld, hd, scale, causal, kv_valid, q_off);
   else
     hipLaunchKernelGGL(attn_bwd_pds_long_kernel, dim3((S + 3) / 4, H), dim3(256), 0, (hipStream_t)s, scores, dP, (const bf16_t*)dO, (const bf16_t*)O,
-                       (bf16_t*)P, (bf16_t*)dS, H, S, ld, hd, scale, causal, kv_valid);
+                       (bf16_t*)P, (bf16_t*)dS, H, S, ld, hd, scale, causal, kv_valid, q_off);
   VL_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int vlaser_attn_bwd_pds(const float* scores, const float* dP, const void* dO, const void* O, void* P, void* dS, int H, int S, int ld, int hd,
                                    float scale, vl_stream_t s) {
-  return vlaser_attn_bwd_pds_masked(scores, dP, dO, O, P, dS, H, S, ld, hd, scale, 1, ld, s);
+  VL_CHECK(ld >= S, "vlaser_attn_bwd_pds: ld < S");
+  return vlaser_attn_bwd_pds_masked(scores, dP, dO, O, P, dS, H, S, ld, hd, scale, 1, ld, 0, s);
 }
 
 // ---------------------------------------------------------------------------------------------- RoPE backward + pack

@@ -611,9 +611,9 @@ def attn_rows_bwd(q, K, VT, dO, O, dq, dk, dv, R, n_q, n_kv, s_max, valid_len, b
 
 
 # ------------------------------------------------------------------------------------------------ f1 with train_vlm: VLM-side backward
-def attn_bwd_pds_masked(scores, dP, dO, O, P, dS, H, S, ld, hd, scale, causal, kv_valid):
+def attn_bwd_pds_masked(scores, dP, dO, O, P, dS, H, S, ld, hd, scale, causal, kv_valid, q_off=0):
     L.check(L.lib().vlaser_attn_bwd_pds_masked(scores.data_ptr(), dP.data_ptr(), dO.data_ptr(), O.data_ptr(), P.data_ptr(), dS.data_ptr(), H, S, ld, hd,
-                                               scale, int(causal), kv_valid, _stream()), 'vlaser_attn_bwd_pds_masked')
+                                               scale, int(causal), kv_valid, q_off, _stream()), 'vlaser_attn_bwd_pds_masked')
 
 
 def rope_bwd_pack_ex(dq, dk, dv, cos, sin, pos, out, S, n_q, n_kv, kv_per_q_head=False, dk_extra=None, dv_extra=None):

@@ -99,7 +99,7 @@ class SFTModel:
     gradient exchange and the optimizer update and returns the (rank-local) loss."""
 
     def __init__(self, cfg: VlaserConfig, device='cuda', max_seq_len=576, max_tiles=1, lr=2e-5, weight_decay=0.05, betas=(0.9, 0.999),
-                 eps=1e-8, max_grad_norm=1.0, process_group=None, bucket_layers=4, seed_state_dict=None, recompute=False):
+                 eps=1e-8, max_grad_norm=1.0, process_group=None, bucket_layers=4, seed_state_dict=None, recompute=False, attn_bwd_block=1024):
         L.lib()
         if not torch.cuda.is_available():
             raise L.VlaserHipError('vlaser_amd needs an MI355X (gfx950) GPU: there is no CPU fallback')
@@ -117,6 +117,9 @@ class SFTModel:
         # activations are ~39 MB at S=560, 1.1 GB for 28 layers -- noise next to 288 GB, so they are kept by default and the
         # backward re-runs nothing.  recompute=True restores the per-layer recompute (same values either way).
         self.recompute = recompute
+        # the attention backward walks the query rows in blocks of this many (r03): its score matrices are [heads, block, keys], not [heads, S, S] --
+        # the reference's launcher trains at --max_seq_length 16384 (…2nd_finetune_full.sh:38,60), where four S x S matrices per head are 38 GB
+        self.attn_bwd_block = attn_bwd_block
         self.ag_events = {}                       # bucket -> event of its last parameter all-gather (data parallel only)
         self.overlap_allgather = os.environ.get('VLASER_SFT_NO_AG_OVERLAP') != '1'
         self.overlap_optimizer = os.environ.get('VLASER_SFT_NO_OPT_OVERLAP') != '1'
@@ -229,9 +232,11 @@ class SFTModel:
         self.dao, self.dq, self.dk, self.dv = z(S, nq * hd), z(S, nq * hd), z(S, nq * hd), z(S, nq * hd)      # dk / dv: one partial per Q head
         self.dqkv = z(S, NQ)
         G = nq // nkv
-        self.sc = torch.zeros(nq, S, S, dtype=F32, device=dev)
-        self.dP = torch.zeros(nq, S, S, dtype=F32, device=dev)
-        self.P, self.dS = z(nq, S, S), z(nq, S, S)
+        QB = min(S, (self.attn_bwd_block + 63) // 64 * 64)
+        self.sc = torch.zeros(nq, QB, S, dtype=F32, device=dev)
+        self.dP = torch.zeros(nq, QB, S, dtype=F32, device=dev)
+        self.P, self.dS = z(nq, QB, S), z(nq, QB, S)
+        self.dkv_acc = None                        # fp32 [2, S, nq*hd]: dK / dV partial sums over the query blocks (allocated by the first multi-block backward)
         self.col = torch.zeros(max(2 * I, NQ, C4, H), dtype=F32, device=dev)
         self.sumsq_ws = torch.zeros(1024, dtype=F32, device=dev)
         self.normw_ws = torch.zeros((S + 3) // 4 * H, dtype=F32, device=dev)      # norm-weight gradient partials of rmsnorm_bwd
@@ -439,11 +444,6 @@ class SFTModel:
         if on_bucket_ready:
             on_bucket_ready(0)
         G = nq // nkv
-        Sp = (S + 63) // 64 * 64
-        sc = self.sc.view(-1)[:nq * S * Sp].view(nq, S, Sp)
-        dP = self.dP.view(-1)[:nq * S * Sp].view(nq, S, Sp)
-        P = self.P.view(-1)[:nq * S * Sp].view(nq, S, Sp)
-        dS = self.dS.view(-1)[:nq * S * Sp].view(nq, S, Sp)
         sm = self.cache.s_max
         scale = hd ** -0.5
         bucket_of_layer = {}
@@ -472,17 +472,7 @@ class SFTModel:
             self._wgrad(dh2, ao, gv[f'l{i}.wo'], S)
             # attention backward through materialised per-head score matrices (S is small: 12 x S x S)
             Kc, VTc = self.cache.k[kslot, 0], self.cache.vt[kslot, 0]         # [nkv, s_max, hd], [nkv, hd, s_max]
-            ops.gemm_raw(L.EPI_F32, q, Kc, sc, S, S, hd, nq * hd, hd, Sp, batch=nq, a_bs=hd, w_bs=sm * hd, o_bs=S * Sp, w_group=G)     # Q K^T
-            # dP = dO V^T and (below) dQ = dS K in the NN form: V^T [hd, keys] and K [keys, hd] are read as the cache holds them (r01/r02
-            # transposed both per layer); dS is zero beyond the causal range, so cache rows past S only need to be finite
-            ops.gemm_raw_nn(L.EPI_F32, dao, VTc, dP, S, Sp, hd, nq * hd, sm, Sp, batch=nq, a_bs=hd, w_bs=hd * sm, o_bs=S * Sp, w_group=G)   # dO V^T
-            ops.attn_bwd_pds(sc, dP, dao, ao, P, dS, nq, S, Sp, hd, scale)         # P = softmax(S), dS = P o (dP - D) * scale
-            ops.gemm_raw_nn(L.EPI_NONE, dS, Kc, self.dq, S, hd, Sp, Sp, hd, nq * hd, batch=nq, a_bs=S * Sp, w_bs=sm * hd, o_bs=hd, w_group=G)  # dQ = dS K
-            # dK[kvh] = sum_g dS[kvh*G+g]^T Q_g, dV[kvh] = sum_g P[kvh*G+g]^T dO_g: contraction along the rows (q) of both operands,
-            # summed over the q heads of the kv group, straight from dS / P [head, q, k] and q / dO [q, head*hd]
-            # one TN GEMM per Q head (108 workgroups instead of 18 serial ones); the sum over the group happens in rope_bwd_pack
-            ops.gemm_tn_grouped(dS, q, self.dk, S, hd, S, Sp, nq * hd, nq * hd, 1, 0, 0, nq, S * Sp, hd, hd)
-            ops.gemm_tn_grouped(P, dao, self.dv, S, hd, S, Sp, nq * hd, nq * hd, 1, 0, 0, nq, S * Sp, hd, hd)
+            self._attn_backward(q, Kc, VTc, dao, ao, S, nq, G, hd, sm, scale)
             dqkv = self.dqkv[:S]
             ops.rope_bwd_pack(self.dq[:S], self.dk[:S], self.dv[:S], self.rope[0], self.rope[1], pos, dqkv, S, nq, nkv, kv_per_q_head=True)
             self._dgrad(dqkv, v[f'l{i}.wqkv'], dx, S)
@@ -514,6 +504,41 @@ class SFTModel:
         if on_bucket_ready:
             on_bucket_ready(len(self.buckets) - 1)
         return loss
+
+    def _attn_backward(self, q, Kc, VTc, dao, ao, S, nq, G, hd, sm, scale):
+        """Causal attention backward through materialised score matrices, one BLOCK of query rows at a time: for rows [q0, q1) only the keys
+        [0, q1) are visible, so the block's matrices are [heads, q1 - q0, q1] -- S <= attn_bwd_block is one block (the r02 path, unchanged);
+        longer sequences accumulate dK / dV over the blocks in fp32 (vlaser_grad_accumulate) and round once.  Leaves dQ in self.dq and one
+        dK / dV partial per Q head in self.dk / self.dv (summed over the kv group by rope_bwd_pack)."""
+        QB = self.sc.shape[1]
+        nblk = -(-S // QB)
+        if nblk > 1 and self.dkv_acc is None:
+            self.dkv_acc = torch.zeros(2, self.S_max, nq * hd, dtype=F32, device=self.device)
+        q1_prev = 0
+        for bi in range(nblk):
+            q0, q1 = bi * QB, min(S, (bi + 1) * QB)
+            nb, kp = q1 - q0, (q1 + 63) // 64 * 64
+            n = nq * nb * kp
+            sc, dP = self.sc.view(-1)[:n].view(nq, nb, kp), self.dP.view(-1)[:n].view(nq, nb, kp)
+            P, dS = self.P.view(-1)[:n].view(nq, nb, kp), self.dS.view(-1)[:n].view(nq, nb, kp)
+            ops.gemm_raw(L.EPI_F32, q[q0:], Kc, sc, nb, q1, hd, nq * hd, hd, kp, batch=nq, a_bs=hd, w_bs=sm * hd, o_bs=nb * kp, w_group=G)     # Q K^T
+            # dP = dO V^T and (below) dQ = dS K in the NN form: V^T [hd, keys] and K [keys, hd] are read as the cache holds them (r01/r02
+            # transposed both per layer); dS is zero beyond the causal range, so cache rows past S only need to be finite
+            ops.gemm_raw_nn(L.EPI_F32, dao[q0:], VTc, dP, nb, kp, hd, nq * hd, sm, kp, batch=nq, a_bs=hd, w_bs=hd * sm, o_bs=nb * kp, w_group=G)   # dO V^T
+            ops.attn_bwd_pds_masked(sc, dP, dao[q0:], ao[q0:], P, dS, nq, nb, kp, hd, scale, True, kp, q0)      # P = softmax(S), dS = P o (dP - D) * scale
+            ops.gemm_raw_nn(L.EPI_NONE, dS, Kc, self.dq[q0:], nb, hd, kp, kp, hd, nq * hd, batch=nq, a_bs=nb * kp, w_bs=sm * hd, o_bs=hd, w_group=G)  # dQ = dS K
+            # dK[kvh] = sum_g dS[kvh*G+g]^T Q_g, dV[kvh] = sum_g P[kvh*G+g]^T dO_g: contraction along the rows (q) of both operands,
+            # summed over the q heads of the kv group, straight from dS / P [head, q, k] and q / dO [q, head*hd]
+            # one TN GEMM per Q head (108 workgroups instead of 18 serial ones); the sum over the group happens in rope_bwd_pack
+            ops.gemm_tn_grouped(dS, q[q0:], self.dk, q1, hd, nb, kp, nq * hd, nq * hd, 1, 0, 0, nq, nb * kp, hd, hd)
+            ops.gemm_tn_grouped(P, dao[q0:], self.dv, q1, hd, nb, kp, nq * hd, nq * hd, 1, 0, 0, nq, nb * kp, hd, hd)
+            if nblk > 1:
+                last = bi == nblk - 1
+                for g_, acc in ((self.dk, self.dkv_acc[0]), (self.dv, self.dkv_acc[1])):
+                    if q1_prev > 0:
+                        ops.grad_accumulate(g_[:q1_prev], acc[:q1_prev], 1.0, False, last)       # keys earlier blocks already reached
+                    ops.grad_accumulate(g_[q1_prev:q1], acc[q1_prev:q1], 1.0, True, last)        # keys first reached by this block
+                q1_prev = q1
 
     # ------------------------------------------------------------------ optimizer / data parallel
     def _norm_bucket(self, b):
