@@ -837,6 +837,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lds_tile, int pitch, int c
   return u.b;
 }
 
+#ifndef TN_LOAD_LATE
+#define TN_LOAD_LATE 0
+#endif
 struct GemmTnP {
   const bf16_t* At; const bf16_t* Wt; bf16_t* out;
   int M, N, K, ldat, ldwt, ldo, tiles_m, tiles_n;
@@ -911,6 +914,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnP p) {
     const int buf = kt & 1;
     const char* As = smem + buf * BUF;
     const char* Ws = As + 64 * PA;
+#if !TN_LOAD_LATE
+    // (r03) tile kt+2 is requested at the TOP of the step: its register stage (nst ^ 1 held tile kt, which went to LDS before this step) is
+    // already free, and the loads then fly under this step's 2 x (fragment reads + MFMAs) instead of starting behind the LDS store of kt+1
+    load_tile(kt + 2, nst ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 fa[MT], fw[NT];
@@ -925,8 +934,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnP p) {
     }
     store_tile(buf ^ 1, nst);
     __builtin_amdgcn_sched_barrier(0);
-    load_tile(kt + 2, nst ^ 1);            // the stage just consumed two steps ago: tile kt went to LDS before this step
+#if TN_LOAD_LATE
+    load_tile(kt + 2, nst ^ 1);            // r02 order: the stage just consumed two steps ago, refilled behind the LDS store
     __builtin_amdgcn_sched_barrier(0);
+#endif
     __syncthreads();
   };
   // register stages alternate: tile kt+1 sits in stage (kt+1)&1; after it is stored, stage kt&1 (tile kt, already in LDS) is refilled with kt+2

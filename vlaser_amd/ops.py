@@ -443,18 +443,23 @@ def split_slab_elems(max_rows, N):
 _GEMM_STEP_US = {32: (5.0, 0.30), 1564: (4.9, 0.177), 1500: (5.1, 0.263), 1100: (5.3, 0.377), 1440: (5.6, 0.509), 1200: (7.0, 0.62), 1300: (9.0, 1.55)}
 
 
+_SPLIT_MIN_K = int(os.environ.get('VLASER_GEMM_SPLIT_MINK', '512'))      # >= 8 K-steps per slice: the fitted model does not extrapolate to shorter loops
+
+
 def gemm_splits(M, N, K, max_elems=None, max_splits=8, nn=False):
     """Split-K factor for a [M,N] output whose tiles alone cannot fill 256 CUs: the factor (K/splits a multiple of 64 and >= 256, at
     most max_splits, splits*M*N fp32 slab elements within max_elems) with the least modelled time = rounds x (fixed + K-steps x step time
     of the tile configuration the kernel will pick) + the consumer's cost of summing the extra fp32 slabs."""
     best = (None, 1)
     for s in range(1, max_splits + 1):
-        if K % (s * 64) or K // s < 256 or (s > 1 and max_elems is not None and s * M * N > max_elems):
+        if K % (s * 64) or (s > 1 and K // s < _SPLIT_MIN_K) or (s > 1 and max_elems is not None and s * M * N > max_elems):
             continue
         code, bm, bn, _ = gemm_tile_config(M, N, s, nn=nn)
         blocks = -(-M // bm) * -(-N // bn) * s
         fixed, step = _GEMM_STEP_US[code]
-        t = -(-blocks // 256) * (fixed + (K // s // 64) * step) + (s > 1) * (0.35 * s + M * N * 4.0 * s / 4e6)
+        # + what the extra fp32 slabs cost their consumer: the seam kernel takes 5.3 / 5.3 / 5.4 us with 1 / 3 / 7 slabs of 2.4 MB, 5.3 / 5.9 with 1 / 4 slabs
+        # of 4.2 MB (profiles/r03l_chunk_kernel_stats.md) -- about 0.04 us per MB of slab
+        t = -(-blocks // 256) * (fixed + (K // s // 64) * step) + (s > 1) * 0.04 * s * M * N * 4.0 / 1e6
         if best[0] is None or t < best[0] - 1e-9:
             best = (t, s)
     return best[1]
