@@ -113,6 +113,7 @@ typedef struct {
   int n_splits;                 /* 1..8 key splits (grid.y) */
   int first_tok_kv_len;         /* > 0: query token 0 of each batch element sees the block keys [blk_start, first_tok_kv_len) only -- the
                                    proprio row riding in front of the action rows (pizero_internvl.py:517-587: proprio sees prefix + self) */
+  float* lse_out;               /* vlaser_attn_prefill, optional (ABI 4): fp32 [B, n_q_heads, sq] base-2 log-sum-exp of the scaled scores, kept for vlaser_attn_bwd */
 } VlaserAttnArgs;
 
 int vlaser_attn_prefill(const VlaserAttnArgs* args, vl_stream_t stream);
@@ -188,6 +189,16 @@ typedef struct {
   unsigned long long* dbg;      /* optional: per-workgroup timestamps [256][8] (wall_clock64, 100 MHz) for kernel tuning */
 } VlaserFusedOguArgs;
 int vlaser_fused_ogu(const VlaserFusedOguArgs* args, vl_stream_t stream);
+
+/* ---- fused attention backward (ABI 4, r03): the backward of vlaser_attn_prefill's causal / valid-prefix attention (HF eager_attention_forward /
+ * flash_attention_2 autograd, modeling_internvl_chat.py:194-203) without materialised score matrices: two deterministic kernels (no atomics) --
+ *   dQ:      one workgroup per (64 query rows, q head) walks the visible key tiles:  S^T, P^T = exp2(S^T - lse), dP^T = V dO^T, dS^T, dQ^T += K^T dS^T
+ *   dK, dV:  one workgroup per (64 keys, q head) walks the query tiles that see them: S, P, dP, dS, dV^T += dO^T P, dK^T += Q^T dS
+ * q / o / d_o / dq: bf16 [S, n_q*128]; k: [n_kv, s_max, 128] (post-RoPE), vt: [n_kv, 128, s_max]; lse: fp32 [n_q, S] from vlaser_attn_prefill;
+ * dk / dv: bf16 [S, n_q*128] -- ONE partial per Q head (vlaser_rope_bwd_pack sums the heads of a kv group); delta_ws: fp32 [n_q, S] scratch.
+ * Key k is visible to query q iff k < kv_valid and (k <= q when causal != 0).  head_dim 128. */
+int vlaser_attn_bwd(const void* q, const void* k, const void* vt, const void* o, const void* d_o, const float* lse, float* delta_ws, void* dq, void* dk,
+                    void* dv, int S, int n_q, int n_kv, int s_max, float scale, int causal, int kv_valid, vl_stream_t stream);
 
 /* Weight-gradient GEMM: out[M,N] (bf16) = At^T @ Wt, At [K,M] and Wt [K,N] row-major bf16 (contraction along rows).
  * dW = dY^T X of every nn.Linear on the SFT path (autograd of modeling_internvl_chat.py:194-203): At = dY [S,N_out],

@@ -81,7 +81,10 @@ def test_world2_step_equals_gradient_averaging(tmp_path, clip):
             grads.append(m.fp.g.clone())
         m.fp.g.copy_(((grads[0].float() + grads[1].float()) / 2).to(BF))
         m.optimizer_step()
-        assert abs(losses[0] - r0['losses'][step]) < 1e-6 and abs(losses[1] - r1['losses'][step]) < 1e-6
+        # step 0 runs on identical parameters: exact.  With the clip on, the parameters after step 0 differ from the emulation's by one bf16 ulp on a
+        # handful of elements (the fp32 norm is summed per shard + all-reduced: different order, checked below), which the next loss sees: 1e-3 relative
+        tol = 1e-6 if (clip == 0.0 or step == 0) else 1e-3 * abs(losses[0])
+        assert abs(losses[0] - r0['losses'][step]) <= tol and abs(losses[1] - r1['losses'][step]) <= tol, (step, losses, r0['losses'], r1['losses'])
     ref = m.state_dict()
     for k in KEYS:
         a, b = r0['params'][k].float(), ref[k].float().cpu()

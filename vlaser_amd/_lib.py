@@ -25,7 +25,7 @@ class AttnArgs(C.Structure):
                 ('k_bs', i64), ('k_hs', i64), ('vt_bs', i64), ('vt_hs', i64), ('o_bs', i64), ('o_ss', i64),
                 ('ld_vt', i32), ('scale', f32), ('mode', i32), ('causal_off', i32), ('valid_len', vp),
                 ('blk_start', i32), ('q_row_off', i32), ('part_m', vp), ('part_l', vp), ('part_o', vp), ('n_splits', i32),
-                ('first_tok_kv_len', i32)]
+                ('first_tok_kv_len', i32), ('lse_out', vp)]
 
 
 class SkinnyArgs(C.Structure):
@@ -56,6 +56,7 @@ _SIGS = {
     'vlaser_gemm_nn': [i32, C.POINTER(GemmArgs), vp],
     'vlaser_attn_prefill': [C.POINTER(AttnArgs), vp],
     'vlaser_attn_skinny': [C.POINTER(AttnArgs), vp],
+    'vlaser_attn_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp],
     'vlaser_skinny': [i32, i32, C.POINTER(SkinnyArgs), vp],
     'vlaser_fused_ogu': [C.POINTER(FusedOguArgs), vp],
     'vlaser_layernorm': [vp, vp, vp, vp, i32, i32, f32, vp],

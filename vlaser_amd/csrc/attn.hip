@@ -275,6 +275,8 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
   l_tot += __shfl_xor(l_tot, 32, 64);
   if (q_row < a.sq) {
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    // base-2 log-sum-exp of the scaled scores, for the fused backward (vlaser_attn_bwd): P = exp2(s * scale * log2 e - lse)
+    if (a.lse_out && g == 0) a.lse_out[((size_t)b * a.n_q_heads + h) * a.sq + q_row] = m_run + __builtin_amdgcn_logf(l_tot);
     bf16_t* O = reinterpret_cast<bf16_t*>(a.out) + (size_t)b * a.o_bs + (size_t)q_row * a.o_ss + h * HD;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {

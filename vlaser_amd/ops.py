@@ -165,7 +165,7 @@ def linear(x, W, bias=None, epi=None, res=None, ls=None, out=None, out_dtype=BF1
 
 # ------------------------------------------------------------------------------------------------ attention
 def _attn_args(q, k, vt, out, batch, sq, kv_len, n_q, n_kv, hd, q_str, k_str, vt_str, o_str, ld_vt, scale, mode,
-               causal_off=0, valid_len=None, blk_start=0, q_row_off=0, parts=None, n_splits=1, first_tok_kv_len=0):
+               causal_off=0, valid_len=None, blk_start=0, q_row_off=0, parts=None, n_splits=1, first_tok_kv_len=0, lse_out=None):
     a = L.AttnArgs()
     a.q, a.k, a.vt, a.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), _p(out)
     a.batch, a.sq, a.kv_len, a.n_q_heads, a.n_kv_heads, a.head_dim = batch, sq, kv_len, n_q, n_kv, hd
@@ -180,12 +180,19 @@ def _attn_args(q, k, vt, out, batch, sq, kv_len, n_q, n_kv, hd, q_str, k_str, vt
         a.part_m, a.part_l, a.part_o = parts[0].data_ptr(), parts[1].data_ptr(), parts[2].data_ptr()
     a.n_splits = n_splits
     a.first_tok_kv_len = first_tok_kv_len
+    a.lse_out = _p(lse_out)
     return a
 
 
 def attn_prefill(*args, **kw):
     a = _attn_args(*args, **kw)
     L.check(L.lib().vlaser_attn_prefill(C.byref(a), _stream()), 'vlaser_attn_prefill')
+
+
+def attn_bwd(q, k, vt, o, d_o, lse, delta_ws, dq, dk, dv, S, n_q, n_kv, s_max, scale, causal=True, kv_valid=None):
+    """Fused backward of the prefill attention (csrc/attn_bwd.hip): dq, and one dk / dv partial per Q head, from q / k / v^T / o / d_o and the forward's lse."""
+    L.check(L.lib().vlaser_attn_bwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta_ws.data_ptr(), dq.data_ptr(),
+                                    dk.data_ptr(), dv.data_ptr(), S, n_q, n_kv, s_max, scale, int(causal), S if kv_valid is None else kv_valid, _stream()), 'vlaser_attn_bwd')
 
 
 def attn_splits(kv_len):

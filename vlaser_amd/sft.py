@@ -99,7 +99,7 @@ class SFTModel:
     gradient exchange and the optimizer update and returns the (rank-local) loss."""
 
     def __init__(self, cfg: VlaserConfig, device='cuda', max_seq_len=576, max_tiles=1, lr=2e-5, weight_decay=0.05, betas=(0.9, 0.999),
-                 eps=1e-8, max_grad_norm=1.0, process_group=None, bucket_layers=4, seed_state_dict=None, recompute=False, attn_bwd_block=1024):
+                 eps=1e-8, max_grad_norm=1.0, process_group=None, bucket_layers=4, seed_state_dict=None, recompute=False, attn_bwd_block=1024, attn_bwd='fused'):
         L.lib()
         if not torch.cuda.is_available():
             raise L.VlaserHipError('vlaser_amd needs an MI355X (gfx950) GPU: there is no CPU fallback')
@@ -120,6 +120,9 @@ class SFTModel:
         # the attention backward walks the query rows in blocks of this many (r03): its score matrices are [heads, block, keys], not [heads, S, S] --
         # the reference's launcher trains at --max_seq_length 16384 (…2nd_finetune_full.sh:38,60), where four S x S matrices per head are 38 GB
         self.attn_bwd_block = attn_bwd_block
+        self.attn_bwd_mode = os.environ.get('VLASER_SFT_ATTN_BWD', attn_bwd)
+        if self.attn_bwd_mode not in ('fused', 'materialised'):
+            raise ValueError(f'VLASER_SFT_ATTN_BWD={self.attn_bwd_mode!r}: fused | materialised')
         self.ag_events = {}                       # bucket -> event of its last parameter all-gather (data parallel only)
         self.overlap_allgather = os.environ.get('VLASER_SFT_NO_AG_OVERLAP') != '1'
         self.overlap_optimizer = os.environ.get('VLASER_SFT_NO_OPT_OVERLAP') != '1'
@@ -232,10 +235,15 @@ class SFTModel:
         self.dao, self.dq, self.dk, self.dv = z(S, nq * hd), z(S, nq * hd), z(S, nq * hd), z(S, nq * hd)      # dk / dv: one partial per Q head
         self.dqkv = z(S, NQ)
         G = nq // nkv
-        QB = min(S, (self.attn_bwd_block + 63) // 64 * 64)
-        self.sc = torch.zeros(nq, QB, S, dtype=F32, device=dev)
-        self.dP = torch.zeros(nq, QB, S, dtype=F32, device=dev)
-        self.P, self.dS = z(nq, QB, S), z(nq, QB, S)
+        # attention backward: fused (csrc/attn_bwd.hip: the forward keeps the log-sum-exp, no score matrices) or, VLASER_SFT_ATTN_BWD=materialised,
+        # the r02 path through [heads, rows, keys] score matrices, one block of attn_bwd_block query rows at a time
+        self.lse = torch.zeros(Lk, nq * S, dtype=F32, device=dev)
+        self.delta_ws = torch.zeros(nq * S, dtype=F32, device=dev)
+        if self.attn_bwd_mode == 'materialised':
+            QB = min(S, (self.attn_bwd_block + 63) // 64 * 64)
+            self.sc = torch.zeros(nq, QB, S, dtype=F32, device=dev)
+            self.dP = torch.zeros(nq, QB, S, dtype=F32, device=dev)
+            self.P, self.dS = z(nq, QB, S), z(nq, QB, S)
         self.dkv_acc = None                        # fp32 [2, S, nq*hd]: dK / dV partial sums over the query blocks (allocated by the first multi-block backward)
         self.col = torch.zeros(max(2 * I, NQ, C4, H), dtype=F32, device=dev)
         self.sumsq_ws = torch.zeros(1024, dtype=F32, device=dev)
@@ -326,7 +334,7 @@ class SFTModel:
                  tok_per_batch=S, slot_base=0)
         ks, vs = self.cache.strides()
         ops.attn_prefill(q, self.cache.k[j], self.cache.vt[j], ao, 1, S, S, nq, nkv, hd, (S * nq * hd, hd, nq * hd), ks, vs,
-                         (S * nq * hd, nq * hd), self.cache.s_max, hd ** -0.5, L.ATTN_CAUSAL)
+                         (S * nq * hd, nq * hd), self.cache.s_max, hd ** -0.5, L.ATTN_CAUSAL, lse_out=self.lse[j])
         sp = ops.gemm_splits(S, H, nq * hd)
         ops.gemm(L.EPI_PARTIAL, ao, v[f'l{i}.wo'], out_f32=self.part, k_splits=sp)
         ops.reduce_norm(h_in, self.part, sp, S, H, h2, x2, norm=1, norm_w=v[f'l{i}.ln_post'], eps=llm.rms_norm_eps)
@@ -470,9 +478,11 @@ class SFTModel:
             # attention block: h2 = h_in + ao Wo^T
             self._dgrad(dh2, v[f'l{i}.wo'], dao, S)
             self._wgrad(dh2, ao, gv[f'l{i}.wo'], S)
-            # attention backward through materialised per-head score matrices (S is small: 12 x S x S)
             Kc, VTc = self.cache.k[kslot, 0], self.cache.vt[kslot, 0]         # [nkv, s_max, hd], [nkv, hd, s_max]
-            self._attn_backward(q, Kc, VTc, dao, ao, S, nq, G, hd, sm, scale)
+            if self.attn_bwd_mode == 'fused':
+                ops.attn_bwd(q, Kc, VTc, ao, dao, self.lse[kslot], self.delta_ws, self.dq[:S], self.dk[:S], self.dv[:S], S, nq, nkv, sm, scale)
+            else:
+                self._attn_backward(q, Kc, VTc, dao, ao, S, nq, G, hd, sm, scale)
             dqkv = self.dqkv[:S]
             ops.rope_bwd_pack(self.dq[:S], self.dk[:S], self.dv[:S], self.rope[0], self.rope[1], pos, dqkv, S, nq, nkv, kv_per_q_head=True)
             self._dgrad(dqkv, v[f'l{i}.wqkv'], dx, S)
