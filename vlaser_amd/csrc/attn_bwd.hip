@@ -32,6 +32,21 @@ __device__ __forceinline__ bf16x8 ab_tr_frag(const char* tile, int pitch, int co
   return u.b;
 }
 
+// lab build only (-DAB_TIMELINE, tools/micro/attn_bwd_timeline.py): cycle stamps of wave 0 of the workgroup with the longest tile chain
+#ifdef AB_TIMELINE
+__device__ long long ab_dbg[2][64];
+#define AB_STAMP(k, i, cond)                                                                            \
+  {                                                                                                     \
+    const int _i = (i);                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if ((cond) && threadIdx.x == 0 && blockIdx.y == 0 && _i < 60) ab_dbg[k][_i] = clock64();            \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+  }
+extern "C" int vlaser_attn_bwd_debug_read(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ab_dbg), sizeof(long long) * 128); }
+#else
+#define AB_STAMP(k, i, cond)
+#endif
+
 struct AttnBwdP {
   const bf16_t *q, *k, *vt, *o, *d_o;
   const float* lse;
@@ -50,17 +65,27 @@ __device__ __forceinline__ bf16x8 ab_load_tr_order(const bf16_t* row, int c0, in
 }
 
 // ---------------------------------------------------------------------------------------------- dQ (+ D)
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
-  constexpr int HD = 128, DC = 4, DT = 8;
-  __shared__ __attribute__((aligned(16))) char Ks[64 * AB_PQ];
-  __shared__ __attribute__((aligned(16))) char Vs[128 * AB_PV];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
+// TK = keys per staged tile; KS = wave groups (of 4 waves) that take the key tiles in turn and merge their dQ sums at the end: at SFT lengths the grid
+// is 108 workgroups on 256 CUs and one wave per SIMD runs LDS reads, MFMAs and the softmax arithmetic back to back -- a second group per
+// workgroup gives every SIMD a second instruction stream to overlap them with and halves the chain of tile iterations.
+template <int TK, int KS>
+__global__ __launch_bounds__(256 * KS) void attn_bwd_dq_kernel(AttnBwdP p) {
+  constexpr int HD = 128, DC = 4, DT = 8, NCH = TK / 32, NLD = TK / 16, PV = TK == 64 ? AB_PV : AB_PQ;
+  constexpr int TILE_B = TK * AB_PQ + 128 * PV, MERGE_WAVE = DT * 4 * 64 * 4;
+  extern __shared__ __attribute__((aligned(16))) char ab_smem[];
+  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
+  char* Ks = ab_smem + grp * TILE_B;       // [TK keys][128 d], pitch 288
+  char* Vs = Ks + TK * AB_PQ;              // [128 d][TK keys], pitch 160 / 288
   const int qb = blockIdx.x, h = blockIdx.y, kvh = h / (p.n_q / p.n_kv);
   const int qi = qb * 64 + wave * 16 + fr;                   // this lane's query (operand column)
   const int qc = min(qi, p.S - 1);
   const size_t qrow = (size_t)qc * p.n_q * HD + (size_t)h * HD;
   const bf16_t* K = p.k + (size_t)kvh * p.s_max * HD;
   const bf16_t* VT = p.vt + (size_t)kvh * HD * p.s_max;
+  const bool ab_me = blockIdx.x == gridDim.x - 1;
+  int ab_i = 0;
+  (void)ab_me; (void)ab_i;
+  AB_STAMP(0, ab_i++, ab_me)
   bf16x8 qf[DC], dof[DC];
   float dsum = 0.f;
 #pragma unroll
@@ -75,43 +100,48 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
   dsum += __shfl_xor(dsum, 32, 64);
   const float D = dsum;
   const float lse = p.lse[(size_t)h * p.S + qc];
-  if (g == 0 && qi < p.S) p.delta[(size_t)h * p.S + qi] = D;
+  if (g == 0 && grp == 0 && qi < p.S) p.delta[(size_t)h * p.S + qi] = D;
   const int klim = qi < p.S ? (p.causal ? min(qi + 1, p.kv_valid) : p.kv_valid) : 0;
   const float sc = p.scale * 1.4426950408889634f;
   f32x4 dqT[DT];
 #pragma unroll
   for (int i = 0; i < DT; ++i) dqT[i] = f32x4{0, 0, 0, 0};
+  AB_STAMP(0, ab_i++, ab_me)          // prologue values arrived (D reduced)
   const int kmax = p.causal ? min(p.kv_valid, min(p.S, qb * 64 + 64)) : p.kv_valid;     // keys any row of this workgroup sees
-  const int n_tiles = (kmax + 63) >> 6;
-  u32x4 rk[4], rv[4];
+  const int n_tiles = (kmax + TK - 1) / TK;
+  u32x4 rk[NLD], rv[NLD];
   auto load_tile = [&](int it) {
-    const int key0 = it * 64;
+    const int key0 = it * TK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + i * 256, row = c >> 4, slot = c & 15;                     // K tile: 64 rows x 16 chunks
+    for (int i = 0; i < NLD; ++i) {
+      const int c = tid + i * 256, row = c >> 4, slot = c & 15;                     // K tile: TK rows x 16 chunks
       rk[i] = ld_global_16(K + (size_t)min(key0 + row, p.s_max - 1) * HD + slot * 8);
-      const int c2 = tid + i * 256, row2 = c2 >> 3, slot2 = c2 & 7;                 // V^T tile: 128 rows x 8 chunks (8 keys each)
+      const int row2 = c / (TK / 8), slot2 = c % (TK / 8);                          // V^T tile: 128 rows x TK/8 chunks (8 keys each)
       rv[i] = ld_global_16(VT + (size_t)row2 * p.s_max + min(key0 + slot2 * 8, p.s_max - 8));
     }
   };
   auto store_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NLD; ++i) {
       const int c = tid + i * 256;
       *reinterpret_cast<u32x4*>(Ks + (c >> 4) * AB_PQ + (c & 15) * 16) = rk[i];
-      *reinterpret_cast<u32x4*>(Vs + (c >> 3) * AB_PV + (c & 7) * 16) = rv[i];
+      *reinterpret_cast<u32x4*>(Vs + (c / (TK / 8)) * PV + (c % (TK / 8)) * 16) = rv[i];
     }
   };
-  if (n_tiles > 0) load_tile(0);
-  for (int it = 0; it < n_tiles; ++it) {
+  const int n_it = (n_tiles + KS - 1) / KS;                   // workgroup-uniform trip count: a group past its last tile idles at the barriers
+  if (n_tiles > 0) load_tile(min(grp, n_tiles - 1));
+  for (int itg = 0; itg < n_it; ++itg) {
+    const int it = itg * KS + grp;
     __syncthreads();
     store_tile();
     __syncthreads();
-    load_tile(min(it + 1, n_tiles - 1));
-    const int key0 = it * 64;
-    bf16x8 dsf[2];
+    load_tile(min(it + KS, n_tiles - 1));
+    AB_STAMP(0, ab_i++, ab_me)        // tile staged (both barriers passed), next loads issued
+    if (it >= n_tiles) continue;
+    const int key0 = it * TK;
+    bf16x8 dsf[NCH];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       float dsv[8];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -121,7 +151,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
         for (int dc = 0; dc < DC; ++dc) {
           const bf16x8 kf = as_bf16x8(*reinterpret_cast<const u32x4*>(Ks + krow * AB_PQ + (dc * 32 + g * 8) * 2));
           s = mfma16(kf, qf[dc], s);
-          const bf16x8 vf = ab_tr_frag(Vs, AB_PV, c * 32 + t * 16, dc * 32, g, fr);
+          const bf16x8 vf = ab_tr_frag(Vs, PV, c * 32 + t * 16, dc * 32, g, fr);
           dp = mfma16(vf, dof[dc], dp);
         }
 #pragma unroll
@@ -133,12 +163,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
       }
       dsf[c] = as_bf16x8(u32x4{pack_bf16x2(dsv[0], dsv[1]), pack_bf16x2(dsv[2], dsv[3]), pack_bf16x2(dsv[4], dsv[5]), pack_bf16x2(dsv[6], dsv[7])});
     }
+    AB_STAMP(0, ab_i++, ab_me)        // S^T, dP^T, dS done
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       f32x4 acc = dqT[dt];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) acc = mfma16(ab_tr_frag(Ks, AB_PQ, dt * 16, c * 32, g, fr), dsf[c], acc);
+      for (int c = 0; c < NCH; ++c) acc = mfma16(ab_tr_frag(Ks, AB_PQ, dt * 16, c * 32, g, fr), dsf[c], acc);
       dqT[dt] = acc;
+    }
+  }
+  AB_STAMP(0, ab_i++, ab_me)          // loop done
+  if constexpr (KS > 1) {          // sum the groups' dQ: lane for lane (every group holds the same elements in the same registers), fixed order
+    __syncthreads();
+    if (grp > 0) {
+      float* mw = reinterpret_cast<float*>(ab_smem + ((grp - 1) * 4 + wave) * MERGE_WAVE) + lane;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mw[(dt * 4 + r) * 64] = dqT[dt][r];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int j = 1; j < KS; ++j) {
+      const float* rw = reinterpret_cast<const float*>(ab_smem + ((j - 1) * 4 + wave) * MERGE_WAVE) + lane;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dqT[dt][r] += rw[(dt * 4 + r) * 64];
     }
   }
   if (qi < p.S) {
@@ -147,15 +199,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
     for (int dt = 0; dt < DT; ++dt)
       *reinterpret_cast<u32x2*>(o + dt * 16 + g * 4) = u32x2{pack_bf16x2(dqT[dt][0], dqT[dt][1]), pack_bf16x2(dqT[dt][2], dqT[dt][3])};
   }
+  AB_STAMP(0, ab_i++, ab_me)
+#ifdef AB_TIMELINE
+  if (ab_me && threadIdx.x == 0 && blockIdx.y == 0) ab_dbg[0][62] = ab_i;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------- dK, dV (one partial per Q head)
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdP p) {
-  constexpr int HD = 128, DC = 4, DT = 8;
-  __shared__ __attribute__((aligned(16))) char Qs[64 * AB_PQ];
-  __shared__ __attribute__((aligned(16))) char Os[64 * AB_PQ];
-  __shared__ float lse_s[64], del_s[64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
+template <int TK, int KS>      // TK queries per staged tile, KS wave groups taking the query tiles in turn (as above)
+__global__ __launch_bounds__(256 * KS) void attn_bwd_dkv_kernel(AttnBwdP p) {
+  constexpr int HD = 128, DC = 4, DT = 8, NCH = TK / 32, NLD = TK / 16;
+  constexpr int TILE_B = 2 * TK * AB_PQ + 2 * TK * 4, MERGE_WAVE = 2 * DT * 4 * 64 * 4;
+  extern __shared__ __attribute__((aligned(16))) char ab_smem[];
+  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
+  char* Qs = ab_smem + grp * TILE_B;       // [TK queries][128 d], pitch 288
+  char* Os = Qs + TK * AB_PQ;              // dO, same shape
+  float* lse_s = reinterpret_cast<float*>(Qs + 2 * TK * AB_PQ);
+  float* del_s = lse_s + TK;
   const int kb = blockIdx.x, h = blockIdx.y, kvh = h / (p.n_q / p.n_kv);
   const int key = kb * 64 + wave * 16 + fr;                  // this lane's key (operand column)
   const int keyc = min(key, p.s_max - 1);
@@ -175,20 +235,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdP p) {
   f32x4 dvT[DT], dkT[DT];
 #pragma unroll
   for (int i = 0; i < DT; ++i) { dvT[i] = f32x4{0, 0, 0, 0}; dkT[i] = f32x4{0, 0, 0, 0}; }
-  const int n_qt = (p.S + 63) >> 6;
-  const int it0 = p.causal ? kb : 0;                          // causal: query tiles left of this key tile see none of its keys
-  u32x4 rq[4], ro[4];
+  const int n_qt = (p.S + TK - 1) / TK;
+  const int it0 = p.causal ? (kb * 64) / TK : 0;              // causal: query tiles left of this key tile see none of its keys
+  u32x4 rq[NLD], ro[NLD];
   float rl = 0.f, rd = 0.f;
   auto load_tile = [&](int it) {
-    const int q0 = it * 64;
+    const int q0 = it * TK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NLD; ++i) {
       const int c = tid + i * 256, row = c >> 4, slot = c & 15;
       const size_t off = (size_t)min(q0 + row, p.S - 1) * p.n_q * HD + (size_t)h * HD + slot * 8;
       rq[i] = ld_global_16(p.q + off);
       ro[i] = ld_global_16(p.d_o + off);
     }
-    if (tid < 64) {
+    if (tid < TK) {
       const int qq = min(q0 + tid, p.S - 1);
       rl = p.lse[(size_t)h * p.S + qq];
       rd = p.delta[(size_t)h * p.S + qq];
@@ -196,23 +256,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdP p) {
   };
   auto store_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NLD; ++i) {
       const int c = tid + i * 256;
       *reinterpret_cast<u32x4*>(Qs + (c >> 4) * AB_PQ + (c & 15) * 16) = rq[i];
       *reinterpret_cast<u32x4*>(Os + (c >> 4) * AB_PQ + (c & 15) * 16) = ro[i];
     }
-    if (tid < 64) { lse_s[tid] = rl; del_s[tid] = rd; }
+    if (tid < TK) { lse_s[tid] = rl; del_s[tid] = rd; }
   };
-  if (it0 < n_qt) load_tile(it0);
-  for (int it = it0; it < n_qt; ++it) {
+  const int n_it = (max(n_qt - it0, 0) + KS - 1) / KS;
+  if (it0 < n_qt) load_tile(min(it0 + grp, n_qt - 1));
+  for (int itg = 0; itg < n_it; ++itg) {
+    const int it = it0 + itg * KS + grp;
     __syncthreads();
     store_tile();
     __syncthreads();
-    load_tile(min(it + 1, n_qt - 1));
-    const int q0 = it * 64;
-    bf16x8 pf[2], dsf[2];
+    load_tile(min(it + KS, n_qt - 1));
+    if (it >= n_qt) continue;
+    const int q0 = it * TK;
+    bf16x8 pf[NCH], dsf[NCH];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       float pv[8], dsv[8];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -241,11 +304,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdP p) {
     for (int dt = 0; dt < DT; ++dt) {
       f32x4 av = dvT[dt], ak = dkT[dt];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
+      for (int c = 0; c < NCH; ++c) {
         av = mfma16(ab_tr_frag(Os, AB_PQ, dt * 16, c * 32, g, fr), pf[c], av);
         ak = mfma16(ab_tr_frag(Qs, AB_PQ, dt * 16, c * 32, g, fr), dsf[c], ak);
       }
       dvT[dt] = av; dkT[dt] = ak;
+    }
+  }
+  if constexpr (KS > 1) {
+    __syncthreads();
+    if (grp > 0) {
+      float* mw = reinterpret_cast<float*>(ab_smem + ((grp - 1) * 4 + wave) * MERGE_WAVE) + lane;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { mw[(dt * 4 + r) * 64] = dvT[dt][r]; mw[(DT * 4 + dt * 4 + r) * 64] = dkT[dt][r]; }
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int j = 1; j < KS; ++j) {
+      const float* rw = reinterpret_cast<const float*>(ab_smem + ((j - 1) * 4 + wave) * MERGE_WAVE) + lane;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dvT[dt][r] += rw[(dt * 4 + r) * 64]; dkT[dt][r] += rw[(DT * 4 + dt * 4 + r) * 64]; }
     }
   }
   if (key < p.S) {
@@ -267,8 +350,18 @@ extern "C" int vlaser_attn_bwd(const void* q, const void* k, const void* vt, con
   p.lse = lse; p.delta = delta_ws; p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
   p.S = S; p.n_q = n_q; p.n_kv = n_kv; p.s_max = s_max; p.scale = scale; p.causal = causal; p.kv_valid = kv_valid < S ? kv_valid : (causal ? S : kv_valid);
   const dim3 grid((S + 63) / 64, n_q);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)s, p);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)s, p);
+  static const int force_ks = getenv("VLASER_ATTN_BWD_KS") ? atoi(getenv("VLASER_ATTN_BWD_KS")) : 0;       // tuning / A-B
+  const int ks = force_ks == 1 || force_ks == 2 ? force_ks : (S > 128 ? 2 : 1);
+#define AB_LAUNCH(KS_)                                                                                               \
+  {                                                                                                                  \
+    const int lds_q = KS_ * (64 * AB_PQ + 128 * AB_PV), lds_kv = KS_ * (2 * 64 * AB_PQ + 2 * 64 * 4);                \
+    if (int rc = set_max_lds_once(attn_bwd_dq_kernel<64, KS_>, lds_q)) return rc;                                   \
+    if (int rc = set_max_lds_once(attn_bwd_dkv_kernel<64, KS_>, lds_kv)) return rc;                                 \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<64, KS_>), grid, dim3(256 * KS_), lds_q, (hipStream_t)s, p);             \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, KS_>), grid, dim3(256 * KS_), lds_kv, (hipStream_t)s, p);           \
+  }
+  if (ks == 2) AB_LAUNCH(2) else AB_LAUNCH(1)
+#undef AB_LAUNCH
   VL_LAUNCH_CHECK();
   return 0;
 }
