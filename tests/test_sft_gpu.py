@@ -226,6 +226,28 @@ def test_gemm_tn_weight_gradient(K, M, N):
     assert rel < 5e-3 and cos > 0.9999
 
 
+@pytest.mark.parametrize('K,M,N,cfg', [(560, 1536, 2048, 0), (560, 17920, 1536, 0), (560, 1536, 8960, 0), (313, 256, 1536, 1100), (64, 136, 264, 1105),
+                                       (130, 2048, 1536, 1200), (200, 1000, 520, 1300)])
+def test_gemm_tn_lds_padded_contraction(K, M, N, cfg):
+    """vlaser_gemm_tn_lds (the TN weight-gradient product on the LDS-DMA pipeline, both operands k-major): contraction axis padded to 64-row
+    tiles with ZERO pad rows in At and arbitrary finite pad rows in Wt; edge tiles in M and N; every tile configuration.  Against fp32 and
+    against the register-staged vlaser_gemm_tn on the unpadded views (same products, different summation order: bf16-rounding tolerance)."""
+    from vlaser_amd import ops
+    g = torch.Generator().manual_seed(K + M + N)
+    Kp = (K + 63) // 64 * 64
+    At = torch.zeros(Kp, M, dtype=BF, device='cuda'); Wt = torch.randn(Kp, N, generator=g).to(BF).cuda()       # Wt pad rows: finite garbage
+    At[:K] = torch.randn(K, M, generator=g).to(BF).cuda()
+    out = torch.full((M, N), 7.0, dtype=BF, device='cuda'); out_old = torch.zeros_like(out)
+    ops.gemm_tn_lds(At, Wt, out, Kp, force_cfg=cfg)
+    ops.gemm_tn(At[:K], Wt[:K], out_old)
+    ref = At[:K].float().t() @ Wt[:K].float()
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 2e-2 * ref.abs().max().item() + 1e-3, err
+    rel, cos = _rel(out, ref)
+    assert rel < 5e-3 and cos > 0.9999
+    assert (out.float() - out_old.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
 def test_attention_backward_fused_pds_and_grouped_tn():
     """vlaser_attn_bwd_pds (softmax + dS in one pass) and the grouped TN GEMM (dK / dV summed over the q heads of a kv group)
     against the closed forms, on a ragged S (not a multiple of 64)."""

@@ -18,4 +18,17 @@ for (N, K, name) in [(17920, 1536, 'gate/up'), (1536, 8960, 'down'), (2048, 1536
     out2 = torch.zeros(N, K, dtype=BF, device='cuda')
     us2 = timeit([lambda t=t: ops.gemm(L.EPI_NONE, t, xt, out=out2) for t in dts])
     fl = 2.0 * S * N * K
+    dps = [torch.zeros(Sp, N, dtype=BF, device='cuda') for _ in range(6)]; xp = torch.zeros(Sp, K, dtype=BF, device='cuda')
+    for d, t in zip(dys, dps): t[:S] = d
+    xp[:S] = x
+    out3 = torch.zeros(N, K, dtype=BF, device='cuda')
+    res = []
+    for cfg in (1100, 1105, 1200, 1300):
+        try:
+            u = timeit([lambda t=t: ops.gemm_tn_lds(t, xp, out3, Sp, force_cfg=cfg) for t in dps])
+            res.append(f'{cfg}: {u:6.2f} us ({fl / u / 1e6:5.0f} TF)')
+        except Exception as e:
+            res.append(f'{cfg}: {type(e).__name__}')
+    ops.gemm_tn_lds(dps[-1], xp, out3, Sp)
+    print(f'   LDS-DMA TN  ' + '   '.join(res) + f'   max diff vs TN {(out3.float() - out.float()).abs().max().item():.3g}')
     print(f'wgrad {name:8s} [{N}x{K}] S={S}: TN {us:7.2f} us ({fl / us / 1e6:6.1f} TF)   NT on transposed {us2:7.2f} us ({fl / us2 / 1e6:6.1f} TF)   max diff {(out.float() - out2.float()).abs().max().item():.3g}')

@@ -77,6 +77,7 @@ _SIGS = {
     'vlaser_ce_rows': [vp, vp, i32, i32, i64, vp, vp, i64, vp],
     'vlaser_reduce_norm': [vp, vp, i32, vp, vp, i32, vp, vp, f32, vp, vp, i32, i32, vp],
     'vlaser_gemm_tn': [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    'vlaser_gemm_tn_lds': [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     'vlaser_gemm_tn_grouped': [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, i64, i32, i64, i64, i64, vp],
     'vlaser_attn_bwd_pds': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     'vlaser_transpose': [vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i32, i64, i64, vp],

@@ -579,7 +579,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // 4 (fr & 3) .. +3 and receives column fr's four k-values, i.e. operand element e <-> k = 8 fq + e, the same order the
 // row-major A fragment has.  A 32-lane phase of that read touches k-rows {0-3, 8-11} (+4), 32 bytes each, at the same two
 // logical slots: the swizzle key 2 ((k & 3) | ((k >> 3) & 1) << 2) sends them to eight different slot pairs of the 256-byte bank row.
-template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false>
+// AKM ("A k-major", r03): the FIRST operand is stored [K][M] row-major as well -- together with WKM the TN form out = At^T @ Wt of the weight gradients
+// (dW = dY^T X, contraction over the sequence), both operands staged and read exactly like the WKM operand.  K must be a whole number of 64-row tiles:
+// the caller pads the sequence axis (rows K_true..K of At zero, of Wt finite).
+template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BNT / WN;
@@ -587,6 +590,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
   constexpr int STAGE = (BM + BNT) * 128;               // bytes: A tile | W tile (row-major, 128 B = 64 k per row)
   constexpr int NPA = BM / 8, NPW = BNT / 8;             // 1 KiB (8-row) pieces of the A / W tile (WKM: 64 k-rows x 2 BNT bytes = the same count)
   constexpr int WROWB = BNT * 2, WRPP = 1024 / WROWB, WSPR = BNT / 8;      // WKM: bytes per k-row, k-rows per piece, 16-byte slots per k-row
+  constexpr int AROWB = BM * 2, ARPP = 1024 / AROWB, ASPR = BM / 8;        // AKM: the same for the A tile
+  static_assert(!AKM || (WKM && (BM == 128 || BM == 256)), "AKM needs WKM and a power-of-two tile of >= 16 slots per k-row");
   constexpr int PA = (NPA + NW - 1) / NW, PW = (NPW + NW - 1) / NW;     // pieces per wave per K-tile; an uneven split re-issues the last piece
   constexpr int PIECES = PA + PW;                        // (same bytes to the same LDS address: benign) so every wave's vmcnt arithmetic is identical
   static_assert(NPA * 8 == BM && NPW * 8 == BNT, "tile rows must be multiples of 8");
@@ -616,8 +621,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
   const bf16_t* srcW[PW];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
-    const int row = min(wave * PA + i, NPA - 1) * 8 + prow;
-    srcA[i] = A + (size_t)min(m0 + row, a.M - 1) * a.lda + kbase + ((pslot ^ (row & 7)) << 3);
+    if constexpr (AKM) {
+      const int krow = min(wave * PA + i, NPA - 1) * ARPP + lane / ASPR;
+      const int slot = (lane % ASPR) ^ (2 * ((krow & 3) | (((krow >> 3) & 1) << 2)));
+      srcA[i] = A + (size_t)(kbase + krow) * a.lda + min(m0 + slot * 8, ((a.M + 7) & ~7) - 8);
+    } else {
+      const int row = min(wave * PA + i, NPA - 1) * 8 + prow;
+      srcA[i] = A + (size_t)min(m0 + row, a.M - 1) * a.lda + kbase + ((pslot ^ (row & 7)) << 3);
+    }
   }
 #pragma unroll
   for (int i = 0; i < PW; ++i) {
@@ -635,7 +646,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
     const int ko = min(kt, nk - 1) * BK;                 // tiles past the end re-fetch the last one (never read)
     const uint32_t base = lds0 + st * STAGE;
 #pragma unroll
-    for (int i = 0; i < PA; ++i) glds16(srcA[i] + ko, __builtin_amdgcn_readfirstlane(base + min(wave * PA + i, NPA - 1) * 1024));
+    for (int i = 0; i < PA; ++i) glds16(srcA[i] + (AKM ? (size_t)ko * a.lda : (size_t)ko), __builtin_amdgcn_readfirstlane(base + min(wave * PA + i, NPA - 1) * 1024));
 #pragma unroll
     for (int i = 0; i < PW; ++i) glds16(srcW[i] + (WKM ? (size_t)ko * a.ldw : (size_t)ko), __builtin_amdgcn_readfirstlane(base + BM * 128 + min(wave * PW + i, NPW - 1) * 1024));
   };
@@ -664,8 +675,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
       if (ks == 1 && !GLDS_ISSUE_FIRST) issue_tile(kt + NST - 1, stn);
       if (ks == 0 && GLDS_ISSUE_FIRST) issue_tile(kt + NST - 1, stn);
 #pragma unroll
-      for (int t = 0; t < MT; ++t)
-        fa[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + lds_off(wr * WTM + t * 16 + fr, ks * 4 + fq)));
+      for (int t = 0; t < MT; ++t) {
+        if constexpr (AKM) {
+          const int kr = ks * 32 + 8 * fq + (fr >> 2), c0 = wr * WTM + t * 16;
+          const int sl = (c0 >> 3) + ((fr & 3) >> 1), hb = (fr & 1) * 8;
+          const int key_lo = 2 * ((kr & 3) | (((kr >> 3) & 1) << 2)), key_hi = 2 * (((kr + 4) & 3) | ((((kr + 4) >> 3) & 1) << 2));
+          typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+          const char* plo = As + kr * AROWB + (((sl & ~15) | ((sl & 15) ^ key_lo)) << 4) + hb;
+          const char* phi = As + (kr + 4) * AROWB + (((sl & ~15) | ((sl & 15) ^ key_hi)) << 4) + hb;
+          union { s16x4_t h[2]; bf16x8 b; } u;
+          u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(uint32_t)(uintptr_t)plo);
+          u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(uint32_t)(uintptr_t)phi);
+          fa[t] = u.b;
+        } else {
+          fa[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + lds_off(wr * WTM + t * 16 + fr, ks * 4 + fq)));
+        }
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         if constexpr (WKM) {
@@ -727,7 +752,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
   }
 }
 
-template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false>
+template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false>
 static int launch_glds(const VlaserGemmArgs* args, hipStream_t stream, int splits) {
   GemmP p;
   p.a = *args;
@@ -735,8 +760,8 @@ static int launch_glds(const VlaserGemmArgs* args, hipStream_t stream, int split
   p.tiles_n = (args->N + BNT - 1) / BNT;
   constexpr int lds = NST * (BM + BNT) * 128;
   static_assert(lds <= 160 * 1024, "stage ring exceeds the 160 KiB LDS of a CU");
-  if (int rc = set_max_lds_once(gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM>, lds)) return rc;
-  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM>), dim3(p.tiles_m * p.tiles_n, splits, args->batch > 1 ? args->batch : 1),
+  if (int rc = set_max_lds_once(gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM>, lds)) return rc;
+  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM>), dim3(p.tiles_m * p.tiles_n, splits, args->batch > 1 ? args->batch : 1),
                      dim3(WM * WN * 64), lds, stream, p);
   VL_LAUNCH_CHECK();
   return 0;
@@ -760,7 +785,7 @@ static int launch_bm(const VlaserGemmArgs* args, hipStream_t stream, int splits)
 // first losing to smallest: 64x128 (8 waves, 4 stages) for the smallest problems, then 128x128 (4 stages), 128x256 (3 stages),
 // 256x256 (2 stages).  Multi-round grids take the configuration with the least modelled time (rounds x tile area / measured
 // rate); <= 32 activation rows stay on the 32-row register-staged kernel (a 64-row tile would be 50+ % padding).
-template <int EPI, bool WKM = false>
+template <int EPI, bool WKM = false, bool AKM = false>
 static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
   const int splits = (EPI == VL_EPI_PARTIAL && args->k_splits > 1) ? args->k_splits : 1;
   const int tn = (args->N + BN - 1) / BN;
@@ -769,7 +794,13 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
   (void)tn;
   int bm = args->force_bm;
   if (bm == 0) {
-    if (args->M <= 32 && !WKM) {
+    if constexpr (AKM) {                 // TN form: 128- and 256-row tiles only (>= 16 slots per staged k-row on both operands)
+      // measured at K = 576 (tools/micro/tn_lab.py): qkv / o (192 / 144 tiles of 128x128) 10.2 / 10.0 us; down 1100 / 1200 / 1300 = 33.7 / 29.5 / 26.2 us,
+      // gate/up 67.2 / 59.9 / 50.5 us -- multi-round grids want the largest tile
+      if (blocks(128, 128) <= 256) bm = 1100;
+      else if (blocks(128, 256) <= 256) bm = 1200;
+      else bm = 1300;
+    } else if (args->M <= 32 && !WKM) {
       bm = 32;
     } else if (!WKM && blocks(64, 64) <= 256) {      // (the NN form's transposing reads need >= 16 slots per staged k-row: BNT >= 128)
       bm = 1564;                       // r03: a K-step costs the same ~0.4 us whatever the tile, so the smallest problems want the most workgroups (profiles/r03e_gemm_lab.md)
@@ -793,6 +824,15 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
     }
   }
   // LDS-DMA pipeline configurations: 1100 = 128x128 / 4 stages, 1200 = 128x256 / 3, 1300 = 256x256 / 2, 1500 = 64x128 / 4 (8 waves each), 1440 = 144x128 / 4 (6 waves)
+  if constexpr (AKM) {
+    switch (bm) {
+      case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4, true, true>(args, stream, splits);
+      case 1105: return launch_glds<EPI, 128, 128, 2, 4, 5, true, true>(args, stream, splits);
+      case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3, true, true>(args, stream, splits);
+      case 1300: return launch_glds<EPI, 256, 256, 2, 4, 2, true, true>(args, stream, splits);
+      default: vlaser_set_error("vlaser_gemm_tn_lds: force_cfg must be 0 or 1100 / 1105 / 1200 / 1300 (got %d)", bm); return -1;
+    }
+  }
   switch (bm) {
     case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM>(args, stream, splits);
     case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3, WKM>(args, stream, splits);
@@ -993,6 +1033,21 @@ extern "C" int vlaser_gemm_tn_grouped(const void* At, const void* Wt, void* out,
 
 extern "C" int vlaser_gemm_tn(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, vl_stream_t s) {
   return vlaser_gemm_tn_grouped(At, Wt, out, M, N, K, ldat, ldwt, ldo, 1, 0, 0, 1, 0, 0, 0, s);
+}
+
+// The TN form on the LDS-DMA pipeline (r03): same result as vlaser_gemm_tn when the contraction axis is PADDED -- K is a whole number of 64-row tiles,
+// the rows K_true..K of At are zero and those of Wt finite (the SFT step keeps its activations in buffers of ceil64(S) rows and zeroes the pad rows
+// of the dY operands once per backward).  No staging registers, no ds_write pass, 8 waves on 128x128 .. 256x256 tiles.
+extern "C" int vlaser_gemm_tn_lds(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, int force_cfg, vl_stream_t s) {
+  VL_CHECK(At && Wt && out && M > 0 && N > 0 && K > 0, "vlaser_gemm_tn_lds: bad args");
+  VL_CHECK(K % BK == 0, "vlaser_gemm_tn_lds: K=%d must be a multiple of %d (pad the contraction axis: zero rows in At)", K, BK);
+  VL_CHECK(M % 8 == 0 && N % 8 == 0 && ldat % 8 == 0 && ldwt % 8 == 0 && ldat >= M && ldwt >= N && ldo >= N, "vlaser_gemm_tn_lds: M, N, ldat, ldwt must be multiples of 8");
+  VL_CHECK((((uintptr_t)At | (uintptr_t)Wt) & 15) == 0 && ((uintptr_t)out & 7) == 0, "vlaser_gemm_tn_lds: operands must be 16-byte aligned");
+  VlaserGemmArgs a = {};
+  a.A = At; a.W = Wt; a.out = out;
+  a.M = M; a.N = N; a.K = K; a.lda = ldat; a.ldw = ldwt; a.ldo = ldo;
+  a.k_splits = 1; a.force_bm = force_cfg;
+  return launch<VL_EPI_NONE, true, true>(&a, reinterpret_cast<hipStream_t>(s));
 }
 
 extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {

@@ -514,6 +514,14 @@ def gemm_tn(At, Wt, out, K=None):
     return out
 
 
+def gemm_tn_lds(At, Wt, out, K_pad, force_cfg=0):
+    """out[M,N] = At[:K_pad]^T @ Wt[:K_pad] on the LDS-DMA pipeline: K_pad a multiple of 64, rows past the true K of At ZERO and of Wt finite."""
+    M, N = At.shape[1], Wt.shape[1]
+    L.check(L.lib().vlaser_gemm_tn_lds(At.data_ptr(), Wt.data_ptr(), out.data_ptr(), M, N, K_pad, At.stride(0), Wt.stride(0), out.stride(0), force_cfg, _stream()),
+            'vlaser_gemm_tn_lds')
+    return out
+
+
 def gemm_tn_grouped(At, Wt, out, M, N, K, ldat, ldwt, ldo, groups, a_gs, w_gs, batch, a_bs, w_bs, o_bs):
     """out[b] = sum_g At[b,g]^T @ Wt[b,g] (raw pointers + element strides; see include/vlaser_hip.h)."""
     L.check(L.lib().vlaser_gemm_tn_grouped(At.data_ptr(), Wt.data_ptr(), out.data_ptr(), M, N, K, ldat, ldwt, ldo, groups, a_gs, w_gs, batch,

@@ -120,6 +120,8 @@ class SFTModel:
         # the attention backward walks the query rows in blocks of this many (r03): its score matrices are [heads, block, keys], not [heads, S, S] --
         # the reference's launcher trains at --max_seq_length 16384 (…2nd_finetune_full.sh:38,60), where four S x S matrices per head are 38 GB
         self.attn_bwd_block = attn_bwd_block
+        self.wgrad_lds = os.environ.get('VLASER_SFT_WGRAD', 'lds') == 'lds'      # 'tn': the register-staged TN kernel everywhere (A/B)
+        self._wgrad_pad_S = None
         self.attn_bwd_mode = os.environ.get('VLASER_SFT_ATTN_BWD', attn_bwd)
         if self.attn_bwd_mode not in ('fused', 'materialised'):
             raise ValueError(f'VLASER_SFT_ATTN_BWD={self.attn_bwd_mode!r}: fused | materialised')
@@ -296,12 +298,29 @@ class SFTModel:
             torch.cuda.current_stream().wait_event(ev)
 
     # ------------------------------------------------------------------ small helpers
-    def _wgrad(self, dY, X, out, S, bias_out=None):
+    def _wgrad(self, dY, X, out, S, bias_out=None, padded=False):
         """out[N,K] = dY[S,N]^T @ X[S,K] (bf16) by the TN GEMM: both operands are read as they lie (contraction along their
-        rows, transposing LDS reads) -- no transposed activation copies."""
-        ops.gemm_tn(dY[:S], X[:S], out)
+        rows, transposing LDS reads) -- no transposed activation copies.  `padded`: dY / X are views of step buffers with ceil64(S)
+        rows whose dY pad rows are zero (`_zero_wgrad_pad`): the product then runs on the LDS-DMA pipeline (r03: 97 instead of 135 us
+        per layer at S = 560, tools/micro/tn_lab.py)."""
+        Sp = (S + 63) // 64 * 64
+        if padded and self.wgrad_lds and dY.shape[1] % 8 == 0 and X.shape[1] % 8 == 0:
+            for t in (dY, X):       # the pad rows must lie inside the buffer the view was cut from
+                assert t.storage_offset() + (Sp - 1) * t.stride(0) + t.shape[1] <= t.untyped_storage().nbytes() // t.element_size()
+            ops.gemm_tn_lds(dY, X, out, Sp)
+        else:
+            ops.gemm_tn(dY[:S], X[:S], out)
         if bias_out is not None:
             ops.colsum_bf16(dY, bias_out, S, dY.shape[1])
+
+    def _zero_wgrad_pad(self, S):
+        """Rows S..ceil64(S) of the four dY buffers the layer weight gradients contract over: zero, so that the padded TN GEMM may read whole
+        64-row tiles.  Nothing writes those rows while S stays the same (every kernel is bounded by S), so this runs when S changes."""
+        Sp = (S + 63) // 64 * 64
+        if Sp != S and self._wgrad_pad_S != S:
+            for b in (self.dh, self.dh2, self.dgu, self.dqkv):
+                b[S:Sp].zero_()
+        self._wgrad_pad_S = S
 
     def _dgrad(self, dY, W, out, S):
         """out[S,K] = dY[S,N] @ W[N,K], W as the forward stores it (NN GEMM); long contractions over few output tiles run split-K."""
@@ -447,6 +466,7 @@ class SFTModel:
         dxn = self.dx[:S]
         dxn.zero_()
         dxn.index_copy_(0, rows, dx_rows)
+        self._zero_wgrad_pad(S)
         dh = self.dh[:S]
         ops.rmsnorm_bwd(dxn, h_fin, v['norm'], None, dh, S, H, llm.rms_norm_eps, dw_out=gv['norm'], dw_ws=self.normw_ws)
         if on_bucket_ready:
@@ -471,13 +491,13 @@ class SFTModel:
             else:
                 self._dgrad(dh, v[f'l{i}.wdown'], dact, S)
                 ops.swiglu_bwd(gu, dact, dgu, S, I)
-            self._wgrad(dh, act, gv[f'l{i}.wdown'], S)
+            self._wgrad(dh, act, gv[f'l{i}.wdown'], S, padded=True)
             self._dgrad(dgu, v[f'l{i}.wgu'], dx, S)
-            self._wgrad(dgu, x2, gv[f'l{i}.wgu'], S)
+            self._wgrad(dgu, x2, gv[f'l{i}.wgu'], S, padded=True)
             ops.rmsnorm_bwd(dx, h2, v[f'l{i}.ln_post'], dh, dh2, S, H, llm.rms_norm_eps, dw_out=gv[f'l{i}.ln_post'], dw_ws=self.normw_ws)
             # attention block: h2 = h_in + ao Wo^T
             self._dgrad(dh2, v[f'l{i}.wo'], dao, S)
-            self._wgrad(dh2, ao, gv[f'l{i}.wo'], S)
+            self._wgrad(dh2, ao, gv[f'l{i}.wo'], S, padded=True)
             Kc, VTc = self.cache.k[kslot, 0], self.cache.vt[kslot, 0]         # [nkv, s_max, hd], [nkv, hd, s_max]
             if self.attn_bwd_mode == 'fused':
                 ops.attn_bwd(q, Kc, VTc, ao, dao, self.lse[kslot], self.delta_ws, self.dq[:S], self.dk[:S], self.dv[:S], S, nq, nkv, sm, scale)
@@ -486,7 +506,7 @@ class SFTModel:
             dqkv = self.dqkv[:S]
             ops.rope_bwd_pack(self.dq[:S], self.dk[:S], self.dv[:S], self.rope[0], self.rope[1], pos, dqkv, S, nq, nkv, kv_per_q_head=True)
             self._dgrad(dqkv, v[f'l{i}.wqkv'], dx, S)
-            self._wgrad(dqkv, x1, gv[f'l{i}.wqkv'], S, bias_out=gv[f'l{i}.bqkv'])
+            self._wgrad(dqkv, x1, gv[f'l{i}.wqkv'], S, bias_out=gv[f'l{i}.bqkv'], padded=True)
             ops.rmsnorm_bwd(dx, h_in, v[f'l{i}.ln_in'], dh2, dh, S, H, llm.rms_norm_eps, dw_out=gv[f'l{i}.ln_in'], dw_ws=self.normw_ws)
             if on_bucket_ready and (i == 0 or bucket_of_layer[i - 1] != bucket_of_layer[i]):
                 on_bucket_ready(bucket_of_layer[i])
