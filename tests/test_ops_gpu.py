@@ -543,7 +543,7 @@ def test_gemm_splitk_reduce_norm(ops, M, N, K, S):
     close(h3, href.float(), rtol=8e-3, name='h none')
 
 
-@pytest.mark.parametrize('bm', [1100, 1105, 1200, 1300, 1440, 1500, 1506, 1532, 1564])
+@pytest.mark.parametrize('bm', [1100, 1105, 1200, 1300, 1440, 1500, 1506, 1532, 1564, 1900])
 def test_gemm_glds_ragged_and_splitk(ops, bm):
     """LDS-DMA pipelines on shapes that do not fill their tiles: ragged M and N (fp32 logits epilogue), K shorter than the stage
     ring (look-ahead tiles are clamped re-fetches), and split-K partial slabs."""
@@ -581,7 +581,7 @@ def test_gemm_lds_attribute_is_set_per_kernel_in_any_order():
     assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
 
 
-@pytest.mark.parametrize('bm', [0, 1100, 1200, 1300, 1440, 1500])
+@pytest.mark.parametrize('bm', [0, 1100, 1200, 1300, 1440, 1500, 1900])
 def test_gemm_nn_reads_the_weight_as_stored(ops, bm):
     """NN form (dgrad dX = dY @ W with W [N_out, K_in] as the forward stores it): every LDS-DMA configuration against fp32 matmul on
     ragged M / N, a short contraction (K shorter than the stage ring), a strided B (a slice of a wider matrix), and split-K slabs."""

@@ -433,6 +433,8 @@ def gemm_tile_config(M, N, splits=1, batch=1, nn=False):
     if M <= 32 and not nn:
         return (32, 32, 128, 500.0)
     for c in _GEMM_CFGS:
+        if c[0] == 1300 and blocks(192, 256) <= 256 and -(-M // 192) * 192 < -(-M // 256) * 256:
+            return (1900, 192, 256, 1208.0)
         if blocks(c[1], c[2]) <= 256 and not (nn and c[0] == 1564):
             return c
     return min((c for c in _GEMM_CFGS if c[0] not in (1440, 1564)), key=lambda c: -(-blocks(c[1], c[2]) // 256) * c[1] * c[2] / c[3])
@@ -447,7 +449,7 @@ def split_slab_elems(max_rows, N):
 
 # per-launch time model of the LDS-DMA pipelines, fitted on MI355X (profiles/r03e_gemm_lab.md: 24 vs 64 K-steps per configuration):
 # a launch costs a fixed ~5-7 us (launch, cold first tiles, epilogue) + a per-K-step time that grows with the tile area
-_GEMM_STEP_US = {32: (5.0, 0.30), 1564: (4.9, 0.177), 1500: (5.1, 0.263), 1100: (5.3, 0.377), 1440: (5.6, 0.509), 1200: (7.0, 0.62), 1300: (9.0, 1.55)}
+_GEMM_STEP_US = {32: (5.0, 0.30), 1564: (4.9, 0.177), 1500: (5.1, 0.263), 1100: (5.3, 0.377), 1440: (5.6, 0.509), 1200: (7.0, 0.62), 1300: (9.0, 1.55), 1900: (8.5, 1.2)}
 
 
 _SPLIT_MIN_K = int(os.environ.get('VLASER_GEMM_SPLIT_MINK', '512'))      # >= 8 K-steps per slice: the fitted model does not extrapolate to shorter loops
@@ -505,10 +507,16 @@ def avg_update(avg, p, c, first):
 
 
 # ------------------------------------------------------------------------------------------------ SFT (backward / optimizer)
+_TN_LDS = os.environ.get('VLASER_TN_LDS', '1') == '1'
+
+
 def gemm_tn(At, Wt, out, K=None):
     """out[M,N] = At[:K]^T @ Wt[:K] (bf16): At [K,M], Wt [K,N] row-major views (row strides honoured)."""
     K = At.shape[0] if K is None else K
     M, N = At.shape[1], Wt.shape[1]
+    if K % 64 == 0 and M % 8 == 0 and N % 8 == 0 and At.stride(0) % 8 == 0 and Wt.stride(0) % 8 == 0 and (At.data_ptr() | Wt.data_ptr()) % 16 == 0 \
+            and M * N >= 128 * 128 and _TN_LDS:
+        return gemm_tn_lds(At, Wt, out, K)          # whole 64-row tiles: nothing to pad, the LDS-DMA pipeline applies as is
     L.check(L.lib().vlaser_gemm_tn(At.data_ptr(), Wt.data_ptr(), out.data_ptr(), M, N, K, At.stride(0), Wt.stride(0), out.stride(0), _stream()),
             'vlaser_gemm_tn')
     return out
