@@ -488,7 +488,10 @@ extern "C" int vlaser_attn_prefill(const VlaserAttnArgs* a, vl_stream_t s) {
   // unmasked head_dim-64 case around one workgroup per CU (ViT, 1 tile: 23.9 -> 22.8 us); more registers per wave (a forced
   // 4 waves / SIMD) and a 4-way split both lose everywhere
   const long blocks = (long)grid.x * grid.y * grid.z;
-  int ks = blocks <= 192 ? 2 : 1;
+  static const int force_ks = getenv("VLASER_ATTN_KS") ? atoi(getenv("VLASER_ATTN_KS")) : 0;      // tuning / A-B
+  // r03: the split is 8 % faster alone at 108 workgroups (S = 560: 14.7 vs 15.9 us) but stretches x2.5 instead of x1.5 when the SFT step's AdamW streams
+  // beside it (tools/micro/contention_lab.py; whole step 23.4 -> 22.8 ms with the split off): only grids below 96 workgroups split
+  int ks = force_ks == 1 || force_ks == 2 ? force_ks : (blocks <= 96 ? 2 : 1);
   const int tk = (a->head_dim == 64 && a->mode == VL_ATTN_FULL && blocks <= 512 && ks == 1) ? 128 : 64;
   if (a->kv_len <= tk) ks = 1;
 #define VL_ATTN_LAUNCH(HD_, KS_, TK_)                                                                                       \
