@@ -61,13 +61,14 @@ def _median(xs):
 def cpu_baseline(vla_full, seed=0):
     """this repo's CPU oracle (the fp32 torch-CPU restatement of the reference path, pinned against the
     reference's own outputs by the golden fixtures) on the host cores, same synthetic inputs as the GPU run: 1 warm-up + 3 timed
-    runs, median, with `os.cpu_count()` threads -- and, because the oracle's small matmuls get SLOWER with hundreds of threads,
-    also capped at 32 threads; `value` is the better of the two, both are stated.  Bounded sample: full widths, depth-truncated
-    (2 ViT / 2 LLM+expert layers, 2 Euler steps), phase times scaled linearly to 24 / 28 layers and 10 steps."""
+    runs, median, on min(host cores, 32) threads (r02 also timed all 256 threads of the GPU box's host: the oracle's small matmuls
+    collapse there -- 0.001 chunks/s -- and that leg cost a minute of every bench run; dropped).  Bounded sample (~10 s of CPU work):
+    full widths, a QUARTER of the depth (6 of 24 ViT layers, 7 of 28 LLM + expert layers: generating fp32 weights for more costs more wall
+    time than timing them), all 10 Euler steps; phase times scaled x4 to full depth (r02 sampled 2 layers and 2 steps)."""
     from vlaser_amd import config as C, synth
     from oracle import vla as ovla
     import torch.nn.functional as F
-    dv, dl, de = 2, 2, 2                      # ViT layers, LLM/expert layers, Euler steps in the sample
+    dv, dl, de = 6, 7, 10                     # ViT layers, LLM/expert layers, Euler steps in the sample
     cfg = C.truncated(vla_full.base, dv, dl)
     vla = C.VLAConfig(base=cfg)
     sd = synth.vla_state_dict(vla)
@@ -96,7 +97,7 @@ def cpu_baseline(vla_full, seed=0):
 
     res = {}
     with torch.no_grad():
-        for threads in sorted({os.cpu_count(), min(os.cpu_count(), 32)}, reverse=True):
+        for threads in (min(os.cpu_count(), 32),):
             torch.set_num_threads(threads)
             run()                       # warm-up
             ts = [run() for _ in range(3)]
