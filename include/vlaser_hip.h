@@ -238,6 +238,14 @@ int vlaser_vla_prep(const float* action, const void* w1, const void* b1, void* x
 int vlaser_small_linear(const float* x, const void* w, const void* b, void* out, int M, int N, int K, vl_stream_t stream);
 int vlaser_vla_euler(const void* h_in, const float* partials, int n_partials, int M, const void* norm_w, float eps, const void* wd,
                      const void* bd, float* action, int W, int adim, float dt, float clip, int do_clip, float* vel_out, vl_stream_t stream);
+/* (ABI 4) Everything between two passes through the expert's layers in ONE launch: [finish != 0: the tail of the previous Euler step exactly as
+ * vlaser_vla_euler computes it, without the clamp, on rows row_off .. row_off + M of h_in / partials (slabs of rows_in rows), a_out = a_in + dt * vel,
+ * vel_out optional] + the action encoder of the next step (modules.py:25-56 ActionEncoder: linear_1, time embedding, cat, linear_2, swish, linear_3)
+ * with linear_1 / the time embedding folded into linear_2 by the host: w21 = W2[:, W:] @ W1 (fp32 [W, adim]), cs = W2[:, :W] @ temb(t) + W2[:, W:] @ b1 + b2
+ * (fp32 [W], this step's row).  h_out [M, W] bf16 = linear_3's output.  a_in / a_out must differ when finish != 0.  W multiple of 256, <= 1024. */
+int vlaser_vla_step(const void* h_in, const float* partials, int n_partials, int rows_in, int row_off, const void* norm_w, float eps, const void* wd,
+                    const void* bd, const float* a_in, float* a_out, float* vel_out, float dt, int finish, const float* w21, const float* cs, const void* w3,
+                    const void* b3, void* h_out, int M, int W, int adim, vl_stream_t stream);
 int vlaser_reduce_partials(const void* h_in, const float* partials, int n_partials, int M, int K, void* out, vl_stream_t stream);
 int vlaser_cast_f32_bf16(const float* x, void* y, long long n, vl_stream_t stream);
 /* uint8 image -> normalised bf16 pixel_values [n_img, 3, H, W] (ABI 4).  Replaces the host-side fp32 normalisation of

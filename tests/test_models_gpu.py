@@ -476,3 +476,33 @@ def test_euler_kernel_options_are_bit_identical(golden_model, golden_dir):
     ref = outs[('none', False)]
     for k, v in outs.items():
         assert torch.equal(v[0], ref[0]) and torch.equal(v[1], ref[1]), k
+
+
+@pytest.mark.parametrize('ride', [True, False])
+def test_euler_glue1_one_launch_between_layer_passes(golden_model, golden_dir, ride):
+    """'glue1' (vlaser_vla_step: tail of Euler step s-1 + action encoder of step s in ONE launch, linear_1 / time embedding folded into linear_2 on
+    the host): the chunk and every step's velocity stay within bf16 noise of the 4-launch path (the fold drops one bf16 rounding of linear_1's
+    output), eager == graph bit for bit, with the proprio token riding in step 0 and without, and against the reference's own chunk (G7)."""
+    from vlaser_amd.pizero import PiZeroInference
+    _, vla, sd = golden_model
+    d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))
+    ids = torch.from_numpy(d['a_input_ids'])
+    pv = torch.randn(1, 3, 448, 448, generator=torch.Generator().manual_seed(int(d['a_seed'])))
+    pro, noise = torch.from_numpy(d['a_proprio']), torch.from_numpy(d['a_noise'])
+    outs = {}
+    for opts in ('qkv16', 'qkv16,glue1'):
+        for graph in (False, True):
+            m = PiZeroInference(vla, max_batch=1, use_graph=graph, euler_opts=opts, ride_proprio=ride); m.load_state_dict(sd)
+            for _ in range(3):
+                a = m.infer_action(ids, pv, proprios=pro, noise=noise)
+            outs[(opts, graph)] = (a.float().cpu().clone(), m.last_velocities().float().cpu().clone())
+    assert torch.equal(outs[('qkv16,glue1', False)][0], outs[('qkv16,glue1', True)][0])
+    assert torch.equal(outs[('qkv16,glue1', False)][1], outs[('qkv16,glue1', True)][1])
+    a0, v0 = outs[('qkv16', True)]
+    a1, v1 = outs[('qkv16,glue1', True)]
+    assert (a1 - a0).abs().max().item() <= 4e-3 * max(1.0, a0.abs().max().item()), (a1 - a0).abs().max().item()
+    assert (v1 - v0).abs().max().item() <= 2e-2 * max(1.0, v0.abs().max().item()), (v1 - v0).abs().max().item()
+    ref = torch.from_numpy(d['a_action']).float() if 'a_action' in d.files else None
+    if ref is not None:
+        assert (a1.view_as(ref) - ref).abs().max().item() <= (a0.view_as(ref) - ref).abs().max().item() + 4e-3
+

@@ -467,6 +467,193 @@ extern "C" int vlaser_vla_euler(const void* h_in, const float* partials, int n_p
   return 0;
 }
 
+// vla_step (r03): everything BETWEEN two passes through the expert's layers in ONE launch -- the tail of Euler step s-1 (vla_euler above: last split-K
+// reduce + final norm + action decoder + x += dt v) and the action encoder of step s (pizero_internvl.py:863-900: linear_1, sinusoidal time embedding,
+// cat, linear_2, swish, linear_3), which were 4 launches of ~5 us each for a few KB of arithmetic.  The two Linear layers before the swish have no
+// nonlinearity between them and the time embedding does not depend on the action, so the host folds them once per checkpoint:
+//     pre[m, n] = sum_k W21[n, k] a[m, k] + C[s, n],   W21 = W2[:, Wd:] W1  (Wd x adim),   C[s] = W2[:, :Wd] temb(t_s) + W2[:, Wd:] b1 + b2
+// (fp32; the reference rounds linear_1's output to bf16 before linear_2 -- a 2^-9 relative perturbation of each of the Wd addends, far below the
+// bf16 rounding of `pre` itself).  Every workgroup recomputes the tail and e2 = swish(pre) for all rows (a few thousand MACs) and owns Wd / gridDim.x
+// output columns of linear_3, whose weights it requests first.  Actions ping-pong between two buffers (all workgroups read, workgroup 0 writes).
+template <int ADIM, int KJ>       // KJ = Wd / 256: 4-column chunks per lane of a row (columns lane*4 + 256 j)
+__global__ __launch_bounds__(256) void vla_step_kernel(const bf16_t* __restrict__ h_in, const float* __restrict__ partials, int n_partials, int rows_in, int row_off,
+                                                       const bf16_t* __restrict__ norm_w, float eps, const bf16_t* __restrict__ wd, const bf16_t* __restrict__ bd,
+                                                       const float* __restrict__ a_in, float* __restrict__ a_out, float* __restrict__ vel_out, float dt, int finish,
+                                                       const float* __restrict__ w21, const float* __restrict__ cs, const bf16_t* __restrict__ w3,
+                                                       const bf16_t* __restrict__ b3, bf16_t* __restrict__ h_out, int M, int Wd, int adim) {
+  constexpr int MAXM = 16, MAXW = 1024;
+  __shared__ float a_s[MAXM * ADIM];
+  __shared__ __attribute__((aligned(16))) bf16_t e2_s[MAXM * MAXW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 16;                                                // this workgroup's 16 linear_3 outputs; wave w owns columns n0 + w + 4 i
+  // ---- linear_3 weights of this wave's first column: requested before anything else (the only HBM-cold data of the launch)
+  constexpr int CPW = 4;                                                         // linear_3 columns per wave (16 per workgroup): all requested up front
+  u32x2 w3v[CPW][KJ];
+  float b3v[CPW];
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const int n = min(n0 + wave + 4 * i, Wd - 1);
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) w3v[i][j] = *reinterpret_cast<const u32x2*>(w3 + (size_t)n * Wd + lane * 4 + 256 * j);
+    b3v[i] = bf16_to_f32(b3[n]);
+  }
+  // the folded encoder constants of this thread's KJ columns (n = tid + 256 j): also up front
+  float w21v[KJ][ADIM], csv[KJ];
+#pragma unroll
+  for (int j = 0; j < KJ; ++j) {
+    csv[j] = cs[tid + 256 * j];
+#pragma unroll
+    for (int k = 0; k < ADIM; ++k) w21v[j][k] = w21[(tid + 256 * j) * adim + min(k, adim - 1)];
+  }
+  // ---- tail of the previous Euler step: wave w finishes rows w, w + 4, ... (wave-level reductions only)
+  if (finish) {
+    for (int m = wave; m < M; m += 4) {
+      const size_t off = (size_t)(m + row_off) * Wd, slab = (size_t)rows_in * Wd;
+      // every load of the row is issued up front in straight-line code (clamped slab index, select on use): a runtime slab loop is one round trip per slab
+      u32x2 hv[KJ];
+      f32x4 q[KJ][8];
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) hv[j] = *reinterpret_cast<const u32x2*>(h_in + off + lane * 4 + 256 * j);
+      if (n_partials > 0) {
+#pragma unroll
+        for (int j = 0; j < KJ; ++j)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) q[j][u] = *reinterpret_cast<const f32x4*>(partials + (size_t)min(u, n_partials - 1) * slab + off + lane * 4 + 256 * j);
+      }
+      float v[KJ][4];
+      float ssq = 0.f;
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) {
+        f32x4 sl = {0, 0, 0, 0};
+        if (n_partials > 0) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const bool use = u < n_partials;
+            sl[0] += use ? q[j][u][0] : 0.f; sl[1] += use ? q[j][u][1] : 0.f; sl[2] += use ? q[j][u][2] : 0.f; sl[3] += use ? q[j][u][3] : 0.f;
+          }
+        }
+        const float hv4[4] = {bf16lo_to_f32(hv[j][0]), bf16hi_to_f32(hv[j][0]), bf16lo_to_f32(hv[j][1]), bf16hi_to_f32(hv[j][1])};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[j][e] = round_bf16(hv4[e] + sl[e]);
+          ssq += v[j][e] * v[j][e];
+        }
+      }
+      ssq = wave_sum(ssq);
+      const float rs = rsqrtf(ssq / (float)Wd + eps);
+      float acc[ADIM];
+#pragma unroll
+      for (int k = 0; k < ADIM; ++k) acc[k] = 0.f;
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) {
+        const int c = lane * 4 + 256 * j;
+        const u32x2 nw = *reinterpret_cast<const u32x2*>(norm_w + c);
+        const float nw4[4] = {bf16lo_to_f32(nw[0]), bf16hi_to_f32(nw[0]), bf16lo_to_f32(nw[1]), bf16hi_to_f32(nw[1])};
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = round_bf16(round_bf16(v[j][e] * rs) * nw4[e]);
+#pragma unroll
+        for (int k = 0; k < ADIM; ++k) {
+          const u32x2 wv = *reinterpret_cast<const u32x2*>(wd + (size_t)min(k, adim - 1) * Wd + c);
+          acc[k] += y[0] * bf16lo_to_f32(wv[0]) + y[1] * bf16hi_to_f32(wv[0]) + y[2] * bf16lo_to_f32(wv[1]) + y[3] * bf16hi_to_f32(wv[1]);
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < ADIM; ++k) acc[k] += __shfl_xor(acc[k], o, 64);
+      if (lane < adim) {
+        float vel = 0.f;
+#pragma unroll
+        for (int k = 0; k < ADIM; ++k) vel = lane == k ? acc[k] : vel;
+        vel = round_bf16(vel + bf16_to_f32(bd[lane]));
+        const float av = a_in[m * adim + lane] + dt * vel;
+        a_s[m * ADIM + lane] = av;
+        if (blockIdx.x == 0) {
+          a_out[m * adim + lane] = av;
+          if (vel_out) vel_out[m * adim + lane] = vel;
+        }
+      }
+    }
+  } else {
+    for (int i = tid; i < M * adim; i += 256) {
+      const float av = a_in[i];
+      a_s[(i / adim) * ADIM + i % adim] = av;
+      if (blockIdx.x == 0 && a_out != a_in) a_out[i] = av;
+    }
+  }
+  __syncthreads();
+  // ---- e2 = swish(bf16(W21 bf16(a) + C[s]))  for all rows (the encoder reads the action through a bf16 cast, as nn.Linear on a bf16 module does)
+  for (int m = 0; m < M; ++m) {
+    float av[ADIM];
+#pragma unroll
+    for (int k = 0; k < ADIM; ++k) av[k] = k < adim ? round_bf16(a_s[m * ADIM + k]) : 0.f;
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+      float pre = csv[j];
+#pragma unroll
+      for (int k = 0; k < ADIM; ++k) pre += w21v[j][k] * av[k];
+      e2_s[m * Wd + tid + 256 * j] = f32_to_bf16(silu(round_bf16(pre)));
+    }
+  }
+  __syncthreads();
+  // ---- linear_3: columns n0 + wave + 4 i of this workgroup; lane owns k = lane*4 + 256 j.  Four rows at a time, all 16 (row, column) dot products
+  // reduced TOGETHER: a wave reduction is 6 dependent cross-lane steps of ~100 cycles, and 16 of them one after the other were 4 us of this launch
+  for (int mb = 0; mb < M; mb += 4) {
+    float acc[4][CPW];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = min(mb + r, M - 1);
+      u32x2 ev[KJ];
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) ev[j] = *reinterpret_cast<const u32x2*>(e2_s + m * Wd + lane * 4 + 256 * j);
+#pragma unroll
+      for (int i = 0; i < CPW; ++i) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < KJ; ++j)
+          a += bf16lo_to_f32(ev[j][0]) * bf16lo_to_f32(w3v[i][j][0]) + bf16hi_to_f32(ev[j][0]) * bf16hi_to_f32(w3v[i][j][0]) +
+               bf16lo_to_f32(ev[j][1]) * bf16lo_to_f32(w3v[i][j][1]) + bf16hi_to_f32(ev[j][1]) * bf16hi_to_f32(w3v[i][j][1]);
+        acc[r][i] = a;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) acc[r][i] += __shfl_xor(acc[r][i], o, 64);
+    if (lane < 4 * CPW) {
+      const int r = lane >> 2, i = lane & 3;
+      float v = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int ii = 0; ii < CPW; ++ii) v = (r == rr && i == ii) ? acc[rr][ii] + b3v[ii] : v;
+      if (mb + r < M) h_out[(size_t)(mb + r) * Wd + n0 + wave + 4 * i] = f32_to_bf16(v);
+    }
+  }
+}
+extern "C" int vlaser_vla_step(const void* h_in, const float* partials, int n_partials, int rows_in, int row_off, const void* norm_w, float eps, const void* wd,
+                               const void* bd, const float* a_in, float* a_out, float* vel_out, float dt, int finish, const float* w21, const float* cs,
+                               const void* w3, const void* b3, void* h_out, int M, int Wd, int adim, vl_stream_t s) {
+  VL_CHECK(a_in && a_out && w21 && cs && w3 && b3 && h_out && M >= 1 && M <= 16, "vlaser_vla_step: bad args (1..16 rows)");
+  VL_CHECK(Wd % 256 == 0 && Wd <= 1024 && adim >= 1 && adim <= 16, "vlaser_vla_step: Wd must be a multiple of 256 and <= 1024, action_dim <= 16 (wider experts keep the separate launches)");
+  VL_CHECK(!finish || (h_in && norm_w && wd && bd && n_partials >= 0 && n_partials <= 8 && (n_partials == 0 || partials) && rows_in >= M + row_off && row_off >= 0 && a_in != a_out),
+           "vlaser_vla_step: finish needs h_in / norm / decoder, <= 8 slabs of rows_in >= M + row_off rows, and distinct action buffers");
+  const int blocks = Wd / 16;                    // 16 linear_3 outputs per workgroup (48 workgroups at Wd = 768)
+#define VL_STEP(AD_, KJ_)                                                                                                                          \
+  hipLaunchKernelGGL((vla_step_kernel<AD_, KJ_>), dim3(blocks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)h_in, partials, n_partials, rows_in, row_off, \
+                     (const bf16_t*)norm_w, eps, (const bf16_t*)wd, (const bf16_t*)bd, a_in, a_out, vel_out, dt, finish, w21, cs, (const bf16_t*)w3,   \
+                     (const bf16_t*)b3, (bf16_t*)h_out, M, Wd, adim)
+#define VL_STEP_KJ(AD_) { switch (Wd / 256) { case 1: VL_STEP(AD_, 1); break; case 2: VL_STEP(AD_, 2); break; case 3: VL_STEP(AD_, 3); break; default: VL_STEP(AD_, 4); } }
+  if (adim <= 8) VL_STEP_KJ(8) else VL_STEP_KJ(16)
+#undef VL_STEP_KJ
+#undef VL_STEP
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
 // residual fix-up after the last layer of a prefill-with-skinny row: h = bf16(h_in + sum partials)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const bf16_t* __restrict__ h_in, const float* __restrict__ partials,
                                                               int n_partials, int M, int K, bf16_t* __restrict__ out) {

@@ -1,6 +1,7 @@
 """Thin torch-tensor wrappers over the C ABI (include/vlaser_hip.h).  PyTorch is plumbing here: it owns device
 memory and the stream; every op below is a launch of a hand-written gfx950 kernel in libvlaser_hip.so."""
 import ctypes as C
+import math
 import os
 
 
@@ -410,6 +411,33 @@ def vla_euler(h_in, partials, n_partials, M, norm_w, eps, wd, bd, action, W, adi
     L.check(L.lib().vlaser_vla_euler(h_in.data_ptr(), _p(partials), n_partials, M, norm_w.data_ptr(), eps, wd.data_ptr(),
                                      bd.data_ptr(), action.data_ptr(), W, adim, dt, clip, int(do_clip), _p(vel_out), _stream()),
             'vlaser_vla_euler')
+
+
+def vla_step(a_in, a_out, w21, cs, w3, b3, h_out, M, W, adim, finish=None, vel_out=None, dt=0.0):
+    """One launch between two passes through the expert: `finish` = (h_in, partials, n_partials, rows_in, row_off, norm_w, eps, wd, bd) completes the
+    previous Euler step (a_out = a_in + dt * vel), then the action encoder (folded linear_1 / time embedding: w21, cs) writes h_out."""
+    if finish is None:
+        f = (None, None, 0, M, 0, None, 0.0, None, None)
+    else:
+        f = finish
+    L.check(L.lib().vlaser_vla_step(_p(f[0]), _p(f[1]), f[2], f[3], f[4], _p(f[5]), f[6], _p(f[7]), _p(f[8]), a_in.data_ptr(), a_out.data_ptr(), _p(vel_out), dt,
+                                    0 if finish is None else 1, w21.data_ptr(), cs.data_ptr(), w3.data_ptr(), b3.data_ptr(), h_out.data_ptr(), M, W, adim, _stream()),
+            'vlaser_vla_step')
+
+
+def fold_action_encoder(w1, b1, w2, b2, W, adim, n_steps, max_period):
+    """Host-side constants of vlaser_vla_step (fp32): W21 = W2[:, W:] @ W1 and, per Euler step s (t = s / n_steps), C[s] = W2[:, :W] @ temb(t) + W2[:, W:] @ b1 + b2,
+    temb = SinusoidalPosEmb (modules.py:9-22) rounded to bf16 as the reference's bf16 module sees it."""
+    w1f, b1f, w2f, b2f = w1.float(), b1.float(), w2.float(), b2.float()
+    w21 = (w2f[:, W:] @ w1f).contiguous()
+    half = W // 2
+    e = math.log(max_period) / (half - 1)
+    freq = torch.exp(-e * torch.arange(half, dtype=torch.float32, device=w1.device))
+    t = torch.arange(n_steps, dtype=torch.float32, device=w1.device)[:, None] / n_steps
+    ang = t * freq[None]
+    temb = torch.cat([ang.sin(), ang.cos()], -1).to(torch.bfloat16).float()
+    cs = (temb @ w2f[:, :W].t() + (w2f[:, W:] @ b1f + b2f)[None]).contiguous()
+    return w21, cs
 
 
 def reduce_partials(h_in, partials, n_partials, M, K, out):

@@ -113,8 +113,11 @@ class PiZero:
     #   qkv16: 16-row lane-local units for the q/k/v weight-streaming GEMV (128 instead of 64 workgroups): -0.88 us per layer-step in-chain
     #   gu16: the same for gate/up (1120 units): +0.6 us in-chain (five serial unit-reduce rounds per workgroup) -- off
     #   fuse_ogu (needs gu16): o_proj -> gate/up as one launch with an in-launch hand-off (csrc/euler.hip): +2.0 us in-chain -- off
+    #   glue1: ONE launch between two passes through the layers (vlaser_vla_step: tail of Euler step s-1 + action encoder of step s) instead of four:
+    #          10.9 vs 16.3 us in isolation, -0.085 ms per chunk in-chain (tools/micro/vla_step_lab.py, ab_chunk.py) -- ON.  Not bit-identical to the
+    #          4-launch path (linear_1 / time embedding folded into linear_2 in fp32): same tolerance against oracle and goldens
     # measurements + in-kernel timelines: profiles/r03c_euler_fusion.md
-    EULER_DEFAULT = 'qkv16'
+    EULER_DEFAULT = 'qkv16,glue1'
 
     def __init__(self, cfg: VLAConfig, device='cuda', max_batch=1, use_graph=True, ride_proprio=True, naive_support=False, euler_opts=None):
         L.lib()
@@ -164,6 +167,10 @@ class PiZero:
         self.ae_w1, self.ae_b1 = g('action_encoder.linear_1.weight'), g('action_encoder.linear_1.bias')
         self.ae_w2, self.ae_b2 = ops.pack_skinny(g('action_encoder.linear_2.weight')), g('action_encoder.linear_2.bias')
         self.ae_w3, self.ae_b3 = ops.pack_skinny(g('action_encoder.linear_3.weight')), g('action_encoder.linear_3.bias')
+        # 'glue1' (vlaser_vla_step): linear_1 and the time embedding folded into linear_2 (fp32 constants per Euler step), linear_3 as stored
+        self.ae_w3_raw = g('action_encoder.linear_3.weight')
+        self.ae_w21, self.ae_cs = ops.fold_action_encoder(self.ae_w1, self.ae_b1, g('action_encoder.linear_2.weight'), self.ae_b2, cfg.action_hidden_size,
+                                                          cfg.action_dim, self.num_inference_steps, cfg.time_max_period)
         self.pe_w, self.pe_b = g('proprio_encoder.weight'), g('proprio_encoder.bias')
         self.ad_w, self.ad_b = g('action_decoder.weight'), g('action_decoder.bias')
         self._alloc()
@@ -194,6 +201,7 @@ class PiZero:
         self.vel5 = z(16, cfg.action_dim, dt=torch.float32)
         self.vel_trace = z(cfg.num_inference_steps, 16, cfg.action_dim, dt=torch.float32)   # decoder output of every Euler step
         self.action = z(16, cfg.action_dim, dt=torch.float32)
+        self.action_b = z(16, cfg.action_dim, dt=torch.float32)        # 'glue1': the actions ping-pong between two buffers (all workgroups read, one writes)
         self.rank_ws = z(B * T, dt=torch.int32)
         self.valid_len = z(B, dt=torch.int32)
         # static inputs of the captured graph
@@ -292,6 +300,8 @@ class PiZero:
         dt = 1.0 / n
         W = cfg.action_hidden_size
         clip = self.final_action_clip_value
+        if 'glue1' in self.euler_opts and n >= 2 and W % 256 == 0 and W <= 1024:
+            return self._run_euler_glue1(B, skip)
         if ride:
             self.action5[1:1 + M].copy_(self.in_noise[:M])
         else:
@@ -324,6 +334,54 @@ class PiZero:
                                                blk_start=T, skip=skip, sync=sync(s, i))
             ops.vla_euler(h, parts, npart, M, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action, W, cfg.action_dim, dt,
                           clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel_trace[s])
+
+    def _run_euler_glue1(self, B, skip=()):
+        """The same integration with ONE launch between two passes through the expert's layers (`vlaser_vla_step`: tail of step s-1 + action
+        encoder of step s) instead of four (vla_euler, vla_prep, linear_2 + swish, linear_3): 30 launches of ~5 us less per chunk.  linear_1 and the
+        time embedding are folded into linear_2 at load time, so the encoder output differs from the 4-launch path in the last bf16 bit of a few
+        elements (no longer bit-identical to `VLASER_EULER=qkv16`; same tolerance against the oracle and the reference goldens)."""
+        cfg = self.cfg
+        llm, ex = cfg.base.llm, cfg.expert
+        T, na = self.max_image_text_tokens, self.num_action_tokens
+        nL = llm.num_hidden_layers
+        ride = self.ride_proprio and B == 1
+        M, n, W, ad = B * na, self.num_inference_steps, cfg.action_hidden_size, cfg.action_dim
+        dt = 1.0 / n
+        clip = self.final_action_clip_value
+        acts = [self.action, self.action_b]
+        p = (n - 1) % 2                           # n - 1 ping-pongs later the actions sit in self.action, where the last step finishes in place
+        acts[p][:M].copy_(self.in_noise[:M])
+        fused = any(o.startswith('fuse_') for o in self.euler_opts)
+        if fused:
+            self.euler_sync.zero_()
+        sync = lambda s_, i_: self.euler_sync[s_ * nL + i_] if fused else None
+        fin = None
+        for s in range(n):
+            first = ride and s == 0
+            h_enc = self.h5[1:1 + M] if first else self.h_act
+            if fin is None:
+                ops.vla_step(acts[p], acts[p], self.ae_w21, self.ae_cs[s], self.ae_w3_raw, self.ae_b3, h_enc, M, W, ad)
+            else:
+                ops.vla_step(acts[p], acts[1 - p], self.ae_w21, self.ae_cs[s], self.ae_w3_raw, self.ae_b3, h_enc, M, W, ad, finish=fin,
+                             vel_out=self.vel_trace[s - 1], dt=dt)
+                p = 1 - p
+            if first:
+                h, parts, npart = self.h5, None, 0
+                for i in range(nL):
+                    h, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_pro, h, parts, npart, self.cache, i, self.rope,
+                                                   self.pos5, B, na + 1, T, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len, blk_start=T,
+                                                   first_tok_kv_len=T + 1, skip=skip, sync=sync(s, i))
+                fin = (h, parts, npart, M + 1, 1, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b)       # row 0 = the proprio row: skipped
+            else:
+                h, parts, npart = self.h_act, None, 0
+                for i in range(nL):
+                    h, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_act, h, parts, npart, self.cache, i, self.rope,
+                                                   self.pos_act, B, na, T + 1, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len,
+                                                   blk_start=T, skip=skip, sync=sync(s, i))
+                fin = (h, parts, npart, M, 0, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b)
+        assert acts[p] is self.action
+        ops.vla_euler(fin[0], fin[1], fin[2], M, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action, W, ad, dt,
+                      clip if clip is not None else 0.0, clip is not None, vel_out=self.vel_trace[n - 1])
 
     @torch.no_grad()
     def infer_action(self, input_ids, pixel_values, image_text_proprio_mask=None, action_mask=None, vlm_position_ids=None,
