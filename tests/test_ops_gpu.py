@@ -741,3 +741,55 @@ def test_fused_ogu_equals_the_two_launches_bit_for_bit(ops, M):
         assert torch.equal(h_a, h_b), it
         assert torch.equal(act_a, act_b), (it, int((act_a != act_b).sum()))
     assert act_a.float().abs().max() > 0
+
+
+@pytest.mark.parametrize('M,W,ad,npart,row_off', [(4, 768, 7, 7, 0), (4, 768, 7, 7, 1), (1, 256, 7, 0, 0), (5, 512, 14, 3, 0), (16, 1024, 7, 8, 0), (9, 768, 16, 5, 2)])
+def test_vla_step_one_launch_between_layer_passes(ops, M, W, ad, npart, row_off):
+    """vlaser_vla_step against the same arithmetic in torch fp32 with the kernel's rounding points: tail of an Euler step (split-K reduce + residual ->
+    RMSNorm -> action decoder -> a += dt v) on rows row_off.. of the layer output, then the action encoder with linear_1 / the time embedding folded
+    into linear_2 (ops.fold_action_encoder), swish, linear_3.  Every row-count / width / action-dim branch of the kernel templates; and the folded
+    encoder against the un-folded reference order (modules.py:25-56) within bf16 noise."""
+    torch.manual_seed(M * W + ad)
+    dev = 'cuda'
+    n_steps, mp, dt, eps = 10, 10000.0, 0.1, 1e-6
+    w1, b1, w2, b2, w3, b3 = rnd(W, ad, std=0.3), rnd(W, std=0.1), rnd(W, 2 * W), rnd(W, std=0.1), rnd(W, W), rnd(W, std=0.1)
+    wd, bd = rnd(ad, W, std=0.05), rnd(ad, std=0.1)
+    nw = (1.0 + 0.1 * torch.randn(W, device=dev)).to(BF)
+    rows_in = M + row_off
+    h = rnd(rows_in, W, std=1.0)
+    parts = (torch.randn(max(npart, 1), rows_in, W, device=dev) * 0.2).contiguous()
+    a_in = torch.randn(16, ad, device=dev)
+    a_out = torch.full((16, ad), 9.0, device=dev); vel = torch.full((16, ad), 9.0, device=dev)
+    h_out = torch.zeros(16, W, dtype=BF, device=dev)
+    w21, cs = ops.fold_action_encoder(w1, b1, w2, b2, W, ad, n_steps, mp)
+    s_idx = 3
+    ops.vla_step(a_in, a_out, w21, cs[s_idx], w3, b3, h_out, M, W, ad, finish=(h, parts if npart else None, npart, rows_in, row_off, nw, eps, wd, bd), vel_out=vel, dt=dt)
+    torch.cuda.synchronize()
+    r = lambda x: x.to(BF).float()
+    hs = r(h.float()[row_off:] + (parts[:npart, row_off:].sum(0) if npart else 0.0))
+    y = r(r(hs * torch.rsqrt((hs * hs).mean(-1, keepdim=True) + eps)) * nw.float())
+    v_ref = r(y @ wd.float().t() + bd.float())
+    a_ref = a_in[:M] + dt * v_ref
+    assert (vel[:M] - v_ref).abs().max().item() <= 2e-2 * max(1.0, v_ref.abs().max().item())
+    assert (a_out[:M] - a_ref).abs().max().item() <= 2e-3 * max(1.0, a_ref.abs().max().item())
+    assert (a_out[M:] == 9.0).all() and (vel[M:] == 9.0).all()
+    # encoder on the kernel's own a_out (so the two halves are checked separately)
+    a_b = r(a_out[:M])
+    e2 = r(torch.nn.functional.silu(r(a_b @ w21.t() + cs[s_idx][None])))
+    h_ref = r(e2 @ w3.float().t() + b3.float())
+    close(h_out[:M], h_ref, name='linear_3 of the folded encoder')
+    assert (h_out[M:] == 0).all()
+    # un-folded reference order with its bf16 rounding of linear_1's output and of the time embedding
+    half = W // 2
+    freq = torch.exp(-math.log(mp) / (half - 1) * torch.arange(half, device=dev, dtype=torch.float32))
+    ang = (s_idx / n_steps) * freq
+    temb = r(torch.cat([ang.sin(), ang.cos()]))
+    e1 = r(a_b @ w1.float().t() + b1.float())
+    pre = r(torch.cat([temb[None].expand(M, -1), e1], -1) @ w2.float().t() + b2.float())
+    h_unf = r(r(torch.nn.functional.silu(pre)) @ w3.float().t() + b3.float())
+    close(h_out[:M], h_unf, rtol=3e-2, name='folded vs un-folded encoder')
+    # encoder only (first Euler step): a_out may alias a_in
+    h2 = torch.zeros(16, W, dtype=BF, device=dev)
+    ops.vla_step(a_out, a_out, w21, cs[s_idx], w3, b3, h2, M, W, ad)
+    assert torch.equal(h2[:M], h_out[:M])
+
