@@ -177,3 +177,25 @@ def test_split_batch_length_from_labels_and_mask():
     am = torch.tensor([[1, 1, 1, 1], [1, 1, 1, 0]])               # the collator's mask wins when given
     out = m._split_batch(pv, ids, lab, flags, am)
     assert [o[1].shape[1] for o in out] == [4, 3]
+
+
+def test_fold_action_encoder_equals_the_unfolded_module():
+    """ops.fold_action_encoder (host constants of vlaser_vla_step): W21 a + C[s] must be linear_2([temb(t_s) || linear_1(a)]) of the oracle's
+    ActionEncoder (modules.py:25-56) for every Euler step, up to the bf16 rounding of the time embedding the fold applies (fp32 module here)."""
+    from oracle import vla as ovla
+    from vlaser_amd import ops
+    torch.manual_seed(3)
+    W, ad, n, mp = 256, 7, 10, 10000.0
+    sd = {'action_encoder.linear_1.weight': torch.randn(W, ad) * 0.3, 'action_encoder.linear_1.bias': torch.randn(W) * 0.1,
+          'action_encoder.linear_2.weight': torch.randn(W, 2 * W) * 0.05, 'action_encoder.linear_2.bias': torch.randn(W) * 0.1,
+          'action_encoder.linear_3.weight': torch.randn(W, W) * 0.05, 'action_encoder.linear_3.bias': torch.randn(W) * 0.1}
+    w21, cs = ops.fold_action_encoder(sd['action_encoder.linear_1.weight'], sd['action_encoder.linear_1.bias'], sd['action_encoder.linear_2.weight'],
+                                      sd['action_encoder.linear_2.bias'], W, ad, n, mp)
+    assert w21.shape == (W, ad) and cs.shape == (n, W)
+    a = torch.randn(1, 4, ad)
+    for s in (0, 3, 9):
+        temb = ovla.sinusoidal_pos_emb(torch.full((1,), s / n), W, mp)
+        ref = ovla.action_encoder(sd, a, temb)
+        pre = a[0] @ w21.t() + cs[s][None]
+        got = torch.nn.functional.linear(torch.nn.functional.silu(pre), sd['action_encoder.linear_3.weight'], sd['action_encoder.linear_3.bias'])
+        assert (got - ref[0]).abs().max().item() < 5e-3 * max(1.0, ref.abs().max().item()), s      # the only difference: temb rounded to bf16 inside the fold
