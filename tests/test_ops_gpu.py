@@ -284,6 +284,49 @@ def test_attn_skinny_partials_and_merge(ops, nq_tok, kv_len, mode, nsp):
     close(part.sum(0), ref.reshape(Mrows, -1).to(BF).float() @ wo.float().t(), rtol=2e-2, name='o_proj over merged attention')
 
 
+@pytest.mark.parametrize('nq_tok,kv_len,mode,first,nq,nkv', [(4, 389, 'prefix', 0, 12, 2), (5, 389, 'prefix', 385, 12, 2), (1, 70, 'full', 0, 12, 2), (4, 1200, 'prefix', 0, 12, 2),
+                                                             (2, 33, 'full', 0, 28, 4), (16, 300, 'full', 0, 4, 2)])
+def test_attn_oproj_one_launch(ops, nq_tok, kv_len, mode, first, nq, nkv):
+    """vlaser_attn_oproj (attention + o_proj of a <= 16-row layer-step in ONE launch, every workgroup recomputing its kv group's attention with the key
+    split inside the workgroup): the per-kv-head slabs sum to o_proj(attention) of an fp32 reference, for the expert's geometry (4 action rows; the
+    proprio row riding with its own key limit), a single decode row, more chunks than waves, GQA group 7 (Vlaser-8B) and 16 tokens."""
+    from vlaser_amd import _lib as L
+    smax, H = 1536, 768
+    G = nq // nkv
+    q = rnd(nq_tok, nq * 128, seed=1)
+    k = rnd(1, nkv, smax, 128, seed=2); v = rnd(1, nkv, smax, 128, seed=3)
+    vt = v.transpose(-1, -2).contiguous()
+    sc = 128 ** -0.5
+    valid = torch.tensor([277], dtype=torch.int32, device='cuda')
+    blk = 384
+    kw = dict(valid_len=valid, blk_start=blk) if mode == 'prefix' else {}
+    parts = ops.attn_partial_buffers(1, nkv, 'cuda')
+    a = ops.attn_skinny_args(q, k, vt, parts, 1, nq_tok, kv_len, nq, nkv, 128, (nq_tok * nq * 128, 128, nq * 128), (nkv * smax * 128, smax * 128),
+                             (nkv * 128 * smax, 128 * smax), smax, sc, L.ATTN_PREFIX if mode == 'prefix' else L.ATTN_FULL, 1, first_tok_kv_len=first, **kw)
+    wo = rnd(H, nq * 128, std=0.03, seed=9)
+    out = torch.full((nkv, nq_tok, H), 5.0, dtype=torch.float32, device='cuda')
+    ops.launch_attn_oproj(a, wo, out, H)
+    torch.cuda.synchronize()
+    j = torch.arange(kv_len, device='cuda')[None, None]
+    if mode == 'prefix':
+        vis = ((j < 277) | (j >= blk)).expand(1, nq_tok, kv_len).clone()
+        if first:
+            vis[0, 0] = (j[0, 0] < 277) | ((j[0, 0] >= blk) & (j[0, 0] < first))      # the riding proprio row sees the block only up to itself
+    else:
+        vis = torch.ones(1, nq_tok, kv_len, dtype=torch.bool, device='cuda')
+    qq = q.view(1, nq_tok, nq, 128).permute(0, 2, 1, 3)
+    att = _attn_ref(qq, k[:, :, :kv_len], v[:, :, :kv_len], sc, vis)[0]          # [tok, nq*128]
+    ref = att.to(BF).float() @ wo.float().t()
+    close(out.sum(0), ref, rtol=2e-2, name='sum of the kv-head slabs')
+    # each slab is its own group's contribution
+    for kvh in range(nkv):
+        sl = slice(kvh * G * 128, (kvh + 1) * G * 128)
+        close(out[kvh], att[:, sl].to(BF).float() @ wo[:, sl].float().t(), rtol=2e-2, name=f'slab {kvh}')
+    out2 = torch.zeros_like(out)
+    ops.launch_attn_oproj(a, wo, out2, H)
+    assert torch.equal(out, out2)
+
+
 def _rms_ref(h, w, eps=1e-6):
     hf = h.float()
     return (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + eps)).to(BF).float() * w.float()

@@ -49,6 +49,7 @@ class QwenLayerWeights:
             else:
                 self.sk_qkv = ops.pack_skinny(wqkv, 1)
             self.sk_o = ops.pack_skinny(wo, ks_o, tpu_o)
+            self.wo_raw = wo.contiguous() if 'fuse_ao' in opts else None      # attention + o_proj in one launch reads W_o as stored
             # wide output + short K (action expert: 17920 x 768): 96-row units (tpu = 6) measured slower on MI355X (12.3 vs 11.2 us): kept in
             # the kernel, not used; 16-row lane-local units ('gu16', r03) balance 1120 units over 256 workgroups (80 vs 96 rows on the longest)
             if 'gu16' in opts:
@@ -291,9 +292,14 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
     nsp = ops.attn_splits(kv_len)
     fuse = (sync is not None and 'fuse_ogu' in stack.opts and 'gu16' in stack.opts and not skip_post_attn and stack.tpu_o == 1 and stack.ks_o == 3
             and llm.hidden_size == 768 and nq * hd == 1536 and nsp == 7 and M * (llm.hidden_size // 8) <= 512)
+    # 'fuse_ao' (r03): attention + o_proj as ONE launch without any hand-off (csrc/attn_o.hip: every workgroup recomputes its kv group's attention);
+    # batch 1, <= 32 (head, token) rows per kv head; the consumer then sums n_kv_heads slabs instead of ks_o
+    G_ = nq // nkv
+    fuse_ao = ('fuse_ao' in stack.opts and not fuse and not skip_post_attn and batch == 1 and G_ * tok_per_batch <= 32 and G_ <= 8 and hd == 128
+               and lw.wo_raw is not None and llm.hidden_size % 16 == 0 and nkv <= stack.ks_o and attn_mode in (L.ATTN_FULL, L.ATTN_PREFIX))
     key = (layer, M, tok_per_batch, attn_mode, h_in.data_ptr(), 0 if partials is None else partials.data_ptr(), n_partials,
            0 if valid_len is None else valid_len.data_ptr(), pos_ids.data_ptr(), cache.k.data_ptr(), skip_post_attn, first_tok_kv_len,
-           sync.data_ptr() if fuse else 0)
+           sync.data_ptr() if fuse else 0, fuse_ao)
     plan = sb.plans.get(key)
     if plan is None:
         ks, vs = cache.strides()
@@ -308,8 +314,8 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
         if not skip_post_attn:
             plan.o = ops.skinny_args(None, lw.sk_o, M, out_f32=sb.part_o, attn_m=sb.attn_parts[0], attn_l=sb.attn_parts[1],
                                      attn_o=sb.attn_parts[2], attn_splits=1, attn_group=nq // nkv, attn_nq=tok_per_batch)
-            plan.gu = ops.skinny_args(sb.hA, lw.sk_gu, M, partials=sb.part_o, n_partials=stack.ks_o, norm_w=lw.ln_post, eps=llm.rms_norm_eps,
-                                      h_out=sb.hB, out=sb.act, ldo=sb.act.shape[1])
+            plan.gu = ops.skinny_args(sb.hA, lw.sk_gu, M, partials=sb.part_o, n_partials=nkv if fuse_ao else stack.ks_o, norm_w=lw.ln_post,
+                                      eps=llm.rms_norm_eps, h_out=sb.hB, out=sb.act, ldo=sb.act.shape[1])
             plan.down = ops.skinny_args(sb.act, lw.sk_down, M, out_f32=sb.part_d)
             if fuse:
                 plan.ogu = ops.fused_ogu_args(sb.attn_parts, lw.sk_o, sb.part_o, sb.hA, lw.ln_post, llm.rms_norm_eps, sb.hB, lw.sk_gu, M, sb.act, sync,
@@ -323,6 +329,14 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
         ops.launch_skinny(L.PRO_NORM, L.SK_QKV_ROPE, plan.qkv[0], stream)
     a = plan.attn
     a.kv_len, a.n_splits, a.blk_start = kv_len, nsp, blk_start
+    if fuse_ao:
+        if 'attn' not in skip and 'o' not in skip:
+            ops.launch_attn_oproj(a, lw.wo_raw, sb.part_o, llm.hidden_size, stream)
+        if 'gu' not in skip:
+            ops.launch_skinny(L.PRO_NORM, L.SK_SWIGLU, plan.gu[0], stream)
+        if 'down' not in skip:
+            ops.launch_skinny(L.PRO_PLAIN, L.SK_PARTIAL, plan.down[0], stream)
+        return sb.hB, sb.part_d, stack.ks_down
     if 'attn' not in skip:
         ops.launch_attn_skinny(a, stream)
     if skip_post_attn:

@@ -196,6 +196,12 @@ def attn_bwd(q, k, vt, o, d_o, lse, delta_ws, dq, dk, dv, S, n_q, n_kv, s_max, s
                                     dk.data_ptr(), dv.data_ptr(), S, n_q, n_kv, s_max, scale, int(causal), S if kv_valid is None else kv_valid, _stream()), 'vlaser_attn_bwd')
 
 
+def launch_attn_oproj(args, wo, out_f32, N, stream=None):
+    """Attention + o_proj of a <= 16-row layer-step in one launch (csrc/attn_o.hip): `args` = an attn_skinny argument struct (batch 1), `wo` the o_proj
+    weight as stored [N, n_q_heads*128], out_f32 >= n_kv_heads * sq * N fp32 (one partial slab per kv head)."""
+    L.check(L.lib().vlaser_attn_oproj(C.byref(args), wo.data_ptr(), wo.stride(0), out_f32.data_ptr(), N, _stream() if stream is None else stream), 'vlaser_attn_oproj')
+
+
 def attn_splits(kv_len):
     """Key splits of the skinny attention: about 2 chunks (of 32 keys) per block, at most 8 splits (measured: 389 keys,
     1/2/4/7 splits -> 13.5/9.5/7.7/6.3 us per launch)."""
