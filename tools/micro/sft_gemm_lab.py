@@ -35,6 +35,8 @@ wd = [rnd(H, I) for _ in range(8)]
 dh = rnd(S, H, std=1.0)
 dgu_o = torch.zeros(S, 2 * I, dtype=BF, device='cuda')
 row('down dgrad NN SWIGLU_BWD [560x8960x1536]', 2.0 * S * I * H, lambda c: [lambda w=w: ops.gemm_nn(L.EPI_SWIGLU_BWD, dh, w, out=dgu_o, res=gu, force_bm=c) for w in wd])
+dact_o = torch.zeros(S, I, dtype=BF, device='cuda')
+row('down dgrad NN NONE (no epilogue) [560x8960x1536]', 2.0 * S * I * H, lambda c: [lambda w=w: ops.gemm_nn(L.EPI_NONE, dh, w, out=dact_o, force_bm=c) for w in wd])
 a_ = rnd(S, I, std=1.0)
 for sp in (1, 2, 4):
     row(f'down fwd NT PARTIAL x{sp} [560x1536x8960]', 2.0 * S * I * H, lambda c: [lambda w=w: ops.gemm(L.EPI_PARTIAL, a_, w, out_f32=part, k_splits=sp, force_bm=c) for w in wd])
