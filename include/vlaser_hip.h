@@ -213,7 +213,7 @@ int vlaser_attn_bwd(const void* q, const void* k, const void* vt, const void* o,
 int vlaser_gemm_tn(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, vl_stream_t stream);
 /* The same TN product on the LDS-DMA GEMM pipeline (8 waves, 128x128 .. 256x256 tiles, both operands global -> LDS without staging registers,
  * fragments through the transposing LDS read).  Contract: K is a whole number of 64-row tiles; rows K_true..K of At are ZERO and those of Wt finite
- * (the SFT step pads its sequence axis: sft.py `_wgrad`); M, N, ldat, ldwt multiples of 8.  force_cfg: 0 = heuristic, or 1100 / 1105 / 1200 / 1300. */
+ * (the SFT step pads its sequence axis: sft.py `_wgrad`); ldat, ldwt multiples of 8 and >= M / N rounded up to 8 (rows are read in 16-byte pieces).  force_cfg: 0 = heuristic, or 1100 / 1105 / 1200 / 1300. */
 int vlaser_gemm_tn_lds(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, int force_cfg, vl_stream_t stream);
 /* Grouped + batched form: out[b] = sum_{g < groups} At[b, g]^T @ Wt[b, g], run (b, g) starting at At + b*a_bs + g*a_gs (K rows each);
  * grouped-query attention backward: dK[kvh] = sum_g dS[kvh*G+g]^T Q_g, dV[kvh] = sum_g P[kvh*G+g]^T dO_g (HF sdpa/eager autograd). */

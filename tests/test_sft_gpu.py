@@ -248,6 +248,22 @@ def test_gemm_tn_lds_padded_contraction(K, M, N, cfg):
     assert (out.float() - out_old.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
 
 
+def test_gemm_tn_lds_ragged_output_rows():
+    """The lm_head weight gradient's shape class: M (= vocabulary rows of dW) not a multiple of 8, the operand a column-view of a wider buffer whose
+    rows cover M rounded up to 8 (16-byte pieces are read whole, rows >= M of the result are dropped); through ops.gemm_tn's routing."""
+    from vlaser_amd import ops
+    g = torch.Generator().manual_seed(5)
+    K, M, Mp, N = 128, 1002, 1024, 520
+    big = torch.randn(K, Mp, generator=g).to(BF).cuda()
+    At, Wt = big[:, :M], torch.randn(K, N, generator=g).to(BF).cuda()
+    out = torch.full((M + 3, N), 7.0, dtype=BF, device='cuda')
+    ops.gemm_tn(At, Wt, out[:M])
+    ref = At.float().t() @ Wt.float()
+    rel, cos = _rel(out[:M], ref)
+    assert rel < 5e-3 and cos > 0.9999
+    assert (out[M:] == 7.0).all()                          # nothing written past row M
+
+
 def test_attention_backward_fused_pds_and_grouped_tn():
     """vlaser_attn_bwd_pds (softmax + dS in one pass) and the grouped TN GEMM (dK / dV summed over the q heads of a kv group)
     against the closed forms, on a ragged S (not a multiple of 64)."""

@@ -1044,7 +1044,8 @@ extern "C" int vlaser_gemm_tn(const void* At, const void* Wt, void* out, int M, 
 extern "C" int vlaser_gemm_tn_lds(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, int force_cfg, vl_stream_t s) {
   VL_CHECK(At && Wt && out && M > 0 && N > 0 && K > 0, "vlaser_gemm_tn_lds: bad args");
   VL_CHECK(K % BK == 0, "vlaser_gemm_tn_lds: K=%d must be a multiple of %d (pad the contraction axis: zero rows in At)", K, BK);
-  VL_CHECK(M % 8 == 0 && N % 8 == 0 && ldat % 8 == 0 && ldwt % 8 == 0 && ldat >= M && ldwt >= N && ldo >= N, "vlaser_gemm_tn_lds: M, N, ldat, ldwt must be multiples of 8");
+  VL_CHECK(ldat % 8 == 0 && ldwt % 8 == 0 && ldat >= ((M + 7) & ~7) && ldwt >= ((N + 7) & ~7) && ldo >= N,
+           "vlaser_gemm_tn_lds: ldat, ldwt must be multiples of 8 and cover M / N rounded up to 8 columns (rows are read in 16-byte pieces)");
   VL_CHECK((((uintptr_t)At | (uintptr_t)Wt) & 15) == 0 && ((uintptr_t)out & 7) == 0, "vlaser_gemm_tn_lds: operands must be 16-byte aligned");
   VlaserGemmArgs a = {};
   a.A = At; a.W = Wt; a.out = out;

@@ -548,8 +548,9 @@ def gemm_tn(At, Wt, out, K=None):
     """out[M,N] = At[:K]^T @ Wt[:K] (bf16): At [K,M], Wt [K,N] row-major views (row strides honoured)."""
     K = At.shape[0] if K is None else K
     M, N = At.shape[1], Wt.shape[1]
-    if K % 64 == 0 and M % 8 == 0 and N % 8 == 0 and At.stride(0) % 8 == 0 and Wt.stride(0) % 8 == 0 and (At.data_ptr() | Wt.data_ptr()) % 16 == 0 \
-            and M * N >= 128 * 128 and _TN_LDS:
+    c8 = lambda n: (n + 7) // 8 * 8
+    if K % 64 == 0 and At.stride(0) >= c8(M) and Wt.stride(0) >= c8(N) and At.stride(0) % 8 == 0 and Wt.stride(0) % 8 == 0 \
+            and (At.data_ptr() | Wt.data_ptr()) % 16 == 0 and M * N >= 128 * 128 and _TN_LDS:       # ragged M / N: rows must be readable up to the next multiple of 8
         return gemm_tn_lds(At, Wt, out, K)          # whole 64-row tiles: nothing to pad, the LDS-DMA pipeline applies as is
     L.check(L.lib().vlaser_gemm_tn(At.data_ptr(), Wt.data_ptr(), out.data_ptr(), M, N, K, At.stride(0), Wt.stride(0), out.stride(0), _stream()),
             'vlaser_gemm_tn')

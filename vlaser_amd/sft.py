@@ -449,7 +449,12 @@ class SFTModel:
                 for b in range(len(self.buckets)):
                     on_bucket_ready(b)
             return torch.zeros((), device=dev)
-        x_rows = xn.index_select(0, rows).contiguous()
+        # the R supervised rows, in buffers of ceil64(R) rows (zero pad): the head's weight gradient then contracts over whole 64-row tiles and runs on
+        # the LDS-DMA pipeline (vlaser_gemm_tn_lds; r03: 237 -> ~110 us for the [151 674 x 1536] gradient)
+        Rp = (R + 63) // 64 * 64
+        x_pad = torch.zeros(Rp, H, dtype=BF, device=dev)
+        x_pad[:R] = xn.index_select(0, rows)
+        x_rows = x_pad[:R]
         t_rows = self._h2d(tgt_h.index_select(0, rows_h))
         logits = ops.linear(x_rows, v['head'], epi=L.EPI_F32)         # [R, V] fp32
         loss_rows = torch.empty(R, dtype=F32, device=dev)
@@ -458,11 +463,12 @@ class SFTModel:
         loss = loss_rows.sum() / R
         # ================================================================ backward
         # (every bucket's `_wait_params` has been issued by now: the previous step's AdamW / all-gathers no longer touch fp.p or fp.g)
-        dlog = torch.zeros(R, self.Vp, dtype=BF, device=dev)
+        dlog_pad = torch.zeros(Rp, self.Vp, dtype=BF, device=dev)
+        dlog = dlog_pad[:R]
         ops.ce_dlogits(logits, lse, t_rows, dlog, 1.0 / R)
         dx_rows = torch.empty(R, H, dtype=BF, device=dev)
         self._dgrad(dlog, self.head_full, dx_rows, R)               # dX = dlogits @ W_head (contraction over Vp: dlogits and the pad rows are zero there)
-        ops.gemm_tn(dlog[:, :V], x_rows, gv['head'])                # dW_head = dlogits^T @ x (dlogits rows are padded to Vp columns)
+        ops.gemm_tn(dlog_pad[:, :V], x_pad, gv['head'])             # dW_head = dlogits^T @ x over ceil64(R) rows (zero pad rows; dlogits rows are padded to Vp columns)
         dxn = self.dx[:S]
         dxn.zero_()
         dxn.index_copy_(0, rows, dx_rows)
