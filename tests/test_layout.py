@@ -105,6 +105,26 @@ def test_bad_arguments_return_errors_not_crashes():
     s.x, s.W, s.M, s.N, s.K, s.k_splits = 16, 16, 17, 32, 256, 1
     assert lib.vlaser_skinny(0, 0, ctypes.byref(s), None) != 0
     assert b'1..16' in lib.vlaser_last_error()
+    # round-3 entry points: contraction not padded / rows too short for 16-byte pieces
+    P = 4096
+    assert lib.vlaser_gemm_tn_lds(P, P, P, 1536, 2048, 100, 1536, 2048, 2048, 0, None) != 0
+    assert b'multiple of 64' in lib.vlaser_last_error()
+    assert lib.vlaser_gemm_tn_lds(P, P, P, 1002, 2048, 128, 1002, 2048, 2048, 0, None) != 0
+    assert b'rounded up to 8' in lib.vlaser_last_error()
+    # fused attention backward: cache row length not a multiple of 64 / more valid keys than cache rows
+    assert lib.vlaser_attn_bwd(P, P, P, P, P, P, P, P, P, P, 70, 12, 2, 100, 0.1, 1, 70, None) != 0
+    assert b'bad geometry' in lib.vlaser_last_error()
+    # one launch between two passes through the expert: width not a multiple of 256; finishing in place
+    assert lib.vlaser_vla_step(None, None, 0, 4, 0, None, 1e-6, None, None, P, P, None, 0.1, 0, P, P, P, P, P, 4, 700, 7, None) != 0
+    assert b'multiple of 256' in lib.vlaser_last_error()
+    assert lib.vlaser_vla_step(P, None, 0, 4, 0, P, 1e-6, P, P, P, P, None, 0.1, 1, P, P, P, P, P, 4, 768, 7, None) != 0
+    assert b'distinct action buffers' in lib.vlaser_last_error()
+    # attention + o_proj in one launch: batch 1 only
+    at = _lib.AttnArgs()
+    at.q, at.k, at.vt = P, P, P
+    at.batch, at.sq, at.kv_len, at.n_q_heads, at.n_kv_heads, at.head_dim, at.ld_vt, at.mode = 2, 4, 389, 12, 2, 128, 448, _lib.ATTN_PREFIX
+    assert lib.vlaser_attn_oproj(ctypes.byref(at), P, 1536, P, 768, None) != 0
+    assert b'batch 1' in lib.vlaser_last_error()
 
 
 def test_weight_packing_roundtrip():
