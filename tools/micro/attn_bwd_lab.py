@@ -24,7 +24,7 @@ for name, f in fs.items():
     us = timeit([f] * 8)
     print(f'{name:26s}: {us:7.2f} us   ({2.0 * nq * S * S * hd / us / 1e6:6.1f} TF)')
 
-# ---- the fused backward (csrc/attn_bwd.hip; VLASER_ATTN_BWD_TK=64|128 picks the tile), forward with lse for reference
+# ---- the fused backward (csrc/attn_bwd.hip; VLASER_ATTN_BWD_KS=1|2 picks the number of wave groups), forward with lse for reference
 vt = Vn.transpose(-1, -2).contiguous()
 out = torch.zeros(S, nq * hd, dtype=BF, device='cuda')
 lse = torch.zeros(nq * S, dtype=torch.float32, device='cuda'); delta = torch.zeros_like(lse)
@@ -33,4 +33,4 @@ fwd = lambda: ops.attn_prefill(q, Kc, vt, out, 1, S, S, nq, nkv, hd, (S * nq * h
 fwd()
 bwd = lambda: ops.attn_bwd(q, Kc, vt, out, dao, lse, delta, dq, dk, dv, S, nq, nkv, sm, hd ** -0.5)
 print(f'forward (causal, lse)     : {timeit([fwd] * 8):7.2f} us')
-print(f'fused backward (2 kernels): {timeit([bwd] * 8):7.2f} us   TK={os.environ.get("VLASER_ATTN_BWD_TK", "auto")}')
+print(f'fused backward (2 kernels): {timeit([bwd] * 8):7.2f} us   KS={os.environ.get("VLASER_ATTN_BWD_KS", "auto")}')
