@@ -23,7 +23,7 @@ for (M, N, K, name) in SHAPES:
             print(f'{name:12s} cfg {cfg}: {str(e)[:80]}'); continue
         if ref is None:
             ref = out.clone()
-        blocks = {64: (64, 128), 1500: (64, 128), 1506: (64, 128), 1532: (32, 128), 1564: (64, 64), 1100: (128, 128), 1105: (128, 128), 1440: (144, 128), 1200: (128, 256)}[cfg]
+        blocks = {64: (64, 128), 1500: (64, 128), 1506: (64, 128), 1532: (32, 128), 1564: (64, 64), 1100: (128, 128), 1105: (128, 128), 1440: (144, 128), 1200: (128, 256), 1300: (256, 256), 1900: (192, 256)}[cfg]
         nb = -(-M // blocks[0]) * -(-N // blocks[1])
         print(f'{name:12s} M={M:5d} N={N:5d} K={K:5d} cfg {cfg:5d} ({nb:4d} wgs): {us:7.2f} us {2.0 * M * N * K / us / 1e6:7.1f} TF  maxdiff {(out.float() - ref.float()).abs().max().item():.3g}')
     print()
