@@ -246,6 +246,7 @@ class SFTModel:
             self.sc = torch.zeros(nq, QB, S, dtype=F32, device=dev)
             self.dP = torch.zeros(nq, QB, S, dtype=F32, device=dev)
             self.P, self.dS = z(nq, QB, S), z(nq, QB, S)
+        self.head_red = torch.zeros(S, H, dtype=F32, device=dev)      # fp32 sum of the lm_head dgrad's split-K slabs (one rounding to bf16)
         self.dkv_acc = None                        # fp32 [2, S, nq*hd]: dK / dV partial sums over the query blocks (allocated by the first multi-block backward)
         self.col = torch.zeros(max(2 * I, NQ, C4, H), dtype=F32, device=dev)
         self.sumsq_ws = torch.zeros(1024, dtype=F32, device=dev)
@@ -467,7 +468,16 @@ class SFTModel:
         dlog = dlog_pad[:R]
         ops.ce_dlogits(logits, lse, t_rows, dlog, 1.0 / R)
         dx_rows = torch.empty(R, H, dtype=BF, device=dev)
-        self._dgrad(dlog, self.head_full, dx_rows, R)               # dX = dlogits @ W_head (contraction over Vp: dlogits and the pad rows are zero there)
+        # dX = dlogits @ W_head (contraction over Vp: dlogits and the pad rows are zero there): R rows against a 466 MB weight is a stream, and the stream
+        # wants many slices in flight -- 30 split-K slices 114 us (4.1 TB/s), the generic chooser's 6 slices 210 us (tools/micro/head_lab.py)
+        sp = max(d for d in range(1, int(os.environ.get('VLASER_SFT_HEAD_SPLITS', '32')) + 1) if self.Vp % (64 * d) == 0)
+        if sp > 8 and sp * R * H <= self.part.numel():
+            part = self.part[:sp * R * H]
+            ops.gemm_nn(L.EPI_PARTIAL, dlog, self.head_full, out_f32=part, k_splits=sp)
+            torch.sum(part.view(sp, R, H), dim=0, out=self.head_red[:R])
+            dx_rows.copy_(self.head_red[:R])
+        else:
+            self._dgrad(dlog, self.head_full, dx_rows, R)
         ops.gemm_tn(dlog_pad[:, :V], x_pad, gv['head'])             # dW_head = dlogits^T @ x over ceil64(R) rows (zero pad rows; dlogits rows are padded to Vp columns)
         dxn = self.dx[:S]
         dxn.zero_()
