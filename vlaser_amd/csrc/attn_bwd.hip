@@ -74,7 +74,10 @@ __global__ __launch_bounds__(256 * KS) void attn_bwd_dq_kernel(AttnBwdP p) {
   constexpr int TILE_B = TK * AB_PQ + 128 * PV, MERGE_WAVE = DT * 4 * 64 * 4;
   extern __shared__ __attribute__((aligned(16))) char ab_smem[];
   const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
-  char* Ks = ab_smem + grp * TILE_B;       // [TK keys][128 d], pitch 288
+  // two LDS tile buffers per wave group (r03x): tile i+1 is stored while tile i is still being read, so a tile costs ONE workgroup barrier instead of two --
+  // the SQ counters show the waves waiting 43 % of their cycles and no unit above 13 % busy (profiles/r03x_attn_bwd_pmc.md)
+  char* const tiles = ab_smem + grp * 2 * TILE_B;
+  char* Ks = tiles;                        // [TK keys][128 d], pitch 288
   char* Vs = Ks + TK * AB_PQ;              // [128 d][TK keys], pitch 160 / 288
   const int qb = blockIdx.x, h = blockIdx.y, kvh = h / (p.n_q / p.n_kv);
   const int qi = qb * 64 + wave * 16 + fr;                   // this lane's query (operand column)
@@ -120,23 +123,30 @@ __global__ __launch_bounds__(256 * KS) void attn_bwd_dq_kernel(AttnBwdP p) {
       rv[i] = ld_global_16(VT + (size_t)row2 * p.s_max + min(key0 + slot2 * 8, p.s_max - 8));
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
+    char* ks = tiles + buf * TILE_B;
+    char* vs = ks + TK * AB_PQ;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int c = tid + i * 256;
-      *reinterpret_cast<u32x4*>(Ks + (c >> 4) * AB_PQ + (c & 15) * 16) = rk[i];
-      *reinterpret_cast<u32x4*>(Vs + (c / (TK / 8)) * PV + (c % (TK / 8)) * 16) = rv[i];
+      *reinterpret_cast<u32x4*>(ks + (c >> 4) * AB_PQ + (c & 15) * 16) = rk[i];
+      *reinterpret_cast<u32x4*>(vs + (c / (TK / 8)) * PV + (c % (TK / 8)) * 16) = rv[i];
     }
   };
   const int n_it = (n_tiles + KS - 1) / KS;                   // workgroup-uniform trip count: a group past its last tile idles at the barriers
-  if (n_tiles > 0) load_tile(min(grp, n_tiles - 1));
+  if (n_tiles > 0) {
+    load_tile(min(grp, n_tiles - 1));
+    store_tile(0);
+    load_tile(min(grp + KS, n_tiles - 1));
+  }
   for (int itg = 0; itg < n_it; ++itg) {
     const int it = itg * KS + grp;
-    __syncthreads();
-    store_tile();
-    __syncthreads();
-    load_tile(min(it + KS, n_tiles - 1));
-    AB_STAMP(0, ab_i++, ab_me)        // tile staged (both barriers passed), next loads issued
+    __syncthreads();                   // tile itg is in its buffer for every wave, and every wave is done reading the other buffer (tile itg-1)
+    Ks = tiles + (itg & 1) * TILE_B;
+    Vs = Ks + TK * AB_PQ;
+    store_tile((itg + 1) & 1);         // tile itg+1 (requested one iteration ago) into the other buffer; then request tile itg+2
+    load_tile(min(it + 2 * KS, n_tiles - 1));
+    AB_STAMP(0, ab_i++, ab_me)
     if (it >= n_tiles) continue;
     const int key0 = it * TK;
     bf16x8 dsf[NCH];
@@ -212,7 +222,8 @@ __global__ __launch_bounds__(256 * KS) void attn_bwd_dkv_kernel(AttnBwdP p) {
   constexpr int TILE_B = 2 * TK * AB_PQ + 2 * TK * 4, MERGE_WAVE = 2 * DT * 4 * 64 * 4;
   extern __shared__ __attribute__((aligned(16))) char ab_smem[];
   const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
-  char* Qs = ab_smem + grp * TILE_B;       // [TK queries][128 d], pitch 288
+  char* const tiles = ab_smem + grp * 2 * TILE_B;          // two tile buffers per wave group: one barrier per tile (see the dQ kernel)
+  char* Qs = tiles;                        // [TK queries][128 d], pitch 288
   char* Os = Qs + TK * AB_PQ;              // dO, same shape
   float* lse_s = reinterpret_cast<float*>(Qs + 2 * TK * AB_PQ);
   float* del_s = lse_s + TK;
@@ -254,23 +265,33 @@ __global__ __launch_bounds__(256 * KS) void attn_bwd_dkv_kernel(AttnBwdP p) {
       rd = p.delta[(size_t)h * p.S + qq];
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
+    char* qs = tiles + buf * TILE_B;
+    char* os = qs + TK * AB_PQ;
+    float* ls = reinterpret_cast<float*>(qs + 2 * TK * AB_PQ);
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int c = tid + i * 256;
-      *reinterpret_cast<u32x4*>(Qs + (c >> 4) * AB_PQ + (c & 15) * 16) = rq[i];
-      *reinterpret_cast<u32x4*>(Os + (c >> 4) * AB_PQ + (c & 15) * 16) = ro[i];
+      *reinterpret_cast<u32x4*>(qs + (c >> 4) * AB_PQ + (c & 15) * 16) = rq[i];
+      *reinterpret_cast<u32x4*>(os + (c >> 4) * AB_PQ + (c & 15) * 16) = ro[i];
     }
-    if (tid < TK) { lse_s[tid] = rl; del_s[tid] = rd; }
+    if (tid < TK) { ls[tid] = rl; ls[TK + tid] = rd; }
   };
   const int n_it = (max(n_qt - it0, 0) + KS - 1) / KS;
-  if (it0 < n_qt) load_tile(min(it0 + grp, n_qt - 1));
+  if (it0 < n_qt) {
+    load_tile(min(it0 + grp, n_qt - 1));
+    store_tile(0);
+    load_tile(min(it0 + grp + KS, n_qt - 1));
+  }
   for (int itg = 0; itg < n_it; ++itg) {
     const int it = it0 + itg * KS + grp;
     __syncthreads();
-    store_tile();
-    __syncthreads();
-    load_tile(min(it + KS, n_qt - 1));
+    Qs = tiles + (itg & 1) * TILE_B;
+    Os = Qs + TK * AB_PQ;
+    lse_s = reinterpret_cast<float*>(Qs + 2 * TK * AB_PQ);
+    del_s = lse_s + TK;
+    store_tile((itg + 1) & 1);
+    load_tile(min(it + 2 * KS, n_qt - 1));
     if (it >= n_qt) continue;
     const int q0 = it * TK;
     bf16x8 pf[NCH], dsf[NCH];
@@ -354,7 +375,7 @@ extern "C" int vlaser_attn_bwd(const void* q, const void* k, const void* vt, con
   const int ks = force_ks == 1 || force_ks == 2 ? force_ks : (S > 128 ? 2 : 1);
 #define AB_LAUNCH(KS_)                                                                                               \
   {                                                                                                                  \
-    const int lds_q = KS_ * (64 * AB_PQ + 128 * AB_PV), lds_kv = KS_ * (2 * 64 * AB_PQ + 2 * 64 * 4);                \
+    const int lds_q = 2 * KS_ * (64 * AB_PQ + 128 * AB_PV), lds_kv = 2 * KS_ * (2 * 64 * AB_PQ + 2 * 64 * 4);   /* two tile buffers per wave group */                \
     if (int rc = set_max_lds_once(attn_bwd_dq_kernel<64, KS_>, lds_q)) return rc;                                   \
     if (int rc = set_max_lds_once(attn_bwd_dkv_kernel<64, KS_>, lds_kv)) return rc;                                 \
     hipLaunchKernelGGL((attn_bwd_dq_kernel<64, KS_>), grid, dim3(256 * KS_), lds_q, (hipStream_t)s, p);             \
