@@ -653,12 +653,25 @@ class SFTModel:
                     self.ag_events[b] = torch.cuda.Event()
                     self.ag_events[b].record()
             return gnorm
+        if self.dp_active and self.overlap_allgather and os.environ.get('VLASER_SFT_DP_SERIAL_ADAMW') != '1':
+            # ZeRO-1 (r03): this rank's shard of every bucket is updated ON THE COMM STREAM right in front of that bucket's parameter all-gather, bucket by
+            # bucket in the order the NEXT forward consumes them (embed + projector first, lm_head last); the forward waits per bucket (`_wait_params`), so
+            # AdamW (1/N of the parameters) and the exchange both run under the frozen ViT and the earlier layers instead of between two steps
+            # (world 1 with the exchange forced on: 30.7 -> 23 ms per step, profiles/r03dp_force_dp_world1.md)
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                for b in reversed(range(len(self.buckets))):
+                    adamw_bucket(b)
+                    dp.all_gather_params(self.fp.p, self.buckets[b], self.shards[b], self.pg)
+                    self.ag_events[b] = torch.cuda.Event()
+                    self.ag_events[b].record()
+            return gnorm
         for b in range(len(self.buckets)):
             adamw_bucket(b)
         if self.dp_active:
-            # ZeRO-1: all-gather the updated bf16 parameters bucket by bucket on the comm stream, in the order the NEXT forward
-            # consumes them (embed + projector first, lm_head last); the forward waits per bucket (`_wait_params`), so the
-            # exchange overlaps the frozen ViT and the earlier layers instead of sitting between two steps
+            # all-gather the updated bf16 parameters bucket by bucket on the comm stream, in the order the NEXT forward consumes them
             ev = torch.cuda.Event()
             ev.record()
             with torch.cuda.stream(self.comm_stream):
