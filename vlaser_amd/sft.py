@@ -657,7 +657,7 @@ class SFTModel:
             # ZeRO-1 (r03): this rank's shard of every bucket is updated ON THE COMM STREAM right in front of that bucket's parameter all-gather, bucket by
             # bucket in the order the NEXT forward consumes them (embed + projector first, lm_head last); the forward waits per bucket (`_wait_params`), so
             # AdamW (1/N of the parameters) and the exchange both run under the frozen ViT and the earlier layers instead of between two steps
-            # (world 1 with the exchange forced on: 30.7 -> 23 ms per step, profiles/r03dp_force_dp_world1.md)
+            # (world 1 with the exchange forced on: 31.0 -> 28.9 ms per step, profiles/r03dp_force_dp_world1.md)
             ev = torch.cuda.Event()
             ev.record()
             with torch.cuda.stream(self.comm_stream):
