@@ -20,7 +20,7 @@ def _sft(pg, clip):
     from vlaser_amd.sft import SFTModel
     cfg = C.truncated(C.vlaser_2b(), 1, 2)
     m = SFTModel(cfg, max_seq_len=320, lr=1e-3, max_grad_norm=clip, process_group=pg, bucket_layers=1)
-    m.load_state_dict(synth.vlm_state_dict(cfg))
+    m.load_state_dict(synth.vlm_state_dict(cfg, device='cuda'))
     g = torch.Generator().manual_seed(77)
     pv = torch.randn(1, 3, 448, 448, generator=g)
     ids = torch.cat([torch.randint(0, 151643, (20,), generator=g), torch.full((256,), cfg.img_context_token_id),
@@ -38,7 +38,7 @@ def _vla(pg):
     from vlaser_amd.vla_train import VLATrainer
     vla = C.VLAConfig(base=C.truncated(C.vlaser_2b(), 2, 2))
     m = VLATrainer(vla, lr=1e-3, max_grad_norm=1.0, bucket_layers=1, process_group=pg)
-    m.load_state_dict(synth.vla_state_dict(vla, with_head=True))
+    m.load_state_dict(synth.vla_state_dict(vla, with_head=True, device='cuda'))
     d = np.load(os.path.join(GOLDEN, 'g7_vla.npz'))
     f = np.load(os.path.join(GOLDEN, 'g10_flow_matching.npz'))
     smp = dict(input_ids=torch.from_numpy(d['a_input_ids']), pixel_values=torch.randn(1, 3, 448, 448, generator=torch.Generator().manual_seed(int(d['a_seed']))),

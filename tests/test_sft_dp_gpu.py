@@ -33,7 +33,7 @@ def _model(clip, pg=None):
     from vlaser_amd import config as C, synth
     from vlaser_amd.sft import SFTModel
     cfg = C.truncated(C.vlaser_2b(), 1, 2)
-    sd = synth.vlm_state_dict(cfg)
+    sd = synth.vlm_state_dict(cfg, device='cuda')      # generated on the device: the CPU generator was most of this test's wall time (full 151 674-row vocabulary)
     m = SFTModel(cfg, max_seq_len=320, lr=1e-3, max_grad_norm=clip, process_group=pg, bucket_layers=1)
     m.load_state_dict(sd)
     return cfg, m

@@ -28,7 +28,7 @@ def _trainer(pg=None, train_vlm=False):
     from vlaser_amd.vla_train import VLATrainer
     torch.set_grad_enabled(False)
     vla = C.VLAConfig(base=C.truncated(C.vlaser_2b(), 2, 2))
-    sd = synth.vla_state_dict(vla, with_head=True)
+    sd = synth.vla_state_dict(vla, with_head=True, device='cuda')
     m = VLATrainer(vla, lr=1e-3, max_grad_norm=0.0, bucket_layers=1, process_group=pg, train_vlm=train_vlm, vlm_lr=2e-4)
     m.load_state_dict(sd)
     return m
@@ -86,7 +86,7 @@ def _worker(rank, world, port, out_dir):
     # ---- resume at world 2: rank 0 writes the reference-layout step file, EVERY rank its own optimizer shard; a fresh trainer
     # that loads them continues bit for bit (third step == the uninterrupted third step), and a shard of another rank / world is refused
     from vlaser_amd import config as C, synth
-    frozen = synth.vla_state_dict(C.VLAConfig(base=C.truncated(C.vlaser_2b(), 2, 2)), with_head=True)
+    frozen = synth.vla_state_dict(C.VLAConfig(base=C.truncated(C.vlaser_2b(), 2, 2)), with_head=True, device='cuda')
     ck = os.path.join(out_dir, 'step2.pt')
     m.save_checkpoint(ck, frozen)
     dist.barrier()
