@@ -42,6 +42,12 @@ def test_vla_prompt_layout(golden_dir):
     pv = prep.vla_normalize_images(img)
     probe = [float(pv[0, c, 0, 0]) for c in range(3)] + [float(pv[0, 2, 50, 0])]
     np.testing.assert_allclose(probe, g['vla_spoon']['pixel_probe'], rtol=0, atol=1e-6)
+    # all 256 byte values x 3 channels through the reference's InternVLAProcessor: the host normalisation must reproduce the fp32 values BIT FOR BIT
+    # (the device kernel vlaser_normalize_u8 is tested bit-exact against this host function over every byte value, tests/test_ops_gpu.py)
+    ramp = torch.zeros(1, 1, 3, 448, 448, dtype=torch.uint8)
+    ramp[0, 0, :, 0, :256] = torch.arange(256, dtype=torch.uint8)
+    pr = prep.vla_normalize_images(ramp)[0, :, 0, :256]
+    assert np.array_equal(pr.numpy(), np.array(g['pixel_ramp256'], dtype=np.float32))
 
 
 def test_dynamic_grid(golden_dir):

@@ -128,6 +128,11 @@ def g1_prompts(tok):
                          img_count=int((ids == 151667).sum()),
                          pixel_probe=[float(r['pixel_values'][0, c, 0, 0]) for c in range(3)] +
                                      [float(r['pixel_values'][0, 2, 50, 0])])
+    # every byte value in every channel through the reference's processor (the 4-value probe above pins too little)
+    ramp = torch.zeros(1, 1, 3, 448, 448, dtype=torch.uint8)
+    ramp[0, 0, :, 0, :256] = torch.arange(256, dtype=torch.uint8)
+    r = proc(['x'], ramp)
+    out['pixel_ramp256'] = [[float(v) for v in r['pixel_values'][0, c, 0, :256]] for c in range(3)]
     out['system_message'] = sysmsg
     out['special'] = {t: int(tok.convert_tokens_to_ids(t)) for t in
                       ['<IMG_CONTEXT>', '<img>', '</img>', '<|im_end|>', '<|endoftext|>', '<|im_start|>']}
@@ -652,6 +657,10 @@ def main():
             g7b_trace(fake, vla)
         g10_flow_matching(fake, vla)
         return g10b_flow_matching_vlm(fake, vla, fake._ref_vlm)
+    import subprocess
+    import time
+    from golden_manifest import FIXTURES
+    t_start = time.time() - 1.0
     if '--only-g6b' not in sys.argv:
         tok = ref_import.tokenizer()
         g1_prompts(tok)
@@ -669,12 +678,21 @@ def main():
     fake = g7_vla(vla, sd, ref_vlm)
     g7b_trace(fake, vla)
     g10_flow_matching(fake, vla)
+    g10b_flow_matching_vlm(fake, vla, fake._ref_vlm)
     g8_sft_grads(cfg, build_ref_vlm(cfg, vlm_sd))
     g11_packed(cfg, build_ref_vlm(cfg, vlm_sd))
     meta = dict(vit_layers=VIT_L, llm_layers=LLM_L, widths='vlaser-2b', weights='vlaser_amd.synth seed 0',
                 torch=torch.__version__, transformers=__import__('transformers').__version__,
                 generated_by='tools/gen_golden.py (imports /root/reference)')
     json.dump(meta, open(os.path.join(OUT, 'META.json'), 'w'), indent=1)
+    # the two sibling generators (their own import stubs: separate processes), then the manifest check: ONE command rebuilds every fixture
+    for script in sorted({v for v in FIXTURES.values() if not v.endswith('gen_golden.py')}):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, script)])
+    have = sorted(os.listdir(OUT))
+    assert have == sorted(FIXTURES), f'tests/golden/ != tools/golden_manifest.py: {sorted(set(have) ^ set(FIXTURES))}'
+    stale = [f for f in FIXTURES if os.path.getmtime(os.path.join(OUT, f)) < t_start]
+    assert not stale, f'fixtures not rewritten by this run: {stale}'
+    print(f'all {len(FIXTURES)} fixtures rebuilt')
 
 
 if __name__ == '__main__':
