@@ -243,8 +243,24 @@ int vlaser_argmax(const float* logits, int M, int N, int64_t* out_id, const void
  * (pizero_internvl.py:823); final norm + action_decoder + Euler update (+clamp) (pizero_internvl.py:911-932). */
 int vlaser_vla_prep(const float* action, const void* w1, const void* b1, void* xcat, int M, int W, int adim, float t, float max_period, vl_stream_t stream);
 int vlaser_small_linear(const float* x, const void* w, const void* b, void* out, int M, int N, int K, vl_stream_t stream);
+/* (ABI 5) ring (nullable): the updated actions are ALSO written to slot (*ring_ctr mod ring_n) of `ring` (ring_stride floats per slot), so that the host
+ * surface can hand out a view of the result instead of launching a copy (the reference returns a fresh tensor: pizero_internvl.py:934-936). */
 int vlaser_vla_euler(const void* h_in, const float* partials, int n_partials, int M, const void* norm_w, float eps, const void* wd,
-                     const void* bd, float* action, int W, int adim, float dt, float clip, int do_clip, float* vel_out, vl_stream_t stream);
+                     const void* bd, float* action, int W, int adim, float dt, float clip, int do_clip, float* vel_out, float* ring, const int* ring_ctr,
+                     int ring_n, int ring_stride, vl_stream_t stream);
+/* (ABI 5) Every per-call input of PiZero.infer_action (pizero_internvl.py:798-808: input_ids, pixel_values, proprios; :879-881 the noise the reference
+ * draws inside) into the static input slots of the captured chunk graph in ONE launch: ids int64 [B, T] copied; valid_out[b] = valid_in[b] (int32, or int64
+ * when valid_is_i64) or, with valid_in null, the number of ids != pad_id in row b; proprio / noise fp32 copied; pixels -> bf16 (pix_dtype 0: bf16 copy,
+ * 1: fp32 cast, 2: uint8 planar [n,3,H,W] normalised as vlaser_normalize_u8 mode 0 with mean / std, hw = H*W); *call_ctr += 1 (nullable). */
+typedef struct {
+  const int64_t* ids; int64_t* ids_out; int B, T; long long pad_id;
+  const void* valid_in; int valid_is_i64; int32_t* valid_out;
+  const float* proprio; float* proprio_out; int n_proprio;
+  const float* noise; float* noise_out; int n_noise;
+  const void* pix; void* pix_out; long long n_pix; int pix_dtype; int hw; float mean[3]; float std[3];
+  int* call_ctr;
+} VlaserVlaStageArgs;
+int vlaser_vla_stage(const VlaserVlaStageArgs* args, vl_stream_t stream);
 /* (ABI 4) Everything between two passes through the expert's layers in ONE launch: [finish != 0: the tail of the previous Euler step exactly as
  * vlaser_vla_euler computes it, without the clamp, on rows row_off .. row_off + M of h_in / partials (slabs of rows_in rows), a_out = a_in + dt * vel,
  * vel_out optional] + the action encoder of the next step (modules.py:25-56 ActionEncoder: linear_1, time embedding, cat, linear_2, swish, linear_3)

@@ -45,7 +45,7 @@ def test_infer_action_valid_length_extremes(golden_model):
         m1, m2 = ovla.split_full_mask_into_submasks(mask, vla)
         ref = ovla.infer_action(sd, vla, ids, pv, m1, m2, vp, pp, ap, pro, noise)
         act = m.infer_action(ids, pv, m1, m2, vp, pp, ap, pro, noise=noise)
-        assert (act.cpu() - ref).abs().max().item() < 2.5e-2
+        assert (act.cpu() - ref).abs().max().item() < 1e-2
         singles.append(act.clone())
     # both in one batch: per-sequence valid lengths inside one launch
     cat = [torch.cat([a, b], 0) for a, b in zip(*obs)]
@@ -54,7 +54,7 @@ def test_infer_action_valid_length_extremes(golden_model):
     m1, m2 = ovla.split_full_mask_into_submasks(mask, vla)
     both = m.infer_action(cat[0], cat[1], m1, m2, vp, pp, ap, cat[2], noise=cat[3])
     for b in range(2):
-        assert (both[b] - singles[b][0]).abs().max().item() < 2.5e-2
+        assert (both[b] - singles[b][0]).abs().max().item() < 1e-2
     # the reference's .pt layout (`data["model"]`, aliased / `_orig_mod.`-prefixed keys) loads to the same policy
     import os, tempfile
     aliased = {}
@@ -78,7 +78,7 @@ def test_infer_action_valid_length_extremes(golden_model):
     mask3, vp3, pp3, ap3 = ovla.build_causal_mask_and_position_ids(am3, torch.float32, vla)
     m13, m23 = ovla.split_full_mask_into_submasks(mask3, vla)
     three = m.infer_action(big[0], big[1], m13, m23, vp3, pp3, ap3, big[2], noise=big[3])
-    assert three.shape == (3, 4, 7) and torch.equal(three[:2], both) and (three[2] - singles[0][0]).abs().max().item() < 2.5e-2
+    assert three.shape == (3, 4, 7) and torch.equal(three[:2], both) and (three[2] - singles[0][0]).abs().max().item() < 1e-2
 
 
 def test_generate_eos_in_batch_and_min_new_tokens(golden_model, golden_dir):

@@ -57,7 +57,7 @@ def test_determinism_graph_eager_and_batching(full):
         outs.append(o1.clone())
     both = g2.infer_action(ids, pv, proprios=pro, noise=noise, valid_len=_valid(ids, vla.base))
     for b in range(2):
-        assert (both[b] - outs[b][0]).abs().max().item() < 2.5e-2
+        assert (both[b] - outs[b][0]).abs().max().item() < 1e-2
     assert (outs[0] - outs[1]).abs().max().item() > 1e-3          # different observations -> different chunks
 
 

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in sorted(names):
         assert hasattr(lib, n), f'{n} declared in include/vlaser_hip.h but not exported by libvlaser_hip.so'
-    assert lib.vlaser_abi_version() == 4
+    assert lib.vlaser_abi_version() == 5
     # every bound signature refers to a declared symbol
     assert set(_lib._SIGS) <= names
 

@@ -4,8 +4,8 @@ itself and (b) the fp32 CPU oracle on the same seeded inputs.  GPU box only.
 Stated tolerances (bf16 storage / fp32 accumulate vs an fp32 reference):
   hidden states, visual tokens, logits : max|err| <= 3e-2 * max|ref|   (measured 0.5-1.3e-2 at 2+2 layers)
   SFT loss                             : |err| <= 5e-3
-  action chunk                         : max|err| <= 2.5e-2 (reference's own bf16-vs-fp32 remark: ~1e-3 per cached
-                                         step, eval.py:131; 10 Euler steps integrate it)
+  action chunk                         : max|err| <= 1e-2 (measured 3.6-6.4e-3; the reference's own bf16-vs-fp32 remark is ~1e-3 per
+                                         cached step, eval.py:131, and 10 Euler steps integrate it)
   greedy token ids, visual-token indices, top-k ids : bit-exact (golden margins >= 0.09 logit units >> bf16 noise)
 """
 import os
@@ -274,7 +274,7 @@ def test_infer_action_vs_golden(pz, golden_dir):
         ids, pv, m1, m2, vp, pp, ap, pro, noise = _vla_inputs(d, case, pz)
         act = pz.infer_action(ids, pv, m1, m2, vp, pp, ap, pro, noise=noise)
         assert act.shape == (1, 4, 7)
-        assert (act.cpu() - torch.from_numpy(d[f'{case}_action'])).abs().max().item() < 2.5e-2
+        assert (act.cpu() - torch.from_numpy(d[f'{case}_action'])).abs().max().item() < 1e-2
         act2 = pz.infer_action(ids, pv, m1, m2, vp, pp, ap, pro, noise=noise)       # graph replay is deterministic
         assert torch.equal(act, act2)
 
@@ -362,7 +362,7 @@ def test_infer_action_batch2_equals_singles(pz, golden_dir):
     cat = [torch.cat([x, y], 0) for x, y in zip(a, b)]
     both = pz.infer_action(*cat[:8], noise=cat[8])
     ra = torch.from_numpy(d['a_action']); rb = torch.from_numpy(d['b_action'])
-    assert (both[0].cpu() - ra[0]).abs().max().item() < 2.5e-2 and (both[1].cpu() - rb[0]).abs().max().item() < 2.5e-2
+    assert (both[0].cpu() - ra[0]).abs().max().item() < 1e-2 and (both[1].cpu() - rb[0]).abs().max().item() < 1e-2
 
 
 def test_graph_equals_eager(golden_model, golden_dir):

@@ -727,6 +727,61 @@ def test_infer_action_accepts_uint8_observation(golden_model):
     assert torch.equal(a, b)
 
 
+def test_vla_stage_one_launch(ops):
+    """r04: every per-call input of infer_action staged by ONE launch (vlaser_vla_stage) == the r03 sequence of copies / casts, bit for bit: ids, valid_len
+    (given as int32 / int64, or counted from the pad ids), proprio, noise, pixels as bf16 / fp32 / uint8 (normalised like vlaser_normalize_u8), call counter."""
+    from vlaser_amd import prep
+    g = torch.Generator().manual_seed(5)
+    B, T, pad = 3, 384, 151643
+    ids = torch.randint(0, 151643, (B, T), generator=g)
+    lens = [277, 384, 1]
+    for b, n in enumerate(lens):
+        ids[b, n:] = pad
+    pro, nz = torch.rand(B, 7, generator=g), torch.randn(B * 4, 7, generator=g)
+    u8 = torch.randint(0, 256, (B, 3, 448, 448), generator=g, dtype=torch.uint8)
+    u8[0, :, 0, :256] = torch.arange(256, dtype=torch.uint8)
+    f32 = torch.randn(B, 3, 448, 448, generator=g)
+    ctr = torch.zeros(1, dtype=torch.int32, device='cuda')
+    for pix, want in ((u8, prep.vla_normalize_images(u8[:, None]).to(BF)), (f32, f32.to(BF)), (f32.to(BF), f32.to(BF))):
+        for valid in (None, torch.tensor(lens, dtype=torch.int32), torch.tensor([5, 6, 7], dtype=torch.int64)):
+            o_ids = torch.zeros(B + 1, T, dtype=torch.int64, device='cuda')
+            o_valid = torch.full((B + 1,), -1, dtype=torch.int32, device='cuda')
+            o_pro, o_nz = torch.zeros(B + 1, 7, device='cuda'), torch.zeros(16, 7, device='cuda')
+            o_pix = torch.zeros(B + 1, 3, 448, 448, dtype=BF, device='cuda')
+            ops.vla_stage(ids.cuda(), o_ids, None if valid is None else valid.cuda(), o_valid, pro.cuda(), o_pro, nz.cuda(), o_nz, pix.cuda(), o_pix, pad,
+                          prep.VLA_MEAN, prep.VLA_STD, call_ctr=ctr)
+            assert torch.equal(o_ids[:B].cpu(), ids) and int(o_ids[B].abs().sum()) == 0
+            assert o_valid.cpu().tolist() == (lens if valid is None else valid.tolist()) + [-1]
+            assert torch.equal(o_pro[:B].cpu(), pro) and torch.equal(o_nz[:B * 4].cpu(), nz) and float(o_nz[B * 4:].abs().sum()) == 0
+            assert torch.equal(o_pix[:B].cpu(), want) and float(o_pix[B].float().abs().sum()) == 0
+    assert int(ctr) == 9
+
+
+def test_infer_action_output_ring(golden_model):
+    """infer_action returns a view of a result ring written by the chunk's last kernel (no clone launch): values == the clone path (output_ring=0), a result
+    stays intact for `output_ring` - 1 further calls, and device-resident inputs (one staging launch) == host inputs."""
+    from vlaser_amd.pizero import PiZeroInference
+    cfg, vla, sd = golden_model
+    g = torch.Generator().manual_seed(12)
+    ids = torch.full((1, 384), cfg.pad_token_id)
+    ids[0, :10] = torch.randint(0, 151643, (10,), generator=g)
+    ids[0, 10:266] = cfg.img_context_token_id
+    ids[0, 266:277] = torch.randint(0, 151643, (11,), generator=g)
+    pv = torch.randn(1, 3, 448, 448, generator=g)
+    pro = torch.rand(1, 1, 7, generator=g) * 2 - 1
+    noises = [torch.randn(1, 4, 7, generator=g) for _ in range(5)]
+    m0 = PiZeroInference(vla, max_batch=1, output_ring=0); m0.load_state_dict(sd)
+    want = [m0.infer_action(ids, pv, proprios=pro, noise=n).cpu() for n in noises]
+    m = PiZeroInference(vla, max_batch=1); m.load_state_dict(sd)
+    assert m.output_ring == 4
+    got = [m.infer_action(ids.cuda(), pv.cuda(), proprios=pro.cuda(), noise=n.cuda(), valid_len=torch.tensor([277], device='cuda')) for n in noises]
+    torch.cuda.synchronize()
+    for i in range(1, 5):                                   # the last four results are all still there
+        assert torch.equal(got[i].cpu(), want[i]), i
+    assert got[0].data_ptr() == got[4].data_ptr()           # ... and the fifth call reused the first one's slot
+    assert not torch.equal(want[0], want[4])
+
+
 def test_avg_update_ema_swa(ops):
     """EMA / SWA kernel vs torch.optim.swa_utils semantics (model_averaging.py:8-72): first update copies, then lerp / running mean."""
     from vlaser_amd.vla_train import ModelAveraging

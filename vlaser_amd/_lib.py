@@ -43,6 +43,12 @@ class FusedOguArgs(C.Structure):
                 ('N_gu', i32), ('n_valid_gu', i32), ('act', vp), ('ld_act', i32), ('sync', vp), ('cons_delay', i32), ('dbg', vp)]
 
 
+class VlaStageArgs(C.Structure):
+    _fields_ = [('ids', vp), ('ids_out', vp), ('B', i32), ('T', i32), ('pad_id', i64), ('valid_in', vp), ('valid_is_i64', i32), ('valid_out', vp),
+                ('proprio', vp), ('proprio_out', vp), ('n_proprio', i32), ('noise', vp), ('noise_out', vp), ('n_noise', i32),
+                ('pix', vp), ('pix_out', vp), ('n_pix', i64), ('pix_dtype', i32), ('hw', i32), ('mean', f32 * 3), ('std', f32 * 3), ('call_ctr', vp)]
+
+
 FUSED_SYNC_WORDS, FUSED_SYNC_ERR = 160, 128
 
 # enums (include/vlaser_hip.h)
@@ -71,7 +77,8 @@ _SIGS = {
     'vlaser_small_linear': [vp, vp, vp, vp, i32, i32, i32, vp],
     'vlaser_attn_oproj': [vp, vp, i32, vp, i32, vp],
     'vlaser_vla_step': [vp, vp, i32, i32, i32, vp, f32, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp],
-    'vlaser_vla_euler': [vp, vp, i32, i32, vp, f32, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp],
+    'vlaser_vla_euler': [vp, vp, i32, i32, vp, f32, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, vp, i32, i32, vp],
+    'vlaser_vla_stage': [C.POINTER(VlaStageArgs), vp],
     'vlaser_reduce_partials': [vp, vp, i32, i32, i32, vp, vp],
     'vlaser_cast_f32_bf16': [vp, vp, i64, vp],
     'vlaser_normalize_u8': [vp, vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp],

@@ -388,7 +388,8 @@ template <int ADIM, bool HASP>
 __global__ __launch_bounds__(256) void vla_euler_kernel(const bf16_t* __restrict__ h_in, const float* __restrict__ partials, int n_partials,
                                                         int M, const bf16_t* __restrict__ norm_w, float eps, const bf16_t* __restrict__ wd,
                                                         const bf16_t* __restrict__ bd, float* __restrict__ action, int Wd, int adim, float dt,
-                                                        float clip, int do_clip, float* __restrict__ vel_out) {
+                                                        float clip, int do_clip, float* __restrict__ vel_out, float* __restrict__ ring,
+                                                        const int* __restrict__ ring_ctr, int ring_n, int ring_stride) {
   __shared__ float red[4][ADIM + 1];
   const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool on = (int)threadIdx.x * 8 < Wd;
@@ -449,17 +450,20 @@ __global__ __launch_bounds__(256) void vla_euler_kernel(const bf16_t* __restrict
     if (do_clip) av = fminf(fmaxf(av, -clip), clip);
     action[m * adim + j] = av;
     if (vel_out) vel_out[m * adim + j] = vel;
+    // (ABI 5) the caller's copy of the result: slot (call counter mod ring_n) of a small ring, so infer_action returns a view instead of launching a clone
+    if (ring) ring[(size_t)((unsigned)ring_ctr[0] % (unsigned)ring_n) * ring_stride + m * adim + j] = av;
   }
 }
 extern "C" int vlaser_vla_euler(const void* h_in, const float* partials, int n_partials, int M, const void* norm_w, float eps,
                                 const void* wd, const void* bd, float* action, int Wd, int adim, float dt, float clip, int do_clip,
-                                float* vel_out, vl_stream_t s) {
+                                float* vel_out, float* ring, const int* ring_ctr, int ring_n, int ring_stride, vl_stream_t s) {
   VL_CHECK(h_in && norm_w && wd && bd && action && M > 0 && Wd <= 2048 && Wd % 8 == 0, "vlaser_vla_euler: bad args");
+  VL_CHECK(!ring || (ring_ctr && ring_n >= 1 && ring_stride >= M * adim), "vlaser_vla_euler: the output ring needs its counter, >= 1 slots of >= M * adim floats");
   VL_CHECK(n_partials >= 0 && n_partials <= 8 && (n_partials == 0 || partials) && adim >= 1 && adim <= 16,
            "vlaser_vla_euler: 0..8 partial slabs, action_dim <= 16 (got %d, %d)", n_partials, adim);
 #define VL_EULER(AD_, HP_)                                                                                                          \
   hipLaunchKernelGGL((vla_euler_kernel<AD_, HP_>), dim3(M), dim3(256), 0, (hipStream_t)s, (const bf16_t*)h_in, partials, n_partials, M, \
-                     (const bf16_t*)norm_w, eps, (const bf16_t*)wd, (const bf16_t*)bd, action, Wd, adim, dt, clip, do_clip, vel_out)
+                     (const bf16_t*)norm_w, eps, (const bf16_t*)wd, (const bf16_t*)bd, action, Wd, adim, dt, clip, do_clip, vel_out, ring, ring_ctr, ring_n, ring_stride)
   if (adim <= 8) { if (n_partials > 0) VL_EULER(8, true); else VL_EULER(8, false); }
   else { if (n_partials > 0) VL_EULER(16, true); else VL_EULER(16, false); }
 #undef VL_EULER
@@ -728,6 +732,86 @@ extern "C" int vlaser_normalize_u8(const void* in_u8, void* out_bf16, int n_img,
   const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
   hipLaunchKernelGGL(normalize_u8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const uint8_t*)in_u8, (bf16_t*)out_bf16, hw, layout, mode,
                      mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], total4);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// vla_stage (ABI 5): EVERY per-call input of infer_action into the static slots of the captured chunk graph in ONE launch.  r03 staged them with six
+// torch copy_ / cast launches + a clone of the result: ~90 us of mostly idle GPU between two chunks (tools/chunk_timeline.py: the copies start 13 us apart).
+//   block 0           : input_ids (int64 [B, T]) -> ids slot; valid_len[b] = given (int32 / int64) or the number of non-pad ids of row b; proprio and noise
+//                       (fp32) -> their slots; call counter += 1 (slot of the output ring, read by the chunk's last kernel)
+//   blocks 1 .. grid-1: pixel_values -> bf16 slot: bf16 copy / fp32 cast / uint8 planar normalise ((u8 * (1/255) - mean) / std, vlaser_normalize_u8 mode 0)
+struct VlaStageP {
+  const int64_t* ids; int64_t* ids_out; int B, T; long long pad_id;
+  const void* valid_in; int valid_is_i64; int32_t* valid_out;
+  const float* proprio; float* proprio_out; int n_proprio;
+  const float* noise; float* noise_out; int n_noise;
+  const void* pix; bf16_t* pix_out; long long n_pix8; int pix_dtype; int hw;      // n_pix8: groups of 8 elements
+  float m0, m1, m2, s0, s1, s2;
+  int* ctr;
+};
+__global__ __launch_bounds__(256) void vla_stage_kernel(VlaStageP p) {
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0) {
+    __shared__ int cnt[4];
+    for (int i = tid; i < p.B * p.T; i += 256) p.ids_out[i] = p.ids[i];
+    for (int i = tid; i < p.n_proprio; i += 256) p.proprio_out[i] = p.proprio[i];
+    for (int i = tid; i < p.n_noise; i += 256) p.noise_out[i] = p.noise[i];
+    if (p.valid_in) {
+      if (tid < p.B) p.valid_out[tid] = p.valid_is_i64 ? (int32_t)reinterpret_cast<const int64_t*>(p.valid_in)[tid] : reinterpret_cast<const int32_t*>(p.valid_in)[tid];
+    } else {
+      for (int b = 0; b < p.B; ++b) {                       // (input_ids != pad_token_id).sum(-1): what the reference's attention_mask counts for right-padded prompts
+        int c = 0;
+        for (int i = tid; i < p.T; i += 256) c += p.ids[(size_t)b * p.T + i] != p.pad_id;
+        c = (int)wave_sum((float)c);
+        if ((tid & 63) == 0) cnt[tid >> 6] = c;
+        __syncthreads();
+        if (tid == 0) p.valid_out[b] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        __syncthreads();
+      }
+    }
+    if (tid == 0 && p.ctr) p.ctr[0] = p.ctr[0] + 1;
+    return;
+  }
+  const long long stride = (long long)(gridDim.x - 1) * 256;
+  const float r255 = (float)(1.0 / 255.0);
+  for (long long i = (long long)(blockIdx.x - 1) * 256 + tid; i < p.n_pix8; i += stride) {
+    u32x4 o;
+    if (p.pix_dtype == 0) {
+      o = reinterpret_cast<const u32x4*>(p.pix)[i];
+    } else if (p.pix_dtype == 1) {
+      const f32x4 a = reinterpret_cast<const f32x4*>(p.pix)[2 * i], b = reinterpret_cast<const f32x4*>(p.pix)[2 * i + 1];
+      o = u32x4{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+    } else {
+      const long long plane = (i * 8) / p.hw;                // (n, c): hw is a multiple of 8
+      const int c = (int)(plane % 3);
+      const float mean = c == 0 ? p.m0 : (c == 1 ? p.m1 : p.m2), sd = c == 0 ? p.s0 : (c == 1 ? p.s1 : p.s2);
+      const u32x2 w = reinterpret_cast<const u32x2*>(p.pix)[i];
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = ((float)((w[j >> 2] >> (8 * (j & 3))) & 255u) * r255 - mean) / sd;
+      o = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    }
+    reinterpret_cast<u32x4*>(p.pix_out)[i] = o;
+  }
+}
+extern "C" int vlaser_vla_stage(const VlaserVlaStageArgs* a, vl_stream_t s) {
+  VL_CHECK(a && a->ids && a->ids_out && a->valid_out && a->B >= 1 && a->B <= 256 && a->T >= 1, "vlaser_vla_stage: ids / valid_len slots missing or batch outside 1..256");
+  VL_CHECK((a->n_proprio == 0 || (a->proprio && a->proprio_out)) && (a->n_noise == 0 || (a->noise && a->noise_out)), "vlaser_vla_stage: proprio / noise pointers");
+  VL_CHECK(a->n_pix == 0 || (a->pix && a->pix_out && a->n_pix % 8 == 0 && a->pix_dtype >= 0 && a->pix_dtype <= 2), "vlaser_vla_stage: pixel count must be a multiple of 8, dtype 0 bf16 / 1 f32 / 2 u8");
+  VL_CHECK(a->n_pix == 0 || a->pix_dtype != 2 || (a->hw > 0 && a->hw % 8 == 0), "vlaser_vla_stage: uint8 pixels need H*W (a multiple of 8)");
+  VL_CHECK(a->n_pix == 0 || ((((uintptr_t)a->pix) & (a->pix_dtype == 2 ? 7 : 15)) == 0 && (((uintptr_t)a->pix_out) & 15) == 0), "vlaser_vla_stage: pixel buffers must be 16-byte (uint8: 8-byte) aligned");
+  VlaStageP p;
+  p.ids = a->ids; p.ids_out = a->ids_out; p.B = a->B; p.T = a->T; p.pad_id = a->pad_id;
+  p.valid_in = a->valid_in; p.valid_is_i64 = a->valid_is_i64; p.valid_out = a->valid_out;
+  p.proprio = a->proprio; p.proprio_out = a->proprio_out; p.n_proprio = a->n_proprio;
+  p.noise = a->noise; p.noise_out = a->noise_out; p.n_noise = a->n_noise;
+  p.pix = a->pix; p.pix_out = (bf16_t*)a->pix_out; p.n_pix8 = a->n_pix / 8; p.pix_dtype = a->pix_dtype; p.hw = a->hw;
+  p.m0 = a->mean[0]; p.m1 = a->mean[1]; p.m2 = a->mean[2]; p.s0 = a->std[0]; p.s1 = a->std[1]; p.s2 = a->std[2];
+  p.ctr = a->call_ctr;
+  long long pb = (p.n_pix8 + 255) / 256;
+  if (pb > 1024) pb = 1024;
+  hipLaunchKernelGGL(vla_stage_kernel, dim3(1 + (int)pb), dim3(256), 0, (hipStream_t)s, p);
   VL_LAUNCH_CHECK();
   return 0;
 }

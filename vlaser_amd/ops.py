@@ -413,10 +413,39 @@ def small_linear(x, w, b, out, M, N, K):
             'vlaser_small_linear')
 
 
-def vla_euler(h_in, partials, n_partials, M, norm_w, eps, wd, bd, action, W, adim, dt, clip, do_clip, vel_out=None):
+def vla_euler(h_in, partials, n_partials, M, norm_w, eps, wd, bd, action, W, adim, dt, clip, do_clip, vel_out=None, ring=None, ring_ctr=None):
+    """ring (fp32 [slots, stride]) + ring_ctr (device int32): the result also goes to slot (*ring_ctr mod slots) -- infer_action returns that view."""
     L.check(L.lib().vlaser_vla_euler(h_in.data_ptr(), _p(partials), n_partials, M, norm_w.data_ptr(), eps, wd.data_ptr(),
-                                     bd.data_ptr(), action.data_ptr(), W, adim, dt, clip, int(do_clip), _p(vel_out), _stream()),
+                                     bd.data_ptr(), action.data_ptr(), W, adim, dt, clip, int(do_clip), _p(vel_out), _p(ring), _p(ring_ctr),
+                                     0 if ring is None else ring.shape[0], 0 if ring is None else ring.stride(0), _stream()),
             'vlaser_vla_euler')
+
+
+_PIX_DTYPES = {torch.bfloat16: 0, torch.float32: 1, torch.uint8: 2}
+
+
+def vla_stage(ids, ids_out, valid_in, valid_out, proprio, proprio_out, noise, noise_out, pix, pix_out, pad_id, mean, std, call_ctr=None):
+    """All per-call inputs of infer_action into the chunk graph's static slots in ONE launch (device tensors, contiguous).  pix: bf16 / fp32
+    (already normalised) or uint8 [n,3,H,W] (normalised here, InternVLAProcessor arithmetic); valid_in: int32 / int64 [B] or None (= count of ids != pad_id)."""
+    a = L.VlaStageArgs()
+    B, T = ids.shape
+    assert ids.dtype == torch.int64 and ids.is_cuda and ids.is_contiguous()
+    a.ids, a.ids_out, a.B, a.T, a.pad_id = ids.data_ptr(), ids_out.data_ptr(), B, T, pad_id
+    if valid_in is not None:
+        assert valid_in.dtype in (torch.int32, torch.int64) and valid_in.is_cuda and valid_in.is_contiguous() and valid_in.numel() == B
+        a.valid_in, a.valid_is_i64 = valid_in.data_ptr(), int(valid_in.dtype == torch.int64)
+    a.valid_out = valid_out.data_ptr()
+    for t in (proprio, noise):
+        assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous()
+    a.proprio, a.proprio_out, a.n_proprio = proprio.data_ptr(), proprio_out.data_ptr(), proprio.numel()
+    a.noise, a.noise_out, a.n_noise = noise.data_ptr(), noise_out.data_ptr(), noise.numel()
+    assert pix.is_cuda and pix.is_contiguous() and pix.dtype in _PIX_DTYPES and pix_out.dtype == BF16 and pix_out.numel() >= pix.numel()
+    a.pix, a.pix_out, a.n_pix, a.pix_dtype = pix.data_ptr(), pix_out.data_ptr(), pix.numel(), _PIX_DTYPES[pix.dtype]
+    a.hw = pix.shape[-1] * pix.shape[-2]
+    for i in range(3):
+        a.mean[i], a.std[i] = mean[i], std[i]
+    a.call_ctr = _p(call_ctr)
+    L.check(L.lib().vlaser_vla_stage(C.byref(a), _stream()), 'vlaser_vla_stage')
 
 
 def vla_step(a_in, a_out, w21, cs, w3, b3, h_out, M, W, adim, finish=None, vel_out=None, dt=0.0):

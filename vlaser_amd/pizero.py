@@ -119,7 +119,7 @@ class PiZero:
     # measurements + in-kernel timelines: profiles/r03c_euler_fusion.md
     EULER_DEFAULT = 'qkv16,glue1'
 
-    def __init__(self, cfg: VLAConfig, device='cuda', max_batch=1, use_graph=True, ride_proprio=True, naive_support=False, euler_opts=None):
+    def __init__(self, cfg: VLAConfig, device='cuda', max_batch=1, use_graph=True, ride_proprio=True, naive_support=False, euler_opts=None, output_ring=4):
         L.lib()
         if not torch.cuda.is_available():
             raise L.VlaserHipError('vlaser_amd needs an MI355X (gfx950) GPU: there is no CPU fallback')
@@ -144,6 +144,10 @@ class PiZero:
         self.euler_opts = tuple(x for x in eo.split(',') if x and x != 'none')
         self._graphs = {}
         self._pos_state = None
+        # infer_action returns a VIEW of slot (call number mod output_ring) of a small result ring written by the chunk's last kernel: valid until
+        # `output_ring` further calls have been made (the reference returns a fresh tensor; output_ring=0 restores that with a clone launch per call)
+        self.output_ring = int(output_ring)
+        self._calls = 0
         if max_batch * cfg.num_action_tokens > 16:
             raise ValueError('the weight-streaming action path handles batch * horizon <= 16 rows')
 
@@ -213,6 +217,14 @@ class PiZero:
         self.pos_pro = z(B, dt=torch.int32)
         self.pos_act = z(B * self.num_action_tokens, dt=torch.int32)
         self.pos5 = z(16, dt=torch.int32)
+        self.call_ctr = z(1, dt=torch.int32)
+        self.out_ring = z(max(self.output_ring, 1), 16 * cfg.action_dim, dt=torch.float32)
+        self._calls = 0
+        # where the per-call noise is staged: straight into the buffer the first launch of the Euler phase reads ('glue1': the ping-pong buffer the
+        # integration starts from -- r03 copied in_noise there inside the graph)
+        n = cfg.num_inference_steps
+        self._glue1 = 'glue1' in self.euler_opts and n >= 2 and W % 256 == 0 and W <= 1024
+        self.noise_dst = (self.action, self.action_b)[(n - 1) % 2] if self._glue1 else self.in_noise
 
     def _stage_positions(self, B, vlm_position_ids, proprio_position_ids, action_position_ids):
         """Position ids into the static buffers of the captured graph.  The reference's defaults (1..T, 1, 2..1+na; pizero_internvl.py:576-585)
@@ -300,7 +312,7 @@ class PiZero:
         dt = 1.0 / n
         W = cfg.action_hidden_size
         clip = self.final_action_clip_value
-        if 'glue1' in self.euler_opts and n >= 2 and W % 256 == 0 and W <= 1024:
+        if self._glue1:
             return self._run_euler_glue1(B, skip)
         if ride:
             self.action5[1:1 + M].copy_(self.in_noise[:M])
@@ -332,8 +344,9 @@ class PiZero:
                 h, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_act, h, parts, npart, self.cache, i, self.rope,
                                                self.pos_act, B, na, T + 1, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len,
                                                blk_start=T, skip=skip, sync=sync(s, i))
+            ring = (self.out_ring, self.call_ctr) if (self.output_ring > 0 and s == n - 1) else (None, None)
             ops.vla_euler(h, parts, npart, M, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action, W, cfg.action_dim, dt,
-                          clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel_trace[s])
+                          clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel_trace[s], ring=ring[0], ring_ctr=ring[1])
 
     def _run_euler_glue1(self, B, skip=()):
         """The same integration with ONE launch between two passes through the expert's layers (`vlaser_vla_step`: tail of step s-1 + action
@@ -350,7 +363,7 @@ class PiZero:
         clip = self.final_action_clip_value
         acts = [self.action, self.action_b]
         p = (n - 1) % 2                           # n - 1 ping-pongs later the actions sit in self.action, where the last step finishes in place
-        acts[p][:M].copy_(self.in_noise[:M])
+        assert acts[p] is self.noise_dst          # the staging launch wrote this call's noise here
         fused = any(o.startswith('fuse_') for o in self.euler_opts)
         if fused:
             self.euler_sync.zero_()
@@ -380,8 +393,9 @@ class PiZero:
                                                    blk_start=T, skip=skip, sync=sync(s, i))
                 fin = (h, parts, npart, M, 0, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b)
         assert acts[p] is self.action
+        ring = (self.out_ring, self.call_ctr) if self.output_ring > 0 else (None, None)
         ops.vla_euler(fin[0], fin[1], fin[2], M, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action, W, ad, dt,
-                      clip if clip is not None else 0.0, clip is not None, vel_out=self.vel_trace[n - 1])
+                      clip if clip is not None else 0.0, clip is not None, vel_out=self.vel_trace[n - 1], ring=ring[0], ring_ctr=ring[1])
 
     @torch.no_grad()
     def infer_action(self, input_ids, pixel_values, image_text_proprio_mask=None, action_mask=None, vlm_position_ids=None,
@@ -403,20 +417,13 @@ class PiZero:
             return torch.cat(outs, 0)
         if input_ids.shape != (B, T):
             raise ValueError(f'input_ids must be [B,{T}] (right-padded with pad_token_id), got {tuple(input_ids.shape)}')
-        # ---- stage inputs into the static buffers (host->device plumbing)
-        self.in_ids[:B].copy_(input_ids)
-        stage_pixels(pixel_values, self.in_pix[:B * self.num_images], dev)
-        self.in_proprio[:B].copy_(proprios.reshape(B, -1))
-        if valid_len is None:
-            if image_text_proprio_mask is not None:
-                valid_len = prep.mask_to_descriptor(image_text_proprio_mask.to('cpu'), T)
-            else:
-                valid_len = (input_ids != self.pad_token_id).sum(-1)
-        self.valid_len[:B].copy_(valid_len)                      # copy_ converts dtype and crosses devices in one op
-        self._stage_positions(B, vlm_position_ids, proprio_position_ids, action_position_ids)
+        # ---- stage inputs into the static slots of the captured graph: ONE launch (vlaser_vla_stage) once the tensors are on the device
+        if valid_len is None and image_text_proprio_mask is not None:
+            valid_len = prep.mask_to_descriptor(image_text_proprio_mask.to('cpu'), T)
         if noise is None:
             noise = torch.randn((B, na, cfg.action_dim), generator=generator)      # reference: torch.randn inside (:879-881)
-        self.in_noise[:B * na].copy_(noise.reshape(B * na, -1))
+        self._stage_inputs(B, input_ids, pixel_values, proprios, noise, valid_len)
+        self._stage_positions(B, vlm_position_ids, proprio_position_ids, action_position_ids)
         # ---- run (HIP graph replay after the first call per batch size)
         if self.use_graph:
             g = self._graphs.get(B)
@@ -430,8 +437,32 @@ class PiZero:
             g.replay()
         else:
             self._run(B)
+        if self.output_ring > 0:
+            act = self.out_ring[self._calls % self.output_ring, :B * na * cfg.action_dim].view(B, na, cfg.action_dim)
+            return act[:, -cfg.horizon_steps:]
         act = self.action[:B * na].view(B, na, cfg.action_dim)
         return act[:, -cfg.horizon_steps:].clone()
+
+    def _stage_inputs(self, B, input_ids, pixel_values, proprios, noise, valid_len):
+        """Host / device plumbing of one call's inputs (the reference moves them with .to(device) in its agent loop, eval.py:117-128): anything not yet
+        on the device is copied there, then `vlaser_vla_stage` writes every slot in one launch -- ids, valid_len (given, or counted from the pad ids),
+        proprio, noise (straight into the buffer the Euler phase starts from) and the pixels (bf16 / fp32 -> bf16, or the raw uint8 observation normalised
+        on the device) -- and advances the call counter that selects the result slot."""
+        dev, cfg = self.device, self.cfg
+        na = self.num_action_tokens
+        on = lambda t, dt=None: t.to(device=dev, dtype=dt, non_blocking=True).contiguous()
+        ids = on(input_ids, torch.int64)
+        pv = pixel_values if pixel_values.dtype in (torch.uint8, torch.float32, BF) else pixel_values.float()
+        pv = on(pv)
+        if tuple(pv.shape[-3:]) != tuple(self.in_pix.shape[-3:]) or pv.numel() != B * self.num_images * self.in_pix[0].numel():
+            raise ValueError(f'pixel_values must be [B*{self.num_images},{",".join(map(str, self.in_pix.shape[1:]))}], got {tuple(pixel_values.shape)}')
+        pro = on(proprios.reshape(B, -1), torch.float32)
+        nz = on(noise.reshape(B * na, -1), torch.float32)
+        if valid_len is not None:
+            valid_len = on(valid_len.reshape(-1), valid_len.dtype if valid_len.dtype in (torch.int32, torch.int64) else torch.int64)
+        self._calls += 1
+        ops.vla_stage(ids, self.in_ids, valid_len, self.valid_len, pro, self.in_proprio, nz, self.noise_dst, pv, self.in_pix, self.pad_token_id,
+                      prep.VLA_MEAN, prep.VLA_STD, call_ctr=self.call_ctr)
 
     def sync_errors(self):
         """Number of fused-launch slots whose bounded in-launch wait expired during the last chunk (0 on a healthy run; the result is
