@@ -325,7 +325,9 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'Vlaser-2B-VLA action-chunk inference: 1x448px image, 384-token prompt (277 valid), '
                                    '7-DoF x 4-step chunk, 10 Euler steps, batch 1 per GPU (BASELINE configs[2])',
-                       'parallelism': f'replicas x{world} (no collective)', 'weights': 'random-init, true architecture'},
+                       'parallelism': f'replicas x{world} (no collective)', 'weights': 'random-init, true architecture',
+                       'reference_mode': 'use_bf16=True (bf16 storage / fp32 accumulate: the mode the reference trains in, slurm/train_internvl.sh:35; its shipped eval '
+                                         'config runs fp32, bridge_internvl_448.yaml:36)'},
         }
         if not a.no_roofline:
             iso_ms, byts, n_iso = _probe(model)
@@ -333,6 +335,7 @@ def main():
             avg_ms = inchain_us * 1e-3
             ach = byts / (avg_ms * 1e-3) / 1e9
             line['phases'] = phases
+            phases['call_overhead_ms'] = round(dt / a.steps * 1e3 - phases['chunk_graph_ms'], 4)     # staging launch + graph launch gap per infer_action call
             # whole-chunk floor: 1 726 GFLOP of ViT + projector + joint prefill on MFMA (2.5 PFLOP/s dense bf16) + 10 Euler steps x
             # 1.310 GB of expert weights (+ 11.2 MB of K/V each) over HBM (8 TB/s) = 0.690 + 1.652 ms
             floor_ms = 1726e9 / 2.5e15 * 1e3 + 10 * (1.310e9 + 11.2e6) / 8e12 * 1e3
@@ -594,9 +597,21 @@ def _phases(model):
     pre = _graph_ms(lambda: model._run_prefill(1))
     eul = _graph_ms(lambda: model._run_euler(1))
     eul_wo = _graph_ms(lambda: model._run_euler(1, skip=('gu',)))
+    # the captured chunk graph itself, replayed back to back without any per-call staging: ms_per_step minus this = what infer_action adds around the graph
+    gchunk = model._graphs[1]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    gchunk.replay()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        gchunk.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    chunk_graph = e0.elapsed_time(e1) / 10
     nL, ns = model.cfg.expert.num_hidden_layers, model.num_inference_steps
     n = nL * ns
     ph = {'vit_projector_scatter_ms': round(vit, 4), 'joint_prefill_ms': round(pre, 4), 'euler_ms': round(eul, 4), 'sum_ms': round(vit + pre + eul, 4),
+          'chunk_graph_ms': round(chunk_graph, 4),
           'euler_us_per_layer_step': round(eul * 1e3 / n, 3), 'euler_ms_without_dominant_kernel': round(eul_wo, 4),
           'mfma_part': {'gflop': 1726.0, 'achieved_tflops': round(1726.0 / (vit + pre), 1), 'frac_of_2500': round(1726e9 / ((vit + pre) * 1e-3) / 2.5e15, 4)},
           'euler_part': {'gbytes': 13.21, 'achieved_gbs': round(13.21e9 / (eul * 1e-3) / 1e9, 1), 'frac_of_8000': round(13.21e9 / (eul * 1e-3) / 8e12, 4)},

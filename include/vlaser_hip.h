@@ -190,12 +190,13 @@ typedef struct {
 } VlaserFusedOguArgs;
 int vlaser_fused_ogu(const VlaserFusedOguArgs* args, vl_stream_t stream);
 
-/* ---- attention + o_proj of a <= 16-row decoder layer-step in one launch (ABI 4, r03; batch 1): replaces vlaser_attn_skinny followed by
- * vlaser_skinny(VL_PRO_ATTN, VL_SK_PARTIAL) at joint_model.py:636-671 (attention of the action rows over the cached prefix + o_proj).  Every workgroup
- * recomputes the attention of its kv group (key split across its 8 waves) and owns 16 output columns of W_o [N, n_q_heads*128] (row-major bf16, as
- * stored); out_f32 = n_kv_heads partial slabs [sq, N] fp32 (one per kv head) for the consumer's split-K reduction.  `a` as for vlaser_attn_skinny
- * (part_* / n_splits unused). */
-int vlaser_attn_oproj(const VlaserAttnArgs* a, const void* wo, int ldw, float* out_f32, int N, vl_stream_t stream);
+/* ---- attention + o_proj of a <= 16-row decoder layer-step in one launch (ABI 5, r04; batch 1): replaces vlaser_attn_skinny followed by
+ * vlaser_skinny(VL_PRO_ATTN, VL_SK_PARTIAL) at joint_model.py:636-671 (attention of the proprio / action rows over the cached prefix + their own block,
+ * then o_proj).  Every workgroup recomputes the attention of its kv group from K / V^T tiles staged in LDS by coalesced LDS-DMA (only the keys a row can
+ * see: the valid prefix and [blk_start, kv_len)) and owns 16 output columns of W_o; out_f32 = n_kv_heads partial slabs [sq, N] fp32 (one per kv head)
+ * for the consumer's split-K reduction.  wo_packed = ops.pack_skinny(o_proj.weight [N, n_q_heads*128], k_splits = n_kv_heads, tiles_per_unit = 1).
+ * `a` as for vlaser_attn_skinny (part_* / n_splits unused); GQA group 2 / 4 / 6 / 8, group * sq <= 32, blk_start a multiple of 16. */
+int vlaser_attn_oproj(const VlaserAttnArgs* a, const void* wo_packed, float* out_f32, int N, vl_stream_t stream);
 
 /* ---- fused attention backward (ABI 4, r03): the backward of vlaser_attn_prefill's causal / valid-prefix attention (HF eager_attention_forward /
  * flash_attention_2 autograd, modeling_internvl_chat.py:194-203) without materialised score matrices: two deterministic kernels (no atomics) --

@@ -284,34 +284,41 @@ def test_attn_skinny_partials_and_merge(ops, nq_tok, kv_len, mode, nsp):
     close(part.sum(0), ref.reshape(Mrows, -1).to(BF).float() @ wo.float().t(), rtol=2e-2, name='o_proj over merged attention')
 
 
-@pytest.mark.parametrize('nq_tok,kv_len,mode,first,nq,nkv', [(4, 389, 'prefix', 0, 12, 2), (5, 389, 'prefix', 385, 12, 2), (1, 70, 'full', 0, 12, 2), (4, 1200, 'prefix', 0, 12, 2),
-                                                             (2, 33, 'full', 0, 28, 4), (16, 300, 'full', 0, 4, 2)])
-def test_attn_oproj_one_launch(ops, nq_tok, kv_len, mode, first, nq, nkv):
-    """vlaser_attn_oproj (attention + o_proj of a <= 16-row layer-step in ONE launch, every workgroup recomputing its kv group's attention with the key
-    split inside the workgroup): the per-kv-head slabs sum to o_proj(attention) of an fp32 reference, for the expert's geometry (4 action rows; the
-    proprio row riding with its own key limit), a single decode row, more chunks than waves, GQA group 7 (Vlaser-8B) and 16 tokens."""
+@pytest.mark.parametrize('nq_tok,kv_len,mode,first,nq,nkv,valid', [
+    (4, 389, 'prefix', 0, 12, 2, 277), (5, 389, 'prefix', 385, 12, 2, 277),          # the expert's layer-step: 18 prefix tiles + the block's = 19 tiles, ONE pass
+    (4, 389, 'prefix', 0, 12, 2, 288), (4, 389, 'prefix', 0, 12, 2, 289), (5, 389, 'prefix', 385, 12, 2, 384),      # 19 / 20 / 25 tiles: the second pass
+    (4, 389, 'prefix', 0, 12, 2, 1), (4, 389, 'prefix', 0, 12, 2, 16), (4, 389, 'prefix', 0, 12, 2, 17), (4, 388, 'prefix', 0, 12, 2, 100),
+    (1, 70, 'full', 0, 12, 2, 0), (4, 1200, 'prefix', 0, 12, 2, 277), (16, 300, 'full', 0, 4, 2, 0), (3, 33, 'full', 0, 16, 2, 0), (4, 640, 'full', 0, 8, 2, 0)])
+def test_attn_oproj_one_launch(ops, nq_tok, kv_len, mode, first, nq, nkv, valid):
+    """vlaser_attn_oproj (r04 rewrite: attention + o_proj of a <= 16-row layer-step in ONE launch; every workgroup recomputes its kv group's attention from
+    K / V^T tiles staged in LDS by coalesced LDS-DMA, two-step softmax, P V split by head-dim tile): the per-kv-head slabs sum to o_proj(attention) of an
+    fp32 reference for the expert's geometry (4 action rows; the proprio row riding with its own key limit), prompts of every tile count around the
+    one-pass limit (19 tiles) and beyond (online rescale between passes), a single decode row, GQA groups 2 / 4 / 6 / 8, 16 tokens; the result is
+    bit-reproducible.  Group 7 (Vlaser-8B) is refused (the engine keeps the two launches there)."""
     from vlaser_amd import _lib as L
     smax, H = 1536, 768
     G = nq // nkv
     q = rnd(nq_tok, nq * 128, seed=1)
     k = rnd(1, nkv, smax, 128, seed=2); v = rnd(1, nkv, smax, 128, seed=3)
+    k[:, :, 5] *= 4.0                                        # a dominant key early in the prompt: the second pass must rescale against it
     vt = v.transpose(-1, -2).contiguous()
     sc = 128 ** -0.5
-    valid = torch.tensor([277], dtype=torch.int32, device='cuda')
+    vl = torch.tensor([valid], dtype=torch.int32, device='cuda')
     blk = 384
-    kw = dict(valid_len=valid, blk_start=blk) if mode == 'prefix' else {}
+    kw = dict(valid_len=vl, blk_start=blk) if mode == 'prefix' else {}
     parts = ops.attn_partial_buffers(1, nkv, 'cuda')
     a = ops.attn_skinny_args(q, k, vt, parts, 1, nq_tok, kv_len, nq, nkv, 128, (nq_tok * nq * 128, 128, nq * 128), (nkv * smax * 128, smax * 128),
                              (nkv * 128 * smax, 128 * smax), smax, sc, L.ATTN_PREFIX if mode == 'prefix' else L.ATTN_FULL, 1, first_tok_kv_len=first, **kw)
     wo = rnd(H, nq * 128, std=0.03, seed=9)
+    wp = ops.pack_skinny(wo, nkv, 1)
     out = torch.full((nkv, nq_tok, H), 5.0, dtype=torch.float32, device='cuda')
-    ops.launch_attn_oproj(a, wo, out, H)
+    ops.launch_attn_oproj(a, wp, out, H)
     torch.cuda.synchronize()
     j = torch.arange(kv_len, device='cuda')[None, None]
     if mode == 'prefix':
-        vis = ((j < 277) | (j >= blk)).expand(1, nq_tok, kv_len).clone()
+        vis = ((j < valid) | (j >= blk)).expand(1, nq_tok, kv_len).clone()
         if first:
-            vis[0, 0] = (j[0, 0] < 277) | ((j[0, 0] >= blk) & (j[0, 0] < first))      # the riding proprio row sees the block only up to itself
+            vis[0, 0] = (j[0, 0] < valid) | ((j[0, 0] >= blk) & (j[0, 0] < first))      # the riding proprio row sees the block only up to itself
     else:
         vis = torch.ones(1, nq_tok, kv_len, dtype=torch.bool, device='cuda')
     qq = q.view(1, nq_tok, nq, 128).permute(0, 2, 1, 3)
@@ -323,8 +330,20 @@ def test_attn_oproj_one_launch(ops, nq_tok, kv_len, mode, first, nq, nkv):
         sl = slice(kvh * G * 128, (kvh + 1) * G * 128)
         close(out[kvh], att[:, sl].to(BF).float() @ wo[:, sl].float().t(), rtol=2e-2, name=f'slab {kvh}')
     out2 = torch.zeros_like(out)
-    ops.launch_attn_oproj(a, wo, out2, H)
+    ops.launch_attn_oproj(a, wp, out2, H)
     assert torch.equal(out, out2)
+
+
+def test_attn_oproj_refuses_odd_groups(ops):
+    from vlaser_amd import _lib as L
+    nq, nkv, smax = 28, 4, 512
+    q = rnd(2, nq * 128); k = rnd(1, nkv, smax, 128); vt = rnd(1, nkv, 128, smax)
+    a = ops.attn_skinny_args(q, k, vt, ops.attn_partial_buffers(1, nkv, 'cuda'), 1, 2, 33, nq, nkv, 128, (2 * nq * 128, 128, nq * 128), (nkv * smax * 128, smax * 128),
+                             (nkv * 128 * smax, 128 * smax), smax, 0.1, L.ATTN_FULL, 1)
+    assert not ops.attn_oproj_supported(nq, nkv, 2, 1, 128, 768)
+    wp = ops.pack_skinny(rnd(768, 1024), 4, 1); wp.K = nq * 128       # (geometry only: the launch must be refused before anything is read)
+    with pytest.raises(L.VlaserHipError):
+        ops.launch_attn_oproj(a, wp, torch.zeros(nkv, 2, 768, device='cuda'), 768)
 
 
 def _rms_ref(h, w, eps=1e-6):

@@ -48,6 +48,48 @@ def _worker_vlm(rank, world, port, out_dir):
     losses = [float(m.step([smp]).loss) for _ in range(2)]
     torch.cuda.synchronize()
     torch.save({'losses': losses, 'p': {k: v.cpu() for k, v in m.state_dict().items()}}, os.path.join(out_dir, f'rank{rank}.pt'))
+    # ---- resume at world 2 with BOTH parameter groups: the VLM group's shard keys are written and read back; the third step of
+    # the resumed trainer == the uninterrupted third step bit for bit (weights, masters, both optimisers' moments)
+    from vlaser_amd import config as C, synth
+    from vlaser_amd.vla_train import ModelAveraging
+    frozen = synth.vla_state_dict(C.VLAConfig(base=C.truncated(C.vlaser_2b(), 2, 2)), with_head=True, device='cuda')
+    ck = os.path.join(out_dir, 'vlm_step2.pt')
+    m.save_checkpoint(ck, frozen)
+    dist.barrier()
+    if rank == 0:
+        data = torch.load(ck, weights_only=True)
+        for k in ('cnt_update', 'cnt_batch', 'model', 'action_optimizer', 'vlm_optimizer', 'action_lr_scheduler', 'vlm_lr_scheduler', 'wandb_id', 'n_averaged'):
+            assert k in data, k                                  # the keys the reference's save_training writes (train.py:655-670)
+    # EMA of both groups from here on (the VLM group used to leave un-averaged under an 'ema' label)
+    ma = ModelAveraging(m, use_ema=True, ema_start=3, ema_decay=0.5)
+    m.step([smp]); ma.maybe_initialize(3); ma.maybe_update(3)
+    torch.cuda.synchronize()
+    want = {k: v.cpu() for k, v in m.state_dict().items()}
+    want_state = [t.cpu().clone() for t in (m.m, m.v, m.master, m.vg.m, m.vg.v, m.vg.master)]
+    first = {k: v.float().cpu() for k, v in want.items()}
+    m.step([smp]); ma.maybe_update(4)
+    torch.cuda.synchronize()
+    second = {k: v.float().cpu() for k, v in m.state_dict().items()}
+    avg = ma.state_dict()
+    assert avg['model_type'] == 'ema' and avg['n_averaged'] == 2
+    after = m.state_dict()
+    assert all(torch.equal(after[k].cpu().float(), second[k]) for k in second), 'ModelAveraging.state_dict must restore the live weights'
+    moved = 0
+    for k in ('vision_model.encoder.layers.0.attn.qkv.weight', 'mlp1.1.weight', 'language_model.model.layers.0.mlp.down_proj.weight', 'action_expert.model.layers.0.mlp.down_proj.weight'):
+        mid = 0.5 * (first[k] + second[k])                      # decay 0.5: avg = first + (second - first) / 2, from the fp32 masters
+        got = avg['state_dict'][k].float().cpu()
+        assert (got - mid).abs().max().item() <= 2.0 ** -7 * max(1e-3, mid.abs().max().item()), k
+        moved += int(not torch.equal(first[k], second[k]))
+    assert moved == 4
+    r = _trainer(dist.group.WORLD, train_vlm=True)
+    r.load_checkpoint(ck)
+    assert r.step_count == 2
+    r.step([smp])
+    torch.cuda.synchronize()
+    got = r.state_dict()
+    assert all(torch.equal(want[k], got[k].cpu()) for k in want), 'resumed train_vlm run diverged'
+    for w, t in zip(want_state, (r.m, r.v, r.master, r.vg.m, r.vg.v, r.vg.master)):
+        assert torch.equal(w, t.cpu())
     dist.barrier()
     dist.destroy_process_group()
 

@@ -75,7 +75,7 @@ _SIGS = {
     'vlaser_argmax': [vp, i32, i32, vp, vp, vp, i32, vp],
     'vlaser_vla_prep': [vp, vp, vp, vp, i32, i32, i32, f32, f32, vp],
     'vlaser_small_linear': [vp, vp, vp, vp, i32, i32, i32, vp],
-    'vlaser_attn_oproj': [vp, vp, i32, vp, i32, vp],
+    'vlaser_attn_oproj': [C.POINTER(AttnArgs), vp, vp, i32, vp],
     'vlaser_vla_step': [vp, vp, i32, i32, i32, vp, f32, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     'vlaser_vla_euler': [vp, vp, i32, i32, vp, f32, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, vp, i32, i32, vp],
     'vlaser_vla_stage': [C.POINTER(VlaStageArgs), vp],

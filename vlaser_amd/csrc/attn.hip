@@ -297,6 +297,9 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
 // Visibility is uniform over the rows of a batch element: keys [0, lim1) U [lo2, hi2).
 #define SKA_WAVES 4
 __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
+#ifdef VL_KERNARG_UP_FRONT
+  vl_kernargs_up_front(p);
+#endif
   constexpr int HD = 128, DC = 4, DT = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 waves][ m[32] l[32] o[32][128] ] fp32
   const VlaserAttnArgs& a = p.a;

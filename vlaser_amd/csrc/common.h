@@ -68,6 +68,43 @@ __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcp
 __device__ __forceinline__ u32x4 ld_global_16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st_global_16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
+// ---- kernel arguments in ONE scalar-memory round trip.  hipcc issues the s_load of a by-value argument struct piecemeal, where each field is first
+// needed, with an `s_waitcnt lgkmcnt(0)` in front of every first use: the <= 16-row kernels started with 3-6 SERIALISED round trips to the kernarg segment
+// (scalar cache cold at every kernel start) before their first global load went out (r04, read in the ISA: skinny_kernel 4 rounds, attn_oproj 6).
+// Touching every 16-byte piece of the struct in one empty asm statement at the top of the kernel makes the compiler fetch all of it up front, back to back,
+// behind a single wait.  MEASURED (r04f, same-box A/B of the whole chunk): SLOWER, 13.75 vs 12.99 ms -- inside a replayed HIP graph a kernarg line costs only
+// 40-80 ns (tools/micro/kernarg_lab.hip: the graph keeps its arguments in device memory; eager launches with host-resident kernargs pay 1.2 us per
+// line), the burst fetches all 5 lines of a 264-byte struct where the piecemeal code touches what the variant needs and overlaps the rest with address
+// arithmetic.  Kept behind -DVL_KERNARG_UP_FRONT for the record; OFF.
+template <int NQ, class P>
+__device__ __forceinline__ void vl_kernargs_touch(const P& p) {      // the first NQ 16-byte pieces (+ the 0-3 trailing dwords when NQ covers the struct)
+  constexpr int N4 = sizeof(P) / 16, REM = (sizeof(P) % 16) / 4;
+  const u32x4* q = reinterpret_cast<const u32x4*>(&p);
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(&p) + N4 * 4;
+#define VL_KA(i) "s"(q[(i) < N4 ? (i) : N4 - 1])
+  if constexpr (NQ <= 8)
+    asm volatile("" ::VL_KA(0), VL_KA(1), VL_KA(2), VL_KA(3), VL_KA(4), VL_KA(5), VL_KA(6), VL_KA(7), "s"(w[REM > 0 ? 0 : -1]), "s"(w[REM > 1 ? 1 : -1]), "s"(w[REM > 2 ? 2 : -1]));
+  else if constexpr (NQ <= 12)
+    asm volatile("" ::VL_KA(0), VL_KA(1), VL_KA(2), VL_KA(3), VL_KA(4), VL_KA(5), VL_KA(6), VL_KA(7), VL_KA(8), VL_KA(9), VL_KA(10), VL_KA(11),
+                 "s"(w[REM > 0 ? 0 : -1]), "s"(w[REM > 1 ? 1 : -1]), "s"(w[REM > 2 ? 2 : -1]));
+  else if constexpr (NQ <= 14)
+    asm volatile("" ::VL_KA(0), VL_KA(1), VL_KA(2), VL_KA(3), VL_KA(4), VL_KA(5), VL_KA(6), VL_KA(7), VL_KA(8), VL_KA(9), VL_KA(10), VL_KA(11), VL_KA(12), VL_KA(13),
+                 "s"(w[REM > 0 ? 0 : -1]), "s"(w[REM > 1 ? 1 : -1]), "s"(w[REM > 2 ? 2 : -1]));
+  else if constexpr (NQ <= 17)
+    asm volatile("" ::VL_KA(0), VL_KA(1), VL_KA(2), VL_KA(3), VL_KA(4), VL_KA(5), VL_KA(6), VL_KA(7), VL_KA(8), VL_KA(9), VL_KA(10), VL_KA(11), VL_KA(12), VL_KA(13),
+                 VL_KA(14), VL_KA(15), VL_KA(16), "s"(w[REM > 0 ? 0 : -1]), "s"(w[REM > 1 ? 1 : -1]), "s"(w[REM > 2 ? 2 : -1]));
+  else
+    asm volatile("" ::VL_KA(0), VL_KA(1), VL_KA(2), VL_KA(3), VL_KA(4), VL_KA(5), VL_KA(6), VL_KA(7), VL_KA(8), VL_KA(9), VL_KA(10), VL_KA(11), VL_KA(12), VL_KA(13),
+                 VL_KA(14), VL_KA(15), VL_KA(16), VL_KA(17), VL_KA(18), VL_KA(19), VL_KA(20), VL_KA(21), VL_KA(22), "s"(w[REM > 0 ? 0 : -1]), "s"(w[REM > 1 ? 1 : -1]),
+                 "s"(w[REM > 2 ? 2 : -1]));
+#undef VL_KA
+}
+template <class P>
+__device__ __forceinline__ void vl_kernargs_up_front(const P& p) {
+  static_assert(sizeof(P) % 4 == 0 && sizeof(P) <= 23 * 16 + 12, "argument struct: whole dwords, <= 380 bytes");
+  vl_kernargs_touch<sizeof(P) / 16>(p);
+}
+
 // ---- split-K slab reduction: all loads of one call are independent and in flight together (one L2 round trip)
 // sum of the first S (<= NB) fp32 slabs into v; always issues NB independent load pairs (index clamped) -> one trip
 template <int NB>

@@ -230,6 +230,9 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
   constexpr int UE = TPU == 1 ? 5 : 3;          // EARLY: units held in registers at once (16-row units: 1120 / 256 -> 4 or 5 per workgroup)
   constexpr bool EPI16 = (TPU == 1 && EPI == VL_SK_QKV_ROPE);
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef VL_KERNARG_UP_FRONT
+  vl_kernargs_up_front(p);
+#endif
   const VlaserSkinnyArgs& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;

@@ -49,7 +49,9 @@ class QwenLayerWeights:
             else:
                 self.sk_qkv = ops.pack_skinny(wqkv, 1)
             self.sk_o = ops.pack_skinny(wo, ks_o, tpu_o)
-            self.wo_raw = wo.contiguous() if 'fuse_ao' in opts else None      # attention + o_proj in one launch reads W_o as stored
+            # 'fuse_ao' (r04): attention + o_proj in one launch takes W_o fragment-major with one K split per kv head (the consumer sums n_kv slabs)
+            nkv_ = llm.num_key_value_heads
+            self.sk_ao = ops.pack_skinny(wo, nkv_, 1) if ('fuse_ao' in opts and (llm.num_attention_heads // nkv_) in (2, 4, 6, 8)) else None
             # wide output + short K (action expert: 17920 x 768): 96-row units (tpu = 6) measured slower on MI355X (12.3 vs 11.2 us): kept in
             # the kernel, not used; 16-row lane-local units ('gu16', r03) balance 1120 units over 256 workgroups (80 vs 96 rows on the longest)
             if 'gu16' in opts:
@@ -292,11 +294,13 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
     nsp = ops.attn_splits(kv_len)
     fuse = (sync is not None and 'fuse_ogu' in stack.opts and 'gu16' in stack.opts and not skip_post_attn and stack.tpu_o == 1 and stack.ks_o == 3
             and llm.hidden_size == 768 and nq * hd == 1536 and nsp == 7 and M * (llm.hidden_size // 8) <= 512)
-    # 'fuse_ao' (r03): attention + o_proj as ONE launch without any hand-off (csrc/attn_o.hip: every workgroup recomputes its kv group's attention);
+    # 'fuse_ao' (r04 rewrite): attention + o_proj as ONE launch without any hand-off (csrc/attn_o.hip: every workgroup recomputes its kv group's attention
+    # from K / V^T staged in LDS by coalesced LDS-DMA);
     # batch 1, <= 32 (head, token) rows per kv head; the consumer then sums n_kv_heads slabs instead of ks_o
     G_ = nq // nkv
-    fuse_ao = ('fuse_ao' in stack.opts and not fuse and not skip_post_attn and batch == 1 and G_ * tok_per_batch <= 32 and G_ <= 8 and hd == 128
-               and lw.wo_raw is not None and llm.hidden_size % 16 == 0 and nkv <= stack.ks_o and attn_mode in (L.ATTN_FULL, L.ATTN_PREFIX))
+    fuse_ao = ('fuse_ao' in stack.opts and not fuse and not skip_post_attn and getattr(lw, 'sk_ao', None) is not None
+               and ops.attn_oproj_supported(nq, nkv, tok_per_batch, batch, hd, llm.hidden_size) and nkv <= sb.part_o.shape[0]
+               and attn_mode in (L.ATTN_FULL, L.ATTN_PREFIX) and (attn_mode == L.ATTN_FULL or blk_start % 16 == 0))
     key = (layer, M, tok_per_batch, attn_mode, h_in.data_ptr(), 0 if partials is None else partials.data_ptr(), n_partials,
            0 if valid_len is None else valid_len.data_ptr(), pos_ids.data_ptr(), cache.k.data_ptr(), skip_post_attn, first_tok_kv_len,
            sync.data_ptr() if fuse else 0, fuse_ao)
@@ -331,7 +335,7 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
     a.kv_len, a.n_splits, a.blk_start = kv_len, nsp, blk_start
     if fuse_ao:
         if 'attn' not in skip and 'o' not in skip:
-            ops.launch_attn_oproj(a, lw.wo_raw, sb.part_o, llm.hidden_size, stream)
+            ops.launch_attn_oproj(a, lw.sk_ao, sb.part_o, llm.hidden_size, stream)
         if 'gu' not in skip:
             ops.launch_skinny(L.PRO_NORM, L.SK_SWIGLU, plan.gu[0], stream)
         if 'down' not in skip:

@@ -196,10 +196,17 @@ def attn_bwd(q, k, vt, o, d_o, lse, delta_ws, dq, dk, dv, S, n_q, n_kv, s_max, s
                                     dk.data_ptr(), dv.data_ptr(), S, n_q, n_kv, s_max, scale, int(causal), S if kv_valid is None else kv_valid, _stream()), 'vlaser_attn_bwd')
 
 
-def launch_attn_oproj(args, wo, out_f32, N, stream=None):
-    """Attention + o_proj of a <= 16-row layer-step in one launch (csrc/attn_o.hip): `args` = an attn_skinny argument struct (batch 1), `wo` the o_proj
-    weight as stored [N, n_q_heads*128], out_f32 >= n_kv_heads * sq * N fp32 (one partial slab per kv head)."""
-    L.check(L.lib().vlaser_attn_oproj(C.byref(args), wo.data_ptr(), wo.stride(0), out_f32.data_ptr(), N, _stream() if stream is None else stream), 'vlaser_attn_oproj')
+def launch_attn_oproj(args, wo_packed: 'PackedW', out_f32, N, stream=None):
+    """Attention + o_proj of a <= 16-row layer-step in one launch (csrc/attn_o.hip): `args` = an attn_skinny argument struct (batch 1), `wo_packed` =
+    pack_skinny(o_proj.weight, k_splits = n_kv_heads, tpu = 1), out_f32 >= n_kv_heads * sq * N fp32 (one partial slab per kv head)."""
+    assert wo_packed.tpu == 1 and wo_packed.k_splits == args.n_kv_heads and wo_packed.N == N and wo_packed.K == args.n_q_heads * 128
+    L.check(L.lib().vlaser_attn_oproj(C.byref(args), wo_packed.t.data_ptr(), out_f32.data_ptr(), N, _stream() if stream is None else stream), 'vlaser_attn_oproj')
+
+
+def attn_oproj_supported(n_q, n_kv, tok_per_batch, batch, head_dim, hidden):
+    """Geometry the one-launch attention + o_proj kernel is built for (engine.skinny_layer falls back to the two launches otherwise)."""
+    G = n_q // n_kv
+    return batch == 1 and head_dim == 128 and G in (2, 4, 6, 8) and G * tok_per_batch <= 32 and hidden % 16 == 0
 
 
 def attn_splits(kv_len):

@@ -413,7 +413,7 @@ class PiZero:
                 outs.append(self.infer_action(input_ids[lo:hi], pixel_values[lo * ni:hi * ni], sl(image_text_proprio_mask, lo, hi),
                                               sl(action_mask, lo, hi), sl(vlm_position_ids, lo, hi), sl(proprio_position_ids, lo, hi),
                                               sl(action_position_ids, lo, hi), sl(proprios, lo, hi), sl(noise, lo, hi), generator,
-                                              sl(valid_len, lo, hi)))
+                                              sl(valid_len, lo, hi)).clone())      # (each group's result is a view of the output ring)
             return torch.cat(outs, 0)
         if input_ids.shape != (B, T):
             raise ValueError(f'input_ids must be [B,{T}] (right-padded with pad_token_id), got {tuple(input_ids.shape)}')
@@ -434,6 +434,9 @@ class PiZero:
                 with torch.cuda.graph(g):
                     self._run(B)
                 self._graphs[B] = g
+                # the warm-up run integrated the staged noise away (it is staged straight into the Euler phase's start buffer, and the graph holds no
+                # copy of it any more): stage this call's inputs once more in front of the first replay
+                self._stage_inputs(B, input_ids, pixel_values, proprios, noise, valid_len)
             g.replay()
         else:
             self._run(B)

@@ -844,7 +844,7 @@ class SFTModel:
         self.wait_optimizer()
         _, sd = load_hf_checkpoint(path)
         self.load_state_dict(sd)
-        st = torch.load(os.path.join(path, f'optimizer_rank{self.rank:05d}_of_{self.world:05d}.pt'), map_location='cpu', weights_only=False)
+        st = torch.load(os.path.join(path, f'optimizer_rank{self.rank:05d}_of_{self.world:05d}.pt'), map_location='cpu', weights_only=True)
         if st['world'] != self.world or [tuple(x) for x in st['shards']] != [tuple(x) for x in self.shards]:
             raise ValueError(f"optimizer shard was written for world size {st['world']} / another bucket layout")
         self.step_count = st['step_count']

@@ -74,11 +74,23 @@ class ModelAveraging:
         self.ema_start, self.ema_decay, self.ema_freq = ema_start, ema_decay, ema_freq
         self.swa_start, self.swa_freq = swa_start, swa_freq
         self.avg = None
+        self.avg_vlm = None           # train_vlm=True: the reference's AveragedModel wraps the WHOLE PiZero, so the VLM group is averaged too
         self.n_averaged = 0
+
+    def _groups(self):
+        """(flat parameter owner, its average) per trained group: the action expert and, with `train_vlm`, the VLM group (vision tower, projector, VLM
+        decoder layers) -- `AveragedModel(model)` (model_averaging.py:33-44) averages every parameter of the model it wraps."""
+        tr = self.trainer
+        out = [(tr, self.avg)]
+        if getattr(tr, 'vg', None) is not None:
+            out.append((tr.vg, self.avg_vlm))
+        return out
 
     def maybe_initialize(self, cnt_update):
         if (self.use_swa and cnt_update == self.swa_start) or (self.use_ema and cnt_update == self.ema_start):
             self.avg = torch.zeros_like(self.trainer.master)
+            vg = getattr(self.trainer, 'vg', None)
+            self.avg_vlm = torch.zeros_like(vg.master) if vg is not None else None
             self.n_averaged = 0
 
     def maybe_update(self, cnt_update):
@@ -86,25 +98,30 @@ class ModelAveraging:
             return
         if (self.use_ema and cnt_update % self.ema_freq == 0) or (self.use_swa and cnt_update % self.swa_freq == 0):
             c = (1.0 - self.ema_decay) if self.use_ema else 1.0 / (self.n_averaged + 1)
-            ops.avg_update(self.avg, self.trainer.master, c, self.n_averaged == 0)
+            for owner, avg in self._groups():
+                ops.avg_update(avg, owner.master, c, self.n_averaged == 0)
             self.n_averaged += 1
 
     def state_dict(self):
-        """{'state_dict': averaged weights under the canonical VLA key names (bf16), 'n_averaged', 'model_type'} -- {} before the start step."""
+        """{'state_dict': averaged weights under the canonical VLA key names (bf16), 'n_averaged', 'model_type'} -- {} before the start step.
+        Both trained groups carry their average (the VLM group used to be saved un-averaged under an 'ema' / 'swa' label)."""
         if self.avg is None:
             return {}
         tr = self.trainer
-        keep = tr.fp.p.clone()
+        groups = self._groups()
+        keep = [owner.fp.p.clone() for owner, _ in groups]
         try:
-            for (lo, hi, _), o in zip(tr.shards, tr.shard_off):
-                if hi > lo:
-                    tr.fp.p[lo:hi].copy_(self.avg[o:o + hi - lo].to(BF))
-            if tr.dp_active:
-                for b in range(len(tr.buckets)):
-                    dp.all_gather_params(tr.fp.p, tr.buckets[b], tr.shards[b], tr.pg)
+            for owner, avg in groups:
+                for (lo, hi, _), o in zip(owner.shards, owner.shard_off):
+                    if hi > lo:
+                        owner.fp.p[lo:hi].copy_(avg[o:o + hi - lo].to(BF))
+                if tr.dp_active:
+                    for b in range(len(owner.buckets)):
+                        dp.all_gather_params(owner.fp.p, owner.buckets[b], owner.shards[b], tr.pg)
             sd = tr.state_dict()
         finally:
-            tr.fp.p.copy_(keep)
+            for (owner, _), k in zip(groups, keep):
+                owner.fp.p.copy_(k)
         return {'state_dict': sd, 'n_averaged': self.n_averaged, 'model_type': 'ema' if self.use_ema else 'swa'}
 
 
@@ -524,7 +541,11 @@ class VLATrainer:
         if self.rank == 0:
             sd = {k: v for k, v in canonicalize_vla_state_dict(frozen_sd).items() if not k.startswith(('action_expert.model.', 'action_encoder.', 'proprio_encoder.', 'action_decoder.'))}
             sd.update(self.state_dict())
-            save_vla_checkpoint(path, sd, cnt_update=self.step_count, cnt_batch=cnt_batch)
+            # every key the reference's `save_training` writes (train.py:655-670), so that its `load_checkpoint` (reads data["wandb_id"]) works and its
+            # `load_optimizer` fails on a clear None instead of a KeyError: the optimizer state lives in the per-rank shard files below (fp32 masters +
+            # moments of the ZeRO-1 shard -- not torch.optim state dicts)
+            extra = {'action_optimizer': None, 'vlm_optimizer': None, 'action_lr_scheduler': None, 'vlm_lr_scheduler': None, 'wandb_id': None, 'n_averaged': 1}
+            save_vla_checkpoint(path, sd, cnt_update=self.step_count, cnt_batch=cnt_batch, extra=extra)
         st = {'rank': self.rank, 'world': self.world, 'shards': self.shards, 'step_count': self.step_count, 'master': self.master.cpu(),
               'exp_avg': self.m.cpu(), 'exp_avg_sq': self.v.cpu()}
         if self.vg is not None:                      # the VLM group's shard of the second optimiser (train_vlm)
@@ -535,14 +556,14 @@ class VLATrainer:
         """Weights from the reference-layout `.pt`; with `resume_optimizer` also this rank's optimizer shard -- a missing shard file or one
         written for another world size / bucket layout raises (resuming with zero moments would silently change the run).  Pass
         `resume_optimizer=False` to start a fresh optimizer from released weights."""
-        data = torch.load(path, map_location='cpu', weights_only=False)
+        data = torch.load(path, map_location='cpu', weights_only=True)
         self.load_state_dict(data['model'])
         if not resume_optimizer:
             return self
         sp = self._opt_shard_path(path)
         if not os.path.exists(sp):
             raise FileNotFoundError(f'{sp}: no optimizer shard for rank {self.rank} of {self.world} (resume_optimizer=False loads the weights only)')
-        st = torch.load(sp, map_location='cpu', weights_only=False)
+        st = torch.load(sp, map_location='cpu', weights_only=True)        # tensors, ints and tuples only
         if st['world'] != self.world or st['rank'] != self.rank or [tuple(x) for x in st['shards']] != [tuple(x) for x in self.shards]:
             raise ValueError(f"optimizer shard was written for rank {st['rank']} of {st['world']} / another bucket layout")
         self.step_count = st['step_count']
