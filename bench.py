@@ -600,11 +600,13 @@ def _phases(model):
     # the captured chunk graph itself, replayed back to back without any per-call staging: ms_per_step minus this = what infer_action adds around the graph
     gchunk = model._graphs[1]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    gchunk.replay()
+    for g_ in gchunk:
+        g_.replay()
     torch.cuda.synchronize()
     e0.record()
     for _ in range(10):
-        gchunk.replay()
+        for g_ in gchunk:
+            g_.replay()
     e1.record()
     torch.cuda.synchronize()
     chunk_graph = e0.elapsed_time(e1) / 10

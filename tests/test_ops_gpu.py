@@ -139,17 +139,25 @@ def _attn_ref(q, k, v, scale, vis):
     return (s.softmax(-1) @ v.float()).transpose(1, 2).reshape(q.shape[0], q.shape[2], -1)
 
 
-def test_attn_vit_full(ops):
+@pytest.mark.parametrize('T,S', [(2, 1025), (1, 1024), (1, 1040), (1, 1056), (1, 1153), (1, 200), (13, 1025)])
+def test_attn_vit_full(ops, T, S):
+    """InternViT attention (FULL mode, head_dim 64).  S = 1025 = 8 key tiles of 128 + ONE key and 16 workgroups of 64 query rows + ONE row: since r04 the odd key
+    is a 32-key chunk straight from global memory and the odd row's workgroup splits the keys between its waves (csrc/attn.hip, `TAIL`); 1040 / 1056 / 1153 /
+    200 put 16 / 32 / 1 / 8 keys and rows behind the last full tile (with and without the tail paths), 13 tiles at once, the lse output on the tail row."""
     from vlaser_amd import _lib as L
-    T, Hn, S, Sp = 2, 16, 1025, 1088
+    Hn, Sp = 16, (S + 63) // 64 * 64
     q = rnd(T, Hn, Sp, 64, seed=1); k = rnd(T, Hn, Sp, 64, seed=2); v = rnd(T, Hn, Sp, 64, seed=3)
+    k[:, :, S - 1] *= 3.0                                   # the last key matters: a dropped tail would show
     v[:, :, S:] = 0
     vt = v.transpose(-1, -2).contiguous()
     out = torch.zeros(T, S, Hn * 64, dtype=BF, device='cuda')
+    lse = torch.zeros(T, Hn, S, dtype=torch.float32, device='cuda')
     ops.attn_prefill(q, k, vt, out, T, S, S, Hn, Hn, 64, (Hn * Sp * 64, Sp * 64, 64), (Hn * Sp * 64, Sp * 64),
-                     (Hn * 64 * Sp, 64 * Sp), (S * Hn * 64, Hn * 64), Sp, 1.0, L.ATTN_FULL)
+                     (Hn * 64 * Sp, 64 * Sp), (S * Hn * 64, Hn * 64), Sp, 0.125, L.ATTN_FULL, lse_out=lse)
     vis = torch.ones(T, S, S, dtype=torch.bool, device='cuda')
-    close(out, _attn_ref(q[:, :, :S], k[:, :, :S], v[:, :, :S], 1.0, vis), name='vit attn')
+    close(out, _attn_ref(q[:, :, :S], k[:, :, :S], v[:, :, :S], 0.125, vis), name='vit attn')
+    sref = (q[:, :, :S].float() @ k[:, :, :S].float().transpose(-1, -2)) * 0.125
+    close(lse, torch.logsumexp(sref, -1) * 1.4426950408889634, rtol=2e-3, atol=2e-3, name='base-2 log-sum-exp')
 
 
 @pytest.mark.parametrize('S,off', [(336, 0), (70, 0), (130, 40)])

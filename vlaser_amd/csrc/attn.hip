@@ -17,6 +17,8 @@
 //   FULL   : lim1 = kv_len                         (ViT, modeling_intern_vit.py:220-224: no mask)
 //   CAUSAL : lim1 = min(kv_len, i + 1 + causal_off)
 //   PREFIX : lim1 = valid_len[b]; rows >= blk_start additionally see [blk_start, kv_len)
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "../../include/vlaser_hip.h"
@@ -25,6 +27,10 @@
 
 struct AttnP {
   VlaserAttnArgs a;
+  // (r04, FULL mode only) InternViT's 1025th token: 1025 keys = 8 tiles of 128 + ONE key, 1025 queries = 16 workgroups of 64 rows + ONE row.  r03 paid a ninth
+  // key tile through LDS for the one key and a 17th workgroup walking every tile for the one row: 22.5 us against 14.65 us for 1024 tokens (DESIGN lesson 29).
+  int tail_key0;      // >= 0: keys [tail_key0, kv_len) (<= 32) are NOT a tile: every wave takes them as one 32-key chunk straight from global memory
+  int tail_qb;        // >= 0: workgroup tail_qb holds <= 16 query rows: its 4 waves take the same rows and split the key TILES between them
 };
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -46,6 +52,66 @@ __device__ __forceinline__ int vt_lds_off(int row, int slot) {
   else return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
 }
 
+// One 32-key chunk straight from global memory against a wave's 16 query rows (the layout of attn_skinny's chunks: K-tile t row r <-> key
+// key0 + (r >> 2) * 8 + t * 4 + (r & 3)), online softmax state (m, l, o) updated in place.  Keys >= kv_len are masked; loads are clamped.
+template <int HD>
+struct DirectChunk {
+  static constexpr int DC = HD / 32, DT = HD / 16;
+  u32x4 kf[2][DC], vf[DT];
+  __device__ __forceinline__ void load(const bf16_t* K, const bf16_t* VT, int key0, int kv_len, int ld_vt, int fr, int g) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int key = key0 + (fr >> 2) * 8 + t * 4 + (fr & 3);
+#pragma unroll
+      for (int dc = 0; dc < DC; ++dc) kf[t][dc] = ld_global_16(K + (size_t)min(key, kv_len - 1) * HD + dc * 32 + g * 8);
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vf[dt] = ld_global_16(VT + (size_t)(dt * 16 + fr) * ld_vt + min(key0 + g * 8, ld_vt - 8));
+  }
+  __device__ __forceinline__ void process(const bf16x8 (&qf)[DC], int key0, int kv_len, float sc, int g, float& m_run, float& l_run, f32x4 (&o)[DT]) {
+    f32x4 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int dc = 0; dc < DC; ++dc) acc = mfma16(as_bf16x8(kf[t][dc]), qf[dc], acc);
+      s[t] = acc;
+    }
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[t][r] = key0 + g * 8 + t * 4 + r < kv_len ? s[t][r] * sc : NEG_BIG;
+        mx = fmaxf(mx, s[t][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = fast_exp2(m_run - m_new);
+    m_run = m_new;
+    const float meff = fmaxf(m_new, -1.0e20f);             // nothing visible yet: exp2(-1e30 + 1e20) = 0 without a select
+    float pv[8], psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pe = fast_exp2(s[t][r] - meff);
+        psum += pe;
+        pv[t * 4 + r] = pe;
+      }
+    l_run = l_run * alpha + psum;
+    const u32x4 pk = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]), pack_bf16x2(pv[4], pv[5]), pack_bf16x2(pv[6], pv[7])};
+    // V^T columns past the cache row's padding were clamped (duplicates of real keys): their P is exactly 0
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      f32x4 acc = o[dt];
+      acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
+      o[dt] = mfma16(as_bf16x8(vf[dt]), as_bf16x8(pk), acc);
+    }
+  }
+};
+
 // KS = key splits INSIDE the workgroup: KS groups of 4 waves share the 64 query rows, group j walks key tiles j, j+KS, ... through
 // its own K / V^T staging buffers, and group 0 merges the (m, l, o) triples through LDS at the end (fixed order: deterministic).
 // The path's prefill grids are about one 4-wave workgroup per CU (ViT: 17 x 16 = 272, joint prefill 6 x 12 = 72), i.e. one wave
@@ -54,7 +120,7 @@ __device__ __forceinline__ int vt_lds_off(int row, int slot) {
 // TK = keys per tile (64 / 128): with about one workgroup per CU a wave is alone on its SIMD and every tile is a serial chain
 // barrier -> LDS store -> barrier -> S^T -> max (two cross-lane hops) -> exp -> P V; 128-key tiles halve the number of chains
 // per key and give each one twice the independent MFMA / exp work to overlap.
-template <int HD, int KS, int TK>
+template <int HD, int KS, int TK, bool TAIL = false>      // TAIL: the FULL-mode tail handling (p.tail_key0 / p.tail_qb); its own instantiation, so the other shapes do not carry its registers
 __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
   constexpr int DC = HD / 32;   // d-chunks of 32 for S^T
   constexpr int DT = HD / 16;   // d-tiles of 16 for O^T
@@ -72,9 +138,27 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
   char* Ks = smem + grp * TILE_BYTES;
   char* Vs = Ks + TK * HD * 2;
   const int fr = lane & 15, g = lane >> 4;
-  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  // TAIL launches are 1-D per batch element with the workgroups of the <= 16 tail rows LAST (ids >= n_full * heads): found with a lab switch that made those 16
+  // workgroups exit at once -- the launch still took 22.5 us against 14.8 us for 256 workgroups, i.e. the dispatcher hands out CUs round-robin and, with the
+  // light workgroups sprinkled through a 17 x 16 grid, doubles full workgroups up on some CUs while others idle.  All full workgroups first = one per CU
+  // (empty tail workgroups dispatched last: 17.2 us; with their work 21.7 us -- a workgroup that walks a head's 256 KB of K / V beside a full one takes as long
+  // as the full one, however little it computes: profiles/r04m_vit_attention_tail.md).
+  int qb = blockIdx.x, h = blockIdx.y;
+  if constexpr (TAIL) {
+    if (p.tail_qb >= 0) {
+      const int nfull = p.tail_qb * a.n_q_heads;
+      if ((int)blockIdx.x < nfull) { h = blockIdx.x / p.tail_qb; qb = blockIdx.x - h * p.tail_qb; }
+      else { h = blockIdx.x - nfull; qb = p.tail_qb; }
+    }
+  }
+  const int b = blockIdx.z;
   const int kvh = h / (a.n_q_heads / a.n_kv_heads);
-  const int q_row = qb * 64 + wave * 16 + fr;  // this lane's query row (within the batch element)
+  // TAIL: workgroup p.tail_qb holds the LAST <= 16 query rows (FULL mode).  All four of its waves take those same rows and split the key TILES between them
+  // (wave w computes tiles w, w + 4, ...; the staging and its barriers stay cooperative), flash-decoding merge through LDS at the end: a quarter of a full
+  // workgroup's issue slots, so the full workgroup it shares a CU with (272 workgroups on 256 CUs at S = 1025) is slowed far less than by a second full one.
+  // (First built as a workgroup pulling its chunks straight from global memory: latency-bound, as slow as the full workgroups -- profiles/r04l.)
+  const bool tailwg = TAIL && qb == p.tail_qb;
+  const int q_row = qb * 64 + (tailwg ? 0 : wave * 16) + fr;  // this lane's query row (within the batch element)
 
   const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (size_t)b * a.q_bs + (size_t)h * a.q_hs;
   const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (size_t)b * a.k_bs + (size_t)kvh * a.k_hs;
@@ -113,8 +197,12 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
   float m_run = NEG_BIG, l_run = 0.f;
   const float sc = a.scale * 1.4426950408889634f;  // softmax in base 2
 
+  // the <= 32 keys behind the last full tile (FULL mode): requested now as one chunk straight from global memory, folded in after the tile loop
+  DirectChunk<TAIL ? HD : 32> tailc;
+  if constexpr (TAIL) { if (p.tail_key0 >= 0) tailc.load(K, VT, p.tail_key0, a.kv_len, a.ld_vt, fr, g); }
+
   // key-tile schedule: [0, n1) then tiles overlapping [blk_start, kv_len)
-  const int n1 = (blk_lim1 + TK - 1) / TK;
+  const int n1 = (TAIL && p.tail_key0 >= 0) ? p.tail_key0 / TK : (blk_lim1 + TK - 1) / TK;
   int t2_lo = 0, t2_hi = 0;
   if (blk_has2) { t2_lo = max(n1, a.blk_start / TK); t2_hi = (a.kv_len + TK - 1) / TK; }
   const int n_tiles = n1 + max(0, t2_hi - t2_lo);
@@ -234,6 +322,7 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
     __syncthreads();
     load_tile(min(it + KS, n_tiles - 1));                      // unconditional (clamped): a conditional load costs a full vmcnt drain
     if (it >= n_tiles) continue;
+    if (tailwg && (it & 3) != wave) continue;                  // (wave-uniform) the tail workgroup's waves take every fourth tile each
     const int key0 = tile_key0(it);
 
     // a tile every row of this wave sees in full (all interior tiles of FULL / PREFIX, the tiles left of the diagonal of CAUSAL)
@@ -241,6 +330,47 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
     // against 16 MFMAs at head_dim 64), and the masks were 40 % of it
     if (key0 + TK <= wave_lim1) tile_body(key0, std::false_type{});
     else tile_body(key0, std::true_type{});
+  }
+
+  if constexpr (TAIL) { if (p.tail_key0 >= 0 && grp == 0 && (!tailwg || wave == 0)) tailc.process(qf, p.tail_key0, a.kv_len, sc, g, m_run, l_run, o); }
+  if (tailwg) {
+    // merge of the four waves' partial softmax states (same rows, disjoint keys) through LDS, fixed order
+    constexpr int WS = 32 + 16 * HD;
+    __syncthreads();                                           // every wave is done with the staged tiles: the area becomes the merge buffer
+    float* wm = reinterpret_cast<float*>(smem) + wave * WS;
+    {
+      float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+      l_tot += __shfl_xor(l_tot, 32, 64);
+      if (g == 0) { wm[fr] = m_run; wm[16 + fr] = l_tot; }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(wm + 32 + fr * HD + dt * 16 + g * 4) = o[dt];
+    }
+    __syncthreads();
+    constexpr int DPT = HD / 16;                               // head-dim columns per thread: 16 rows x HD over 256 threads
+    const int row = threadIdx.x >> 4, d0 = (threadIdx.x & 15) * DPT;
+    const float* base = reinterpret_cast<const float*>(smem);
+    float M = NEG_BIG;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) M = fmaxf(M, base[w * WS + row]);
+    float L = 0.f, acc[DPT];
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = fast_exp2(base[w * WS + row] - M);
+      L += base[w * WS + 16 + row] * f;
+#pragma unroll
+      for (int j = 0; j < DPT; ++j) acc[j] += base[w * WS + 32 + row * HD + d0 + j] * f;
+    }
+    const int q_out = qb * 64 + row;
+    if (q_out < a.sq) {
+      const float inv = L > 0.f ? 1.0f / L : 0.f;
+      if (a.lse_out && d0 == 0) a.lse_out[((size_t)b * a.n_q_heads + h) * a.sq + q_out] = M + __builtin_amdgcn_logf(L);
+      bf16_t* O = reinterpret_cast<bf16_t*>(a.out) + (size_t)b * a.o_bs + (size_t)q_out * a.o_ss + h * HD + d0;
+#pragma unroll
+      for (int j = 0; j < DPT; j += 2) *reinterpret_cast<uint32_t*>(O + j) = pack_bf16x2(acc[j] * inv, acc[j + 1] * inv);
+    }
+    return;
   }
 
   if constexpr (KS > 1) {
@@ -484,7 +614,7 @@ extern "C" int vlaser_attn_prefill(const VlaserAttnArgs* a, vl_stream_t s) {
   VL_CHECK(a->ld_vt % 64 == 0, "vlaser_attn_prefill: V^T row length must be padded to a multiple of 64 keys");
   VL_CHECK(a->kv_len <= a->ld_vt, "vlaser_attn_prefill: kv_len exceeds cache");
   VL_CHECK(a->sq > 0 && a->batch > 0, "vlaser_attn_prefill: empty");
-  AttnP p; p.a = *a;
+  AttnP p; p.a = *a; p.tail_key0 = -1; p.tail_qb = -1;
   dim3 grid((a->sq + 63) / 64, a->n_q_heads, a->batch);
   // tile / split choice, measured (tools/micro/attn_lab.py, profiles/r02k_attn.md): a 2-way in-workgroup key split pays only when
   // the grid does not even reach one workgroup per CU (joint prefill: 72 workgroups, 11.4 -> 10.8 us); 128-key tiles only for the
@@ -497,12 +627,28 @@ extern "C" int vlaser_attn_prefill(const VlaserAttnArgs* a, vl_stream_t s) {
   int ks = force_ks == 1 || force_ks == 2 ? force_ks : (blocks <= 96 ? 2 : 1);
   const int tk = (a->head_dim == 64 && a->mode == VL_ATTN_FULL && blocks <= 512 && ks == 1) ? 128 : 64;
   if (a->kv_len <= tk) ks = 1;
+  static const int no_tail = getenv("VLASER_ATTN_NO_TAIL") ? atoi(getenv("VLASER_ATTN_NO_TAIL")) : 0;                       // A/B: the r03 schedule
+  if (a->mode == VL_ATTN_FULL && !no_tail && ks == 1) {      // (the 2-way key-split variant at head_dim 128 has no registers to spare for the tail chunk)
+    const int tail = a->kv_len % tk;
+    if (tail >= 1 && tail <= 32 && a->kv_len > tk) p.tail_key0 = a->kv_len - tail;
+    if (a->sq % 64 >= 1 && a->sq % 64 <= 16 && a->sq > 64) p.tail_qb = a->sq / 64;
+  }
+  static const int dbg_attn = getenv("VLASER_ATTN_DEBUG") ? 1 : 0;
+  if (dbg_attn) fprintf(stderr, "attn_prefill: sq %d kv %d hd %d mode %d blocks %ld ks %d tk %d tail_key0 %d tail_qb %d\n", a->sq, a->kv_len, a->head_dim, a->mode, blocks, ks, tk, p.tail_key0, p.tail_qb);
 #define VL_ATTN_LAUNCH(HD_, KS_, TK_)                                                                                       \
   do {                                                                                                                      \
     constexpr int tile = 2 * TK_ * HD_ * 2, merge = (KS_ - 1) * 4 * (HD_ / 16 * 4 + 2) * 256;                                \
-    constexpr int lds = KS_ * tile > merge ? KS_ * tile : merge;                                                            \
-    if (int rc = set_max_lds_once(attn_prefill_kernel<HD_, KS_, TK_>, lds)) return rc;                                      \
-    hipLaunchKernelGGL((attn_prefill_kernel<HD_, KS_, TK_>), grid, dim3(256 * KS_), lds, stream, p);                        \
+    constexpr int tailm = 4 * KS_ * (32 + 16 * HD_) * 4;                                                                    \
+    constexpr int lds0 = KS_ * tile > merge ? KS_ * tile : merge;                                                           \
+    constexpr int lds = lds0 > tailm ? lds0 : tailm;                                                                        \
+    if (p.tail_key0 >= 0 || p.tail_qb >= 0) {                                                                               \
+      if (int rc = set_max_lds_once(attn_prefill_kernel<HD_, KS_, TK_, true>, lds)) return rc;                              \
+      const dim3 tgrid = p.tail_qb >= 0 ? dim3(grid.x * grid.y, 1, grid.z) : grid;                                          \
+      hipLaunchKernelGGL((attn_prefill_kernel<HD_, KS_, TK_, true>), tgrid, dim3(256 * KS_), lds, stream, p);               \
+    } else {                                                                                                                \
+      if (int rc = set_max_lds_once(attn_prefill_kernel<HD_, KS_, TK_>, lds)) return rc;                                    \
+      hipLaunchKernelGGL((attn_prefill_kernel<HD_, KS_, TK_>), grid, dim3(256 * KS_), lds, stream, p);                      \
+    }                                                                                                                       \
   } while (0)
 #define VL_ATTN_PICK(HD_)                                                                                                   \
   do {                                                                                                                      \

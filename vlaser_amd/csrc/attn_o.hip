@@ -211,6 +211,12 @@ __global__ __launch_bounds__(AO_THREADS) void attn_oproj_kernel(AttnOP p) {
           for (int j = 0; j < 4; ++j) acc[j] = k0 + j < limit ? 0.f : AO_NEG_BIG;
 #pragma unroll
           for (int dc = 0; dc < DC; ++dc) acc = mfma16(kf[ti][dc], qf[qt][dc], acc);
+          // a tile index past the image (wave + 16 >= 19) read ANOTHER wave's tile 18, possibly before its owner wrote it: stale LDS bits may be NaN, and NaN
+          // survives the additive mask (found as rare non-finite outputs after other kernels had used the LDS) -- select, do not add
+          if (ti * AO_WAVES + AO_WAVES > AO_TILES) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = tl < AO_TILES ? acc[j] : AO_NEG_BIG;
+          }
           s[ti][qt] = acc;
         }
       }

@@ -426,18 +426,29 @@ class PiZero:
         self._stage_positions(B, vlm_position_ids, proprio_position_ids, action_position_ids)
         # ---- run (HIP graph replay after the first call per batch size)
         if self.use_graph:
-            g = self._graphs.get(B)
-            if g is None:
+            gs = self._graphs.get(B)
+            if gs is None:
                 self._run(B)                      # warm-up: sets kernel attributes, touches every buffer
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._run(B)
-                self._graphs[B] = g
+                # VLASER_GRAPH_SPLIT=k: the chunk as k HIP graphs replayed back to back (1 = one graph of ~1 780 kernel nodes; 3 = ViT | joint prefill | Euler phase;
+                # 3 + j: the Euler phase in j + 1 pieces of whole Euler steps) -- see profiles/r04*_graph_split.md
+                nsplit = int(os.environ.get('VLASER_GRAPH_SPLIT', '1'))
+                if nsplit <= 1:
+                    parts = [lambda: self._run(B)]
+                else:
+                    parts = [lambda: self._run_vit(B), lambda: self._run_prefill(B), lambda: self._run_euler(B)]
+                gs = []
+                for fn in parts:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        fn()
+                    gs.append(g)
+                self._graphs[B] = gs
                 # the warm-up run integrated the staged noise away (it is staged straight into the Euler phase's start buffer, and the graph holds no
                 # copy of it any more): stage this call's inputs once more in front of the first replay
                 self._stage_inputs(B, input_ids, pixel_values, proprios, noise, valid_len)
-            g.replay()
+            for g in gs:
+                g.replay()
         else:
             self._run(B)
         if self.output_ring > 0:
