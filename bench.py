@@ -209,6 +209,24 @@ def sft_bench(rank, world, local, dist, steps, warmup=2):
     labels[0, -R:] = ids[0, -R:]
     pv = torch.randn(1, 3, 448, 448, generator=g).to(dev).to(torch.bfloat16)
     out = None
+    exchange_info = {}
+    if dist is not None:
+        # the first collective of the process builds the communicator (ring / direct choice, xGMI links): its wall time and the RCCL version on the
+        # line let a first 8-GPU run be read without a second one
+        t = torch.ones(1024, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        first_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        try:
+            ver = '.'.join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:          # noqa: BLE001 -- a missing version query must not cost the run
+            ver = f'unavailable ({type(e).__name__})'
+        exchange_info = {'rccl_version': ver, 'first_collective_ms': round(first_ms, 2), 'second_collective_ms': round((time.perf_counter() - t0) * 1e3, 3)}
     for _ in range(warmup):
         out = model.step(pv, ids, labels)
     torch.cuda.synchronize()
@@ -229,15 +247,23 @@ def sft_bench(rank, world, local, dist, steps, warmup=2):
         dt = t.item()
     loss = float(out.loss)
     assert loss == loss, 'SFT loss is NaN'
+    # forward + backward alone (no gradient norm, no AdamW, no exchange): the part of the step an N-GPU ZeRO-1 rank runs unchanged (its AdamW is 1/N)
+    model.wait_optimizer()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.forward_backward(pv, ids, labels)
+    torch.cuda.synchronize()
+    fwd_bwd_ms = (time.perf_counter() - t0) / steps * 1e3
     buckets_mb = [round((hi - lo) * 2 / 2 ** 20) for lo, hi in model.buckets]
     del model
     torch.cuda.empty_cache()
     fl = sft_flops(cfg, S, R - 1 + 1, 1)
     return {'metric': 'sft_tokens_per_sec', 'value': round(world * steps * S / dt, 1), 'unit': 'tokens/s', 'ms_per_step': round(dt / steps * 1e3, 2),
-            'steps': steps, 'tokens_per_rank_step': S, 'last_loss': round(loss, 4),
+            'steps': steps, 'tokens_per_rank_step': S, 'last_loss': round(loss, 4), 'fwd_bwd_ms': round(fwd_bwd_ms, 2),
             'parallelism': f'dp{world} (ZeRO-1: bucketed RCCL reduce-scatter(mean, bf16) issued from the backward + all-gather of updated params)',
             'exchange': {'bucket_mib': buckets_mb, 'NCCL_ALGO': os.environ.get('NCCL_ALGO', 'default'), 'NCCL_PROTO': os.environ.get('NCCL_PROTO', 'default'),
-                         'gradient_bytes_per_rank': 3570e6 if world > 1 else 0},
+                         'gradient_bytes_per_rank': 3570e6 if world > 1 else 0, **exchange_info},
             'gflop_per_rank_step': round(fl / 1e9, 1), 'mfma_frac': round(fl * world * steps / dt / (world * 2.5e15), 4)}
 
 

@@ -71,6 +71,8 @@ typedef struct {
    * VL_EPI_BIAS_GELU, optional (ABI 4): aux_out [M, N] = bf16(acc + bias), the pre-activation GELU's backward needs (the projector's first
    * Linear, modeling_internvl_chat.py:89-94, was evaluated twice in r02: once with BIAS, once with BIAS_GELU); ld_aux % 4 == 0, 8-byte aligned */
   void* aux_out; int ld_aux;
+  /* ABI 5, set by vlaser_gemm_tn_lds only (vlaser_gemm / vlaser_gemm_nn refuse it): see there */
+  float* sumsq_part; int sumsq_cap;
 } VlaserGemmArgs;
 
 int vlaser_gemm(int epi, const VlaserGemmArgs* args, vl_stream_t stream);
@@ -210,12 +212,19 @@ int vlaser_attn_bwd(const void* q, const void* k, const void* vt, const void* o,
 
 /* Weight-gradient GEMM: out[M,N] (bf16) = At^T @ Wt, At [K,M] and Wt [K,N] row-major bf16 (contraction along rows).
  * dW = dY^T X of every nn.Linear on the SFT path (autograd of modeling_internvl_chat.py:194-203): At = dY [S,N_out],
- * Wt = X [S,K_in].  Rows 16-byte aligned and readable up to M / N rounded up to 8 columns (ld >= that). */
-int vlaser_gemm_tn(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, vl_stream_t stream);
+ * Wt = X [S,K_in].  Rows 16-byte aligned and readable up to M / N rounded up to 8 columns (ld >= that).
+ * sumsq_part (ABI 5, optional, NULL = off): float[sumsq_cap]; every (workgroup, wave) of the launch writes the sum of the squares of the bf16 values it
+ * stored into its own slot (slots the launch does not reach are left untouched; which slots it reaches depends on M, N only).  The caller adds the
+ * slots in index order (vlaser_sum_partials): the weight gradient's share of clip_grad_norm_'s global norm (internvl_chat_finetune.py:1041-1057,
+ * max_grad_norm 1.0) without reading the gradient back.  sumsq_cap >= ceil(M/64) * ceil(N/128) * 4 always suffices. */
+int vlaser_gemm_tn(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, float* sumsq_part, int sumsq_cap,
+                   vl_stream_t stream);
 /* The same TN product on the LDS-DMA GEMM pipeline (8 waves, 128x128 .. 256x256 tiles, both operands global -> LDS without staging registers,
  * fragments through the transposing LDS read).  Contract: K is a whole number of 64-row tiles; rows K_true..K of At are ZERO and those of Wt finite
- * (the SFT step pads its sequence axis: sft.py `_wgrad`); ldat, ldwt multiples of 8 and >= M / N rounded up to 8 (rows are read in 16-byte pieces).  force_cfg: 0 = heuristic, or 1100 / 1105 / 1200 / 1300. */
-int vlaser_gemm_tn_lds(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, int force_cfg, vl_stream_t stream);
+ * (the SFT step pads its sequence axis: sft.py `_wgrad`); ldat, ldwt multiples of 8 and >= M / N rounded up to 8 (rows are read in 16-byte pieces).  force_cfg: 0 = heuristic, or 1100 / 1105 / 1200 / 1300.
+ * sumsq_part / sumsq_cap: as for vlaser_gemm_tn; sumsq_cap >= ceil(M/128) * ceil(N/128) * 8 always suffices. */
+int vlaser_gemm_tn_lds(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, int force_cfg, float* sumsq_part,
+                       int sumsq_cap, vl_stream_t stream);
 /* Grouped + batched form: out[b] = sum_{g < groups} At[b, g]^T @ Wt[b, g], run (b, g) starting at At + b*a_bs + g*a_gs (K rows each);
  * grouped-query attention backward: dK[kvh] = sum_g dS[kvh*G+g]^T Q_g, dV[kvh] = sum_g P[kvh*G+g]^T dO_g (HF sdpa/eager autograd). */
 int vlaser_gemm_tn_grouped(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, int groups,
@@ -345,6 +354,16 @@ int vlaser_adamw_clipped(void* param_bf16, float* master, float* m, float* v, co
 int vlaser_grad_accumulate(void* g_bf16, float* acc, long long n, float w, int first, int finalize, vl_stream_t stream);
 /* out[0] += sum of squares of a bf16 buffer (gradient norm); out must be zeroed by the caller */
 int vlaser_sumsq(const void* x, long long n, float* out, float* partial_ws /* float[1024] */, vl_stream_t stream);
+/* ABI 5 -- the global gradient norm of clip_grad_norm_ (internvl_chat_finetune.py:1041-1057, max_grad_norm 1.0) WITHOUT a second pass over the 3.6 GB of
+ * gradients: the weight-gradient GEMMs leave per-wave partial sums (vlaser_gemm_tn[_lds], `sumsq_part`), and
+ *   vlaser_sumsq_chunks: part[c] = sum of squares of x[tab[c][0] .. + tab[c][1])  (tab = int64 [n_chunks][2] on the device; the small tensors: norm
+ *                        weights, biases, the projector), one workgroup per chunk;
+ *   vlaser_sumsq_rows:   the embedding gradient after vlaser_embed_scatter_add: part[i] = sum of squares of row ids[order[i]] of x [vocab, H] when
+ *                        position i of the id-sorted order starts a run of equal ids, else 0; part[n .. cap) = 0;
+ *   vlaser_sum_partials: out[0] = (accumulate ? out[0] : 0) + part[0] + ... + part[n-1], fixed association (deterministic). */
+int vlaser_sumsq_chunks(const void* x, const long long* tab, int n_chunks, float* part, vl_stream_t stream);
+int vlaser_sumsq_rows(const int64_t* ids, const int32_t* order, const void* x, int n, int H, long long vocab, float* part, int cap, vl_stream_t stream);
+int vlaser_sum_partials(const float* part, long long n, float* out, int accumulate, vl_stream_t stream);
 
 /* ---- VLA flow-matching training step: PiZero.forward, pizero_internvl.py:1064-1197; train.py:470-513 -----------
  * SiLU of ActionEncoder.linear_2 (modules.py:45-52) and its backward (x = pre-activation). */

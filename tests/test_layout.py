@@ -108,9 +108,9 @@ def test_bad_arguments_return_errors_not_crashes():
     assert b'1..16' in lib.vlaser_last_error()
     # round-3 entry points: contraction not padded / rows too short for 16-byte pieces
     P = 4096
-    assert lib.vlaser_gemm_tn_lds(P, P, P, 1536, 2048, 100, 1536, 2048, 2048, 0, None) != 0
+    assert lib.vlaser_gemm_tn_lds(P, P, P, 1536, 2048, 100, 1536, 2048, 2048, 0, None, 0, None) != 0
     assert b'multiple of 64' in lib.vlaser_last_error()
-    assert lib.vlaser_gemm_tn_lds(P, P, P, 1002, 2048, 128, 1002, 2048, 2048, 0, None) != 0
+    assert lib.vlaser_gemm_tn_lds(P, P, P, 1002, 2048, 128, 1002, 2048, 2048, 0, None, 0, None) != 0
     assert b'rounded up to 8' in lib.vlaser_last_error()
     # fused attention backward: cache row length not a multiple of 64 / more valid keys than cache rows
     assert lib.vlaser_attn_bwd(P, P, P, P, P, P, P, P, P, P, 70, 12, 2, 100, 0.1, 1, 70, None) != 0

@@ -248,6 +248,95 @@ def test_gemm_tn_lds_padded_contraction(K, M, N, cfg):
     assert (out.float() - out_old.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize('K,M,N,cfg,lds', [(576, 1536, 2048, 0, True), (576, 17920, 1536, 0, True), (320, 1000, 520, 1300, True), (64, 136, 264, 1105, True),
+                                           (128, 2048, 1536, 1200, True), (100, 304, 200, 0, False), (200, 1000, 1528, 0, False)])
+def test_gemm_tn_sumsq_slots(K, M, N, cfg, lds):
+    """`sumsq_part` of the weight-gradient GEMMs (r04): the slots the launch writes add up to the sum of the squares of the bf16 values it stored (the
+    gradient norm's share of the tensor, without reading it back) -- every tile configuration, ragged edges, both kernels; untouched slots stay as
+    they were; too few slots is refused."""
+    from vlaser_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(K + M + N)
+    At = torch.randn(K, M, generator=g).to(BF).cuda(); Wt = torch.randn(K, N, generator=g).to(BF).cuda()
+    out = torch.zeros(M, N, dtype=BF, device='cuda')
+    cap = ops.tn_sumsq_slots(M, N)
+    part = torch.full((cap,), -1.0, device='cuda')
+    if lds:
+        ops.gemm_tn_lds(At, Wt, out, K, force_cfg=cfg, sumsq_part=part)
+    else:
+        L.check(L.lib().vlaser_gemm_tn(At.data_ptr(), Wt.data_ptr(), out.data_ptr(), M, N, K, At.stride(0), Wt.stride(0), out.stride(0), part.data_ptr(), cap, None), 'tn')
+    written = part >= 0
+    assert 0 < int(written.sum()) <= cap
+    want = out.double().pow(2).sum().item()
+    got = part[written].double().sum().item()
+    assert abs(got - want) <= 1e-5 * want, (got, want)
+    tot = torch.zeros(1, device='cuda')
+    part[~written] = 0
+    ops.sum_partials(part, tot, accumulate=False)
+    tot2 = torch.full((1,), 3.0, device='cuda')
+    ops.sum_partials(part, tot2)
+    assert abs(tot.item() - want) <= 1e-5 * want and tot2.item() == (torch.tensor(3.0) + torch.tensor(tot.item())).item()     # out[0] + sum, in fp32
+    with pytest.raises(L.VlaserHipError, match='slots'):
+        if lds:
+            ops.gemm_tn_lds(At, Wt, out, K, force_cfg=cfg, sumsq_part=part[:3])
+        else:
+            L.check(L.lib().vlaser_gemm_tn(At.data_ptr(), Wt.data_ptr(), out.data_ptr(), M, N, K, At.stride(0), Wt.stride(0), out.stride(0), part.data_ptr(), 3, None), 'tn')
+
+
+def test_sumsq_chunks_and_rows():
+    """The small-tensor and embedding-row legs of the producer-side gradient norm: chunk table with unaligned / odd-length chunks; rows of a table
+    listed through the id-sorted order (duplicates counted once, out-of-range ids skipped, the slots past n zeroed)."""
+    from vlaser_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(100_000, generator=g).to(BF).cuda()
+    chunks = [(0, 8192), (8192, 100), (8293, 4097), (20000, 1), (20008, 8192), (99990, 10)]
+    tab = torch.tensor(chunks, dtype=torch.int64, device='cuda')
+    part = torch.full((len(chunks),), -1.0, device='cuda')
+    ops.sumsq_chunks(x, tab, part)
+    for (o, n), p in zip(chunks, part.tolist()):
+        want = x[o:o + n].double().pow(2).sum().item()
+        assert abs(p - want) <= 1e-5 * want + 1e-12, (o, n, p, want)
+    V, H, n = 500, 64, 40
+    table = torch.randn(V, H, generator=g).to(BF).cuda()
+    ids = torch.randint(0, V, (n,), generator=g)
+    ids[5] = ids[17] = ids[3]; ids[9] = 10 ** 6
+    ids = ids.cuda()
+    order = torch.sort(ids, stable=True).indices.to(torch.int32)
+    rp = torch.full((48,), -1.0, device='cuda')
+    L.check(L.lib().vlaser_sumsq_rows(ids.data_ptr(), order.data_ptr(), table.data_ptr(), n, H, V, rp.data_ptr(), 48, None), 'rows')
+    uniq = [i for i in torch.unique(ids).tolist() if 0 <= i < V]
+    want = table[uniq].double().pow(2).sum().item()
+    assert (rp[n:] == 0).all() and int((rp[:n] > 0).sum()) == len(uniq)
+    assert abs(rp.double().sum().item() - want) <= 1e-5 * want
+
+
+def test_step_norm_from_producers_matches_buffer_norm(setup, monkeypatch):
+    """r04: on one rank with one sample per step the gradient norm is assembled from the weight-gradient GEMM epilogues, the touched embedding rows and
+    a chunk pass over the small tensors instead of re-reading the gradient buffer.  Same step with VLASER_SFT_NO_FUSED_NORM=1 (the buffer pass): the
+    norms agree to fp32 summation order, the updated parameters to the clip factor's last bit; the producer path is deterministic."""
+    from vlaser_amd.sft import SFTModel
+    cfg, sd, _, pv, ids, labels, _ = setup
+
+    def run(fused):
+        monkeypatch.setenv('VLASER_SFT_NO_FUSED_NORM', '0' if fused else '1')
+        m = SFTModel(cfg, max_seq_len=ids.shape[1], lr=1e-3, weight_decay=0.05, max_grad_norm=1.0)
+        m.load_state_dict(sd)
+        outs = [m.step(pv, ids, labels) for _ in range(3)]
+        m.wait_optimizer()
+        assert (getattr(m, 'norm_parts', None) is not None) == fused
+        return [o.grad_norm.item() for o in outs], [o.loss.item() for o in outs], {k: v.clone() for k, v in m.state_dict().items()}
+
+    na, la, pa = run(True)
+    nb, lb, pb = run(False)
+    nc, lc, pc = run(True)
+    assert na == nc and la == lc and all(torch.equal(pa[k], pc[k]) for k in pa), 'the producer-side norm is not deterministic'
+    assert la[0] == lb[0]
+    for a, b in zip(na, nb):
+        assert abs(a - b) <= 2e-5 * b, (na, nb)
+    for k in pa:
+        d = (pa[k].float() - pb[k].float()).abs().max().item()
+        assert d <= 2e-2 * pb[k].float().abs().max().item() + 1e-6, (k, d)
+
+
 def test_gemm_tn_lds_ragged_output_rows():
     """The lm_head weight gradient's shape class: M (= vocabulary rows of dW) not a multiple of 8, the operand a column-view of a wider buffer whose
     rows cover M rounded up to 8 (16-byte pieces are read whole, rows >= M of the result are dropped); through ops.gemm_tn's routing."""

@@ -16,7 +16,7 @@ class GemmArgs(C.Structure):
                 ('rope_cos', vp), ('rope_sin', vp), ('pos_ids', vp), ('n_q_heads', i32), ('n_kv_heads', i32),
                 ('s_max', i32), ('tok_per_batch', i32), ('slot_base', i32), ('vq', vp), ('vk', vp), ('vvt', vp),
                 ('vit_heads', i32), ('vit_seq', i32), ('vit_seq_pad', i32), ('q_scale', f32), ('out_f32', vp), ('k_splits', i32),
-                ('force_bm', i32), ('batch', i32), ('a_bs', i64), ('w_bs', i64), ('o_bs', i64), ('w_group', i32), ('aux_out', vp), ('ld_aux', i32)]
+                ('force_bm', i32), ('batch', i32), ('a_bs', i64), ('w_bs', i64), ('o_bs', i64), ('w_group', i32), ('aux_out', vp), ('ld_aux', i32), ('sumsq_part', vp), ('sumsq_cap', i32)]
 
 
 class AttnArgs(C.Structure):
@@ -85,8 +85,8 @@ _SIGS = {
     'vlaser_avg_update': [vp, vp, i64, f32, i32, vp],
     'vlaser_ce_rows': [vp, vp, i32, i32, i64, vp, vp, i64, vp],
     'vlaser_reduce_norm': [vp, vp, i32, vp, vp, i32, vp, vp, f32, vp, vp, i32, i32, vp],
-    'vlaser_gemm_tn': [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
-    'vlaser_gemm_tn_lds': [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    'vlaser_gemm_tn': [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp],
+    'vlaser_gemm_tn_lds': [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp],
     'vlaser_gemm_tn_grouped': [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, i64, i32, i64, i64, i64, vp],
     'vlaser_attn_bwd_pds': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     'vlaser_transpose': [vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i32, i64, i64, vp],
@@ -103,6 +103,9 @@ _SIGS = {
     'vlaser_gelu_bwd': [vp, vp, vp, i64, vp],
     'vlaser_adamw': [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, i32, vp],
     'vlaser_sumsq': [vp, i64, vp, vp, vp],
+    'vlaser_sumsq_chunks': [vp, vp, i32, vp, vp],
+    'vlaser_sumsq_rows': [vp, vp, vp, i32, i32, i64, vp, i32, vp],
+    'vlaser_sum_partials': [vp, i64, vp, i32, vp],
     'vlaser_adamw_clipped': [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, i32, vp],
     'vlaser_grad_accumulate': [vp, vp, i64, f32, i32, i32, vp],
     'vlaser_silu': [vp, vp, i64, vp],

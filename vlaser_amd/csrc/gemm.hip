@@ -336,8 +336,12 @@ __device__ __forceinline__ void epilogue_tile_swiglu_bwd(const VlaserGemmArgs& a
 // 7.7 us of a 24.5 us launch, one L2 round trip per fragment).  Here the common case -- the tile's columns all inside N, rows
 // clamped instead of branched on -- is straight-line: NT bias / layer-scale vectors and MT x NT residual vectors are requested
 // up front as 8-byte loads, the math is branch-free, only the stores are predicated.
-template <int EPI, int MT, int NT>
-__device__ __forceinline__ void epilogue_tile(const VlaserGemmArgs& a, int m_w, int n_w, int fr, int fq, f32x4 (&acc)[NT][MT]) {
+// SSQ (r04, the TN weight-gradient form only): also returns this lane's sum of the squares of the bf16 values it STORED -- the gradient norm's
+// share of this tile, so that the 3.6 GB gradient buffer is not read back for it (sft.py `_norm_bucket`).
+template <int EPI, int MT, int NT, bool SSQ = false>
+__device__ __forceinline__ float epilogue_tile(const VlaserGemmArgs& a, int m_w, int n_w, int fr, int fq, f32x4 (&acc)[NT][MT]) {
+  static_assert(!SSQ || EPI == VL_EPI_NONE, "the sum of squares is taken of the plain bf16 output");
+  float ssq = 0.f;
   constexpr bool HAS_BIAS = (EPI == VL_EPI_BIAS || EPI == VL_EPI_BIAS_GELU || EPI == VL_EPI_BIAS_LS_RES);
   constexpr bool HAS_RES = (EPI == VL_EPI_BIAS_LS_RES || EPI == VL_EPI_RES);
   const bf16_t* bias = reinterpret_cast<const bf16_t*>(a.bias);
@@ -352,8 +356,19 @@ __device__ __forceinline__ void epilogue_tile(const VlaserGemmArgs& a, int m_w, 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) epilogue<EPI>(a, m_w + mt * 16 + fr, n_w + nt * 16 + fq * 4, acc[nt][mt], acc[nt][mt]);
-    return;
+      for (int nt = 0; nt < NT; ++nt) {
+        epilogue<EPI>(a, m_w + mt * 16 + fr, n_w + nt * 16 + fq * 4, acc[nt][mt], acc[nt][mt]);
+        if constexpr (SSQ) {
+          if (m_w + mt * 16 + fr < a.M) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float r = bf16_to_f32(f32_to_bf16(acc[nt][mt][j]));
+              if (n_w + nt * 16 + fq * 4 + j < a.N) ssq += r * r;
+            }
+          }
+        }
+      }
+    return ssq;
   }
   u32x2 bv[NT], lv[NT];
 #pragma unroll
@@ -393,6 +408,13 @@ __device__ __forceinline__ void epilogue_tile(const VlaserGemmArgs& a, int m_w, 
     if (m < a.M) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<u32x2*>(out + row + n_w + nt * 16 + fq * 4) = pk[nt];
+      if constexpr (SSQ) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float r0 = bf16lo_to_f32(pk[nt][0]), r1 = bf16hi_to_f32(pk[nt][0]), r2 = bf16lo_to_f32(pk[nt][1]), r3 = bf16hi_to_f32(pk[nt][1]);
+          ssq += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+        }
+      }
       if constexpr (EPI == VL_EPI_BIAS_GELU) {
         if (a.aux_out) {                                   // SFT forward of the projector: the rounded pre-activations for GELU's backward (aux rows 8-byte aligned)
           bf16_t* aux = reinterpret_cast<bf16_t*>(a.aux_out) + (size_t)m * a.ld_aux + n_w + fq * 4;
@@ -402,6 +424,7 @@ __device__ __forceinline__ void epilogue_tile(const VlaserGemmArgs& a, int m_w, 
       }
     }
   }
+  return ssq;
 }
 
 template <int EPI, int BM>
@@ -723,6 +746,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
     if (ea.out_f32) ea.out_f32 += (size_t)bz * a.o_bs;
     if (ea.res) ea.res = reinterpret_cast<const char*>(ea.res) + (size_t)bz * a.o_bs * 2;
   }
+  if constexpr (EPI == VL_EPI_NONE && AKM) {           // the weight-gradient form: optionally this wave's share of the gradient norm (one slot per wave,
+    const float ssq = epilogue_tile<EPI, MT, NT, true>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc);      // no atomics: the caller sums the slots in order)
+    if (a.sumsq_part) {
+      const float w = wave_sum(ssq);
+      if (lane == 0) a.sumsq_part[(size_t)(blockIdx.x + gridDim.x * blockIdx.z) * NW + wave] = w;
+    }
+    return;
+  }
   if constexpr (EPI == VL_EPI_NONE || EPI == VL_EPI_BIAS || EPI == VL_EPI_BIAS_GELU || EPI == VL_EPI_BIAS_LS_RES || EPI == VL_EPI_RES) {
     epilogue_tile<EPI, MT, NT>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc);
     return;
@@ -760,6 +791,11 @@ static int launch_glds(const VlaserGemmArgs* args, hipStream_t stream, int split
   p.tiles_n = (args->N + BNT - 1) / BNT;
   constexpr int lds = NST * (BM + BNT) * 128;
   static_assert(lds <= 160 * 1024, "stage ring exceeds the 160 KiB LDS of a CU");
+  if (args->sumsq_part) {
+    VL_CHECK(EPI == VL_EPI_NONE && AKM && splits == 1, "sumsq_part: only the TN weight-gradient form (vlaser_gemm_tn_lds) sums its output's squares");
+    const long long need = (long long)p.tiles_m * p.tiles_n * (args->batch > 1 ? args->batch : 1) * WM * WN;
+    VL_CHECK(args->sumsq_cap >= need, "sumsq_part: %d slots given, this launch writes %lld (workgroups x waves)", args->sumsq_cap, need);
+  }
   if (int rc = set_max_lds_once(gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM>, lds)) return rc;
   hipLaunchKernelGGL((gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM>), dim3(p.tiles_m * p.tiles_n, splits, args->batch > 1 ? args->batch : 1),
                      dim3(WM * WN * 64), lds, stream, p);
@@ -889,6 +925,7 @@ struct GemmTnP {
   // grouped contraction: the K rows are `groups` runs of K rows each (run g starts at At + g*a_gs / Wt + g*w_gs), summed into
   // one output -- dK / dV of grouped-query attention sum over the q heads of a kv group; batch (blockIdx.z) = kv heads
   int groups; long long a_gs, w_gs, a_bs, w_bs, o_bs;
+  float* sumsq_part;       // optional: one slot per (workgroup, wave) = the sum of the squares of the bf16 values that wave stored
 };
 
 template <int BM>
@@ -991,6 +1028,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnP p) {
   }
   if (kt < nk) kstep(kt, 1);
 
+  float ssq = 0.f;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m0 + wr * WTM + mt * 16 + fr;
@@ -1001,28 +1039,43 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnP p) {
       bf16_t* o = p.out + (size_t)blockIdx.z * p.o_bs + (size_t)m * p.ldo + n;
       const f32x4 v = acc[nt][mt];
       if (n + 3 < p.N && (p.ldo & 3) == 0) {
-        *reinterpret_cast<u32x2*>(o) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        const u32x2 pk = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(o) = pk;
+        const float r0 = bf16lo_to_f32(pk[0]), r1 = bf16hi_to_f32(pk[0]), r2 = bf16lo_to_f32(pk[1]), r3 = bf16hi_to_f32(pk[1]);
+        ssq += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (n + j < p.N) o[j] = f32_to_bf16(v[j]);
+          if (n + j < p.N) {
+            const bf16_t b = f32_to_bf16(v[j]);
+            o[j] = b;
+            const float r = bf16_to_f32(b);
+            ssq += r * r;
+          }
       }
     }
   }
+  if (p.sumsq_part) {
+    const float w = wave_sum(ssq);
+    if (lane == 0) p.sumsq_part[(size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 4 + wave] = w;
+  }
 }
 
-extern "C" int vlaser_gemm_tn_grouped(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, int groups,
-                                      long long a_gs, long long w_gs, int batch, long long a_bs, long long w_bs, long long o_bs, vl_stream_t s) {
+static int gemm_tn_launch(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, int groups,
+                          long long a_gs, long long w_gs, int batch, long long a_bs, long long w_bs, long long o_bs, float* sumsq_part, int sumsq_cap, vl_stream_t s) {
   VL_CHECK(At && Wt && out && M >= 8 && N >= 8 && K > 0 && groups >= 1 && batch >= 1, "vlaser_gemm_tn: bad arguments (M, N >= 8)");
   VL_CHECK(ldat % 8 == 0 && ldwt % 8 == 0 && (((uintptr_t)At | (uintptr_t)Wt) & 15) == 0 && ((a_gs | w_gs | a_bs | w_bs) & 7) == 0,
            "vlaser_gemm_tn: operands must be 16-byte aligned rows / group / batch strides");
   VL_CHECK(ldat >= ((M + 7) & ~7) && ldwt >= ((N + 7) & ~7), "vlaser_gemm_tn: operand rows must be readable up to M, N rounded up to 8 columns");
-  GemmTnP p{(const bf16_t*)At, (const bf16_t*)Wt, (bf16_t*)out, M, N, K, ldat, ldwt, ldo, 0, (N + BN - 1) / BN, groups, a_gs, w_gs, a_bs, w_bs, o_bs};
+  GemmTnP p{(const bf16_t*)At, (const bf16_t*)Wt, (bf16_t*)out, M, N, K, ldat, ldwt, ldo, 0, (N + BN - 1) / BN, groups, a_gs, w_gs, a_bs, w_bs, o_bs, sumsq_part};
   hipStream_t stream = reinterpret_cast<hipStream_t>(s);
   constexpr int lds64 = 2 * (64 * (64 * 2 + 32) + 64 * (BN * 2 + 32)), lds128 = 2 * (64 * (128 * 2 + 32) + 64 * (BN * 2 + 32));
   if (int rc = set_max_lds_once(gemm_tn_kernel<64>, lds64)) return rc;
   if (int rc = set_max_lds_once(gemm_tn_kernel<128>, lds128)) return rc;
   const bool big = ((M + 127) / 128) * p.tiles_n * batch >= 512;      // measured: 128-row tiles win on the big weight gradients only
+  p.tiles_m = big ? (M + 127) / 128 : (M + 63) / 64;
+  VL_CHECK(!sumsq_part || sumsq_cap >= (long long)p.tiles_m * p.tiles_n * batch * 4, "vlaser_gemm_tn: %d sumsq slots given, this launch writes %lld (workgroups x 4 waves)",
+           sumsq_cap, (long long)p.tiles_m * p.tiles_n * batch * 4);
   if (big) {
     p.tiles_m = (M + 127) / 128;
     hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(p.tiles_m * p.tiles_n, 1, batch), dim3(256), lds128, stream, p);
@@ -1034,14 +1087,21 @@ extern "C" int vlaser_gemm_tn_grouped(const void* At, const void* Wt, void* out,
   return 0;
 }
 
-extern "C" int vlaser_gemm_tn(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, vl_stream_t s) {
-  return vlaser_gemm_tn_grouped(At, Wt, out, M, N, K, ldat, ldwt, ldo, 1, 0, 0, 1, 0, 0, 0, s);
+extern "C" int vlaser_gemm_tn_grouped(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, int groups,
+                                      long long a_gs, long long w_gs, int batch, long long a_bs, long long w_bs, long long o_bs, vl_stream_t s) {
+  return gemm_tn_launch(At, Wt, out, M, N, K, ldat, ldwt, ldo, groups, a_gs, w_gs, batch, a_bs, w_bs, o_bs, nullptr, 0, s);
+}
+
+extern "C" int vlaser_gemm_tn(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, float* sumsq_part, int sumsq_cap,
+                              vl_stream_t s) {
+  return gemm_tn_launch(At, Wt, out, M, N, K, ldat, ldwt, ldo, 1, 0, 0, 1, 0, 0, 0, sumsq_part, sumsq_cap, s);
 }
 
 // The TN form on the LDS-DMA pipeline (r03): same result as vlaser_gemm_tn when the contraction axis is PADDED -- K is a whole number of 64-row tiles,
 // the rows K_true..K of At are zero and those of Wt finite (the SFT step keeps its activations in buffers of ceil64(S) rows and zeroes the pad rows
 // of the dY operands once per backward).  No staging registers, no ds_write pass, 8 waves on 128x128 .. 256x256 tiles.
-extern "C" int vlaser_gemm_tn_lds(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, int force_cfg, vl_stream_t s) {
+extern "C" int vlaser_gemm_tn_lds(const void* At, const void* Wt, void* out, int M, int N, int K, int ldat, int ldwt, int ldo, int force_cfg, float* sumsq_part,
+                                  int sumsq_cap, vl_stream_t s) {
   VL_CHECK(At && Wt && out && M > 0 && N > 0 && K > 0, "vlaser_gemm_tn_lds: bad args");
   VL_CHECK(K % BK == 0, "vlaser_gemm_tn_lds: K=%d must be a multiple of %d (pad the contraction axis: zero rows in At)", K, BK);
   VL_CHECK(ldat % 8 == 0 && ldwt % 8 == 0 && ldat >= ((M + 7) & ~7) && ldwt >= ((N + 7) & ~7) && ldo >= N,
@@ -1051,6 +1111,7 @@ extern "C" int vlaser_gemm_tn_lds(const void* At, const void* Wt, void* out, int
   a.A = At; a.W = Wt; a.out = out;
   a.M = M; a.N = N; a.K = K; a.lda = ldat; a.ldw = ldwt; a.ldo = ldo;
   a.k_splits = 1; a.force_bm = force_cfg;
+  a.sumsq_part = sumsq_part; a.sumsq_cap = sumsq_cap;
   return launch<VL_EPI_NONE, true, true>(&a, reinterpret_cast<hipStream_t>(s));
 }
 
@@ -1060,6 +1121,7 @@ extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   VL_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "vlaser_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
   VL_CHECK(a->K % BK == 0, "vlaser_gemm: K=%d must be a multiple of %d", a->K, BK);
   VL_CHECK(a->batch <= 1 || (epi == VL_EPI_NONE || epi == VL_EPI_F32 || epi == VL_EPI_BIAS), "vlaser_gemm: batched mode supports NONE / F32 / BIAS epilogues");
+  VL_CHECK(!a->sumsq_part, "vlaser_gemm: sumsq_part is honoured by vlaser_gemm_tn_lds only");
   VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 || a->force_bm == 1564 || a->force_bm == 1532 || a->force_bm == 1900,
            "vlaser_gemm: force_bm must be 0/32/64/128 or an LDS-DMA configuration code 1100/1105/1200/1300/1440/1500/1506/1532/1564/1900");
   VL_CHECK(a->lda % 8 == 0 && a->ldw % 8 == 0, "vlaser_gemm: lda/ldw must be multiples of 8 (16-byte rows)");
@@ -1105,6 +1167,7 @@ extern "C" int vlaser_gemm_nn(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
                a->force_bm == 1532 || a->force_bm == 1900,
            "vlaser_gemm_nn: force_bm must be 0 or an LDS-DMA configuration code 1100/1105/1200/1300/1440/1500/1506/1532/1900");
   VL_CHECK(a->batch <= 1 || epi == VL_EPI_NONE || epi == VL_EPI_F32, "vlaser_gemm_nn: batched mode supports the NONE / F32 epilogues");
+  VL_CHECK(!a->sumsq_part, "vlaser_gemm_nn: sumsq_part is honoured by vlaser_gemm_tn_lds only");
   switch (epi) {
     case VL_EPI_NONE: VL_CHECK(a->out, "out null"); return launch<VL_EPI_NONE, true>(a, stream);
     case VL_EPI_F32: VL_CHECK(a->out, "out null"); return launch<VL_EPI_F32, true>(a, stream);

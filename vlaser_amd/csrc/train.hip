@@ -719,6 +719,91 @@ extern "C" int vlaser_sumsq(const void* x, long long n, float* out, float* parti
   return 0;
 }
 
+// ---- the gradient norm without a second pass over the gradients (r04; sft.py `_norm_bucket`): the weight-gradient GEMMs leave one partial sum per
+// (workgroup, wave) in a slot array (gemm.hip, `sumsq_part`); the small tensors (norm weights, biases, the projector) are summed chunk by chunk, the
+// embedding table row by row over the rows this step touched; ONE workgroup then adds a bucket's slots in a fixed order: deterministic, and
+// clip_grad_norm_'s sqrt(sum g^2) (internvl_chat_finetune.py:1041-1057, max_grad_norm 1.0) up to fp32 summation order.
+// part[c] = sum of squares of x[tab[c][0] .. + tab[c][1]) -- one workgroup per chunk
+__global__ __launch_bounds__(256) void sumsq_chunks_kernel(const bf16_t* __restrict__ x, const long long* __restrict__ tab, float* __restrict__ part) {
+  __shared__ float red[4];
+  const long long off = tab[2 * blockIdx.x], n = tab[2 * blockIdx.x + 1];
+  const bf16_t* p = x + off;
+  float acc = 0.f;
+  if (((uintptr_t)p & 15) == 0) {
+    const long long n8 = n >> 3;
+    for (long long i = threadIdx.x; i < n8; i += 256) {
+      const u32x4 v = reinterpret_cast<const u32x4*>(p)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float lo = bf16lo_to_f32(v[j]), hi = bf16hi_to_f32(v[j]); acc += lo * lo + hi * hi; }
+    }
+    for (long long i = (n8 << 3) + threadIdx.x; i < n; i += 256) { const float v = bf16_to_f32(p[i]); acc += v * v; }
+  } else {
+    for (long long i = threadIdx.x; i < n; i += 256) { const float v = bf16_to_f32(p[i]); acc += v * v; }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+extern "C" int vlaser_sumsq_chunks(const void* x, const long long* tab, int n_chunks, float* part, vl_stream_t s) {
+  VL_CHECK(x && tab && part && n_chunks > 0, "vlaser_sumsq_chunks: bad args (tab = int64 [n_chunks][2] = element offset, length; part = float[n_chunks])");
+  hipLaunchKernelGGL(sumsq_chunks_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, tab, part);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+// the embedding gradient after vlaser_embed_scatter_add: position i of the id-sorted order that STARTS a run of equal ids owns that id's row
+// (a row no text position wrote is still zero from the step's clear); every other slot of part[0 .. cap) is set to 0.  H % 8 == 0.
+__global__ __launch_bounds__(256) void sumsq_rows_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ order, const bf16_t* __restrict__ x, int n, int H,
+                                                         long long vocab, float* __restrict__ part) {
+  __shared__ float red[4];
+  const int i = blockIdx.x;
+  float acc = 0.f;
+  if (i < n) {
+    const int64_t id = ids[order[i]];
+    const bool head = (i == 0 || ids[order[i - 1]] != id) && id >= 0 && id < vocab;
+    if (head) {
+      const u32x4* p = reinterpret_cast<const u32x4*>(x + (size_t)id * H);
+      for (int c = threadIdx.x; c < H / 8; c += 256) {
+        const u32x4 v = p[c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float lo = bf16lo_to_f32(v[j]), hi = bf16hi_to_f32(v[j]); acc += lo * lo + hi * hi; }
+      }
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[i] = red[0] + red[1] + red[2] + red[3];
+}
+extern "C" int vlaser_sumsq_rows(const int64_t* ids, const int32_t* order, const void* x, int n, int H, long long vocab, float* part, int cap, vl_stream_t s) {
+  VL_CHECK(ids && order && x && part && n > 0 && cap >= n && H % 8 == 0 && vocab > 0 && ((uintptr_t)x & 15) == 0,
+           "vlaser_sumsq_rows: bad args (order = the positions sorted by id, as for vlaser_embed_scatter_add; part = float[cap], cap >= n; H %% 8 == 0)");
+  hipLaunchKernelGGL(sumsq_rows_kernel, dim3(cap), dim3(256), 0, (hipStream_t)s, ids, order, (const bf16_t*)x, n, H, vocab, part);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+// out[0] (+)= part[0] + part[1] + ... in a fixed association: thread t adds the slots t, t + 1024, ... in order, then a fixed tree over the threads
+__global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restrict__ part, long long n, float* __restrict__ out, int accumulate) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 1024) acc += part[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    out[0] = accumulate ? out[0] + t : t;
+  }
+}
+extern "C" int vlaser_sum_partials(const float* part, long long n, float* out, int accumulate, vl_stream_t s) {
+  VL_CHECK(part && out && n > 0, "vlaser_sum_partials: bad args");
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, part, n, out, accumulate);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- SiLU (ActionEncoder.linear_2, modules.py:45-52)
 __global__ __launch_bounds__(256) void silu_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long long n) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = f32_to_bf16(silu(bf16_to_f32(x[i])));

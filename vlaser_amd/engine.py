@@ -162,8 +162,9 @@ class VitEngine:
         self.part = torch.zeros(ops.split_slab_elems(T * S, C), dtype=torch.float32, device=dev)      # split-K slabs of proj / fc2
         self.max_tiles = T
 
-    def forward(self, pixel_values, return_layers=False):
-        """pixel_values bf16 [T,3,448,448] -> projected visual tokens bf16 [T*256, H_llm] (view into a workspace)."""
+    def forward(self, pixel_values, return_layers=False, project=True):
+        """pixel_values bf16 [T,3,448,448] -> projected visual tokens bf16 [T*256, H_llm] (view into a workspace).  `project=False` stops after the
+        encoder (last hidden state in `self.h`): the SFT step runs the trainable projector itself, keeping the intermediates its backward needs."""
         v, cfg = self.v, self.cfg
         T = pixel_values.shape[0]
         assert pixel_values.dtype == BF and pixel_values.is_contiguous() and pixel_values.shape[1:] == (3, v.image_size, v.image_size)
@@ -198,6 +199,8 @@ class VitEngine:
                             norm_w=nxt['n1w'] if nxt else None, norm_b=nxt['n1b'] if nxt else None, eps=v.layer_norm_eps)
             if return_layers:
                 layers_out.append(h.clone())
+        if not project:
+            return layers_out if return_layers else None
         n_tok = T * cfg.num_image_token
         G = v.image_size // v.patch_size
         ops.pixel_shuffle_ln(h, self.m0w, self.m0b, self.psln, T, G, C, 1e-5, 1 if cfg.ps_version == 'v1' else 0)

@@ -580,25 +580,54 @@ def avg_update(avg, p, c, first):
 _TN_LDS = os.environ.get('VLASER_TN_LDS', '1') == '1'
 
 
-def gemm_tn(At, Wt, out, K=None):
-    """out[M,N] = At[:K]^T @ Wt[:K] (bf16): At [K,M], Wt [K,N] row-major views (row strides honoured)."""
+def _ssq(part):
+    """(pointer, capacity) of an optional fp32 slot array for the per-wave sums of squares a weight-gradient GEMM leaves behind."""
+    if part is None:
+        return None, 0
+    assert part.dtype == torch.float32 and part.is_contiguous()
+    return part.data_ptr(), part.numel()
+
+
+def gemm_tn(At, Wt, out, K=None, sumsq_part=None):
+    """out[M,N] = At[:K]^T @ Wt[:K] (bf16): At [K,M], Wt [K,N] row-major views (row strides honoured).  `sumsq_part`: see gemm_tn_lds."""
     K = At.shape[0] if K is None else K
     M, N = At.shape[1], Wt.shape[1]
     c8 = lambda n: (n + 7) // 8 * 8
     if K % 64 == 0 and At.stride(0) >= c8(M) and Wt.stride(0) >= c8(N) and At.stride(0) % 8 == 0 and Wt.stride(0) % 8 == 0 \
             and (At.data_ptr() | Wt.data_ptr()) % 16 == 0 and M * N >= 128 * 128 and _TN_LDS:       # ragged M / N: rows must be readable up to the next multiple of 8
-        return gemm_tn_lds(At, Wt, out, K)          # whole 64-row tiles: nothing to pad, the LDS-DMA pipeline applies as is
-    L.check(L.lib().vlaser_gemm_tn(At.data_ptr(), Wt.data_ptr(), out.data_ptr(), M, N, K, At.stride(0), Wt.stride(0), out.stride(0), _stream()),
+        return gemm_tn_lds(At, Wt, out, K, sumsq_part=sumsq_part)          # whole 64-row tiles: nothing to pad, the LDS-DMA pipeline applies as is
+    sp, cap = _ssq(sumsq_part)
+    L.check(L.lib().vlaser_gemm_tn(At.data_ptr(), Wt.data_ptr(), out.data_ptr(), M, N, K, At.stride(0), Wt.stride(0), out.stride(0), sp, cap, _stream()),
             'vlaser_gemm_tn')
     return out
 
 
-def gemm_tn_lds(At, Wt, out, K_pad, force_cfg=0):
-    """out[M,N] = At[:K_pad]^T @ Wt[:K_pad] on the LDS-DMA pipeline: K_pad a multiple of 64, rows past the true K of At ZERO and of Wt finite."""
+def gemm_tn_lds(At, Wt, out, K_pad, force_cfg=0, sumsq_part=None):
+    """out[M,N] = At[:K_pad]^T @ Wt[:K_pad] on the LDS-DMA pipeline: K_pad a multiple of 64, rows past the true K of At ZERO and of Wt finite.
+    `sumsq_part` (fp32 slots, see `tn_sumsq_slots`): every wave of the launch leaves the sum of the squares of the bf16 values it stored in its own
+    slot -- the gradient norm's share of this tensor without reading it back (`sum_partials` adds the slots in a fixed order)."""
     M, N = At.shape[1], Wt.shape[1]
-    L.check(L.lib().vlaser_gemm_tn_lds(At.data_ptr(), Wt.data_ptr(), out.data_ptr(), M, N, K_pad, At.stride(0), Wt.stride(0), out.stride(0), force_cfg, _stream()),
-            'vlaser_gemm_tn_lds')
+    sp, cap = _ssq(sumsq_part)
+    L.check(L.lib().vlaser_gemm_tn_lds(At.data_ptr(), Wt.data_ptr(), out.data_ptr(), M, N, K_pad, At.stride(0), Wt.stride(0), out.stride(0), force_cfg, sp, cap,
+                                        _stream()), 'vlaser_gemm_tn_lds')
     return out
+
+
+def tn_sumsq_slots(M, N):
+    """Slots that always suffice for `sumsq_part` of a TN GEMM with an [M, N] output, whichever kernel / tile takes it (include/vlaser_hip.h)."""
+    c = lambda a, b: (a + b - 1) // b
+    return max(c(M, 64) * c(N, 128) * 4, c(M, 128) * c(N, 128) * 8)
+
+
+def sumsq_chunks(x, tab, part):
+    """part[c] = sum of squares of the bf16 buffer x[tab[c, 0] : tab[c, 0] + tab[c, 1]] (tab int64 [n, 2] on the device)."""
+    assert tab.dtype == torch.int64 and tab.is_contiguous() and part.numel() >= tab.shape[0]
+    L.check(L.lib().vlaser_sumsq_chunks(x.data_ptr(), tab.data_ptr(), tab.shape[0], part.data_ptr(), _stream()), 'vlaser_sumsq_chunks')
+
+
+def sum_partials(part, out, accumulate=True):
+    """out[0] (+)= sum(part) in a fixed association."""
+    L.check(L.lib().vlaser_sum_partials(part.data_ptr(), part.numel(), out.data_ptr(), 1 if accumulate else 0, _stream()), 'vlaser_sum_partials')
 
 
 def gemm_tn_grouped(At, Wt, out, M, N, K, ldat, ldwt, ldo, groups, a_gs, w_gs, batch, a_bs, w_bs, o_bs):
@@ -665,11 +694,16 @@ def ce_dlogits(logits, lse, labels, out, scale, ignore_index=-100):
                                       scale, ignore_index, _stream()), 'vlaser_ce_dlogits')
 
 
-def embed_scatter_add(ids, rank, dh, dembed, n, H):
-    """dEmbed[id] += fp32 sum of dh over the text positions holding id (duplicates summed before the single bf16 rounding)."""
+def embed_scatter_add(ids, rank, dh, dembed, n, H, sumsq_part=None):
+    """dEmbed[id] += fp32 sum of dh over the text positions holding id (duplicates summed before the single bf16 rounding).  `sumsq_part` (fp32, >= n
+    slots): afterwards slot i = the sum of squares of the table row of the i-th distinct id (0 elsewhere) -- the rows this step touched; with the
+    table gradient cleared at the start of the step that is its whole share of the gradient norm."""
     order = torch.sort(ids.reshape(-1)[:n], stable=True).indices.to(torch.int32)          # index bookkeeping only: equal ids -> contiguous runs
     L.check(L.lib().vlaser_embed_scatter_add(ids.data_ptr(), rank.data_ptr(), order.data_ptr(), dh.data_ptr(), dembed.data_ptr(), n, H,
                                              dembed.shape[0], _stream()), 'vlaser_embed_scatter_add')
+    if sumsq_part is not None:
+        sp, cap = _ssq(sumsq_part)
+        L.check(L.lib().vlaser_sumsq_rows(ids.data_ptr(), order.data_ptr(), dembed.data_ptr(), n, H, dembed.shape[0], sp, cap, _stream()), 'vlaser_sumsq_rows')
 
 
 def gelu_bwd(x, dy, dx):

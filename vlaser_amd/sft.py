@@ -299,7 +299,7 @@ class SFTModel:
             torch.cuda.current_stream().wait_event(ev)
 
     # ------------------------------------------------------------------ small helpers
-    def _wgrad(self, dY, X, out, S, bias_out=None, padded=False):
+    def _wgrad(self, dY, X, out, S, bias_out=None, padded=False, ssq=None):
         """out[N,K] = dY[S,N]^T @ X[S,K] (bf16) by the TN GEMM: both operands are read as they lie (contraction along their
         rows, transposing LDS reads) -- no transposed activation copies.  `padded`: dY / X are views of step buffers with ceil64(S)
         rows whose dY pad rows are zero (`_zero_wgrad_pad`): the product then runs on the LDS-DMA pipeline (r03: 97 instead of 135 us
@@ -308,11 +308,47 @@ class SFTModel:
         if padded and self.wgrad_lds and dY.shape[1] % 8 == 0 and X.shape[1] % 8 == 0:
             for t in (dY, X):       # the pad rows must lie inside the buffer the view was cut from
                 assert t.storage_offset() + (Sp - 1) * t.stride(0) + t.shape[1] <= t.untyped_storage().nbytes() // t.element_size()
-            ops.gemm_tn_lds(dY, X, out, Sp)
+            ops.gemm_tn_lds(dY, X, out, Sp, sumsq_part=ssq)
         else:
-            ops.gemm_tn(dY[:S], X[:S], out)
+            ops.gemm_tn(dY[:S], X[:S], out, sumsq_part=ssq)
         if bias_out is not None:
             ops.colsum_bf16(dY, bias_out, S, dY.shape[1])
+
+    # ------------------------------------------------------------------ gradient norm from the producers (single rank, one sample per step)
+    def _plan_fused_norm(self):
+        """Slot layout of the partial sums of squares, bucket by bucket (r04): the weight-gradient GEMMs write one slot per (workgroup, wave) of their
+        launch (`sumsq_part`; which slots depends on the weight's shape only, the rest stay zero), the embedding table one slot per position (the rows
+        this step touched), everything small (norm weights, biases, the projector) one slot per 8192-element chunk, summed by one launch per bucket."""
+        fp, dev = self.fp, self.device
+        Lyr = self.llm.num_hidden_layers
+        by_gemm = {'head'} | {f'l{i}.{w}' for i in range(Lyr) for w in ('wqkv', 'wo', 'wgu', 'wdown')}
+        self.norm_slot, self.norm_plan, n = {}, [], 0
+        for (blo, bhi) in self.buckets:
+            lo, chunks = n, []
+            for name, shape, off in fp.specs:
+                if not (blo <= off < bhi) or name == 'head_pad':         # head_pad: zero gradients by construction
+                    continue
+                numel = math.prod(shape)
+                if name in by_gemm:
+                    cap = ops.tn_sumsq_slots(shape[0], shape[1])
+                    self.norm_slot[name] = (n, cap)
+                    n += cap
+                elif name == 'embed':
+                    self.norm_slot[name] = (n, self.S_max)
+                    n += self.S_max
+                else:
+                    chunks += [(off + c0, min(8192, numel - c0)) for c0 in range(0, numel, 8192)]
+            tab = torch.tensor(chunks, dtype=torch.int64, device=dev).reshape(-1, 2) if chunks else None
+            self.norm_plan.append((lo, n + len(chunks), n, tab))
+            n += len(chunks)
+        self.norm_parts = torch.zeros(n, dtype=F32, device=dev)
+
+    def _ssq(self, name):
+        """The slot slice the producer of gradient `name` fills, or None when this step takes the norm from the gradient buffer."""
+        if not getattr(self, '_fused_norm', False):
+            return None
+        lo, cap = self.norm_slot[name]
+        return self.norm_parts[lo:lo + cap]
 
     def _zero_wgrad_pad(self, S):
         """Rows S..ceil64(S) of the four dY buffers the layer weight gradients contract over: zero, so that the padded TN GEMM may read whole
@@ -407,12 +443,14 @@ class SFTModel:
         vit_w = self.vit
         vit_w.m0w, vit_w.m0b = v['mlp1.m0w'], v['mlp1.m0b']       # the projector weights are the trainable views
         vit_w.m1w, vit_w.m1b, vit_w.m3w, vit_w.m3b = v['mlp1.m1w'], v['mlp1.m1b'], v['mlp1.m3w'], v['mlp1.m3b']
-        self._wait_params(len(self.buckets) - 1)                   # embed + projector bucket (the projector runs inside vit_w.forward)
+        # the frozen encoder needs no parameter of this step: it starts right away, under the previous step's AdamW (r04: it used to sit behind the
+        # wait below, 1.1 ms of an idle compute stream per step -- tools/micro/sft_timeline.py)
+        vit_w.forward(pv, project=False)                           # leaves the last hidden state in vit_w.h
+        self._wait_params(len(self.buckets) - 1)                   # embed + projector bucket
         # every gradient tensor is fully overwritten by its wgrad / column-sum kernel each step, except the embedding rows
         # (scatter-add over the text tokens): only that slice is cleared (466 MB instead of the whole 3.6 GB buffer) -- after the
         # wait above: the previous step's AdamW may still be reading this bucket's gradients on the optimizer stream
         gv['embed'].zero_()
-        vit_w.forward(pv)                                          # leaves the last hidden state in vit_w.h
         nt = T * cfg.num_image_token
         C1 = cfg.vision.hidden_size
         G_ = cfg.vision.image_size // cfg.vision.patch_size
@@ -478,7 +516,7 @@ class SFTModel:
             dx_rows.copy_(self.head_red[:R])
         else:
             self._dgrad(dlog, self.head_full, dx_rows, R)
-        ops.gemm_tn(dlog_pad[:, :V], x_pad, gv['head'])             # dW_head = dlogits^T @ x over ceil64(R) rows (zero pad rows; dlogits rows are padded to Vp columns)
+        ops.gemm_tn(dlog_pad[:, :V], x_pad, gv['head'], sumsq_part=self._ssq('head'))             # dW_head = dlogits^T @ x over ceil64(R) rows (zero pad rows; dlogits rows are padded to Vp columns)
         dxn = self.dx[:S]
         dxn.zero_()
         dxn.index_copy_(0, rows, dx_rows)
@@ -507,13 +545,13 @@ class SFTModel:
             else:
                 self._dgrad(dh, v[f'l{i}.wdown'], dact, S)
                 ops.swiglu_bwd(gu, dact, dgu, S, I)
-            self._wgrad(dh, act, gv[f'l{i}.wdown'], S, padded=True)
+            self._wgrad(dh, act, gv[f'l{i}.wdown'], S, padded=True, ssq=self._ssq(f'l{i}.wdown'))
             self._dgrad(dgu, v[f'l{i}.wgu'], dx, S)
-            self._wgrad(dgu, x2, gv[f'l{i}.wgu'], S, padded=True)
+            self._wgrad(dgu, x2, gv[f'l{i}.wgu'], S, padded=True, ssq=self._ssq(f'l{i}.wgu'))
             ops.rmsnorm_bwd(dx, h2, v[f'l{i}.ln_post'], dh, dh2, S, H, llm.rms_norm_eps, dw_out=gv[f'l{i}.ln_post'], dw_ws=self.normw_ws)
             # attention block: h2 = h_in + ao Wo^T
             self._dgrad(dh2, v[f'l{i}.wo'], dao, S)
-            self._wgrad(dh2, ao, gv[f'l{i}.wo'], S, padded=True)
+            self._wgrad(dh2, ao, gv[f'l{i}.wo'], S, padded=True, ssq=self._ssq(f'l{i}.wo'))
             Kc, VTc = self.cache.k[kslot, 0], self.cache.vt[kslot, 0]         # [nkv, s_max, hd], [nkv, hd, s_max]
             if self.attn_bwd_mode == 'fused':
                 ops.attn_bwd(q, Kc, VTc, ao, dao, self.lse[kslot], self.delta_ws, self.dq[:S], self.dk[:S], self.dv[:S], S, nq, nkv, sm, scale)
@@ -522,12 +560,12 @@ class SFTModel:
             dqkv = self.dqkv[:S]
             ops.rope_bwd_pack(self.dq[:S], self.dk[:S], self.dv[:S], self.rope[0], self.rope[1], pos, dqkv, S, nq, nkv, kv_per_q_head=True)
             self._dgrad(dqkv, v[f'l{i}.wqkv'], dx, S)
-            self._wgrad(dqkv, x1, gv[f'l{i}.wqkv'], S, bias_out=gv[f'l{i}.bqkv'], padded=True)
+            self._wgrad(dqkv, x1, gv[f'l{i}.wqkv'], S, bias_out=gv[f'l{i}.bqkv'], padded=True, ssq=self._ssq(f'l{i}.wqkv'))
             ops.rmsnorm_bwd(dx, h_in, v[f'l{i}.ln_in'], dh2, dh, S, H, llm.rms_norm_eps, dw_out=gv[f'l{i}.ln_in'], dw_ws=self.normw_ws)
             if on_bucket_ready and (i == 0 or bucket_of_layer[i - 1] != bucket_of_layer[i]):
                 on_bucket_ready(bucket_of_layer[i])
         # ---- embeddings (text rows) and projector (image rows)
-        ops.embed_scatter_add(ids, self.rank_ws, dh, gv['embed'], S, H)
+        ops.embed_scatter_add(ids, self.rank_ws, dh, gv['embed'], S, H, sumsq_part=self._ssq('embed'))
         img_rows = self._h2d((ids_h.reshape(-1) == self.img_context_token_id).nonzero().flatten())
         dfeat_used = dh.index_select(0, img_rows).contiguous()
         dvit = self.dvit[:nt]
@@ -592,6 +630,15 @@ class SFTModel:
         (a one-workgroup-per-CU streaming kernel under the backward's GEMMs) instead of a 0.6 ms pass between backward and AdamW.
         Buckets complete in index order, so the partial sums are added in the same order as the loop in optimizer_step."""
         self._norm_buckets_seen = getattr(self, '_norm_buckets_seen', 0) + 1
+        if getattr(self, '_fused_norm', False):
+            # r04: the producers left the partial sums (weight-gradient GEMM epilogues, the touched embedding rows); the small tensors are summed here in
+            # one launch, then one workgroup adds the bucket's slots in a fixed order -- on the compute stream: two ~5 us launches per bucket instead of
+            # 3.6 GB re-read under the backward's GEMMs.  Every AdamW of the previous step was waited for by the forward, so nothing reads gnorm2 now.
+            lo, hi, c_lo, tab = self.norm_plan[b]
+            if tab is not None:
+                ops.sumsq_chunks(self.fp.g, tab, self.norm_parts[c_lo:hi])
+            ops.sum_partials(self.norm_parts[lo:hi], self.gnorm2, accumulate=b != 0)
+            return
         ev = torch.cuda.Event()
         ev.record()
         with torch.cuda.stream(self.opt_stream):
@@ -761,7 +808,14 @@ class SFTModel:
         if len(work) == 1 and work[0][4] == 1.0:
             early = not self.dp_active and self.overlap_optimizer and os.environ.get('VLASER_SFT_NO_EARLY_NORM') != '1'
             self._norm_buckets_seen = 0
-            loss = self.forward_backward(*work[0][:4], on_bucket_ready=self._norm_bucket if early else self._exchange_bucket)
+            # the norm from the producers (r04) needs every gradient element to be written exactly once by a kernel that can sum it: one sample per step
+            self._fused_norm = early and os.environ.get('VLASER_SFT_NO_FUSED_NORM') != '1'
+            if self._fused_norm and getattr(self, 'norm_parts', None) is None:
+                self._plan_fused_norm()
+            try:
+                loss = self.forward_backward(*work[0][:4], on_bucket_ready=self._norm_bucket if early else self._exchange_bucket)
+            finally:
+                self._fused_norm = False
             # a forward_backward that raised never gets here, and one that returned must have signalled every bucket
             self._norm_early = early and self._norm_buckets_seen == len(self.buckets)
         else:
