@@ -208,7 +208,7 @@ int vlaser_attn_oproj(const VlaserAttnArgs* a, const void* wo_packed, float* out
  * dk / dv: bf16 [S, n_q*128] -- ONE partial per Q head (vlaser_rope_bwd_pack sums the heads of a kv group); delta_ws: fp32 [n_q, S] scratch.
  * Key k is visible to query q iff k < kv_valid and (k <= q when causal != 0).  head_dim 128. */
 int vlaser_attn_bwd(const void* q, const void* k, const void* vt, const void* o, const void* d_o, const float* lse, float* delta_ws, void* dq, void* dk,
-                    void* dv, int S, int n_q, int n_kv, int s_max, float scale, int causal, int kv_valid, vl_stream_t stream);
+                    void* dv, int S, int n_q, int n_kv, int s_max, float scale, int causal, int kv_valid, int head_dim /* 128, checked */, vl_stream_t stream);
 
 /* Weight-gradient GEMM: out[M,N] (bf16) = At^T @ Wt, At [K,M] and Wt [K,N] row-major bf16 (contraction along rows).
  * dW = dY^T X of every nn.Linear on the SFT path (autograd of modeling_internvl_chat.py:194-203): At = dY [S,N_out],

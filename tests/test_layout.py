@@ -113,8 +113,10 @@ def test_bad_arguments_return_errors_not_crashes():
     assert lib.vlaser_gemm_tn_lds(P, P, P, 1002, 2048, 128, 1002, 2048, 2048, 0, None, 0, None) != 0
     assert b'rounded up to 8' in lib.vlaser_last_error()
     # fused attention backward: cache row length not a multiple of 64 / more valid keys than cache rows
-    assert lib.vlaser_attn_bwd(P, P, P, P, P, P, P, P, P, P, 70, 12, 2, 100, 0.1, 1, 70, None) != 0
+    assert lib.vlaser_attn_bwd(P, P, P, P, P, P, P, P, P, P, 70, 12, 2, 100, 0.1, 1, 70, 128, None) != 0
     assert b'bad geometry' in lib.vlaser_last_error()
+    assert lib.vlaser_attn_bwd(P, P, P, P, P, P, P, P, P, P, 64, 12, 2, 128, 0.1, 1, 64, 64, None) != 0           # head_dim other than 128 is refused
+    assert b'head_dim 64' in lib.vlaser_last_error()
     # one launch between two passes through the expert: width not a multiple of 256; finishing in place
     assert lib.vlaser_vla_step(None, None, 0, 4, 0, None, 1e-6, None, None, P, P, None, 0.1, 0, P, P, P, P, P, 4, 700, 7, None) != 0
     assert b'multiple of 256' in lib.vlaser_last_error()

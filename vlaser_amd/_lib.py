@@ -62,7 +62,7 @@ _SIGS = {
     'vlaser_gemm_nn': [i32, C.POINTER(GemmArgs), vp],
     'vlaser_attn_prefill': [C.POINTER(AttnArgs), vp],
     'vlaser_attn_skinny': [C.POINTER(AttnArgs), vp],
-    'vlaser_attn_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp],
+    'vlaser_attn_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, i32, vp],
     'vlaser_skinny': [i32, i32, C.POINTER(SkinnyArgs), vp],
     'vlaser_fused_ogu': [C.POINTER(FusedOguArgs), vp],
     'vlaser_layernorm': [vp, vp, vp, vp, i32, i32, f32, vp],

@@ -363,8 +363,9 @@ __global__ __launch_bounds__(256 * KS) void attn_bwd_dkv_kernel(AttnBwdP p) {
 }
 
 extern "C" int vlaser_attn_bwd(const void* q, const void* k, const void* vt, const void* o, const void* d_o, const float* lse, float* delta_ws, void* dq, void* dk,
-                               void* dv, int S, int n_q, int n_kv, int s_max, float scale, int causal, int kv_valid, vl_stream_t s) {
+                               void* dv, int S, int n_q, int n_kv, int s_max, float scale, int causal, int kv_valid, int head_dim, vl_stream_t s) {
   VL_CHECK(q && k && vt && o && d_o && lse && delta_ws && dq && dk && dv, "vlaser_attn_bwd: null pointer");
+  VL_CHECK(head_dim == 128, "vlaser_attn_bwd: head_dim %d -- the kernels are built for head_dim 128 (Qwen2.5)", head_dim);
   VL_CHECK(S >= 1 && n_q % n_kv == 0 && s_max % 64 == 0 && S <= s_max && kv_valid >= 1 && kv_valid <= s_max, "vlaser_attn_bwd: bad geometry");
   AttnBwdP p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.o = (const bf16_t*)o; p.d_o = (const bf16_t*)d_o;

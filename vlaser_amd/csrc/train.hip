@@ -782,11 +782,23 @@ extern "C" int vlaser_sumsq_rows(const int64_t* ids, const int32_t* order, const
   VL_LAUNCH_CHECK();
   return 0;
 }
-// out[0] (+)= part[0] + part[1] + ... in a fixed association: thread t adds the slots t, t + 1024, ... in order, then a fixed tree over the threads
+// out[0] (+)= part[0] + part[1] + ... in a fixed association: thread t owns the 16-byte pieces t, t + 1024, ... (four independent running sums, four
+// pieces requested per round: 34.7 -> ~6 us for a 4-layer bucket's 91 K slots -- the one-load-per-round version was a chain of 89 round trips), then a
+// fixed tree over the lanes and waves
 __global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restrict__ part, long long n, float* __restrict__ out, int accumulate) {
   __shared__ float red[16];
-  float acc = 0.f;
-  for (long long i = threadIdx.x; i < n; i += 1024) acc += part[i];
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  const bool vec = ((uintptr_t)part & 15) == 0;
+  const long long n4 = vec ? (n >> 2) : 0;
+  const f32x4* p4 = reinterpret_cast<const f32x4*>(part);
+  long long i = threadIdx.x;
+  for (; i + 3 * 1024 < n4; i += 4 * 1024) {
+    const f32x4 v0 = p4[i], v1 = p4[i + 1024], v2 = p4[i + 2048], v3 = p4[i + 3072];
+    a += v0; a += v1; a += v2; a += v3;
+  }
+  for (; i < n4; i += 1024) a += p4[i];
+  float acc = (a[0] + a[1]) + (a[2] + a[3]);
+  for (long long j = (n4 << 2) + threadIdx.x; j < n; j += 1024) acc += part[j];
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();

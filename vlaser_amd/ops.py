@@ -190,10 +190,10 @@ def attn_prefill(*args, **kw):
     L.check(L.lib().vlaser_attn_prefill(C.byref(a), _stream()), 'vlaser_attn_prefill')
 
 
-def attn_bwd(q, k, vt, o, d_o, lse, delta_ws, dq, dk, dv, S, n_q, n_kv, s_max, scale, causal=True, kv_valid=None):
+def attn_bwd(q, k, vt, o, d_o, lse, delta_ws, dq, dk, dv, S, n_q, n_kv, s_max, scale, causal=True, kv_valid=None, head_dim=128):
     """Fused backward of the prefill attention (csrc/attn_bwd.hip): dq, and one dk / dv partial per Q head, from q / k / v^T / o / d_o and the forward's lse."""
     L.check(L.lib().vlaser_attn_bwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta_ws.data_ptr(), dq.data_ptr(),
-                                    dk.data_ptr(), dv.data_ptr(), S, n_q, n_kv, s_max, scale, int(causal), S if kv_valid is None else kv_valid, _stream()), 'vlaser_attn_bwd')
+                                    dk.data_ptr(), dv.data_ptr(), S, n_q, n_kv, s_max, scale, int(causal), S if kv_valid is None else kv_valid, head_dim, _stream()), 'vlaser_attn_bwd')
 
 
 def launch_attn_oproj(args, wo_packed: 'PackedW', out_f32, N, stream=None):

@@ -94,6 +94,46 @@ class FlatParams:
         raise KeyError(name)
 
 
+def plan_flat_layout(cfg, world, bucket_layers=4, device='cpu'):
+    """The flat parameter / gradient layout of the SFT step and its gradient buckets, without allocating anything: (FlatParams before `finalize`,
+    [(lo, hi)]).  Order = the order the backward completes the gradients: [head (+ zero pad rows up to a multiple of 64) + final norm], the layers
+    last to first in groups of `bucket_layers`, [embedding + projector]; every bucket boundary is a multiple of 128 * world elements, so each ZeRO-1
+    bucket divides evenly over the ranks and the RCCL collectives run in place (dp.py).  Also used by the CPU test of the world-8 shard plan."""
+    llm = cfg.llm
+    H, I, V = llm.hidden_size, llm.intermediate_size, llm.vocab_size
+    nq, nkv, hd = llm.num_attention_heads, llm.num_key_value_heads, llm.head_dim
+    NQ = (nq + 2 * nkv) * hd
+    Vp = (V + 63) // 64 * 64
+    fp = FlatParams(device)
+    fp.add('head', (V, H))
+    if Vp > V:
+        fp.add('head_pad', (Vp - V, H))       # zero rows (zero gradients, so AdamW keeps them zero): the head's dgrad contracts over Vp = V rounded up to 64
+    fp.add('norm', (H,))
+    fp.align(128 * world)                     # end of bucket 0 (head + final norm)
+    for i in reversed(range(llm.num_hidden_layers)):
+        for nm, shp in [('wqkv', (NQ, H)), ('bqkv', (NQ,)), ('wo', (H, nq * hd)), ('wgu', (2 * I, H)), ('wdown', (H, I)), ('ln_in', (H,)),
+                        ('ln_post', (H,))]:
+            fp.add(f'l{i}.{nm}', shp)
+    fp.align(128 * world)                     # layer buckets are whole layers: already multiples for world <= 8, keep it explicit
+    fp.add('embed', (V, H))
+    C4 = cfg.vision.hidden_size * 4
+    for nm, shp in [('m0w', (C4,)), ('m0b', (C4,)), ('m1w', (H, C4)), ('m1b', (H,)), ('m3w', (H, H)), ('m3b', (H,))]:
+        fp.add('mlp1.' + nm, shp)
+    n_total = (fp.n + 128 * world * 8 - 1) // (128 * world * 8) * (128 * world * 8)       # what finalize(pad_to=128 * world * 8) makes of it
+    bounds = [fp.offset_of(f'l{llm.num_hidden_layers - 1}.wqkv')]
+    layers_rev = list(reversed(range(llm.num_hidden_layers)))
+    for j in range(bucket_layers, llm.num_hidden_layers, bucket_layers):
+        bounds.append(fp.offset_of(f'l{layers_rev[j]}.wqkv'))
+    bounds.append(fp.offset_of('embed'))
+    bounds.append(n_total)
+    buckets, lo = [], 0
+    for hi in bounds:
+        if hi > lo:
+            buckets.append((lo, hi))
+            lo = hi
+    return fp, buckets
+
+
 class SFTModel:
     """Trainable Vlaser-2B SFT step (per rank).  `step(pixel_values, input_ids, labels)` runs forward, backward, the
     gradient exchange and the optimizer update and returns the (rank-local) loss."""
@@ -144,23 +184,9 @@ class SFTModel:
         nq, nkv, hd = llm.num_attention_heads, llm.num_key_value_heads, llm.head_dim
         NQ = (nq + 2 * nkv) * hd
         self.Vp = (V + 63) // 64 * 64
-        fp = FlatParams(dev)
-        fp.add('head', (V, H))
-        if self.Vp > V:
-            fp.add('head_pad', (self.Vp - V, H))   # zero rows (zero gradients, so AdamW keeps them zero): the head's dgrad contracts over Vp = V rounded up to 64
-        fp.add('norm', (H,))
-        fp.align(128 * self.world)                # end of bucket 0 (head + final norm)
-        self.bucket_bounds = [0]                  # flat offsets where a gradient bucket ends
-        for i in reversed(range(llm.num_hidden_layers)):
-            for nm, shp in [('wqkv', (NQ, H)), ('bqkv', (NQ,)), ('wo', (H, nq * hd)), ('wgu', (2 * I, H)), ('wdown', (H, I)), ('ln_in', (H,)),
-                            ('ln_post', (H,))]:
-                fp.add(f'l{i}.{nm}', shp)
-        fp.align(128 * self.world)                # layer buckets are whole layers: already multiples for world <= 8, keep it explicit
-        fp.add('embed', (V, H))
-        C4 = cfg.vision.hidden_size * 4
-        for nm, shp in [('m0w', (C4,)), ('m0b', (C4,)), ('m1w', (H, C4)), ('m1b', (H,)), ('m3w', (H, H)), ('m3b', (H,))]:
-            fp.add('mlp1.' + nm, shp)
+        fp, self.buckets = plan_flat_layout(cfg, self.world, self.bucket_layers, dev)
         fp.finalize(pad_to=128 * self.world * 8)
+        assert fp.n == self.buckets[-1][1], 'plan_flat_layout and FlatParams.finalize disagree on the padded length'
         self.fp = fp
         o_head = fp.offset_of('head')
         self.head_full = fp.p[o_head:o_head + self.Vp * H].view(self.Vp, H)      # [Vp, H]: lm_head rows + the zero pad rows
@@ -181,19 +207,6 @@ class SFTModel:
         for nm, k in [('m0w', 'mlp1.0.weight'), ('m0b', 'mlp1.0.bias'), ('m1w', 'mlp1.1.weight'), ('m1b', 'mlp1.1.bias'),
                       ('m3w', 'mlp1.3.weight'), ('m3b', 'mlp1.3.bias')]:
             fp.view['mlp1.' + nm].copy_(g(k))
-        # gradient buckets: [head+norm], groups of `bucket_layers` layers (reverse order), [embed+mlp1]; each padded to world*128
-        bounds = [fp.offset_of(f'l{llm.num_hidden_layers - 1}.wqkv')]
-        layers_rev = list(reversed(range(llm.num_hidden_layers)))
-        for j in range(self.bucket_layers, llm.num_hidden_layers, self.bucket_layers):
-            bounds.append(fp.offset_of(f'l{layers_rev[j]}.wqkv'))
-        bounds.append(fp.offset_of('embed'))
-        bounds.append(fp.n)
-        self.buckets = []
-        lo = 0
-        for hi in bounds:
-            if hi > lo:
-                self.buckets.append((lo, hi))
-                lo = hi
         # ZeRO-1: every rank owns the slice [lo + r*len/N, lo + (r+1)*len/N) of each bucket (bucket lengths are multiples of 128;
         # uneven division is handled by padding the reduce-scatter input)
         assert all((hi - lo) % (128 * self.world) == 0 for lo, hi in self.buckets), 'ZeRO-1 buckets must divide evenly over the ranks'
@@ -246,7 +259,6 @@ class SFTModel:
             self.sc = torch.zeros(nq, QB, S, dtype=F32, device=dev)
             self.dP = torch.zeros(nq, QB, S, dtype=F32, device=dev)
             self.P, self.dS = z(nq, QB, S), z(nq, QB, S)
-        self.head_red = torch.zeros(S, H, dtype=F32, device=dev)      # fp32 sum of the lm_head dgrad's split-K slabs (one rounding to bf16)
         self.dkv_acc = None                        # fp32 [2, S, nq*hd]: dK / dV partial sums over the query blocks (allocated by the first multi-block backward)
         self.col = torch.zeros(max(2 * I, NQ, C4, H), dtype=F32, device=dev)
         self.sumsq_ws = torch.zeros(1024, dtype=F32, device=dev)
@@ -307,7 +319,8 @@ class SFTModel:
         Sp = (S + 63) // 64 * 64
         if padded and self.wgrad_lds and dY.shape[1] % 8 == 0 and X.shape[1] % 8 == 0:
             for t in (dY, X):       # the pad rows must lie inside the buffer the view was cut from
-                assert t.storage_offset() + (Sp - 1) * t.stride(0) + t.shape[1] <= t.untyped_storage().nbytes() // t.element_size()
+                if t.storage_offset() + (Sp - 1) * t.stride(0) + t.shape[1] > t.untyped_storage().nbytes() // t.element_size():
+                    raise ValueError(f'_wgrad(padded=True): the operand has no {Sp - S} pad rows behind its {S} rows')
             ops.gemm_tn_lds(dY, X, out, Sp, sumsq_part=ssq)
         else:
             ops.gemm_tn(dY[:S], X[:S], out, sumsq_part=ssq)
@@ -324,6 +337,7 @@ class SFTModel:
         by_gemm = {'head'} | {f'l{i}.{w}' for i in range(Lyr) for w in ('wqkv', 'wo', 'wgu', 'wdown')}
         self.norm_slot, self.norm_plan, n = {}, [], 0
         for (blo, bhi) in self.buckets:
+            n = (n + 3) // 4 * 4                     # a bucket's slots start 16-byte aligned (vlaser_sum_partials reads them in 16-byte pieces)
             lo, chunks = n, []
             for name, shape, off in fp.specs:
                 if not (blo <= off < bhi) or name == 'head_pad':         # head_pad: zero gradients by construction
@@ -350,6 +364,20 @@ class SFTModel:
         lo, cap = self.norm_slot[name]
         return self.norm_parts[lo:lo + cap]
 
+    def _head_pads(self, R, Rp):
+        """The lm_head's two row-padded operands ([ceil64(R), H] inputs, [ceil64(R), Vp] dlogits), allocated once per padded row count; their rows
+        R..Rp must be zero (they enter the weight gradient's contraction): cleared when R changes -- the kernels only ever write rows < R."""
+        if getattr(self, '_head_pad_Rp', None) != Rp:
+            self._x_pad = torch.zeros(Rp, self.llm.hidden_size, dtype=BF, device=self.device)
+            self._dlog_pad = torch.zeros(Rp, self.Vp, dtype=BF, device=self.device)
+            self._head_pad_Rp, self._head_pad_R = Rp, R
+        elif self._head_pad_R != R:
+            lo = min(R, self._head_pad_R)
+            self._x_pad[lo:].zero_()
+            self._dlog_pad[lo:].zero_()
+            self._head_pad_R = R
+        return self._x_pad, self._dlog_pad
+
     def _zero_wgrad_pad(self, S):
         """Rows S..ceil64(S) of the four dY buffers the layer weight gradients contract over: zero, so that the padded TN GEMM may read whole
         64-row tiles.  Nothing writes those rows while S stays the same (every kernel is bounded by S), so this runs when S changes."""
@@ -357,6 +385,10 @@ class SFTModel:
         if Sp != S and self._wgrad_pad_S != S:
             for b in (self.dh, self.dh2, self.dgu, self.dqkv):
                 b[S:Sp].zero_()
+            # the X-side operands are multiplied by those zero rows, so their pad rows only have to be FINITE -- they hold whatever an earlier, longer
+            # sample left there; cleared as well when S changes (<= 63 rows per buffer) so that a stale Inf / NaN cannot turn 0 * x into NaN
+            for b in (self.act, self.x2, self.ao, self.x1):
+                b[:, S:Sp].zero_()
         self._wgrad_pad_S = S
 
     def _dgrad(self, dY, W, out, S):
@@ -491,8 +523,8 @@ class SFTModel:
         # the R supervised rows, in buffers of ceil64(R) rows (zero pad): the head's weight gradient then contracts over whole 64-row tiles and runs on
         # the LDS-DMA pipeline (vlaser_gemm_tn_lds; r03: 237 -> ~110 us for the [151 674 x 1536] gradient)
         Rp = (R + 63) // 64 * 64
-        x_pad = torch.zeros(Rp, H, dtype=BF, device=dev)
-        x_pad[:R] = xn.index_select(0, rows)
+        x_pad, dlog_pad = self._head_pads(R, Rp)
+        torch.index_select(xn, 0, rows, out=x_pad[:R])
         x_rows = x_pad[:R]
         t_rows = self._h2d(tgt_h.index_select(0, rows_h))
         logits = ops.linear(x_rows, v['head'], epi=L.EPI_F32)         # [R, V] fp32
@@ -502,7 +534,6 @@ class SFTModel:
         loss = loss_rows.sum() / R
         # ================================================================ backward
         # (every bucket's `_wait_params` has been issued by now: the previous step's AdamW / all-gathers no longer touch fp.p or fp.g)
-        dlog_pad = torch.zeros(Rp, self.Vp, dtype=BF, device=dev)
         dlog = dlog_pad[:R]
         ops.ce_dlogits(logits, lse, t_rows, dlog, 1.0 / R)
         dx_rows = torch.empty(R, H, dtype=BF, device=dev)
@@ -512,8 +543,7 @@ class SFTModel:
         if sp > 8 and sp * R * H <= self.part.numel():
             part = self.part[:sp * R * H]
             ops.gemm_nn(L.EPI_PARTIAL, dlog, self.head_full, out_f32=part, k_splits=sp)
-            torch.sum(part.view(sp, R, H), dim=0, out=self.head_red[:R])
-            dx_rows.copy_(self.head_red[:R])
+            ops.reduce_norm(None, part, sp, R, H, dx_rows)          # fp32 sum of the slabs in slab order, one rounding to bf16
         else:
             self._dgrad(dlog, self.head_full, dx_rows, R)
         ops.gemm_tn(dlog_pad[:, :V], x_pad, gv['head'], sumsq_part=self._ssq('head'))             # dW_head = dlogits^T @ x over ceil64(R) rows (zero pad rows; dlogits rows are padded to Vp columns)
@@ -554,7 +584,7 @@ class SFTModel:
             self._wgrad(dh2, ao, gv[f'l{i}.wo'], S, padded=True, ssq=self._ssq(f'l{i}.wo'))
             Kc, VTc = self.cache.k[kslot, 0], self.cache.vt[kslot, 0]         # [nkv, s_max, hd], [nkv, hd, s_max]
             if self.attn_bwd_mode == 'fused':
-                ops.attn_bwd(q, Kc, VTc, ao, dao, self.lse[kslot], self.delta_ws, self.dq[:S], self.dk[:S], self.dv[:S], S, nq, nkv, sm, scale)
+                ops.attn_bwd(q, Kc, VTc, ao, dao, self.lse[kslot], self.delta_ws, self.dq[:S], self.dk[:S], self.dv[:S], S, nq, nkv, sm, scale, head_dim=hd)
             else:
                 self._attn_backward(q, Kc, VTc, dao, ao, S, nq, G, hd, sm, scale)
             dqkv = self.dqkv[:S]
