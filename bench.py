@@ -522,8 +522,18 @@ def qa_bench(local):
                 m.generate(pv, ids, max_new_tokens=n_new, min_new_tokens=n_new)
             torch.cuda.synchronize()
             ts.append((time.perf_counter() - t0) / 3)
+        step_ms = (ts[1] - ts[0]) / 32 * 1e3
+        llm = cfg.llm
+        NQ = (llm.num_attention_heads + 2 * llm.num_key_value_heads) * llm.head_dim
+        # bytes one decode step streams: every layer's weights + the lm_head once (shared by the B rows), each row's K / V^T cache (S + the new tokens)
+        w_bytes = 2 * (llm.num_hidden_layers * (NQ * llm.hidden_size + llm.hidden_size * llm.num_attention_heads * llm.head_dim + 3 * llm.intermediate_size * llm.hidden_size)
+                       + llm.vocab_size * llm.hidden_size)
+        kv_bytes = B * llm.num_hidden_layers * 2 * llm.num_key_value_heads * llm.head_dim * (ids.shape[1] + 16) * 2
         out[f'batch{B}'] = {'prefill_ms': round(ts[0] * 1e3, 2), 'decode_tokens_per_s': round(B * 32 / (ts[1] - ts[0]), 1),
-                            'decode_ms_per_step': round((ts[1] - ts[0]) / 32 * 1e3, 3)}
+                            'decode_ms_per_step': round(step_ms, 3), 'decode_us_per_layer_step': round(step_ms * 1e3 / llm.num_hidden_layers, 2),
+                            'decode_roofline': {'bound': 'hbm', 'gbytes_per_step': round((w_bytes + kv_bytes) / 1e9, 3),
+                                                'achieved_gbs': round((w_bytes + kv_bytes) / (step_ms * 1e-3) / 1e9, 1),
+                                                'frac_of_8000': round((w_bytes + kv_bytes) / (step_ms * 1e-3) / 8e12, 4)}}
     out['config'] = 'Vlaser-2B, 1 tile + 256-token prompt (S=560), greedy, 32 new tokens; prefill_ms = ViT + prefill + first token; decode steps replayed from one HIP graph (device-resident slot / key-count state)'
     del m
     torch.cuda.empty_cache()
