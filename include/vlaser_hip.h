@@ -163,42 +163,8 @@ typedef struct {
 
 int vlaser_skinny(int prologue, int epi, const VlaserSkinnyArgs* args, vl_stream_t stream);
 
-/* ---- fused layer-step launches (ABI 4, r03): one launch instead of two of the five of a <= 5-row decoder layer-step -------------------------
- * vlaser_fused_ogu = vlaser_skinny(VL_PRO_ATTN, VL_SK_PARTIAL) [o_proj: flash-decoding merge of the vlaser_attn_skinny partials + split-K GEMV]
- *                  + vlaser_skinny(VL_PRO_NORM, VL_SK_SWIGLU)  [residual + split-K reduce + Qwen2RMSNorm + gate/up GEMV + SwiGLU],
- * bit-identical to the pair (16-row units), replacing the same reference call sites (joint_model.py:140-232,410-696 for the action mixture of
- * every Euler step, pizero_internvl.py:884-924).  The first H/16 * ks_o workgroups compute the o_proj partial tiles and hand them to all 256
- * workgroups INSIDE the launch (write-through stores + arrival counters), while every workgroup's share of the gate/up weights is already in
- * flight.  sync: device uint32[VL_FUSED_SYNC_WORDS], ZEROED BY THE CALLER on the stream before every launch (one memset over all launch
- * slots of a HIP graph); sync[VL_FUSED_SYNC_ERR] != 0 afterwards = a bounded wait expired (result invalid, nothing hangs). */
-#define VL_FUSED_SYNC_WORDS 160
-#define VL_FUSED_SYNC_ERR 128
-typedef struct {
-  /* o_proj: as VlaserSkinnyArgs' VL_PRO_ATTN prologue */
-  const float* attn_m; const float* attn_l; const float* attn_o; int attn_splits, attn_group, attn_nq;
-  const void* Wo;      /* ops.pack_skinny(o_proj.weight, ks_o, tiles_per_unit = 1) */
-  int K_o, ks_o;       /* n_q_heads * 128; cross-workgroup K splits */
-  float* part_o;       /* fp32 [ks_o][M][H] split-K slabs (written write-through, read by every workgroup) */
-  /* gate/up: as VlaserSkinnyArgs' VL_PRO_NORM prologue + VL_SK_SWIGLU on 16-row lane-local units */
-  const void* h_in;    /* bf16 [M,H] residual stream */
-  const void* norm_w; float eps;
-  void* h_out;         /* bf16 [M,H] = bf16(h_in + o_proj), written by workgroup 0 (may be null) */
-  const void* Wgu;     /* ops.pack_skinny(ops.pack_gate_up8(gate, up), 1, 1) */
-  int M, H, N_gu, n_valid_gu;   /* rows; hidden; packed gate/up rows (2 I) and their un-padded count */
-  void* act; int ld_act;        /* bf16 [M, ld_act]: silu(gate) * up */
-  unsigned int* sync;
-  int cons_delay;               /* tuning: consumer-only workgroups start their weight stream this many 10-ns ticks after their start (0 = at once) */
-  unsigned long long* dbg;      /* optional: per-workgroup timestamps [256][8] (wall_clock64, 100 MHz) for kernel tuning */
-} VlaserFusedOguArgs;
-int vlaser_fused_ogu(const VlaserFusedOguArgs* args, vl_stream_t stream);
-
-/* ---- attention + o_proj of a <= 16-row decoder layer-step in one launch (ABI 5, r04; batch 1): replaces vlaser_attn_skinny followed by
- * vlaser_skinny(VL_PRO_ATTN, VL_SK_PARTIAL) at joint_model.py:636-671 (attention of the proprio / action rows over the cached prefix + their own block,
- * then o_proj).  Every workgroup recomputes the attention of its kv group from K / V^T tiles staged in LDS by coalesced LDS-DMA (only the keys a row can
- * see: the valid prefix and [blk_start, kv_len)) and owns 16 output columns of W_o; out_f32 = n_kv_heads partial slabs [sq, N] fp32 (one per kv head)
- * for the consumer's split-K reduction.  wo_packed = ops.pack_skinny(o_proj.weight [N, n_q_heads*128], k_splits = n_kv_heads, tiles_per_unit = 1).
- * `a` as for vlaser_attn_skinny (part_* / n_splits unused); GQA group 2 / 4 / 6 / 8, group * sq <= 32, blk_start a multiple of 16. */
-int vlaser_attn_oproj(const VlaserAttnArgs* a, const void* wo_packed, float* out_f32, int N, vl_stream_t stream);
+/* The two fused layer-step launches measured in r03 / r04 (vlaser_fused_ogu: o_proj -> gate/up with an in-launch hand-off, +2.0 us in-chain;
+ * vlaser_attn_oproj: attention + o_proj in one launch, break-even) are NOT on the default path: include/vlaser_hip_experimental.h. */
 
 /* ---- fused attention backward (ABI 4, r03): the backward of vlaser_attn_prefill's causal / valid-prefix attention (HF eager_attention_forward /
  * flash_attention_2 autograd, modeling_internvl_chat.py:194-203) without materialised score matrices: two deterministic kernels (no atomics) --
@@ -279,7 +245,6 @@ int vlaser_vla_stage(const VlaserVlaStageArgs* args, vl_stream_t stream);
 int vlaser_vla_step(const void* h_in, const float* partials, int n_partials, int rows_in, int row_off, const void* norm_w, float eps, const void* wd,
                     const void* bd, const float* a_in, float* a_out, float* vel_out, float dt, int finish, const float* w21, const float* cs, const void* w3,
                     const void* b3, void* h_out, int M, int W, int adim, vl_stream_t stream);
-int vlaser_reduce_partials(const void* h_in, const float* partials, int n_partials, int M, int K, void* out, vl_stream_t stream);
 int vlaser_cast_f32_bf16(const float* x, void* y, long long n, vl_stream_t stream);
 /* uint8 image -> normalised bf16 pixel_values [n_img, 3, H, W] (ABI 4).  Replaces the host-side fp32 normalisation of
  * InternVLAProcessor.__call__ (Vlaser_VLA/Simpler/src/model/vla/processing.py:51-63,303-311; mode 0: (u8 * (1/255) - mean) / std) and of
@@ -307,16 +272,6 @@ int vlaser_reduce_norm(const void* h_in /* may be null = 0 */, const float* part
  * strides: matrix (b, i), b < batch, i < inner (inner >= 1), starts at in + b*in_bs + i*in_is / out + b*out_bs + i*out_is */
 int vlaser_transpose(const void* in, void* out, int rows, int cols, int ld_in, int ld_out, int pad_rows, int batch, long long in_bs, long long out_bs,
                      int inner, long long in_is, long long out_is, vl_stream_t stream);
-/* fused causal softmax + dS: P = softmax(scale * scores) (bf16), dS = P o (dP - D) * scale with D[q] = sum_d dO[q,d] O[q,d];
- * scores, dP fp32 [H, S, ld]; dO, O bf16 [S, H*hd]; P, dS bf16 [H, S, ld] (0 beyond the diagonal / beyond S) */
-int vlaser_attn_bwd_pds(const float* scores, const float* dP, const void* dO, const void* O, void* P, void* dS, int H, int S, int ld, int hd,
-                        float scale, vl_stream_t stream);
-/* causal softmax of fp32 scores [B, S, ld] * scale -> P bf16 [B, S, ld] (0 beyond the diagonal / beyond S) */
-int vlaser_softmax_causal(const float* scores, void* P, int batch, int S, int ld, float scale, vl_stream_t stream);
-/* dS = P o (dP - D) * scale with D[q] = sum_d dO[q,d] O[q,d]; writes dS [H,S,ld] and the grouped transposes
- * dS_T, P_T [n_kv, ld, G*ld] (key-major, contraction axis (g, q)) for the dK / dV GEMMs */
-int vlaser_attn_bwd_ds(const void* P, const float* dP, const void* dO, const void* O, void* dS, void* dS_T, void* P_T, int n_heads,
-                       int n_kv, int S, int ld, int hd, float scale, vl_stream_t stream);
 /* inverse RoPE on dq/dk + pack [dq | dk | dv] (natural [S, heads*128]) into the packed q/k/v column order.
  * kv_per_q_head != 0: dk / dv are [S, n_q*128] partials, one per Q head, summed here over the heads of each kv group */
 int vlaser_rope_bwd_pack(const void* dq, const void* dk, const void* dv, const float* rope_cos, const float* rope_sin, const int32_t* pos_ids,
@@ -380,9 +335,11 @@ int vlaser_attn_rows_bwd(const void* q, const void* K, const void* VT, const voi
  * vision tower + projector + the VLM mixture's decoder layers; optimiser + schedule train.py:270-295, stepped :509-520).  The gradient reaches the
  * VLM through the keys / values its rows hand to the proprio / action rows, then runs back through the Qwen2 layers (bidirectional valid-prefix
  * mask), mlp1, pixel_shuffle and the 24 InternViT blocks (modeling_intern_vit.py:177-295: LayerNorm, full attention, GELU MLP, layer scale). */
-/* vlaser_attn_bwd_pds with an explicit mask: key k is visible to query row q iff k < kv_valid and (k <= q + q_off when causal != 0); q_off = global
- * index of row 0 when the S rows are a block of a longer sequence (long-sequence SFT walks the queries in blocks: the score matrices stay
- * [heads, block, keys] instead of [heads, S, S]) */
+/* softmax + dS of an attention backward through materialised score matrices, in one pass: P = softmax(scale * scores) over the visible keys (bf16),
+ * dS = P o (dP - D) * scale with D[q] = sum_d dO[q,d] O[q,d]; scores, dP fp32 [H, S, ld]; dO, O bf16 [S, H*hd]; P, dS bf16 [H, S, ld] (0 on masked keys).
+ * Key k is visible to query row q iff k < kv_valid and (k <= q + q_off when causal != 0); q_off = global index of row 0 when the S rows are a block
+ * of a longer sequence (`VLASER_SFT_ATTN_BWD=materialised` walks the queries in blocks: the score matrices stay [heads, block, keys]).  On the default
+ * path this serves the bidirectional valid-prefix / full masks of the VLM group (vla_vlm_group.py); the causal SFT attention uses vlaser_attn_bwd. */
 int vlaser_attn_bwd_pds_masked(const float* scores, const float* dP, const void* dO, const void* O, void* P, void* dS, int n_heads, int S, int ld, int hd,
                                float scale, int causal, int kv_valid, int q_off, vl_stream_t stream);
 /* vlaser_attn_rows_bwd that also stores P and dS of EVERY key, bf16 [n_q][16][s_max] (row r of head h at (h*16 + r)*s_max): the prefix keys' dK / dV

@@ -13,24 +13,40 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header():
-    return open(os.path.join(ROOT, 'include', 'vlaser_hip.h')).read()
+def _header(name='vlaser_hip.h'):
+    return open(os.path.join(ROOT, 'include', name)).read()
+
+
+_PROTO = r'\b(?:int|const char\*)\s+(vlaser_\w+)\s*\('
 
 
 def test_library_exports_every_declared_symbol():
     from vlaser_amd import _lib
     lib = _lib.lib()
-    names = set(re.findall(r'\b(?:int|const char\*)\s+(vlaser_\w+)\s*\(', _header()))
+    names = set(re.findall(_PROTO, _header()))
     assert len(names) >= 20
     for n in sorted(names):
         assert hasattr(lib, n), f'{n} declared in include/vlaser_hip.h but not exported by libvlaser_hip.so'
     assert lib.vlaser_abi_version() == 5
-    # every bound signature refers to a declared symbol
-    assert set(_lib._SIGS) <= names
+    # the entry points that are measured but on no default path live in their own header, and INTEGRATION.md does not offer them
+    experimental = set(re.findall(_PROTO, _header('vlaser_hip_experimental.h')))
+    assert experimental == {'vlaser_fused_ogu', 'vlaser_attn_oproj'} and not (experimental & names)
+    for n in sorted(experimental):
+        assert hasattr(lib, n), n
+    integration = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    assert not any(n in integration for n in experimental)
+    # every bound signature refers to a declared symbol, and the library exports nothing that no header declares
+    assert set(_lib._SIGS) <= names | experimental
+    import subprocess
+    out = subprocess.run(['/usr/bin/nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r'\bT (vlaser_\w+)', out))
+    assert exported and exported - {'vlaser_set_error', 'vlaser_attn_oproj_debug_read'} <= names | experimental, sorted(exported - names - experimental)
 
 
 def _struct_fields(name):
     h = _header()
+    if ('} ' + name + ';') not in h:
+        h = _header('vlaser_hip_experimental.h')
     end = h.index('} ' + name + ';')
     body = h[h.rindex('typedef struct {', 0, end) + len('typedef struct {'):end]
     body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)

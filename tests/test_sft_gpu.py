@@ -354,7 +354,7 @@ def test_gemm_tn_lds_ragged_output_rows():
 
 
 def test_attention_backward_fused_pds_and_grouped_tn():
-    """vlaser_attn_bwd_pds (softmax + dS in one pass) and the grouped TN GEMM (dK / dV summed over the q heads of a kv group)
+    """vlaser_attn_bwd_pds_masked (softmax + dS in one pass, causal) and the grouped TN GEMM (dK / dV summed over the q heads of a kv group)
     against the closed forms, on a ragged S (not a multiple of 64)."""
     from vlaser_amd import ops
     g = torch.Generator().manual_seed(5)
@@ -365,7 +365,7 @@ def test_attention_backward_fused_pds_and_grouped_tn():
     sc[:, :, :S] = (torch.randn(H, S, S, generator=g) * 4).cuda(); dP[:, :, :S] = torch.randn(H, S, S, generator=g).cuda()
     dO = torch.randn(S, H * hd, generator=g).to(BF).cuda(); O = torch.randn(S, H * hd, generator=g).to(BF).cuda()
     P = torch.full((H, S, Sp), 7, dtype=BF, device='cuda'); dS = torch.full((H, S, Sp), 7, dtype=BF, device='cuda')
-    ops.attn_bwd_pds(sc, dP, dO, O, P, dS, H, S, Sp, hd, scale)
+    ops.attn_bwd_pds_masked(sc, dP, dO, O, P, dS, H, S, Sp, hd, scale, True, Sp, 0)
     mask = torch.tril(torch.ones(S, S, dtype=torch.bool, device='cuda'))
     Pref = (sc[:, :, :S] * scale).masked_fill(~mask, float('-inf')).softmax(-1)
     D = (dO.float() * O.float()).view(S, H, hd).sum(-1).t()                      # [H, S]

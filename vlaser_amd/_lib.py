@@ -79,7 +79,6 @@ _SIGS = {
     'vlaser_vla_step': [vp, vp, i32, i32, i32, vp, f32, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     'vlaser_vla_euler': [vp, vp, i32, i32, vp, f32, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, vp, i32, i32, vp],
     'vlaser_vla_stage': [C.POINTER(VlaStageArgs), vp],
-    'vlaser_reduce_partials': [vp, vp, i32, i32, i32, vp, vp],
     'vlaser_cast_f32_bf16': [vp, vp, i64, vp],
     'vlaser_normalize_u8': [vp, vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp],
     'vlaser_avg_update': [vp, vp, i64, f32, i32, vp],
@@ -88,10 +87,7 @@ _SIGS = {
     'vlaser_gemm_tn': [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp],
     'vlaser_gemm_tn_lds': [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp],
     'vlaser_gemm_tn_grouped': [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, i64, i32, i64, i64, i64, vp],
-    'vlaser_attn_bwd_pds': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     'vlaser_transpose': [vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i32, i64, i64, vp],
-    'vlaser_softmax_causal': [vp, vp, i32, i32, i32, f32, vp],
-    'vlaser_attn_bwd_ds': [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp],
     'vlaser_rope_bwd_pack': [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     'vlaser_rmsnorm_bwd': [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     'vlaser_colsum_bf16': [vp, vp, i32, i32, i32, vp],

@@ -18,7 +18,7 @@
 // Row order, masks (VL_ATTN_FULL / VL_ATTN_PREFIX with valid_len, blk_start, first_tok_kv_len) and rounding points are attn_skinny's + VL_PRO_ATTN's:
 // scores in fp32, P rounded to bf16 for the MFMA, attention rows rounded to bf16 before o_proj, fp32 partial slabs out.
 #include "common.h"
-#include "../../include/vlaser_hip.h"
+#include "../../include/vlaser_hip_experimental.h"
 
 #define AO_WAVES 8
 #define AO_THREADS (AO_WAVES * 64)

@@ -24,7 +24,7 @@
 // Numerics: identical arithmetic, in the same order, as the two kernels it replaces (skinny_kernel<ATTN,PARTIAL> with 16-row units + skinny_kernel<NORM,SWIGLU>
 // with 16-row lane-local units): tests/test_ops_gpu.py asserts bit equality.
 #include "common.h"
-#include "../../include/vlaser_hip.h"
+#include "../../include/vlaser_hip_experimental.h"
 
 #define EU_W 8
 #define EU_T (EU_W * 64)

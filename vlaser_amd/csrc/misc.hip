@@ -658,23 +658,6 @@ extern "C" int vlaser_vla_step(const void* h_in, const float* partials, int n_pa
   return 0;
 }
 
-// residual fix-up after the last layer of a prefill-with-skinny row: h = bf16(h_in + sum partials)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const bf16_t* __restrict__ h_in, const float* __restrict__ partials,
-                                                              int n_partials, int M, int K, bf16_t* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= M * K) return;
-  float v = bf16_to_f32(h_in[i]);
-  for (int s = 0; s < n_partials; ++s) v += partials[(size_t)s * M * K + i];
-  out[i] = f32_to_bf16(v);
-}
-extern "C" int vlaser_reduce_partials(const void* h_in, const float* partials, int n_partials, int M, int K, void* out, vl_stream_t s) {
-  VL_CHECK(h_in && out && (n_partials == 0 || partials), "vlaser_reduce_partials: bad args");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((M * K + 255) / 256), dim3(256), 0, (hipStream_t)s, (const bf16_t*)h_in, partials,
-                     n_partials, M, K, (bf16_t*)out);
-  VL_LAUNCH_CHECK();
-  return 0;
-}
-
 // fp32 -> bf16 cast (pixel values / host inputs)
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -72,66 +72,6 @@ extern "C" int vlaser_transpose(const void* in, void* out, int rows, int cols, i
   return 0;
 }
 
-// ---------------------------------------------------------------------------------------------- causal softmax
-// P[b, q, k] = softmax_k(scale * scores[b, q, k]) over k <= q, 0 elsewhere (k < ld).  One wave per row.
-__global__ __launch_bounds__(256) void softmax_causal_kernel(const float* __restrict__ sc, bf16_t* __restrict__ P, int S, int ld, float scale) {
-  const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
-  if (q >= S) return;
-  const float* row = sc + ((size_t)b * S + q) * ld;
-  bf16_t* prow = P + ((size_t)b * S + q) * ld;
-  float mx = -INFINITY;
-  for (int k = lane; k <= q; k += 64) mx = fmaxf(mx, row[k] * scale);
-  mx = wave_max(mx);
-  float sum = 0.f;
-  for (int k = lane; k <= q; k += 64) sum += __expf(row[k] * scale - mx);
-  sum = wave_sum(sum);
-  const float inv = 1.0f / sum;
-  for (int k = lane; k < ld; k += 64) prow[k] = (k <= q) ? f32_to_bf16(__expf(row[k] * scale - mx) * inv) : (bf16_t)0;
-}
-extern "C" int vlaser_softmax_causal(const float* scores, void* P, int batch, int S, int ld, float scale, vl_stream_t s) {
-  VL_CHECK(scores && P && S > 0 && ld >= S, "vlaser_softmax_causal: bad args");
-  hipLaunchKernelGGL(softmax_causal_kernel, dim3((S + 3) / 4, batch), dim3(256), 0, (hipStream_t)s, scores, (bf16_t*)P, S, ld, scale);
-  VL_LAUNCH_CHECK();
-  return 0;
-}
-
-// ---------------------------------------------------------------------------------------------- attention backward dS
-// D[q] = sum_d dO[q, h*hd + d] * O[q, h*hd + d];  dS[h,q,k] = P * (dP - D) * scale.
-// Writes dS [H, S, ld] and the grouped transposes dS_T / P_T [n_kv, ld(k), G*ld] at [kvh][k][g*ld + q] (zero padded rows/cols
-// come from the zero-initialised buffers: only k, q < S are written).  One wave per (h, q) row.
-__global__ __launch_bounds__(256) void attn_bwd_ds_kernel(const bf16_t* __restrict__ P, const float* __restrict__ dP, const bf16_t* __restrict__ dO,
-                                                          const bf16_t* __restrict__ O, bf16_t* __restrict__ dS, bf16_t* __restrict__ dS_T,
-                                                          bf16_t* __restrict__ P_T, int H, int n_kv, int S, int ld, int hd, float scale) {
-  const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y;
-  if (q >= S) return;
-  const int G = H / n_kv, kvh = h / G, g = h - kvh * G;
-  const bf16_t* dorow = dO + (size_t)q * H * hd + h * hd;
-  const bf16_t* orow = O + (size_t)q * H * hd + h * hd;
-  float d = 0.f;
-  for (int i = lane; i < hd; i += 64) d += bf16_to_f32(dorow[i]) * bf16_to_f32(orow[i]);
-  d = wave_sum(d);
-  const size_t ro = ((size_t)h * S + q) * ld;
-  bf16_t* dsT = dS_T + (size_t)kvh * ld * G * ld + (size_t)g * ld + q;
-  bf16_t* pT = P_T + (size_t)kvh * ld * G * ld + (size_t)g * ld + q;
-  for (int k = lane; k < ld; k += 64) {
-    const float p = bf16_to_f32(P[ro + k]);
-    const bf16_t ds = (k <= q) ? f32_to_bf16(p * (dP[ro + k] - d) * scale) : (bf16_t)0;
-    dS[ro + k] = ds;
-    if (k < S) {
-      dsT[(size_t)k * G * ld] = ds;
-      pT[(size_t)k * G * ld] = P[ro + k];
-    }
-  }
-}
-extern "C" int vlaser_attn_bwd_ds(const void* P, const float* dP, const void* dO, const void* O, void* dS, void* dS_T, void* P_T, int H, int n_kv,
-                                  int S, int ld, int hd, float scale, vl_stream_t s) {
-  VL_CHECK(P && dP && dO && O && dS && dS_T && P_T && H % n_kv == 0 && ld >= S, "vlaser_attn_bwd_ds: bad args");
-  hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3((S + 3) / 4, H), dim3(256), 0, (hipStream_t)s, (const bf16_t*)P, dP, (const bf16_t*)dO,
-                     (const bf16_t*)O, (bf16_t*)dS, (bf16_t*)dS_T, (bf16_t*)P_T, H, n_kv, S, ld, hd, scale);
-  VL_LAUNCH_CHECK();
-  return 0;
-}
-
 // ---------------------------------------------------------------------------------------------- fused softmax + dS
 // One wave per (h, q) row, the row (ld <= 1024 columns) stays in registers: P = softmax(scale * s) over k <= q, D = <dO, O>,
 // dS = P (dP - D) scale.  dK / dV then come from the grouped TN GEMM, so no transposed copies of P / dS are produced.
@@ -216,11 +156,6 @@ extern "C" int vlaser_attn_bwd_pds_masked(const float* scores, const float* dP, 
                        (bf16_t*)P, (bf16_t*)dS, H, S, ld, hd, scale, causal, kv_valid, q_off);
   VL_LAUNCH_CHECK();
   return 0;
-}
-extern "C" int vlaser_attn_bwd_pds(const float* scores, const float* dP, const void* dO, const void* O, void* P, void* dS, int H, int S, int ld, int hd,
-                                   float scale, vl_stream_t s) {
-  VL_CHECK(ld >= S, "vlaser_attn_bwd_pds: ld < S");
-  return vlaser_attn_bwd_pds_masked(scores, dP, dO, O, P, dS, H, S, ld, hd, scale, 1, ld, 0, s);
 }
 
 // ---------------------------------------------------------------------------------------------- RoPE backward + pack

@@ -482,11 +482,6 @@ def fold_action_encoder(w1, b1, w2, b2, W, adim, n_steps, max_period):
     return w21, cs
 
 
-def reduce_partials(h_in, partials, n_partials, M, K, out):
-    L.check(L.lib().vlaser_reduce_partials(h_in.data_ptr(), _p(partials), n_partials, M, K, out.data_ptr(), _stream()),
-            'vlaser_reduce_partials')
-
-
 def reduce_norm(h_in, partials, n_partials, M, C, h_out, x_out=None, bias=None, ls=None, norm=0, norm_w=None, norm_b=None, eps=1e-6):
     """h_out = h_in + [ls*](sum partials [+bias]); x_out = norm(h_out) (norm: 0 none, 1 RMS, 2 LayerNorm)."""
     L.check(L.lib().vlaser_reduce_norm(_p(h_in), _p(partials), n_partials, _p(bias), _p(ls), norm, _p(norm_w), _p(norm_b), eps,
@@ -636,23 +631,9 @@ def gemm_tn_grouped(At, Wt, out, M, N, K, ldat, ldwt, ldo, groups, a_gs, w_gs, b
                                            a_bs, w_bs, o_bs, _stream()), 'vlaser_gemm_tn_grouped')
 
 
-def attn_bwd_pds(scores, dP, dO, O, P, dS, H, S, ld, hd, scale):
-    L.check(L.lib().vlaser_attn_bwd_pds(scores.data_ptr(), dP.data_ptr(), dO.data_ptr(), O.data_ptr(), P.data_ptr(), dS.data_ptr(), H, S, ld, hd,
-                                        scale, _stream()), 'vlaser_attn_bwd_pds')
-
-
 def transpose(x, out, rows, cols, ld_in, ld_out, pad_rows=None, batch=1, in_bs=0, out_bs=0, inner=1, in_is=0, out_is=0):
     L.check(L.lib().vlaser_transpose(x.data_ptr(), out.data_ptr(), rows, cols, ld_in, ld_out, ld_out if pad_rows is None else pad_rows, batch,
                                      in_bs, out_bs, inner, in_is, out_is, _stream()), 'vlaser_transpose')
-
-
-def softmax_causal(scores, P, batch, S, ld, scale):
-    L.check(L.lib().vlaser_softmax_causal(scores.data_ptr(), P.data_ptr(), batch, S, ld, scale, _stream()), 'vlaser_softmax_causal')
-
-
-def attn_bwd_ds(P, dP, dO, O, dS, dS_T, P_T, H, n_kv, S, ld, hd, scale):
-    L.check(L.lib().vlaser_attn_bwd_ds(P.data_ptr(), dP.data_ptr(), dO.data_ptr(), O.data_ptr(), dS.data_ptr(), dS_T.data_ptr(), P_T.data_ptr(),
-                                       H, n_kv, S, ld, hd, scale, _stream()), 'vlaser_attn_bwd_ds')
 
 
 def rope_bwd_pack(dq, dk, dv, cos, sin, pos, out, S, n_q, n_kv, kv_per_q_head=False):
