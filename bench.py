@@ -370,7 +370,7 @@ def main():
                                               '(5 per layer-step), see DESIGN.md section 3'}
             line['roofline'] = {'bound': 'hbm', 'kernel': 'skinny_kernel<NORM,SWIGLU> (action-expert gate/up GEMV, N=17920 K=768, M=4; 307 launches per chunk)',
                                 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                                'traffic': _pmc_traffic(), 'traffic_source': {'file': 'profiles/r03m_pmc_dominant_kernel.json', 'measured_in_run': False,
+                                'traffic': _pmc_traffic(), 'traffic_source': {'file': 'profiles/r04s_pmc_dominant_kernel.json', 'measured_in_run': False,
                                                                         'how': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on tools/pmc/skinny_pmc (torch-free harness, same kernel and shape)'},
                                 'bytes_per_launch': byts, 'us_per_launch': round(avg_ms * 1e3, 3), 'launches_timed': n,
                                 'timing': 'IN-CHAIN: (Euler-phase graph with the kernel - the same graph without it) / launches, HIP events on the launch stream; '
@@ -586,9 +586,9 @@ def qa8b_bench(local):
 def _pmc_traffic():
     """HBM bytes per launch of the dominant kernel from hardware counters.  rocprofv3 --pmc cannot run under torch on this
     image, so the counters are collected by the torch-free harness tools/pmc/skinny_pmc.cpp on the same kernel and shape
-    (profiles/r03m_pmc_dominant_kernel.md has the commands and the gfx950 FETCH_SIZE correction; re-collected whenever skinny.hip
+    (profiles/r04s_pmc_dominant_kernel.md has the commands and the gfx950 FETCH_SIZE correction; re-collected whenever skinny.hip
     changes); None if absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03m_pmc_dominant_kernel.json')
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r04s_pmc_dominant_kernel.json')
     try:
         return json.load(open(path))['traffic_bytes_per_launch']
     except (OSError, KeyError, ValueError):

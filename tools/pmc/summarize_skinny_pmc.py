@@ -20,13 +20,13 @@ alg = N * K * 2 + M * K * 2 + NP * M * K * 4 + M * (N // 2) * 2
 fetch_b = fm * 1024 * 2                   # gfx950: FETCH_SIZE tallies the 128-B requests of wide coalesced reads at 64 B (MI355X_MICROARCH.md, HBM)
 write_b = wm * 1024
 unprof = open(os.path.join(raw, 'unprofiled.log')).read().strip().splitlines()[-1] if os.path.exists(os.path.join(raw, 'unprofiled.log')) else ''
-js = {'kernel': 'skinny_kernel<NORM,SWIGLU,2,3,SP=3> (action-expert gate/up GEMV, N=17920 K=768 M=4, 3 split-K slabs), round-3 build',
+js = {'kernel': 'skinny_kernel<NORM,SWIGLU,2,3,SP=3> (action-expert gate/up GEMV, N=17920 K=768 M=4, 3 split-K slabs)',
       'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- tools/pmc/skinny_pmc 2 (separate passes; tools/pmc/collect_skinny_pmc.sh)',
       'fetch_size_kb_mean': round(fm, 2), 'write_size_kb_mean': round(wm, 2), 'fetch_bytes_corrected': fetch_b, 'write_bytes': write_b,
       'traffic_bytes_per_launch': int(fetch_b + write_b), 'algorithmic_bytes_per_launch': alg, 'traffic_over_algorithmic': round((fetch_b + write_b) / alg, 4)}
 json.dump(js, open(os.path.join(out, f'{tag}_pmc_dominant_kernel.json'), 'w'), indent=1)
 with open(os.path.join(out, f'{tag}_pmc_dominant_kernel.md'), 'w') as f:
-    f.write(f'# {tag} -- HBM traffic of the dominant kernel from hardware counters (round-3 build)\n\n')
+    f.write(f'# {tag} -- HBM traffic of the dominant kernel from hardware counters\n\n')
     f.write('`skinny_kernel<NORM,SWIGLU,2,3,SP=3>`, N=17920, K=768, M=4, 3 slabs; harness `tools/pmc/skinny_pmc.cpp` (torch-free), 28 distinct 27.5 MB weight buffers cycled;\n')
     f.write('separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes with `--kernel-trace` only (`tools/pmc/collect_skinny_pmc.sh`); raw CSVs next to this file.\n\n')
     f.write('| counter | dispatches used | mean (KB) | min | max |\n|---|---|---|---|---|\n')
