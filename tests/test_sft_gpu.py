@@ -227,7 +227,8 @@ def test_gemm_tn_weight_gradient(K, M, N):
 
 
 @pytest.mark.parametrize('K,M,N,cfg', [(560, 1536, 2048, 0), (560, 17920, 1536, 0), (560, 1536, 8960, 0), (313, 256, 1536, 1100), (64, 136, 264, 1105),
-                                       (130, 2048, 1536, 1200), (200, 1000, 520, 1300)])
+                                       (130, 2048, 1536, 1200), (200, 1000, 520, 1300), (560, 17920, 1536, 1340), (200, 1000, 520, 1340), (313, 264, 1536, 1240), (64, 136, 264, 1140),
+                                       (96, 1536, 2048, 1140), (32, 304, 264, 1340)])
 def test_gemm_tn_lds_padded_contraction(K, M, N, cfg):
     """vlaser_gemm_tn_lds (the TN weight-gradient product on the LDS-DMA pipeline, both operands k-major): contraction axis padded to 64-row
     tiles with ZERO pad rows in At and arbitrary finite pad rows in Wt; edge tiles in M and N; every tile configuration.  Against fp32 and
@@ -249,7 +250,7 @@ def test_gemm_tn_lds_padded_contraction(K, M, N, cfg):
 
 
 @pytest.mark.parametrize('K,M,N,cfg,lds', [(576, 1536, 2048, 0, True), (576, 17920, 1536, 0, True), (320, 1000, 520, 1300, True), (64, 136, 264, 1105, True),
-                                           (128, 2048, 1536, 1200, True), (100, 304, 200, 0, False), (200, 1000, 1528, 0, False)])
+                                           (128, 2048, 1536, 1200, True), (576, 17920, 1536, 1340, True), (320, 1000, 520, 1240, True), (100, 304, 200, 0, False), (200, 1000, 1528, 0, False)])
 def test_gemm_tn_sumsq_slots(K, M, N, cfg, lds):
     """`sumsq_part` of the weight-gradient GEMMs (r04): the slots the launch writes add up to the sum of the squares of the bf16 values it stored (the
     gradient norm's share of the tensor, without reading it back) -- every tile configuration, ragged edges, both kernels; untouched slots stay as

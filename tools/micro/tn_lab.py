@@ -23,7 +23,7 @@ for (N, K, name) in [(17920, 1536, 'gate/up'), (1536, 8960, 'down'), (2048, 1536
     xp[:S] = x
     out3 = torch.zeros(N, K, dtype=BF, device='cuda')
     res = []
-    for cfg in (1100, 1105, 1200, 1300):
+    for cfg in (1100, 1200, 1300, 1140, 1240, 1340):
         try:
             u = timeit([lambda t=t: ops.gemm_tn_lds(t, xp, out3, Sp, force_cfg=cfg) for t in dps])
             res.append(f'{cfg}: {u:6.2f} us ({fl / u / 1e6:5.0f} TF)')

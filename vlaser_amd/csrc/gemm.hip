@@ -298,6 +298,7 @@ __device__ __forceinline__ void epilogue_tile_swiglu_bwd(const VlaserGemmArgs& a
   const bf16_t* gu = reinterpret_cast<const bf16_t*>(a.res);
   bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
   const bool in_range = n_w + NT * 16 <= a.N;              // wave-uniform; a ragged right edge takes the guarded path per fragment
+  const bool wide = (a.ldo & 7) == 0 && (((uintptr_t)out & 15) == 0);      // 16-byte stores
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m_w + mt * 16 + fr;
@@ -322,9 +323,17 @@ __device__ __forceinline__ void epilogue_tile_swiglu_bwd(const VlaserGemmArgs& a
         dg[j] = d * u * sig * (1.0f + g * (1.0f - sig));
         du[j] = d * g * sig;
       }
-      if (m < a.M && (in_range || n + 3 < a.N)) {
-        *reinterpret_cast<u32x2*>(out + row + pg) = u32x2{pack_bf16x2(dg[0], dg[1]), pack_bf16x2(dg[2], dg[3])};
-        *reinterpret_cast<u32x2*>(out + row + pg + 16) = u32x2{pack_bf16x2(du[0], du[1]), pack_bf16x2(du[2], du[3])};
+      const u32x2 pg_ = u32x2{pack_bf16x2(dg[0], dg[1]), pack_bf16x2(dg[2], dg[3])}, pu_ = u32x2{pack_bf16x2(du[0], du[1]), pack_bf16x2(du[2], du[3])};
+      if (in_range && wide) {
+        // r04: d(gate) and d(up) of one column tile are neighbours in the packed row ([gate16 | up16]): lane pairs 16 apart trade halves
+        // (v_permlane16_swap; both lanes of a pair hold the same row, so the row mask cannot split them) and every lane stores 16 bytes -- one
+        // instruction per tile writing 64 contiguous bytes of 16 rows instead of two writing 32
+        const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pg_[0], pu_[0], false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pg_[1], pu_[1], false, false);
+        if (m < a.M) *reinterpret_cast<u32x4*>(out + row + (n_w + nt * 16) * 2 + (fq & 1) * 16 + (fq >> 1) * 8) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+      } else if (m < a.M && (in_range || n + 3 < a.N)) {
+        *reinterpret_cast<u32x2*>(out + row + pg) = pg_;
+        *reinterpret_cast<u32x2*>(out + row + pg + 16) = pu_;
       }
     }
   }
@@ -338,9 +347,25 @@ __device__ __forceinline__ void epilogue_tile_swiglu_bwd(const VlaserGemmArgs& a
 // up front as 8-byte loads, the math is branch-free, only the stores are predicated.
 // SSQ (r04, the TN weight-gradient form only): also returns this lane's sum of the squares of the bf16 values it STORED -- the gradient norm's
 // share of this tile, so that the 3.6 GB gradient buffer is not read back for it (sft.py `_norm_bucket`).
+// Row-contiguous stores (r04).  An MFMA output fragment gives a lane 4 consecutive columns of one row: stored directly, a wave instruction writes 16 rows x 32
+// bytes -- a quarter of a 128-byte line per row, and MT x NT such instructions per wave.  Priced with the stores predicated off (tools/micro/
+// gemm_epilogue_lab.py): 19 of the 54 us of the gate/up weight gradient, 10 of 27 (down), 3 of 15 (ViT fc1).  With `scr` (this wave's private piece of the
+// stage ring, free once every wave has left the K loop: the caller barriers first) the wave tile goes through LDS MC x 16 rows at a time and leaves as
+// 16 bytes per lane, whole rows of the wave tile per 2 NT lanes: NT x 32 bytes contiguous, a quarter of the instructions for NT = 4.  The row pitch of the
+// scratch image (+16 bytes) spreads the 16 rows of a fragment store over distinct banks.
+#ifndef GEMM_STORE_MODE
+#define GEMM_STORE_MODE 1        // 0 = fragment stores (8 bytes per lane), 1 = rows through LDS (16 bytes per lane, NT x 32 contiguous), 2 = lane-pair swap (16 bytes, 64 contiguous)
+#endif
+template <int MT, int NT> struct EpiScratch {
+  static constexpr int MC = (MT % 4 == 0) ? 4 : (MT % 3 == 0) ? 3 : (MT % 2 == 0) ? 2 : 1;      // 16-row tiles per pass through the scratch image
+  static constexpr int ROWB = NT * 32 + 16, LPR = NT * 2, RPI = 64 / LPR;                        // row pitch; lanes per row; rows per 64-lane instruction
+  static constexpr int BYTES = MC * 16 * ROWB;
+  static_assert(64 % LPR == 0 && (MC * 16) % RPI == 0, "wave tiles of 1 / 2 / 4 / 8 column tiles");
+};
 template <int EPI, int MT, int NT, bool SSQ = false>
-__device__ __forceinline__ float epilogue_tile(const VlaserGemmArgs& a, int m_w, int n_w, int fr, int fq, f32x4 (&acc)[NT][MT]) {
+__device__ __forceinline__ float epilogue_tile(const VlaserGemmArgs& a, int m_w, int n_w, int fr, int fq, f32x4 (&acc)[NT][MT], char* scr = nullptr) {
   static_assert(!SSQ || EPI == VL_EPI_NONE, "the sum of squares is taken of the plain bf16 output");
+  typedef EpiScratch<MT, NT> ES;
   float ssq = 0.f;
   constexpr bool HAS_BIAS = (EPI == VL_EPI_BIAS || EPI == VL_EPI_BIAS_GELU || EPI == VL_EPI_BIAS_LS_RES);
   constexpr bool HAS_RES = (EPI == VL_EPI_BIAS_LS_RES || EPI == VL_EPI_RES);
@@ -370,6 +395,7 @@ __device__ __forceinline__ float epilogue_tile(const VlaserGemmArgs& a, int m_w,
       }
     return ssq;
   }
+  const bool via_lds = GEMM_STORE_MODE == 1 && scr != nullptr && (a.ldo & 7) == 0 && (((uintptr_t)out & 15) == 0);
   u32x2 bv[NT], lv[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -405,9 +431,70 @@ __device__ __forceinline__ float epilogue_tile(const VlaserGemmArgs& a, int m_w,
       pk[nt] = u32x2{pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
       if constexpr (EPI == VL_EPI_BIAS_GELU) pa[nt] = u32x2{pack_bf16x2(z[0], z[1]), pack_bf16x2(z[2], z[3])};
     }
-    if (m < a.M) {
+#if GEMM_STORE_MODE == 2
+    // lane pairs 16 apart trade halves of two neighbouring column tiles (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the
+    // second): afterwards a lane holds 8 consecutive columns (16 bytes) of ONE tile -- tile nt for even fq, nt + 1 for odd fq -- and a wave
+    // instruction writes 64 contiguous bytes of each of 16 rows, with no LDS pass and half the store instructions
+    if ((a.ldo & 7) == 0 && (((uintptr_t)out & 15) == 0)) {
+#ifdef GEMM_LAB_NOSTORE
+      const bool st_ok = m < a.M && a.ldo == 12345;
+#else
+      const bool st_ok = m < a.M;
+#endif
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<u32x2*>(out + row + n_w + nt * 16 + fq * 4) = pk[nt];
+      for (int nt = 0; nt < NT; nt += 2) {
+        const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[nt][0], pk[nt + 1][0], false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[nt][1], pk[nt + 1][1], false, false);
+        if (st_ok) *reinterpret_cast<u32x4*>(out + row + n_w + (nt + (fq & 1)) * 16 + (fq >> 1) * 8) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+      }
+      if constexpr (SSQ) {
+        if (m < a.M) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const float r0 = bf16lo_to_f32(pk[nt][0]), r1 = bf16hi_to_f32(pk[nt][0]), r2 = bf16lo_to_f32(pk[nt][1]), r3 = bf16hi_to_f32(pk[nt][1]);
+            ssq += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+          }
+        }
+      }
+      if constexpr (EPI == VL_EPI_BIAS_GELU) {
+        if (m < a.M && a.aux_out) {
+          bf16_t* aux = reinterpret_cast<bf16_t*>(a.aux_out) + (size_t)m * a.ld_aux + n_w + fq * 4;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<u32x2*>(aux + nt * 16) = pa[nt];
+        }
+      }
+      continue;
+    }
+#endif
+    if (via_lds) {
+      char* wrow = scr + ((mt % ES::MC) * 16 + fr) * ES::ROWB + fq * 8;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<u32x2*>(wrow + nt * 32) = pk[nt];
+      if ((mt % ES::MC) == ES::MC - 1) {                   // the pass is complete: whole rows back out, 16 bytes per lane
+        const int lane = fq * 16 + fr;
+#pragma unroll
+        for (int i = 0; i < ES::MC * 16 / ES::RPI; ++i) {
+          const int r = i * ES::RPI + lane / ES::LPR, slot = lane % ES::LPR;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(scr + r * ES::ROWB + slot * 16);
+          const int mr = m_w + (mt - (ES::MC - 1)) * 16 + r;
+#ifdef GEMM_LAB_NOSTORE          // lab build only (tools/micro/gemm_epilogue_lab.py): the epilogue's global stores predicated off, to price them
+          if (mr < a.M && a.ldo == 12345)
+#else
+          if (mr < a.M)
+#endif
+            *reinterpret_cast<u32x4*>(out + (size_t)mr * a.ldo + n_w + slot * 8) = v;
+        }
+      }
+    }
+#ifdef GEMM_LAB_NOSTORE
+    if (m < a.M && (a.ldo == 12345 || via_lds)) {
+#else
+    if (m < a.M) {
+#endif
+      if (!via_lds) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<u32x2*>(out + row + n_w + nt * 16 + fq * 4) = pk[nt];
+      }
       if constexpr (SSQ) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -590,6 +677,14 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// Lab build (-DGEMM_TIMELINE, tools/micro/gemm_timeline.py): s_memtime stamps of wave 0 of every workgroup of gemm_glds_kernel
+#ifdef GEMM_TIMELINE
+__device__ long long gemm_dbg[1024 * 40];
+#define GEMM_STAMP(i) { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x < 1024 && (i) < 40) gemm_dbg[blockIdx.x * 40 + (i)] = clock64(); __builtin_amdgcn_sched_barrier(0); }
+extern "C" int vlaser_gemm_debug_read(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gemm_dbg), sizeof(long long) * 1024 * 40); }
+#else
+#define GEMM_STAMP(i)
+#endif
 #ifndef GLDS_ISSUE_FIRST
 #define GLDS_ISSUE_FIRST 0        // 1 = r02 order (refill issued right behind the barrier, in front of the fragment reads)
 #endif
@@ -624,6 +719,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
   const int nwg = gridDim.x;
+  GEMM_STAMP(0)
   int bid = blockIdx.x;
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -682,11 +778,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
 
 #pragma unroll
   for (int st = 0; st < NST - 1; ++st) issue_tile(st, st);
+  GEMM_STAMP(1)
   const int fr = lane & 15, fq = lane >> 4;
   int st = 0;                                            // stage of tile kt
   for (int kt = 0; kt < nk; ++kt) {
     wait_vmcnt<PIECES * (NST - 2)>();                    // this wave's pieces of tile kt have landed (younger tiles may fly)
     __builtin_amdgcn_s_barrier();                        // ... and everyone else's; also: all waves are done reading stage kt-1
+    GEMM_STAMP(2 + kt)
     int stn = st + NST - 1; if (stn >= NST) stn -= NST;  // = (kt-1) % NST: the stage read in the previous step
     const char* As = smem + st * STAGE;
     const char* Ws = As + BM * 128;
@@ -738,6 +836,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
     }
     if (++st == NST) st = 0;
   }
+  GEMM_STAMP(36)
   wait_vmcnt<0>();                                       // drain the clamped look-ahead tiles before the block retires
 
   VlaserGemmArgs ea = a;
@@ -746,16 +845,26 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
     if (ea.out_f32) ea.out_f32 += (size_t)bz * a.o_bs;
     if (ea.res) ea.res = reinterpret_cast<const char*>(ea.res) + (size_t)bz * a.o_bs * 2;
   }
+  [[maybe_unused]] char* scr = nullptr;                // this wave's scratch for the row-contiguous stores: the stage ring, once every wave is out of the K loop
+  if constexpr (EPI == VL_EPI_NONE || EPI == VL_EPI_BIAS || EPI == VL_EPI_BIAS_GELU || EPI == VL_EPI_BIAS_LS_RES || EPI == VL_EPI_RES) {
+    static_assert(NW * EpiScratch<MT, NT>::BYTES <= NST * STAGE, "epilogue scratch exceeds the stage ring");
+    __builtin_amdgcn_s_barrier();                        // (each wave drained its own LDS-DMA pieces above: nothing lands in the ring any more)
+    scr = smem + wave * EpiScratch<MT, NT>::BYTES;
+  }
   if constexpr (EPI == VL_EPI_NONE && AKM) {           // the weight-gradient form: optionally this wave's share of the gradient norm (one slot per wave,
-    const float ssq = epilogue_tile<EPI, MT, NT, true>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc);      // no atomics: the caller sums the slots in order)
+    GEMM_STAMP(37)
+    const float ssq = epilogue_tile<EPI, MT, NT, true>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc, scr);      // no atomics: the caller sums the slots in order)
     if (a.sumsq_part) {
       const float w = wave_sum(ssq);
       if (lane == 0) a.sumsq_part[(size_t)(blockIdx.x + gridDim.x * blockIdx.z) * NW + wave] = w;
     }
+    GEMM_STAMP(38)
     return;
   }
   if constexpr (EPI == VL_EPI_NONE || EPI == VL_EPI_BIAS || EPI == VL_EPI_BIAS_GELU || EPI == VL_EPI_BIAS_LS_RES || EPI == VL_EPI_RES) {
-    epilogue_tile<EPI, MT, NT>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc);
+    GEMM_STAMP(37)
+    epilogue_tile<EPI, MT, NT>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc, scr);
+    GEMM_STAMP(38)
     return;
   }
   if constexpr (EPI == VL_EPI_QKV_ROPE) {
@@ -781,6 +890,154 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
       for (int nt = 0; nt < NT; ++nt) epilogue<EPI>(ea, m, n0 + wc * WTN + nt * 16 + fq * 4, acc[nt][mt], acc[nt][mt]);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------- TN form, two staggered wave groups (r04)
+// The eight waves of gemm_glds_kernel read their fragments together and issue their MFMAs together: the MFMA pipe sits idle while both waves of a SIMD
+// are in their LDS-read phase, and 36-51 % of the wave time is an issue stall behind the sibling (profiles/r04r_pmc_gemm.md: 24 % of the pipe busy on
+// the weight gradients).  Here waves 0-3 and waves 4-7 (one of each per SIMD) run ONE BARRIER APART: a phase is [LDS-DMA issue + fragment reads | barrier |
+// MFMAs | barrier], so while one group issues the MFMAs of phase p the other reads the fragments of phase p (or p + 1) -- the CDNA guide's two-group
+// schedule.  Both operands are k-major, so a phase is simply 32 k-rows of each; FOUR such buffers (4 x 32 KB for 256x256) form the ring:
+//   phase p:  issue tile p+2 into buffer (p+2) % 4  -- last read in phase p-2, by the late group one barrier interval later, retired (lgkmcnt) before
+//                                                      this interval began: three buffers would let the DMA land under those reads
+//             read tile p (buffer p % 4)            -- made visible by the wait of phase p-1 + one barrier for the early group, + two for the late one
+//             vmcnt(pieces of ONE tile)             -- tile p+1 has landed (tile p+2 may still fly): read in the NEXT phase, never in this one
+// Every wave executes the same number of barriers: the late group takes one extra in front of the loop, the early group one behind it.
+template <int BM, int BNT>
+__global__ __launch_bounds__(512) void gemm_tn_stag_kernel(GemmP p) {
+  constexpr int WM = 2, WN = 4, NW = 8, KT = 32, NB = 4;
+  constexpr int WTM = BM / WM, WTN = BNT / WN;
+  constexpr int MT = WTM / 16, NT = WTN / 16;
+  constexpr int ABYTES = BM * 2 * KT, BUF = (BM + BNT) * 2 * KT;
+  constexpr int NPA = ABYTES / 1024, NPW = BNT * 2 * KT / 1024;
+  constexpr int WROWB = BNT * 2, WRPP = 1024 / WROWB, WSPR = BNT / 8;
+  constexpr int AROWB = BM * 2, ARPP = 1024 / AROWB, ASPR = BM / 8;
+  constexpr int PA = (NPA + NW - 1) / NW, PW = (NPW + NW - 1) / NW, PIECES = PA + PW;
+  static_assert((BM == 128 || BM == 256) && (BNT == 128 || BNT == 256), "power-of-two tiles of >= 16 slots per staged k-row");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const VlaserGemmArgs& a = p.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wc = wave % WN;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = bid % p.tiles_m, tile_n = bid / p.tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BNT;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
+  const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W);
+  const int nk = a.K / KT;
+  const bf16_t* srcA[PA];
+  const bf16_t* srcW[PW];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int krow = min(wave * PA + i, NPA - 1) * ARPP + lane / ASPR;
+    const int slot = (lane % ASPR) ^ (2 * ((krow & 3) | (((krow >> 3) & 1) << 2)));
+    srcA[i] = A + (size_t)krow * a.lda + min(m0 + slot * 8, ((a.M + 7) & ~7) - 8);
+  }
+#pragma unroll
+  for (int i = 0; i < PW; ++i) {
+    const int krow = min(wave * PW + i, NPW - 1) * WRPP + lane / WSPR;
+    const int slot = (lane % WSPR) ^ (2 * ((krow & 3) | (((krow >> 3) & 1) << 2)));
+    srcW[i] = W + (size_t)krow * a.ldw + min(n0 + slot * 8, ((a.N + 7) & ~7) - 8);
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  auto issue_tile = [&](int kt, int b) {
+    const int ko = min(kt, nk - 1) * KT;                 // tiles past the end re-fetch the last one (never read)
+    const uint32_t base = lds0 + b * BUF;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) glds16(srcA[i] + (size_t)ko * a.lda, __builtin_amdgcn_readfirstlane(base + min(wave * PA + i, NPA - 1) * 1024));
+#pragma unroll
+    for (int i = 0; i < PW; ++i) glds16(srcW[i] + (size_t)ko * a.ldw, __builtin_amdgcn_readfirstlane(base + ABYTES + min(wave * PW + i, NPW - 1) * 1024));
+  };
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+  const int fr = lane & 15, fq = lane >> 4;
+  // fragment addresses inside a buffer (k-row kr and kr + 4 of the 32 staged; swizzle as in gemm_glds_kernel's k-major operands)
+  const int kr = 8 * fq + (fr >> 2), hb = (fr & 1) * 8;
+  const int key_lo = 2 * ((kr & 3) | (((kr >> 3) & 1) << 2)), key_hi = 2 * (((kr + 4) & 3) | ((((kr + 4) >> 3) & 1) << 2));
+  typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+  issue_tile(0, 0);
+  issue_tile(1, 1);
+  wait_vmcnt<PIECES>();                                  // tile 0 has landed
+  __builtin_amdgcn_s_barrier();
+  const bool late = wr == 1;                             // waves 4-7: one barrier interval behind waves 0-3
+  if (late) __builtin_amdgcn_s_barrier();
+  int b = 0;
+  for (int ph = 0; ph < nk; ++ph) {
+    int nb = b + 2; if (nb >= NB) nb -= NB;
+    issue_tile(ph + 2, nb);
+    __builtin_amdgcn_sched_barrier(0);
+    const char* As = smem + b * BUF;
+    const char* Ws = As + ABYTES;
+    bf16x8 fa[MT], fw[NT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int c0 = wr * WTM + t * 16, sl = (c0 >> 3) + ((fr & 3) >> 1);
+      const char* plo = As + kr * AROWB + (((sl & ~15) | ((sl & 15) ^ key_lo)) << 4) + hb;
+      const char* phi = As + (kr + 4) * AROWB + (((sl & ~15) | ((sl & 15) ^ key_hi)) << 4) + hb;
+      union { s16x4_t h[2]; bf16x8 v; } u;
+      u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(uint32_t)(uintptr_t)plo);
+      u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(uint32_t)(uintptr_t)phi);
+      fa[t] = u.v;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int c0 = wc * WTN + t * 16, sl = (c0 >> 3) + ((fr & 3) >> 1);
+      const char* plo = Ws + kr * WROWB + (((sl & ~15) | ((sl & 15) ^ key_lo)) << 4) + hb;
+      const char* phi = Ws + (kr + 4) * WROWB + (((sl & ~15) | ((sl & 15) ^ key_hi)) << 4) + hb;
+      union { s16x4_t h[2]; bf16x8 v; } u;
+      u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(uint32_t)(uintptr_t)plo);
+      u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(uint32_t)(uintptr_t)phi);
+      fw[t] = u.v;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vmcnt<PIECES>();                                // tile ph+1 has landed (this wave's pieces); tile ph+2 may still fly
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(fw[nt], fa[mt], acc[nt][mt]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (++b == NB) b = 0;
+  }
+  if (!late) __builtin_amdgcn_s_barrier();
+  wait_vmcnt<0>();                                       // drain the clamped look-ahead tiles before the block retires
+  static_assert(NW * EpiScratch<MT, NT>::BYTES <= NB * BUF, "epilogue scratch exceeds the buffer ring");
+  __builtin_amdgcn_s_barrier();                          // every wave is out of the loop and its LDS-DMA pieces have landed: the ring is scratch now
+  const float ssq = epilogue_tile<VL_EPI_NONE, MT, NT, true>(a, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc, smem + wave * EpiScratch<MT, NT>::BYTES);
+  if (a.sumsq_part) {
+    const float w = wave_sum(ssq);
+    if (lane == 0) a.sumsq_part[(size_t)blockIdx.x * NW + wave] = w;
+  }
+}
+
+template <int BM, int BNT>
+static int launch_tn_stag(const VlaserGemmArgs* args, hipStream_t stream) {
+  GemmP p;
+  p.a = *args;
+  p.tiles_m = (args->M + BM - 1) / BM;
+  p.tiles_n = (args->N + BNT - 1) / BNT;
+  constexpr int lds = 4 * (BM + BNT) * 2 * 32;
+  static_assert(lds <= 160 * 1024, "buffer ring exceeds the 160 KiB LDS of a CU");
+  VL_CHECK(args->batch <= 1 && args->K % 32 == 0, "vlaser_gemm_tn_lds (staggered configuration): plain (unbatched) products, K a multiple of 32");
+  if (args->sumsq_part) {
+    const long long need = (long long)p.tiles_m * p.tiles_n * 8;
+    VL_CHECK(args->sumsq_cap >= need, "sumsq_part: %d slots given, this launch writes %lld (workgroups x waves)", args->sumsq_cap, need);
+  }
+  if (int rc = set_max_lds_once(gemm_tn_stag_kernel<BM, BNT>, lds)) return rc;
+  hipLaunchKernelGGL((gemm_tn_stag_kernel<BM, BNT>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds, stream, p);
+  VL_LAUNCH_CHECK();
+  return 0;
 }
 
 template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false>
@@ -833,9 +1090,10 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
     if constexpr (AKM) {                 // TN form: 128- and 256-row tiles only (>= 16 slots per staged k-row on both operands)
       // measured at K = 576 (tools/micro/tn_lab.py): qkv / o (192 / 144 tiles of 128x128) 10.2 / 10.0 us; down 1100 / 1200 / 1300 = 33.7 / 29.5 / 26.2 us,
       // gate/up 67.2 / 59.9 / 50.5 us -- multi-round grids want the largest tile
+      // r04: grids of more than one round take the staggered two-group kernel (gate/up 46.0 -> 43.8 us; single-round shapes tie: tools/micro/gemm_epilogue_lab.py)
       if (blocks(128, 128) <= 256) bm = 1100;
       else if (blocks(128, 256) <= 256) bm = 1200;
-      else bm = 1300;
+      else bm = (EPI == VL_EPI_NONE && nb == 1 && blocks(256, 256) > 256) ? 1340 : 1300;
     } else if (args->M <= 32 && !WKM) {
       bm = 32;
     } else if (!WKM && blocks(64, 64) <= 256) {      // (the NN form's transposing reads need >= 16 slots per staged k-row: BNT >= 128)
@@ -868,8 +1126,14 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
       case 1105: return launch_glds<EPI, 128, 128, 2, 4, 5, true, true>(args, stream, splits);
       case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3, true, true>(args, stream, splits);
       case 1300: return launch_glds<EPI, 256, 256, 2, 4, 2, true, true>(args, stream, splits);
-      default: vlaser_set_error("vlaser_gemm_tn_lds: force_cfg must be 0 or 1100 / 1105 / 1200 / 1300 (got %d)", bm); return -1;
+      // r04: two staggered wave groups over a ring of four 32-deep buffers (gemm_tn_stag_kernel)
+      case 1340: if constexpr (EPI == VL_EPI_NONE) return launch_tn_stag<256, 256>(args, stream); break;
+      case 1240: if constexpr (EPI == VL_EPI_NONE) return launch_tn_stag<128, 256>(args, stream); break;
+      case 1140: if constexpr (EPI == VL_EPI_NONE) return launch_tn_stag<128, 128>(args, stream); break;
+      default: break;
     }
+    vlaser_set_error("vlaser_gemm_tn_lds: force_cfg must be 0 or 1100 / 1105 / 1200 / 1300 / 1140 / 1240 / 1340 (got %d)", bm);
+    return -1;
   }
   switch (bm) {
     case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM>(args, stream, splits);
