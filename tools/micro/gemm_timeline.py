@@ -31,15 +31,14 @@ def report(name, us, nk, nwg):
     lib.vlaser_gemm_debug_read(buf)
     t = torch.tensor(list(buf), dtype=torch.int64).view(1024, 40)[:min(nwg, 1024)].double()
     t0 = t[:, 0].min()
-    clk = 2.4e3                          # shader cycles per us (nominal); s_memtime ticks are 100 MHz on this chip -> ticks * 10 ns
-    ticks_us = 1e-2
-    rows = [('start (after the earliest workgroup)', t[:, 0] - t0), ('prologue tiles requested', t[:, 1] - t[:, 0]), ('first tile landed + barrier', t[:, 2] - t[:, 1])]
+    ticks_us = 1.0 / float(os.environ.get('SHADER_MHZ', '2100'))        # clock64() counts shader cycles on this chip (~2.1 GHz under MFMA load, guide: DVFS)
+    rows = [('prologue tiles requested', t[:, 1] - t[:, 0]), ('first tile landed + barrier', t[:, 2] - t[:, 1])]
     if nk > 1:
         steps = (t[:, 2 + nk - 1] - t[:, 2]) / (nk - 1)
         rows.append((f'one K-step (mean of {nk - 1})', steps))
     rows += [('last K-step -> loop end', t[:, 36] - t[:, 2 + nk - 1]), ('drain + barrier before the epilogue', t[:, 37] - t[:, 36]), ('epilogue (math + stores issued)', t[:, 38] - t[:, 37]),
              ('whole workgroup', t[:, 38] - t[:, 0])]
-    print(f'{name}: {us:.2f} us per launch, {nwg} workgroups, {nk} K-steps; us, min / median / max over workgroups')
+    print(f'{name}: {us:.2f} us per launch, {nwg} workgroups, {nk} K-steps; us at 2.1 GHz, min / median / max over workgroups')
     for n, v in rows:
         v = v * ticks_us
         print(f'    {n:42s} {v.min():7.2f} {v.median():7.2f} {v.max():7.2f}')
@@ -62,3 +61,18 @@ for (M, N, K, name, bm, bn) in [(560, 17920, 1536, 'forward gate/up-sized NT (NO
     out = torch.zeros(M, N, dtype=BF, device='cuda')
     us = timeit([lambda w=w: ops.gemm(L.EPI_NONE, x, w, out=out) for w in ws])
     report(name, us, K // 64, -(-M // bm) * -(-N // bn))
+
+# the epilogues with their own store code: SwiGLU (+ the training forward's aux), SwiGLU backward (NN form), ViT qkv, Qwen qkv + RoPE
+from vlaser_amd import config as Cfg  # noqa: E402
+H, I = 1536, 8960
+x560, x384 = rnd(560, H, std=1.0), rnd(384, H, std=1.0)
+wgus = [ops.pack_gate_up(rnd(I, H), rnd(I, H)) for _ in range(6)]
+act = torch.zeros(560, I, dtype=BF, device='cuda'); aux = torch.zeros(560, 2 * I, dtype=BF, device='cuda')
+us = timeit([lambda w=w: ops.gemm(L.EPI_SWIGLU, x560, w, out=act, aux_out=aux, ld_aux=aux.stride(0)) for w in wgus])
+report('SFT forward gate/up, SwiGLU + aux, M = 560 (192x256)', us, H // 64, 3 * 70)
+us = timeit([lambda w=w: ops.gemm(L.EPI_SWIGLU, x384, w, out=act[:384]) for w in wgus])
+report('prefill gate/up, SwiGLU, M = 384', us, H // 64, -(-384 // 128) * 70)
+wds = [rnd(H, I) for _ in range(6)]
+dh = rnd(560, H, std=1.0); dgu = torch.zeros(560, 2 * I, dtype=BF, device='cuda')
+us = timeit([lambda w=w: ops.gemm_nn(L.EPI_SWIGLU_BWD, dh, w, out=dgu, res=aux) for w in wds])
+report('SFT dgrad down + SwiGLU backward, NN, M = 560 (128x256)', us, H // 64, 5 * 35)

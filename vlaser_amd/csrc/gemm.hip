@@ -299,25 +299,37 @@ __device__ __forceinline__ void epilogue_tile_swiglu_bwd(const VlaserGemmArgs& a
   bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
   const bool in_range = n_w + NT * 16 <= a.N;              // wave-uniform; a ragged right edge takes the guarded path per fragment
   const bool wide = (a.ldo & 7) == 0 && (((uintptr_t)out & 15) == 0);      // 16-byte stores
+  // r04: ALL of the wave tile's saved pre-activations are requested before the first is used (MT x NT x 2 eight-byte loads in flight, 64 VGPRs for the
+  // 64x64 wave tile) -- one L2 / HBM round trip per workgroup instead of one per 16-row tile (the epilogue was 10.7 of the workgroup's 33.5 us:
+  // tools/micro/gemm_timeline.py)
+  constexpr int MG = MT < 4 ? MT : ((MT % 4 == 0) ? 4 : (MT % 3 == 0 ? 3 : 2));      // 16-row tiles whose loads fly together (<= 64 VGPRs)
+  static_assert(MT % MG == 0, "wave tile height");
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = m_w + mt * 16 + fr;
-    const size_t row = (size_t)min(m, a.M - 1) * a.ldo;
-    u32x2 gv[NT], uv[NT];
+  for (int mg = 0; mg < MT; mg += MG) {
+  u32x2 gv[MT][NT], uv[MT][NT];
+#pragma unroll
+  for (int mt = mg; mt < mg + MG; ++mt) {
+    const size_t row = (size_t)min(m_w + mt * 16 + fr, a.M - 1) * a.ldo;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = min(n_w + nt * 16 + fq * 4, a.N - 4), pg = (n >> 4) * 32 + (n & 15);
-      gv[nt] = *reinterpret_cast<const u32x2*>(gu + row + pg);
-      uv[nt] = *reinterpret_cast<const u32x2*>(gu + row + pg + 16);
+      gv[mt][nt] = *reinterpret_cast<const u32x2*>(gu + row + pg);
+      uv[mt][nt] = *reinterpret_cast<const u32x2*>(gu + row + pg + 16);
     }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int mt = mg; mt < mg + MG; ++mt) {
+    const int m = m_w + mt * 16 + fr;
+    const size_t row = (size_t)min(m, a.M - 1) * a.ldo;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = n_w + nt * 16 + fq * 4, pg = (n >> 4) * 32 + (n & 15);
       float dg[4], du[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float g = (j & 1) ? bf16hi_to_f32(gv[nt][j >> 1]) : bf16lo_to_f32(gv[nt][j >> 1]);
-        const float u = (j & 1) ? bf16hi_to_f32(uv[nt][j >> 1]) : bf16lo_to_f32(uv[nt][j >> 1]);
+        const float g = (j & 1) ? bf16hi_to_f32(gv[mt][nt][j >> 1]) : bf16lo_to_f32(gv[mt][nt][j >> 1]);
+        const float u = (j & 1) ? bf16hi_to_f32(uv[mt][nt][j >> 1]) : bf16lo_to_f32(uv[mt][nt][j >> 1]);
         const float d = round_bf16(acc[nt][mt][j]);
         const float sig = 1.0f / (1.0f + __expf(-g));
         dg[j] = d * u * sig * (1.0f + g * (1.0f - sig));
@@ -337,6 +349,54 @@ __device__ __forceinline__ void epilogue_tile_swiglu_bwd(const VlaserGemmArgs& a
       }
     }
   }
+  }
+}
+
+// SwiGLU for a whole wave tile (r04): the same values as epilogue<VL_EPI_SWIGLU> per fragment (HF rounds gate and up to bf16 before the activation), with
+// 16-byte stores -- the aux image's [gate16 | up16] neighbours through a lane-pair swap like the backward above, the activation tiles of two neighbouring
+// (gate, up) pairs through another (the epilogue was 5.3 of the training forward's 45 us per workgroup: tools/micro/gemm_timeline.py).  Returns false
+// (nothing done) when the tile is ragged or an operand unaligned: the caller falls back to the per-fragment path.
+template <int MT, int NT>
+__device__ __forceinline__ bool epilogue_tile_swiglu(const VlaserGemmArgs& a, int m_w, int n_w, int fr, int fq, f32x4 (&acc)[NT][MT]) {
+  bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
+  bf16_t* aux = reinterpret_cast<bf16_t*>(a.aux_out);
+  const bool ok = n_w + NT * 16 <= a.N && (a.ldo & 7) == 0 && (((uintptr_t)out & 15) == 0) && (!aux || ((a.ld_aux & 7) == 0 && (((uintptr_t)aux & 15) == 0)));
+  if (!ok) return false;                                     // wave-uniform
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m_w + mt * 16 + fr;
+    const bool st = m < a.M;
+    const size_t mrow = (size_t)min(m, a.M - 1);
+    u32x2 actp[NT / 2];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt += 2) {
+      const f32x4 v = acc[nt][mt], v2 = acc[nt + 1][mt];
+      float r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = round_bf16(silu(round_bf16(v[j]))) * round_bf16(v2[j]);
+      actp[nt / 2] = u32x2{pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+      if (aux) {
+        const u32x2 g_ = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, u_ = u32x2{pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3])};
+        const u32x2 s0 = __builtin_amdgcn_permlane16_swap(g_[0], u_[0], false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane16_swap(g_[1], u_[1], false, false);
+        if (st) *reinterpret_cast<u32x4*>(aux + mrow * a.ld_aux + n_w + nt * 16 + (fq & 1) * 16 + (fq >> 1) * 8) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+      }
+    }
+    bf16_t* orow = out + mrow * a.ldo + (n_w >> 1);          // activation column of packed column n: (n / 32) * 16 + n % 16
+    if constexpr (NT % 4 == 0) {
+#pragma unroll
+      for (int pp = 0; pp < NT / 2; pp += 2) {
+        const u32x2 s0 = __builtin_amdgcn_permlane16_swap(actp[pp][0], actp[pp + 1][0], false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane16_swap(actp[pp][1], actp[pp + 1][1], false, false);
+        if (st) *reinterpret_cast<u32x4*>(orow + (pp + (fq & 1)) * 16 + (fq >> 1) * 8) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+      }
+    } else {
+#pragma unroll
+      for (int pp = 0; pp < NT / 2; ++pp)
+        if (st) *reinterpret_cast<u32x2*>(orow + pp * 16 + fq * 4) = actp[pp];
+    }
+  }
+  return true;
 }
 
 // Whole wave tile at once for the bf16-row epilogues (NONE / BIAS / BIAS_GELU / BIAS_LS_RES / RES).  The per-fragment epilogue
@@ -868,16 +928,29 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
     return;
   }
   if constexpr (EPI == VL_EPI_QKV_ROPE) {
+    GEMM_STAMP(37)
     epilogue_tile_rope<MT, NT>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc);
+    GEMM_STAMP(38)
     return;
   }
   if constexpr (EPI == VL_EPI_VIT_QKV) {
+    GEMM_STAMP(37)
     epilogue_tile_vit_qkv<MT, NT>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc);
+    GEMM_STAMP(38)
     return;
   }
   if constexpr (EPI == VL_EPI_SWIGLU_BWD) {
+    GEMM_STAMP(37)
     epilogue_tile_swiglu_bwd<MT, NT>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc);
+    GEMM_STAMP(38)
     return;
+  }
+  GEMM_STAMP(37)
+  if constexpr (EPI == VL_EPI_SWIGLU) {
+    if (epilogue_tile_swiglu<MT, NT>(ea, m0 + wr * WTM, n0 + wc * WTN, fr, fq, acc)) {
+      GEMM_STAMP(38)
+      return;
+    }
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -890,6 +963,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
       for (int nt = 0; nt < NT; ++nt) epilogue<EPI>(ea, m, n0 + wc * WTN + nt * 16 + fq * 4, acc[nt][mt], acc[nt][mt]);
     }
   }
+  GEMM_STAMP(38)
 }
 
 // ---------------------------------------------------------------------------------------------- TN form, two staggered wave groups (r04)
