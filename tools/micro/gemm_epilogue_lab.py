@@ -12,7 +12,9 @@ if os.environ.get('GEMM_LAB_CHILD') != '1':
     flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-mllvm', '-amdgpu-mfma-vgpr-form']
     objs = [os.path.join(src, f) for f in ('attn.o', 'skinny.o', 'euler.o', 'misc.o', 'train.o', 'attn_bwd.o', 'attn_o.o', 'api.o')]
     variants = [('product', None), ('fragments', ['-DGEMM_STORE_MODE=0']), ('via LDS', ['-DGEMM_STORE_MODE=1']), ('lane swap', ['-DGEMM_STORE_MODE=2']),
-                ('no stores', ['-DGEMM_LAB_NOSTORE'])]
+                ('no stores', ['-DGEMM_LAB_NOSTORE']), ('issue 1st', ['-DGLDS_ISSUE_FIRST=1'])]
+    if os.environ.get('GEMM_LAB_ONLY'):
+        variants = [v for v in variants if v[0] in os.environ['GEMM_LAB_ONLY'].split(',')]
     for tag, defs in variants:
         env = dict(os.environ, GEMM_LAB_CHILD='1', GEMM_LAB_TAG=tag)
         if defs is not None:
@@ -42,9 +44,20 @@ for (N, K, name, cfgs) in [(17920, 1536, 'wgrad gate/up', (1300, 1340)), (1536, 
     for cfg in cfgs:
         res.append(f'{name} {cfg}: {timeit([lambda t=t: ops.gemm_tn_lds(t, xp, out, Sp, force_cfg=cfg) for t in dps]):6.2f} us')
 # forward shapes (NT): gate/up with SwiGLU at M = 560, ViT fc1 at M = 1025, LLM prefill qkv-sized at M = 384
-for (M, N, K, name) in [(560, 17920, 1536, 'fwd gate/up (NONE)'), (1025, 4096, 1024, 'ViT fc1 (NONE)'), (384, 2048, 1536, 'prefill 384x2048')]:
+for (M, N, K, name) in [(560, 17920, 1536, 'fwd gate/up (NONE)'), (1025, 4096, 1024, 'ViT fc1 (NONE)'), (384, 2048, 1536, 'prefill 384x2048'), (384, 17920, 1536, 'prefill gate/up-sized'),
+                        (1025, 3072, 1024, 'ViT qkv-sized'), (560, 1536, 8960, 'SFT down-sized')]:
     ws = [rnd(N, K) for _ in range(6)]
     x = rnd(M, K, std=1.0)
     out = torch.zeros(M, N, dtype=BF, device='cuda')
     res.append(f'{name}: {timeit([lambda w=w: ops.gemm(L.EPI_NONE, x, w, out=out) for w in ws]):6.2f} us')
 print(f'[{tag:9s}] ' + '   '.join(res))
+# 8B prefill shapes (13 tiles, M = 3408): the two-stage 256x256 ring with the refill requested behind the first half's reads (1300) or first (1301)
+if tag == 'product':
+    res = []
+    for (M, N, K, name) in [(3408, 4608, 3584, '8B qkv-sized'), (3408, 3584, 3584, '8B o-sized'), (3408, 18944, 3584, '8B half gate/up'), (3408, 3584, 18944, '8B down-sized')]:
+        ws = [rnd(N, K) for _ in range(3)]
+        x = rnd(M, K, std=1.0)
+        out = torch.zeros(M, N, dtype=BF, device='cuda')
+        for cfg in (0, 1300, 1301):
+            res.append(f'{name} {cfg}: {timeit([lambda w=w: ops.gemm(L.EPI_NONE, x, w, out=out, force_bm=cfg) for w in ws]):7.2f} us')
+    print('[8B shapes] ' + '   '.join(res))

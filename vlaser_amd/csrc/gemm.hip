@@ -760,7 +760,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // AKM ("A k-major", r03): the FIRST operand is stored [K][M] row-major as well -- together with WKM the TN form out = At^T @ Wt of the weight gradients
 // (dW = dY^T X, contraction over the sequence), both operands staged and read exactly like the WKM operand.  K must be a whole number of 64-row tiles:
 // the caller pads the sequence axis (rows K_true..K of At zero, of Wt finite).
-template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false>
+// IFIRST: the refill of the stage read in the previous step is requested right behind the barrier, in FRONT of this step's fragment reads (r02 order) instead
+// of behind the first half's (r03).  With only two stages and HBM-cold weights (192x256, the training forward's gate/up) the extra half step of lead is
+// worth more than the reads it delays: 43.7 -> 38.7 us; every ring of three or more stages loses 5-13 % with it (tools/micro/gemm_epilogue_lab.py).
+template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false, bool IFIRST = GLDS_ISSUE_FIRST != 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BNT / WN;
@@ -853,8 +856,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
       bf16x8 fa[MT], fw[NT];
       // (r03) the refill of stage kt-1 is issued BEHIND the first half's fragment reads: an LDS-DMA piece costs ~100-185 issue cycles
       // (MI355X_MICROARCH.md), and in front of the reads the whole K-step sat behind PIECES of them before its first ds_read went out
-      if (ks == 1 && !GLDS_ISSUE_FIRST) issue_tile(kt + NST - 1, stn);
-      if (ks == 0 && GLDS_ISSUE_FIRST) issue_tile(kt + NST - 1, stn);
+      if (ks == 1 && !IFIRST) issue_tile(kt + NST - 1, stn);
+      if (ks == 0 && IFIRST) issue_tile(kt + NST - 1, stn);
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         if constexpr (AKM) {
@@ -1114,7 +1117,7 @@ static int launch_tn_stag(const VlaserGemmArgs* args, hipStream_t stream) {
   return 0;
 }
 
-template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false>
+template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false, bool IFIRST = GLDS_ISSUE_FIRST != 0>
 static int launch_glds(const VlaserGemmArgs* args, hipStream_t stream, int splits) {
   GemmP p;
   p.a = *args;
@@ -1127,8 +1130,8 @@ static int launch_glds(const VlaserGemmArgs* args, hipStream_t stream, int split
     const long long need = (long long)p.tiles_m * p.tiles_n * (args->batch > 1 ? args->batch : 1) * WM * WN;
     VL_CHECK(args->sumsq_cap >= need, "sumsq_part: %d slots given, this launch writes %lld (workgroups x waves)", args->sumsq_cap, need);
   }
-  if (int rc = set_max_lds_once(gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM>, lds)) return rc;
-  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM>), dim3(p.tiles_m * p.tiles_n, splits, args->batch > 1 ? args->batch : 1),
+  if (int rc = set_max_lds_once(gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM, IFIRST>, lds)) return rc;
+  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM, IFIRST>), dim3(p.tiles_m * p.tiles_n, splits, args->batch > 1 ? args->batch : 1),
                      dim3(WM * WN * 64), lds, stream, p);
   VL_LAUNCH_CHECK();
   return 0;
@@ -1213,6 +1216,7 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
     case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM>(args, stream, splits);
     case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3, WKM>(args, stream, splits);
     case 1300: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM>(args, stream, splits);
+    case 1301: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM, false, true>(args, stream, splits);      // lab: the two-stage 256x256 ring with the refill requested first
     case 1500: return launch_glds<EPI, 64, 128, 2, 4, 4, WKM>(args, stream, splits);
     case 1440: return launch_glds<EPI, 144, 128, 3, 2, 4, WKM>(args, stream, splits);
     // r03: deeper rings / smaller tiles for the latency-bound single-round shapes (a K-step of the 64x128 tile takes ~0.38 us with 3 tiles in flight:
@@ -1221,7 +1225,7 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
     case 1105: return launch_glds<EPI, 128, 128, 2, 4, 5, WKM>(args, stream, splits);
     case 1564: if constexpr (!WKM) return launch_glds<EPI, 64, 64, 2, 2, 8, false>(args, stream, splits); break;
     case 1532: return launch_glds<EPI, 32, 128, 1, 4, 7, WKM>(args, stream, splits);
-    case 1900: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM>(args, stream, splits);      // r03: 3 tile rows for the SFT step's 560 rows (256-row tiles pad 27 %)
+    case 1900: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, true>(args, stream, splits);      // r03: 3 tile rows for the SFT step's 560 rows (256-row tiles pad 27 %)
     default: break;
   }
   if constexpr (WKM) {
@@ -1460,8 +1464,8 @@ extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   VL_CHECK(a->K % BK == 0, "vlaser_gemm: K=%d must be a multiple of %d", a->K, BK);
   VL_CHECK(a->batch <= 1 || (epi == VL_EPI_NONE || epi == VL_EPI_F32 || epi == VL_EPI_BIAS), "vlaser_gemm: batched mode supports NONE / F32 / BIAS epilogues");
   VL_CHECK(!a->sumsq_part, "vlaser_gemm: sumsq_part is honoured by vlaser_gemm_tn_lds only");
-  VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 || a->force_bm == 1564 || a->force_bm == 1532 || a->force_bm == 1900,
-           "vlaser_gemm: force_bm must be 0/32/64/128 or an LDS-DMA configuration code 1100/1105/1200/1300/1440/1500/1506/1532/1564/1900");
+  VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1301 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 || a->force_bm == 1564 || a->force_bm == 1532 || a->force_bm == 1900,
+           "vlaser_gemm: force_bm must be 0/32/64/128 or an LDS-DMA configuration code 1100/1105/1200/1300/1301/1440/1500/1506/1532/1564/1900");
   VL_CHECK(a->lda % 8 == 0 && a->ldw % 8 == 0, "vlaser_gemm: lda/ldw must be multiples of 8 (16-byte rows)");
   VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm: operands must be 16-byte aligned");
   switch (epi) {
@@ -1501,7 +1505,7 @@ extern "C" int vlaser_gemm_nn(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   VL_CHECK(a->M > 0 && a->N > 0 && a->K > 0 && a->K % BK == 0, "vlaser_gemm_nn: bad shape M=%d N=%d K=%d (K must be a multiple of %d)", a->M, a->N, a->K, BK);
   VL_CHECK(a->N % 8 == 0 && a->lda % 8 == 0 && a->ldw % 8 == 0 && a->ldw >= a->N, "vlaser_gemm_nn: N, lda, ldw must be multiples of 8 and ldw >= N");
   VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm_nn: operands must be 16-byte aligned");
-  VL_CHECK(a->force_bm == 0 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 ||
+  VL_CHECK(a->force_bm == 0 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1301 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 ||
                a->force_bm == 1532 || a->force_bm == 1900,
            "vlaser_gemm_nn: force_bm must be 0 or an LDS-DMA configuration code 1100/1105/1200/1300/1440/1500/1506/1532/1900");
   VL_CHECK(a->batch <= 1 || epi == VL_EPI_NONE || epi == VL_EPI_F32, "vlaser_gemm_nn: batched mode supports the NONE / F32 epilogues");
