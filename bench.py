@@ -368,10 +368,10 @@ def main():
             line['chunk_roofline'] = {'floor_ms': round(floor_ms, 3), 'ms_per_chunk': round(dt / a.steps * 1e3, 3), 'frac': round(floor_ms / (dt / a.steps * 1e3), 4),
                                       'note': 'MFMA-bound part at 2.5 PFLOP/s + HBM-bound Euler part at 8 TB/s; the Euler phase is a chain of 1 400 dependent launches '
                                               '(5 per layer-step), see DESIGN.md section 3'}
+            traffic, traffic_src = _pmc_traffic()
             line['roofline'] = {'bound': 'hbm', 'kernel': 'skinny_kernel<NORM,SWIGLU> (action-expert gate/up GEMV, N=17920 K=768, M=4; 307 launches per chunk)',
                                 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                                'traffic': _pmc_traffic(), 'traffic_source': {'file': 'profiles/r04s_pmc_dominant_kernel.json', 'measured_in_run': False,
-                                                                        'how': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on tools/pmc/skinny_pmc (torch-free harness, same kernel and shape)'},
+                                'traffic': traffic, 'traffic_source': traffic_src,
                                 'bytes_per_launch': byts, 'us_per_launch': round(avg_ms * 1e3, 3), 'launches_timed': n,
                                 'timing': 'IN-CHAIN: (Euler-phase graph with the kernel - the same graph without it) / launches, HIP events on the launch stream; '
                                           'includes the kernel boundary, so it is an upper bound of the rocprof duration in profiles/',
@@ -584,15 +584,42 @@ def qa8b_bench(local):
 
 
 def _pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from hardware counters.  rocprofv3 --pmc cannot run under torch on this
-    image, so the counters are collected by the torch-free harness tools/pmc/skinny_pmc.cpp on the same kernel and shape
-    (profiles/r04s_pmc_dominant_kernel.md has the commands and the gfx950 FETCH_SIZE correction; re-collected whenever skinny.hip
-    changes); None if absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r04s_pmc_dominant_kernel.json')
+    """HBM bytes per launch of the dominant kernel from hardware counters -> (bytes or None, source dict).  rocprofv3 --pmc cannot run under torch on this
+    image, so the counters come from the torch-free harness tools/pmc/skinny_pmc (same kernel, same shape, 28 weight buffers cycled), collected as the
+    guide prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE `--pmc` passes with `--kernel-trace` only, FETCH_SIZE x 2 on gfx950 (128-byte requests of wide
+    coalesced reads are tallied at 64 B).  Measured IN THIS RUN when the harness and rocprofv3 are there (each pass is a child process of its own: the
+    profiler never wraps this torch process; ~5 s); otherwise the committed collection profiles/r04s_pmc_dominant_kernel.json."""
+    root = os.path.dirname(os.path.abspath(__file__))
+    how = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) on tools/pmc/skinny_pmc (torch-free harness, same kernel and shape); FETCH_SIZE x 2 (gfx950)'
+    exe = os.path.join(root, 'tools', 'pmc', 'skinny_pmc')
+    import shutil
+    import tempfile
+    rocprof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if os.path.exists(exe) and os.path.exists(rocprof) and os.environ.get('VLASER_BENCH_NO_LIVE_PMC') != '1':
+        try:
+            import csv
+            import glob
+            means = {}
+            for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+                with tempfile.TemporaryDirectory(dir='/tmp') as d:
+                    env = dict(os.environ, TMPDIR='/tmp')
+                    subprocess.run([rocprof, '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', d, '--', exe, '2'], cwd='/tmp', env=env, timeout=180,
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+                    f = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)[0]
+                    vals = [float(r['Counter_Value']) for r in csv.DictReader(open(f)) if 'skinny_kernel' in r['Kernel_Name'] and r['Counter_Name'] == ctr]
+                    vals = vals[len(vals) // 3:]                # drop the warm-up round
+                    means[ctr] = sum(vals) / len(vals)
+            traffic = int(means['FETCH_SIZE'] * 1024 * 2 + means['WRITE_SIZE'] * 1024)
+            return traffic, {'measured_in_run': True, 'fetch_size_kb': round(means['FETCH_SIZE'], 1), 'write_size_kb': round(means['WRITE_SIZE'], 1), 'how': how}
+        except Exception as e:                                  # noqa: BLE001 -- the counters are evidence, never a reason to lose the line
+            err = f'{type(e).__name__}: {e}'[:200]
+    else:
+        err = 'harness or rocprofv3 not found'
+    path = os.path.join(root, 'profiles', 'r04s_pmc_dominant_kernel.json')
     try:
-        return json.load(open(path))['traffic_bytes_per_launch']
+        return json.load(open(path))['traffic_bytes_per_launch'], {'file': 'profiles/r04s_pmc_dominant_kernel.json', 'measured_in_run': False, 'live_attempt': err, 'how': how}
     except (OSError, KeyError, ValueError):
-        return None
+        return None, {'measured_in_run': False, 'live_attempt': err}
 
 
 def _finish(dist, line):
