@@ -247,12 +247,12 @@ def prefill_layer(stack: QwenStack, lw: QwenLayerWeights, buf: PrefillBuffers, h
     x, q, ao, act = buf.x[:M], buf.q[:M], buf.ao[:M], buf.act[:M]
     ops.gemm(L.EPI_QKV_ROPE, x, lw.wqkv, bias=lw.bqkv, q_out=q, k_cache=cache.k[layer], vt_cache=cache.vt[layer], rope_cos=rope[0],
              rope_sin=rope[1], pos_ids=pos_ids, n_q_heads=nq, n_kv_heads=nkv, s_max=cache.s_max, tok_per_batch=tok_per_batch, slot_base=slot_base)
+    if skip_post_attn:          # the last layer of a mixture whose hidden states nobody reads (the VLM / proprio rows of the VLA): only its K / V are needed
+        return
     ks, vs = cache.strides()
     ops.attn_prefill(q, cache.k[layer], cache.vt[layer], ao, batch, tok_per_batch, tok_per_batch if kv_len is None else kv_len, nq, nkv, hd,
                      (tok_per_batch * nq * hd, hd, nq * hd), ks, vs, (tok_per_batch * nq * hd, nq * hd), cache.s_max, hd ** -0.5,
                      attn_mode, causal_off=causal_off, valid_len=valid_len, blk_start=blk_start, q_row_off=slot_base)
-    if skip_post_attn:
-        return
     part = buf.part
     sp_o, sp_d = ops.gemm_splits(M, H, nq * hd, part.numel()), ops.gemm_splits(M, H, I, part.numel())
     ops.gemm(L.EPI_PARTIAL, ao, lw.wo, out_f32=part, k_splits=sp_o)
@@ -344,10 +344,10 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
         if 'down' not in skip:
             ops.launch_skinny(L.PRO_PLAIN, L.SK_PARTIAL, plan.down[0], stream)
         return sb.hB, sb.part_d, stack.ks_down
+    if skip_post_attn:          # only this layer's K / V are needed (written by the qkv launch above)
+        return sb.hA, None, 0
     if 'attn' not in skip:
         ops.launch_attn_skinny(a, stream)
-    if skip_post_attn:
-        return sb.hA, None, 0
     # o_proj: the prologue merges the attention split partials (flash-decoding) straight into its activation tile
     if fuse:
         if 'gu' not in skip and 'o' not in skip:
