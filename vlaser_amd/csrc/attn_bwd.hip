@@ -68,8 +68,8 @@ __device__ __forceinline__ bf16x8 ab_load_tr_order(const bf16_t* row, int c0, in
 // TK = keys per staged tile; KS = wave groups (of 4 waves) that take the key tiles in turn and merge their dQ sums at the end: at SFT lengths the grid
 // is 108 workgroups on 256 CUs and one wave per SIMD runs LDS reads, MFMAs and the softmax arithmetic back to back -- a second group per
 // workgroup gives every SIMD a second instruction stream to overlap them with and halves the chain of tile iterations.
-template <int TK, int KS>
-__global__ __launch_bounds__(256 * KS) void attn_bwd_dq_kernel(AttnBwdP p) {
+template <int TK, int KS, bool WRITE_D>
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnBwdP& p) {
   constexpr int HD = 128, DC = 4, DT = 8, NCH = TK / 32, NLD = TK / 16, PV = TK == 64 ? AB_PV : AB_PQ;
   constexpr int TILE_B = TK * AB_PQ + 128 * PV, MERGE_WAVE = DT * 4 * 64 * 4;
   extern __shared__ __attribute__((aligned(16))) char ab_smem[];
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256 * KS) void attn_bwd_dq_kernel(AttnBwdP p) {
   dsum += __shfl_xor(dsum, 32, 64);
   const float D = dsum;
   const float lse = p.lse[(size_t)h * p.S + qc];
-  if (g == 0 && grp == 0 && qi < p.S) p.delta[(size_t)h * p.S + qi] = D;
+  if (WRITE_D && g == 0 && grp == 0 && qi < p.S) p.delta[(size_t)h * p.S + qi] = D;      // (the one-launch form gets D from attn_bwd_delta_kernel: same bits)
   const int klim = qi < p.S ? (p.causal ? min(qi + 1, p.kv_valid) : p.kv_valid) : 0;
   const float sc = p.scale * 1.4426950408889634f;
   f32x4 dqT[DT];
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256 * KS) void attn_bwd_dq_kernel(AttnBwdP p) {
 
 // ---------------------------------------------------------------------------------------------- dK, dV (one partial per Q head)
 template <int TK, int KS>      // TK queries per staged tile, KS wave groups taking the query tiles in turn (as above)
-__global__ __launch_bounds__(256 * KS) void attn_bwd_dkv_kernel(AttnBwdP p) {
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnBwdP& p) {
   constexpr int HD = 128, DC = 4, DT = 8, NCH = TK / 32, NLD = TK / 16;
   constexpr int TILE_B = 2 * TK * AB_PQ + 2 * TK * 4, MERGE_WAVE = 2 * DT * 4 * 64 * 4;
   extern __shared__ __attribute__((aligned(16))) char ab_smem[];
@@ -362,6 +362,38 @@ __global__ __launch_bounds__(256 * KS) void attn_bwd_dkv_kernel(AttnBwdP p) {
   }
 }
 
+template <int TK, int KS>
+__global__ __launch_bounds__(256 * KS) void attn_bwd_dq_kernel(AttnBwdP p) { attn_bwd_dq_body<TK, KS, true>(p); }
+template <int TK, int KS>
+__global__ __launch_bounds__(256 * KS) void attn_bwd_dkv_kernel(AttnBwdP p) { attn_bwd_dkv_body<TK, KS>(p); }
+
+// r04: both halves in ONE launch.  At S = 560 each of the two kernels is 9 x 12 = 108 workgroups on 256 CUs, one after the other (18 + 22 us per layer); the only thing
+// the dK / dV half needed from the dQ half was D_q = <dO_q, O_q>.  A small kernel computes D first (the dQ prologue's own summation order, so both halves see the bits the
+// two-launch form produces), then blockIdx.z picks the half: 216 workgroups side by side.
+__global__ __launch_bounds__(256) void attn_bwd_delta_kernel(AttnBwdP p) {
+  constexpr int HD = 128, DC = 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
+  const int qi = blockIdx.x * 64 + wave * 16 + fr, h = blockIdx.y;
+  const int qc = min(qi, p.S - 1);
+  const size_t qrow = (size_t)qc * p.n_q * HD + (size_t)h * HD;
+  float dsum = 0.f;
+#pragma unroll
+  for (int dc = 0; dc < DC; ++dc) {
+    const bf16x8 dof = ab_load_tr_order(p.d_o + qrow, dc * 32, g);
+    const bf16x8 of = ab_load_tr_order(p.o + qrow, dc * 32, g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dsum += (float)dof[e] * (float)of[e];
+  }
+  dsum += __shfl_xor(dsum, 16, 64);
+  dsum += __shfl_xor(dsum, 32, 64);
+  if (g == 0 && qi < p.S) p.delta[(size_t)h * p.S + qi] = dsum;
+}
+template <int TK, int KS>
+__global__ __launch_bounds__(256 * KS) void attn_bwd_both_kernel(AttnBwdP p) {
+  if (blockIdx.z == 0) attn_bwd_dq_body<TK, KS, false>(p);
+  else attn_bwd_dkv_body<TK, KS>(p);
+}
+
 extern "C" int vlaser_attn_bwd(const void* q, const void* k, const void* vt, const void* o, const void* d_o, const float* lse, float* delta_ws, void* dq, void* dk,
                                void* dv, int S, int n_q, int n_kv, int s_max, float scale, int causal, int kv_valid, int head_dim, vl_stream_t s) {
   VL_CHECK(q && k && vt && o && d_o && lse && delta_ws && dq && dk && dv, "vlaser_attn_bwd: null pointer");
@@ -374,13 +406,21 @@ extern "C" int vlaser_attn_bwd(const void* q, const void* k, const void* vt, con
   const dim3 grid((S + 63) / 64, n_q);
   static const int force_ks = getenv("VLASER_ATTN_BWD_KS") ? atoi(getenv("VLASER_ATTN_BWD_KS")) : 0;       // tuning / A-B
   const int ks = force_ks == 1 || force_ks == 2 ? force_ks : (S > 128 ? 2 : 1);
+  static const bool two_launches = getenv("VLASER_ATTN_BWD_TWO_LAUNCHES") && atoi(getenv("VLASER_ATTN_BWD_TWO_LAUNCHES")) == 1;      // A/B: the r03 form
 #define AB_LAUNCH(KS_)                                                                                               \
   {                                                                                                                  \
     const int lds_q = 2 * KS_ * (64 * AB_PQ + 128 * AB_PV), lds_kv = 2 * KS_ * (2 * 64 * AB_PQ + 2 * 64 * 4);   /* two tile buffers per wave group */                \
-    if (int rc = set_max_lds_once(attn_bwd_dq_kernel<64, KS_>, lds_q)) return rc;                                   \
-    if (int rc = set_max_lds_once(attn_bwd_dkv_kernel<64, KS_>, lds_kv)) return rc;                                 \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<64, KS_>), grid, dim3(256 * KS_), lds_q, (hipStream_t)s, p);             \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, KS_>), grid, dim3(256 * KS_), lds_kv, (hipStream_t)s, p);           \
+    if (two_launches) {                                                                                              \
+      if (int rc = set_max_lds_once(attn_bwd_dq_kernel<64, KS_>, lds_q)) return rc;                                 \
+      if (int rc = set_max_lds_once(attn_bwd_dkv_kernel<64, KS_>, lds_kv)) return rc;                               \
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, KS_>), grid, dim3(256 * KS_), lds_q, (hipStream_t)s, p);           \
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, KS_>), grid, dim3(256 * KS_), lds_kv, (hipStream_t)s, p);         \
+    } else {                                                                                                         \
+      const int lds_b = lds_q > lds_kv ? lds_q : lds_kv;                                                            \
+      if (int rc = set_max_lds_once(attn_bwd_both_kernel<64, KS_>, lds_b)) return rc;                               \
+      hipLaunchKernelGGL(attn_bwd_delta_kernel, grid, dim3(256), 0, (hipStream_t)s, p);                             \
+      hipLaunchKernelGGL((attn_bwd_both_kernel<64, KS_>), dim3(grid.x, grid.y, 2), dim3(256 * KS_), lds_b, (hipStream_t)s, p); \
+    }                                                                                                                \
   }
   if (ks == 2) AB_LAUNCH(2) else AB_LAUNCH(1)
 #undef AB_LAUNCH
