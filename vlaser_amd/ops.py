@@ -12,8 +12,11 @@ from . import _lib as L
 BF16 = torch.bfloat16
 
 
+_STREAM_OVERRIDE = None      # raw hipStream_t: set (and reset) by a caller that queues a run of launches on another stream without torch's stream context (sft.py)
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream().cuda_stream if _STREAM_OVERRIDE is None else _STREAM_OVERRIDE
 
 
 def _p(t):

@@ -272,6 +272,9 @@ class SFTModel:
         # single rank: AdamW (HBM-bound, a third of a step) runs on its own stream bucket by bucket in the order the next forward
         # consumes the parameters, so the next step's frozen-ViT / early-layer GEMMs (MFMA-bound) overlap it
         self.opt_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get('VLASER_SFT_OPT_PRIORITY', '0')))
+        # r04: the layer weight gradients run on a stream of their own.  dW = dY^T X depends on dY only, nothing in the backward chain depends on it, and most
+        # of the chain's launches are single-round grids of 108-252 workgroups on 256 CUs (tools/micro/sft_timeline.py): the weight-gradient GEMMs fill the gaps
+        self.wgrad_stream = None if os.environ.get('VLASER_SFT_NO_WGRAD_STREAM') == '1' else torch.cuda.Stream(device=dev)
 
     def _alloc_projector_ws(self):
         """Projector (mlp1) workspaces, sized for `max_tiles` tiles x 256 visual tokens."""
@@ -377,6 +380,34 @@ class SFTModel:
             self._dlog_pad[lo:].zero_()
             self._head_pad_R = R
         return self._x_pad, self._dlog_pad
+
+    def _wgrad_side(self, *args, want_done=False, **kw):
+        """`_wgrad` on the weight-gradient stream, behind everything the compute stream has queued so far (its dY operand); `want_done`: returns the event
+        that marks its end."""
+        if self.wgrad_stream is None:
+            self._wgrad(*args, **kw)
+            return None
+        ev = torch.cuda.Event()
+        ev.record()
+        ws = self.wgrad_stream
+        ws.wait_event(ev)
+        # `_wgrad` launches only through the C ABI: its launches are redirected by handle -- torch's stream context manager costs ~10 us of host time per
+        # use, which made the backward host-bound (4 weight gradients x 28 layers: tools/micro/sft_phases.py)
+        ops._STREAM_OVERRIDE = ws.cuda_stream
+        try:
+            self._wgrad(*args, **kw)
+        finally:
+            ops._STREAM_OVERRIDE = None
+        if not want_done:
+            return None
+        done = torch.cuda.Event()
+        done.record(ws)
+        return done
+
+    def _join_wgrad(self):
+        """The compute stream waits for every weight gradient queued so far (before their dY buffers are overwritten / the bucket is handed on)."""
+        if self.wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
 
     def _zero_wgrad_pad(self, S):
         """Rows S..ceil64(S) of the four dY buffers the layer weight gradients contract over: zero, so that the padded TN GEMM may read whole
@@ -564,6 +595,7 @@ class SFTModel:
             bucket_of_layer[li] = 1 + j // self.bucket_layers
         for i in reversed(range(Lyr)):
             h_in = self.h_in[i, :S]
+            self._join_wgrad()          # the previous layer's weight gradients still read dgu / dh2 / dqkv (and, with recompute, the one activation slot)
             x1, x2, h2, q, ao, gu, act = self._layer_forward(i, h_in, S, pos) if self.recompute else self._saved(i, S)
             kslot = 0 if self.recompute else i
             dact, dgu, dx, dh2, dao = self.dact[:S], self.dgu[:S], self.dx[:S], self.dh2[:S], self.dao[:S]
@@ -575,13 +607,13 @@ class SFTModel:
             else:
                 self._dgrad(dh, v[f'l{i}.wdown'], dact, S)
                 ops.swiglu_bwd(gu, dact, dgu, S, I)
-            self._wgrad(dh, act, gv[f'l{i}.wdown'], S, padded=True, ssq=self._ssq(f'l{i}.wdown'))
+            ev_wdown = self._wgrad_side(dh, act, gv[f'l{i}.wdown'], S, padded=True, ssq=self._ssq(f'l{i}.wdown'), want_done=True)
             self._dgrad(dgu, v[f'l{i}.wgu'], dx, S)
-            self._wgrad(dgu, x2, gv[f'l{i}.wgu'], S, padded=True, ssq=self._ssq(f'l{i}.wgu'))
+            self._wgrad_side(dgu, x2, gv[f'l{i}.wgu'], S, padded=True, ssq=self._ssq(f'l{i}.wgu'))
             ops.rmsnorm_bwd(dx, h2, v[f'l{i}.ln_post'], dh, dh2, S, H, llm.rms_norm_eps, dw_out=gv[f'l{i}.ln_post'], dw_ws=self.normw_ws)
             # attention block: h2 = h_in + ao Wo^T
             self._dgrad(dh2, v[f'l{i}.wo'], dao, S)
-            self._wgrad(dh2, ao, gv[f'l{i}.wo'], S, padded=True, ssq=self._ssq(f'l{i}.wo'))
+            self._wgrad_side(dh2, ao, gv[f'l{i}.wo'], S, padded=True, ssq=self._ssq(f'l{i}.wo'))
             Kc, VTc = self.cache.k[kslot, 0], self.cache.vt[kslot, 0]         # [nkv, s_max, hd], [nkv, hd, s_max]
             if self.attn_bwd_mode == 'fused':
                 ops.attn_bwd(q, Kc, VTc, ao, dao, self.lse[kslot], self.delta_ws, self.dq[:S], self.dk[:S], self.dv[:S], S, nq, nkv, sm, scale, head_dim=hd)
@@ -590,10 +622,14 @@ class SFTModel:
             dqkv = self.dqkv[:S]
             ops.rope_bwd_pack(self.dq[:S], self.dk[:S], self.dv[:S], self.rope[0], self.rope[1], pos, dqkv, S, nq, nkv, kv_per_q_head=True)
             self._dgrad(dqkv, v[f'l{i}.wqkv'], dx, S)
-            self._wgrad(dqkv, x1, gv[f'l{i}.wqkv'], S, bias_out=gv[f'l{i}.bqkv'], padded=True, ssq=self._ssq(f'l{i}.wqkv'))
+            self._wgrad_side(dqkv, x1, gv[f'l{i}.wqkv'], S, bias_out=gv[f'l{i}.bqkv'], padded=True, ssq=self._ssq(f'l{i}.wqkv'))
+            if ev_wdown is not None:
+                torch.cuda.current_stream().wait_event(ev_wdown)          # the down_proj weight gradient read dh, which the next kernel overwrites
             ops.rmsnorm_bwd(dx, h_in, v[f'l{i}.ln_in'], dh2, dh, S, H, llm.rms_norm_eps, dw_out=gv[f'l{i}.ln_in'], dw_ws=self.normw_ws)
             if on_bucket_ready and (i == 0 or bucket_of_layer[i - 1] != bucket_of_layer[i]):
+                self._join_wgrad()
                 on_bucket_ready(bucket_of_layer[i])
+        self._join_wgrad()
         # ---- embeddings (text rows) and projector (image rows)
         ops.embed_scatter_add(ids, self.rank_ws, dh, gv['embed'], S, H, sumsq_part=self._ssq('embed'))
         img_rows = self._h2d((ids_h.reshape(-1) == self.img_context_token_id).nonzero().flatten())
