@@ -291,3 +291,25 @@ def test_golden_manifest_matches_directory():
     for fn in ('g1_prompts(', 'g2_tiling(', 'g3_g4(', 'g5_g6(', 'g6b_ragged(', 'g7_vla(', 'g7b_trace(', 'g10_flow_matching(', 'g10b_flow_matching_vlm(',
                'g8_sft_grads(', 'g11_packed('):
         assert fn in default_path, f'{fn} missing from the default path of tools/gen_golden.py'
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The bench line committed with the round (profiles/r04w_bench_line.json, produced by `python bench.py` on the GPU box) carries what the contract asks of it:
+    the headline metric of BASELINE.json with `roofline` (measured traffic) and `cpu_baseline`, the SFT side line with its own CPU baseline, a consistent value."""
+    import glob
+    import json
+    lines = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r04*_bench_line.json')))
+    assert lines
+    d = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['metric'] == 'action_chunks_per_sec' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['dtype'] == 'bf16'
+    assert 'workload' in d['config'] and 'model' not in d['config'] and 'reference_mode' in d['config']
+    assert abs(d['value'] - d['n_gpus'] * 1e3 / d['ms_per_step']) < 0.02 * d['value']
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    assert r['traffic'] is not None and 0.95 < r['traffic'] / r['bytes_per_launch'] < 1.2       # counter traffic ~ algorithmic bytes: no wasted re-reads
+    c = d['cpu_baseline']
+    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
+    s = d['sft']
+    assert s['metric'] == 'sft_tokens_per_sec' and s['fwd_bwd_ms'] < s['ms_per_step'] and 'cpu_baseline' in s
