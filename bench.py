@@ -602,7 +602,9 @@ def _pmc_traffic():
             means = {}
             for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
                 with tempfile.TemporaryDirectory(dir='/tmp') as d:
-                    env = dict(os.environ, TMPDIR='/tmp')
+                    # a clean environment for the child profiler: when this process itself runs under rocprofv3 its preload / tool variables must not leak in
+                    env = {k: v for k, v in os.environ.items() if not (k.startswith(('ROCP', 'ROCPROF', 'HSA_TOOLS', 'ROCTRACER', 'ROCTX')) or k == 'LD_PRELOAD')}
+                    env['TMPDIR'] = '/tmp'
                     subprocess.run([rocprof, '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', d, '--', exe, '2'], cwd='/tmp', env=env, timeout=180,
                                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
                     f = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)[0]
