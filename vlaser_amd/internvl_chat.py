@@ -15,6 +15,8 @@ There is no CPU path: constructing the model without the HIP library / a GPU rai
 """
 from types import SimpleNamespace
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -98,7 +100,11 @@ class InternVLChatModel:
             raise RuntimeError(f'state_dict lacks tensors the kernels need: {missing[:8]}{" ..." if len(missing) > 8 else ""}')
         self.vit = VitEngine(sd, self.config, self.device, max_tiles=self._max_tiles)
         self.use_skinny = ops.skinny_supported(self.config.llm)      # Vlaser-8B (hidden 3584) decodes through the GEMM path
-        self.llm = QwenStack(sd, 'language_model.', self.config.llm, self.device, skinny=self.use_skinny)
+        # 16-row lane-local units for the q/k/v and gate/up GEMVs of the <= 16-row path (r03 kernels; at H = 1536 both help the decode: 1.169 -> 1.12 ms per token,
+        # same-box A/B r04; the action expert at K = 768 keeps gate/up on 32-row units): VLASER_DECODE_OPTS=none restores the r03 decode
+        self.llm = QwenStack(sd, 'language_model.', self.config.llm, self.device, skinny=self.use_skinny,
+                             opts=tuple(o for o in os.environ.get('VLASER_DECODE_OPTS', 'qkv16,gu16' if self.config.llm.hidden_size in (768, 1536) else '').split(',')
+                                        if o and o != 'none'))      # (the 16-row units are built for hidden sizes 768 / 1536: 3 / 6 K-steps per wave)
         self._alloc_llm()
         return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
 
