@@ -5,6 +5,8 @@ import math
 import os
 
 
+import threading
+
 import torch
 
 from . import _lib as L
@@ -12,11 +14,24 @@ from . import _lib as L
 BF16 = torch.bfloat16
 
 
-_STREAM_OVERRIDE = None      # raw hipStream_t: set (and reset) by a caller that queues a run of launches on another stream without torch's stream context (sft.py)
+_TLS = threading.local()      # .stream: raw hipStream_t pinned by a caller that queues a run of launches without looking the current stream up per launch
+                              # (sft.py: `torch.cuda.current_stream()` was 30 % of a forward + backward's host time); per thread, like torch's current stream
+
+
+def pinned_stream():
+    return getattr(_TLS, 'stream', None)
+
+
+def pin_stream(handle):
+    """Pin (handle) or lift (None) the stream of this thread's C-ABI launches; returns the previous pin so that callers can restore it."""
+    prev = getattr(_TLS, 'stream', None)
+    _TLS.stream = handle
+    return prev
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream if _STREAM_OVERRIDE is None else _STREAM_OVERRIDE
+    h = getattr(_TLS, 'stream', None)
+    return torch.cuda.current_stream().cuda_stream if h is None else h
 
 
 def _p(t):

@@ -393,12 +393,11 @@ class SFTModel:
         ws.wait_event(ev)
         # `_wgrad` launches only through the C ABI: its launches are redirected by handle -- torch's stream context manager costs ~10 us of host time per
         # use, which made the backward host-bound (4 weight gradients x 28 layers: tools/micro/sft_phases.py)
-        prev = ops._STREAM_OVERRIDE
-        ops._STREAM_OVERRIDE = ws.cuda_stream
+        prev = ops.pin_stream(ws.cuda_stream)
         try:
             self._wgrad(*args, **kw)
         finally:
-            ops._STREAM_OVERRIDE = prev
+            ops.pin_stream(prev)
         if not want_done:
             return None
         done = torch.cuda.Event()
@@ -476,20 +475,20 @@ class SFTModel:
         """Loss + gradients of ONE sample.  The ~850 launches of the call all go to the stream that is current at entry: its handle is looked up once and
         pinned for the C-ABI launches (`torch.cuda.current_stream()` per launch was 30 % of the call's host time: tools/micro/sft_host_profile.py); the
         bucket callbacks, which switch streams themselves, run with the pin lifted."""
-        prev = ops._STREAM_OVERRIDE
-        self._main_handle = ops._STREAM_OVERRIDE = torch.cuda.current_stream().cuda_stream
+        main = torch.cuda.current_stream().cuda_stream
+        prev = ops.pin_stream(main)
         cb = on_bucket_ready
         if cb is not None:
             def on_bucket_ready(b, _cb=cb):
-                ops._STREAM_OVERRIDE = prev
+                ops.pin_stream(prev)
                 try:
                     _cb(b)
                 finally:
-                    ops._STREAM_OVERRIDE = self._main_handle
+                    ops.pin_stream(main)
         try:
             return self._forward_backward(pixel_values, input_ids, labels, image_flags, on_bucket_ready)
         finally:
-            ops._STREAM_OVERRIDE = prev
+            ops.pin_stream(prev)
 
     def _forward_backward(self, pixel_values, input_ids, labels, image_flags=None, on_bucket_ready=None):
         cfg, llm, dev = self.cfg, self.llm, self.device
