@@ -249,6 +249,27 @@ def test_gemm_tn_lds_padded_contraction(K, M, N, cfg):
     assert (out.float() - out_old.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
 
 
+def test_rmsnorm_bwd_from_split_k_slabs():
+    """r04: vlaser_rmsnorm_bwd fed the fp32 split-K slabs of the dgrad before it == vlaser_reduce_norm into bf16 followed by vlaser_rmsnorm_bwd, bit for bit
+    (dx and the weight gradient); ragged row count, 1 .. 8 slabs."""
+    from vlaser_amd import ops
+    g = torch.Generator().manual_seed(21)
+    for S, C, n in ((561, 1536, 8), (70, 768, 3), (5, 1536, 1)):
+        slabs = (torch.randn(n, S, C, generator=g) * 0.3).cuda()
+        x = torch.randn(S, C, generator=g).to(BF).cuda(); w = (1 + 0.1 * torch.randn(C, generator=g)).to(BF).cuda(); dres = torch.randn(S, C, generator=g).to(BF).cuda()
+        dy = torch.empty(S, C, dtype=BF, device='cuda')
+        ops.reduce_norm(None, slabs, n, S, C, dy)
+        ws = torch.zeros(((S + 3) // 4) * C, device='cuda')
+        dx_a, dx_b = torch.empty_like(dy), torch.empty_like(dy)
+        dw_a, dw_b = torch.empty(C, dtype=BF, device='cuda'), torch.empty(C, dtype=BF, device='cuda')
+        ops.rmsnorm_bwd(dy, x, w, dres, dx_a, S, C, 1e-6, dw_out=dw_a, dw_ws=ws)
+        ops.rmsnorm_bwd(None, x, w, dres, dx_b, S, C, 1e-6, dw_out=dw_b, dw_ws=ws, dy_partials=slabs, n_partials=n)
+        assert torch.equal(dx_a, dx_b) and torch.equal(dw_a, dw_b), (S, C, n)
+        ops.rmsnorm_bwd(None, x, w, None, dx_b, S, C, 1e-6, dy_partials=slabs, n_partials=n)              # no residual, no weight gradient
+        ops.rmsnorm_bwd(dy, x, w, None, dx_a, S, C, 1e-6)
+        assert torch.equal(dx_a, dx_b)
+
+
 @pytest.mark.parametrize('K,M,N,cfg,lds', [(576, 1536, 2048, 0, True), (576, 17920, 1536, 0, True), (320, 1000, 520, 1300, True), (64, 136, 264, 1105, True),
                                            (128, 2048, 1536, 1200, True), (576, 17920, 1536, 1340, True), (320, 1000, 520, 1240, True), (100, 304, 200, 0, False), (200, 1000, 1528, 0, False)])
 def test_gemm_tn_sumsq_slots(K, M, N, cfg, lds):

@@ -226,18 +226,36 @@ extern "C" int vlaser_rope_bwd_pack(const void* dq, const void* dk, const void* 
 // ---------------------------------------------------------------------------------------------- RMSNorm backward
 // y = w * bf16(x rs), rs = rsqrt(mean(x^2) + eps).  dx = rs * (g - xhat * mean(g xhat)), g = w dy, xhat = x rs.
 // dx_out = dres + dx.  One wave per row.
+// dy_part (r04, optional): dy is not given as a bf16 tensor but as the n_part fp32 split-K slabs [n_part][S][C] of the dgrad GEMM that produced it; they
+// are added in slab order and rounded to bf16 exactly as vlaser_reduce_norm would have (same bits), once, into an LDS row -- the stand-alone reduction
+// launch between the gate/up dgrad and this kernel is gone.
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                           const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, float* __restrict__ dw_partial,
-                                                          int S, int C, float eps) {
+                                                          int S, int C, float eps, const float* __restrict__ dy_part, int n_part) {
   // dw_partial (optional, fp32 [gridDim.x][C]): this block's share of the weight gradient dw[c] = sum_s dy[s,c] x[s,c] rs_s, so the
   // norm-weight gradient needs no pass of its own over dy / x (finished by colsum_partials_kernel)
-  extern __shared__ float dw_lds[];            // [4][C] when dw_partial
+  extern __shared__ float dw_lds[];            // [4][C] fp32 when dw_partial, then [4][C] bf16 when dy_part
   const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6, row = blockIdx.x * 4 + wv_;
   const bool live = row < S;
   const size_t ro = (size_t)min(row, S - 1) * C;
+  bf16_t* dyl = reinterpret_cast<bf16_t*>(dw_lds + (dw_partial ? 4 * C : 0)) + wv_ * C;      // this wave's row of reduced dy
   float ss = 0.f, dot = 0.f;
   for (int c = lane * 8; c < C; c += 512) {
-    const u32x4 xv = ld_global_16(x + ro + c), gv = ld_global_16(dy + ro + c), wv = ld_global_16(w + c);
+    const u32x4 xv = ld_global_16(x + ro + c), wv = ld_global_16(w + c);
+    u32x4 gv;
+    if (dy_part) {
+      float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const float* pp = dy_part + ro + c;
+      for (int u = 0; u < n_part; ++u, pp += (size_t)S * C) {
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(pp), q1 = *reinterpret_cast<const f32x4*>(pp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += q0[j]; v[4 + j] += q1[j]; }
+      }
+      gv = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+      *reinterpret_cast<u32x4*>(dyl + c) = gv;              // read back by the same lane in the second pass
+    } else {
+      gv = ld_global_16(dy + ro + c);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float x0 = bf16lo_to_f32(xv[j]), x1 = bf16hi_to_f32(xv[j]);
@@ -250,7 +268,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
   const float rs = rsqrtf(ss / (float)C + eps);
   const float coef = dot * rs * rs * rs / (float)C;   // = rs * mean(g xhat) * rs
   for (int c = lane * 8; c < C; c += 512) {
-    const u32x4 xv = ld_global_16(x + ro + c), gv = ld_global_16(dy + ro + c), wv = ld_global_16(w + c);
+    const u32x4 xv = ld_global_16(x + ro + c), wv = ld_global_16(w + c);
+    const u32x4 gv = dy_part ? *reinterpret_cast<const u32x4*>(dyl + c) : ld_global_16(dy + ro + c);
     u32x4 rv = {0, 0, 0, 0};
     if (dres) rv = ld_global_16(dres + ro + c);
     u32x4 o;
@@ -291,12 +310,15 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __res
   if (q == 0 && c < C) out[c] = f32_to_bf16((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
 }
 extern "C" int vlaser_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* dres, void* dx, void* dw_out, float* dw_ws, int S, int C,
-                                  float eps, vl_stream_t s) {
-  VL_CHECK(dy && x && w && dx && S > 0 && C % 8 == 0, "vlaser_rmsnorm_bwd: bad args");
+                                  float eps, const float* dy_partials, int n_partials, vl_stream_t s) {
+  VL_CHECK((dy || dy_partials) && x && w && dx && S > 0 && C % 8 == 0, "vlaser_rmsnorm_bwd: bad args");
+  VL_CHECK(!dy_partials || (n_partials >= 1 && (((uintptr_t)dy_partials) & 15) == 0), "vlaser_rmsnorm_bwd: dy_partials = n_partials >= 1 fp32 slabs [S][C], 16-byte aligned");
   VL_CHECK(!dw_out || (dw_ws && C * 16 <= 64 * 1024), "vlaser_rmsnorm_bwd: weight gradient needs the [ceil(S/4)][C] fp32 workspace and C <= 4096");
   const int nb = (S + 3) / 4;
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nb), dim3(256), dw_out ? (size_t)C * 16 : 0, (hipStream_t)s, (const bf16_t*)dy, (const bf16_t*)x,
-                     (const bf16_t*)w, (const bf16_t*)dres, (bf16_t*)dx, dw_out ? dw_ws : nullptr, S, C, eps);
+  const size_t lds = (dw_out ? (size_t)C * 16 : 0) + (dy_partials ? (size_t)C * 8 : 0);
+  VL_CHECK(lds <= 64 * 1024, "vlaser_rmsnorm_bwd: C = %d too wide", C);
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nb), dim3(256), lds, (hipStream_t)s, (const bf16_t*)dy, (const bf16_t*)x,
+                     (const bf16_t*)w, (const bf16_t*)dres, (bf16_t*)dx, dw_out ? dw_ws : nullptr, S, C, eps, dy_partials, dy_partials ? n_partials : 0);
   if (dw_out) hipLaunchKernelGGL(colsum_partials_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)s, dw_ws, nb, C, (bf16_t*)dw_out);
   VL_LAUNCH_CHECK();
   return 0;

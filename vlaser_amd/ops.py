@@ -659,10 +659,11 @@ def rope_bwd_pack(dq, dk, dv, cos, sin, pos, out, S, n_q, n_kv, kv_per_q_head=Fa
                                          out.data_ptr(), S, n_q, n_kv, 1 if kv_per_q_head else 0, _stream()), 'vlaser_rope_bwd_pack')
 
 
-def rmsnorm_bwd(dy, x, w, dres, dx, S, Cc, eps, dw_out=None, dw_ws=None):
-    """dx = dres + RMSNorm backward; with dw_out (bf16 [C]) also the weight gradient (dw_ws: fp32 [ceil(S/4) * C] scratch)."""
-    L.check(L.lib().vlaser_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), _p(dres), dx.data_ptr(), _p(dw_out), _p(dw_ws), S, Cc, eps,
-                                       _stream()), 'vlaser_rmsnorm_bwd')
+def rmsnorm_bwd(dy, x, w, dres, dx, S, Cc, eps, dw_out=None, dw_ws=None, dy_partials=None, n_partials=0):
+    """dx = dres + RMSNorm backward; with dw_out (bf16 [C]) also the weight gradient (dw_ws: fp32 [ceil(S/4) * C] scratch).  `dy_partials` (fp32, >= n_partials * S * C):
+    dy comes as the split-K slabs of the dgrad GEMM before (summed + rounded in the kernel exactly as reduce_norm would; `dy` may be None)."""
+    L.check(L.lib().vlaser_rmsnorm_bwd(_p(dy), x.data_ptr(), w.data_ptr(), _p(dres), dx.data_ptr(), _p(dw_out), _p(dw_ws), S, Cc, eps,
+                                       _p(dy_partials), n_partials if dy_partials is not None else 0, _stream()), 'vlaser_rmsnorm_bwd')
 
 
 def colsum_bf16(a, out, S, Cc):

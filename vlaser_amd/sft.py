@@ -274,6 +274,7 @@ class SFTModel:
         self.opt_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get('VLASER_SFT_OPT_PRIORITY', '0')))
         # r04: the layer weight gradients run on a stream of their own.  dW = dY^T X depends on dY only, nothing in the backward chain depends on it, and most
         # of the chain's launches are single-round grids of 108-252 workgroups on 256 CUs (tools/micro/sft_timeline.py): the weight-gradient GEMMs fill the gaps
+        self._slab_norm = os.environ.get('VLASER_SFT_NO_SLAB_NORM') != '1'      # A/B: reduce the gate/up dgrad's slabs in their own launch again
         self.wgrad_stream = None if os.environ.get('VLASER_SFT_NO_WGRAD_STREAM') == '1' else torch.cuda.Stream(device=dev)
 
     def _alloc_projector_ws(self):
@@ -422,8 +423,9 @@ class SFTModel:
                 b[:, S:Sp].zero_()
         self._wgrad_pad_S = S
 
-    def _dgrad(self, dY, W, out, S):
-        """out[S,K] = dY[S,N] @ W[N,K], W as the forward stores it (NN GEMM); long contractions over few output tiles run split-K."""
+    def _dgrad(self, dY, W, out, S, keep_slabs=False):
+        """out[S,K] = dY[S,N] @ W[N,K], W as the forward stores it (NN GEMM); long contractions over few output tiles run split-K.  `keep_slabs`: a
+        split-K product is NOT reduced -- returns (slabs, count) for a consumer that sums them itself (`vlaser_rmsnorm_bwd`'s dy_partials), else None."""
         Nin, Kout = W.shape
         # measured at S = 560, 1536 outputs (tools/micro/nn_lab.py): contraction <= 2048 -> one pass (11.5-14.6 us) beats split-K slabs +
         # their reduction (9-11 + 5 us); longer contractions (8960 / 17920) keep split-K
@@ -431,9 +433,12 @@ class SFTModel:
         if sp > 1:
             part = self.part[:sp * S * Kout]
             ops.gemm_nn(L.EPI_PARTIAL, dY, W, out_f32=part, k_splits=sp)
+            if keep_slabs:
+                return part, sp
             ops.reduce_norm(None, part, sp, S, Kout, out)
         else:
             ops.gemm_nn(L.EPI_NONE, dY, W, out=out)
+        return None
 
     def _norm_wgrad(self, dy, x, out, S, Cc, mode=2, eps=1e-6):
         ops.colsum_mul(dy, x, self.col, S, Cc, mode, eps, self.rowstat)
@@ -627,9 +632,13 @@ class SFTModel:
                 self._dgrad(dh, v[f'l{i}.wdown'], dact, S)
                 ops.swiglu_bwd(gu, dact, dgu, S, I)
             ev_wdown = self._wgrad_side(dh, act, gv[f'l{i}.wdown'], S, padded=True, ssq=self._ssq(f'l{i}.wdown'), want_done=True)
-            self._dgrad(dgu, v[f'l{i}.wgu'], dx, S)
+            slabs = self._dgrad(dgu, v[f'l{i}.wgu'], dx, S, keep_slabs=self._slab_norm)
             self._wgrad_side(dgu, x2, gv[f'l{i}.wgu'], S, padded=True, ssq=self._ssq(f'l{i}.wgu'))
-            ops.rmsnorm_bwd(dx, h2, v[f'l{i}.ln_post'], dh, dh2, S, H, llm.rms_norm_eps, dw_out=gv[f'l{i}.ln_post'], dw_ws=self.normw_ws)
+            if slabs is not None:       # r04: the split-K slabs of the gate/up dgrad go straight into the norm's backward (one launch less per layer, same bits)
+                ops.rmsnorm_bwd(None, h2, v[f'l{i}.ln_post'], dh, dh2, S, H, llm.rms_norm_eps, dw_out=gv[f'l{i}.ln_post'], dw_ws=self.normw_ws,
+                                dy_partials=slabs[0], n_partials=slabs[1])
+            else:
+                ops.rmsnorm_bwd(dx, h2, v[f'l{i}.ln_post'], dh, dh2, S, H, llm.rms_norm_eps, dw_out=gv[f'l{i}.ln_post'], dw_ws=self.normw_ws)
             # attention block: h2 = h_in + ao Wo^T
             self._dgrad(dh2, v[f'l{i}.wo'], dao, S)
             self._wgrad_side(dh2, ao, gv[f'l{i}.wo'], S, padded=True, ssq=self._ssq(f'l{i}.wo'))
