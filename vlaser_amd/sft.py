@@ -445,14 +445,15 @@ class SFTModel:
         out.copy_(self.col[:Cc])
 
     # ------------------------------------------------------------------ forward of one layer with everything saved for its backward
-    def _layer_forward(self, i, h_in, S, pos):
+    def _layer_forward(self, i, h_in, S, pos, x1_ready=False):
         llm = self.llm
         v = self.fp.view
         H, I = llm.hidden_size, llm.intermediate_size
         nq, nkv, hd = llm.num_attention_heads, llm.num_key_value_heads, llm.head_dim
         x1, x2, h2, q, ao, gu, act = self._saved(i, S)
         j = 0 if self.recompute else i
-        ops.rmsnorm(h_in, v[f'l{i}.ln_in'], llm.rms_norm_eps, out=x1)
+        if not x1_ready:            # (the forward pass gets x1 of layers 1 .. L-1 from the previous layer's down_proj seam)
+            ops.rmsnorm(h_in, v[f'l{i}.ln_in'], llm.rms_norm_eps, out=x1)
         ops.gemm(L.EPI_QKV_ROPE, x1, v[f'l{i}.wqkv'], bias=v[f'l{i}.bqkv'], q_out=q, k_cache=self.cache.k[j], vt_cache=self.cache.vt[j],
                  rope_cos=self.rope[0], rope_sin=self.rope[1], pos_ids=pos, n_q_heads=nq, n_kv_heads=nkv, s_max=self.cache.s_max,
                  tok_per_batch=S, slot_base=0)
@@ -469,11 +470,14 @@ class SFTModel:
         j = 0 if self.recompute else i
         return (self.x1[j, :S], self.x2[j, :S], self.h2[j, :S], self.q[j, :S], self.ao[j, :S], self.gu[j, :S], self.act[j, :S])
 
-    def _layer_out(self, i, S, h2, act, h_out):
+    def _layer_out(self, i, S, h2, act, h_out, norm_w=None, x_out=None):
         llm = self.llm
         sp = ops.gemm_splits(S, llm.hidden_size, llm.intermediate_size)
         ops.gemm(L.EPI_PARTIAL, act, self.fp.view[f'l{i}.wdown'], out_f32=self.part, k_splits=sp)
-        ops.reduce_norm(h2, self.part, sp, S, llm.hidden_size, h_out)
+        if norm_w is None:
+            ops.reduce_norm(h2, self.part, sp, S, llm.hidden_size, h_out)
+        else:
+            ops.reduce_norm(h2, self.part, sp, S, llm.hidden_size, h_out, x_out, norm=1, norm_w=norm_w, eps=llm.rms_norm_eps)
 
     # ------------------------------------------------------------------ forward (loss) + backward (grads into self.fp.g)
     def forward_backward(self, pixel_values, input_ids, labels, image_flags=None, on_bucket_ready=None):
@@ -557,14 +561,24 @@ class SFTModel:
         h0 = self.h_in[0, :S]
         ops.embed_merge(ids, v['embed'], feat_used, h0, self.img_context_token_id, cfg.pad_token_id, False, self.rank_ws)
         # ---- forward through the layers (saved activations per layer, or only the layer inputs when recompute=True)
+        # r04: the down_proj seam (split-K reduce + residual) also applies the following layer's input_layernorm into its x1 slot, as the inference prefill
+        # does: one launch less per layer (`VLASER_SFT_NO_SEAM_NORM=1`: A/B)
+        seam = os.environ.get('VLASER_SFT_NO_SEAM_NORM') != '1'
+        xn = self.xn[:S]
+        bucket_of = lambda li: 1 + (Lyr - 1 - li) // self.bucket_layers          # layer buckets hold the layers in reverse order (bucket 1 = last layers)
+        x1_ready = False
         for i in range(Lyr):
-            self._wait_params(1 + (Lyr - 1 - i) // self.bucket_layers)     # layer buckets hold the layers in reverse order (bucket 1 = last layers)
-            _, _, h2, _, _, _, act = self._layer_forward(i, self.h_in[i, :S], S, pos)
-            self._layer_out(i, S, h2, act, self.h_in[i + 1, :S])
+            self._wait_params(bucket_of(i))
+            _, _, h2, _, _, _, act = self._layer_forward(i, self.h_in[i, :S], S, pos, x1_ready=x1_ready)
+            # (only inside a parameter bucket: across a boundary the seam would have to wait for the NEXT bucket's AdamW / all-gather one GEMM early)
+            x1_ready = seam and i + 1 < Lyr and bucket_of(i + 1) == bucket_of(i)
+            if x1_ready:
+                self._layer_out(i, S, h2, act, self.h_in[i + 1, :S], norm_w=v[f'l{i + 1}.ln_in'], x_out=self._saved(i + 1, S)[0])
+            else:
+                self._layer_out(i, S, h2, act, self.h_in[i + 1, :S])
         h_fin = self.h_in[Lyr, :S]
         # ---- loss head on the labelled rows only (rows with label -100 contribute neither loss nor gradient)
         rows = self._h2d(rows_h) if R else None
-        xn = self.xn[:S]
         self._wait_params(0)                                         # lm_head + final norm
         ops.rmsnorm(h_fin, v['norm'], llm.rms_norm_eps, out=xn)
         if R == 0:
