@@ -278,10 +278,15 @@ int vlaser_rope_bwd_pack(const void* dq, const void* dk, const void* dv, const f
                          void* out_packed, int S, int n_q, int n_kv, int kv_per_q_head, vl_stream_t stream);
 /* Qwen2RMSNorm backward: dx_out = dres + rmsnorm_bwd(dy, x, w).  dw_out (bf16 [C], nullable) = sum_s dy x rs, the weight
  * gradient, accumulated in the same pass through dw_ws (fp32 [ceil(S/4)][C] scratch).
+ * dw_ws WITHOUT dw_out (ABI 5): only the per-block partials [ceil(S/4)][C] are left in dw_ws; vlaser_colsum_partials_multi finishes several tensors in one launch.
  * dy_partials (ABI 5, nullable): dy handed over as the n_partials fp32 split-K slabs [n_partials][S][C] of the dgrad GEMM that produced it (then `dy` may be NULL): summed
  * in slab order and rounded to bf16 once, exactly as vlaser_reduce_norm would -- the reduction launch between the two is not needed. */
 int vlaser_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* dres, void* dx_out, void* dw_out, float* dw_ws, int S, int C,
                        float eps, const float* dy_partials, int n_partials, vl_stream_t stream);
+/* n_tensors norm-weight gradients whose partials vlaser_rmsnorm_bwd left at ws + t * slot_stride (n_part = ceil(S/4) rows of C): out_base[out_off[t] + c] (bf16) =
+ * sum over the rows, the sums and their order of the per-call reduction (out_off: device int64[n_tensors], element offsets) */
+int vlaser_colsum_partials_multi(const float* ws, long long slot_stride, int n_tensors, int n_part, int C, void* out_base, const long long* out_off,
+                                 vl_stream_t stream);
 /* out[c] = sum_s a[s,c] * f(b)[s,c]: mode 0: 1; 1: b; 2: rmsnorm-normalised b (b = norm input); 3: layernorm-normalised b */
 /* bias gradient of an nn.Linear: out[c] (bf16) = sum_s a[s, c], one launch */
 int vlaser_colsum_bf16(const void* a, void* out, int S, int C, int lda, vl_stream_t stream);

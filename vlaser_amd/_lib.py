@@ -90,6 +90,7 @@ _SIGS = {
     'vlaser_transpose': [vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i32, i64, i64, vp],
     'vlaser_rope_bwd_pack': [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     'vlaser_rmsnorm_bwd': [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, i32, vp],
+    'vlaser_colsum_partials_multi': [vp, i64, i32, i32, i32, vp, vp, vp],
     'vlaser_colsum_bf16': [vp, vp, i32, i32, i32, vp],
     'vlaser_colsum_mul': [vp, vp, vp, i32, i32, i32, f32, vp, vp],
     'vlaser_swiglu': [vp, vp, i32, i32, vp],

@@ -294,7 +294,11 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
 // out[c] (bf16) = sum_p partial[p][c], fixed order.  64 columns x 4 row-slices per workgroup: slice q sums rows q, q+4, ... with all of
 // its loads independent (4 accumulators), the slices meet in LDS in a fixed order.  (One thread per column over the whole column,
 // C / 256 = 6 workgroups, took 12 us for the 140 x 1536 partials of a norm-weight gradient: a serial chain of 35 load batches.)
-__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partial, int n_part, int C, bf16_t* __restrict__ out) {
+// blockIdx.y > 0 (vlaser_colsum_partials_multi): tensor t = blockIdx.y reads its partials at partial + t * slot and writes out + out_off[t]
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partial, int n_part, int C, bf16_t* __restrict__ out,
+                                                              long long slot = 0, const long long* __restrict__ out_off = nullptr) {
+  partial += (size_t)blockIdx.y * slot;
+  if (out_off) out += out_off[blockIdx.y];
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, q = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
   const int cc = min(c, C - 1);
@@ -313,13 +317,25 @@ extern "C" int vlaser_rmsnorm_bwd(const void* dy, const void* x, const void* w, 
                                   float eps, const float* dy_partials, int n_partials, vl_stream_t s) {
   VL_CHECK((dy || dy_partials) && x && w && dx && S > 0 && C % 8 == 0, "vlaser_rmsnorm_bwd: bad args");
   VL_CHECK(!dy_partials || (n_partials >= 1 && (((uintptr_t)dy_partials) & 15) == 0), "vlaser_rmsnorm_bwd: dy_partials = n_partials >= 1 fp32 slabs [S][C], 16-byte aligned");
-  VL_CHECK(!dw_out || (dw_ws && C * 16 <= 64 * 1024), "vlaser_rmsnorm_bwd: weight gradient needs the [ceil(S/4)][C] fp32 workspace and C <= 4096");
+  VL_CHECK(!dw_out || dw_ws, "vlaser_rmsnorm_bwd: the weight gradient needs the [ceil(S/4)][C] fp32 workspace");
+  VL_CHECK(!dw_ws || C * 16 <= 64 * 1024, "vlaser_rmsnorm_bwd: weight-gradient partials need C <= 4096");
   const int nb = (S + 3) / 4;
-  const size_t lds = (dw_out ? (size_t)C * 16 : 0) + (dy_partials ? (size_t)C * 8 : 0);
+  const size_t lds = (dw_ws ? (size_t)C * 16 : 0) + (dy_partials ? (size_t)C * 8 : 0);
   VL_CHECK(lds <= 64 * 1024, "vlaser_rmsnorm_bwd: C = %d too wide", C);
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nb), dim3(256), lds, (hipStream_t)s, (const bf16_t*)dy, (const bf16_t*)x,
-                     (const bf16_t*)w, (const bf16_t*)dres, (bf16_t*)dx, dw_out ? dw_ws : nullptr, S, C, eps, dy_partials, dy_partials ? n_partials : 0);
+                     (const bf16_t*)w, (const bf16_t*)dres, (bf16_t*)dx, dw_ws, S, C, eps, dy_partials, dy_partials ? n_partials : 0);
   if (dw_out) hipLaunchKernelGGL(colsum_partials_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)s, dw_ws, nb, C, (bf16_t*)dw_out);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// Several norm-weight gradients finished by ONE launch (r04): vlaser_rmsnorm_bwd called with dw_ws but WITHOUT dw_out only leaves its per-block partials
+// [ceil(S/4)][C] in its slot; tensor t's slot starts at ws + t * slot_stride, its bf16 output at out_base + out_off[t] (device int64 table).  Same sums in
+// the same order as the per-call reduction.
+extern "C" int vlaser_colsum_partials_multi(const float* ws, long long slot_stride, int n_tensors, int n_part, int C, void* out_base, const long long* out_off,
+                                            vl_stream_t s) {
+  VL_CHECK(ws && out_base && out_off && n_tensors >= 1 && n_part >= 1 && C >= 1 && slot_stride >= (long long)n_part * C, "vlaser_colsum_partials_multi: bad args");
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((C + 63) / 64, n_tensors), dim3(256), 0, (hipStream_t)s, ws, n_part, C, (bf16_t*)out_base, slot_stride, out_off);
   VL_LAUNCH_CHECK();
   return 0;
 }

@@ -666,6 +666,13 @@ def rmsnorm_bwd(dy, x, w, dres, dx, S, Cc, eps, dw_out=None, dw_ws=None, dy_part
                                        _p(dy_partials), n_partials if dy_partials is not None else 0, _stream()), 'vlaser_rmsnorm_bwd')
 
 
+def colsum_partials_multi(ws, slot_stride, n_tensors, n_part, Cc, out_base, out_off):
+    """Finish n_tensors norm-weight gradients (partials left by rmsnorm_bwd(dw_out=None, dw_ws=slot)) in one launch; out_off: device int64 element offsets into out_base."""
+    assert out_off.dtype == torch.int64 and out_off.numel() >= n_tensors
+    L.check(L.lib().vlaser_colsum_partials_multi(ws.data_ptr(), slot_stride, n_tensors, n_part, Cc, out_base.data_ptr(), out_off.data_ptr(), _stream()),
+            'vlaser_colsum_partials_multi')
+
+
 def colsum_bf16(a, out, S, Cc):
     L.check(L.lib().vlaser_colsum_bf16(a.data_ptr(), out.data_ptr(), S, Cc, a.stride(0), _stream()), 'vlaser_colsum_bf16')
 

@@ -263,6 +263,11 @@ class SFTModel:
         self.col = torch.zeros(max(2 * I, NQ, C4, H), dtype=F32, device=dev)
         self.sumsq_ws = torch.zeros(1024, dtype=F32, device=dev)
         self.normw_ws = torch.zeros((S + 3) // 4 * H, dtype=F32, device=dev)      # norm-weight gradient partials of rmsnorm_bwd
+        # r04: the two norm-weight gradients of every layer of a bucket leave their partials in slots of their own and are finished by ONE launch when the
+        # bucket completes (2 x bucket_layers launches less per bucket; `VLASER_SFT_NO_NORMW_BATCH=1`: A/B)
+        self.normw_slot = (S + 3) // 4 * H
+        self.normw_multi = None if os.environ.get('VLASER_SFT_NO_NORMW_BATCH') == '1' else torch.zeros(2 * self.bucket_layers * self.normw_slot, dtype=F32, device=dev)
+        self._normw_off = {}                    # first layer of a bucket -> device int64 offsets of its ln_post / ln_in gradients in fp.g, in slot order
         self.gnorm2 = torch.zeros(1, dtype=F32, device=dev)
         self.rank_ws = torch.zeros(S, dtype=torch.int32, device=dev)
         self.pos_all = torch.arange(S, dtype=torch.int32, device=dev)
@@ -631,6 +636,7 @@ class SFTModel:
         layers_rev = list(reversed(range(Lyr)))
         for j, li in enumerate(layers_rev):
             bucket_of_layer[li] = 1 + j // self.bucket_layers
+        nslot = 0                       # norm-weight gradients of the current bucket whose partials wait in self.normw_multi
         for i in reversed(range(Lyr)):
             h_in = self.h_in[i, :S]
             self._join_wgrad()          # the previous layer's weight gradients still read dgu / dh2 / dqkv (and, with recompute, the one activation slot)
@@ -648,11 +654,13 @@ class SFTModel:
             ev_wdown = self._wgrad_side(dh, act, gv[f'l{i}.wdown'], S, padded=True, ssq=self._ssq(f'l{i}.wdown'), want_done=True)
             slabs = self._dgrad(dgu, v[f'l{i}.wgu'], dx, S, keep_slabs=self._slab_norm)
             self._wgrad_side(dgu, x2, gv[f'l{i}.wgu'], S, padded=True, ssq=self._ssq(f'l{i}.wgu'))
+            nw = self.normw_multi
+            dw_kw = dict(dw_out=gv[f'l{i}.ln_post'], dw_ws=self.normw_ws) if nw is None else dict(dw_ws=nw[nslot * self.normw_slot:(nslot + 1) * self.normw_slot])
             if slabs is not None:       # r04: the split-K slabs of the gate/up dgrad go straight into the norm's backward (one launch less per layer, same bits)
-                ops.rmsnorm_bwd(None, h2, v[f'l{i}.ln_post'], dh, dh2, S, H, llm.rms_norm_eps, dw_out=gv[f'l{i}.ln_post'], dw_ws=self.normw_ws,
-                                dy_partials=slabs[0], n_partials=slabs[1])
+                ops.rmsnorm_bwd(None, h2, v[f'l{i}.ln_post'], dh, dh2, S, H, llm.rms_norm_eps, dy_partials=slabs[0], n_partials=slabs[1], **dw_kw)
             else:
-                ops.rmsnorm_bwd(dx, h2, v[f'l{i}.ln_post'], dh, dh2, S, H, llm.rms_norm_eps, dw_out=gv[f'l{i}.ln_post'], dw_ws=self.normw_ws)
+                ops.rmsnorm_bwd(dx, h2, v[f'l{i}.ln_post'], dh, dh2, S, H, llm.rms_norm_eps, **dw_kw)
+            nslot += nw is not None
             # attention block: h2 = h_in + ao Wo^T
             self._dgrad(dh2, v[f'l{i}.wo'], dao, S)
             self._wgrad_side(dh2, ao, gv[f'l{i}.wo'], S, padded=True, ssq=self._ssq(f'l{i}.wo'))
@@ -667,8 +675,21 @@ class SFTModel:
             self._wgrad_side(dqkv, x1, gv[f'l{i}.wqkv'], S, bias_out=gv[f'l{i}.bqkv'], padded=True, ssq=self._ssq(f'l{i}.wqkv'))
             if ev_wdown is not None:
                 torch.cuda.current_stream().wait_event(ev_wdown)          # the down_proj weight gradient read dh, which the next kernel overwrites
-            ops.rmsnorm_bwd(dx, h_in, v[f'l{i}.ln_in'], dh2, dh, S, H, llm.rms_norm_eps, dw_out=gv[f'l{i}.ln_in'], dw_ws=self.normw_ws)
-            if on_bucket_ready and (i == 0 or bucket_of_layer[i - 1] != bucket_of_layer[i]):
+            dw_kw = dict(dw_out=gv[f'l{i}.ln_in'], dw_ws=self.normw_ws) if nw is None else dict(dw_ws=nw[nslot * self.normw_slot:(nslot + 1) * self.normw_slot])
+            ops.rmsnorm_bwd(dx, h_in, v[f'l{i}.ln_in'], dh2, dh, S, H, llm.rms_norm_eps, **dw_kw)
+            nslot += nw is not None
+            last_of_bucket = i == 0 or bucket_of_layer[i - 1] != bucket_of_layer[i]
+            if nw is not None and last_of_bucket:
+                # the bucket's layers are i .. i + nslot/2 - 1, visited last to first: slots = (ln_post, ln_in) of layer i + nslot/2 - 1, ..., of layer i
+                key = (i, nslot)
+                if key not in self._normw_off:
+                    offs = []
+                    for li in reversed(range(i, i + nslot // 2)):
+                        offs += [self.fp.offset_of(f'l{li}.ln_post'), self.fp.offset_of(f'l{li}.ln_in')]
+                    self._normw_off[key] = torch.tensor(offs, dtype=torch.int64, device=dev)
+                ops.colsum_partials_multi(nw, self.normw_slot, nslot, (S + 3) // 4, H, self.fp.g, self._normw_off[key])
+                nslot = 0
+            if on_bucket_ready and last_of_bucket:
                 self._join_wgrad()
                 on_bucket_ready(bucket_of_layer[i])
         self._join_wgrad()
