@@ -249,6 +249,32 @@ def test_gemm_tn_lds_padded_contraction(K, M, N, cfg):
     assert (out.float() - out_old.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
 
 
+def test_embedding_gradient_row_clear_equals_full_clear(setup, monkeypatch):
+    """r04: inside train_step's one-sample path only the embedding-gradient rows the previous step touched are cleared (not the 466 MB table).  Steps over
+    samples with DIFFERENT token ids (A, B, A, B): parameters, losses and gradient norms bit-identical to the same steps with the full clear."""
+    from vlaser_amd.sft import SFTModel
+    cfg, sd, _, pv, ids, labels, _ = setup
+    ids_b = ids.clone()
+    txt = ids_b != cfg.img_context_token_id
+    ids_b[txt] = (ids_b[txt] * 7 + 13) % 150000 + 1            # other text tokens, same image positions
+    lab_b = labels.clone()
+    lab_b[labels != -100] = ids_b[labels != -100]
+
+    def run(full):
+        monkeypatch.setenv('VLASER_SFT_EMBED_FULL_CLEAR', '1' if full else '0')
+        m = SFTModel(cfg, max_seq_len=ids.shape[1], lr=1e-3, weight_decay=0.05, max_grad_norm=1.0)
+        m.load_state_dict(sd)
+        outs = [m.step(pv, i_, l_) for i_, l_ in ((ids, labels), (ids_b, lab_b), (ids, labels), (ids_b, lab_b))]
+        m.wait_optimizer()
+        return [o.loss.item() for o in outs], [o.grad_norm.item() for o in outs], m.state_dict()['language_model.model.embed_tokens.weight'].clone(), m.fp.gview['embed'].clone()
+
+    la, na, ea, ga = run(False)
+    lb, nb, eb, gb = run(True)
+    assert la == lb and na == nb
+    assert torch.equal(ea, eb) and torch.equal(ga, gb)
+    assert int((ga.float().abs().sum(1) > 0).sum()) <= int(torch.unique(ids_b).numel())       # only the last step's rows hold gradients
+
+
 def test_rmsnorm_bwd_from_split_k_slabs():
     """r04: vlaser_rmsnorm_bwd fed the fp32 split-K slabs of the dgrad before it == vlaser_reduce_norm into bf16 followed by vlaser_rmsnorm_bwd, bit for bit
     (dx and the weight gradient); ragged row count, 1 .. 8 slabs."""

@@ -498,7 +498,7 @@ extern "C" int vlaser_ce_dlogits(const float* logits, const float* lse, const in
 // chunk holds the run's first position -- a workgroup skips a leading run that started in the previous chunk and finishes its
 // last run past its own chunk end) and rounded to bf16 once, like torch's embedding backward; a token that occurs hundreds of times
 // in a 16k-token sample no longer loses its later contributions to bf16 re-rounding.  Ids outside [0, vocab) are skipped.
-#define ESA_CHUNK 64
+#define ESA_CHUNK 4       // r04: 64 -> 4 positions per workgroup: a chunk is walked serially (one dependent load per position), 9 workgroups took 100 us for S = 560
 __global__ __launch_bounds__(256) void embed_scatter_add_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ rank, const int32_t* __restrict__ order,
                                                                 const bf16_t* __restrict__ dh, bf16_t* __restrict__ dembed, int n, int H, long long vocab) {
   const int c = (blockIdx.y * 256 + threadIdx.x) * 2;               // two adjacent columns per thread (4-byte accesses)

@@ -178,6 +178,7 @@ class SFTModel:
     def load_state_dict(self, sd):
         cfg, llm, dev = self.cfg, self.llm, self.device
         self.wait_optimizer()
+        self._embed_touched = None
         self.vit = VitEngine(sd, cfg, dev, max_tiles=self.max_tiles)     # frozen (freeze_backbone True)
         self.frozen_sd = {k: v.detach().to('cpu') for k, v in sd.items() if k.startswith('vision_model.')}      # for save_pretrained
         H, I, V = llm.hidden_size, llm.intermediate_size, llm.vocab_size
@@ -546,7 +547,17 @@ class SFTModel:
         # every gradient tensor is fully overwritten by its wgrad / column-sum kernel each step, except the embedding rows
         # (scatter-add over the text tokens): only that slice is cleared (466 MB instead of the whole 3.6 GB buffer) -- after the
         # wait above: the previous step's AdamW may still be reading this bucket's gradients on the optimizer stream
-        gv['embed'].zero_()
+        # r04: on one rank with one sample per step the only non-zero rows are the ones the PREVIOUS call scattered into: those rows are cleared (a 560-row
+        # fill) instead of the table; anything else that wrote the bucket (gradient accumulation's finalize, a reduce-scatter) resets to the full clear
+        # (only inside train_step's one-sample path -- `_fused_norm` -- where nothing but this function writes the gradient buffer between two calls; a direct
+        # forward_backward() call, whose caller may do anything to fp.g in between, clears the table)
+        touched = getattr(self, '_embed_touched', None)
+        own = getattr(self, '_fused_norm', False) and os.environ.get('VLASER_SFT_EMBED_FULL_CLEAR') != '1'
+        if touched is not None and own:
+            gv['embed'].index_fill_(0, touched, 0)
+        else:
+            gv['embed'].zero_()
+        self._embed_touched = ids.reshape(-1).clamp(0, gv['embed'].shape[0] - 1) if own else None
         nt = T * cfg.num_image_token
         C1 = cfg.vision.hidden_size
         G_ = cfg.vision.image_size // cfg.vision.patch_size
@@ -590,6 +601,7 @@ class SFTModel:
             # no supervised position on this rank: zero loss, zero gradients -- but the SAME collective sequence as every other
             # rank (one reduce-scatter per bucket, in backward order)
             self.fp.g.zero_()
+            self._embed_touched = None
             if on_bucket_ready:
                 for b in range(len(self.buckets)):
                     on_bucket_ready(b)
@@ -906,6 +918,7 @@ class SFTModel:
         DeepSpeed's gradient-accumulation boundary: train.py:470-482, zero_stage1_config.json)."""
         lo, hi = self.buckets[b]
         ops.grad_accumulate(self.fp.g[lo:hi], self.gacc[lo:hi], w, first, last)
+        self._embed_touched = None              # (the finalised bucket holds every sample's rows: the next call clears the whole table)
         if last:
             self._exchange_bucket(b)
 
