@@ -409,6 +409,7 @@ def main():
             line['sft'] = sft_line
         if world == 1 and a.workload == 'both':
             line['batched'] = batched_chunks(vla, dev, a.steps)
+            line['two_in_flight'] = two_in_flight(vla, dev, a.steps)
             line['qa'] = qa_bench(local)
             if not a.no_8b:
                 line['qa_8b'] = qa8b_bench(local)
@@ -465,6 +466,45 @@ def _dry_run(rank, world):
     rc = int(os.environ.get('VLASER_BENCH_DRYRUN_EXIT', '0'))      # test hook: a rank that fails AFTER the line was printed
     if rc and rank == world - 1:
         sys.exit(rc)
+
+
+def two_in_flight(vla, dev, steps):
+    """Side number (never `value`): TWO independent batch-1 requests in flight -- two PiZeroInference instances (own workspaces, KV caches and graphs; same weights' values)
+    on two streams, calls alternating -- the serving situation of two robots / environments on one GPU.  The launch-bound Euler phase of one request (few CUs busy)
+    runs under the MFMA-bound ViT + prefill of the other.  Throughput only: each request's latency roughly doubles the per-chunk figure."""
+    from vlaser_amd import synth
+    from vlaser_amd.pizero import PiZeroInference
+    sd = synth.vla_state_dict(vla, device=dev, dtype=torch.bfloat16)
+    models, streams, inputs = [], [], []
+    for i in range(2):
+        m = PiZeroInference(vla, device=dev, max_batch=1)
+        m.load_state_dict(sd)
+        models.append(m)
+        streams.append(torch.cuda.Stream(device=dev))
+        ids, pv, proprio, noise = make_inputs(vla.base, 1, seed=200 + i)
+        inputs.append((ids.to(dev), pv.to(dev).to(torch.bfloat16), proprio.to(dev), noise.to(dev), (ids != vla.base.pad_token_id).sum(-1).to(dev)))
+    del sd
+
+    def call(i):
+        ids, pv, pro, noise, valid = inputs[i]
+        with torch.cuda.stream(streams[i]):
+            return models[i].infer_action(ids, pv, proprios=pro, noise=noise, valid_len=valid)
+
+    for i in range(2):
+        for _ in range(3):
+            call(i)
+    torch.cuda.synchronize()
+    n = 2 * max(steps // 2, 10)
+    t0 = time.perf_counter()
+    for k in range(n):
+        out = call(k % 2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    del models
+    torch.cuda.empty_cache()
+    return {'requests_in_flight': 2, 'action_chunks_per_sec': round(n / dt, 1), 'ms_per_chunk': round(dt / n * 1e3, 3),
+            'note': 'two independent batch-1 requests on two streams (two model instances); throughput of a 2-client serving loop, NOT the headline: one request at a time is `value`'}
 
 
 def batched_chunks(vla, dev, steps):
