@@ -275,6 +275,35 @@ def test_embedding_gradient_row_clear_equals_full_clear(setup, monkeypatch):
     assert int((ga.float().abs().sum(1) > 0).sum()) <= int(torch.unique(ids_b).numel())       # only the last step's rows hold gradients
 
 
+@pytest.mark.parametrize('cfg', [1340, 1240, 1140])
+def test_gemm_tn_staggered_race_screen(cfg):
+    """The staggered two-wave-group TN kernel has its own synchronisation structure (refill two phases after the last read, read one phase after the counted vmcnt):
+    30 runs on the same operands, with an unrelated GEMM stream running beside them to move the timing around, must be bit-identical to the first run and within
+    bf16 rounding of fp32 -- an early LDS read would show as a run that differs."""
+    from vlaser_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(cfg)
+    K, M, N = 576, 2048 + 24, 1536 + 8
+    At = torch.zeros(K, M, dtype=BF, device='cuda'); Wt = torch.randn(K, N, generator=g).to(BF).cuda()
+    At[:560] = torch.randn(560, M, generator=g).to(BF).cuda()
+    ref = At.float().t() @ Wt.float()
+    side = torch.cuda.Stream()
+    a2, w2, o2 = torch.randn(1024, 1024, device='cuda').to(BF), torch.randn(4096, 1024, device='cuda').to(BF), torch.empty(1024, 4096, dtype=BF, device='cuda')
+    first = None
+    for it in range(30):
+        out = torch.full((M, N), 3.0, dtype=BF, device='cuda')
+        if it % 2:
+            with torch.cuda.stream(side):
+                for _ in range(1 + it % 5):
+                    ops.gemm(L.EPI_NONE, a2, w2, out=o2)
+        ops.gemm_tn_lds(At, Wt, out, K, force_cfg=cfg)
+        torch.cuda.synchronize()
+        if first is None:
+            first = out.clone()
+            assert (out.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item() + 1e-3
+        else:
+            assert torch.equal(out, first), it
+
+
 def test_rmsnorm_bwd_from_split_k_slabs():
     """r04: vlaser_rmsnorm_bwd fed the fp32 split-K slabs of the dgrad before it == vlaser_reduce_norm into bf16 followed by vlaser_rmsnorm_bwd, bit for bit
     (dx and the weight gradient); ragged row count, 1 .. 8 slabs."""
