@@ -918,3 +918,47 @@ def test_vla_step_one_launch_between_layer_passes(ops, M, W, ad, npart, row_off)
     ops.vla_step(a_out, a_out, w21, cs[s_idx], w3, b3, h2, M, W, ad)
     assert torch.equal(h2[:M], h_out[:M])
 
+
+
+@pytest.mark.parametrize('case', ['nt_bias_gelu_144x128', 'nt_res_64x64', 'nn_none_128x256', 'nt_swiglu_aux_192x256'])
+def test_gemm_row_store_race_screen(ops, case):
+    """r04: the bf16 epilogues reuse the stage ring as scratch for whole-row stores (after a barrier that follows every wave's own vmcnt(0)) / trade fragments between lanes:
+    25 runs on the same operands, an unrelated GEMM stream beside every other one, must be bit-identical -- a store that met a late LDS-DMA piece or a stale scratch row
+    would differ between runs."""
+    from vlaser_amd import _lib as L
+    g = torch.Generator().manual_seed(len(case))
+    rn = lambda *sh, sc=0.05: (torch.randn(*sh, generator=g) * sc).to(BF).cuda()
+    if case == 'nt_bias_gelu_144x128':
+        x, w, b = rn(1025, 1024, sc=1.0), rn(4096, 1024), rn(4096)
+        run = lambda out: ops.gemm(L.EPI_BIAS_GELU, x, w, out=out, bias=b)
+        shape = (1025, 4096)
+    elif case == 'nt_res_64x64':
+        x, w, r = rn(384, 1536, sc=1.0), rn(1536, 1536), rn(384, 1536, sc=1.0)
+        run = lambda out: ops.gemm(L.EPI_RES, x, w, out=out, res=r, force_bm=1564)
+        shape = (384, 1536)
+    elif case == 'nn_none_128x256':
+        x, w = rn(560, 1536, sc=1.0), rn(1536, 8960)
+        run = lambda out: ops.gemm_nn(L.EPI_NONE, x, w, out=out)
+        shape = (560, 8960)
+    else:
+        x, w = rn(560, 1536, sc=1.0), ops.pack_gate_up(rn(8960, 1536), rn(8960, 1536))
+        aux = torch.zeros(560, 17920, dtype=BF, device='cuda')
+        run = lambda out: ops.gemm(L.EPI_SWIGLU, x, w, out=out, aux_out=aux, ld_aux=aux.stride(0))
+        shape = (560, 8960)
+    side = torch.cuda.Stream()
+    a2, w2, o2 = rn(1024, 1024, sc=1.0), rn(4096, 1024), torch.empty(1024, 4096, dtype=BF, device='cuda')
+    first = None
+    for it in range(25):
+        out = torch.full(shape, 3.0, dtype=BF, device='cuda')
+        if it % 2:
+            with torch.cuda.stream(side):
+                for _ in range(1 + it % 4):
+                    ops.gemm(L.EPI_NONE, a2, w2, out=o2)
+        run(out)
+        torch.cuda.synchronize()
+        keep = (out.clone(), aux.clone()) if case.startswith('nt_swiglu') else (out.clone(),)
+        if first is None:
+            first = keep
+            assert torch.isfinite(out.float()).all() and not (out == 3.0).all()
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(keep, first)), it
