@@ -562,6 +562,25 @@ def test_checkpoint_resume_is_bit_identical(golden_model, tmp_path):
     assert torch.equal(a.fp.p, c.fp.p) and torch.equal(a.master, c.master) and torch.equal(a.m, c.m) and torch.equal(a.v, c.v)
 
 
+@pytest.mark.parametrize('V,ld,off', [(151674, 151674, 0), (1001, 1001, 0), (1000, 1003, 1), (8195, 8200, 0), (7, 7, 0)])
+def test_ce_rows_matches_logsumexp(ops, V, ld, off):
+    """vlaser_ce_rows (CrossEntropyLoss rows of modeling_internvl_chat.py:231-243) against torch.logsumexp in fp64: full vocabulary width, odd widths, rows that are
+    only 4-byte aligned (the 8-byte loads of the kernel must fall back), ignore_index rows"""
+    R = 9
+    g = torch.Generator(device='cuda').manual_seed(V + off)
+    buf = torch.randn(R * ld + off + 8, device='cuda', generator=g) * 6.0
+    logits = buf[off:off + R * ld].view(R, ld)[:, :V]
+    labels = torch.randint(0, V, (R,), device='cuda', generator=g)
+    labels[2] = -100
+    loss = torch.full((R,), 7.0, device='cuda'); lse = torch.empty(R, device='cuda')
+    ops.ce_rows(logits, labels, loss, lse)
+    ref_lse = torch.logsumexp(logits.double(), dim=1)
+    ref = ref_lse - logits.double().gather(1, labels.clamp(min=0)[:, None])[:, 0]
+    ref[2] = 0.0
+    assert torch.allclose(lse.double(), ref_lse, rtol=0, atol=2e-5 * max(1.0, float(ref_lse.abs().max())))
+    assert torch.allclose(loss.double(), ref, rtol=0, atol=4e-5 * max(1.0, float(ref_lse.abs().max())))
+
+
 def test_device_side_clip_matches_host_formula(ops):
     n = 50_000
     g = torch.Generator().manual_seed(8)
