@@ -520,6 +520,20 @@ def test_embed_merge_and_argmax(ops):
     assert torch.equal(nh, big[oid])
 
 
+@pytest.mark.parametrize('N', [7, 1001, 8193, 16386, 151674, 151675])
+def test_argmax_widths_and_ties(ops, N):
+    """vlaser_argmax == torch.argmax (lowest index wins ties) at odd widths (rows of an odd N are only 4-byte aligned: the 8-byte loads fall back), with ties
+    planted across the unrolled / remainder / tail loops of the kernel"""
+    g = torch.Generator(device='cuda').manual_seed(N)
+    logits = torch.randn(4, N, device='cuda', generator=g)
+    logits[1, N - 1] = 40.0
+    logits[2, N - 1] = 40.0; logits[2, N // 2] = 40.0; logits[2, min(N - 1, 2 * 8192 + 1)] = 40.0
+    logits[3, :] = 1.0
+    oid = torch.full((4,), -1, dtype=torch.int64, device='cuda')
+    ops.argmax(logits, oid, None, None)
+    assert torch.equal(oid, logits.argmax(-1)) and oid[3] == 0 and oid[1] == N - 1
+
+
 def test_vla_glue(ops):
     W, adim, M = 768, 7, 8
     act = torch.randn(M, adim).cuda(); w1 = rnd(W, adim, std=0.2); b1 = rnd(W, std=0.1, seed=1)
