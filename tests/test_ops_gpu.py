@@ -139,11 +139,13 @@ def _attn_ref(q, k, v, scale, vis):
     return (s.softmax(-1) @ v.float()).transpose(1, 2).reshape(q.shape[0], q.shape[2], -1)
 
 
-@pytest.mark.parametrize('T,S', [(2, 1025), (1, 1024), (1, 1040), (1, 1056), (1, 1153), (1, 200), (13, 1025)])
+@pytest.mark.parametrize('T,S', [(2, 1025), (1, 1025), (1, 1024), (1, 1040), (1, 1056), (1, 1153), (1, 449), (1, 200), (13, 1025)])
 def test_attn_vit_full(ops, T, S):
     """InternViT attention (FULL mode, head_dim 64).  S = 1025 = 8 key tiles of 128 + ONE key and 16 workgroups of 64 query rows + ONE row: since r04 the odd key
     is a 32-key chunk straight from global memory and the odd row's workgroup splits the keys between its waves (csrc/attn.hip, `TAIL`); 1040 / 1056 / 1153 /
-    200 put 16 / 32 / 1 / 8 keys and rows behind the last full tile (with and without the tail paths), 13 tiles at once, the lse output on the tail row."""
+    200 put 16 / 32 / 1 / 8 keys and rows behind the last full tile (with and without the tail paths), 13 tiles at once, the lse output on the tail row.
+    One tile (T = 1, <= 512 workgroups): the tail rows are HOSTED by the last full workgroup of their head (a second softmax state per wave on every fourth key
+    tile, `HOST`): 1025 / 1040 / 1153 with the tail-key chunk, 449 with a masked last tile instead."""
     from vlaser_amd import _lib as L
     Hn, Sp = 16, (S + 63) // 64 * 64
     q = rnd(T, Hn, Sp, 64, seed=1); k = rnd(T, Hn, Sp, 64, seed=2); v = rnd(T, Hn, Sp, 64, seed=3)

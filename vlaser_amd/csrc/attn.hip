@@ -31,6 +31,7 @@ struct AttnP {
   // key tile through LDS for the one key and a 17th workgroup walking every tile for the one row: 22.5 us against 14.65 us for 1024 tokens (DESIGN lesson 29).
   int tail_key0;      // >= 0: keys [tail_key0, kv_len) (<= 32) are NOT a tile: every wave takes them as one 32-key chunk straight from global memory
   int tail_qb;        // >= 0: workgroup tail_qb holds <= 16 query rows: its 4 waves take the same rows and split the key TILES between them
+  int tail_host;      // 1: there is NO workgroup tail_qb -- workgroup tail_qb - 1 of each head carries those rows as a fifth 16-row tile dealt over its 4 waves
 };
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -120,7 +121,7 @@ struct DirectChunk {
 // TK = keys per tile (64 / 128): with about one workgroup per CU a wave is alone on its SIMD and every tile is a serial chain
 // barrier -> LDS store -> barrier -> S^T -> max (two cross-lane hops) -> exp -> P V; 128-key tiles halve the number of chains
 // per key and give each one twice the independent MFMA / exp work to overlap.
-template <int HD, int KS, int TK, bool TAIL = false>      // TAIL: the FULL-mode tail handling (p.tail_key0 / p.tail_qb); its own instantiation, so the other shapes do not carry its registers
+template <int HD, int KS, int TK, bool TAIL = false, bool HOST = false>      // HOST: TAIL with the tail rows hosted by the last full workgroup (p.tail_host; its own instantiation: +2 x 16 registers); TAIL: the FULL-mode tail handling (p.tail_key0 / p.tail_qb); its own instantiation, so the other shapes do not carry its registers
 __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
   constexpr int DC = HD / 32;   // d-chunks of 32 for S^T
   constexpr int DT = HD / 16;   // d-tiles of 16 for O^T
@@ -157,7 +158,11 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
   // (wave w computes tiles w, w + 4, ...; the staging and its barriers stay cooperative), flash-decoding merge through LDS at the end: a quarter of a full
   // workgroup's issue slots, so the full workgroup it shares a CU with (272 workgroups on 256 CUs at S = 1025) is slowed far less than by a second full one.
   // (First built as a workgroup pulling its chunks straight from global memory: latency-bound, as slow as the full workgroups -- profiles/r04l.)
-  const bool tailwg = TAIL && qb == p.tail_qb;
+  const bool tailwg = TAIL && !HOST && qb == p.tail_qb;
+  // r04 (tail_host): the <= 16 tail rows ride in the LAST FULL workgroup of their head instead -- a second softmax state per wave, advanced over a quarter of the
+  // keys of every tile (wave w: the w-th 32-key chunk), merged like the tail workgroup's.  The grid is exactly tail_qb x heads workgroups (ViT: 256 = one per CU, one
+  // round) and 16 of them carry +25 % work, instead of 16 extra workgroups that each walk a head's K / V beside a full one.
+  const bool hostwg = HOST && qb == p.tail_qb - 1;
   const int q_row = qb * 64 + (tailwg ? 0 : wave * 16) + fr;  // this lane's query row (within the batch element)
 
   const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (size_t)b * a.q_bs + (size_t)h * a.q_hs;
@@ -195,6 +200,21 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
 #pragma unroll
   for (int i = 0; i < DT; ++i) o[i] = f32x4{0, 0, 0, 0};
   float m_run = NEG_BIG, l_run = 0.f;
+  // the host workgroup's second state: rows tail_qb * 64 + fr (rows >= sq: zero queries, never written)
+  bf16x8 qf2[HOST ? DC : 1];
+  f32x4 o2[HOST ? DT : 1];
+  float m2 = NEG_BIG, l2 = 0.f;
+  if constexpr (HOST) {
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o2[i] = f32x4{0, 0, 0, 0};
+    const int q_row2 = p.tail_qb * 64 + fr;
+#pragma unroll
+    for (int dc = 0; dc < DC; ++dc) {
+      u32x4 v = {0, 0, 0, 0};
+      if (hostwg && q_row2 < a.sq) v = ld_global_16(Q + (size_t)q_row2 * a.q_ss + dc * 32 + g * 8);
+      qf2[dc] = as_bf16x8(v);
+    }
+  }
   const float sc = a.scale * 1.4426950408889634f;  // softmax in base 2
 
   // the <= 32 keys behind the last full tile (FULL mode): requested now as one chunk straight from global memory, folded in after the tile loop
@@ -239,15 +259,17 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
   };
 
   // one TK-key tile against this wave's 16 query rows; S^T tiles s[c][t], key(c,t,reg) = key0 + c*32 + g*8 + t*4 + reg
-  auto tile_body = [&](int key0, auto masked_c) __attribute__((always_inline)) {
+  // (nc_c chunks of 32 keys starting at chunk cb of the tile: the whole tile for a wave's own rows, ONE chunk for the hosted tail rows)
+  auto tile_body = [&](int key0, auto masked_c, auto nc_c, int cb, const auto& qf, float& m_run, float& l_run, auto& o) __attribute__((always_inline)) {
     constexpr bool MASKED = decltype(masked_c)::value;
+    constexpr int NC = decltype(nc_c)::value;
     f32x4 s[NC][2];
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         f32x4 acc = {0, 0, 0, 0};
-        const int krow = c * 32 + (fr >> 2) * 8 + t * 4 + (fr & 3);
+        const int krow = (cb + c) * 32 + (fr >> 2) * 8 + t * 4 + (fr & 3);
 #pragma unroll
         for (int dc = 0; dc < DC; ++dc) {
           bf16x8 kf = as_bf16x8(*reinterpret_cast<const u32x4*>(Ks + k_lds_off<HD>(krow, dc * 4 + g)));
@@ -266,7 +288,7 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if constexpr (MASKED) {
-            const int key = key0 + c * 32 + g * 8 + t * 4 + r;
+            const int key = key0 + (cb + c) * 32 + g * 8 + t * 4 + r;
             const bool v = (key < lim1) || (key >= lo2 && key < hi2);
             vis[c][t][r] = v;
             if (v) mx = fmaxf(mx, s[c][t][r]);
@@ -304,7 +326,7 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
       acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        bf16x8 vf = as_bf16x8(*reinterpret_cast<const u32x4*>(Vs + vt_lds_off<TK>(dt * 16 + fr, c * 4 + g)));
+        bf16x8 vf = as_bf16x8(*reinterpret_cast<const u32x4*>(Vs + vt_lds_off<TK>(dt * 16 + fr, (cb + c) * 4 + g)));
         acc = mfma16(vf, pf[c], acc);
       }
       o[dt] = acc;
@@ -328,13 +350,27 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
     // a tile every row of this wave sees in full (all interior tiles of FULL / PREFIX, the tiles left of the diagonal of CAUSAL)
     // skips the visibility arithmetic: the loop is VALU-issue bound (about 230 VALU + 17 transcendental instructions per tile
     // against 16 MFMAs at head_dim 64), and the masks were 40 % of it
-    if (key0 + TK <= wave_lim1) tile_body(key0, std::false_type{});
-    else tile_body(key0, std::true_type{});
+    using all_c = std::integral_constant<int, NC>;
+    if (key0 + TK <= wave_lim1) tile_body(key0, std::false_type{}, all_c{}, 0, qf, m_run, l_run, o);
+    else tile_body(key0, std::true_type{}, all_c{}, 0, qf, m_run, l_run, o);
+    if constexpr (HOST) {
+      // the hosted rows: wave w takes the w-th 32-key chunk of EVERY tile (+25 % per wave and tile; a whole tile every fourth trip would double the time
+      // of every trip -- the tiles are barrier-stepped: measured 24.6 us against 21.5 for the tail workgroups).  FULL mode: the limits do not depend on the row
+      static_assert(!HOST || NC == 4, "HOST deals one 32-key chunk of a 128-key tile to each of the 4 waves");
+      if (hostwg) {
+        using one_c = std::integral_constant<int, 1>;
+        if (key0 + TK <= wave_lim1) tile_body(key0, std::false_type{}, one_c{}, wave, qf2, m2, l2, o2);
+        else tile_body(key0, std::true_type{}, one_c{}, wave, qf2, m2, l2, o2);
+      }
+    }
   }
 
-  if constexpr (TAIL) { if (p.tail_key0 >= 0 && grp == 0 && (!tailwg || wave == 0)) tailc.process(qf, p.tail_key0, a.kv_len, sc, g, m_run, l_run, o); }
-  if (tailwg) {
-    // merge of the four waves' partial softmax states (same rows, disjoint keys) through LDS, fixed order
+  if constexpr (TAIL) {
+    if (p.tail_key0 >= 0 && grp == 0 && (!tailwg || wave == 0)) tailc.process(qf, p.tail_key0, a.kv_len, sc, g, m_run, l_run, o);
+    if constexpr (HOST) { if (p.tail_key0 >= 0 && hostwg && wave == 0) tailc.process(qf2, p.tail_key0, a.kv_len, sc, g, m2, l2, o2); }
+  }
+  // merge of the four waves' partial softmax states (same rows, disjoint keys) through LDS, fixed order; writes rows out_qb * 64 ...
+  auto merge4 = [&](float m_run, float l_run, const auto& o, int out_qb) __attribute__((always_inline)) {
     constexpr int WS = 32 + 16 * HD;
     __syncthreads();                                           // every wave is done with the staged tiles: the area becomes the merge buffer
     float* wm = reinterpret_cast<float*>(smem) + wave * WS;
@@ -362,7 +398,7 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
 #pragma unroll
       for (int j = 0; j < DPT; ++j) acc[j] += base[w * WS + 32 + row * HD + d0 + j] * f;
     }
-    const int q_out = qb * 64 + row;
+    const int q_out = out_qb * 64 + row;
     if (q_out < a.sq) {
       const float inv = L > 0.f ? 1.0f / L : 0.f;
       if (a.lse_out && d0 == 0) a.lse_out[((size_t)b * a.n_q_heads + h) * a.sq + q_out] = M + __builtin_amdgcn_logf(L);
@@ -370,7 +406,10 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
 #pragma unroll
       for (int j = 0; j < DPT; j += 2) *reinterpret_cast<uint32_t*>(O + j) = pack_bf16x2(acc[j] * inv, acc[j + 1] * inv);
     }
-    return;
+  };
+  if constexpr (TAIL) {
+    if (tailwg) { merge4(m_run, l_run, o, qb); return; }
+    if constexpr (HOST) { if (hostwg) merge4(m2, l2, o2, p.tail_qb); }
   }
 
   if constexpr (KS > 1) {
@@ -614,7 +653,7 @@ extern "C" int vlaser_attn_prefill(const VlaserAttnArgs* a, vl_stream_t s) {
   VL_CHECK(a->ld_vt % 64 == 0, "vlaser_attn_prefill: V^T row length must be padded to a multiple of 64 keys");
   VL_CHECK(a->kv_len <= a->ld_vt, "vlaser_attn_prefill: kv_len exceeds cache");
   VL_CHECK(a->sq > 0 && a->batch > 0, "vlaser_attn_prefill: empty");
-  AttnP p; p.a = *a; p.tail_key0 = -1; p.tail_qb = -1;
+  AttnP p; p.a = *a; p.tail_key0 = -1; p.tail_qb = -1; p.tail_host = 0;
   dim3 grid((a->sq + 63) / 64, a->n_q_heads, a->batch);
   // tile / split choice, measured (tools/micro/attn_lab.py, profiles/r02k_attn.md): a 2-way in-workgroup key split pays only when
   // the grid does not even reach one workgroup per CU (joint prefill: 72 workgroups, 11.4 -> 10.8 us); 128-key tiles only for the
@@ -632,6 +671,8 @@ extern "C" int vlaser_attn_prefill(const VlaserAttnArgs* a, vl_stream_t s) {
     const int tail = a->kv_len % tk;
     if (tail >= 1 && tail <= 32 && a->kv_len > tk) p.tail_key0 = a->kv_len - tail;
     if (a->sq % 64 >= 1 && a->sq % 64 <= 16 && a->sq > 64) p.tail_qb = a->sq / 64;
+    static const int tail_wg = getenv("VLASER_ATTN_TAIL_WG") ? atoi(getenv("VLASER_ATTN_TAIL_WG")) : 0;                     // A/B: the tail rows in workgroups of their own (first r04 form)
+    if (p.tail_qb >= 0 && !tail_wg && tk == 128) p.tail_host = 1;          // the one-round grids (tk == 128 <=> <= 512 workgroups); larger grids keep the tail workgroups
   }
   static const int dbg_attn = getenv("VLASER_ATTN_DEBUG") ? 1 : 0;
   if (dbg_attn) fprintf(stderr, "attn_prefill: sq %d kv %d hd %d mode %d blocks %ld ks %d tk %d tail_key0 %d tail_qb %d\n", a->sq, a->kv_len, a->head_dim, a->mode, blocks, ks, tk, p.tail_key0, p.tail_qb);
@@ -641,9 +682,14 @@ extern "C" int vlaser_attn_prefill(const VlaserAttnArgs* a, vl_stream_t s) {
     constexpr int tailm = 4 * KS_ * (32 + 16 * HD_) * 4;                                                                    \
     constexpr int lds0 = KS_ * tile > merge ? KS_ * tile : merge;                                                           \
     constexpr int lds = lds0 > tailm ? lds0 : tailm;                                                                        \
-    if (p.tail_key0 >= 0 || p.tail_qb >= 0) {                                                                               \
+    if (p.tail_host) {                                                                                                      \
+      if constexpr (HD_ == 64 && KS_ == 1 && TK_ == 128) {                                                                  \
+        if (int rc = set_max_lds_once(attn_prefill_kernel<HD_, KS_, TK_, true, true>, lds)) return rc;                      \
+        hipLaunchKernelGGL((attn_prefill_kernel<HD_, KS_, TK_, true, true>), dim3((grid.x - 1) * grid.y, 1, grid.z), dim3(256 * KS_), lds, stream, p); \
+      }                                                                                                                     \
+    } else if (p.tail_key0 >= 0 || p.tail_qb >= 0) {                                                                        \
       if (int rc = set_max_lds_once(attn_prefill_kernel<HD_, KS_, TK_, true>, lds)) return rc;                              \
-      const dim3 tgrid = p.tail_qb >= 0 ? dim3(grid.x * grid.y, 1, grid.z) : grid;                                          \
+      const dim3 tgrid = p.tail_qb >= 0 ? dim3(grid.x * grid.y, 1, grid.z) : grid;                                                               \
       hipLaunchKernelGGL((attn_prefill_kernel<HD_, KS_, TK_, true>), tgrid, dim3(256 * KS_), lds, stream, p);               \
     } else {                                                                                                                \
       if (int rc = set_max_lds_once(attn_prefill_kernel<HD_, KS_, TK_>, lds)) return rc;                                    \
