@@ -689,6 +689,11 @@ static int launch_ns(const VlaserSkinnyArgs* a, hipStream_t stream) {
   int gx = 256 / a->k_splits;            // <= one block per CU (256 CUs)
   if (gx > n_units) gx = n_units;
   if (gx < 1) gx = 1;
+  // r04: the FEWEST workgroups that keep the longest run as short as 256 would: the launch lasts as long as its longest workgroup, and the workgroups that
+  // would have finished a unit early only add start spread and contention for the ones still streaming (expert gate/up: 560 units -> 187 x 3 instead of
+  // 48 x 3 + 208 x 2: 12.87 -> 12.77 ms per chunk; 170 x 3.3 and 280 x 2 on 256 CUs are both slower).  Same units, same arithmetic: bit-identical outputs.
+  static const int gx_full = getenv("VLASER_SKINNY_GX_FULL") ? atoi(getenv("VLASER_SKINNY_GX_FULL")) : 0;                   // A/B: 1 = the r03 grid
+  if (!gx_full) { const int longest = (n_units + gx - 1) / gx; gx = (n_units + longest - 1) / longest; }
   p.ulo = n_units / gx;
   p.urem = n_units % gx;
   p.attn_nkv = PRO == VL_PRO_ATTN ? a->K / (128 * a->attn_group) : 0;
