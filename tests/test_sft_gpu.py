@@ -389,7 +389,8 @@ def test_sumsq_chunks_and_rows():
 def test_step_norm_from_producers_matches_buffer_norm(setup, monkeypatch):
     """r04: on one rank with one sample per step the gradient norm is assembled from the weight-gradient GEMM epilogues, the touched embedding rows and
     a chunk pass over the small tensors instead of re-reading the gradient buffer.  Same step with VLASER_SFT_NO_FUSED_NORM=1 (the buffer pass): the
-    norms agree to fp32 summation order, the updated parameters to the clip factor's last bit; the producer path is deterministic."""
+    norms agree to fp32 summation order -- checked at every step against the buffer norm of the SAME gradients, and across the two runs on the first step --, the
+    updated parameters to what the clip factor's last bit can move; the producer path is deterministic."""
     from vlaser_amd.sft import SFTModel
     cfg, sd, _, pv, ids, labels, _ = setup
 
@@ -397,7 +398,12 @@ def test_step_norm_from_producers_matches_buffer_norm(setup, monkeypatch):
         monkeypatch.setenv('VLASER_SFT_NO_FUSED_NORM', '0' if fused else '1')
         m = SFTModel(cfg, max_seq_len=ids.shape[1], lr=1e-3, weight_decay=0.05, max_grad_norm=1.0)
         m.load_state_dict(sd)
-        outs = [m.step(pv, ids, labels) for _ in range(3)]
+        outs = []
+        for _ in range(3):
+            outs.append(m.step(pv, ids, labels))
+            # the same gradients, summed from the buffer: the producers' slots must account for every element (any trajectory, every step)
+            buf = torch.linalg.vector_norm(m.fp.g.float()).item()
+            assert abs(outs[-1].grad_norm.item() - buf) <= 2e-5 * buf, (fused, outs[-1].grad_norm.item(), buf)
         m.wait_optimizer()
         assert (getattr(m, 'norm_parts', None) is not None) == fused
         return [o.grad_norm.item() for o in outs], [o.loss.item() for o in outs], {k: v.clone() for k, v in m.state_dict().items()}
@@ -407,11 +413,15 @@ def test_step_norm_from_producers_matches_buffer_norm(setup, monkeypatch):
     nc, lc, pc = run(True)
     assert na == nc and la == lc and all(torch.equal(pa[k], pc[k]) for k in pa), 'the producer-side norm is not deterministic'
     assert la[0] == lb[0]
-    for a, b in zip(na, nb):
-        assert abs(a - b) <= 2e-5 * b, (na, nb)
+    assert abs(na[0] - nb[0]) <= 2e-5 * nb[0], (na, nb)
+    # later steps: the two runs' clip factors may differ in their last bit, which the lr = 1e-3 steps of this test amplify (a few hundred bf16 parameters round the
+    # other way; measured 3e-4 on the second step's norm) -- the per-step buffer check above is the exact statement, this one only bounds the drift
+    for a, b in zip(na[1:], nb[1:]):
+        assert abs(a - b) <= 5e-3 * b, (na, nb)
     for k in pa:
         d = (pa[k].float() - pb[k].float()).abs().max().item()
-        assert d <= 2e-2 * pb[k].float().abs().max().item() + 1e-6, (k, d)
+        # steps 2 and 3 of the two trajectories may move an element with a near-zero gradient in opposite directions: <= 2 lr per step
+        assert d <= 2 * 2 * 1e-3 + 2e-2 * pb[k].float().abs().max().item(), (k, d)
 
 
 def test_gemm_tn_lds_ragged_output_rows():
@@ -560,6 +570,23 @@ def test_checkpoint_resume_is_bit_identical(golden_model, tmp_path):
     c.step(pvs[2], rows[2][None], labs[2][None], total_steps=10)
     a.wait_optimizer(); c.wait_optimizer()          # the last AdamW is still in flight on the optimizer stream
     assert torch.equal(a.fp.p, c.fp.p) and torch.equal(a.master, c.master) and torch.equal(a.m, c.m) and torch.equal(a.v, c.v)
+
+
+@pytest.mark.parametrize('S,C,mode', [(256, 4096, 3), (37, 1024, 3), (50, 100, 3), (20, 8192, 3), (256, 4096, 2), (33, 100, 2)])
+def test_colsum_mul_norm_weight_grad(ops, S, C, mode):
+    """vlaser_colsum_mul modes 2 / 3 (RMSNorm / LayerNorm weight gradient: sum_s dy * normalised x, row statistics by `rowstat_kernel`) against fp32 autograd -- the
+    projector's LayerNorm(4096) of modeling_internvl_chat.py:72-77 and widths that take the kernel's register-resident (C <= 4096, C % 8 == 0) and fallback paths"""
+    g = torch.Generator().manual_seed(S * C + mode)
+    x = (torch.randn(S, C, generator=g) * 1.5 + 0.3).to(BF).cuda(); dy = torch.randn(S, C, generator=g).to(BF).cuda()
+    col = torch.zeros(C, device='cuda'); ws = torch.zeros(2 * S + 16 * C, device='cuda')
+    ops.colsum_mul(dy, x, col, S, C, mode, 1e-6, ws)
+    xf = x.float()
+    if mode == 3:
+        xn = (xf - xf.mean(-1, keepdim=True)) * torch.rsqrt(xf.var(-1, unbiased=False, keepdim=True) + 1e-6)
+    else:
+        xn = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)
+    ref = (dy.float() * xn).sum(0)
+    assert float((col - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-4
 
 
 @pytest.mark.parametrize('V,ld,off', [(151674, 151674, 0), (1001, 1001, 0), (1000, 1003, 1), (8195, 8200, 0), (7, 7, 0)])
