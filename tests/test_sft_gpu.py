@@ -325,6 +325,41 @@ def test_rmsnorm_bwd_from_split_k_slabs():
         assert torch.equal(dx_a, dx_b)
 
 
+_RB_SCRIPT = """
+import hashlib, sys, torch
+sys.path.insert(0, %r)
+from vlaser_amd import ops
+BF = torch.bfloat16
+g = torch.Generator().manual_seed(33)
+h = hashlib.sha256()
+for S, C, n in ((561, 1536, 3), (70, 4096, 0), (130, 1024, 2), (9, 3584, 0), (33, 2048, 5), (64, 512, 1)):
+    slabs = (torch.randn(max(n, 1), S, C, generator=g) * 0.3).cuda()
+    x = torch.randn(S, C, generator=g).to(BF).cuda(); w = (1 + 0.1 * torch.randn(C, generator=g)).to(BF).cuda(); dres = torch.randn(S, C, generator=g).to(BF).cuda()
+    dy = torch.randn(S, C, generator=g).to(BF).cuda()
+    ws = torch.zeros(((S + 3) // 4) * C, device='cuda'); dx = torch.empty_like(dy); dw = torch.empty(C, dtype=BF, device='cuda')
+    if n:
+        ops.rmsnorm_bwd(None, x, w, dres, dx, S, C, 1e-6, dw_out=dw, dw_ws=ws, dy_partials=slabs, n_partials=n)
+    else:
+        ops.rmsnorm_bwd(dy, x, w, dres, dx, S, C, 1e-6, dw_out=dw, dw_ws=ws)
+    h.update(dx.view(torch.int16).cpu().numpy().tobytes()); h.update(dw.view(torch.int16).cpu().numpy().tobytes())
+print('SHA', h.hexdigest())
+"""
+
+
+def test_rmsnorm_bwd_register_kernel_bit_identical_to_loops():
+    """r04: the register-resident vlaser_rmsnorm_bwd (C = 512 * n, one load round trip) writes the same bits as the chunk-loop kernel it replaces
+    (VLASER_RMSNORM_BWD_LOOPS=1, read once per process: two child processes): dx and the norm-weight gradient, bf16 dy and split-K slabs, C = 512 .. 4096."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for loops in ('0', '1'):
+        env = dict(os.environ, VLASER_RMSNORM_BWD_LOOPS=loops)
+        r = subprocess.run([sys.executable, '-c', _RB_SCRIPT % root], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith('SHA')][0])
+    assert outs[0] == outs[1], outs
+
+
 @pytest.mark.parametrize('K,M,N,cfg,lds', [(576, 1536, 2048, 0, True), (576, 17920, 1536, 0, True), (320, 1000, 520, 1300, True), (64, 136, 264, 1105, True),
                                            (128, 2048, 1536, 1200, True), (576, 17920, 1536, 1340, True), (320, 1000, 520, 1240, True), (100, 304, 200, 0, False), (200, 1000, 1528, 0, False)])
 def test_gemm_tn_sumsq_slots(K, M, N, cfg, lds):

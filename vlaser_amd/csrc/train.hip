@@ -291,6 +291,82 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
       dw_partial[(size_t)blockIdx.x * C + c] = dw_lds[c] + dw_lds[C + c] + dw_lds[2 * C + c] + dw_lds[3 * C + c];
   }
 }
+// r04, C = 512 * NCH (NCH <= 8): the row lives in registers -- x, w, dres and dy (or the slabs, NCH x 2 loads per slab in flight) are requested up front and the second
+// pass reads nothing: ONE load round trip (+ one per slab) instead of six (the loops above wait for each chunk's loads in turn: 12 us per launch at S = 560, C = 1536,
+// 72 launches per SFT step).  Same operations in the same order per lane: bit-identical to the kernel above.
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_reg_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                              const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, float* __restrict__ dw_partial,
+                                                              int S, float eps, const float* __restrict__ dy_part, int n_part) {
+  constexpr int C = 512 * NCH;
+  extern __shared__ float dw_lds[];            // [4][C] fp32 when dw_partial
+  const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6, row = blockIdx.x * 4 + wv_;
+  const bool live = row < S;
+  const size_t ro = (size_t)min(row, S - 1) * C;
+  u32x4 xv[NCH], wv[NCH], gv[NCH], rv[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane * 8 + i * 512;
+    xv[i] = ld_global_16(x + ro + c);
+    wv[i] = ld_global_16(w + c);
+    rv[i] = dres ? ld_global_16(dres + ro + c) : u32x4{0, 0, 0, 0};
+    if (!dy_part) gv[i] = ld_global_16(dy + ro + c);
+  }
+  if (dy_part) {
+    float v[NCH][8];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    const float* pp = dy_part + ro + lane * 8;
+    for (int u = 0; u < n_part; ++u, pp += (size_t)S * C) {
+      f32x4 q0[NCH], q1[NCH];
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) { q0[i] = *reinterpret_cast<const f32x4*>(pp + i * 512); q1[i] = *reinterpret_cast<const f32x4*>(pp + i * 512 + 4); }
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[i][j] += q0[i][j]; v[i][4 + j] += q1[i][j]; }
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      gv[i] = u32x4{pack_bf16x2(v[i][0], v[i][1]), pack_bf16x2(v[i][2], v[i][3]), pack_bf16x2(v[i][4], v[i][5]), pack_bf16x2(v[i][6], v[i][7])};
+  }
+  float ss = 0.f, dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x0 = bf16lo_to_f32(xv[i][j]), x1 = bf16hi_to_f32(xv[i][j]);
+      ss += x0 * x0 + x1 * x1;
+      dot += x0 * bf16lo_to_f32(gv[i][j]) * bf16lo_to_f32(wv[i][j]) + x1 * bf16hi_to_f32(gv[i][j]) * bf16hi_to_f32(wv[i][j]);
+    }
+  ss = wave_sum(ss);
+  dot = wave_sum(dot);
+  const float rs = rsqrtf(ss / (float)C + eps);
+  const float coef = dot * rs * rs * rs / (float)C;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane * 8 + i * 512;
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float lo = bf16lo_to_f32(rv[i][j]) + rs * bf16lo_to_f32(gv[i][j]) * bf16lo_to_f32(wv[i][j]) - coef * bf16lo_to_f32(xv[i][j]);
+      const float hi = bf16hi_to_f32(rv[i][j]) + rs * bf16hi_to_f32(gv[i][j]) * bf16hi_to_f32(wv[i][j]) - coef * bf16hi_to_f32(xv[i][j]);
+      o[j] = pack_bf16x2(lo, hi);
+      if (dw_partial) {
+        dw_lds[wv_ * C + c + 2 * j] = live ? bf16lo_to_f32(gv[i][j]) * bf16lo_to_f32(xv[i][j]) * rs : 0.f;
+        dw_lds[wv_ * C + c + 2 * j + 1] = live ? bf16hi_to_f32(gv[i][j]) * bf16hi_to_f32(xv[i][j]) * rs : 0.f;
+      }
+    }
+    if (live) st_global_16(dx + ro + c, o);
+  }
+  if (dw_partial) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+      dw_partial[(size_t)blockIdx.x * C + c] = dw_lds[c] + dw_lds[C + c] + dw_lds[2 * C + c] + dw_lds[3 * C + c];
+  }
+}
 // out[c] (bf16) = sum_p partial[p][c], fixed order.  64 columns x 4 row-slices per workgroup: slice q sums rows q, q+4, ... with all of
 // its loads independent (4 accumulators), the slices meet in LDS in a fixed order.  (One thread per column over the whole column,
 // C / 256 = 6 workgroups, took 12 us for the 140 x 1536 partials of a norm-weight gradient: a serial chain of 35 load batches.)
@@ -320,10 +396,22 @@ extern "C" int vlaser_rmsnorm_bwd(const void* dy, const void* x, const void* w, 
   VL_CHECK(!dw_out || dw_ws, "vlaser_rmsnorm_bwd: the weight gradient needs the [ceil(S/4)][C] fp32 workspace");
   VL_CHECK(!dw_ws || C * 16 <= 64 * 1024, "vlaser_rmsnorm_bwd: weight-gradient partials need C <= 4096");
   const int nb = (S + 3) / 4;
-  const size_t lds = (dw_ws ? (size_t)C * 16 : 0) + (dy_partials ? (size_t)C * 8 : 0);
+  static const int old_form = getenv("VLASER_RMSNORM_BWD_LOOPS") ? atoi(getenv("VLASER_RMSNORM_BWD_LOOPS")) : 0;          // A/B: 1 = the chunk loops
+  const int nch = (C % 512 == 0 && C / 512 <= 8 && !old_form) ? C / 512 : 0;
+  const size_t lds = (dw_ws ? (size_t)C * 16 : 0) + (dy_partials && !nch ? (size_t)C * 8 : 0);       // (the register kernel keeps the reduced dy row in registers)
   VL_CHECK(lds <= 64 * 1024, "vlaser_rmsnorm_bwd: C = %d too wide", C);
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nb), dim3(256), lds, (hipStream_t)s, (const bf16_t*)dy, (const bf16_t*)x,
-                     (const bf16_t*)w, (const bf16_t*)dres, (bf16_t*)dx, dw_ws, S, C, eps, dy_partials, dy_partials ? n_partials : 0);
+#define VL_RB_CASE(N_)                                                                                                                                    \
+  case N_:                                                                                                                                                \
+    hipLaunchKernelGGL(rmsnorm_bwd_reg_kernel<N_>, dim3(nb), dim3(256), dw_ws ? (size_t)C * 16 : 0, (hipStream_t)s, (const bf16_t*)dy, (const bf16_t*)x,  \
+                       (const bf16_t*)w, (const bf16_t*)dres, (bf16_t*)dx, dw_ws, S, eps, dy_partials, dy_partials ? n_partials : 0);                    \
+    break;
+  switch (nch) {
+    VL_RB_CASE(1) VL_RB_CASE(2) VL_RB_CASE(3) VL_RB_CASE(4) VL_RB_CASE(5) VL_RB_CASE(6) VL_RB_CASE(7) VL_RB_CASE(8)
+    default:
+      hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nb), dim3(256), lds, (hipStream_t)s, (const bf16_t*)dy, (const bf16_t*)x,
+                         (const bf16_t*)w, (const bf16_t*)dres, (bf16_t*)dx, dw_ws, S, C, eps, dy_partials, dy_partials ? n_partials : 0);
+  }
+#undef VL_RB_CASE
   if (dw_out) hipLaunchKernelGGL(colsum_partials_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)s, dw_ws, nb, C, (bf16_t*)dw_out);
   VL_LAUNCH_CHECK();
   return 0;
