@@ -318,10 +318,16 @@ def main():
     del sd
     torch.cuda.empty_cache()
     ids, pv, proprio, noise = make_inputs(vla.base, 1, seed=rank)
-    # inputs resident in HBM before the timed region
+    # inputs resident in HBM before the timed region.  The timed call is the REFERENCE's call (pizero_internvl.py:798-808): the eight tensors exactly as
+    # Vlaser_VLA/Simpler/src/agent/eval.py:110-130 builds them per control step and moves them to the device -- dense image_text_proprio_mask / action_mask,
+    # three position-id tensors -- plus the explicit noise; the result is a fresh tensor per call, as the reference returns
     ids_d, pv_d, pro_d, noise_d = ids.to(dev), pv.to(dev).to(torch.bfloat16), proprio.to(dev), noise.to(dev)
     valid = (ids != vla.base.pad_token_id).sum(-1).to(dev)
-    call = lambda: model.infer_action(ids_d, pv_d, proprios=pro_d, noise=noise_d, valid_len=valid)
+    mask, vp, pp, ap = model.build_causal_mask_and_position_ids((ids != vla.base.pad_token_id).long(), torch.bfloat16)
+    m1, m2 = model.split_full_mask_into_submasks(mask)
+    m1_d, m2_d, vp_d, pp_d, ap_d = (t.to(dev) for t in (m1, m2, vp, pp, ap))
+    call = lambda: model.infer_action(ids_d, pv_d, m1_d, m2_d, vp_d, pp_d, ap_d, pro_d, noise=noise_d)
+    call_ext = lambda: model.infer_action(ids_d, pv_d, proprios=pro_d, noise=noise_d, valid_len=valid)      # the `valid_len=` extension (no dense masks)
 
     for _ in range(max(a.warmup, 1)):
         out = call()
@@ -342,9 +348,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     assert torch.isfinite(out).all()
+    model.check_errors()                                             # the device-side mask check of every timed call came back clean
+
+    def _time_calls(fn, n):
+        fn(); torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        for _ in range(n):
+            o_ = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0_) / n * 1e3, o_
 
     line = None
     if rank == 0:
+        # side timings of the same chunk through the two other call forms (never `value`): the valid_len extension with a fresh result, and with the
+        # zero-copy result ring switched on (output_ring = 4: a view that is overwritten four calls later)
+        ext_ms, out_ext = _time_calls(call_ext, a.steps)
+        model.output_ring = 4
+        ring_ms, _ = _time_calls(call_ext, a.steps)
+        model.output_ring = 0
+        assert torch.equal(out_ext, out)
         line = {
             'metric': 'action_chunks_per_sec', 'value': round(world * a.steps / dt, 3), 'unit': 'action-chunks/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 4),
@@ -352,9 +374,15 @@ def main():
             'config': {'workload': 'Vlaser-2B-VLA action-chunk inference: 1x448px image, 384-token prompt (277 valid), '
                                    '7-DoF x 4-step chunk, 10 Euler steps, batch 1 per GPU (BASELINE configs[2])',
                        'parallelism': f'replicas x{world} (no collective)', 'weights': 'random-init, true architecture',
+                       'call': 'reference signature: infer_action(input_ids, pixel_values, image_text_proprio_mask, action_mask, vlm / proprio / action position ids, '
+                               'proprios) + noise, all on the device (eval.py:110-130); fresh result tensor per call',
                        'reference_mode': 'use_bf16=True (bf16 storage / fp32 accumulate: the mode the reference trains in, slurm/train_internvl.sh:35; its shipped eval '
                                          'config runs fp32, bridge_internvl_448.yaml:36)'},
         }
+        line['reference_signature'] = {'ms_per_chunk': round(dt / a.steps * 1e3, 4), 'is_headline': True,
+                                       'valid_len_extension_ms': round(ext_ms, 4), 'valid_len_extension_output_ring4_ms': round(ring_ms, 4),
+                                       'note': 'the dense masks are checked and valid_len counted ON the device by the one staging launch (vlaser_vla_stage, ABI 6); '
+                                               'no host copy, no sync inside the call'}
         if not a.no_roofline:
             iso_ms, byts, n_iso = _probe(model)
             phases, inchain_us, n = _phases(model)

@@ -116,6 +116,7 @@ typedef struct {
   int first_tok_kv_len;         /* > 0: query token 0 of each batch element sees the block keys [blk_start, first_tok_kv_len) only -- the
                                    proprio row riding in front of the action rows (pizero_internvl.py:517-587: proprio sees prefix + self) */
   float* lse_out;               /* vlaser_attn_prefill, optional (ABI 4): fp32 [B, n_q_heads, sq] base-2 log-sum-exp of the scaled scores, kept for vlaser_attn_bwd */
+  unsigned long long* dbg;      /* vlaser_attn_skinny, optional (ABI 6): per-workgroup timestamps [grid][8] (wall_clock64, 100 MHz) for kernel tuning */
 } VlaserAttnArgs;
 
 int vlaser_attn_prefill(const VlaserAttnArgs* args, vl_stream_t stream);
@@ -162,6 +163,24 @@ typedef struct {
 } VlaserSkinnyArgs;
 
 int vlaser_skinny(int prologue, int epi, const VlaserSkinnyArgs* args, vl_stream_t stream);
+
+/* ---- (ABI 6, r05) the <= 16-row layer-step chain rebuilt for latency (csrc/chain.hip): same call sites as vlaser_skinny -- joint_model.py:140-232 with only the
+ * action mixture active (10 Euler steps x 28 layers), HF Qwen2DecoderLayer under greedy decode -- with every shape a compile-time parameter, every load of a launch
+ * issued in one straight-line block, and the down projection publishing the next layer's residual stream ONCE (bf16) instead of fp32 split-K slabs that every
+ * consumer workgroup re-reduces.  All three take device pointers, are asynchronous on `stream`, return 0 / negative like everything else here.
+ *   vlaser_chain_qkv : args as vlaser_skinny(VL_PRO_NORM, VL_SK_QKV_ROPE) with tiles_per_unit = 1, n_partials = 0 (x = the published residual stream): one wave per 16-row
+ *                      unit, RMSNorm + q/k/v GEMV + bias + RoPE + KV-cache scatter;  hidden 768 / 1536
+ *   vlaser_chain_gu  : args as vlaser_skinny(VL_PRO_NORM, VL_SK_SWIGLU) with tiles_per_unit = 2 and 2 or 3 producer slabs: bit-identical outputs, all units of a workgroup
+ *                      requested up front; h_out (nullable) = bf16(x + sum partials), the residual vlaser_chain_down adds back
+ *   vlaser_chain_down: h_out [M, N] = bf16(res + x [M, K] @ W^T), W = down_proj.weight packed by ops.pack_down4 ([N/4][7 waves][10 loads][64 lanes][8]): a workgroup
+ *                      owns 4 output columns over the whole K = 8960 (no cross-workgroup split-K); res != h_out
+ * *_supported(...) != 0 tells the host surface whether a geometry has a variant (it keeps vlaser_skinny otherwise). */
+int vlaser_chain_qkv_supported(int M, int N, int K);
+int vlaser_chain_gu_supported(int M, int N, int K, int n_partials);
+int vlaser_chain_down_supported(int M, int N, int K);
+int vlaser_chain_qkv(const VlaserSkinnyArgs* args, vl_stream_t stream);
+int vlaser_chain_gu(const VlaserSkinnyArgs* args, vl_stream_t stream);
+int vlaser_chain_down(const void* x, int ldx, const void* W, const void* res, void* h_out, int M, int N, int K, unsigned long long* dbg, vl_stream_t stream);
 
 /* The two fused layer-step launches measured in r03 / r04 (vlaser_fused_ogu: o_proj -> gate/up with an in-launch hand-off, +2.0 us in-chain;
  * vlaser_attn_oproj: attention + o_proj in one launch, break-even) are NOT on the default path: include/vlaser_hip_experimental.h. */
@@ -219,15 +238,26 @@ int vlaser_argmax(const float* logits, int M, int N, int64_t* out_id, const void
  * (pizero_internvl.py:823); final norm + action_decoder + Euler update (+clamp) (pizero_internvl.py:911-932). */
 int vlaser_vla_prep(const float* action, const void* w1, const void* b1, void* xcat, int M, int W, int adim, float t, float max_period, vl_stream_t stream);
 int vlaser_small_linear(const float* x, const void* w, const void* b, void* out, int M, int N, int K, vl_stream_t stream);
-/* (ABI 5) ring (nullable): the updated actions are ALSO written to slot (*ring_ctr mod ring_n) of `ring` (ring_stride floats per slot), so that the host
- * surface can hand out a view of the result instead of launching a copy (the reference returns a fresh tensor: pizero_internvl.py:934-936). */
+/* (ABI 5) ring (nullable): the updated actions are ALSO written to slot (ring_ctr[0] mod ring_n) of `ring` (ring_stride floats per slot), so that the host
+ * surface can hand out a view of the result instead of launching a copy (the reference returns a fresh tensor: pizero_internvl.py:934-936).
+ * (ABI 6) ring_ctr = int32[3] = VlaserVlaStageArgs.call_ctr: {call number k, error word of even calls, error word of odd calls}; when this call's error word
+ * (ring_ctr[1 + (k & 1)]) is non-zero the ring copy is NaN: a dense mask the kernels cannot honour is never served silently. */
 int vlaser_vla_euler(const void* h_in, const float* partials, int n_partials, int M, const void* norm_w, float eps, const void* wd,
                      const void* bd, float* action, int W, int adim, float dt, float clip, int do_clip, float* vel_out, float* ring, const int* ring_ctr,
                      int ring_n, int ring_stride, vl_stream_t stream);
 /* (ABI 5) Every per-call input of PiZero.infer_action (pizero_internvl.py:798-808: input_ids, pixel_values, proprios; :879-881 the noise the reference
  * draws inside) into the static input slots of the captured chunk graph in ONE launch: ids int64 [B, T] copied; valid_out[b] = valid_in[b] (int32, or int64
  * when valid_is_i64) or, with valid_in null, the number of ids != pad_id in row b; proprio / noise fp32 copied; pixels -> bf16 (pix_dtype 0: bf16 copy,
- * 1: fp32 cast, 2: uint8 planar [n,3,H,W] normalised as vlaser_normalize_u8 mode 0 with mean / std, hw = H*W); *call_ctr += 1 (nullable). */
+ * 1: fp32 cast, 2: uint8 planar [n,3,H,W] normalised as vlaser_normalize_u8 mode 0 with mean / std, hw = H*W).
+ * (ABI 6) The reference's other five call tensors, exactly as Vlaser_VLA/Simpler/src/agent/eval.py:110-128 builds them per control step and moves them to the
+ * device, are consumed ON the device -- no host copy of a mask, no synchronisation inside the call:
+ *   itp_mask [B,1,T+1,T+1] / action_mask [B,1,n_act,T+1+n_act] (additive, 0 or dtype-min; pizero_internvl.py:517-603): with valid_in null, valid_out[b] = zero
+ *   count of the proprio row over the T image / text columns; every row that matters (valid prefix rows, proprio row, action rows) is compared with the
+ *   prefix + trailing-block pattern that (valid_len, blk_start) descriptors express; a mismatch ORs bits into this call's error word: 1 = the valid prefix is
+ *   not contiguous, 2 = another image_text_proprio_mask row, 4 = an action_mask row (the reference feeds action_mask to every Euler step, :894-896);
+ *   pos_vlm / pos_pro / pos_act int64 [B,T] / [B,1] / [B,n_act] -> the int32 position slots of the graph (+ pos_ride_out = [proprio | action], batch 1);
+ *   call_ctr int32[3] = {call number, error word of even calls, error word of odd calls}: call_ctr[0] = call_no (given by the HOST, which advances it only
+ *   after the launch was accepted), this call's word is call_ctr[1 + (call_no & 1)], the next call's word is cleared. */
 typedef struct {
   const int64_t* ids; int64_t* ids_out; int B, T; long long pad_id;
   const void* valid_in; int valid_is_i64; int32_t* valid_out;
@@ -235,6 +265,12 @@ typedef struct {
   const float* noise; float* noise_out; int n_noise;
   const void* pix; void* pix_out; long long n_pix; int pix_dtype; int hw; float mean[3]; float std[3];
   int* call_ctr;
+  /* ABI 6 */
+  int call_no;
+  const void* itp_mask; const void* action_mask; int mask_dtype /* 0 bf16, 1 f32, 2 f16 */; int n_act;
+  const int64_t* pos_vlm; const int64_t* pos_pro; const int64_t* pos_act;
+  int32_t* pos_vlm_out; int32_t* pos_pro_out; int32_t* pos_act_out; int32_t* pos_ride_out;
+  long long itp_bs, itp_rs, act_bs, act_rs;   /* element strides of the masks' batch / row axes (0 = dense): split_full_mask_into_submasks (:589-603) returns slices of the full mask */
 } VlaserVlaStageArgs;
 int vlaser_vla_stage(const VlaserVlaStageArgs* args, vl_stream_t stream);
 /* (ABI 4) Everything between two passes through the expert's layers in ONE launch: [finish != 0: the tail of the previous Euler step exactly as

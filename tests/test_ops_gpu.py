@@ -410,17 +410,15 @@ def test_skinny_norm_swiglu(ops, M, H, I, npart):
     g, u = rnd(I, H, std=0.03, seed=1), rnd(I, H, std=0.03, seed=2)
     W = ops.pack_gate_up(g, u)
     out = torch.zeros(M, I, dtype=BF, device='cuda'); h_out = torch.zeros(M, H, dtype=BF, device='cuda')
-    if H == 768:      # 96-row units (tiles_per_unit = 6) must give the same result
-        out6 = torch.zeros(M, I, dtype=BF, device='cuda')
-        ops.skinny(L.PRO_NORM, L.SK_SWIGLU, h, ops.pack_skinny(W, 1, 6), M, partials=parts, n_partials=npart, norm_w=nw, out=out6, ldo=I)
+    if H == 768:      # 96-row units (tiles_per_unit = 6; slower, and the only skinny variant that spilled) are refused since r05
+        with pytest.raises(L.VlaserHipError, match='tiles_per_unit'):
+            ops.skinny(L.PRO_NORM, L.SK_SWIGLU, h, ops.pack_skinny(W, 1, 6), M, partials=parts, n_partials=npart, norm_w=nw, out=out, ldo=I)
     ops.skinny(L.PRO_NORM, L.SK_SWIGLU, h, ops.pack_skinny(W), M, partials=parts, n_partials=npart, norm_w=nw, h_out=h_out, out=out, ldo=I)
     hs = (h.float() + (parts[:npart].sum(0) if npart else 0)).to(BF)
     assert torch.equal(h_out, hs) or (h_out.float() - hs.float()).abs().max() <= 2 ** -7 * hs.float().abs().max()
     xn = _rms_ref(h_out, nw).to(BF).float()
     gr = (xn @ g.float().t()).to(BF).float(); ur = (xn @ u.float().t()).to(BF).float()
     close(out, F.silu(gr).to(BF).float() * ur, name='norm swiglu')
-    if H == 768:
-        assert torch.equal(out6, out)
     if H in (768, 1536):      # 16-row lane-local units (tiles_per_unit = 1, r03): same K order per output -> bit-identical
         out16 = torch.zeros(M, I, dtype=BF, device='cuda'); h16 = torch.zeros(M, H, dtype=BF, device='cuda')
         pw = ops.pack_skinny(ops.pack_gate_up8(g, u), 1, 1)
@@ -456,6 +454,105 @@ def test_skinny_norm_qkv_rope(ops):
     ops.skinny(L.PRO_NORM, L.SK_QKV_ROPE, h, ops.pack_skinny(W16, 1, 1), M, n_partials=0, norm_w=nw, bias=B16, q_out=q16, k_cache=kc16, vt_cache=vtc16,
                rope_cos=cos, rope_sin=sin, pos_ids=pos, n_q_heads=nq, n_kv_heads=nkv, s_max=smax, tok_per_batch=tok, slot_base=385)
     assert torch.equal(q16, q_out) and torch.equal(kc16, kc) and torch.equal(vtc16, vtc)
+
+
+@pytest.mark.parametrize('M,H,I,npart', [(4, 768, 8960, 3), (5, 768, 8960, 3), (1, 1536, 8960, 2), (8, 1536, 8960, 2), (16, 768, 8960, 3), (11, 768, 8960, 2), (3, 768, 5120, 3)])
+def test_chain_gu_bit_identical_to_skinny(ops, M, H, I, npart):
+    """r05 csrc/chain.hip: gate/up with every unit of the workgroup requested up front == skinny_kernel<NORM, SWIGLU> bit for bit (activations and the rounded residual
+    stream), for 1-3 chunks per thread and 2 / 3 units per workgroup; ten runs beside a second stream stay identical (race screen of the reordered loads)."""
+    from vlaser_amd import _lib as L
+    assert ops.chain_gu_supported(M, 2 * I, H, npart)
+    h, nw = rnd(M, H), (1 + 0.1 * rnd(H, seed=5).float()).to(BF)
+    parts = (torch.randn(npart, M, H, generator=torch.Generator().manual_seed(7)) * 0.3).cuda()
+    pw = ops.pack_skinny(ops.pack_gate_up(rnd(I, H, std=0.03, seed=1), rnd(I, H, std=0.03, seed=2)))
+    o0, h0 = torch.zeros(M, I, dtype=BF, device='cuda'), torch.zeros(M, H, dtype=BF, device='cuda')
+    ops.skinny(L.PRO_NORM, L.SK_SWIGLU, h, pw, M, partials=parts, n_partials=npart, norm_w=nw, h_out=h0, out=o0, ldo=I)
+    a, _ = ops.skinny_args(h, pw, M, partials=parts, n_partials=npart, norm_w=nw, h_out=None, out=None, ldo=I)
+    side = torch.cuda.Stream()
+    junk = torch.randn(4096, 4096, device='cuda')
+    for rep in range(10):
+        o1, h1 = torch.full((M, I), 7.0, dtype=BF, device='cuda'), torch.full((M, H), 7.0, dtype=BF, device='cuda')
+        a.out, a.h_out = o1.data_ptr(), h1.data_ptr()
+        with torch.cuda.stream(side):
+            junk @ junk
+        ops.launch_chain_gu(a)
+        assert torch.equal(o1, o0) and torch.equal(h1, h0), rep
+    torch.cuda.synchronize()
+    assert not ops.chain_gu_supported(M, 2 * I, 1024, npart) and not ops.chain_gu_supported(M, 2 * I, H, 5)
+
+
+@pytest.mark.parametrize('B,tok,H', [(1, 4, 768), (1, 5, 768), (2, 4, 768), (4, 4, 768), (1, 1, 1536), (8, 1, 1536)])
+def test_chain_qkv_vs_skinny_and_fp32(ops, B, tok, H):
+    """r05: one wave per 16-row q/k/v unit over the whole K (no LDS exchange between waves): q, K cache and V^T cache vs the fp32 reference and vs the 8-wave skinny
+    kernel (different fp32 summation order: bf16-level agreement), untouched cache slots stay untouched."""
+    from vlaser_amd import _lib as L
+    nq, nkv, smax = 12, 2, 448
+    M = B * tok
+    assert ops.chain_qkv_supported(M, (nq + 2 * nkv) * 128, H)
+    h, nw = rnd(M, H), (1 + 0.1 * rnd(H, seed=5).float()).to(BF)
+    qw, kw, vw = rnd(nq * 128, H, std=0.03, seed=1), rnd(nkv * 128, H, std=0.03, seed=2), rnd(nkv * 128, H, std=0.03, seed=3)
+    qb, kb, vb = rnd(nq * 128, std=0.3, seed=4), rnd(nkv * 128, std=0.3, seed=5), rnd(nkv * 128, std=0.3, seed=6)
+    W16, B16 = ops.pack_qkv16(qw, kw, vw, qb, kb, vb)
+    pw = ops.pack_skinny(W16, 1, 1)
+    cos, sin = ops.rope_table(64)
+    pos = (torch.arange(tok).repeat(B) + 2).int().cuda()
+    outs = []
+    for chain in (False, True):
+        q_out = torch.zeros(M, nq * 128, dtype=BF, device='cuda')
+        kc = torch.full((B, nkv, smax, 128), 3.0, dtype=BF, device='cuda'); vtc = torch.full((B, nkv, 128, smax), 3.0, dtype=BF, device='cuda')
+        a, keep = ops.skinny_args(h, pw, M, n_partials=0, norm_w=nw, bias=B16, q_out=q_out, k_cache=kc, vt_cache=vtc, rope_cos=cos, rope_sin=sin, pos_ids=pos,
+                                  n_q_heads=nq, n_kv_heads=nkv, s_max=smax, tok_per_batch=tok, slot_base=385)
+        (ops.launch_chain_qkv(a) if chain else ops.launch_skinny(L.PRO_NORM, L.SK_QKV_ROPE, a))
+        outs.append((q_out, kc, vtc))
+    xn = _rms_ref(h, nw).to(BF).float()
+    q = (xn @ qw.float().t() + qb.float()).to(BF).float().view(M, nq, 128)
+    k = (xn @ kw.float().t() + kb.float()).to(BF).float().view(M, nkv, 128)
+    v = (xn @ vw.float().t() + vb.float()).to(BF).float().view(M, nkv, 128)
+    q_out, kc, vtc = outs[1]
+    close(q_out.view(M, nq, 128), _rope_ref(q, pos), name='q')
+    close(kc[:, :, 385:385 + tok], _rope_ref(k, pos).view(B, tok, nkv, 128).permute(0, 2, 1, 3), name='k')
+    close(vtc[:, :, :, 385:385 + tok], v.view(B, tok, nkv, 128).permute(0, 2, 3, 1), name='vT')
+    assert float((kc[:, :, :385].float() - 3).abs().max()) == 0 and float((vtc[:, :, :, 385 + tok:].float() - 3).abs().max()) == 0
+    for a_, b_ in zip(outs[0], outs[1]):           # vs the 8-wave kernel: the same values up to the fp32 summation order
+        assert (a_.float() - b_.float()).abs().max().item() <= 2 ** -6 * max(1.0, b_.float().abs().max().item())
+    # slot_base < 0: the cache slot is the row's position id (graph-replayable decode)
+    kc2 = torch.zeros(B, nkv, smax, 128, dtype=BF, device='cuda'); vtc2 = torch.zeros(B, nkv, 128, smax, dtype=BF, device='cuda')
+    pos2 = (torch.arange(tok).repeat(B) + 100).int().cuda()
+    a, keep = ops.skinny_args(h, pw, M, n_partials=0, norm_w=nw, bias=B16, q_out=q_out, k_cache=kc2, vt_cache=vtc2, rope_cos=ops.rope_table(256)[0], rope_sin=ops.rope_table(256)[1],
+                              pos_ids=pos2, n_q_heads=nq, n_kv_heads=nkv, s_max=smax, tok_per_batch=tok, slot_base=-1)
+    ops.launch_chain_qkv(a)
+    close(kc2[:, :, 100:100 + tok], _rope_ref(k, pos2).view(B, tok, nkv, 128).permute(0, 2, 1, 3), name='k slot = position')
+    assert float(kc2[:, :, :100].float().abs().max()) == 0
+
+
+@pytest.mark.parametrize('M,N', [(4, 768), (5, 768), (1, 1536), (8, 1536), (16, 768), (13, 768), (3, 772)])
+def test_chain_down_vs_fp32(ops, M, N):
+    """r05: the down projection without cross-workgroup split-K (4 output columns per workgroup over the whole K = 8960, v_mfma_f32_4x4x4_16b_bf16) + residual ->
+    the bf16 residual stream: vs fp32, deterministic over ten runs beside a second stream, rows / columns outside [M, N] untouched."""
+    K = 8960
+    assert ops.chain_down_supported(M, N, K)
+    x, w, res = rnd(M, K, std=0.7), rnd(N, K, std=0.03, seed=1), rnd(M, N, std=1.5, seed=2)
+    w4 = ops.pack_down4(w)
+    ref = res.float() + x.float() @ w.float().t()
+    side = torch.cuda.Stream()
+    junk = torch.randn(4096, 4096, device='cuda')
+    first = None
+    for rep in range(10):
+        out = torch.full((M + 1, N), 9.0, dtype=BF, device='cuda')
+        with torch.cuda.stream(side):
+            junk @ junk
+        ops.chain_down(x, w4, res, out, M, N, K)
+        first = out.clone() if first is None else first
+        assert torch.equal(out, first), rep
+    torch.cuda.synchronize()
+    close(first[:M], ref, rtol=8e-3, atol=8e-3 * ref.abs().max().item(), name='down4')
+    assert float((first[M].float() - 9).abs().max()) == 0
+    # a strided activation buffer (the engine's [16, I] workspace) and the unsupported widths
+    xs = torch.zeros(16, K + 64, dtype=BF, device='cuda'); xs[:M, :K] = x
+    out2 = torch.zeros(M, N, dtype=BF, device='cuda')
+    ops.chain_down(xs, w4, res, out2, M, N, K)
+    assert torch.equal(out2, first[:M])
+    assert not ops.chain_down_supported(M, N, 18944) and not ops.chain_down_supported(17, N, K)
 
 
 def test_norms(ops):
@@ -784,25 +881,135 @@ def test_vla_stage_one_launch(ops):
     u8 = torch.randint(0, 256, (B, 3, 448, 448), generator=g, dtype=torch.uint8)
     u8[0, :, 0, :256] = torch.arange(256, dtype=torch.uint8)
     f32 = torch.randn(B, 3, 448, 448, generator=g)
-    ctr = torch.zeros(1, dtype=torch.int32, device='cuda')
+    ctr = torch.zeros(4, dtype=torch.int32, device='cuda')
+    k = 0
     for pix, want in ((u8, prep.vla_normalize_images(u8[:, None]).to(BF)), (f32, f32.to(BF)), (f32.to(BF), f32.to(BF))):
         for valid in (None, torch.tensor(lens, dtype=torch.int32), torch.tensor([5, 6, 7], dtype=torch.int64)):
             o_ids = torch.zeros(B + 1, T, dtype=torch.int64, device='cuda')
             o_valid = torch.full((B + 1,), -1, dtype=torch.int32, device='cuda')
             o_pro, o_nz = torch.zeros(B + 1, 7, device='cuda'), torch.zeros(16, 7, device='cuda')
             o_pix = torch.zeros(B + 1, 3, 448, 448, dtype=BF, device='cuda')
+            k += 1
             ops.vla_stage(ids.cuda(), o_ids, None if valid is None else valid.cuda(), o_valid, pro.cuda(), o_pro, nz.cuda(), o_nz, pix.cuda(), o_pix, pad,
-                          prep.VLA_MEAN, prep.VLA_STD, call_ctr=ctr)
+                          prep.VLA_MEAN, prep.VLA_STD, call_ctr=ctr, call_no=k)
             assert torch.equal(o_ids[:B].cpu(), ids) and int(o_ids[B].abs().sum()) == 0
             assert o_valid.cpu().tolist() == (lens if valid is None else valid.tolist()) + [-1]
             assert torch.equal(o_pro[:B].cpu(), pro) and torch.equal(o_nz[:B * 4].cpu(), nz) and float(o_nz[B * 4:].abs().sum()) == 0
             assert torch.equal(o_pix[:B].cpu(), want) and float(o_pix[B].float().abs().sum()) == 0
-    assert int(ctr) == 9
+    assert ctr.tolist() == [9, 0, 0, 0]
+    with pytest.raises(ValueError):            # slot capacities are checked by the wrapper (the C side never sees them)
+        ops.vla_stage(ids.cuda(), o_ids, None, o_valid, pro.cuda(), torch.zeros(2, 7, device='cuda'), nz.cuda(), o_nz, f32.cuda(), o_pix, pad, prep.VLA_MEAN, prep.VLA_STD)
+
+
+def test_vla_stage_reference_tensors(ops):
+    """r05 (ABI 6): the reference's dense masks and int64 position ids (eval.py:110-128) consumed by the staging launch on the device: valid_len = zero count of
+    the proprio row, positions converted into the int32 slots, masks of the supported pattern leave the error word 0 (fp32 / bf16 / fp16, dense or sliced out of
+    the full mask), and each kind of unsupported mask sets its bit -- in THIS call's word only."""
+    from vlaser_amd import prep
+    g = torch.Generator().manual_seed(6)
+    B, T, na, pad = 2, 384, 4, 151643
+    lens = [277, 31]
+    ids = torch.randint(0, 151643, (B, T), generator=g)
+    am = torch.zeros(B, T, dtype=torch.long)
+    for b, n in enumerate(lens):
+        ids[b, n:] = pad
+        am[b, :n] = 1
+    pro, nz = torch.rand(B, 7, generator=g).cuda(), torch.randn(B * na, 7, generator=g).cuda()
+    pix = torch.randn(B, 3, 448, 448, generator=g).to(BF).cuda()
+    ctr = torch.zeros(4, dtype=torch.int32, device='cuda')
+    slots = lambda: (torch.zeros(B, T, dtype=torch.int64, device='cuda'), torch.full((B,), -1, dtype=torch.int32, device='cuda'), torch.zeros(B, 7, device='cuda'),
+                     torch.zeros(16, 7, device='cuda'), torch.zeros(B, 3, 448, 448, dtype=BF, device='cuda'))
+    k = 0
+
+    def stage(m1, m2, valid=None, positions=None, pos_out=None):
+        nonlocal k
+        k += 1
+        o_ids, o_valid, o_pro, o_nz, o_pix = slots()
+        ops.vla_stage(ids.cuda(), o_ids, valid, o_valid, pro, o_pro, nz, o_nz, pix, o_pix, pad, prep.VLA_MEAN, prep.VLA_STD, call_ctr=ctr, call_no=k,
+                      masks=(m1, m2), n_act=na, positions=positions, pos_out=pos_out)
+        c = ctr.tolist()
+        assert c[0] == k and c[1 + ((k + 1) & 1)] == 0
+        return o_valid.tolist(), c[1 + (k & 1)]
+
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        full, vp, pp, ap = prep.build_causal_mask_and_position_ids(am, dt, T, 1, na)
+        m1, m2 = prep.split_full_mask_into_submasks(full, T, 1, na)
+        full_d = full.cuda()
+        m1v, m2v = prep.split_full_mask_into_submasks(full_d, T, 1, na)           # device-side slices: strided views, no copy
+        assert not m1v.is_contiguous()
+        for a, b_ in ((m1.contiguous().cuda(), m2.contiguous().cuda()), (m1v, m2v)):
+            assert stage(a, b_) == (lens, 0)
+            assert stage(a, b_, valid=torch.tensor(lens, dtype=torch.int32, device='cuda')) == (lens, 0)
+            assert stage(a, None) == (lens, 0) and stage(None, b_) == (lens, 0)      # one mask alone (valid_len from the ids when the proprio row is absent)
+        # positions: int64 -> int32 slots (+ the batch-1 [proprio | action] row is refused for B = 2)
+        pv_, pp_, pa_ = (torch.zeros(B, T, dtype=torch.int32, device='cuda'), torch.zeros(B, dtype=torch.int32, device='cuda'), torch.zeros(B * na, dtype=torch.int32, device='cuda'))
+        assert stage(m1v, m2v, positions=(vp.cuda() + 3, pp.cuda() + 5, ap.cuda() + 7), pos_out=(pv_, pp_, pa_, None)) == (lens, 0)
+        assert torch.equal(pv_.cpu().long(), vp + 3) and torch.equal(pp_.cpu().long().view(B, 1), pp + 5) and torch.equal(pa_.cpu().long().view(B, na), ap + 7)
+        lo = torch.finfo(dt).min
+        # (1) a hole in the valid prefix of the proprio row; (2) a prefix row that sees a padded key; (2) the proprio row blind to itself; (4) an action row that
+        # does not see an action token; (4) an action row that sees a padded key; a "don't care" row (padded position) may hold anything
+        cases = [(1, lambda a, b_: a[1, 0, T].__setitem__(7, lo)), (2, lambda a, b_: a[0, 0, 5].__setitem__(300, 0.0)), (2, lambda a, b_: a[0, 0, T].__setitem__(T, lo)),
+                 (4, lambda a, b_: b_[1, 0, 2].__setitem__(T + 2, lo)), (4, lambda a, b_: b_[0, 0, 0].__setitem__(350, 0.0)), (0, lambda a, b_: a[1, 0, 200, :].fill_(0.0))]
+        for bit, poke in cases:
+            a, b_ = m1.contiguous().clone(), m2.contiguous().clone()
+            poke(a, b_)
+            v, word = stage(a.cuda(), b_.cuda(), valid=torch.tensor(lens, dtype=torch.int64, device='cuda'))
+            assert word == bit, (dt, bit, word)
+        a = m1.contiguous().clone(); a[1, 0, T, 7] = lo                       # without a given valid_len the same hole shows as a non-contiguous prefix
+        v, word = stage(a.cuda(), m2.contiguous().cuda())
+        assert v == [lens[0], lens[1] - 1] and word & 1
+
+
+def test_infer_action_reference_signature(golden_model):
+    """The reference's 8-tensor call (pizero_internvl.py:798-808, built at eval.py:110-128) served without a host round trip: == the valid_len extension bit for
+    bit; a non-block `action_mask` and a non-prefix `image_text_proprio_mask` each give a NaN result and raise at the next poll (r04 ignored action_mask)."""
+    from vlaser_amd.pizero import PiZeroInference
+    cfg, vla, sd = golden_model
+    g = torch.Generator().manual_seed(13)
+    ids = torch.full((1, 384), cfg.pad_token_id)
+    ids[0, :10] = torch.randint(0, 151643, (10,), generator=g)
+    ids[0, 10:266] = cfg.img_context_token_id
+    ids[0, 266:277] = torch.randint(0, 151643, (11,), generator=g)
+    pv = torch.randn(1, 3, 448, 448, generator=g)
+    pro, noise = torch.rand(1, 1, 7, generator=g) * 2 - 1, torch.randn(1, 4, 7, generator=g)
+    m = PiZeroInference(vla, max_batch=1); m.load_state_dict(sd)
+    assert m.output_ring == 0
+    want = m.infer_action(ids, pv, proprios=pro, noise=noise, valid_len=torch.tensor([277]))
+    for dt in (torch.float32, torch.bfloat16):
+        mask, vp, pp, ap = m.build_causal_mask_and_position_ids((ids != cfg.pad_token_id).long(), dt)
+        m1, m2 = m.split_full_mask_into_submasks(mask)
+        dev = lambda t: t.to('cuda')                                      # eval.py:130: every tensor moved to the device
+        got = m.infer_action(dev(ids), dev(pv), dev(m1), dev(m2), dev(vp), dev(pp), dev(ap), dev(pro), noise=dev(noise))
+        assert got.data_ptr() != want.data_ptr() and torch.equal(got.cpu(), want.cpu())     # a fresh tensor per call, as the reference returns
+        m.check_errors()
+        bad2 = m2.clone(); bad2[0, 0, 1, 384 + 2] = torch.finfo(dt).min       # action token 1 blind to action token 1
+        out = m.infer_action(dev(ids), dev(pv), dev(m1), dev(bad2), dev(vp), dev(pp), dev(ap), dev(pro), noise=dev(noise))
+        assert torch.isnan(out).all()
+        with pytest.raises(ValueError, match='action_mask'):
+            m.check_errors()
+        bad1 = m1.clone(); bad1[0, 0, 384, 100] = torch.finfo(dt).min        # a hole in the prefix the proprio row sees
+        out = m.infer_action(dev(ids), dev(pv), dev(bad1), dev(m2), dev(vp), dev(pp), dev(ap), dev(pro), noise=dev(noise))
+        with pytest.raises(ValueError, match='image_text_proprio_mask'):     # ... also raised lazily, by the NEXT call
+            torch.cuda.synchronize()
+            m.infer_action(dev(ids), dev(pv), dev(m1), dev(m2), dev(vp), dev(pp), dev(ap), dev(pro), noise=dev(noise))
+        assert torch.isnan(out).all()
+        m.check_errors()                                                    # the call that raised was not run; nothing outstanding
+        again = m.infer_action(dev(ids), dev(pv), dev(m1), dev(m2), dev(vp), dev(pp), dev(ap), dev(pro), noise=dev(noise))
+        assert torch.equal(again.cpu(), want.cpu())
+    # custom positions reach the kernels (different result), the defaults come back when none are passed
+    other = m.infer_action(dev(ids), dev(pv), dev(m1), dev(m2), dev(vp) + 2, dev(pp), dev(ap) + 1, dev(pro), noise=dev(noise))
+    assert not torch.equal(other.cpu(), want.cpu())
+    assert torch.equal(m.infer_action(ids, pv, proprios=pro, noise=noise, valid_len=torch.tensor([277])).cpu(), want.cpu())
+    with pytest.raises(ValueError):
+        m.infer_action(ids, pv, proprios=torch.zeros(1, 1, 6), noise=noise)
+    with pytest.raises(ValueError):
+        m.infer_action(ids, pv, proprios=pro, noise=torch.zeros(1, 5, 7))
 
 
 def test_infer_action_output_ring(golden_model):
-    """infer_action returns a view of a result ring written by the chunk's last kernel (no clone launch): values == the clone path (output_ring=0), a result
-    stays intact for `output_ring` - 1 further calls, and device-resident inputs (one staging launch) == host inputs."""
+    """output_ring = n (opt-in): infer_action returns a view of a result ring written by the chunk's last kernel (no copy launch): values == the default
+    fresh-tensor path (output_ring = 0, what the reference returns), a result stays intact for n - 1 further calls, and device-resident inputs (one staging
+    launch) == host inputs."""
     from vlaser_amd.pizero import PiZeroInference
     cfg, vla, sd = golden_model
     g = torch.Generator().manual_seed(12)
@@ -815,8 +1022,7 @@ def test_infer_action_output_ring(golden_model):
     noises = [torch.randn(1, 4, 7, generator=g) for _ in range(5)]
     m0 = PiZeroInference(vla, max_batch=1, output_ring=0); m0.load_state_dict(sd)
     want = [m0.infer_action(ids, pv, proprios=pro, noise=n).cpu() for n in noises]
-    m = PiZeroInference(vla, max_batch=1); m.load_state_dict(sd)
-    assert m.output_ring == 4
+    m = PiZeroInference(vla, max_batch=1, output_ring=4); m.load_state_dict(sd)
     got = [m.infer_action(ids.cuda(), pv.cuda(), proprios=pro.cuda(), noise=n.cuda(), valid_len=torch.tensor([277], device='cuda')) for n in noises]
     torch.cuda.synchronize()
     for i in range(1, 5):                                   # the last four results are all still there

@@ -25,7 +25,7 @@ class AttnArgs(C.Structure):
                 ('k_bs', i64), ('k_hs', i64), ('vt_bs', i64), ('vt_hs', i64), ('o_bs', i64), ('o_ss', i64),
                 ('ld_vt', i32), ('scale', f32), ('mode', i32), ('causal_off', i32), ('valid_len', vp),
                 ('blk_start', i32), ('q_row_off', i32), ('part_m', vp), ('part_l', vp), ('part_o', vp), ('n_splits', i32),
-                ('first_tok_kv_len', i32), ('lse_out', vp)]
+                ('first_tok_kv_len', i32), ('lse_out', vp), ('dbg', vp)]
 
 
 class SkinnyArgs(C.Structure):
@@ -46,7 +46,9 @@ class FusedOguArgs(C.Structure):
 class VlaStageArgs(C.Structure):
     _fields_ = [('ids', vp), ('ids_out', vp), ('B', i32), ('T', i32), ('pad_id', i64), ('valid_in', vp), ('valid_is_i64', i32), ('valid_out', vp),
                 ('proprio', vp), ('proprio_out', vp), ('n_proprio', i32), ('noise', vp), ('noise_out', vp), ('n_noise', i32),
-                ('pix', vp), ('pix_out', vp), ('n_pix', i64), ('pix_dtype', i32), ('hw', i32), ('mean', f32 * 3), ('std', f32 * 3), ('call_ctr', vp)]
+                ('pix', vp), ('pix_out', vp), ('n_pix', i64), ('pix_dtype', i32), ('hw', i32), ('mean', f32 * 3), ('std', f32 * 3), ('call_ctr', vp),
+                ('call_no', i32), ('itp_mask', vp), ('action_mask', vp), ('mask_dtype', i32), ('n_act', i32), ('pos_vlm', vp), ('pos_pro', vp), ('pos_act', vp),
+                ('pos_vlm_out', vp), ('pos_pro_out', vp), ('pos_act_out', vp), ('pos_ride_out', vp), ('itp_bs', i64), ('itp_rs', i64), ('act_bs', i64), ('act_rs', i64)]
 
 
 FUSED_SYNC_WORDS, FUSED_SYNC_ERR = 160, 128
@@ -65,6 +67,12 @@ _SIGS = {
     'vlaser_attn_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, i32, vp],
     'vlaser_skinny': [i32, i32, C.POINTER(SkinnyArgs), vp],
     'vlaser_fused_ogu': [C.POINTER(FusedOguArgs), vp],
+    'vlaser_chain_qkv_supported': [i32, i32, i32],
+    'vlaser_chain_gu_supported': [i32, i32, i32, i32],
+    'vlaser_chain_down_supported': [i32, i32, i32],
+    'vlaser_chain_qkv': [C.POINTER(SkinnyArgs), vp],
+    'vlaser_chain_gu': [C.POINTER(SkinnyArgs), vp],
+    'vlaser_chain_down': [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp],
     'vlaser_layernorm': [vp, vp, vp, vp, i32, i32, f32, vp],
     'vlaser_rmsnorm': [vp, vp, vp, i32, i32, f32, vp],
     'vlaser_im2col': [vp, vp, i32, i32, i32, vp],

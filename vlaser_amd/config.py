@@ -81,6 +81,13 @@ class VLAConfig:
     time_max_period: float = 10000.0
     flow_sig_min: float = 0.001
     extra_action_tokens: int = 256           # '<a i>' tokens appended to the vocab (pizero_internvl.py:45-48,85)
+    integration_method: str = 'euler'        # pizero_internvl.py:164 (`cfg.get("integration_method", "euler")`); the eval YAML does not set it
+
+    def __post_init__(self):
+        # the reference also offers midpoint / rk4-style steps through integration_step (pizero_internvl.py:910-922,1309-1331); the captured chunk graph
+        # implements the forward-Euler update only -- refuse anything else instead of silently integrating differently
+        if self.integration_method != 'euler':
+            raise ValueError(f"integration_method={self.integration_method!r}: only 'euler' (the reference's default, pizero_internvl.py:164,910-912) is built")
 
     @property
     def expert(self) -> LLMConfig:

@@ -14,4 +14,4 @@ void vlaser_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* vlaser_last_error(void) { return g_err; }
-extern "C" int vlaser_abi_version(void) { return 5; }
+extern "C" int vlaser_abi_version(void) { return 6; }

@@ -475,6 +475,10 @@ __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int kvh = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+  // optional in-kernel timeline (tools/micro/chain_timeline.py): [0] start, [1] first chunk processed, [2] merge barrier passed, [3] end
+  unsigned long long* dbg = a.dbg ? a.dbg + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 : nullptr;
+#define STAMP(i) do { if (dbg && tid == 0) dbg[i] = wall_clock64(); } while (0)
+  STAMP(0);
   const int G = a.n_q_heads / a.n_kv_heads, nq = a.sq, nrows = G * nq;
   const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (size_t)b * a.k_bs + (size_t)kvh * a.k_hs;
   const bf16_t* VT = reinterpret_cast<const bf16_t*>(a.vt) + (size_t)b * a.vt_bs + (size_t)kvh * a.vt_hs;
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
   }
   int lim1 = a.kv_len, lo2 = 0x7fffffff, hi2 = 0;
   if (a.mode == VL_ATTN_PREFIX) {
-    lim1 = min(a.valid_len ? a.valid_len[b] : a.kv_len, a.kv_len);
+    lim1 = min(a.valid_len ? vl_sload_i32(a.valid_len + b) : a.kv_len, a.kv_len);      // scalar load: not in the vmcnt queue (see vl_sload_i32)
     lo2 = a.blk_start; hi2 = a.kv_len;
   }
   f32x4 o[2][DT];
@@ -590,6 +594,7 @@ __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
     const int ci0 = c_begin + wave;
     load_chunk(min(ci0, n_chunks - 1) << 5, kf, vf);          // n_chunks >= 1; the chunk's keys lie inside the padded cache row
     if (ci0 < c_end) process_chunk(ci0 << 5, kf, vf);
+    if (dbg) { asm volatile("" ::"v"(o[0][0][0])); STAMP(1); }
     for (int ci = ci0 + SKA_WAVES; ci < c_end; ci += SKA_WAVES) {
       load_chunk(ci << 5, kf, vf);
       process_chunk(ci << 5, kf, vf);
@@ -611,6 +616,7 @@ __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
   }
   }
   __syncthreads();
+  STAMP(2);
   {
     const size_t pidx = ((size_t)b * a.n_kv_heads + kvh) * a.n_splits + split;
     float* PM = a.part_m + pidx * 32;
@@ -643,6 +649,8 @@ __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
       for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<f32x4*>(PO + row * 128 + d0 + q4 * 4) = acc[q4];
     }
   }
+  STAMP(3);
+#undef STAMP
 }
 
 extern "C" int vlaser_attn_prefill(const VlaserAttnArgs* a, vl_stream_t s) {
@@ -688,9 +696,11 @@ extern "C" int vlaser_attn_prefill(const VlaserAttnArgs* a, vl_stream_t s) {
         hipLaunchKernelGGL((attn_prefill_kernel<HD_, KS_, TK_, true, true>), dim3((grid.x - 1) * grid.y, 1, grid.z), dim3(256 * KS_), lds, stream, p); \
       }                                                                                                                     \
     } else if (p.tail_key0 >= 0 || p.tail_qb >= 0) {                                                                        \
-      if (int rc = set_max_lds_once(attn_prefill_kernel<HD_, KS_, TK_, true>, lds)) return rc;                              \
-      const dim3 tgrid = p.tail_qb >= 0 ? dim3(grid.x * grid.y, 1, grid.z) : grid;                                                               \
-      hipLaunchKernelGGL((attn_prefill_kernel<HD_, KS_, TK_, true>), tgrid, dim3(256 * KS_), lds, stream, p);               \
+      if constexpr (KS_ == 1) {      /* tails are only set with ks == 1 (above): the 2-way key-split variant would spill (196 B of scratch) and is not built */ \
+        if (int rc = set_max_lds_once(attn_prefill_kernel<HD_, KS_, TK_, true>, lds)) return rc;                            \
+        const dim3 tgrid = p.tail_qb >= 0 ? dim3(grid.x * grid.y, 1, grid.z) : grid;                                        \
+        hipLaunchKernelGGL((attn_prefill_kernel<HD_, KS_, TK_, true>), tgrid, dim3(256 * KS_), lds, stream, p);             \
+      }                                                                                                                     \
     } else {                                                                                                                \
       if (int rc = set_max_lds_once(attn_prefill_kernel<HD_, KS_, TK_>, lds)) return rc;                                    \
       hipLaunchKernelGGL((attn_prefill_kernel<HD_, KS_, TK_>), grid, dim3(256 * KS_), lds, stream, p);                      \

@@ -1,0 +1,482 @@
+// The <= 16-row layer-step chain (action-expert Euler steps, greedy decode), round 5: three kernels rebuilt around what the in-chain, in-kernel
+// timeline showed (tools/micro/chain_timeline.py, profiles/r05a_chain_timeline.md): a dependent kernel boundary costs 1.4-1.6 us on this chip and a
+// dependent load -> store kernel 1.75 us (tools/micro/launch_floor.hip) -- the r01-r04 "4.9 us floor" of a short kernel was its own serial structure:
+//   * runtime-optional code paths (slab-count loops, second chunks, `if (ucount > u)` weight requests) make hipcc's waitcnt pass merge the worst case of
+//     every path: `s_waitcnt vmcnt(0)` in front of units 1 and 2 of the gate/up stream (three dependent HBM round trips instead of one), in front of
+//     the K / V^T requests of the attention, before the norm of every prologue;
+//   * every workgroup of a consumer re-reduced the producer's fp32 split-K slabs (66-98 KB through one CU's L1 = 0.7 us before the first FLOP).
+// Here every shape parameter is a template argument, every load of a kernel is issued in ONE straight-line block (small dependent data first, the
+// weight stream behind it: vmcnt retires in issue order), and the down projection publishes the residual stream ONCE, as bf16:
+//
+//   chain_qkv  : one WAVE per 16-row unit (no LDS exchange between waves, no barrier): RMSNorm of the published bf16 residual stream, q/k/v GEMV over the
+//                whole K, bias + RoPE + cache scatter (lane-local epilogue of skinny.hip's 16-row units; same packed weights)
+//   chain_gu   : residual + o_proj's split-K slabs + RMSNorm -> gate/up GEMV -> SwiGLU with ALL units of the workgroup requested up front; same
+//                arithmetic and summation order as skinny_kernel<NORM, SWIGLU> (bit-identical outputs)
+//   chain_down : down projection WITHOUT cross-workgroup split-K: a workgroup owns 4 output columns over the whole K (v_mfma_f32_4x4x4_16b_bf16: 16
+//                independent 4 x 4 x 4 blocks per instruction = 4 columns x 4 rows x 64 k), adds the residual and stores the next layer's bf16
+//                residual stream -- the consumer loads 6 KB instead of 66 KB and runs no slab reduction
+#include "common.h"
+#include "../../include/vlaser_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define CH_STAMP(i) do { if constexpr (DBG) { if (threadIdx.x == 0) dbg[i] = wall_clock64(); } } while (0)
+
+__device__ __forceinline__ int ch_fdiv(int x, float inv_d) { return (int)(((float)x + 0.5f) * inv_d); }
+
+// ------------------------------------------------------------------------------------------------------------------ gate / up
+struct ChainGuP {
+  const bf16_t* h_in; const float* partials; const bf16_t* norm_w; bf16_t* h_out;
+  const u32x4* W; bf16_t* out;
+  int M, ldo, ulo, urem, n_valid;
+  float eps, inv_cpr;
+  unsigned long long* dbg;
+};
+
+// NS = K / 256 (K-steps of 32 per wave), UE = units (32 packed rows = [gate16 | up16]) per workgroup, SP = split-K slabs of the producer, CPT = 16-byte chunks
+// of the [M, K] residual stream per thread (ceil(M * K / 8 / 512))
+template <int NS, int UE, int SP, int CPT, bool DBG>
+__global__ __launch_bounds__(512) void chain_gu_kernel(ChainGuP p) {
+  constexpr int K = NS * 256, cpr = K / 8, ngr = cpr / 16, gstride = (ngr + 3) & ~3, XS = K * 2 + 16, NF = 2 * NS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
+  unsigned long long* dbg = DBG ? p.dbg + (size_t)blockIdx.x * 8 : nullptr;
+  CH_STAMP(0);
+  const int M = p.M;
+  const int ucount = p.ulo + ((int)blockIdx.x < p.urem ? 1 : 0);
+  const int ustart = (int)blockIdx.x * p.ulo + min((int)blockIdx.x, p.urem);
+  const int xs_bytes = (M * XS + 15) & ~15;
+  char* xs = smem;
+  float* red = reinterpret_cast<float*>(smem + xs_bytes);      // [2][7][2][64] f32x4, double-buffered by unit parity; group sums [M][gstride] during the prologue
+  float* gs = red;
+  const int nch = M * cpr, slab = M * K;
+
+  // ---- every request of the kernel, in issue order: residual chunk(s), norm weight, the producer's slabs (L2), then the whole weight stream (HBM)
+  u32x4 hv[CPT], wv[CPT];
+  f32x4 q[CPT][SP > 0 ? 2 * SP : 1];
+  int mm[CPT], cc[CPT];
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    const int ch = min(c * 512 + tid, nch - 1);
+    mm[c] = ch_fdiv(ch, p.inv_cpr);
+    cc[c] = (ch - mm[c] * cpr) << 3;
+    const int off = mm[c] * K + cc[c];
+    hv[c] = ld_global_16(p.h_in + off);
+    wv[c] = ld_global_16(p.norm_w + cc[c]);
+#pragma unroll
+    for (int u = 0; u < SP; ++u) {
+      const float* pp = p.partials + (off + u * slab);
+      q[c][2 * u] = *reinterpret_cast<const f32x4*>(pp);
+      q[c][2 * u + 1] = *reinterpret_cast<const f32x4*>(pp + 4);
+    }
+  }
+  // (hipcc's scheduler moves loads freely -- it does not know that vmcnt retires in issue order: without the fences below it put the norm-weight chunk and two
+  //  fragments of unit 0 BEHIND units 1 and 2, so the norm and the first MFMAs waited for the whole stream)
+  __builtin_amdgcn_sched_barrier(0);
+  u32x4 w[UE][NF];
+  {
+    const u32x4* wp = p.W + (size_t)wave * (NF * 64) + lane;
+#pragma unroll
+    for (int u = 0; u < UE; ++u) {
+      const u32x4* src = wp + (size_t)(ustart + min(u, ucount - 1)) * (8 * NF * 64);      // a workgroup with fewer units re-requests its last one
+#pragma unroll
+      for (int f = 0; f < NF; ++f) w[u][f] = __builtin_nontemporal_load(src + f * 64);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- phase 1: h = bf16(h_in + sum slabs) (slabs first, residual last), sum of squares per 16-lane group -> LDS
+  u32x4 hr[CPT];
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    float v[8], sl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[2 * j] = bf16lo_to_f32(hv[c][j]); v[2 * j + 1] = bf16hi_to_f32(hv[c][j]); }
+#pragma unroll
+    for (int u = 0; u < SP; ++u) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { sl[j] += q[c][2 * u][j]; sl[4 + j] += q[c][2 * u + 1][j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) hr[c][j] = pack_bf16x2(sl[2 * j] + v[2 * j], sl[2 * j + 1] + v[2 * j + 1]);
+    float ssq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float lo = bf16lo_to_f32(hr[c][j]), hi = bf16hi_to_f32(hr[c][j]); ssq += lo * lo + hi * hi; }
+    const bool on = c * 512 + tid < nch;
+    if (!on) ssq = 0.f;                      // clamped duplicate chunk
+    ssq = group16_sum(ssq);                 // same operand pairs as the xor butterfly of skinny_kernel: identical bits
+    if ((lane & 15) == 0 && on) gs[mm[c] * gstride + (cc[c] >> 7)] = ssq;
+  }
+  __syncthreads();
+  CH_STAMP(1);
+  // ---- phase 2: row total in a fixed order, normalise the thread's own values, bf16 activations -> LDS
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    float tot = 0.f;
+    const float* gr = gs + mm[c] * gstride;
+#pragma unroll
+    for (int i = 0; i < ngr; i += 4) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(gr + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tot += (i + j < ngr) ? t[j] : 0.f;
+    }
+    const float rs = rsqrtf(tot / (float)K + p.eps);
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float lo = round_bf16(bf16lo_to_f32(hr[c][j]) * rs) * bf16lo_to_f32(wv[c][j]);
+      const float hi = round_bf16(bf16hi_to_f32(hr[c][j]) * rs) * bf16hi_to_f32(wv[c][j]);
+      o[j] = pack_bf16x2(lo, hi);
+    }
+    if (c * 512 + tid < nch) *reinterpret_cast<u32x4*>(xs + mm[c] * XS + cc[c] * 2) = o;
+  }
+  __syncthreads();          // (the group sums alias `red`: every thread has read them before any wave writes a partial accumulator)
+  CH_STAMP(2);
+
+  // ---- units: in-workgroup split-K over the 8 waves, reduced through LDS by wave 0 (same order as skinny_kernel: bit-identical)
+  const bool mok = fr < M;
+  const char* xrow = xs + (mok ? fr : 0) * XS + (wave * (NS * 32) + g * 8) * 2;       // lanes of rows >= M shadow row 0: MFMA columns are independent, their results are never stored
+  bf16x8 xf[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) xf[s] = as_bf16x8(*reinterpret_cast<const u32x4*>(xrow + s * 64));
+  int par = 0;
+#pragma unroll
+  for (int u = 0; u < UE; ++u) {
+    if (u < ucount) {
+      f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        a0 = mfma16(as_bf16x8(w[u][2 * s]), xf[s], a0);
+        a1 = mfma16(as_bf16x8(w[u][2 * s + 1]), xf[s], a1);
+      }
+      if (u == 0) { if constexpr (DBG) asm volatile("" ::"v"(a0[0])); CH_STAMP(3); }
+      float* rb = red + par * (7 * 2 * 64 * 4);
+      if (wave != 0) {
+        float* r = rb + ((wave - 1) * 2 * 64 + lane) * 4;
+        *reinterpret_cast<f32x4*>(r) = a0;
+        *reinterpret_cast<f32x4*>(r + 64 * 4) = a1;
+      }
+      __syncthreads();
+      if (u == 0) CH_STAMP(4);
+      par ^= 1;
+      if (wave == 0) {
+#pragma unroll
+        for (int w2 = 0; w2 < 7; ++w2) {
+          const float* r = rb + (w2 * 2 * 64 + lane) * 4;
+          a0 += *reinterpret_cast<const f32x4*>(r);
+          a1 += *reinterpret_cast<const f32x4*>(r + 64 * 4);
+        }
+        const int pair = ustart + u;
+        if (mok && pair * 32 < p.n_valid) {              // pair = [gate16 | up16] -> output columns pair*16 + g*4 + j
+          bf16_t* o = p.out + (size_t)fr * p.ldo + pair * 16 + g * 4;
+          float r4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) r4[j] = round_bf16(silu(round_bf16(a0[j]))) * round_bf16(a1[j]);
+          *reinterpret_cast<u32x2*>(o) = u32x2{pack_bf16x2(r4[0], r4[1]), pack_bf16x2(r4[2], r4[3])};
+        }
+      }
+    }
+  }
+  // the rounded residual stream (the down projection adds it back): workgroup 0, last -- nothing in this launch waits for these stores
+  if (p.h_out && blockIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < CPT; ++c)
+      if (c * 512 + tid < nch) st_global_16(p.h_out + mm[c] * K + cc[c], hr[c]);
+  }
+  CH_STAMP(5);
+}
+
+template <int NS, int UE, int SP, int CPT>
+static int chain_gu_launch(const ChainGuP& p, int gx, int lds, hipStream_t stream) {
+  if (p.dbg) {
+    if (int rc = set_max_lds_once(chain_gu_kernel<NS, UE, SP, CPT, true>, lds)) return rc;
+    hipLaunchKernelGGL((chain_gu_kernel<NS, UE, SP, CPT, true>), dim3(gx), dim3(512), lds, stream, p);
+  } else {
+    if (int rc = set_max_lds_once(chain_gu_kernel<NS, UE, SP, CPT, false>, lds)) return rc;
+    hipLaunchKernelGGL((chain_gu_kernel<NS, UE, SP, CPT, false>), dim3(gx), dim3(512), lds, stream, p);
+  }
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vlaser_chain_gu_supported(int M, int N, int K, int n_partials) {
+  if (M < 1 || M > 16 || (K != 768 && K != 1536) || N % 32 || (n_partials != 2 && n_partials != 3) || (K == 1536 && n_partials != 2)) return 0;
+  const int cpt = (M * (K / 8) + 511) / 512;
+  if (cpt > 3) return 0;
+  const int units = N / 32;
+  const int longest = (units + 255) / 256;
+  return longest == 2 || longest == 3;
+}
+
+extern "C" int vlaser_chain_gu(const VlaserSkinnyArgs* a, vl_stream_t s) {
+  VL_CHECK(a && a->x && a->W && a->norm_w && a->out && a->partials, "vlaser_chain_gu: null operand");
+  VL_CHECK(a->tiles_per_unit == 2 || a->tiles_per_unit == 0, "vlaser_chain_gu: weights packed in 32-row units (pack_skinny(..., 1, 2))");
+  VL_CHECK(a->k_splits == 1 && vlaser_chain_gu_supported(a->M, a->N, a->K, a->n_partials),
+           "vlaser_chain_gu: built for K = 768 / 1536, 2 or 3 producer slabs, 2-3 units per workgroup, M * K / 8 <= 1536 chunks (got M %d N %d K %d slabs %d)", a->M, a->N,
+           a->K, a->n_partials);
+  VL_CHECK(((uintptr_t)a->W & 15) == 0 && ((uintptr_t)a->x & 15) == 0 && ((uintptr_t)a->partials & 15) == 0 && ((uintptr_t)a->out & 7) == 0 && a->ldo % 4 == 0, "vlaser_chain_gu: alignment");
+  const int n_valid = a->n_valid > 0 ? a->n_valid : a->N;
+  VL_CHECK(n_valid % 32 == 0, "vlaser_chain_gu: whole [gate|up] groups");
+  ChainGuP p;
+  p.h_in = (const bf16_t*)a->x; p.partials = a->partials; p.norm_w = (const bf16_t*)a->norm_w; p.h_out = (bf16_t*)a->h_out;
+  p.W = (const u32x4*)a->W; p.out = (bf16_t*)a->out;
+  p.M = a->M; p.ldo = a->ldo; p.n_valid = n_valid; p.eps = a->eps; p.inv_cpr = 8.0f / (float)a->K; p.dbg = a->dbg;
+  const int units = a->N / 32, longest = (units + 255) / 256, gx = (units + longest - 1) / longest;
+  p.ulo = units / gx; p.urem = units % gx;
+  const int ns = a->K / 256, cpt = (a->M * (a->K / 8) + 511) / 512;
+  const int lds = ((a->M * (a->K * 2 + 16) + 15) & ~15) + 2 * 7 * 2 * 64 * 16;
+  hipStream_t stream = (hipStream_t)s;
+#define CG_CASE(NS_, UE_, SP_, CPT_) if (ns == NS_ && longest == UE_ && a->n_partials == SP_ && cpt == CPT_) return chain_gu_launch<NS_, UE_, SP_, CPT_>(p, gx, lds, stream);
+#define CG_CPT(NS_, UE_, SP_) CG_CASE(NS_, UE_, SP_, 1) CG_CASE(NS_, UE_, SP_, 2) CG_CASE(NS_, UE_, SP_, 3)
+  CG_CPT(3, 3, 3) CG_CPT(3, 3, 2) CG_CPT(6, 3, 2) CG_CPT(3, 2, 3) CG_CPT(6, 2, 2)
+#undef CG_CPT
+#undef CG_CASE
+  vlaser_set_error("vlaser_chain_gu: no variant for K %d, %d units per workgroup, %d slabs, %d chunks per thread", a->K, longest, a->n_partials, cpt);
+  return -1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ q / k / v
+struct ChainQkvP {
+  const bf16_t* h_in; const bf16_t* norm_w; const u32x4* W; const bf16_t* bias;
+  bf16_t* q_out; bf16_t* k_cache; bf16_t* vt_cache; const float* rope_cos; const float* rope_sin; const int32_t* pos_ids;
+  int M, n_q_heads, n_kv_heads, s_max, tok_per_batch, slot_base;
+  float eps;
+  unsigned long long* dbg;
+};
+
+// KS = K / 32 K-steps (24: hidden 768, 48: hidden 1536), RG = ceil(M / 4) row groups of the norm prologue.  One wave = one 16-row unit of the fused q/k/v
+// matrix (head_perm16 packing: lane group g of a unit holds [d, d+1, d+64, d+65], d = 8 (unit % 8) + 2 g -- the RoPE partner of every value in the same lane).
+template <int KS, int RG, bool DBG>
+__global__ __launch_bounds__(64) void chain_qkv_kernel(ChainQkvP p) {
+  constexpr int K = KS * 32, NCH = KS / 4, XS = K * 2 + 16;        // NCH: 16-byte chunks of a row per lane of its 16-lane group
+  extern __shared__ __attribute__((aligned(16))) char xs[];        // [4 RG][XS] normalised activations (bf16)
+  const int lane = threadIdx.x, fr = lane & 15, g = lane >> 4, r4 = lane >> 4, j16 = lane & 15;
+  const int unit = blockIdx.x, M = p.M;
+  unsigned long long* dbg = DBG ? p.dbg + (size_t)blockIdx.x * 8 : nullptr;
+  CH_STAMP(0);
+  // ---- requests, in issue order: position id of the lane's row (cos / sin hang off it), norm weight + residual stream (L2), epilogue bias, weights (HBM)
+  const int pos = p.pos_ids[min(fr, M - 1)];
+  u32x4 wn[NCH], hc[RG][NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) wn[i] = ld_global_16(p.norm_w + (j16 + 16 * i) * 8);
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) {
+    const int row = min(rg * 4 + r4, M - 1);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) hc[rg][i] = ld_global_16(p.h_in + (size_t)row * K + (j16 + 16 * i) * 8);
+  }
+  const u32x2 bias = *reinterpret_cast<const u32x2*>(p.bias + unit * 16 + g * 4);
+  __builtin_amdgcn_sched_barrier(0);           // pin the issue order: vmcnt retires in order, the scheduler does not know
+  u32x4 w[KS];
+  {
+    const u32x4* src = p.W + (size_t)unit * (KS * 64) + lane;
+#pragma unroll
+    for (int f = 0; f < KS; ++f) w[f] = __builtin_nontemporal_load(src + f * 64);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const int d = ((unit & 7) << 3) + 2 * g;
+  int pos_l = pos;
+  asm volatile("" : "+v"(pos_l));              // everything computed from the position id stays BEHIND the weight requests (hipcc hoisted its sign extension -- and with it
+                                               // a wait for the id's round trip -- in front of them)
+  const f32x2_t cs = *reinterpret_cast<const f32x2_t*>(p.rope_cos + (size_t)pos_l * 64 + d);     // behind the weights in the queue: only the epilogue needs them
+  const f32x2_t sn = *reinterpret_cast<const f32x2_t*>(p.rope_sin + (size_t)pos_l * 64 + d);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- RMSNorm: xn = bf16(w * bf16(h * rsqrt(mean(h^2) + eps))), one row per 16-lane group and row group; wave-local (no barrier)
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) {
+    float ssq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float lo = bf16lo_to_f32(hc[rg][i][e]), hi = bf16hi_to_f32(hc[rg][i][e]); ssq += lo * lo + hi * hi; }
+    ssq = group16_sum(ssq);
+    const float rs = rsqrtf(ssq / (float)K + p.eps);
+    const int row = rg * 4 + r4;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = round_bf16(bf16lo_to_f32(hc[rg][i][e]) * rs) * bf16lo_to_f32(wn[i][e]);
+        const float hi = round_bf16(bf16hi_to_f32(hc[rg][i][e]) * rs) * bf16hi_to_f32(wn[i][e]);
+        o[e] = pack_bf16x2(lo, hi);
+      }
+      if (row < M) *reinterpret_cast<u32x4*>(xs + row * XS + (j16 + 16 * i) * 16) = o;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  CH_STAMP(2);
+  // ---- GEMV over the whole K: two accumulators so that consecutive MFMAs do not wait for each other
+  const bool mok = fr < M;
+  const char* xrow = xs + (mok ? fr : 0) * XS + g * 16;
+  f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+  for (int f = 0; f < KS; f += 2) {
+    const u32x4 x0 = *reinterpret_cast<const u32x4*>(xrow + f * 64), x1 = *reinterpret_cast<const u32x4*>(xrow + (f + 1) * 64);     // rows >= M shadow row 0 (never stored)
+    acc0 = mfma16(as_bf16x8(w[f]), as_bf16x8(x0), acc0);
+    acc1 = mfma16(as_bf16x8(w[f + 1]), as_bf16x8(x1), acc1);
+  }
+  f32x4 acc;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = acc0[e] + acc1[e];
+  if constexpr (DBG) asm volatile("" ::"v"(acc[0]));
+  CH_STAMP(3);
+  // ---- epilogue: bias + RoPE + scatter (as skinny_epilogue16<QKV_ROPE>): lane -> row m = fr, values [d, d+1, d+64, d+65] of head unit / 8
+  if (mok) {
+    const int m = fr, head = unit >> 3;
+    const float b0 = bf16lo_to_f32(bias[0]), b1 = bf16hi_to_f32(bias[0]), b2 = bf16lo_to_f32(bias[1]), b3 = bf16hi_to_f32(bias[1]);
+    const float x1[2] = {round_bf16(acc[0] + b0), round_bf16(acc[1] + b1)}, x2[2] = {round_bf16(acc[2] + b2), round_bf16(acc[3] + b3)};
+    const int b = ch_fdiv(m, __builtin_amdgcn_rcpf((float)p.tok_per_batch));
+    const int slot = p.slot_base >= 0 ? p.slot_base + (m - b * p.tok_per_batch) : pos_l;
+    const int nq = p.n_q_heads, nkv = p.n_kv_heads;
+    if (head < nq + nkv) {
+      float o1[2], o2[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        o1[e] = x1[e] * cs[e] - x2[e] * sn[e];
+        o2[e] = x2[e] * cs[e] + x1[e] * sn[e];
+      }
+      bf16_t* dst = head < nq ? p.q_out + (size_t)m * nq * 128 + head * 128 : p.k_cache + (((size_t)b * nkv + (head - nq)) * p.s_max + slot) * 128;
+      *reinterpret_cast<uint32_t*>(dst + d) = pack_bf16x2(o1[0], o1[1]);
+      *reinterpret_cast<uint32_t*>(dst + d + 64) = pack_bf16x2(o2[0], o2[1]);
+    } else {
+      bf16_t* vt = p.vt_cache + ((size_t)b * nkv + (head - nq - nkv)) * 128 * p.s_max + slot;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        vt[(size_t)(d + e) * p.s_max] = f32_to_bf16(x1[e]);
+        vt[(size_t)(d + 64 + e) * p.s_max] = f32_to_bf16(x2[e]);
+      }
+    }
+  }
+  CH_STAMP(5);
+}
+
+extern "C" int vlaser_chain_qkv_supported(int M, int N, int K) { return M >= 1 && ((K == 768 && M <= 16) || (K == 1536 && M <= 8)) && N % 128 == 0; }      // (hidden 1536 x 16 rows would spill)
+
+extern "C" int vlaser_chain_qkv(const VlaserSkinnyArgs* a, vl_stream_t s) {
+  VL_CHECK(a && a->x && a->W && a->norm_w && a->bias && a->q_out && a->k_cache && a->vt_cache && a->rope_cos && a->rope_sin && a->pos_ids, "vlaser_chain_qkv: null operand");
+  VL_CHECK(a->tiles_per_unit == 1 && a->k_splits == 1, "vlaser_chain_qkv: weights packed in 16-row lane-local units (pack_qkv16 + pack_skinny(..., 1, 1))");
+  VL_CHECK(a->n_partials == 0, "vlaser_chain_qkv: reads the residual stream as published by vlaser_chain_down (no split-K slabs)");
+  VL_CHECK(vlaser_chain_qkv_supported(a->M, a->N, a->K), "vlaser_chain_qkv: built for hidden 768 / 1536, M <= 16, whole heads (got M %d N %d K %d)", a->M, a->N, a->K);
+  VL_CHECK(((uintptr_t)a->W & 15) == 0 && ((uintptr_t)a->x & 15) == 0 && ((uintptr_t)a->norm_w & 15) == 0 && ((uintptr_t)a->bias & 7) == 0, "vlaser_chain_qkv: alignment");
+  ChainQkvP p;
+  p.h_in = (const bf16_t*)a->x; p.norm_w = (const bf16_t*)a->norm_w; p.W = (const u32x4*)a->W; p.bias = (const bf16_t*)a->bias;
+  p.q_out = (bf16_t*)a->q_out; p.k_cache = (bf16_t*)a->k_cache; p.vt_cache = (bf16_t*)a->vt_cache; p.rope_cos = a->rope_cos; p.rope_sin = a->rope_sin;
+  p.pos_ids = a->pos_ids; p.M = a->M; p.n_q_heads = a->n_q_heads; p.n_kv_heads = a->n_kv_heads; p.s_max = a->s_max; p.tok_per_batch = a->tok_per_batch;
+  p.slot_base = a->slot_base; p.eps = a->eps; p.dbg = a->dbg;
+  const int units = a->N / 16, rg = (a->M + 3) / 4, ks = a->K / 32;
+  const int lds = 4 * rg * (a->K * 2 + 16);
+  hipStream_t stream = (hipStream_t)s;
+#define CQ_LAUNCH(KS_, RG_, DBG_)                                                                       \
+  do {                                                                                                  \
+    if (int rc = set_max_lds_once(chain_qkv_kernel<KS_, RG_, DBG_>, lds)) return rc;                     \
+    hipLaunchKernelGGL((chain_qkv_kernel<KS_, RG_, DBG_>), dim3(units), dim3(64), lds, stream, p);       \
+    VL_LAUNCH_CHECK();                                                                                  \
+    return 0;                                                                                           \
+  } while (0)
+#define CQ_CASE(KS_, RG_) if (ks == KS_ && rg == RG_) { if (p.dbg) CQ_LAUNCH(KS_, RG_, true); else CQ_LAUNCH(KS_, RG_, false); }
+  CQ_CASE(24, 1) CQ_CASE(24, 2) CQ_CASE(24, 3) CQ_CASE(24, 4) CQ_CASE(48, 1) CQ_CASE(48, 2)
+#undef CQ_CASE
+#undef CQ_LAUNCH
+  vlaser_set_error("vlaser_chain_qkv: no variant");
+  return -1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ down projection
+struct ChainDownP {
+  const bf16_t* x; const u32x4* W; const bf16_t* res; bf16_t* h_out;
+  int M, N, ldx;
+  unsigned long long* dbg;
+};
+
+// A workgroup = 4 output columns n0 .. n0 + 3 over the WHOLE K = NW waves x NL loads x 128.  Lane (b = lane >> 2, i = lane & 3) of wave w, load l holds
+// W[n0 + i][(w NL + l) 128 + 8 b .. + 8] (ops.pack_down4: one contiguous 1 KiB per wave-level load) and x[row i of its row group][same k]; the two halves of
+// the 16 bytes feed two v_mfma_f32_4x4x4_16b_bf16 (block b: D_b[n][m] += sum_k W[n0 + n][k] x[m][k] over 4 k): lane (b, m) accumulates out[m][n0 .. n0 + 3]
+// over its block's k, the 16 blocks are summed across the lanes, the NW waves through LDS in a fixed order.  RG = ceil(M / 4) row groups.
+template <int NW, int NL, int RG, bool DBG>
+__global__ __launch_bounds__(NW * 64) void chain_down_kernel(ChainDownP p) {
+  __shared__ __attribute__((aligned(16))) float part[NW][RG][4][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = lane >> 2, i = lane & 3;
+  const int M = p.M, n0 = blockIdx.x * 4;
+  unsigned long long* dbg = DBG ? p.dbg + (size_t)blockIdx.x * 8 : nullptr;
+  CH_STAMP(0);
+  // ---- requests: residual (final phase, threads 0 .. M-1), activations (L2), weights (HBM)
+  const u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + (size_t)min(tid, M - 1) * p.N + n0);      // unconditional (clamped): no branch in front of the load burst
+  u32x4 xv[RG][NL], wv[NL];
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) {
+    const bf16_t* xr = p.x + (size_t)min(rg * 4 + i, M - 1) * p.ldx + (wave * NL) * 128 + b * 8;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) xv[rg][l] = ld_global_16(xr + l * 128);
+  }
+  __builtin_amdgcn_sched_barrier(0);           // activations (L2) strictly in front of the weights (HBM) in the queue
+  {
+    const u32x4* src = p.W + ((size_t)blockIdx.x * NW + wave) * (NL * 64) + lane;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) wv[l] = __builtin_nontemporal_load(src + l * 64);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 acc[RG];
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4{0, 0, 0, 0};
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const s16x4 wlo = __builtin_bit_cast(s16x4, u32x2{wv[l][0], wv[l][1]}), whi = __builtin_bit_cast(s16x4, u32x2{wv[l][2], wv[l][3]});
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) {
+      const s16x4 xlo = __builtin_bit_cast(s16x4, u32x2{xv[rg][l][0], xv[rg][l][1]}), xhi = __builtin_bit_cast(s16x4, u32x2{xv[rg][l][2], xv[rg][l][3]});
+      acc[rg] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wlo, xlo, acc[rg], 0, 0, 0);
+      acc[rg] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(whi, xhi, acc[rg], 0, 0, 0);
+    }
+  }
+  CH_STAMP(3);
+  // ---- sum of the 16 blocks (lanes with equal lane & 3), then of the waves
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[rg][r] = vl_blocks16_sum(acc[rg][r]);
+    if (lane < 4) *reinterpret_cast<f32x4*>(&part[wave][rg][lane][0]) = acc[rg];       // [row i of the group][column n]
+  }
+  __syncthreads();
+  CH_STAMP(4);
+  if (tid < 4 * RG && tid < M) {
+    const int rg = tid >> 2, ri = tid & 3;
+    float s4[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(&part[w2][rg][ri][0]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s4[r] += t[r];
+    }
+    const float r0 = bf16lo_to_f32(rv[0]), r1 = bf16hi_to_f32(rv[0]), r2 = bf16lo_to_f32(rv[1]), r3 = bf16hi_to_f32(rv[1]);
+    *reinterpret_cast<u32x2*>(p.h_out + (size_t)tid * p.N + n0) = u32x2{pack_bf16x2(s4[0] + r0, s4[1] + r1), pack_bf16x2(s4[2] + r2, s4[3] + r3)};
+  }
+  CH_STAMP(5);
+}
+
+extern "C" int vlaser_chain_down_supported(int M, int N, int K) { return M >= 1 && M <= 16 && N % 4 == 0 && K == 8960; }
+
+/* x bf16 [M, ldx] (ldx >= K), W = ops.pack_down4(down_proj.weight, NW, NL), res / h_out bf16 [M, N] (may not alias): h_out = bf16(res + x @ W^T) */
+extern "C" int vlaser_chain_down(const void* x, int ldx, const void* W, const void* res, void* h_out, int M, int N, int K, unsigned long long* dbg, vl_stream_t s) {
+  VL_CHECK(x && W && res && h_out && res != h_out, "vlaser_chain_down: null operand (or res == h_out: every workgroup reads its residual columns while others store)");
+  VL_CHECK(vlaser_chain_down_supported(M, N, K) && ldx >= K && ldx % 8 == 0, "vlaser_chain_down: built for K = 8960 (7 waves x 10 loads x 128), N %% 4 == 0, M <= 16 (got M %d N %d K %d)", M, N, K);
+  VL_CHECK(((uintptr_t)W & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)res & 7) == 0 && ((uintptr_t)h_out & 7) == 0 && N % 4 == 0, "vlaser_chain_down: alignment");
+  ChainDownP p;
+  p.x = (const bf16_t*)x; p.W = (const u32x4*)W; p.res = (const bf16_t*)res; p.h_out = (bf16_t*)h_out; p.M = M; p.N = N; p.ldx = ldx; p.dbg = dbg;
+  const int rg = (M + 3) / 4;
+  hipStream_t stream = (hipStream_t)s;
+#define CD_CASE(RG_)                                                                                                                   \
+  if (rg == RG_) {                                                                                                                     \
+    if (dbg) hipLaunchKernelGGL((chain_down_kernel<7, 10, RG_, true>), dim3(N / 4), dim3(7 * 64), 0, stream, p);                         \
+    else hipLaunchKernelGGL((chain_down_kernel<7, 10, RG_, false>), dim3(N / 4), dim3(7 * 64), 0, stream, p);                            \
+    VL_LAUNCH_CHECK();                                                                                                                 \
+    return 0;                                                                                                                          \
+  }
+  CD_CASE(1) CD_CASE(2) CD_CASE(3) CD_CASE(4)
+#undef CD_CASE
+  vlaser_set_error("vlaser_chain_down: no variant");
+  return -1;
+}

@@ -53,6 +53,42 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Sum over the 16 lanes of a DPP row, every lane receiving the SAME bits: the xor butterfly (1, 2, 4, 8) on the VALU's own cross-lane path.  `__shfl_xor` compiles
+// to ds_bpermute_b32 + `s_waitcnt lgkmcnt(0)` per step (four LDS round trips in a row); quad_perm swaps lanes 1 and 2 apart, and once the quads (halves) hold
+// uniform values the 8-lane (16-lane) mirror pairs every lane with a lane of the partner quad (half) -- the same operands as xor 4 (xor 8).
+template <int CTRL>
+__device__ __forceinline__ float vl_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float group16_sum(float v) {
+  v += vl_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += vl_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += vl_dpp<0x141>(v);     // row_half_mirror
+  v += vl_dpp<0x140>(v);     // row_mirror
+  return v;
+}
+
+// xor-16 / xor-32 butterfly steps without the LDS crossbar: v_permlane16_swap (v_permlane32_swap) exchanges the odd 16-lane rows (the upper half) of its first operand
+// with the even rows (the lower half) of its second; with both operands = v the two results hold {own row pair's even row, odd row} in every lane
+__device__ __forceinline__ float vl_xor16_sum(float v) {
+  const uint32_t b = __builtin_bit_cast(uint32_t, v);
+  const u32x2 s = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+  return __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+}
+__device__ __forceinline__ float vl_xor32_sum(float v) {
+  const uint32_t b = __builtin_bit_cast(uint32_t, v);
+  const u32x2 s = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+  return __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+}
+// sum over the 16 lanes that share lane & 3 (the 16 blocks of a 4x4x4 MFMA), every lane receiving the same bits: rotate by 8 (= xor 8 inside a row), by 4 (= xor 4 once the
+// values are 8-periodic), then the rows
+__device__ __forceinline__ float vl_blocks16_sum(float v) {
+  v += vl_dpp<0x128>(v);     // row_ror:8
+  v += vl_dpp<0x124>(v);     // row_ror:4
+  v = vl_xor16_sum(v);
+  return vl_xor32_sum(v);
+}
+
 // erf by Abramowitz & Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution): ~12 VALU ops instead of the ~60 of the
 // device library's erff, which made the GELU epilogue of the ViT fc1 GEMM cost as much as half its K loop.
 __device__ __forceinline__ float fast_erf(float x) {
@@ -67,6 +103,12 @@ __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcp
 
 __device__ __forceinline__ u32x4 ld_global_16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st_global_16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+// A block-uniform int32 read through the SCALAR cache (s_load_dword, lgkmcnt): `valid_len[b]` and the like.  As a vector load it sits in the vmcnt queue, and
+// hipcc waits for it with vmcnt(0) at its first use -- in attn_skinny that drained Q's round trip before the first K / V^T request went out (r05, read in the ISA:
+// two serialised memory round trips in front of the first MFMA).  The constant address space promises that nobody writes the word during the launch.
+typedef const __attribute__((address_space(4))) int32_t* vl_cptr_i32;
+__device__ __forceinline__ int vl_sload_i32(const int32_t* p) { return *reinterpret_cast<vl_cptr_i32>(reinterpret_cast<uintptr_t>(p)); }
 
 // ---- kernel arguments in ONE scalar-memory round trip.  hipcc issues the s_load of a by-value argument struct piecemeal, where each field is first
 // needed, with an `s_waitcnt lgkmcnt(0)` in front of every first use: the <= 16-row kernels started with 3-6 SERIALISED round trips to the kernarg segment

@@ -460,8 +460,14 @@ __global__ __launch_bounds__(256) void vla_euler_kernel(const bf16_t* __restrict
     if (do_clip) av = fminf(fmaxf(av, -clip), clip);
     action[m * adim + j] = av;
     if (vel_out) vel_out[m * adim + j] = vel;
-    // (ABI 5) the caller's copy of the result: slot (call counter mod ring_n) of a small ring, so infer_action returns a view instead of launching a clone
-    if (ring) ring[(size_t)((unsigned)ring_ctr[0] % (unsigned)ring_n) * ring_stride + m * adim + j] = av;
+    // (ABI 5) the caller's copy of the result: slot (call counter mod ring_n) of a small ring, so infer_action returns a view instead of launching a clone.
+    // (ABI 6) ring_ctr = {call number k, error word of even calls, error word of odd calls} (vlaser_vla_stage): a dense mask the kernels' descriptors cannot
+    // express turns the caller's copy into NaN -- an unsupported mask is never served silently (the host raises at its next poll of the word)
+    if (ring) {
+      const int k = ring_ctr[0];
+      if (ring_ctr[1 + (k & 1)] != 0) av = __builtin_nanf("");
+      ring[(size_t)((unsigned)k % (unsigned)ring_n) * ring_stride + m * adim + j] = av;
+    }
   }
 }
 extern "C" int vlaser_vla_euler(const void* h_in, const float* partials, int n_partials, int M, const void* norm_w, float eps,
@@ -653,6 +659,7 @@ extern "C" int vlaser_vla_step(const void* h_in, const float* partials, int n_pa
                                const void* w3, const void* b3, void* h_out, int M, int Wd, int adim, vl_stream_t s) {
   VL_CHECK(a_in && a_out && w21 && cs && w3 && b3 && h_out && M >= 1 && M <= 16, "vlaser_vla_step: bad args (1..16 rows)");
   VL_CHECK(Wd % 256 == 0 && Wd <= 1024 && adim >= 1 && adim <= 16, "vlaser_vla_step: Wd must be a multiple of 256 and <= 1024, action_dim <= 16 (wider experts keep the separate launches)");
+  VL_CHECK(adim <= 8 || Wd <= 768, "vlaser_vla_step: action_dim > 8 is built for Wd <= 768 (the 16 x 1024 variant needs scratch: such heads keep the separate launches)");
   VL_CHECK(!finish || (h_in && norm_w && wd && bd && n_partials >= 0 && n_partials <= 8 && (n_partials == 0 || partials) && rows_in >= M + row_off && row_off >= 0 && a_in != a_out),
            "vlaser_vla_step: finish needs h_in / norm / decoder, <= 8 slabs of rows_in >= M + row_off rows, and distinct action buffers");
   const int blocks = Wd / 16;                    // 16 linear_3 outputs per workgroup (48 workgroups at Wd = 768)
@@ -660,7 +667,7 @@ extern "C" int vlaser_vla_step(const void* h_in, const float* partials, int n_pa
   hipLaunchKernelGGL((vla_step_kernel<AD_, KJ_>), dim3(blocks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)h_in, partials, n_partials, rows_in, row_off, \
                      (const bf16_t*)norm_w, eps, (const bf16_t*)wd, (const bf16_t*)bd, a_in, a_out, vel_out, dt, finish, w21, cs, (const bf16_t*)w3,   \
                      (const bf16_t*)b3, (bf16_t*)h_out, M, Wd, adim)
-#define VL_STEP_KJ(AD_) { switch (Wd / 256) { case 1: VL_STEP(AD_, 1); break; case 2: VL_STEP(AD_, 2); break; case 3: VL_STEP(AD_, 3); break; default: VL_STEP(AD_, 4); } }
+#define VL_STEP_KJ(AD_) { switch (Wd / 256) { case 1: VL_STEP(AD_, 1); break; case 2: VL_STEP(AD_, 2); break; case 3: VL_STEP(AD_, 3); break; default: if constexpr (AD_ <= 8) VL_STEP(AD_, 4); } }
   if (adim <= 8) VL_STEP_KJ(8) else VL_STEP_KJ(16)
 #undef VL_STEP_KJ
 #undef VL_STEP
@@ -731,9 +738,14 @@ extern "C" int vlaser_normalize_u8(const void* in_u8, void* out_bf16, int n_img,
 
 // vla_stage (ABI 5): EVERY per-call input of infer_action into the static slots of the captured chunk graph in ONE launch.  r03 staged them with six
 // torch copy_ / cast launches + a clone of the result: ~90 us of mostly idle GPU between two chunks (tools/chunk_timeline.py: the copies start 13 us apart).
-//   block 0           : input_ids (int64 [B, T]) -> ids slot; valid_len[b] = given (int32 / int64) or the number of non-pad ids of row b; proprio and noise
-//                       (fp32) -> their slots; call counter += 1 (slot of the output ring, read by the chunk's last kernel)
-//   blocks 1 .. grid-1: pixel_values -> bf16 slot: bf16 copy / fp32 cast / uint8 planar normalise ((u8 * (1/255) - mean) / std, vlaser_normalize_u8 mode 0)
+//   block 0           : input_ids (int64 [B, T]) -> ids slot; valid_len[b] = given (int32 / int64), or the zero count of the dense mask's proprio row, or the
+//                       number of non-pad ids of row b; proprio and noise (fp32) -> their slots; position ids (int64 -> int32 slots); call counter += 1 (slot of
+//                       the output ring, read by the chunk's last kernel); the NEXT call's error word cleared
+//   blocks 1 .. nm    : (ABI 6) the reference's dense masks (pizero_internvl.py:517-603: image_text_proprio_mask [B,1,T+1,T+1], action_mask [B,1,na,T+1+na], additive
+//                       0 / dtype-min) checked against the ONLY pattern the (valid_len, blk_start) descriptors of the kernels express; a mismatch sets bits of this
+//                       call's error word (the chunk's last kernel then returns NaN, the host raises at its next poll) -- r04 copied the mask to the host per call
+//                       (a blocking 593 KB D2H) and never read action_mask
+//   the other blocks  : pixel_values -> bf16 slot: bf16 copy / fp32 cast / uint8 planar normalise ((u8 * (1/255) - mean) / std, vlaser_normalize_u8 mode 0)
 struct VlaStageP {
   const int64_t* ids; int64_t* ids_out; int B, T; long long pad_id;
   const void* valid_in; int valid_is_i64; int32_t* valid_out;
@@ -741,21 +753,39 @@ struct VlaStageP {
   const float* noise; float* noise_out; int n_noise;
   const void* pix; bf16_t* pix_out; long long n_pix8; int pix_dtype; int hw;      // n_pix8: groups of 8 elements
   float m0, m1, m2, s0, s1, s2;
-  int* ctr;
+  int* ctr; int call_no;
+  const void* itp_mask; const void* action_mask; int mask_dtype, n_act, n_mask_blocks;
+  long long itp_bs, itp_rs, act_bs, act_rs;       // element strides of the masks' batch / row axes (the reference hands out SLICES of the full mask, :589-603)
+  const int64_t* pos_vlm; const int64_t* pos_pro; const int64_t* pos_act;
+  int32_t* pos_vlm_out; int32_t* pos_pro_out; int32_t* pos_act_out; int32_t* pos_ride_out;
 };
+#define VLS_ROWS_PER_BLOCK 8
+// element e of an additive mask "lets the key through" iff it is +-0 (the reference writes exactly 0 or finfo(dtype).min)
+__device__ __forceinline__ bool vls_mask_open(const void* m, int dt, size_t e) {
+  if (dt == 1) return (reinterpret_cast<const uint32_t*>(m)[e] & 0x7fffffffu) == 0;
+  return (reinterpret_cast<const uint16_t*>(m)[e] & 0x7fffu) == 0;      // bf16 / fp16
+}
 __global__ __launch_bounds__(256) void vla_stage_kernel(VlaStageP p) {
   const int tid = threadIdx.x;
+  const int T = p.T, W1 = T + 1, na = p.n_act, W2 = T + 1 + na;
   if (blockIdx.x == 0) {
     __shared__ int cnt[4];
     for (int i = tid; i < p.B * p.T; i += 256) p.ids_out[i] = p.ids[i];
     for (int i = tid; i < p.n_proprio; i += 256) p.proprio_out[i] = p.proprio[i];
     for (int i = tid; i < p.n_noise; i += 256) p.noise_out[i] = p.noise[i];
+    if (p.pos_vlm) for (int i = tid; i < p.B * T; i += 256) p.pos_vlm_out[i] = (int32_t)p.pos_vlm[i];
+    if (p.pos_pro) for (int i = tid; i < p.B; i += 256) p.pos_pro_out[i] = (int32_t)p.pos_pro[i];
+    if (p.pos_act) for (int i = tid; i < p.B * na; i += 256) p.pos_act_out[i] = (int32_t)p.pos_act[i];
+    if (p.pos_ride_out && p.pos_pro && p.pos_act && tid <= na) p.pos_ride_out[tid] = tid == 0 ? (int32_t)p.pos_pro[0] : (int32_t)p.pos_act[tid - 1];
     if (p.valid_in) {
       if (tid < p.B) p.valid_out[tid] = p.valid_is_i64 ? (int32_t)reinterpret_cast<const int64_t*>(p.valid_in)[tid] : reinterpret_cast<const int32_t*>(p.valid_in)[tid];
     } else {
-      for (int b = 0; b < p.B; ++b) {                       // (input_ids != pad_token_id).sum(-1): what the reference's attention_mask counts for right-padded prompts
+      for (int b = 0; b < p.B; ++b) {
+        // dense mask given: the zero count of the proprio row over the image / text columns (what r04's host-side mask_to_descriptor did); else
+        // (input_ids != pad_token_id).sum(-1): what the reference's attention_mask counts for right-padded prompts
         int c = 0;
-        for (int i = tid; i < p.T; i += 256) c += p.ids[(size_t)b * p.T + i] != p.pad_id;
+        if (p.itp_mask) { for (int i = tid; i < T; i += 256) c += vls_mask_open(p.itp_mask, p.mask_dtype, (size_t)(b * p.itp_bs + T * p.itp_rs + i)); }
+        else { for (int i = tid; i < T; i += 256) c += p.ids[(size_t)b * T + i] != p.pad_id; }
         c = (int)wave_sum((float)c);
         if ((tid & 63) == 0) cnt[tid >> 6] = c;
         __syncthreads();
@@ -763,12 +793,57 @@ __global__ __launch_bounds__(256) void vla_stage_kernel(VlaStageP p) {
         __syncthreads();
       }
     }
-    if (tid == 0 && p.ctr) p.ctr[0] = p.ctr[0] + 1;
+    if (tid == 0 && p.ctr) {
+      // the call number comes from the HOST (it advances only after this launch was accepted): the device copy cannot drift from the host's ring index.
+      // ctr[1 + (k & 1)] = this call's error word (cleared by the previous call, OR-ed by the mask blocks below, read by the chunk's last kernel);
+      // clear the NEXT call's word: nobody else touches it during this call
+      p.ctr[0] = p.call_no;
+      p.ctr[1 + ((p.call_no + 1) & 1)] = 0;
+    }
     return;
   }
-  const long long stride = (long long)(gridDim.x - 1) * 256;
+  if ((int)blockIdx.x <= p.n_mask_blocks) {
+    // rows [r0, r0 + 8) of batch element b over the concatenation {T+1 rows of image_text_proprio_mask, na rows of action_mask}; one wave per 2 rows
+    const int rpb = W1 + na, bpb = (rpb + VLS_ROWS_PER_BLOCK - 1) / VLS_ROWS_PER_BLOCK;
+    const int mb = blockIdx.x - 1, b = mb / bpb, r0 = (mb - b * bpb) * VLS_ROWS_PER_BLOCK;
+    const int lane = tid & 63, wave = tid >> 6;
+    int c;          // valid prefix length of this batch element: given, or the proprio row's zero count (every wave counts it itself: 385 elements)
+    if (p.valid_in) c = p.valid_is_i64 ? (int)reinterpret_cast<const int64_t*>(p.valid_in)[b] : reinterpret_cast<const int32_t*>(p.valid_in)[b];
+    else if (p.itp_mask) {
+      int n = 0;
+      for (int i = lane; i < T; i += 64) n += vls_mask_open(p.itp_mask, p.mask_dtype, (size_t)(b * p.itp_bs + T * p.itp_rs + i));
+      c = (int)wave_sum((float)n);
+    } else {
+      int n = 0;
+      for (int i = lane; i < T; i += 64) n += p.ids[(size_t)b * T + i] != p.pad_id;
+      c = (int)wave_sum((float)n);
+    }
+    int bad = 0;
+    for (int rr = wave; rr < VLS_ROWS_PER_BLOCK; rr += 4) {
+      const int r = r0 + rr;
+      if (r >= rpb) break;
+      if (r < W1) {
+        if (!p.itp_mask || (r >= c && r < T)) continue;           // rows of padded image / text positions: "don't care" (nobody attends to them)
+        for (int j = lane; j < W1; j += 64) {
+          const bool want = (j < c) || (r == T && j == T);        // valid prefix (+ the proprio row sees itself); prefix rows never see the proprio key
+          if (vls_mask_open(p.itp_mask, p.mask_dtype, (size_t)(b * p.itp_bs + r * p.itp_rs + j)) != want) bad |= (r == T && j < T) ? 1 : 2;    // 1: the valid prefix is not contiguous
+        }
+      } else {
+        if (!p.action_mask) continue;
+        const int a = r - W1;
+        for (int j = lane; j < W2; j += 64) {
+          const bool want = (j < c) || (j >= T);                   // valid prefix + proprio + every action token
+          if (vls_mask_open(p.action_mask, p.mask_dtype, (size_t)(b * p.act_bs + a * p.act_rs + j)) != want) bad |= 4;
+        }
+      }
+    }
+    if (bad && p.ctr) atomicOr(&p.ctr[1 + (p.call_no & 1)], bad);
+    return;
+  }
+  const int pb0 = 1 + p.n_mask_blocks;
+  const long long stride = (long long)(gridDim.x - pb0) * 256;
   const float r255 = (float)(1.0 / 255.0);
-  for (long long i = (long long)(blockIdx.x - 1) * 256 + tid; i < p.n_pix8; i += stride) {
+  for (long long i = (long long)(blockIdx.x - pb0) * 256 + tid; i < p.n_pix8; i += stride) {
     u32x4 o;
     if (p.pix_dtype == 0) {
       o = reinterpret_cast<const u32x4*>(p.pix)[i];
@@ -794,6 +869,11 @@ extern "C" int vlaser_vla_stage(const VlaserVlaStageArgs* a, vl_stream_t s) {
   VL_CHECK(a->n_pix == 0 || (a->pix && a->pix_out && a->n_pix % 8 == 0 && a->pix_dtype >= 0 && a->pix_dtype <= 2), "vlaser_vla_stage: pixel count must be a multiple of 8, dtype 0 bf16 / 1 f32 / 2 u8");
   VL_CHECK(a->n_pix == 0 || a->pix_dtype != 2 || (a->hw > 0 && a->hw % 8 == 0), "vlaser_vla_stage: uint8 pixels need H*W (a multiple of 8)");
   VL_CHECK(a->n_pix == 0 || ((((uintptr_t)a->pix) & (a->pix_dtype == 2 ? 7 : 15)) == 0 && (((uintptr_t)a->pix_out) & 15) == 0), "vlaser_vla_stage: pixel buffers must be 16-byte (uint8: 8-byte) aligned");
+  const bool masks = a->itp_mask || a->action_mask;
+  VL_CHECK(!masks || (a->call_ctr && a->mask_dtype >= 0 && a->mask_dtype <= 2 && a->n_act >= 1 && a->n_act <= 64),
+           "vlaser_vla_stage: dense masks need the call-counter / error words, mask_dtype 0 bf16 / 1 f32 / 2 f16 and 1..64 action tokens");
+  VL_CHECK((!a->pos_vlm || a->pos_vlm_out) && (!a->pos_pro || a->pos_pro_out) && (!a->pos_act || (a->pos_act_out && a->n_act >= 1)), "vlaser_vla_stage: position-id slots missing");
+  VL_CHECK(!a->pos_ride_out || (a->B == 1 && a->n_act >= 1 && a->n_act < 256), "vlaser_vla_stage: pos_ride_out is the batch-1 [proprio | action] position row");
   VlaStageP p;
   p.ids = a->ids; p.ids_out = a->ids_out; p.B = a->B; p.T = a->T; p.pad_id = a->pad_id;
   p.valid_in = a->valid_in; p.valid_is_i64 = a->valid_is_i64; p.valid_out = a->valid_out;
@@ -801,10 +881,16 @@ extern "C" int vlaser_vla_stage(const VlaserVlaStageArgs* a, vl_stream_t s) {
   p.noise = a->noise; p.noise_out = a->noise_out; p.n_noise = a->n_noise;
   p.pix = a->pix; p.pix_out = (bf16_t*)a->pix_out; p.n_pix8 = a->n_pix / 8; p.pix_dtype = a->pix_dtype; p.hw = a->hw;
   p.m0 = a->mean[0]; p.m1 = a->mean[1]; p.m2 = a->mean[2]; p.s0 = a->std[0]; p.s1 = a->std[1]; p.s2 = a->std[2];
-  p.ctr = a->call_ctr;
+  p.ctr = a->call_ctr; p.call_no = a->call_no;
+  p.itp_mask = a->itp_mask; p.action_mask = a->action_mask; p.mask_dtype = a->mask_dtype; p.n_act = a->n_act > 0 ? a->n_act : 0;
+  p.itp_bs = a->itp_bs > 0 ? a->itp_bs : (long long)(a->T + 1) * (a->T + 1); p.itp_rs = a->itp_rs > 0 ? a->itp_rs : a->T + 1;
+  p.act_bs = a->act_bs > 0 ? a->act_bs : (long long)a->n_act * (a->T + 1 + a->n_act); p.act_rs = a->act_rs > 0 ? a->act_rs : a->T + 1 + a->n_act;
+  p.n_mask_blocks = masks ? a->B * ((a->T + 1 + a->n_act + VLS_ROWS_PER_BLOCK - 1) / VLS_ROWS_PER_BLOCK) : 0;
+  p.pos_vlm = a->pos_vlm; p.pos_pro = a->pos_pro; p.pos_act = a->pos_act;
+  p.pos_vlm_out = a->pos_vlm_out; p.pos_pro_out = a->pos_pro_out; p.pos_act_out = a->pos_act_out; p.pos_ride_out = a->pos_ride_out;
   long long pb = (p.n_pix8 + 255) / 256;
   if (pb > 1024) pb = 1024;
-  hipLaunchKernelGGL(vla_stage_kernel, dim3(1 + (int)pb), dim3(256), 0, (hipStream_t)s, p);
+  hipLaunchKernelGGL(vla_stage_kernel, dim3(1 + p.n_mask_blocks + (int)pb), dim3(256), 0, (hipStream_t)s, p);
   VL_LAUNCH_CHECK();
   return 0;
 }

@@ -470,9 +470,9 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
     }  // SP < 0
     __syncthreads();
     STAMP(1);
-    if constexpr (EARLY) {                     // block-uniform conditions; hipcc then waits for all of them at the first use: fine,
-      if (ucount > 1) load_unit(1, nw, ne);    // they were requested ~2 us before anything consumes them
-#pragma unroll
+    if constexpr (EARLY) {                     // block-uniform conditions; hipcc then waits for all of them at the first use -- and, read in the ISA in r05, puts an
+      if (ucount > 1) load_unit(1, nw, ne);    // `s_waitcnt vmcnt(0)` in FRONT of each of these blocks: the units stream one after the other.  csrc/chain.hip's
+#pragma unroll                                 // chain_gu requests everything up front and replaces this path wherever it has a variant
       for (int u = 2; u < UE; ++u)
         if (ucount > u) load_unit(u, ew[u - 2], te);
     }
@@ -754,11 +754,8 @@ static int launch(const VlaserSkinnyArgs* a, hipStream_t stream) {
     vlaser_set_error("vlaser_skinny: tiles_per_unit = 1 is built for PLAIN + PARTIAL (5 / 7 K-steps per wave), ATTN + PARTIAL (2 / 3) and NORM + SWIGLU / QKV_ROPE (3 / 6)");
     return -1;
   }
-  if (a->tiles_per_unit == 6) {
-    if constexpr (PRO == VL_PRO_NORM && EPI == VL_SK_SWIGLU) {
-      if (ns == 3) return launch_ns<PRO, EPI, 6, 3>(a, stream);
-    }
-    vlaser_set_error("vlaser_skinny: tiles_per_unit = 6 is only built for NORM + SWIGLU with K = 768");
+  if (a->tiles_per_unit == 6) {      // 96-row units (r01: 12.3 vs 11.2 us for the expert's gate/up, and 380 B of scratch): removed in r05
+    vlaser_set_error("vlaser_skinny: tiles_per_unit = 6 is no longer built (slower than 32-row units and the only variant that spilled)");
     return -1;
   }
   switch (ns) {
@@ -788,7 +785,7 @@ extern "C" int vlaser_skinny(int pro, int epi, const VlaserSkinnyArgs* a, vl_str
   VL_CHECK(a->M >= 1 && a->M <= 16, "vlaser_skinny: M=%d must be in 1..16", a->M);
   VL_CHECK(a->k_splits >= 1 && a->K % (a->k_splits * 32 * SKW) == 0, "vlaser_skinny: K=%d not divisible by k_splits*%d (k_splits=%d)", a->K,
            32 * SKW, a->k_splits);
-  VL_CHECK(a->tiles_per_unit == 0 || a->tiles_per_unit == 1 || a->tiles_per_unit == 2 || a->tiles_per_unit == 6, "vlaser_skinny: tiles_per_unit must be 1, 2 or 6");
+  VL_CHECK(a->tiles_per_unit == 0 || a->tiles_per_unit == 1 || a->tiles_per_unit == 2, "vlaser_skinny: tiles_per_unit must be 1 or 2");
   VL_CHECK(a->N % (a->tiles_per_unit == 6 ? 96 : (a->tiles_per_unit == 1 ? 16 : 32)) == 0,
            "vlaser_skinny: N=%d must be a multiple of the unit height (pack_skinny pads the weight rows; pass n_valid)", a->N);
   VL_CHECK(a->n_valid <= a->N && (a->n_valid <= 0 || a->n_valid > a->N - (a->tiles_per_unit == 6 ? 96 : (a->tiles_per_unit == 1 ? 16 : 32))),

@@ -59,6 +59,10 @@ class QwenLayerWeights:
             else:
                 self.sk_gu = ops.pack_skinny(wgu, 1, 2)
             self.sk_down = ops.pack_skinny(wdown, ks_down, tpu_down, k_pad=i_pad)
+            # 'chain' (r05, csrc/chain.hip): the down projection without cross-workgroup split-K (4 output columns per workgroup over the whole K) publishes the next
+            # layer's residual stream as bf16; needs the 16-row q/k/v packing and the MLP width the kernel is built for
+            self.sk_down4 = (ops.pack_down4(wdown) if ('chain' in opts and 'qkv16' in opts and wdown.shape[1] == ops.DOWN4_WAVES * ops.DOWN4_LOADS * 128
+                                                       and wdown.shape[0] % 4 == 0) else None)
 
 
 class QwenStack:
@@ -270,7 +274,7 @@ class SkinnyBuffers:
         llm = stack.llm
         H, I = llm.hidden_size, llm.intermediate_size
         z = lambda *s: torch.zeros(*s, dtype=BF, device=device)
-        self.hA, self.hB = z(max_rows, H), z(max_rows, H)
+        self.hA, self.hB, self.hC = z(max_rows, H), z(max_rows, H), z(max_rows, H)      # hC: the residual stream as `vlaser_chain_down` publishes it
         self.q = z(max_rows, stack.nq * llm.head_dim)
         self.ao = z(max_rows, stack.nq * llm.head_dim)
         self.act = z(max_rows, getattr(stack, 'I_pad', I))      # zero padding columns (never written) feed the zero-padded down weight
@@ -304,9 +308,15 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
     fuse_ao = ('fuse_ao' in stack.opts and not fuse and not skip_post_attn and getattr(lw, 'sk_ao', None) is not None
                and ops.attn_oproj_supported(nq, nkv, tok_per_batch, batch, hd, llm.hidden_size) and nkv <= sb.part_o.shape[0]
                and attn_mode in (L.ATTN_FULL, L.ATTN_PREFIX) and (attn_mode == L.ATTN_FULL or blk_start % 16 == 0))
+    # 'chain' (r05): qkv / gate-up / down on the latency-built kernels of csrc/chain.hip -- the layer takes a residual stream that is already reduced (n_partials == 0:
+    # the action encoder's output, or what the previous layer's vlaser_chain_down published) and hands on (hC, None, 0)
+    H_, I_ = llm.hidden_size, llm.intermediate_size
+    chain = ('chain' in stack.opts and not fuse and not fuse_ao and n_partials == 0 and getattr(lw, 'sk_down4', None) is not None and lw.sk_qkv.tpu == 1
+             and lw.sk_gu.tpu == 2 and ops.chain_qkv_supported(M, lw.sk_qkv.N, H_) and ops.chain_gu_supported(M, lw.sk_gu.N, H_, stack.ks_o)
+             and ops.chain_down_supported(M, H_, I_) and sb.act.shape[1] == I_ and h_in.data_ptr() != sb.hB.data_ptr())
     key = (layer, M, tok_per_batch, attn_mode, h_in.data_ptr(), 0 if partials is None else partials.data_ptr(), n_partials,
            0 if valid_len is None else valid_len.data_ptr(), pos_ids.data_ptr(), cache.k.data_ptr(), skip_post_attn, first_tok_kv_len,
-           sync.data_ptr() if fuse else 0, fuse_ao)
+           sync.data_ptr() if fuse else 0, fuse_ao, chain)
     plan = sb.plans.get(key)
     if plan is None:
         ks, vs = cache.strides()
@@ -321,9 +331,10 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
         if not skip_post_attn:
             plan.o = ops.skinny_args(None, lw.sk_o, M, out_f32=sb.part_o, attn_m=sb.attn_parts[0], attn_l=sb.attn_parts[1],
                                      attn_o=sb.attn_parts[2], attn_splits=1, attn_group=nq // nkv, attn_nq=tok_per_batch)
-            plan.gu = ops.skinny_args(sb.hA, lw.sk_gu, M, partials=sb.part_o, n_partials=nkv if fuse_ao else stack.ks_o, norm_w=lw.ln_post,
+            # (chain: vlaser_chain_qkv leaves no rounded copy of the residual stream behind -- its input already IS the rounded stream)
+            plan.gu = ops.skinny_args(h_in if chain else sb.hA, lw.sk_gu, M, partials=sb.part_o, n_partials=nkv if fuse_ao else stack.ks_o, norm_w=lw.ln_post,
                                       eps=llm.rms_norm_eps, h_out=sb.hB, out=sb.act, ldo=sb.act.shape[1])
-            plan.down = ops.skinny_args(sb.act, lw.sk_down, M, out_f32=sb.part_d)
+            plan.down = SimpleNamespace(dbg=None) if chain else ops.skinny_args(sb.act, lw.sk_down, M, out_f32=sb.part_d)
             if fuse:
                 plan.ogu = ops.fused_ogu_args(sb.attn_parts, lw.sk_o, sb.part_o, sb.hA, lw.ln_post, llm.rms_norm_eps, sb.hB, lw.sk_gu, M, sb.act, sync,
                                               nsp, nq // nkv, tok_per_batch)
@@ -333,9 +344,25 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
     stream = torch.cuda.current_stream().cuda_stream
     plan.qkv[0].slot_base = slot_base
     if 'qkv' not in skip:                 # `skip` (bench.py only): in-chain timing of one launch = chain with it - chain without it
-        ops.launch_skinny(L.PRO_NORM, L.SK_QKV_ROPE, plan.qkv[0], stream)
+        if chain:
+            ops.launch_chain_qkv(plan.qkv[0], stream)
+        else:
+            ops.launch_skinny(L.PRO_NORM, L.SK_QKV_ROPE, plan.qkv[0], stream)
     a = plan.attn
     a.kv_len, a.n_splits, a.blk_start = kv_len, nsp, blk_start
+    if chain:
+        if skip_post_attn:
+            return h_in, None, 0
+        if 'attn' not in skip:
+            ops.launch_attn_skinny(a, stream)
+        plan.o[0].attn_splits = nsp
+        if 'o' not in skip:
+            ops.launch_skinny(L.PRO_ATTN, L.SK_PARTIAL, plan.o[0], stream)
+        if 'gu' not in skip:
+            ops.launch_chain_gu(plan.gu[0], stream)
+        if 'down' not in skip:
+            ops.chain_down(sb.act, lw.sk_down4, sb.hB, sb.hC, M, H_, I_, dbg=plan.down.dbg, stream=stream)
+        return sb.hC, None, 0
     if fuse_ao:
         if 'attn' not in skip and 'o' not in skip:
             ops.launch_attn_oproj(a, lw.sk_ao, sb.part_o, llm.hidden_size, stream)

@@ -312,6 +312,46 @@ def skinny(pro, epi, x, W: PackedW, M, **kw):
     launch_skinny(pro, epi, a)
 
 
+# ---- r05 latency chain (csrc/chain.hip)
+DOWN4_WAVES, DOWN4_LOADS = 7, 10          # K = 7 waves x 10 loads x 128 = 8960 (Qwen2.5-1.5B / action-expert MLP width)
+
+
+def pack_down4(W, nw=DOWN4_WAVES, nl=DOWN4_LOADS):
+    """down_proj.weight [N, K] -> [N/4][nw waves][nl loads][64 lanes][8] bf16 for vlaser_chain_down: lane (b = lane >> 2, i = lane & 3) of wave w, load l holds
+    W[4 g + i, (w nl + l) 128 + 8 b : + 8] -- one contiguous 1 KiB per wave-level load, one contiguous stream per workgroup (4 output columns over the whole K)."""
+    N, K = W.shape
+    assert N % 4 == 0 and K == nw * nl * 128, (N, K)
+    v = W.view(N // 4, 4, nw, nl, 16, 8)                  # [g, i, w, l, b, e]
+    return v.permute(0, 2, 3, 4, 1, 5).contiguous().reshape(-1)      # [g, w, l, b, i, e]
+
+
+def chain_qkv_supported(M, N, K):
+    return bool(L.lib().vlaser_chain_qkv_supported(M, N, K))
+
+
+def chain_gu_supported(M, N, K, n_partials):
+    return bool(L.lib().vlaser_chain_gu_supported(M, N, K, n_partials))
+
+
+def chain_down_supported(M, N, K):
+    return bool(L.lib().vlaser_chain_down_supported(M, N, K))
+
+
+def launch_chain_qkv(a, stream=None):
+    L.check(L.lib().vlaser_chain_qkv(C.byref(a), _stream() if stream is None else stream), 'vlaser_chain_qkv')
+
+
+def launch_chain_gu(a, stream=None):
+    L.check(L.lib().vlaser_chain_gu(C.byref(a), _stream() if stream is None else stream), 'vlaser_chain_gu')
+
+
+def chain_down(x, W4, res, h_out, M, N, K, dbg=None, stream=None):
+    """h_out[M, N] = bf16(res + x[M, :K] @ W^T), W4 = pack_down4(W)."""
+    assert x.dtype == BF16 and res.dtype == BF16 and h_out.dtype == BF16 and x.stride(-1) == 1 and res.data_ptr() != h_out.data_ptr()
+    L.check(L.lib().vlaser_chain_down(x.data_ptr(), x.stride(0), W4.data_ptr(), res.data_ptr(), h_out.data_ptr(), M, N, K, dbg if isinstance(dbg, int) else _p(dbg),
+                                      _stream() if stream is None else stream), 'vlaser_chain_down')
+
+
 def fused_ogu_args(attn_parts, Wo: PackedW, part_o, h_in, norm_w, eps, h_out, Wgu: PackedW, M, act, sync, attn_splits, attn_group, attn_nq, cons_delay=None, dbg=None):
     """Filled VlaserFusedOguArgs: o_proj (attention-split merge + split-K partial tiles) handed to gate/up (+ residual, RMSNorm, SwiGLU) inside ONE
     launch (csrc/euler.hip).  `sync`: int32 view of VL_FUSED_SYNC_WORDS words, zeroed by the caller on the stream before every launch."""
@@ -449,9 +489,17 @@ def vla_euler(h_in, partials, n_partials, M, norm_w, eps, wd, bd, action, W, adi
 _PIX_DTYPES = {torch.bfloat16: 0, torch.float32: 1, torch.uint8: 2}
 
 
-def vla_stage(ids, ids_out, valid_in, valid_out, proprio, proprio_out, noise, noise_out, pix, pix_out, pad_id, mean, std, call_ctr=None):
+_MASK_DTYPES = {torch.bfloat16: 0, torch.float32: 1, torch.float16: 2}
+
+
+def vla_stage(ids, ids_out, valid_in, valid_out, proprio, proprio_out, noise, noise_out, pix, pix_out, pad_id, mean, std, call_ctr=None, call_no=0,
+              masks=None, n_act=0, positions=None, pos_out=None):
     """All per-call inputs of infer_action into the chunk graph's static slots in ONE launch (device tensors, contiguous).  pix: bf16 / fp32
-    (already normalised) or uint8 [n,3,H,W] (normalised here, InternVLAProcessor arithmetic); valid_in: int32 / int64 [B] or None (= count of ids != pad_id)."""
+    (already normalised) or uint8 [n,3,H,W] (normalised here, InternVLAProcessor arithmetic); valid_in: int32 / int64 [B] or None (= zero count of the dense
+    mask's proprio row when `masks` is given, else the count of ids != pad_id).  masks = (image_text_proprio_mask | None, action_mask | None): the
+    reference's dense additive masks, checked on the device against the prefix + trailing-block pattern (error word in call_ctr, see the header).
+    positions = (vlm | None, proprio | None, action | None) int64 device tensors -> pos_out = (vlm, proprio, action, ride | None) int32 slots.
+    call_ctr: int32[3] {call number, error word of even calls, of odd calls}; call_no: this call's number (host-owned)."""
     a = L.VlaStageArgs()
     B, T = ids.shape
     assert ids.dtype == torch.int64 and ids.is_cuda and ids.is_contiguous()
@@ -462,6 +510,10 @@ def vla_stage(ids, ids_out, valid_in, valid_out, proprio, proprio_out, noise, no
     a.valid_out = valid_out.data_ptr()
     for t in (proprio, noise):
         assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous()
+    # the C side never sees the capacities of the slots it copies into: a wrong proprio_dim / action_dim / horizon must not become an out-of-bounds device write
+    if proprio_out.numel() < proprio.numel() or noise_out.numel() < noise.numel() or valid_out.numel() < B or ids_out.numel() < ids.numel():
+        raise ValueError(f'vla_stage: slot smaller than its input (proprio {proprio.numel()} -> {proprio_out.numel()}, noise {noise.numel()} -> {noise_out.numel()}, '
+                         f'ids {ids.numel()} -> {ids_out.numel()}, valid_len {B} -> {valid_out.numel()})')
     a.proprio, a.proprio_out, a.n_proprio = proprio.data_ptr(), proprio_out.data_ptr(), proprio.numel()
     a.noise, a.noise_out, a.n_noise = noise.data_ptr(), noise_out.data_ptr(), noise.numel()
     assert pix.is_cuda and pix.is_contiguous() and pix.dtype in _PIX_DTYPES and pix_out.dtype == BF16 and pix_out.numel() >= pix.numel()
@@ -469,7 +521,39 @@ def vla_stage(ids, ids_out, valid_in, valid_out, proprio, proprio_out, noise, no
     a.hw = pix.shape[-1] * pix.shape[-2]
     for i in range(3):
         a.mean[i], a.std[i] = mean[i], std[i]
-    a.call_ctr = _p(call_ctr)
+    a.call_ctr, a.call_no = _p(call_ctr), call_no
+    if call_ctr is not None:
+        assert call_ctr.dtype == torch.int32 and call_ctr.numel() >= 3
+    a.n_act = n_act
+    if masks is not None and (masks[0] is not None or masks[1] is not None):
+        m1, m2 = masks
+        dts = {m.dtype for m in (m1, m2) if m is not None}
+        if len(dts) != 1 or next(iter(dts)) not in _MASK_DTYPES:
+            raise ValueError(f'vla_stage: the dense masks must share one dtype out of bf16 / fp32 / fp16, got {dts}')
+        a.mask_dtype = _MASK_DTYPES[next(iter(dts))]
+        if m1 is not None:
+            if tuple(m1.shape) != (B, 1, T + 1, T + 1):
+                raise ValueError(f'image_text_proprio_mask must be [{B},1,{T + 1},{T + 1}], got {tuple(m1.shape)}')
+            assert m1.is_cuda and m1.stride(-1) == 1, 'image_text_proprio_mask: rows must be contiguous (any batch / row stride)'
+            a.itp_mask, a.itp_bs, a.itp_rs = m1.data_ptr(), m1.stride(0), m1.stride(2)
+        if m2 is not None:
+            if tuple(m2.shape) != (B, 1, n_act, T + 1 + n_act):
+                raise ValueError(f'action_mask must be [{B},1,{n_act},{T + 1 + n_act}], got {tuple(m2.shape)}')
+            assert m2.is_cuda and m2.stride(-1) == 1, 'action_mask: rows must be contiguous (any batch / row stride)'
+            a.action_mask, a.act_bs, a.act_rs = m2.data_ptr(), m2.stride(0), m2.stride(2)
+    if positions is not None:
+        want = ((B, T), (B, 1), (B, n_act))
+        for name, t, o, shp in zip(('pos_vlm', 'pos_pro', 'pos_act'), positions, pos_out[:3], want):
+            if t is None:
+                continue
+            if tuple(t.shape) != shp:
+                raise ValueError(f'{name}: position ids must be {list(shp)}, got {tuple(t.shape)}')
+            assert t.dtype == torch.int64 and t.is_cuda and t.is_contiguous() and o.dtype == torch.int32 and o.numel() >= t.numel()
+            setattr(a, name, t.data_ptr())
+            setattr(a, name + '_out', o.data_ptr())
+        if len(pos_out) > 3 and pos_out[3] is not None and positions[1] is not None and positions[2] is not None:
+            assert B == 1 and pos_out[3].numel() >= 1 + n_act
+            a.pos_ride_out = pos_out[3].data_ptr()
     L.check(L.lib().vlaser_vla_stage(C.byref(a), _stream()), 'vlaser_vla_stage')
 
 

@@ -117,9 +117,16 @@ class PiZero:
     #          10.9 vs 16.3 us in isolation, -0.085 ms per chunk in-chain (tools/micro/vla_step_lab.py, ab_chunk.py) -- ON.  Not bit-identical to the
     #          4-launch path (linear_1 / time embedding folded into linear_2 in fp32): same tolerance against oracle and goldens
     # measurements + in-kernel timelines: profiles/r03c_euler_fusion.md
-    EULER_DEFAULT = 'qkv16,glue1'
+    #   chain (r05, needs qkv16): q/k/v, gate/up and the down projection on the latency-built kernels of csrc/chain.hip -- every request of a launch issued up front,
+    #          one wave per q/k/v unit, the down projection publishing the bf16 residual stream once (no split-K slabs for the next layer to re-reduce): ON.  Same
+    #          tolerance against oracle / goldens as the skinny kernels; gate/up bit-identical, q/k/v and down sum in a different fp32 order
+    EULER_DEFAULT = 'qkv16,glue1,chain'
 
-    def __init__(self, cfg: VLAConfig, device='cuda', max_batch=1, use_graph=True, ride_proprio=True, naive_support=False, euler_opts=None, output_ring=4):
+    ERR_BITS = {1: 'image_text_proprio_mask: the keys the proprio row sees are not a contiguous valid prefix',
+                2: 'image_text_proprio_mask: a valid-prefix row (or the proprio row\'s own key) does not have the prefix pattern of build_causal_mask_and_position_ids',
+                4: 'action_mask: an action row does not see exactly {valid prefix, proprio, every action token}'}
+
+    def __init__(self, cfg: VLAConfig, device='cuda', max_batch=1, use_graph=True, ride_proprio=True, naive_support=False, euler_opts=None, output_ring=0):
         L.lib()
         if not torch.cuda.is_available():
             raise L.VlaserHipError('vlaser_amd needs an MI355X (gfx950) GPU: there is no CPU fallback')
@@ -144,10 +151,13 @@ class PiZero:
         self.euler_opts = tuple(x for x in eo.split(',') if x and x != 'none')
         self._graphs = {}
         self._pos_state = None
-        # infer_action returns a VIEW of slot (call number mod output_ring) of a small result ring written by the chunk's last kernel: valid until
-        # `output_ring` further calls have been made (the reference returns a fresh tensor; output_ring=0 restores that with a clone launch per call)
+        # output_ring = 0 (default): infer_action returns a FRESH tensor, as the reference does (pizero_internvl.py:934-936).  output_ring = n > 0 (opt-in, serving
+        # loops / bench.py): it returns a VIEW of slot (call number mod n) of a small result ring written by the chunk's last kernel -- no copy launch, but the
+        # view is overwritten n calls later
         self.output_ring = int(output_ring)
         self._calls = 0
+        self._err_pending = []                  # (event, pinned int32[4] snapshot of call_ctr) of calls that passed dense masks and were not polled yet
+        self._err_pins = None
         if max_batch * cfg.num_action_tokens > 16:
             raise ValueError('the weight-streaming action path handles batch * horizon <= 16 rows')
 
@@ -217,31 +227,33 @@ class PiZero:
         self.pos_pro = z(B, dt=torch.int32)
         self.pos_act = z(B * self.num_action_tokens, dt=torch.int32)
         self.pos5 = z(16, dt=torch.int32)
-        self.call_ctr = z(1, dt=torch.int32)
-        self.out_ring = z(max(self.output_ring, 1), 16 * cfg.action_dim, dt=torch.float32)
+        self.call_ctr = z(4, dt=torch.int32)    # {call number, error word of even calls, error word of odd calls, pad}: vlaser_vla_stage / vlaser_vla_euler
+        self.out_ring = z(max(self.output_ring, 4), 16 * cfg.action_dim, dt=torch.float32)      # >= 4 slots: `output_ring` may be switched on later without re-capturing the graph
         self._calls = 0
+        self._err_pending = []
+        self._pos_defaults = {}
         # where the per-call noise is staged: straight into the buffer the first launch of the Euler phase reads ('glue1': the ping-pong buffer the
         # integration starts from -- r03 copied in_noise there inside the graph)
         n = cfg.num_inference_steps
-        self._glue1 = 'glue1' in self.euler_opts and n >= 2 and W % 256 == 0 and W <= 1024
+        self._glue1 = 'glue1' in self.euler_opts and n >= 2 and W % 256 == 0 and W <= (1024 if cfg.action_dim <= 8 else 768)
         self.noise_dst = (self.action, self.action_b)[(n - 1) % 2] if self._glue1 else self.in_noise
 
-    def _stage_positions(self, B, vlm_position_ids, proprio_position_ids, action_position_ids):
-        """Position ids into the static buffers of the captured graph.  The reference's defaults (1..T, 1, 2..1+na; pizero_internvl.py:576-585)
-        are written ONCE per batch size: a per-call host tensor -> device copy from pageable memory makes the host wait for the previous
-        chunk, so every call started its ~10 small staging launches on an idle GPU (0.5 ms per chunk in r02's bench loop)."""
-        T, na = self.max_image_text_tokens, self.num_action_tokens
+    def _positions_for_stage(self, B, vlm_position_ids, proprio_position_ids, action_position_ids):
+        """The three position-id tensors the staging launch has to write this call, as int64 DEVICE tensors, or None when the slots already hold what is
+        asked for.  The reference passes them on every call (eval.py:110-128; values 1..T, 1, 2..1+na: pizero_internvl.py:576-585): they are converted
+        int64 -> int32 slots by `vlaser_vla_stage` itself -- r04 issued five small host-staged copies per call whenever they were given.  With all three
+        None the defaults are written once per batch size."""
+        T, na, dev = self.max_image_text_tokens, self.num_action_tokens, self.device
         custom = not (vlm_position_ids is None and proprio_position_ids is None and action_position_ids is None)
         if not custom and self._pos_state == ('default', B):
-            return
-        bpos = lambda p, default: (default if p is None else p).to(torch.int32).reshape(-1)
-        self.pos_vlm[:B * T].copy_(bpos(vlm_position_ids, torch.arange(1, T + 1).repeat(B, 1)))
-        self.pos_pro[:B].copy_(bpos(proprio_position_ids, torch.ones(B, 1, dtype=torch.long)))
-        self.pos_act[:B * na].copy_(bpos(action_position_ids, torch.arange(2, 2 + na).repeat(B, 1)))
-        if B == 1:
-            self.pos5[:1].copy_(self.pos_pro[:1])
-            self.pos5[1:1 + na].copy_(self.pos_act[:na])
+            return None
+        d = self._pos_defaults.get(B)
+        if d is None:
+            d = self._pos_defaults[B] = (torch.arange(1, T + 1, device=dev).repeat(B, 1), torch.ones(B, 1, dtype=torch.long, device=dev),
+                                         torch.arange(2, 2 + na, device=dev).repeat(B, 1))
+        on = lambda t, dflt: dflt if t is None else t.to(device=dev, dtype=torch.int64, non_blocking=True).contiguous()
         self._pos_state = ('custom', B) if custom else ('default', B)
+        return on(vlm_position_ids, d[0]), on(proprio_position_ids, d[1]), on(action_position_ids, d[2])
 
     # ------------------------------------------------------------------ reference helpers (API parity)
     def build_causal_mask_and_position_ids(self, attention_mask, dtype):
@@ -344,7 +356,7 @@ class PiZero:
                 h, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_act, h, parts, npart, self.cache, i, self.rope,
                                                self.pos_act, B, na, T + 1, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len,
                                                blk_start=T, skip=skip, sync=sync(s, i))
-            ring = (self.out_ring, self.call_ctr) if (self.output_ring > 0 and s == n - 1) else (None, None)
+            ring = (self.out_ring, self.call_ctr) if s == n - 1 else (None, None)
             ops.vla_euler(h, parts, npart, M, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action, W, cfg.action_dim, dt,
                           clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel_trace[s], ring=ring[0], ring_ctr=ring[1])
 
@@ -393,7 +405,7 @@ class PiZero:
                                                    blk_start=T, skip=skip, sync=sync(s, i))
                 fin = (h, parts, npart, M, 0, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b)
         assert acts[p] is self.action
-        ring = (self.out_ring, self.call_ctr) if self.output_ring > 0 else (None, None)
+        ring = (self.out_ring, self.call_ctr)     # always: the caller's copy (a 1-slot ring when output_ring == 0) is where an unsupported mask turns into NaN
         ops.vla_euler(fin[0], fin[1], fin[2], M, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action, W, ad, dt,
                       clip if clip is not None else 0.0, clip is not None, vel_out=self.vel_trace[n - 1], ring=ring[0], ring_ctr=ring[1])
 
@@ -413,17 +425,20 @@ class PiZero:
                 outs.append(self.infer_action(input_ids[lo:hi], pixel_values[lo * ni:hi * ni], sl(image_text_proprio_mask, lo, hi),
                                               sl(action_mask, lo, hi), sl(vlm_position_ids, lo, hi), sl(proprio_position_ids, lo, hi),
                                               sl(action_position_ids, lo, hi), sl(proprios, lo, hi), sl(noise, lo, hi), generator,
-                                              sl(valid_len, lo, hi)).clone())      # (each group's result is a view of the output ring)
-            return torch.cat(outs, 0)
+                                              sl(valid_len, lo, hi)))
+            return torch.cat(outs, 0)             # (a copy: also with output_ring > 0, where each group's result is a view of the ring)
         if input_ids.shape != (B, T):
             raise ValueError(f'input_ids must be [B,{T}] (right-padded with pad_token_id), got {tuple(input_ids.shape)}')
-        # ---- stage inputs into the static slots of the captured graph: ONE launch (vlaser_vla_stage) once the tensors are on the device
-        if valid_len is None and image_text_proprio_mask is not None:
-            valid_len = prep.mask_to_descriptor(image_text_proprio_mask.to('cpu'), T)
+        # ---- stage inputs into the static slots of the captured graph: ONE launch (vlaser_vla_stage) once the tensors are on the device.  The reference's
+        # dense masks are NOT copied to the host: valid_len is counted from the mask's proprio row on the device and both masks are checked there against the
+        # pattern the kernels' (valid_len, blk_start) descriptors express (an unsupported mask -> NaN result + ValueError at the next poll, never a silent
+        # mis-service: `action_mask` was accepted and ignored until r04)
+        self._poll_errors(block=False)
         if noise is None:
             noise = torch.randn((B, na, cfg.action_dim), generator=generator)      # reference: torch.randn inside (:879-881)
-        self._stage_inputs(B, input_ids, pixel_values, proprios, noise, valid_len)
-        self._stage_positions(B, vlm_position_ids, proprio_position_ids, action_position_ids)
+        masks = None if (image_text_proprio_mask is None and action_mask is None) else (image_text_proprio_mask, action_mask)
+        positions = self._positions_for_stage(B, vlm_position_ids, proprio_position_ids, action_position_ids)
+        self._stage_inputs(B, input_ids, pixel_values, proprios, noise, valid_len, masks, positions)
         # ---- run (HIP graph replay after the first call per batch size)
         if self.use_graph:
             gs = self._graphs.get(B)
@@ -446,22 +461,59 @@ class PiZero:
                 self._graphs[B] = gs
                 # the warm-up run integrated the staged noise away (it is staged straight into the Euler phase's start buffer, and the graph holds no
                 # copy of it any more): stage this call's inputs once more in front of the first replay
-                self._stage_inputs(B, input_ids, pixel_values, proprios, noise, valid_len)
+                self._stage_inputs(B, input_ids, pixel_values, proprios, noise, valid_len, masks, positions)
             for g in gs:
                 g.replay()
         else:
             self._run(B)
-        if self.output_ring > 0:
-            act = self.out_ring[self._calls % self.output_ring, :B * na * cfg.action_dim].view(B, na, cfg.action_dim)
-            return act[:, -cfg.horizon_steps:]
-        act = self.action[:B * na].view(B, na, cfg.action_dim)
-        return act[:, -cfg.horizon_steps:].clone()
+        if masks is not None:
+            # snapshot of {call number, error words} behind the chunk, into pinned host memory: polled at the NEXT call / by check_errors(), never waited for here
+            if self._err_pins is None:
+                self._err_pins = [torch.empty(4, dtype=torch.int32).pin_memory() for _ in range(12)]      # > 8 outstanding + the ones being read
+            pin = self._err_pins[self._calls % len(self._err_pins)]
+            pin.copy_(self.call_ctr, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._err_pending.append((ev, pin))
+            if len(self._err_pending) > 8:        # a host running more than 8 calls ahead of the device waits for the oldest one
+                self._poll_errors(block=False, at_most_pending=8)
+        slot = self._calls % self.out_ring.shape[0]
+        act = self.out_ring[slot, :B * na * cfg.action_dim].view(B, na, cfg.action_dim)[:, -cfg.horizon_steps:]
+        return act if self.output_ring > 0 else act.clone()
 
-    def _stage_inputs(self, B, input_ids, pixel_values, proprios, noise, valid_len):
-        """Host / device plumbing of one call's inputs (the reference moves them with .to(device) in its agent loop, eval.py:117-128): anything not yet
-        on the device is copied there, then `vlaser_vla_stage` writes every slot in one launch -- ids, valid_len (given, or counted from the pad ids),
-        proprio, noise (straight into the buffer the Euler phase starts from) and the pixels (bf16 / fp32 -> bf16, or the raw uint8 observation normalised
-        on the device) -- and advances the call counter that selects the result slot."""
+    def _poll_errors(self, block, at_most_pending=0):
+        """Raise for a finished call whose dense masks the kernels cannot honour (error word written by `vlaser_vla_stage`).  block=False looks only at calls
+        the device has completed (no synchronisation), except that it waits until at most `at_most_pending` snapshots are outstanding."""
+        keep = []
+        pend, self._err_pending = self._err_pending, []
+        n_wait = len(pend) - at_most_pending if at_most_pending else 0
+        bad = None
+        for i, (ev, pin) in enumerate(pend):
+            if block or i < n_wait:
+                ev.synchronize()
+            elif not ev.query():
+                keep.append((ev, pin))
+                continue
+            k = int(pin[0])
+            word = int(pin[1 + (k & 1)])
+            if word and bad is None:
+                bad = (k, word)
+        self._err_pending = keep
+        if bad is not None:
+            why = '; '.join(t for b_, t in self.ERR_BITS.items() if bad[1] & b_)
+            raise ValueError(f'infer_action call #{bad[0]}: the dense masks are not the prefix + trailing-block pattern of build_causal_mask_and_position_ids '
+                             f'(pizero_internvl.py:517-603) -- the only visibility the kernels\' (valid_len, blk_start) descriptors express; its result was NaN.  {why}')
+
+    def check_errors(self):
+        """Wait for every outstanding call and raise if one of them passed a mask the kernels cannot honour (the lazy check of infer_action, made now)."""
+        self._poll_errors(block=True)
+
+    def _stage_inputs(self, B, input_ids, pixel_values, proprios, noise, valid_len, masks=None, positions=None):
+        """Host / device plumbing of one call's inputs (the reference moves them with .to(device) in its agent loop, eval.py:117-130): anything not yet
+        on the device is copied there, then `vlaser_vla_stage` writes every slot in one launch -- ids, valid_len (given, or the zero count of the dense
+        mask's proprio row, or counted from the pad ids), proprio, noise (straight into the buffer the Euler phase starts from), position ids, the pixels
+        (bf16 / fp32 -> bf16, or the raw uint8 observation normalised on the device) -- checks the dense masks and sets the call number that selects the result
+        slot."""
         dev, cfg = self.device, self.cfg
         na = self.num_action_tokens
         on = lambda t, dt=None: t.to(device=dev, dtype=dt, non_blocking=True).contiguous()
@@ -470,13 +522,31 @@ class PiZero:
         pv = on(pv)
         if tuple(pv.shape[-3:]) != tuple(self.in_pix.shape[-3:]) or pv.numel() != B * self.num_images * self.in_pix[0].numel():
             raise ValueError(f'pixel_values must be [B*{self.num_images},{",".join(map(str, self.in_pix.shape[1:]))}], got {tuple(pixel_values.shape)}')
+        if proprios is None:
+            raise ValueError('infer_action: proprios [B,1,proprio_dim] is required')
+        if proprios.numel() != B * self.num_proprio_tokens * cfg.proprio_dim or noise.numel() != B * na * cfg.action_dim:
+            # (the staging launch copies element counts it is given: a wrong proprio_dim / action_dim / horizon must not become an out-of-bounds device write)
+            raise ValueError(f'proprios must be [B,{self.num_proprio_tokens},{cfg.proprio_dim}] and noise [B,{na},{cfg.action_dim}], got {tuple(proprios.shape)} / {tuple(noise.shape)}')
         pro = on(proprios.reshape(B, -1), torch.float32)
         nz = on(noise.reshape(B * na, -1), torch.float32)
         if valid_len is not None:
             valid_len = on(valid_len.reshape(-1), valid_len.dtype if valid_len.dtype in (torch.int32, torch.int64) else torch.int64)
-        self._calls += 1
-        ops.vla_stage(ids, self.in_ids, valid_len, self.valid_len, pro, self.in_proprio, nz, self.noise_dst, pv, self.in_pix, self.pad_token_id,
-                      prep.VLA_MEAN, prep.VLA_STD, call_ctr=self.call_ctr)
+            if valid_len.numel() != B:
+                raise ValueError(f'valid_len must have {B} entries, got {valid_len.numel()}')
+        if masks is not None:
+            # the masks stay where they are (any batch / row stride: the reference hands out slices of the full [B,1,L,L] mask, :589-603); only a
+            # non-unit innermost stride or a host tensor costs a copy
+            def fix(m):
+                if m is None:
+                    return None
+                m = m.to(dev, non_blocking=True)
+                return m if m.stride(-1) == 1 else m.contiguous()
+            masks = tuple(fix(m) for m in masks)
+        k = self._calls + 1
+        ops.vla_stage(ids, self.in_ids[:B], valid_len, self.valid_len, pro, self.in_proprio, nz, self.noise_dst, pv, self.in_pix, self.pad_token_id,
+                      prep.VLA_MEAN, prep.VLA_STD, call_ctr=self.call_ctr, call_no=k, masks=masks, n_act=na, positions=positions,
+                      pos_out=(self.pos_vlm, self.pos_pro, self.pos_act, self.pos5 if B == 1 else None))
+        self._calls = k                           # only after the launch was accepted: the host's ring index cannot run ahead of the device's call number
 
     def sync_errors(self):
         """Number of fused-launch slots whose bounded in-launch wait expired during the last chunk (0 on a healthy run; the result is
@@ -516,7 +586,10 @@ class PiZero:
         if valid_len is None:
             valid_len = prep.mask_to_descriptor(causal_mask[:, :, :T + 1, :T + 1].to('cpu'), T) if causal_mask is not None else (input_ids != self.pad_token_id).sum(-1)
         self.valid_len[:1].copy_(valid_len.to(torch.int32))
-        self._stage_positions(1, vlm_position_ids, proprio_position_ids, action_position_ids)
+        pos = self._positions_for_stage(1, vlm_position_ids, proprio_position_ids, action_position_ids)
+        if pos is not None:                       # (test surface: plain torch copies; the hot path converts them inside vlaser_vla_stage)
+            self.pos_vlm[:T].copy_(pos[0].reshape(-1)); self.pos_pro[:1].copy_(pos[1].reshape(-1)); self.pos_act[:na].copy_(pos[2].reshape(-1))
+            self.pos5[:1].copy_(self.pos_pro[:1]); self.pos5[1:1 + na].copy_(self.pos_act[:na])
         if noise is None:
             noise = torch.randn((1, na, cfg.action_dim), generator=generator)
         self.action[:na].copy_(noise.reshape(na, -1).to(torch.float32))

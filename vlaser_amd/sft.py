@@ -602,6 +602,8 @@ class SFTModel:
             # rank (one reduce-scatter per bucket, in backward order)
             self.fp.g.zero_()
             self._embed_touched = None
+            if getattr(self, '_fused_norm', False):
+                self.norm_parts.zero_()            # nothing wrote this step's slots: the producers' partial sums of the PREVIOUS step must not become this step's norm
             if on_bucket_ready:
                 for b in range(len(self.buckets)):
                     on_bucket_ready(b)
@@ -951,7 +953,9 @@ class SFTModel:
             early = not self.dp_active and self.overlap_optimizer and os.environ.get('VLASER_SFT_NO_EARLY_NORM') != '1'
             self._norm_buckets_seen = 0
             # the norm from the producers (r04) needs every gradient element to be written exactly once by a kernel that can sum it: one sample per step
-            self._fused_norm = early and os.environ.get('VLASER_SFT_NO_FUSED_NORM') != '1'
+            # ... and a slot layout that depends on the weight's shape only: true for the LDS-DMA weight-gradient kernel the step takes by default; the A/B fallback
+            # (VLASER_SFT_WGRAD=tn) picks its kernel -- and with it the slots it reaches -- by the sequence length, so it keeps the buffer pass
+            self._fused_norm = early and self.wgrad_lds and os.environ.get('VLASER_SFT_NO_FUSED_NORM') != '1'
             if self._fused_norm and getattr(self, 'norm_parts', None) is None:
                 self._plan_fused_norm()
             try:
