@@ -170,14 +170,24 @@ int vlaser_skinny(int prologue, int epi, const VlaserSkinnyArgs* args, vl_stream
  * consumer workgroup re-reduces.  All three take device pointers, are asynchronous on `stream`, return 0 / negative like everything else here.
  *   vlaser_chain_qkv : args as vlaser_skinny(VL_PRO_NORM, VL_SK_QKV_ROPE) with tiles_per_unit = 1, n_partials = 0 (x = the published residual stream): one wave per 16-row
  *                      unit, RMSNorm + q/k/v GEMV + bias + RoPE + KV-cache scatter;  hidden 768 / 1536
- *   vlaser_chain_gu  : args as vlaser_skinny(VL_PRO_NORM, VL_SK_SWIGLU) with tiles_per_unit = 2 and 2 or 3 producer slabs: bit-identical outputs, all units of a workgroup
+ *   vlaser_chain_gu  : args as vlaser_skinny(VL_PRO_NORM, VL_SK_SWIGLU) with tiles_per_unit = 2 (or 1: 16-row lane-local units) and 2 or 3 producer slabs: bit-identical outputs, all units of a workgroup
  *                      requested up front; h_out (nullable) = bf16(x + sum partials), the residual vlaser_chain_down adds back
- *   vlaser_chain_down: h_out [M, N] = bf16(res + x [M, K] @ W^T), W = down_proj.weight packed by ops.pack_down4 ([N/4][7 waves][10 loads][64 lanes][8]): a workgroup
- *                      owns 4 output columns over the whole K = 8960 (no cross-workgroup split-K); res != h_out
+ *   vlaser_chain_down: h_out [M, N] = bf16(res + x [M, K] @ W^T), W = down_proj.weight packed by ops.pack_down4 ([workgroup][7 waves][10 loads][groups][16 blocks][cols][8]):
+ *                      a workgroup owns `groups` x `cols` output columns (vlaser_chain_down_geometry) over the whole K = 8960 (no cross-workgroup split-K); res != h_out
  * *_supported(...) != 0 tells the host surface whether a geometry has a variant (it keeps vlaser_skinny otherwise). */
+/*   vlaser_chain_attn : vlaser_attn_skinny's arguments; one WAVE per (kv head, key split, batch element) with 2 chunks of 32 keys each (no LDS merge, no barrier);
+ *                       part_m = fp32 [B, n_kv, n_splits, 32, 2] (m, l) pairs, part_o = BF16 [B, n_kv, n_splits, 32, 128] NORMALISED rows (part_l unused);
+ *                       n_splits = vlaser_chain_attn_splits(kv_len) = ceil(ceil(kv_len / 32) / 2) <= 16
+ *   vlaser_chain_oproj: args as vlaser_skinny(VL_PRO_ATTN, VL_SK_PARTIAL) with tiles_per_unit = 1, attn_m / attn_o = what vlaser_chain_attn wrote: merge of the splits
+ *                       (weights l 2^(m - max m)) -> o_proj GEMV -> fp32 split-K slabs */
+int vlaser_chain_attn_splits(int kv_len);
+int vlaser_chain_attn(const VlaserAttnArgs* args, vl_stream_t stream);
+int vlaser_chain_oproj_supported(int M, int N, int K, int k_splits, int attn_splits, int group);
+int vlaser_chain_oproj(const VlaserSkinnyArgs* args, vl_stream_t stream);
 int vlaser_chain_qkv_supported(int M, int N, int K);
-int vlaser_chain_gu_supported(int M, int N, int K, int n_partials);
+int vlaser_chain_gu_supported(int M, int N, int K, int n_partials, int tiles_per_unit);
 int vlaser_chain_down_supported(int M, int N, int K);
+int vlaser_chain_down_geometry(int N, int* cols, int* groups);      /* returns the workgroup count; cols (3 / 4) per column group, groups (1 / 2) per workgroup: the layout ops.pack_down4 writes */
 int vlaser_chain_qkv(const VlaserSkinnyArgs* args, vl_stream_t stream);
 int vlaser_chain_gu(const VlaserSkinnyArgs* args, vl_stream_t stream);
 int vlaser_chain_down(const void* x, int ldx, const void* W, const void* res, void* h_out, int M, int N, int K, unsigned long long* dbg, vl_stream_t stream);

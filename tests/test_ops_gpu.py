@@ -344,6 +344,55 @@ def test_attn_oproj_one_launch(ops, nq_tok, kv_len, mode, first, nq, nkv, valid)
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize('nq_tok,B,kv_len,first,valid,H', [(4, 1, 389, 0, [277], 768), (5, 1, 389, 385, [277], 768), (4, 2, 389, 0, [277, 31], 768), (4, 1, 389, 0, [384], 768),
+                                                       (4, 1, 389, 0, [1], 768), (1, 1, 389, 0, [200], 1536), (4, 2, 389, 0, [384, 100], 768)])
+def test_chain_attn_oproj_vs_fp32(ops, nq_tok, B, kv_len, first, valid, H):
+    """r05: one wave per (kv head, key split) attention leaving (m, l) + normalised bf16 rows, merged by the o_proj launch's prologue: the sum of the split-K slabs ==
+    o_proj(attention) of an fp32 reference under the VLA block mask (valid prefix + trailing block, the riding proprio row's own key limit, batches with ragged
+    prefixes, a prefix of one key), and the pair agrees with vlaser_attn_skinny + vlaser_skinny(ATTN, PARTIAL) to bf16 noise; deterministic."""
+    from vlaser_amd import _lib as L
+    nq, nkv, smax, blk = 12, 2, 448, 384
+    G, M = nq // nkv, B * nq_tok
+    ks_o = 3 if H == 768 else 2
+    nsp = ops.chain_attn_splits(kv_len)
+    assert nsp == 7 and ops.chain_oproj_supported(M, H, nq * 128, ks_o, nsp, G)
+    q = rnd(M, nq * 128, seed=1)
+    k = rnd(B, nkv, smax, 128, seed=2); v = rnd(B, nkv, smax, 128, seed=3)
+    k[:, :, 5] *= 4.0
+    vt = v.transpose(-1, -2).contiguous()
+    sc = 128 ** -0.5
+    vl = torch.tensor(valid, dtype=torch.int32, device='cuda')
+    wo = rnd(H, nq * 128, std=0.03, seed=9)
+    wp = ops.pack_skinny(wo, ks_o, 1)
+    strides = ((nq_tok * nq * 128, 128, nq * 128), (nkv * smax * 128, smax * 128), (nkv * 128 * smax, 128 * smax))
+    cp = ops.chain_attn_buffers(B, nkv, 'cuda')
+    a = ops.attn_skinny_args(q, k, vt, (cp[0], cp[0], cp[1]), B, nq_tok, kv_len, nq, nkv, 128, *strides, smax, sc, L.ATTN_PREFIX, nsp, valid_len=vl, blk_start=blk,
+                             first_tok_kv_len=first)
+    outs = []
+    for rep in range(2):
+        out = torch.full((ks_o, M, H), 5.0, dtype=torch.float32, device='cuda')
+        ops.launch_chain_attn(a)
+        o_args, _ = ops.skinny_args(None, wp, M, out_f32=out, attn_m=cp[0], attn_o=cp[1], attn_splits=nsp, attn_group=G, attn_nq=nq_tok)
+        ops.launch_chain_oproj(o_args)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    j = torch.arange(kv_len, device='cuda')[None, None]
+    vis = ((j < vl.view(B, 1, 1)) | (j >= blk)).expand(B, nq_tok, kv_len).clone()
+    if first:
+        vis[:, 0] = (j[0] < vl.view(B, 1)) | ((j[0] >= blk) & (j[0] < first))
+    qq = q.view(B, nq_tok, nq, 128).permute(0, 2, 1, 3)
+    att = _attn_ref(qq, k[:, :, :kv_len], v[:, :, :kv_len], sc, vis).reshape(M, nq * 128)
+    ref = att.to(BF).float() @ wo.float().t()
+    close(outs[0].sum(0), ref, rtol=2e-2, name='sum of the split-K slabs')
+    # the r01-r04 pair on the same inputs
+    parts = ops.attn_partial_buffers(B, nkv, 'cuda')
+    n_old = ops.attn_splits(kv_len)
+    ops.attn_skinny(q, k, vt, parts, B, nq_tok, kv_len, nq, nkv, 128, *strides, smax, sc, L.ATTN_PREFIX, n_old, valid_len=vl, blk_start=blk, first_tok_kv_len=first)
+    old = torch.zeros(ks_o, M, H, dtype=torch.float32, device='cuda')
+    ops.skinny(L.PRO_ATTN, L.SK_PARTIAL, None, wp, M, out_f32=old, attn_m=parts[0], attn_l=parts[1], attn_o=parts[2], attn_splits=n_old, attn_group=G, attn_nq=nq_tok)
+    assert (outs[0].sum(0) - old.sum(0)).abs().max().item() <= 2e-2 * max(1.0, old.sum(0).abs().max().item())
+
+
 def test_attn_oproj_refuses_odd_groups(ops):
     from vlaser_amd import _lib as L
     nq, nkv, smax = 28, 4, 512
@@ -479,6 +528,14 @@ def test_chain_gu_bit_identical_to_skinny(ops, M, H, I, npart):
         assert torch.equal(o1, o0) and torch.equal(h1, h0), rep
     torch.cuda.synchronize()
     assert not ops.chain_gu_supported(M, 2 * I, 1024, npart) and not ops.chain_gu_supported(M, 2 * I, H, 5)
+    # 16-row lane-local units (pack_gate_up8: 224 workgroups x 5 units for the expert): the same bits again
+    if I == 8960 and ops.chain_gu_supported(M, 2 * I, H, npart, 1):
+        pw8 = ops.pack_skinny(ops.pack_gate_up8(rnd(I, H, std=0.03, seed=1), rnd(I, H, std=0.03, seed=2)), 1, 1)
+        a8, _ = ops.skinny_args(h, pw8, M, partials=parts, n_partials=npart, norm_w=nw, h_out=None, out=None, ldo=I)
+        o8, h8 = torch.full((M, I), 7.0, dtype=BF, device='cuda'), torch.full((M, H), 7.0, dtype=BF, device='cuda')
+        a8.out, a8.h_out = o8.data_ptr(), h8.data_ptr()
+        ops.launch_chain_gu(a8)
+        assert torch.equal(o8, o0) and torch.equal(h8, h0)
 
 
 @pytest.mark.parametrize('B,tok,H', [(1, 4, 768), (1, 5, 768), (2, 4, 768), (4, 4, 768), (1, 1, 1536), (8, 1, 1536)])

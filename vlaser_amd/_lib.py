@@ -68,9 +68,14 @@ _SIGS = {
     'vlaser_skinny': [i32, i32, C.POINTER(SkinnyArgs), vp],
     'vlaser_fused_ogu': [C.POINTER(FusedOguArgs), vp],
     'vlaser_chain_qkv_supported': [i32, i32, i32],
-    'vlaser_chain_gu_supported': [i32, i32, i32, i32],
+    'vlaser_chain_gu_supported': [i32, i32, i32, i32, i32],
     'vlaser_chain_down_supported': [i32, i32, i32],
+    'vlaser_chain_down_geometry': [i32, C.POINTER(i32), C.POINTER(i32)],
     'vlaser_chain_qkv': [C.POINTER(SkinnyArgs), vp],
+    'vlaser_chain_attn_splits': [i32],
+    'vlaser_chain_attn': [C.POINTER(AttnArgs), vp],
+    'vlaser_chain_oproj_supported': [i32, i32, i32, i32, i32, i32],
+    'vlaser_chain_oproj': [C.POINTER(SkinnyArgs), vp],
     'vlaser_chain_gu': [C.POINTER(SkinnyArgs), vp],
     'vlaser_chain_down': [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp],
     'vlaser_layernorm': [vp, vp, vp, vp, i32, i32, f32, vp],

@@ -33,11 +33,12 @@ struct ChainGuP {
   unsigned long long* dbg;
 };
 
-// NS = K / 256 (K-steps of 32 per wave), UE = units (32 packed rows = [gate16 | up16]) per workgroup, SP = split-K slabs of the producer, CPT = 16-byte chunks
-// of the [M, K] residual stream per thread (ceil(M * K / 8 / 512))
-template <int NS, int UE, int SP, int CPT, bool DBG>
+// NS = K / 256 (K-steps of 32 per wave), UE = units per workgroup, SP = split-K slabs of the producer, CPT = 16-byte chunks of the [M, K] residual stream per thread
+// (ceil(M * K / 8 / 512)), TPU = MFMA tiles per unit: 2 = 32 packed rows [gate16 | up16] (ops.pack_gate_up), 1 = 16 rows whose lane group g holds
+// [gate 2g, gate 2g+1, up 2g, up 2g+1] of the unit's 8 activation columns (ops.pack_gate_up8: 1120 instead of 560 units -> 224 workgroups x 5 instead of 187 x 3)
+template <int NS, int UE, int SP, int CPT, int TPU, bool DBG>
 __global__ __launch_bounds__(512) void chain_gu_kernel(ChainGuP p) {
-  constexpr int K = NS * 256, cpr = K / 8, ngr = cpr / 16, gstride = (ngr + 3) & ~3, XS = K * 2 + 16, NF = 2 * NS;
+  constexpr int K = NS * 256, cpr = K / 8, ngr = cpr / 16, gstride = (ngr + 3) & ~3, XS = K * 2 + 16, NF = TPU * NS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
   unsigned long long* dbg = DBG ? p.dbg + (size_t)blockIdx.x * 8 : nullptr;
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(512) void chain_gu_kernel(ChainGuP p) {
   const int ustart = (int)blockIdx.x * p.ulo + min((int)blockIdx.x, p.urem);
   const int xs_bytes = (M * XS + 15) & ~15;
   char* xs = smem;
-  float* red = reinterpret_cast<float*>(smem + xs_bytes);      // [2][7][2][64] f32x4, double-buffered by unit parity; group sums [M][gstride] during the prologue
+  float* red = reinterpret_cast<float*>(smem + xs_bytes);      // [UE][8][TPU][64] f32x4 partial tiles; group sums [M][gstride] during the prologue
   float* gs = red;
   const int nch = M * cpr, slab = M * K;
 
@@ -72,6 +73,11 @@ __global__ __launch_bounds__(512) void chain_gu_kernel(ChainGuP p) {
   }
   // (hipcc's scheduler moves loads freely -- it does not know that vmcnt retires in issue order: without the fences below it put the norm-weight chunk and two
   //  fragments of unit 0 BEHIND units 1 and 2, so the norm and the first MFMAs waited for the whole stream)
+  __builtin_amdgcn_sched_barrier(0);
+  // All 8 waves put their (L2-resident) prologue requests into the CU's memory pipeline BEFORE any wave queues weight requests: the pipeline is FIFO per CU, and a
+  // wave that started late found its 8 small requests behind 7 x 18 KB of the others' HBM requests (in-chain timeline r05b: prologue data back 3.7 us after the start
+  // instead of 2.3).  The barrier waits for instruction issue only -- nobody waits for data here.
+  __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   u32x4 w[UE][NF];
   {
@@ -139,41 +145,55 @@ __global__ __launch_bounds__(512) void chain_gu_kernel(ChainGuP p) {
   bf16x8 xf[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) xf[s] = as_bf16x8(*reinterpret_cast<const u32x4*>(xrow + s * 64));
-  int par = 0;
+  // Every unit's MFMAs as its fragments land (issue order), ALL eight waves leave their partial tiles in LDS, ONE barrier, then wave u finishes unit u: sum of the
+  // eight K-slices in wave order (the order of skinny_kernel: wave 0's tile first -- identical bits) + SwiGLU + store.  r05b timeline: with wave 0 finishing the units
+  // one after the other behind a barrier each, 1.6-2.1 us passed between "prologue done" and the end of the workgroup -- the weights had landed long before.
 #pragma unroll
   for (int u = 0; u < UE; ++u) {
     if (u < ucount) {
       f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        a0 = mfma16(as_bf16x8(w[u][2 * s]), xf[s], a0);
-        a1 = mfma16(as_bf16x8(w[u][2 * s + 1]), xf[s], a1);
+        a0 = mfma16(as_bf16x8(w[u][TPU * s]), xf[s], a0);
+        if constexpr (TPU == 2) a1 = mfma16(as_bf16x8(w[u][2 * s + 1]), xf[s], a1);
       }
       if (u == 0) { if constexpr (DBG) asm volatile("" ::"v"(a0[0])); CH_STAMP(3); }
-      float* rb = red + par * (7 * 2 * 64 * 4);
-      if (wave != 0) {
-        float* r = rb + ((wave - 1) * 2 * 64 + lane) * 4;
-        *reinterpret_cast<f32x4*>(r) = a0;
-        *reinterpret_cast<f32x4*>(r + 64 * 4) = a1;
+      float* r = red + (((u * 8 + wave) * TPU) * 64 + lane) * 4;
+      *reinterpret_cast<f32x4*>(r) = a0;
+      if constexpr (TPU == 2) *reinterpret_cast<f32x4*>(r + 64 * 4) = a1;
+    }
+  }
+  __syncthreads();
+  CH_STAMP(4);
+  if (wave < UE && wave < ucount) {
+    const int u = wave;
+    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int w2 = 0; w2 < 8; ++w2) {
+      const float* r = red + (((u * 8 + w2) * TPU) * 64 + lane) * 4;
+      if (w2 == 0) {
+        a0 = *reinterpret_cast<const f32x4*>(r);
+        if constexpr (TPU == 2) a1 = *reinterpret_cast<const f32x4*>(r + 64 * 4);
+      } else {
+        a0 += *reinterpret_cast<const f32x4*>(r);
+        if constexpr (TPU == 2) a1 += *reinterpret_cast<const f32x4*>(r + 64 * 4);
       }
-      __syncthreads();
-      if (u == 0) CH_STAMP(4);
-      par ^= 1;
-      if (wave == 0) {
+    }
+    const int unit = ustart + u;
+    if constexpr (TPU == 2) {
+      if (mok && unit * 32 < p.n_valid) {              // unit = [gate16 | up16] -> output columns unit*16 + g*4 + j
+        bf16_t* o = p.out + (size_t)fr * p.ldo + unit * 16 + g * 4;
+        float r4[4];
 #pragma unroll
-        for (int w2 = 0; w2 < 7; ++w2) {
-          const float* r = rb + (w2 * 2 * 64 + lane) * 4;
-          a0 += *reinterpret_cast<const f32x4*>(r);
-          a1 += *reinterpret_cast<const f32x4*>(r + 64 * 4);
-        }
-        const int pair = ustart + u;
-        if (mok && pair * 32 < p.n_valid) {              // pair = [gate16 | up16] -> output columns pair*16 + g*4 + j
-          bf16_t* o = p.out + (size_t)fr * p.ldo + pair * 16 + g * 4;
-          float r4[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) r4[j] = round_bf16(silu(round_bf16(a0[j]))) * round_bf16(a1[j]);
-          *reinterpret_cast<u32x2*>(o) = u32x2{pack_bf16x2(r4[0], r4[1]), pack_bf16x2(r4[2], r4[3])};
-        }
+        for (int j = 0; j < 4; ++j) r4[j] = round_bf16(silu(round_bf16(a0[j]))) * round_bf16(a1[j]);
+        *reinterpret_cast<u32x2*>(o) = u32x2{pack_bf16x2(r4[0], r4[1]), pack_bf16x2(r4[2], r4[3])};
+      }
+    } else {
+      if (mok && unit * 16 < p.n_valid) {              // lane group g: [gate 2g, gate 2g+1, up 2g, up 2g+1] -> output columns unit*8 + 2g, + 1
+        bf16_t* o = p.out + (size_t)fr * p.ldo + unit * 8 + g * 2;
+        const float r0 = round_bf16(silu(round_bf16(a0[0]))) * round_bf16(a0[2]);
+        const float r1 = round_bf16(silu(round_bf16(a0[1]))) * round_bf16(a0[3]);
+        *reinterpret_cast<uint32_t*>(o) = pack_bf16x2(r0, r1);
       }
     }
   }
@@ -186,52 +206,54 @@ __global__ __launch_bounds__(512) void chain_gu_kernel(ChainGuP p) {
   CH_STAMP(5);
 }
 
-template <int NS, int UE, int SP, int CPT>
+template <int NS, int UE, int SP, int CPT, int TPU>
 static int chain_gu_launch(const ChainGuP& p, int gx, int lds, hipStream_t stream) {
   if (p.dbg) {
-    if (int rc = set_max_lds_once(chain_gu_kernel<NS, UE, SP, CPT, true>, lds)) return rc;
-    hipLaunchKernelGGL((chain_gu_kernel<NS, UE, SP, CPT, true>), dim3(gx), dim3(512), lds, stream, p);
+    if (int rc = set_max_lds_once(chain_gu_kernel<NS, UE, SP, CPT, TPU, true>, lds)) return rc;
+    hipLaunchKernelGGL((chain_gu_kernel<NS, UE, SP, CPT, TPU, true>), dim3(gx), dim3(512), lds, stream, p);
   } else {
-    if (int rc = set_max_lds_once(chain_gu_kernel<NS, UE, SP, CPT, false>, lds)) return rc;
-    hipLaunchKernelGGL((chain_gu_kernel<NS, UE, SP, CPT, false>), dim3(gx), dim3(512), lds, stream, p);
+    if (int rc = set_max_lds_once(chain_gu_kernel<NS, UE, SP, CPT, TPU, false>, lds)) return rc;
+    hipLaunchKernelGGL((chain_gu_kernel<NS, UE, SP, CPT, TPU, false>), dim3(gx), dim3(512), lds, stream, p);
   }
   VL_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int vlaser_chain_gu_supported(int M, int N, int K, int n_partials) {
-  if (M < 1 || M > 16 || (K != 768 && K != 1536) || N % 32 || (n_partials != 2 && n_partials != 3) || (K == 1536 && n_partials != 2)) return 0;
+/* tpu = tiles per unit of the packed weights (2: pack_gate_up, 1: pack_gate_up8) */
+extern "C" int vlaser_chain_gu_supported(int M, int N, int K, int n_partials, int tpu) {
+  if (M < 1 || M > 16 || (K != 768 && K != 1536) || (tpu != 1 && tpu != 2) || N % (16 * tpu) || (K == 768 && n_partials != 2 && n_partials != 3) || (K == 1536 && n_partials != 2)) return 0;
   const int cpt = (M * (K / 8) + 511) / 512;
   if (cpt > 3) return 0;
-  const int units = N / 32;
+  const int units = N / (16 * tpu);
   const int longest = (units + 255) / 256;
-  return longest == 2 || longest == 3;
+  return tpu == 2 ? (longest == 2 || longest == 3) : (longest == 5 && !(K == 768 && n_partials == 2));
 }
 
 extern "C" int vlaser_chain_gu(const VlaserSkinnyArgs* a, vl_stream_t s) {
   VL_CHECK(a && a->x && a->W && a->norm_w && a->out && a->partials, "vlaser_chain_gu: null operand");
-  VL_CHECK(a->tiles_per_unit == 2 || a->tiles_per_unit == 0, "vlaser_chain_gu: weights packed in 32-row units (pack_skinny(..., 1, 2))");
-  VL_CHECK(a->k_splits == 1 && vlaser_chain_gu_supported(a->M, a->N, a->K, a->n_partials),
-           "vlaser_chain_gu: built for K = 768 / 1536, 2 or 3 producer slabs, 2-3 units per workgroup, M * K / 8 <= 1536 chunks (got M %d N %d K %d slabs %d)", a->M, a->N,
+  const int tpu = a->tiles_per_unit == 1 ? 1 : 2;
+  VL_CHECK(a->tiles_per_unit == 2 || a->tiles_per_unit == 0 || a->tiles_per_unit == 1, "vlaser_chain_gu: weights packed in 32-row (pack_gate_up) or 16-row (pack_gate_up8) units");
+  VL_CHECK(a->k_splits == 1 && vlaser_chain_gu_supported(a->M, a->N, a->K, a->n_partials, tpu),
+           "vlaser_chain_gu: built for K = 768 / 1536, 2 or 3 producer slabs, 2-3 (32-row) or 5 (16-row) units per workgroup, M * K / 8 <= 1536 chunks (got M %d N %d K %d slabs %d)", a->M, a->N,
            a->K, a->n_partials);
   VL_CHECK(((uintptr_t)a->W & 15) == 0 && ((uintptr_t)a->x & 15) == 0 && ((uintptr_t)a->partials & 15) == 0 && ((uintptr_t)a->out & 7) == 0 && a->ldo % 4 == 0, "vlaser_chain_gu: alignment");
   const int n_valid = a->n_valid > 0 ? a->n_valid : a->N;
-  VL_CHECK(n_valid % 32 == 0, "vlaser_chain_gu: whole [gate|up] groups");
+  VL_CHECK(n_valid % (16 * tpu) == 0, "vlaser_chain_gu: whole [gate|up] groups");
   ChainGuP p;
   p.h_in = (const bf16_t*)a->x; p.partials = a->partials; p.norm_w = (const bf16_t*)a->norm_w; p.h_out = (bf16_t*)a->h_out;
   p.W = (const u32x4*)a->W; p.out = (bf16_t*)a->out;
   p.M = a->M; p.ldo = a->ldo; p.n_valid = n_valid; p.eps = a->eps; p.inv_cpr = 8.0f / (float)a->K; p.dbg = a->dbg;
-  const int units = a->N / 32, longest = (units + 255) / 256, gx = (units + longest - 1) / longest;
+  const int units = a->N / (16 * tpu), longest = (units + 255) / 256, gx = (units + longest - 1) / longest;
   p.ulo = units / gx; p.urem = units % gx;
   const int ns = a->K / 256, cpt = (a->M * (a->K / 8) + 511) / 512;
-  const int lds = ((a->M * (a->K * 2 + 16) + 15) & ~15) + 2 * 7 * 2 * 64 * 16;
+  const int lds = ((a->M * (a->K * 2 + 16) + 15) & ~15) + longest * 8 * tpu * 64 * 16;
   hipStream_t stream = (hipStream_t)s;
-#define CG_CASE(NS_, UE_, SP_, CPT_) if (ns == NS_ && longest == UE_ && a->n_partials == SP_ && cpt == CPT_) return chain_gu_launch<NS_, UE_, SP_, CPT_>(p, gx, lds, stream);
-#define CG_CPT(NS_, UE_, SP_) CG_CASE(NS_, UE_, SP_, 1) CG_CASE(NS_, UE_, SP_, 2) CG_CASE(NS_, UE_, SP_, 3)
-  CG_CPT(3, 3, 3) CG_CPT(3, 3, 2) CG_CPT(6, 3, 2) CG_CPT(3, 2, 3) CG_CPT(6, 2, 2)
+#define CG_CASE(NS_, UE_, SP_, CPT_, TPU_) if (ns == NS_ && longest == UE_ && a->n_partials == SP_ && cpt == CPT_ && tpu == TPU_) return chain_gu_launch<NS_, UE_, SP_, CPT_, TPU_>(p, gx, lds, stream);
+#define CG_CPT(NS_, UE_, SP_, TPU_) CG_CASE(NS_, UE_, SP_, 1, TPU_) CG_CASE(NS_, UE_, SP_, 2, TPU_) CG_CASE(NS_, UE_, SP_, 3, TPU_)
+  CG_CPT(3, 3, 3, 2) CG_CPT(3, 3, 2, 2) CG_CPT(6, 3, 2, 2) CG_CPT(3, 2, 3, 2) CG_CPT(6, 2, 2, 2) CG_CPT(3, 5, 3, 1) CG_CPT(6, 5, 2, 1)
 #undef CG_CPT
 #undef CG_CASE
-  vlaser_set_error("vlaser_chain_gu: no variant for K %d, %d units per workgroup, %d slabs, %d chunks per thread", a->K, longest, a->n_partials, cpt);
+  vlaser_set_error("vlaser_chain_gu: no variant for K %d, %d units per workgroup, %d slabs, %d chunks per thread, %d tiles per unit", a->K, longest, a->n_partials, cpt, tpu);
   return -1;
 }
 
@@ -392,20 +414,30 @@ struct ChainDownP {
   unsigned long long* dbg;
 };
 
-// A workgroup = 4 output columns n0 .. n0 + 3 over the WHOLE K = NW waves x NL loads x 128.  Lane (b = lane >> 2, i = lane & 3) of wave w, load l holds
-// W[n0 + i][(w NL + l) 128 + 8 b .. + 8] (ops.pack_down4: one contiguous 1 KiB per wave-level load) and x[row i of its row group][same k]; the two halves of
-// the 16 bytes feed two v_mfma_f32_4x4x4_16b_bf16 (block b: D_b[n][m] += sum_k W[n0 + n][k] x[m][k] over 4 k): lane (b, m) accumulates out[m][n0 .. n0 + 3]
-// over its block's k, the 16 blocks are summed across the lanes, the NW waves through LDS in a fixed order.  RG = ceil(M / 4) row groups.
-template <int NW, int NL, int RG, bool DBG>
+// A workgroup = CG groups of COLS (3 or 4) output columns over the WHOLE K = NW waves x NL loads x 128.  Lane (b = lane >> 2, i = lane & 3) of wave w, load l, group c
+// holds W[n0 + c COLS + min(i, COLS - 1)][(w NL + l) 128 + 8 b .. + 8] (ops.pack_down4: one contiguous 16 x COLS x 16 bytes per wave-level load; with COLS = 3 the
+// fourth lane of a block re-reads the third's 16 bytes) and x[row i of its row group][same k]; the two halves of the 16 bytes feed two v_mfma_f32_4x4x4_16b_bf16
+// (layout probed on the GPU, tools/micro/mfma4_probe.hip: D[reg = lane & 3 of the A lane][lane of the B lane]; block b: D_b[n][m] += sum_k W[n0 + n][k] x[m][k] over
+// 4 k): lane (b, m) accumulates out[m][n0 .. n0 + COLS) over its block's k, the 16 blocks are summed across the lanes, the NW waves through LDS in a fixed order.
+// COLS = 3 puts N = 768 on 256 workgroups: a CU sustains ~35 GB/s of requests, so the launch lasts as long as the bytes of its busiest CU -- 54 KB of weights + the
+// whole [M, K] activation (every workgroup contracts over all of K: the price of publishing the result once) instead of 72 + 71 KB on 192 CUs.
+// RG = ceil(M / 4) row groups.
+template <int NW, int NL, int RG, int COLS, int CG, bool DBG>
 __global__ __launch_bounds__(NW * 64) void chain_down_kernel(ChainDownP p) {
-  __shared__ __attribute__((aligned(16))) float part[NW][RG][4][4];
+  __shared__ __attribute__((aligned(16))) float part[NW][CG][RG][4][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = lane >> 2, i = lane & 3;
-  const int M = p.M, n0 = blockIdx.x * 4;
+  const int M = p.M, n0 = blockIdx.x * (COLS * CG);
   unsigned long long* dbg = DBG ? p.dbg + (size_t)blockIdx.x * 8 : nullptr;
   CH_STAMP(0);
-  // ---- requests: residual (final phase, threads 0 .. M-1), activations (L2), weights (HBM)
-  const u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + (size_t)min(tid, M - 1) * p.N + n0);      // unconditional (clamped): no branch in front of the load burst
-  u32x4 xv[RG][NL], wv[NL];
+  // ---- requests: residual (final phase: thread t -> row t / CG... see below), activations (L2), weights (HBM)
+  const int fr_row = min(tid / CG, M - 1), fr_cg = tid % CG;            // final phase: thread t < M * CG finishes row t / CG of column group t % CG
+  float rres[COLS];
+  {
+    const bf16_t* rp = p.res + (size_t)fr_row * p.N + n0 + fr_cg * COLS;
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) rres[c] = bf16_to_f32(rp[c]);          // unconditional (clamped): no branch in front of the load burst
+  }
+  u32x4 xv[RG][NL], wv[CG][NL];
 #pragma unroll
   for (int rg = 0; rg < RG; ++rg) {
     const bf16_t* xr = p.x + (size_t)min(rg * 4 + i, M - 1) * p.ldx + (wave * NL) * 128 + b * 8;
@@ -414,69 +446,375 @@ __global__ __launch_bounds__(NW * 64) void chain_down_kernel(ChainDownP p) {
   }
   __builtin_amdgcn_sched_barrier(0);           // activations (L2) strictly in front of the weights (HBM) in the queue
   {
-    const u32x4* src = p.W + ((size_t)blockIdx.x * NW + wave) * (NL * 64) + lane;
+    const u32x4* src = p.W + (((size_t)blockIdx.x * NW + wave) * NL) * (CG * 16 * COLS) + b * COLS + min(i, COLS - 1);
 #pragma unroll
-    for (int l = 0; l < NL; ++l) wv[l] = __builtin_nontemporal_load(src + l * 64);
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+      for (int c = 0; c < CG; ++c) wv[c][l] = __builtin_nontemporal_load(src + (l * CG + c) * (16 * COLS));
   }
   __builtin_amdgcn_sched_barrier(0);
-  f32x4 acc[RG];
+  f32x4 acc[CG][RG];
 #pragma unroll
-  for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4{0, 0, 0, 0};
+  for (int c = 0; c < CG; ++c)
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) acc[c][rg] = f32x4{0, 0, 0, 0};
 #pragma unroll
   for (int l = 0; l < NL; ++l) {
-    const s16x4 wlo = __builtin_bit_cast(s16x4, u32x2{wv[l][0], wv[l][1]}), whi = __builtin_bit_cast(s16x4, u32x2{wv[l][2], wv[l][3]});
 #pragma unroll
-    for (int rg = 0; rg < RG; ++rg) {
-      const s16x4 xlo = __builtin_bit_cast(s16x4, u32x2{xv[rg][l][0], xv[rg][l][1]}), xhi = __builtin_bit_cast(s16x4, u32x2{xv[rg][l][2], xv[rg][l][3]});
-      acc[rg] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wlo, xlo, acc[rg], 0, 0, 0);
-      acc[rg] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(whi, xhi, acc[rg], 0, 0, 0);
+    for (int c = 0; c < CG; ++c) {
+      const s16x4 wlo = __builtin_bit_cast(s16x4, u32x2{wv[c][l][0], wv[c][l][1]}), whi = __builtin_bit_cast(s16x4, u32x2{wv[c][l][2], wv[c][l][3]});
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) {
+        const s16x4 xlo = __builtin_bit_cast(s16x4, u32x2{xv[rg][l][0], xv[rg][l][1]}), xhi = __builtin_bit_cast(s16x4, u32x2{xv[rg][l][2], xv[rg][l][3]});
+        acc[c][rg] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wlo, xlo, acc[c][rg], 0, 0, 0);
+        acc[c][rg] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(whi, xhi, acc[c][rg], 0, 0, 0);
+      }
     }
   }
+  if constexpr (DBG) asm volatile("" ::"v"(acc[0][0][0]));
   CH_STAMP(3);
   // ---- sum of the 16 blocks (lanes with equal lane & 3), then of the waves
 #pragma unroll
-  for (int rg = 0; rg < RG; ++rg) {
+  for (int c = 0; c < CG; ++c)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[rg][r] = vl_blocks16_sum(acc[rg][r]);
-    if (lane < 4) *reinterpret_cast<f32x4*>(&part[wave][rg][lane][0]) = acc[rg];       // [row i of the group][column n]
-  }
+    for (int rg = 0; rg < RG; ++rg) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[c][rg][r] = vl_blocks16_sum(acc[c][rg][r]);
+      if (lane < 4) *reinterpret_cast<f32x4*>(&part[wave][c][rg][lane][0]) = acc[c][rg];       // [row i of the group][column n]
+    }
   __syncthreads();
   CH_STAMP(4);
-  if (tid < 4 * RG && tid < M) {
-    const int rg = tid >> 2, ri = tid & 3;
+  if (tid < M * CG) {
+    const int rg = fr_row >> 2, ri = fr_row & 3;
     float s4[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int w2 = 0; w2 < NW; ++w2) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(&part[w2][rg][ri][0]);
+      const f32x4 t = *reinterpret_cast<const f32x4*>(&part[w2][fr_cg][rg][ri][0]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) s4[r] += t[r];
     }
-    const float r0 = bf16lo_to_f32(rv[0]), r1 = bf16hi_to_f32(rv[0]), r2 = bf16lo_to_f32(rv[1]), r3 = bf16hi_to_f32(rv[1]);
-    *reinterpret_cast<u32x2*>(p.h_out + (size_t)tid * p.N + n0) = u32x2{pack_bf16x2(s4[0] + r0, s4[1] + r1), pack_bf16x2(s4[2] + r2, s4[3] + r3)};
+    bf16_t* op = p.h_out + (size_t)fr_row * p.N + n0 + fr_cg * COLS;
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) op[c] = f32_to_bf16(s4[c] + rres[c]);
   }
   CH_STAMP(5);
 }
 
-extern "C" int vlaser_chain_down_supported(int M, int N, int K) { return M >= 1 && M <= 16 && N % 4 == 0 && K == 8960; }
+extern "C" int vlaser_chain_down_geometry(int N, int* cols, int* groups);
+extern "C" int vlaser_chain_down_supported(int M, int N, int K) {
+  if (!(M >= 1 && M <= 16 && (N % 3 == 0 || N % 4 == 0) && K == 8960)) return 0;
+  int c, g;
+  vlaser_chain_down_geometry(N, &c, &g);
+  return g == 1 || M <= 8;            // two column groups per workgroup x 16 rows would spill
+}
+/* column geometry of vlaser_chain_down / ops.pack_down4 for an output width N: cols per group (3 or 4) and groups per workgroup, chosen for ~256 workgroups */
+extern "C" int vlaser_chain_down_geometry(int N, int* cols, int* groups) {
+  const int c = (N % 3 == 0) ? 3 : 4;
+  const int g = (N / c >= 512 && (N / c) % 2 == 0) ? 2 : 1;
+  if (cols) *cols = c;
+  if (groups) *groups = g;
+  return N / (c * g);
+}
 
-/* x bf16 [M, ldx] (ldx >= K), W = ops.pack_down4(down_proj.weight, NW, NL), res / h_out bf16 [M, N] (may not alias): h_out = bf16(res + x @ W^T) */
+/* x bf16 [M, ldx] (ldx >= K), W = ops.pack_down4(down_proj.weight), res / h_out bf16 [M, N] (may not alias): h_out = bf16(res + x @ W^T) */
 extern "C" int vlaser_chain_down(const void* x, int ldx, const void* W, const void* res, void* h_out, int M, int N, int K, unsigned long long* dbg, vl_stream_t s) {
   VL_CHECK(x && W && res && h_out && res != h_out, "vlaser_chain_down: null operand (or res == h_out: every workgroup reads its residual columns while others store)");
-  VL_CHECK(vlaser_chain_down_supported(M, N, K) && ldx >= K && ldx % 8 == 0, "vlaser_chain_down: built for K = 8960 (7 waves x 10 loads x 128), N %% 4 == 0, M <= 16 (got M %d N %d K %d)", M, N, K);
-  VL_CHECK(((uintptr_t)W & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)res & 7) == 0 && ((uintptr_t)h_out & 7) == 0 && N % 4 == 0, "vlaser_chain_down: alignment");
+  VL_CHECK(vlaser_chain_down_supported(M, N, K) && ldx >= K && ldx % 8 == 0, "vlaser_chain_down: built for K = 8960 (7 waves x 10 loads x 128), N %% 3 == 0 or N %% 4 == 0, M <= 16 (got M %d N %d K %d)", M, N, K);
+  VL_CHECK(((uintptr_t)W & 15) == 0 && ((uintptr_t)x & 15) == 0, "vlaser_chain_down: alignment");
   ChainDownP p;
   p.x = (const bf16_t*)x; p.W = (const u32x4*)W; p.res = (const bf16_t*)res; p.h_out = (bf16_t*)h_out; p.M = M; p.N = N; p.ldx = ldx; p.dbg = dbg;
+  int cols, groups;
+  const int wgs = vlaser_chain_down_geometry(N, &cols, &groups);
   const int rg = (M + 3) / 4;
   hipStream_t stream = (hipStream_t)s;
-#define CD_CASE(RG_)                                                                                                                   \
-  if (rg == RG_) {                                                                                                                     \
-    if (dbg) hipLaunchKernelGGL((chain_down_kernel<7, 10, RG_, true>), dim3(N / 4), dim3(7 * 64), 0, stream, p);                         \
-    else hipLaunchKernelGGL((chain_down_kernel<7, 10, RG_, false>), dim3(N / 4), dim3(7 * 64), 0, stream, p);                            \
-    VL_LAUNCH_CHECK();                                                                                                                 \
-    return 0;                                                                                                                          \
-  }
-  CD_CASE(1) CD_CASE(2) CD_CASE(3) CD_CASE(4)
-#undef CD_CASE
+#define CD_LAUNCH(RG_, COLS_, CG_)                                                                                                       \
+  do {                                                                                                                                   \
+    if (dbg) hipLaunchKernelGGL((chain_down_kernel<7, 10, RG_, COLS_, CG_, true>), dim3(wgs), dim3(7 * 64), 0, stream, p);                 \
+    else hipLaunchKernelGGL((chain_down_kernel<7, 10, RG_, COLS_, CG_, false>), dim3(wgs), dim3(7 * 64), 0, stream, p);                    \
+    VL_LAUNCH_CHECK();                                                                                                                   \
+    return 0;                                                                                                                            \
+  } while (0)
+#define CD_CASE1(RG_) if (rg == RG_ && groups == 1) { if (cols == 3) CD_LAUNCH(RG_, 3, 1); else CD_LAUNCH(RG_, 4, 1); }
+#define CD_CASE2(RG_) if (rg == RG_ && groups == 2) { if (cols == 3) CD_LAUNCH(RG_, 3, 2); else CD_LAUNCH(RG_, 4, 2); }
+  CD_CASE1(1) CD_CASE1(2) CD_CASE1(3) CD_CASE1(4) CD_CASE2(1) CD_CASE2(2)
+#undef CD_CASE1
+#undef CD_CASE2
+#undef CD_LAUNCH
   vlaser_set_error("vlaser_chain_down: no variant");
+  return -1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ attention over the KV cache, <= 16 query tokens
+// One WAVE per (kv head, key split, batch element), NC 32-key chunks each, no LDS, no barrier: Q of the kv head's (q head, token) rows (<= 32 rows = two MFMA
+// tiles), then K and V^T of every chunk of the wave are requested in one burst (vlaser_attn_skinny staged the same work through 4-wave workgroups whose merge
+// through LDS was 1.0 us of its 6.1 us, and its vector load of valid_len[b] put an `s_waitcnt vmcnt(0)` -- a second full round trip -- between the Q and the K / V^T
+// requests).  A split leaves (m, l) fp32 and its NORMALISED output rows in bf16 (half the bytes of the fp32 partials for the 144 workgroups of the o_proj launch
+// that each merge the splits of their K range); chain_oproj weights them by l 2^(m - max m).
+struct ChainAttnP {
+  const bf16_t* q; const bf16_t* k; const bf16_t* vt;
+  float* pml; bf16_t* po;
+  const int32_t* valid_len;
+  long long q_bs, q_hs, q_ss, k_bs, k_hs, vt_bs, vt_hs;
+  int sq, kv_len, G, ld_vt, mode, blk_start, first_tok_kv_len, n_splits, n_kv;
+  float scale;
+  unsigned long long* dbg;
+};
+
+template <int NC, bool DBG>
+__global__ __launch_bounds__(64) void chain_attn_kernel(ChainAttnP p) {
+  constexpr int HD = 128, DC = 4, DT = 8;
+  const int lane = threadIdx.x, fr = lane & 15, g = lane >> 4;
+  const int kvh = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+  unsigned long long* dbg = DBG ? p.dbg + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 : nullptr;
+  CH_STAMP(0);
+  const int nq = p.sq, nrows = p.G * nq;
+  const bf16_t* K = p.k + (size_t)b * p.k_bs + (size_t)kvh * p.k_hs;
+  const bf16_t* VT = p.vt + (size_t)b * p.vt_bs + (size_t)kvh * p.vt_hs;
+  const int n_chunks = (p.kv_len + 31) >> 5;
+  // ---- every request of the wave: Q rows (written by the previous launch), then K / V^T of its NC chunks (clamped: a chunk past the end is fully masked)
+  u32x4 qv[2][DC];
+  int row_hi2[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int r = min(qt * 16 + fr, nrows - 1);
+    const int hg = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)nq)), tok = r - hg * nq;
+    row_hi2[qt] = (tok == 0 && p.first_tok_kv_len > 0) ? p.first_tok_kv_len : 0x7fffffff;
+    const bf16_t* Q = p.q + (size_t)b * p.q_bs + (size_t)(kvh * p.G + hg) * p.q_hs + (size_t)tok * p.q_ss;
+#pragma unroll
+    for (int dc = 0; dc < DC; ++dc) qv[qt][dc] = ld_global_16(Q + dc * 32 + g * 8);
+  }
+  u32x4 kf[NC][2][DC], vf[NC][DT];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int key0 = min(split * NC + c, n_chunks - 1) << 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int key = key0 + (fr >> 2) * 8 + t * 4 + (fr & 3);
+#pragma unroll
+      for (int dc = 0; dc < DC; ++dc) kf[c][t][dc] = ld_global_16(K + (size_t)min(key, p.kv_len - 1) * HD + dc * 32 + g * 8);
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vf[c][dt] = ld_global_16(VT + (size_t)(dt * 16 + fr) * p.ld_vt + key0 + g * 8);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // (behind the requests: the two scalar round trips -- pointer, value -- of the valid length run while the vector loads are in flight)
+  int lim1 = p.kv_len, lo2 = 0x7fffffff, hi2 = 0;
+  if (p.mode == VL_ATTN_PREFIX) {
+    lim1 = min(p.valid_len ? vl_sload_i32(p.valid_len + b) : p.kv_len, p.kv_len);      // scalar cache: not in the vmcnt queue
+    lo2 = p.blk_start; hi2 = p.kv_len;
+  }
+  f32x4 o[2][DT];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[qt][i] = f32x4{0, 0, 0, 0};
+  float m_run[2] = {-1.0e30f, -1.0e30f}, l_run[2] = {0.f, 0.f};
+  const float sc = p.scale * 1.4426950408889634f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int ci = split * NC + c;
+    const int key0 = min(ci, n_chunks - 1) << 5;
+    const bool live = ci < n_chunks;                         // wave-uniform
+    bool visk[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + g * 8 + t * 4 + r;
+        visk[t][r] = live & ((key < lim1) | ((key >= lo2) & (key < hi2)));        // bitwise: `&&` / `||` on lane-varying flags become exec-branch blocks
+      }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      f32x4 s[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int dc = 0; dc < DC; ++dc) acc = mfma16(as_bf16x8(kf[c][t][dc]), as_bf16x8(qv[qt][dc]), acc);
+        s[t] = acc;
+      }
+      float mx = -1.0e30f;
+      bool vis[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = key0 + g * 8 + t * 4 + r;
+          vis[t][r] = visk[t][r] & ((key < lim1) | (key < row_hi2[qt]));
+          s[t][r] *= sc;
+          mx = vis[t][r] ? fmaxf(mx, s[t][r]) : mx;
+        }
+      mx = vl_xor32_max(vl_xor16_max(mx));
+      const float m_new = fmaxf(m_run[qt], mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+      m_run[qt] = m_new;
+      float pv[8], psum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pe = vis[t][r] ? __builtin_amdgcn_exp2f(s[t][r] - m_new) : 0.f;
+          psum += pe;
+          pv[t * 4 + r] = pe;
+        }
+      l_run[qt] = l_run[qt] * alpha + psum;
+      const u32x4 pk = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]), pack_bf16x2(pv[4], pv[5]), pack_bf16x2(pv[6], pv[7])};
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        f32x4 acc = o[qt][dt];
+        acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
+        o[qt][dt] = mfma16(as_bf16x8(vf[c][dt]), as_bf16x8(pk), acc);
+      }
+    }
+  }
+  if constexpr (DBG) asm volatile("" ::"v"(o[0][0][0]));
+  CH_STAMP(1);
+  // ---- the split's partial: (m, l) and the normalised rows (bf16); lane (fr, g) holds d = 16 dt + 4 g .. + 4 of row 16 qt + fr
+  const size_t pidx = ((size_t)b * p.n_kv + kvh) * p.n_splits + split;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const float l_tot = vl_xor32_sum(vl_xor16_sum(l_run[qt]));
+    const int row = qt * 16 + fr;
+    if (row < nrows) {
+      if (g == 0) *reinterpret_cast<f32x2_t*>(p.pml + (pidx * 32 + row) * 2) = f32x2_t{m_run[qt], l_tot};
+      const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+      bf16_t* dst = p.po + (pidx * 32 + row) * 128 + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+        *reinterpret_cast<u32x2*>(dst + dt * 16) = u32x2{pack_bf16x2(o[qt][dt][0] * inv, o[qt][dt][1] * inv), pack_bf16x2(o[qt][dt][2] * inv, o[qt][dt][3] * inv)};
+    }
+  }
+  CH_STAMP(3);
+}
+
+/* vlaser_attn_skinny's arguments (part_m = fp32 [B, n_kv, n_splits, 32, 2] (m, l) pairs, part_o = BF16 [B, n_kv, n_splits, 32, 128] normalised rows, part_l unused);
+ * n_splits must equal ceil(ceil(kv_len / 32) / 2). */
+extern "C" int vlaser_chain_attn_splits(int kv_len) { return (((kv_len + 31) >> 5) + 1) / 2; }
+extern "C" int vlaser_chain_attn(const VlaserAttnArgs* a, vl_stream_t s) {
+  VL_CHECK(a && a->q && a->k && a->vt && a->part_m && a->part_o, "vlaser_chain_attn: null pointer");
+  VL_CHECK(a->head_dim == 128 && a->n_q_heads % a->n_kv_heads == 0 && a->sq >= 1 && a->sq * (a->n_q_heads / a->n_kv_heads) <= 32, "vlaser_chain_attn: head_dim 128, group * tokens <= 32");
+  VL_CHECK(a->ld_vt % 32 == 0 && a->kv_len >= 1 && a->kv_len <= a->ld_vt && (a->mode == VL_ATTN_FULL || a->mode == VL_ATTN_PREFIX), "vlaser_chain_attn: bad cache geometry / mode");
+  VL_CHECK(a->n_splits == vlaser_chain_attn_splits(a->kv_len) && a->n_splits <= 16, "vlaser_chain_attn: n_splits must be ceil(chunks / 2) <= 16 (kv_len <= 1024)");
+  ChainAttnP p;
+  p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.vt = (const bf16_t*)a->vt; p.pml = a->part_m; p.po = (bf16_t*)a->part_o; p.valid_len = a->valid_len;
+  p.q_bs = a->q_bs; p.q_hs = a->q_hs; p.q_ss = a->q_ss; p.k_bs = a->k_bs; p.k_hs = a->k_hs; p.vt_bs = a->vt_bs; p.vt_hs = a->vt_hs;
+  p.sq = a->sq; p.kv_len = a->kv_len; p.G = a->n_q_heads / a->n_kv_heads; p.ld_vt = a->ld_vt; p.mode = a->mode; p.blk_start = a->blk_start;
+  p.first_tok_kv_len = a->first_tok_kv_len; p.n_splits = a->n_splits; p.n_kv = a->n_kv_heads; p.scale = a->scale; p.dbg = a->dbg;
+  const dim3 grid(a->n_kv_heads, a->n_splits, a->batch);
+  if (p.dbg) hipLaunchKernelGGL((chain_attn_kernel<2, true>), grid, dim3(64), 0, (hipStream_t)s, p);
+  else hipLaunchKernelGGL((chain_attn_kernel<2, false>), grid, dim3(64), 0, (hipStream_t)s, p);
+  VL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ o_proj: merge of the attention splits -> GEMV -> split-K slabs
+struct ChainOprojP {
+  const float* pml; const bf16_t* po; const u32x4* W; float* out;
+  int M, N, n_units, G, nq, nkv;
+  float inv_cpr;
+  unsigned long long* dbg;
+};
+
+// grid (N / 16 units, ks K-splits); NS = K / (ks * 256) K-steps per wave; S = attention splits (exact); the K range of a workgroup = whole heads
+template <int NS, int S, bool DBG>
+__global__ __launch_bounds__(512) void chain_oproj_kernel(ChainOprojP p) {
+  constexpr int KB = NS * 256, cpr = KB / 8, XS = KB * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
+  const int unit = blockIdx.x, ks = blockIdx.y, M = p.M;
+  unsigned long long* dbg = DBG ? p.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+  CH_STAMP(0);
+  const int xs_bytes = (M * XS + 15) & ~15;
+  char* xs = smem;
+  float* red = reinterpret_cast<float*>(smem + xs_bytes);        // [7][64] f32x4
+  const int nch = M * cpr;
+  const int ch = min(tid, nch - 1);
+  const int mm = ch_fdiv(ch, p.inv_cpr), j = ch - mm * cpr;
+  const int k = ks * KB + j * 8, h = k >> 7, d = k & 127;
+  const int b = ch_fdiv(mm, __builtin_amdgcn_rcpf((float)p.nq)), tok = mm - b * p.nq, kvh = ch_fdiv(h, __builtin_amdgcn_rcpf((float)p.G)), hg = h - kvh * p.G,
+            r = hg * p.nq + tok;
+  const size_t pbase = ((size_t)b * p.nkv + kvh) * S;
+  f32x2_t ml[S];
+  u32x4 ov[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    ml[s] = *reinterpret_cast<const f32x2_t*>(p.pml + ((pbase + s) * 32 + r) * 2);
+    ov[s] = ld_global_16(p.po + ((pbase + s) * 32 + r) * 128 + d);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  u32x4 w[NS];
+  {
+    const u32x4* src = p.W + (((size_t)ks * p.n_units + unit) * 8 + wave) * (NS * 64) + lane;
+#pragma unroll
+    for (int f = 0; f < NS; ++f) w[f] = __builtin_nontemporal_load(src + f * 64);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- x[m][k] = sum_s w_s o_s / sum_s w_s,  w_s = l_s 2^(m_s - max m)
+  float Mx = -1.0e30f;
+#pragma unroll
+  for (int s = 0; s < S; ++s) Mx = fmaxf(Mx, ml[s][0]);
+  float Ls = 0.f, v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const float f = ml[s][1] * __builtin_amdgcn_exp2f(ml[s][0] - Mx);
+    Ls += f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] += f * bf16lo_to_f32(ov[s][e]); v[2 * e + 1] += f * bf16hi_to_f32(ov[s][e]); }
+  }
+  const float inv = Ls > 0.f ? 1.0f / Ls : 0.f;
+  if (tid < nch) *reinterpret_cast<u32x4*>(xs + mm * XS + j * 16) = u32x4{pack_bf16x2(v[0] * inv, v[1] * inv), pack_bf16x2(v[2] * inv, v[3] * inv), pack_bf16x2(v[4] * inv, v[5] * inv), pack_bf16x2(v[6] * inv, v[7] * inv)};
+  __syncthreads();
+  CH_STAMP(2);
+  const bool mok = fr < M;
+  const char* xrow = xs + (mok ? fr : 0) * XS + (wave * (NS * 32) + g * 8) * 2;
+  f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int s = 0; s < NS; ++s) acc = mfma16(as_bf16x8(w[s]), as_bf16x8(*reinterpret_cast<const u32x4*>(xrow + s * 64)), acc);
+  if constexpr (DBG) asm volatile("" ::"v"(acc[0]));
+  CH_STAMP(3);
+  if (wave != 0) *reinterpret_cast<f32x4*>(red + ((wave - 1) * 64 + lane) * 4) = acc;
+  __syncthreads();
+  CH_STAMP(4);
+  if (wave == 0) {
+#pragma unroll
+    for (int w2 = 0; w2 < 7; ++w2) acc += *reinterpret_cast<const f32x4*>(red + (w2 * 64 + lane) * 4);
+    if (mok) *reinterpret_cast<f32x4*>(p.out + ((size_t)ks * M + fr) * p.N + unit * 16 + g * 4) = acc;
+  }
+  CH_STAMP(5);
+}
+
+extern "C" int vlaser_chain_oproj_supported(int M, int N, int K, int k_splits, int attn_splits, int group) {
+  if (M < 1 || M > 16 || N % 16 || K % (k_splits * 256) || K % (128 * group) || (K / k_splits) % (128) ) return 0;
+  const int ns = K / (k_splits * 256);
+  if (!((ns == 2 || ns == 3) && attn_splits == 7)) return 0;
+  return M * (K / k_splits / 8) <= 512;
+}
+
+/* args as vlaser_skinny(VL_PRO_ATTN, VL_SK_PARTIAL) with tiles_per_unit = 1, attn_m = the (m, l) pairs and attn_o = the bf16 rows written by vlaser_chain_attn */
+extern "C" int vlaser_chain_oproj(const VlaserSkinnyArgs* a, vl_stream_t s) {
+  VL_CHECK(a && a->W && a->attn_m && a->attn_o && a->out_f32, "vlaser_chain_oproj: null operand");
+  VL_CHECK(a->tiles_per_unit == 1 && vlaser_chain_oproj_supported(a->M, a->N, a->K, a->k_splits, a->attn_splits, a->attn_group),
+           "vlaser_chain_oproj: built for 16-row units, 2 / 3 K-steps per wave, 7 attention splits, M * K / k_splits / 8 <= 512 (got M %d N %d K %d ks %d splits %d)", a->M, a->N, a->K,
+           a->k_splits, a->attn_splits);
+  ChainOprojP p;
+  p.pml = a->attn_m; p.po = (const bf16_t*)a->attn_o; p.W = (const u32x4*)a->W; p.out = a->out_f32;
+  p.M = a->M; p.N = a->n_valid > 0 ? a->n_valid : a->N; p.n_units = a->N / 16; p.G = a->attn_group; p.nq = a->attn_nq; p.nkv = a->K / (128 * a->attn_group);
+  const int kb = a->K / a->k_splits, ns = kb / 256;
+  p.inv_cpr = 8.0f / (float)kb; p.dbg = a->dbg;
+  VL_CHECK(p.N % 16 == 0, "vlaser_chain_oproj: N must be a whole number of 16-column units");
+  const int lds = ((a->M * (kb * 2 + 16) + 15) & ~15) + 7 * 64 * 16;
+  const dim3 grid(a->N / 16, a->k_splits);
+  hipStream_t stream = (hipStream_t)s;
+#define CO_LAUNCH(NS_, DBG_)                                                                              \
+  do {                                                                                                    \
+    if (int rc = set_max_lds_once(chain_oproj_kernel<NS_, 7, DBG_>, lds)) return rc;                       \
+    hipLaunchKernelGGL((chain_oproj_kernel<NS_, 7, DBG_>), grid, dim3(512), lds, stream, p);               \
+    VL_LAUNCH_CHECK();                                                                                    \
+    return 0;                                                                                             \
+  } while (0)
+  if (ns == 2) { if (p.dbg) CO_LAUNCH(2, true); else CO_LAUNCH(2, false); }
+  if (ns == 3) { if (p.dbg) CO_LAUNCH(3, true); else CO_LAUNCH(3, false); }
+#undef CO_LAUNCH
+  vlaser_set_error("vlaser_chain_oproj: no variant");
   return -1;
 }

@@ -42,17 +42,6 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
 // Sum over the 16 lanes of a DPP row, every lane receiving the SAME bits: the xor butterfly (1, 2, 4, 8) on the VALU's own cross-lane path.  `__shfl_xor` compiles
 // to ds_bpermute_b32 + `s_waitcnt lgkmcnt(0)` per step (four LDS round trips in a row); quad_perm swaps lanes 1 and 2 apart, and once the quads (halves) hold
 // uniform values the 8-lane (16-lane) mirror pairs every lane with a lane of the partner quad (half) -- the same operands as xor 4 (xor 8).
@@ -69,16 +58,50 @@ __device__ __forceinline__ float group16_sum(float v) {
 }
 
 // xor-16 / xor-32 butterfly steps without the LDS crossbar: v_permlane16_swap (v_permlane32_swap) exchanges the odd 16-lane rows (the upper half) of its first operand
-// with the even rows (the lower half) of its second; with both operands = v the two results hold {own row pair's even row, odd row} in every lane
-__device__ __forceinline__ float vl_xor16_sum(float v) {
-  const uint32_t b = __builtin_bit_cast(uint32_t, v);
-  const u32x2 s = __builtin_amdgcn_permlane16_swap(b, b, false, false);
-  return __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+// with the even rows (the lower half) of its second; with both operands = v the two results hold {own row pair's even row, odd row} in every lane.
+// COMPILER TRAP (hipcc / ROCm 7.2, found on the GPU in r05): a float add / max of the two results of the builtin is folded to `op(result0, result0)`
+// (`v_permlane16_swap v1, v2; v_add_f32 v1, v1, v1`) -- every reduction through the first version of these helpers was wrong.  Storing the results separately is
+// compiled correctly; passing them through an empty asm statement restores `v_add_f32 v1, v1, v2`.
+struct vl_pair { float a, b; };
+__device__ __forceinline__ vl_pair vl_swap16(float v) {
+  const uint32_t x = __builtin_bit_cast(uint32_t, v);
+  const u32x2 s = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  uint32_t s0 = s[0], s1 = s[1];
+  asm volatile("" : "+v"(s0), "+v"(s1));
+  return {__builtin_bit_cast(float, s0), __builtin_bit_cast(float, s1)};
 }
-__device__ __forceinline__ float vl_xor32_sum(float v) {
-  const uint32_t b = __builtin_bit_cast(uint32_t, v);
-  const u32x2 s = __builtin_amdgcn_permlane32_swap(b, b, false, false);
-  return __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+__device__ __forceinline__ vl_pair vl_swap32(float v) {
+  const uint32_t x = __builtin_bit_cast(uint32_t, v);
+  const u32x2 s = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  uint32_t s0 = s[0], s1 = s[1];
+  asm volatile("" : "+v"(s0), "+v"(s1));
+  return {__builtin_bit_cast(float, s0), __builtin_bit_cast(float, s1)};
+}
+__device__ __forceinline__ float vl_xor16_sum(float v) { const vl_pair p = vl_swap16(v); return p.a + p.b; }
+__device__ __forceinline__ float vl_xor32_sum(float v) { const vl_pair p = vl_swap32(v); return p.a + p.b; }
+__device__ __forceinline__ float vl_xor16_max(float v) { const vl_pair p = vl_swap16(v); return fmaxf(p.a, p.b); }
+__device__ __forceinline__ float vl_xor32_max(float v) { const vl_pair p = vl_swap32(v); return fmaxf(p.a, p.b); }
+// Whole-wave butterfly reductions (xor 32, 16, 8, 4, 2, 1 -- every lane receives the same bits) on the VALU's cross-lane paths.  r01-r04 spelled them with
+// `__shfl_xor`, which hipcc compiles to ds_bpermute_b32 + `s_waitcnt lgkmcnt(0)` per step: six dependent LDS-crossbar round trips (~0.3 us) in every norm / seam /
+// argmax kernel.  Same operand pairs, hence identical results: permlane swaps for the two row-crossing steps, row_ror:8 = xor 8 inside a 16-lane row, row_ror:4 =
+// xor 4 once the values are 8-periodic, quad_perm for xor 2 and xor 1.
+__device__ __forceinline__ float wave_sum(float v) {
+  v = vl_xor32_sum(v);
+  v = vl_xor16_sum(v);
+  v += vl_dpp<0x128>(v);
+  v += vl_dpp<0x124>(v);
+  v += vl_dpp<0x4E>(v);
+  v += vl_dpp<0xB1>(v);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = vl_xor32_max(v);
+  v = vl_xor16_max(v);
+  v = fmaxf(v, vl_dpp<0x128>(v));
+  v = fmaxf(v, vl_dpp<0x124>(v));
+  v = fmaxf(v, vl_dpp<0x4E>(v));
+  v = fmaxf(v, vl_dpp<0xB1>(v));
+  return v;
 }
 // sum over the 16 lanes that share lane & 3 (the 16 blocks of a 4x4x4 MFMA), every lane receiving the same bits: rotate by 8 (= xor 8 inside a row), by 4 (= xor 4 once the
 // values are 8-periodic), then the rows

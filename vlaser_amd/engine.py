@@ -279,6 +279,7 @@ class SkinnyBuffers:
         self.ao = z(max_rows, stack.nq * llm.head_dim)
         self.act = z(max_rows, getattr(stack, 'I_pad', I))      # zero padding columns (never written) feed the zero-padded down weight
         self.attn_parts = ops.attn_partial_buffers(max_rows, stack.nkv, device)
+        self.chain_parts = ops.chain_attn_buffers(max_rows, stack.nkv, device)          # r05: (m, l) pairs + normalised bf16 rows of vlaser_chain_attn
         self.part_o = torch.zeros(stack.ks_o, max_rows, H, dtype=torch.float32, device=device)
         self.part_d = torch.zeros(stack.ks_down, max_rows, H, dtype=torch.float32, device=device)
         self.plans = {}      # cached launch argument structs of skinny_layer
@@ -312,11 +313,15 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
     # the action encoder's output, or what the previous layer's vlaser_chain_down published) and hands on (hC, None, 0)
     H_, I_ = llm.hidden_size, llm.intermediate_size
     chain = ('chain' in stack.opts and not fuse and not fuse_ao and n_partials == 0 and getattr(lw, 'sk_down4', None) is not None and lw.sk_qkv.tpu == 1
-             and lw.sk_gu.tpu == 2 and ops.chain_qkv_supported(M, lw.sk_qkv.N, H_) and ops.chain_gu_supported(M, lw.sk_gu.N, H_, stack.ks_o)
+             and ops.chain_qkv_supported(M, lw.sk_qkv.N, H_) and ops.chain_gu_supported(M, lw.sk_gu.N, H_, stack.ks_o, lw.sk_gu.tpu)
              and ops.chain_down_supported(M, H_, I_) and sb.act.shape[1] == I_ and h_in.data_ptr() != sb.hB.data_ptr())
+    # ... and attention + o_proj on the one-wave-per-split attention / bf16-partial merge pair when the key count gives the split count they are built for
+    nsp2 = ops.chain_attn_splits(kv_len)
+    chain_ao = (chain and not skip_post_attn and lw.sk_o.tpu == 1 and tok_per_batch * (nq // nkv) <= 32
+                and ops.chain_oproj_supported(M, lw.sk_o.N, nq * hd, stack.ks_o, nsp2, nq // nkv) and 'chain_noao' not in stack.opts)
     key = (layer, M, tok_per_batch, attn_mode, h_in.data_ptr(), 0 if partials is None else partials.data_ptr(), n_partials,
            0 if valid_len is None else valid_len.data_ptr(), pos_ids.data_ptr(), cache.k.data_ptr(), skip_post_attn, first_tok_kv_len,
-           sync.data_ptr() if fuse else 0, fuse_ao, chain)
+           sync.data_ptr() if fuse else 0, fuse_ao, chain, chain_ao)
     plan = sb.plans.get(key)
     if plan is None:
         ks, vs = cache.strides()
@@ -331,6 +336,12 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
         if not skip_post_attn:
             plan.o = ops.skinny_args(None, lw.sk_o, M, out_f32=sb.part_o, attn_m=sb.attn_parts[0], attn_l=sb.attn_parts[1],
                                      attn_o=sb.attn_parts[2], attn_splits=1, attn_group=nq // nkv, attn_nq=tok_per_batch)
+            if chain_ao:
+                plan.attn = ops.attn_skinny_args(sb.q, cache.k[layer], cache.vt[layer], (sb.chain_parts[0], sb.chain_parts[0], sb.chain_parts[1]), batch, tok_per_batch,
+                                                 kv_len, nq, nkv, hd, (tok_per_batch * nq * hd, hd, nq * hd), ks, vs, cache.s_max, hd ** -0.5, attn_mode, nsp2,
+                                                 valid_len=valid_len, blk_start=blk_start, first_tok_kv_len=first_tok_kv_len)
+                plan.o = ops.skinny_args(None, lw.sk_o, M, out_f32=sb.part_o, attn_m=sb.chain_parts[0], attn_o=sb.chain_parts[1], attn_splits=nsp2,
+                                         attn_group=nq // nkv, attn_nq=tok_per_batch)
             # (chain: vlaser_chain_qkv leaves no rounded copy of the residual stream behind -- its input already IS the rounded stream)
             plan.gu = ops.skinny_args(h_in if chain else sb.hA, lw.sk_gu, M, partials=sb.part_o, n_partials=nkv if fuse_ao else stack.ks_o, norm_w=lw.ln_post,
                                       eps=llm.rms_norm_eps, h_out=sb.hB, out=sb.act, ldo=sb.act.shape[1])
@@ -349,15 +360,21 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
         else:
             ops.launch_skinny(L.PRO_NORM, L.SK_QKV_ROPE, plan.qkv[0], stream)
     a = plan.attn
-    a.kv_len, a.n_splits, a.blk_start = kv_len, nsp, blk_start
+    a.kv_len, a.n_splits, a.blk_start = kv_len, (nsp2 if chain_ao else nsp), blk_start
     if chain:
         if skip_post_attn:
             return h_in, None, 0
-        if 'attn' not in skip:
-            ops.launch_attn_skinny(a, stream)
-        plan.o[0].attn_splits = nsp
-        if 'o' not in skip:
-            ops.launch_skinny(L.PRO_ATTN, L.SK_PARTIAL, plan.o[0], stream)
+        if chain_ao:
+            if 'attn' not in skip:
+                ops.launch_chain_attn(a, stream)
+            if 'o' not in skip:
+                ops.launch_chain_oproj(plan.o[0], stream)
+        else:
+            if 'attn' not in skip:
+                ops.launch_attn_skinny(a, stream)
+            plan.o[0].attn_splits = nsp
+            if 'o' not in skip:
+                ops.launch_skinny(L.PRO_ATTN, L.SK_PARTIAL, plan.o[0], stream)
         if 'gu' not in skip:
             ops.launch_chain_gu(plan.gu[0], stream)
         if 'down' not in skip:

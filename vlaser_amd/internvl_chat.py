@@ -101,9 +101,10 @@ class InternVLChatModel:
         self.vit = VitEngine(sd, self.config, self.device, max_tiles=self._max_tiles)
         self.use_skinny = ops.skinny_supported(self.config.llm)      # Vlaser-8B (hidden 3584) decodes through the GEMM path
         # 16-row lane-local units for the q/k/v and gate/up GEMVs of the <= 16-row path (r03 kernels; at H = 1536 both help the decode: 1.169 -> 1.12 ms per token,
-        # same-box A/B r04; the action expert at K = 768 keeps gate/up on 32-row units): VLASER_DECODE_OPTS=none restores the r03 decode
+        # same-box A/B r04; the action expert at K = 768 keeps gate/up on 32-row units): VLASER_DECODE_OPTS=none restores the r03 decode.
+        # 'chain' (r05, csrc/chain.hip): q/k/v, gate/up and the down projection on the latency-built kernels (batch <= 8): 1.089 -> 1.038 ms per token, same-box A/B
         self.llm = QwenStack(sd, 'language_model.', self.config.llm, self.device, skinny=self.use_skinny,
-                             opts=tuple(o for o in os.environ.get('VLASER_DECODE_OPTS', 'qkv16,gu16' if self.config.llm.hidden_size in (768, 1536) else '').split(',')
+                             opts=tuple(o for o in os.environ.get('VLASER_DECODE_OPTS', 'qkv16,gu16,chain' if self.config.llm.hidden_size in (768, 1536) else '').split(',')
                                         if o and o != 'none'))      # (the 16-row units are built for hidden sizes 768 / 1536: 3 / 6 K-steps per wave)
         self._alloc_llm()
         return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)

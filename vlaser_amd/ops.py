@@ -316,25 +316,55 @@ def skinny(pro, epi, x, W: PackedW, M, **kw):
 DOWN4_WAVES, DOWN4_LOADS = 7, 10          # K = 7 waves x 10 loads x 128 = 8960 (Qwen2.5-1.5B / action-expert MLP width)
 
 
+def chain_down_geometry(N):
+    """(workgroups, columns per group, groups per workgroup) of vlaser_chain_down for an output width N."""
+    c, g = C.c_int(), C.c_int()
+    wgs = L.lib().vlaser_chain_down_geometry(N, C.byref(c), C.byref(g))
+    return wgs, c.value, g.value
+
+
 def pack_down4(W, nw=DOWN4_WAVES, nl=DOWN4_LOADS):
-    """down_proj.weight [N, K] -> [N/4][nw waves][nl loads][64 lanes][8] bf16 for vlaser_chain_down: lane (b = lane >> 2, i = lane & 3) of wave w, load l holds
-    W[4 g + i, (w nl + l) 128 + 8 b : + 8] -- one contiguous 1 KiB per wave-level load, one contiguous stream per workgroup (4 output columns over the whole K)."""
+    """down_proj.weight [N, K] -> [workgroup][nw waves][nl loads][groups][16 blocks][cols][8] bf16 for vlaser_chain_down: block b, column i of group c of wave w,
+    load l holds W[(wg groups + c) cols + i, (w nl + l) 128 + 8 b : + 8] -- one contiguous 16 x cols x 16 bytes per wave-level load, one contiguous stream per
+    workgroup (groups x cols output columns over the whole K)."""
     N, K = W.shape
-    assert N % 4 == 0 and K == nw * nl * 128, (N, K)
-    v = W.view(N // 4, 4, nw, nl, 16, 8)                  # [g, i, w, l, b, e]
-    return v.permute(0, 2, 3, 4, 1, 5).contiguous().reshape(-1)      # [g, w, l, b, i, e]
+    wgs, cols, groups = chain_down_geometry(N)
+    assert N == wgs * cols * groups and K == nw * nl * 128, (N, K)
+    v = W.view(wgs, groups, cols, nw, nl, 16, 8)                # [wg, c, i, w, l, b, e]
+    return v.permute(0, 3, 4, 1, 5, 2, 6).contiguous().reshape(-1)      # [wg, w, l, c, b, i, e]
 
 
 def chain_qkv_supported(M, N, K):
     return bool(L.lib().vlaser_chain_qkv_supported(M, N, K))
 
 
-def chain_gu_supported(M, N, K, n_partials):
-    return bool(L.lib().vlaser_chain_gu_supported(M, N, K, n_partials))
+def chain_gu_supported(M, N, K, n_partials, tpu=2):
+    return bool(L.lib().vlaser_chain_gu_supported(M, N, K, n_partials, tpu))
 
 
 def chain_down_supported(M, N, K):
     return bool(L.lib().vlaser_chain_down_supported(M, N, K))
+
+
+def chain_attn_splits(kv_len):
+    return ((kv_len + 31) // 32 + 1) // 2
+
+
+def chain_attn_buffers(batch, n_kv, device, max_splits=16):
+    """(m, l) pairs fp32 [B, n_kv, splits, 32, 2] and normalised rows bf16 [B, n_kv, splits, 32, 128] of vlaser_chain_attn."""
+    return (torch.zeros(batch, n_kv, max_splits, 32, 2, dtype=torch.float32, device=device), torch.zeros(batch, n_kv, max_splits, 32, 128, dtype=BF16, device=device))
+
+
+def chain_oproj_supported(M, N, K, k_splits, attn_splits, group):
+    return bool(L.lib().vlaser_chain_oproj_supported(M, N, K, k_splits, attn_splits, group))
+
+
+def launch_chain_attn(a, stream=None):
+    L.check(L.lib().vlaser_chain_attn(C.byref(a), _stream() if stream is None else stream), 'vlaser_chain_attn')
+
+
+def launch_chain_oproj(a, stream=None):
+    L.check(L.lib().vlaser_chain_oproj(C.byref(a), _stream() if stream is None else stream), 'vlaser_chain_oproj')
 
 
 def launch_chain_qkv(a, stream=None):
