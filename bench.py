@@ -263,6 +263,7 @@ def sft_bench(rank, world, local, dist, steps, warmup=2):
             'steps': steps, 'tokens_per_rank_step': S, 'last_loss': round(loss, 4), 'fwd_bwd_ms': round(fwd_bwd_ms, 2),
             'parallelism': f'dp{world} (ZeRO-1: bucketed RCCL reduce-scatter(mean, bf16) issued from the backward + all-gather of updated params)',
             'exchange': {'bucket_mib': buckets_mb, 'NCCL_ALGO': os.environ.get('NCCL_ALGO', 'default'), 'NCCL_PROTO': os.environ.get('NCCL_PROTO', 'default'),
+                         'NCCL_MAX_NCHANNELS': os.environ.get('NCCL_MAX_NCHANNELS', 'default (profiles/r05_rccl_contention.md: 8 / 16 / 32 measured beside it)'),
                          'gradient_bytes_per_rank': 3570e6 if world > 1 else 0, **exchange_info},
             'gflop_per_rank_step': round(fl / 1e9, 1), 'mfma_frac': round(fl * world * steps / dt / (world * 2.5e15), 4)}
 
@@ -397,7 +398,8 @@ def main():
                                       'note': 'MFMA-bound part at 2.5 PFLOP/s + HBM-bound Euler part at 8 TB/s; the Euler phase is a chain of 1 400 dependent launches '
                                               '(5 per layer-step), see DESIGN.md section 3'}
             traffic, traffic_src = _pmc_traffic()
-            line['roofline'] = {'bound': 'hbm', 'kernel': 'skinny_kernel<NORM,SWIGLU> (action-expert gate/up GEMV, N=17920 K=768, M=4; 307 launches per chunk)',
+            line['roofline'] = {'bound': 'hbm', 'kernel': 'chain_gu_kernel (csrc/chain.hip: action-expert gate/up GEMV, residual + split-K reduce + RMSNorm -> SwiGLU, N=17920 K=768, M=4; '
+                                                          '280 launches per chunk)',
                                 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
                                 'traffic': traffic, 'traffic_source': traffic_src,
                                 'bytes_per_launch': byts, 'us_per_launch': round(avg_ms * 1e3, 3), 'launches_timed': n,
@@ -432,6 +434,8 @@ def main():
             watchdog.cancel()
     if rank == 0:
         if sft_line is not None:
+            if world == 1 and dist is None and 'error' not in sft_line and os.environ.get('VLASER_BENCH_NO_FORCED_DP') != '1':
+                sft_line['forced_dp_world1_ms'] = _forced_dp_world1(a.sft_steps)
             if world == 1 and not a.no_cpu_baseline and 'error' not in sft_line:
                 sft_line['cpu_baseline'] = sft_cpu_baseline(vla.base)
             line['sft'] = sft_line
@@ -444,6 +448,24 @@ def main():
     _finish(dist, line if rank == 0 else None)
     if isinstance(sft_line, dict) and 'error' in sft_line:
         sys.exit(3)                                              # the headline line is out; a failed SFT sub-bench is still a failed run
+
+
+def _forced_dp_world1(steps):
+    """ms per SFT step with the ZeRO-1 exchange forced on at world size 1 (`VLASER_FORCE_DP=1`: every bucket goes through RCCL's reduce_scatter / all_gather with
+    itself, the optimizer runs on the comm stream in front of each all-gather -- what an N-GPU rank executes, with N = 1): a CHILD bench process (the process group
+    cannot be added to this one after the fact), its own line parsed; None (with the reason) when the child fails."""
+    env = dict(os.environ, VLASER_FORCE_DP='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--workload', 'sft', '--sft-steps', str(steps), '--no-cpu-baseline'], env=env, capture_output=True,
+                           text=True, timeout=600)
+        ln = next((x for x in reversed(r.stdout.splitlines()) if x.startswith('{')), None)
+        if ln is None:
+            return {'error': f'child rc {r.returncode}: ' + (r.stderr.strip().splitlines()[-1][:160] if r.stderr.strip() else 'no line')}
+        d = json.loads(ln)
+        return {'ms_per_step': d['ms_per_step'], 'fwd_bwd_ms': d['fwd_bwd_ms'], 'rccl_version': d['exchange'].get('rccl_version'),
+                'note': 'the whole model is this rank\'s "shard": all of AdamW sits in front of the all-gathers (1/N of it at N ranks)'}
+    except Exception as e:          # noqa: BLE001 -- a side number, never a reason to lose the line
+        return {'error': f'{type(e).__name__}: {e}'[:200]}
 
 
 def _free_port():
@@ -676,7 +698,7 @@ def _pmc_traffic():
                     subprocess.run([rocprof, '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', d, '--', exe, '2'], cwd='/tmp', env=env, timeout=180,
                                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
                     f = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)[0]
-                    vals = [float(r['Counter_Value']) for r in csv.DictReader(open(f)) if 'skinny_kernel' in r['Kernel_Name'] and r['Counter_Name'] == ctr]
+                    vals = [float(r['Counter_Value']) for r in csv.DictReader(open(f)) if 'chain_gu_kernel' in r['Kernel_Name'] and r['Counter_Name'] == ctr]
                     vals = vals[len(vals) // 3:]                # drop the warm-up round
                     means[ctr] = sum(vals) / len(vals)
             traffic = int(means['FETCH_SIZE'] * 1024 * 2 + means['WRITE_SIZE'] * 1024)
@@ -756,7 +778,7 @@ def _phases(model):
 
 def _probe(model):
     """ISOLATED per-launch time of the dominant kernel -- the action expert's gate/up weight-streaming GEMV
-    (skinny_kernel<NORM,SWIGLU>, 27.5 MB of packed weights per launch): HIP events around replays of a HIP graph holding the 28
+    (chain_gu_kernel since r05, 27.5 MB of packed weights per launch): HIP events around replays of a HIP graph holding the 28
     layers' launches back to back (each launch streams a different layer's weights, i.e. HBM-cold as in the real chunk), graph
     boundaries included.  With no producer kernel in front of each launch this comes out slightly BELOW the kernel's duration inside
     the real chain (r02: 8.2 vs 8.6 us in rocprof); the roofline uses the in-chain figure of `_phases`, this one is reported beside it."""
@@ -767,8 +789,12 @@ def _probe(model):
 
     def seq():
         for lw in ex.layers:
-            ops.skinny(L.PRO_NORM, L.SK_SWIGLU, sb.hA, lw.sk_gu, M, partials=sb.part_o, n_partials=ex.ks_o, norm_w=lw.ln_post,
-                       eps=llm.rms_norm_eps, h_out=sb.hB, out=sb.act, ldo=llm.intermediate_size)
+            a, _ = ops.skinny_args(sb.hA, lw.sk_gu, M, partials=sb.part_o, n_partials=ex.ks_o, norm_w=lw.ln_post, eps=llm.rms_norm_eps, h_out=sb.hB, out=sb.act,
+                                   ldo=llm.intermediate_size)
+            if 'chain' in ex.opts and ops.chain_gu_supported(M, lw.sk_gu.N, llm.hidden_size, ex.ks_o, lw.sk_gu.tpu):
+                ops.launch_chain_gu(a)
+            else:
+                ops.launch_skinny(L.PRO_NORM, L.SK_SWIGLU, a)
     ms = _graph_ms(seq, reps=20)
     w = ex.layers[0].sk_gu
     # algorithmic bytes per launch: packed gate/up weights once + residual/partials in + SwiGLU activations out

@@ -18,8 +18,8 @@ from parity import elementwise, parity
 
 pytestmark = pytest.mark.gpu
 # per-tensor bounds of the full-depth SFT gradients (<= 2 x measured in round 5; profiles/r05_parity_numbers.md)
-GRAD_REL = {'default': 0.12}
-GRAD_COS = {'default': 0.993}
+GRAD_REL = {'language_model.lm_head.weight': 0.057, 'language_model.model.norm.weight': 0.052, 'mlp1.1.weight': 0.09, 'language_model.model.layers.27.self_attn.q_proj.weight': 0.079, 'language_model.model.layers.27.self_attn.v_proj.weight': 0.026, 'language_model.model.layers.27.mlp.down_proj.weight': 0.08, 'language_model.model.layers.14.self_attn.q_proj.weight': 0.075, 'language_model.model.layers.14.self_attn.v_proj.weight': 0.057, 'language_model.model.layers.14.mlp.down_proj.weight': 0.081, 'language_model.model.layers.0.self_attn.q_proj.weight': 0.086, 'language_model.model.layers.0.self_attn.v_proj.weight': 0.08, 'language_model.model.layers.0.mlp.down_proj.weight': 0.082, 'default': 0.09}
+GRAD_COS = {'language_model.lm_head.weight': 0.9998, 'language_model.model.norm.weight': 0.99933, 'mlp1.1.weight': 0.9989, 'language_model.model.layers.27.self_attn.q_proj.weight': 0.9986, 'language_model.model.layers.27.self_attn.v_proj.weight': 0.9998, 'language_model.model.layers.27.mlp.down_proj.weight': 0.9998, 'language_model.model.layers.14.self_attn.q_proj.weight': 0.99902, 'language_model.model.layers.14.self_attn.v_proj.weight': 0.9992, 'language_model.model.layers.14.mlp.down_proj.weight': 0.9998, 'language_model.model.layers.0.self_attn.q_proj.weight': 0.9981, 'language_model.model.layers.0.self_attn.v_proj.weight': 0.9983, 'language_model.model.layers.0.mlp.down_proj.weight': 0.9998, 'default': 0.998}
 BF = torch.bfloat16
 
 
@@ -151,7 +151,7 @@ def test_full_depth_chunk_vs_fp32_oracle(full):
     print(f'full depth vs fp32 oracle: action max|err| {e_act:.3e}; per-step velocity max|err| {[f"{x:.2e}" for x in e_vel.tolist()]} (ref max {rvel.abs().max():.3f}); '
           f'last-layer K rel err {e_k:.3e}')
     parity('full-depth chunk (2 Euler steps) vs fp32 oracle: action max|err|', e_act, 1e-2)
-    parity('full-depth chunk vs fp32 oracle: worst per-step velocity max|err|', e_vel.max().item(), 2e-2)
+    parity('full-depth chunk vs fp32 oracle: worst per-step velocity max|err|', e_vel.max().item(), 1.9e-2)
     parity('full-depth chunk vs fp32 oracle: last-layer K max|err|/max|ref|', e_k, 5e-2)
 
 
@@ -254,7 +254,7 @@ def test_full_depth_qa_logits_and_greedy_ids_vs_fp32_oracle(full):
     parity('full-depth 2B QA last-position logits vs fp32 oracle relative L2', l2, 5e-2)
     parity('full-depth 2B QA last-position logits vs fp32 oracle cosine', cos0, 0.999, lower=True)
     top = rlg[0, 0].topk(8)
-    parity('full-depth 2B QA top-8 logit VALUES vs fp32 oracle, elementwise (rtol 2e-2, atol 5e-2)', elementwise(lg[0, 0][top.indices], top.values, 2e-2, 5e-2), 1.0)
+    parity('full-depth 2B QA top-8 logit VALUES vs fp32 oracle, elementwise (rtol 2e-2, atol 5e-2)', elementwise(lg[0, 0][top.indices], top.values, 2e-2, 5e-2), 0.6)
     for t in range(4):
         t2 = rlg[0, t].topk(2).values
         if (t2[0] - t2[1]).item() > 4 * e0 * rlg[0, t].abs().max().item():          # clear margin: the ids must agree
@@ -304,7 +304,7 @@ def test_full_depth_sft_loss_and_grads_vs_fp32_oracle():
     finally:
         torch.set_grad_enabled(False)
     print(f'full-depth SFT vs fp32 oracle: loss {loss:.5f} vs {ref.item():.5f}')
-    parity('full-depth SFT loss vs fp32 oracle |err|', abs(loss - ref.item()), 2e-2)
+    parity('full-depth SFT loss vs fp32 oracle |err|', abs(loss - ref.item()), 2.5e-3)
     worst = []
     for k in keys:
         a, b = grads[k].flatten(), sdc[k].grad.flatten()
@@ -316,7 +316,7 @@ def test_full_depth_sft_loss_and_grads_vs_fp32_oracle():
     for k, rel, cos, nrel in worst:
         parity(f'full-depth SFT gradient {k}: relative Frobenius error', rel, GRAD_REL.get(k, GRAD_REL['default']))
         parity(f'full-depth SFT gradient {k}: cosine', cos, GRAD_COS.get(k, GRAD_COS['default']), lower=True)
-        parity(f'full-depth SFT gradient {k}: relative norm error', nrel, 5e-2)
+        parity(f'full-depth SFT gradient {k}: relative norm error', nrel, 5e-3)
 
 
 def test_full_depth_8b_one_tile_logits_vs_fp32_oracle():
@@ -360,7 +360,7 @@ def test_full_depth_8b_one_tile_logits_vs_fp32_oracle():
     # logit vector (2B at the same depth: see the test above; measured here 5.3e-2 in L2, 5.4e-2 in the maximum norm)
     parity('full-depth 8B last-position logits vs fp32 oracle relative L2', l2, 8e-2)
     parity('full-depth 8B last-position logits vs fp32 oracle max|err|/max|ref|', e0, 8e-2)
-    parity('full-depth 8B last-position logits vs fp32 oracle cosine', cos0, 0.997, lower=True)
+    parity('full-depth 8B last-position logits vs fp32 oracle cosine', cos0, 0.9974, lower=True)
     top = rlg[0, 0].topk(8)
     parity('full-depth 8B top-8 logit VALUES vs fp32 oracle, elementwise (rtol 2e-2, atol 5e-2)', elementwise(lg[0, 0][top.indices], top.values, 2e-2, 5e-2), 1.0)
     for t in range(3):

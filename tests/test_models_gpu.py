@@ -19,8 +19,9 @@ from parity import elementwise, parity, relmax
 pytestmark = pytest.mark.gpu
 
 # Asserted bounds = at most 2 x the worst value measured on MI355X in round 5 (profiles/r05_parity_numbers.md lists every measured figure next to its bound)
-TOL = {'vit_emb': 1.5e-2, 'vit_layer': 3e-2, 'vit_feat': 3e-2, 'logits': 3e-2, 'logits_8b': 3e-2, 'loss': 5e-3, 'graph_vs_eager': 2e-2, 'action': 1e-2,
-       'action_rel': 2.5e-2, 'velocity': 1.5e-2, 'kv': 2.2e-2, 'naive_vs_cached': 5e-3}
+TOL = {'vit_emb': 1.1e-2, 'vit_layer': 2.1e-2, 'vit_feat': 1.6e-2, 'logits': 2.7e-2, 'logits_8b': 2.9e-2, 'loss': 2e-3, 'graph_vs_eager': 2e-3, 'action': 1e-2,
+       'action_rel': 2.5e-2, 'velocity': 1.5e-2, 'kv': 2.2e-2, 'naive_vs_cached': 3.4e-3}
+EW = 0.7          # element-wise checks (worst |err| / (atol + rtol |ref|)): measured 0.23-0.45
 
 
 @pytest.fixture(scope='module')
@@ -58,13 +59,13 @@ def test_vit_layers_vs_oracle_and_golden(vlm, g56, golden_model):
     parity('vit embeddings vs oracle max|err|/max|ref|', relmax(layers[0].view(1, 1025, 1024), ovit.embeddings(sd, cfg.vision, pv)), TOL['vit_emb'])
     for i, (a, b) in enumerate(zip(layers[1:], olayers)):
         parity(f'vit layer {i} vs oracle max|err|/max|ref|', relmax(a.view(1, 1025, 1024), b), TOL['vit_layer'])
-        parity(f'vit layer {i} vs oracle elementwise (rtol 2e-2, atol 2e-2 max|ref|)', elementwise(a.view(1, 1025, 1024), b, 2e-2, 2e-2 * b.abs().max().item()), 1.0)
+        parity(f'vit layer {i} vs oracle elementwise (rtol 2e-2, atol 2e-2 max|ref|)', elementwise(a.view(1, 1025, 1024), b, 2e-2, 2e-2 * b.abs().max().item()), EW)
         _golden_close(g56, f'vit_l{i}', a.view(1, 1025, 1024), TOL['vit_layer'])
     f = vlm.extract_feature(pv)
     assert f.shape == (1, 256, cfg.llm.hidden_size)
     of = ovit.extract_feature(sd, cfg, pv)
     parity('visual tokens vs oracle max|err|/max|ref|', relmax(f, of), TOL['vit_feat'])
-    parity('visual tokens vs oracle elementwise (rtol 2e-2, atol 2e-2 max|ref|)', elementwise(f, of, 2e-2, 2e-2 * of.abs().max().item()), 1.0)
+    parity('visual tokens vs oracle elementwise (rtol 2e-2, atol 2e-2 max|ref|)', elementwise(f, of, 2e-2, 2e-2 * of.abs().max().item()), EW)
     _golden_close(g56, 'vit_feat', f, TOL['vit_feat'])
 
 
@@ -87,7 +88,7 @@ def test_logits_loss_topk(vlm, g56, golden_model):
     assert out.logits[0, -1].topk(8).indices.tolist() == g56['last_top_ids'].tolist()
     # element-wise on the values that decide the ids: the top-8 logits of the last position, each within atol + rtol |ref| of the fp32 oracle's
     top = ol[0, -1].topk(8)
-    parity('last-position top-8 logit VALUES vs oracle, elementwise (rtol 1e-2, atol 2e-2)', elementwise(out.logits[0, -1].cpu()[top.indices], top.values, 1e-2, 2e-2), 1.0)
+    parity('last-position top-8 logit VALUES vs oracle, elementwise (rtol 1e-2, atol 2e-2)', elementwise(out.logits[0, -1].cpu()[top.indices], top.values, 1e-2, 2e-2), EW)
     # visual-token indices: rank workspace holds the scatter map
     sel = (ids.flatten() == cfg.img_context_token_id)
     rank = vlm.rank_ws[:ids.numel()].cpu()
@@ -126,7 +127,7 @@ def test_greedy_ids_bit_exact(vlm, g56):
     assert gen.cpu().tolist() == g56['greedy_ids'].tolist()
     top = lg[0].topk(4, dim=-1).values.cpu().numpy()
     parity('greedy top-4 logit values vs golden max|err|/max|ref|', np.abs(top - g56['greedy_top_vals']).max() / np.abs(g56['greedy_top_vals']).max(), TOL['logits'])
-    parity('greedy top-4 logit values vs golden elementwise (rtol 1e-2, atol 2e-2)', elementwise(top, g56['greedy_top_vals'], 1e-2, 2e-2), 1.0)
+    parity('greedy top-4 logit values vs golden elementwise (rtol 1e-2, atol 2e-2)', elementwise(top, g56['greedy_top_vals'], 1e-2, 2e-2), EW)
     # eos handling: stop at the first generated token when it is declared eos
     first = int(g56['greedy_ids'][0, 0])
     gen2 = vlm.generate(pv, ids, max_new_tokens=8, eos_token_id=first)
@@ -144,7 +145,7 @@ def test_ragged_batch_generate_bit_exact(vlm, golden_dir):
     assert gen.cpu().tolist() == d['greedy_ids'].tolist()
     top = lg.topk(4, dim=-1).values.cpu().numpy()
     parity('ragged batch top-4 logit values vs golden max|err|/max|ref|', np.abs(top - d['greedy_top_vals']).max() / np.abs(d['greedy_top_vals']).max(), TOL['logits'])
-    parity('ragged batch top-4 logit values vs golden elementwise (rtol 1e-2, atol 2e-2)', elementwise(top, d['greedy_top_vals'], 1e-2, 2e-2), 1.0)
+    parity('ragged batch top-4 logit values vs golden elementwise (rtol 1e-2, atol 2e-2)', elementwise(top, d['greedy_top_vals'], 1e-2, 2e-2), 0.9)
     n1 = int(am[1].sum())
     ids_r, am_r = ids.clone(), am.clone()
     ids_r[1, :n1], ids_r[1, n1:] = ids[1, -n1:], 151643

@@ -1,7 +1,8 @@
 // Torch-free harness for hardware counters on the dominant kernel (rocprofv3 --pmc aborts inside torch on this image).
-// Launches vlaser_skinny(NORM, SWIGLU) -- the action expert's gate/up GEMV, N = 17920, K = 768, M = 4 -- through the
+// Launches the action expert's gate/up GEMV, N = 17920, K = 768, M = 4 -- since r05 vlaser_chain_gu (csrc/chain.hip: chain_gu_kernel, every unit of a workgroup
+// requested up front), with `skinny` as second argument the r01-r04 vlaser_skinny(NORM, SWIGLU) -- through the
 // C ABI, cycling over 28 distinct 27.5 MB weight buffers (770 MB > the 256 MiB Infinity Cache, so every launch
-// streams from HBM exactly as in the real layer sequence).  Usage: skinny_pmc [rounds]
+// streams from HBM exactly as in the real layer sequence).  Usage: skinny_pmc [rounds] [chain|chain16|skinny]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +16,8 @@ static unsigned short bf16(float f) { unsigned u; memcpy(&u, &f, 4); return (uns
 
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 4;
+  const char* which = argc > 2 ? argv[2] : "chain";
+  const bool old_kernel = !strcmp(which, "skinny"), units16 = !strcmp(which, "chain16");
   const int M = 4, K = 768, N = 17920, NL = 28, NP = 3;
   const size_t wbytes = (size_t)N * K * 2;
   std::vector<unsigned short> hw((size_t)N * K);
@@ -33,13 +36,14 @@ int main(int argc, char** argv) {
   hipStream_t st; CK(hipStreamCreate(&st));
   VlaserSkinnyArgs a; memset(&a, 0, sizeof(a));
   a.x = x; a.partials = parts; a.n_partials = NP; a.norm_w = nw; a.eps = 1e-6f; a.h_out = hout;
-  a.M = M; a.N = N; a.K = K; a.n_valid = N; a.tiles_per_unit = 2; a.k_splits = 1; a.out = out; a.ldo = N / 2;
+  a.M = M; a.N = N; a.K = K; a.n_valid = N; a.tiles_per_unit = units16 ? 1 : 2; a.k_splits = 1; a.out = out; a.ldo = N / 2;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int r = 0; r < rounds + 1; ++r) {
     if (r == 1) CK(hipEventRecord(e0, st));
     for (int i = 0; i < NL; ++i) {
       a.W = W[i];
-      if (vlaser_skinny(VL_PRO_NORM, VL_SK_SWIGLU, &a, (vl_stream_t)st) != 0) { fprintf(stderr, "%s\n", vlaser_last_error()); return 2; }
+      const int rc = old_kernel ? vlaser_skinny(VL_PRO_NORM, VL_SK_SWIGLU, &a, (vl_stream_t)st) : vlaser_chain_gu(&a, (vl_stream_t)st);
+      if (rc != 0) { fprintf(stderr, "%s\n", vlaser_last_error()); return 2; }
     }
   }
   CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));

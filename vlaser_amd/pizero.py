@@ -111,7 +111,8 @@ def stage_pixels(pixel_values, out, dev):
 class PiZero:
     # Euler-phase kernel options of the action expert (VLASER_EULER overrides: comma list, "none" = the r02 kernels):
     #   qkv16: 16-row lane-local units for the q/k/v weight-streaming GEMV (128 instead of 64 workgroups): -0.88 us per layer-step in-chain
-    #   gu16: the same for gate/up (1120 units): +0.6 us in-chain (five serial unit-reduce rounds per workgroup) -- off
+    #   gu16: the same for gate/up (1120 units): +0.6 us in-chain with the r03 kernel (its five units streamed one after the other, see csrc/chain.hip) -- on again
+    #         with 'chain' (r05), whose gate/up requests all five up front
     #   fuse_ogu (needs gu16): o_proj -> gate/up as one launch with an in-launch hand-off (csrc/euler.hip): +2.0 us in-chain -- off
     #   glue1: ONE launch between two passes through the layers (vlaser_vla_step: tail of Euler step s-1 + action encoder of step s) instead of four:
     #          10.9 vs 16.3 us in isolation, -0.085 ms per chunk in-chain (tools/micro/vla_step_lab.py, ab_chunk.py) -- ON.  Not bit-identical to the
@@ -120,7 +121,7 @@ class PiZero:
     #   chain (r05, needs qkv16): q/k/v, gate/up and the down projection on the latency-built kernels of csrc/chain.hip -- every request of a launch issued up front,
     #          one wave per q/k/v unit, the down projection publishing the bf16 residual stream once (no split-K slabs for the next layer to re-reduce): ON.  Same
     #          tolerance against oracle / goldens as the skinny kernels; gate/up bit-identical, q/k/v and down sum in a different fp32 order
-    EULER_DEFAULT = 'qkv16,glue1,chain'
+    EULER_DEFAULT = 'qkv16,gu16,glue1,chain'      # (gu16 ON with chain since r05: 224 workgroups x 5 units instead of 187 x 3, 11.79 -> 11.68 ms per chunk, same-box A/B)
 
     ERR_BITS = {1: 'image_text_proprio_mask: the keys the proprio row sees are not a contiguous valid prefix',
                 2: 'image_text_proprio_mask: a valid-prefix row (or the proprio row\'s own key) does not have the prefix pattern of build_causal_mask_and_position_ids',
