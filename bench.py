@@ -678,7 +678,7 @@ def _pmc_traffic():
     image, so the counters come from the torch-free harness tools/pmc/skinny_pmc (same kernel, same shape, 28 weight buffers cycled), collected as the
     guide prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE `--pmc` passes with `--kernel-trace` only, FETCH_SIZE x 2 on gfx950 (128-byte requests of wide
     coalesced reads are tallied at 64 B).  Measured IN THIS RUN when the harness and rocprofv3 are there (each pass is a child process of its own: the
-    profiler never wraps this torch process; ~5 s); otherwise the committed collection profiles/r04s_pmc_dominant_kernel.json."""
+    profiler never wraps this torch process; ~5 s); otherwise the committed collection profiles/r05g_pmc_dominant_kernel.json."""
     root = os.path.dirname(os.path.abspath(__file__))
     how = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) on tools/pmc/skinny_pmc (torch-free harness, same kernel and shape); FETCH_SIZE x 2 (gfx950)'
     exe = os.path.join(root, 'tools', 'pmc', 'skinny_pmc')
@@ -707,9 +707,9 @@ def _pmc_traffic():
             err = f'{type(e).__name__}: {e}'[:200]
     else:
         err = 'harness or rocprofv3 not found'
-    path = os.path.join(root, 'profiles', 'r04s_pmc_dominant_kernel.json')
+    path = os.path.join(root, 'profiles', 'r05g_pmc_dominant_kernel.json')
     try:
-        return json.load(open(path))['traffic_bytes_per_launch'], {'file': 'profiles/r04s_pmc_dominant_kernel.json', 'measured_in_run': False, 'live_attempt': err, 'how': how}
+        return json.load(open(path))['traffic_bytes_per_launch'], {'file': 'profiles/r05g_pmc_dominant_kernel.json', 'measured_in_run': False, 'live_attempt': err, 'how': how}
     except (OSError, KeyError, ValueError):
         return None, {'measured_in_run': False, 'live_attempt': err}
 
@@ -765,6 +765,33 @@ def _phases(model):
     e1.record()
     torch.cuda.synchronize()
     chunk_graph = e0.elapsed_time(e1) / 10
+    # the three phases IN the chain: one HIP graph each, replayed back to back with an event between them -- where the difference between `sum_ms` (each phase
+    # replayed alone, 10 x in a row) and the chunk graph sits (r04 attributed it to "cache state" without a measurement)
+    in_chain = None
+    try:
+        gs = []
+        for fn in (lambda: model._run_vit(1), lambda: model._run_prefill(1), lambda: model._run_euler(1)):
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_):
+                fn()
+            gs.append(g_)
+        for g_ in gs:
+            g_.replay()
+        torch.cuda.synchronize()
+        reps = 10
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
+        for r in range(reps):
+            evs[r][0].record()
+            for i, g_ in enumerate(gs):
+                g_.replay()
+                evs[r][i + 1].record()
+        torch.cuda.synchronize()
+        d = [sum(evs[r][i].elapsed_time(evs[r][i + 1]) for r in range(reps)) / reps for i in range(3)]
+        in_chain = {'vit_projector_scatter_ms': round(d[0], 4), 'joint_prefill_ms': round(d[1], 4), 'euler_ms': round(d[2], 4), 'sum_ms': round(sum(d), 4),
+                    'how': 'the same three graphs replayed back to back (ViT, prefill, Euler, ViT, ...) with a HIP event between them: each phase behind its real predecessor'}
+        del gs
+    except Exception as e:          # noqa: BLE001 -- a diagnostic, never a reason to lose the line
+        in_chain = {'error': f'{type(e).__name__}: {e}'[:160]}
     nL, ns = model.cfg.expert.num_hidden_layers, model.num_inference_steps
     n = nL * ns
     ph = {'vit_projector_scatter_ms': round(vit, 4), 'joint_prefill_ms': round(pre, 4), 'euler_ms': round(eul, 4), 'sum_ms': round(vit + pre + eul, 4),
@@ -772,6 +799,7 @@ def _phases(model):
           'euler_us_per_layer_step': round(eul * 1e3 / n, 3), 'euler_ms_without_dominant_kernel': round(eul_wo, 4),
           'mfma_part': {'gflop': 1726.0, 'achieved_tflops': round(1726.0 / (vit + pre), 1), 'frac_of_2500': round(1726e9 / ((vit + pre) * 1e-3) / 2.5e15, 4)},
           'euler_part': {'gbytes': 13.21, 'achieved_gbs': round(13.21e9 / (eul * 1e-3) / 1e9, 1), 'frac_of_8000': round(13.21e9 / (eul * 1e-3) / 8e12, 4)},
+          'in_chain': in_chain,
           'how': 'HIP events around 10 replays of one HIP graph per phase; the chunk graph is the three phases back to back'}
     return ph, (eul - eul_wo) * 1e3 / n, n
 

@@ -76,6 +76,9 @@ typedef struct {
 } VlaserGemmArgs;
 
 int vlaser_gemm(int epi, const VlaserGemmArgs* args, vl_stream_t stream);
+/* (ABI 6) CUs the GEMM tile heuristics may count on (64..256, default 256; returns the previous value): a ZeRO-1 rank whose RCCL reduce-scatter runs beside the
+ * backward (zero_stage1_config.json: overlap_comm) sets 256 - the CUs of RCCL's channel workgroups, so that its single-round grids stay single-round. */
+int vlaser_set_cu_budget(int cus);
 
 /* NN form: out[M,N] = A[M,K] @ B[K,N], B = args->W row-major with row stride args->ldw ("k-major").  The dgrad of an nn.Linear
  * (dX = dY @ W, autograd of modeling_internvl_chat.py:194-203 / joint_model.py:410-696) reads the forward weight [N_out, K_in] as it
@@ -168,7 +171,7 @@ int vlaser_skinny(int prologue, int epi, const VlaserSkinnyArgs* args, vl_stream
  * action mixture active (10 Euler steps x 28 layers), HF Qwen2DecoderLayer under greedy decode -- with every shape a compile-time parameter, every load of a launch
  * issued in one straight-line block, and the down projection publishing the next layer's residual stream ONCE (bf16) instead of fp32 split-K slabs that every
  * consumer workgroup re-reduces.  All three take device pointers, are asynchronous on `stream`, return 0 / negative like everything else here.
- *   vlaser_chain_qkv : args as vlaser_skinny(VL_PRO_NORM, VL_SK_QKV_ROPE) with tiles_per_unit = 1, n_partials = 0 (x = the published residual stream): one wave per 16-row
+ *   vlaser_chain_qkv : args as vlaser_skinny(VL_PRO_NORM, VL_SK_QKV_ROPE) with tiles_per_unit = 1, n_partials = 0 (x = the published residual stream) or 2 (see vlaser_chain_down2): one wave per 16-row
  *                      unit, RMSNorm + q/k/v GEMV + bias + RoPE + KV-cache scatter;  hidden 768 / 1536
  *   vlaser_chain_gu  : args as vlaser_skinny(VL_PRO_NORM, VL_SK_SWIGLU) with tiles_per_unit = 2 (or 1: 16-row lane-local units) and 2 or 3 producer slabs: bit-identical outputs, all units of a workgroup
  *                      requested up front; h_out (nullable) = bf16(x + sum partials), the residual vlaser_chain_down adds back
@@ -191,9 +194,16 @@ int vlaser_chain_down_geometry(int N, int* cols, int* groups);      /* returns t
 int vlaser_chain_qkv(const VlaserSkinnyArgs* args, vl_stream_t stream);
 int vlaser_chain_gu(const VlaserSkinnyArgs* args, vl_stream_t stream);
 int vlaser_chain_down(const void* x, int ldx, const void* W, const void* res, void* h_out, int M, int N, int K, unsigned long long* dbg, vl_stream_t stream);
+/*   vlaser_chain_down2: the same contraction as two K halves on 256 workgroups of six columns (grid.y = half): out_f32 [2][M][N] fp32 slabs, no residual, no rounding;
+ *                      W = ops.pack_down4(W, k_splits=2).  The consumer is vlaser_chain_qkv with n_partials = 2 (h = bf16(x + slab 0 + slab 1), stored to h_out by unit 0's
+ *                      wave for the o_proj -> gate/up seam): half the activation bytes per CU of vlaser_chain_down, 24 more L2 loads per lane in the q/k/v launch */
+int vlaser_chain_down2_supported(int M, int N, int K);
+int vlaser_chain_qkv2_supported(int M, int N, int K);
+int vlaser_chain_down2(const void* x, int ldx, const void* W, float* out_f32, int M, int N, int K, unsigned long long* dbg, vl_stream_t stream);
 
-/* The two fused layer-step launches measured in r03 / r04 (vlaser_fused_ogu: o_proj -> gate/up with an in-launch hand-off, +2.0 us in-chain;
- * vlaser_attn_oproj: attention + o_proj in one launch, break-even) are NOT on the default path: include/vlaser_hip_experimental.h. */
+/* (The two fused layer-step launches measured in r03 / r04 -- o_proj -> gate/up with an in-launch hand-off, +2.0 us in-chain; attention + o_proj in one launch,
+ * break-even -- lost to the chain kernels above and left the library in r05 together with include/vlaser_hip_experimental.h: profiles/r03c_euler_fusion.md,
+ * profiles/r04i_attn_oproj_timeline.md keep their measurements.) */
 
 /* ---- fused attention backward (ABI 4, r03): the backward of vlaser_attn_prefill's causal / valid-prefix attention (HF eager_attention_forward /
  * flash_attention_2 autograd, modeling_internvl_chat.py:194-203) without materialised score matrices: two deterministic kernels (no atomics) --

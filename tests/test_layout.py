@@ -28,25 +28,18 @@ def test_library_exports_every_declared_symbol():
     for n in sorted(names):
         assert hasattr(lib, n), f'{n} declared in include/vlaser_hip.h but not exported by libvlaser_hip.so'
     assert lib.vlaser_abi_version() == 6
-    # the entry points that are measured but on no default path live in their own header, and INTEGRATION.md does not offer them
-    experimental = set(re.findall(_PROTO, _header('vlaser_hip_experimental.h')))
-    assert experimental == {'vlaser_fused_ogu', 'vlaser_attn_oproj'} and not (experimental & names)
-    for n in sorted(experimental):
-        assert hasattr(lib, n), n
-    integration = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
-    assert not any(n in integration for n in experimental)
-    # every bound signature refers to a declared symbol, and the library exports nothing that no header declares
-    assert set(_lib._SIGS) <= names | experimental
+    # ONE public header (the experimental one and its two off-by-default kernels left in r05); every bound signature refers to a declared symbol, and the
+    # library exports nothing that no header declares
+    assert sorted(os.listdir(os.path.join(ROOT, 'include'))) == ['vlaser_hip.h']
+    assert set(_lib._SIGS) <= names
     import subprocess
     out = subprocess.run(['/usr/bin/nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r'\bT (vlaser_\w+)', out))
-    assert exported and exported - {'vlaser_set_error', 'vlaser_attn_oproj_debug_read'} <= names | experimental, sorted(exported - names - experimental)
+    assert exported and exported - {'vlaser_set_error'} <= names, sorted(exported - names)
 
 
 def _struct_fields(name):
     h = _header()
-    if ('} ' + name + ';') not in h:
-        h = _header('vlaser_hip_experimental.h')
     end = h.index('} ' + name + ';')
     body = h[h.rindex('typedef struct {', 0, end) + len('typedef struct {'):end]
     body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
@@ -162,12 +155,6 @@ def test_bad_arguments_return_errors_not_crashes():
     assert b'multiple of 256' in lib.vlaser_last_error()
     assert lib.vlaser_vla_step(P, None, 0, 4, 0, P, 1e-6, P, P, P, P, None, 0.1, 1, P, P, P, P, P, 4, 768, 7, None) != 0
     assert b'distinct action buffers' in lib.vlaser_last_error()
-    # attention + o_proj in one launch: batch 1 only
-    at = _lib.AttnArgs()
-    at.q, at.k, at.vt = P, P, P
-    at.batch, at.sq, at.kv_len, at.n_q_heads, at.n_kv_heads, at.head_dim, at.ld_vt, at.mode = 2, 4, 389, 12, 2, 128, 448, _lib.ATTN_PREFIX
-    assert lib.vlaser_attn_oproj(ctypes.byref(at), P, 1536, P, 768, None) != 0
-    assert b'batch 1' in lib.vlaser_last_error()
 
 
 def test_weight_packing_roundtrip():

@@ -466,9 +466,8 @@ def test_config4_shape_8b_widths_13_tiles_vs_oracle():
 
 
 def test_euler_kernel_options_are_bit_identical(golden_model, golden_dir):
-    """r03 Euler-phase kernels: 16-row lane-local units ('gu16', 'qkv16') and the fused o_proj -> gate/up launch ('fuse_ogu') compute the same
-    arithmetic in the same order as the r02 kernels -- the whole chunk (10 Euler steps, proprio riding) is bit-identical, eager and graph,
-    and no in-launch wait expires."""
+    """r03 Euler-phase kernels: 16-row lane-local units ('gu16', 'qkv16') compute the same arithmetic in the same order as the r02 kernels -- the whole
+    chunk (10 Euler steps, proprio riding) is bit-identical, eager and graph."""
     from vlaser_amd.pizero import PiZeroInference
     _, vla, sd = golden_model
     d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))
@@ -476,12 +475,11 @@ def test_euler_kernel_options_are_bit_identical(golden_model, golden_dir):
     pv = torch.randn(1, 3, 448, 448, generator=torch.Generator().manual_seed(int(d['a_seed'])))
     pro, noise = torch.from_numpy(d['a_proprio']), torch.from_numpy(d['a_noise'])
     outs = {}
-    for opts in ('none', 'gu16', 'qkv16', 'gu16,qkv16', 'gu16,qkv16,fuse_ogu'):
+    for opts in ('none', 'gu16', 'qkv16', 'gu16,qkv16'):
         for graph in (False, True):
             m = PiZeroInference(vla, max_batch=1, use_graph=graph, euler_opts=opts); m.load_state_dict(sd)
             for _ in range(3):
                 a = m.infer_action(ids, pv, proprios=pro, noise=noise)
-            assert m.sync_errors() == 0
             outs[(opts, graph)] = (a.clone(), m.last_velocities().clone())
     ref = outs[('none', False)]
     for k, v in outs.items():
@@ -515,24 +513,3 @@ def test_euler_glue1_one_launch_between_layer_passes(golden_model, golden_dir, r
     ref = torch.from_numpy(d['a_action']).float() if 'a_action' in d.files else None
     if ref is not None:
         assert (a1.view_as(ref) - ref).abs().max().item() <= (a0.view_as(ref) - ref).abs().max().item() + 4e-3
-
-
-def test_euler_fuse_ao_attention_and_o_proj_in_one_launch(golden_model, golden_dir):
-    """'fuse_ao' (vlaser_attn_oproj; measured slower, off by default -- profiles/r03u_attn_oproj.md): the engine path stays correct -- the chunk and every
-    step's velocity within bf16 noise of the two-launch path (different fp32 summation order of the attention merge and of o_proj's split-K)."""
-    from vlaser_amd.pizero import PiZeroInference
-    _, vla, sd = golden_model
-    d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))
-    ids = torch.from_numpy(d['a_input_ids'])
-    pv = torch.randn(1, 3, 448, 448, generator=torch.Generator().manual_seed(int(d['a_seed'])))
-    pro, noise = torch.from_numpy(d['a_proprio']), torch.from_numpy(d['a_noise'])
-    outs = {}
-    for opts in ('qkv16,glue1', 'qkv16,glue1,fuse_ao'):
-        m = PiZeroInference(vla, max_batch=1, use_graph=True, euler_opts=opts); m.load_state_dict(sd)
-        for _ in range(2):
-            a = m.infer_action(ids, pv, proprios=pro, noise=noise)
-        outs[opts] = (a.float().cpu().clone(), m.last_velocities().float().cpu().clone())
-    (a0, v0), (a1, v1) = outs['qkv16,glue1'], outs['qkv16,glue1,fuse_ao']
-    assert (a1 - a0).abs().max().item() <= 8e-3 * max(1.0, a0.abs().max().item()), (a1 - a0).abs().max().item()
-    assert (v1 - v0).abs().max().item() <= 3e-2 * max(1.0, v0.abs().max().item()), (v1 - v0).abs().max().item()
-

@@ -294,68 +294,29 @@ def test_attn_skinny_partials_and_merge(ops, nq_tok, kv_len, mode, nsp):
     close(part.sum(0), ref.reshape(Mrows, -1).to(BF).float() @ wo.float().t(), rtol=2e-2, name='o_proj over merged attention')
 
 
-@pytest.mark.parametrize('nq_tok,kv_len,mode,first,nq,nkv,valid', [
-    (4, 389, 'prefix', 0, 12, 2, 277), (5, 389, 'prefix', 385, 12, 2, 277),          # the expert's layer-step: 18 prefix tiles + the block's = 19 tiles, ONE pass
-    (4, 389, 'prefix', 0, 12, 2, 288), (4, 389, 'prefix', 0, 12, 2, 289), (5, 389, 'prefix', 385, 12, 2, 384),      # 19 / 20 / 25 tiles: the second pass
-    (4, 389, 'prefix', 0, 12, 2, 1), (4, 389, 'prefix', 0, 12, 2, 16), (4, 389, 'prefix', 0, 12, 2, 17), (4, 388, 'prefix', 0, 12, 2, 100),
-    (1, 70, 'full', 0, 12, 2, 0), (4, 1200, 'prefix', 0, 12, 2, 277), (16, 300, 'full', 0, 4, 2, 0), (3, 33, 'full', 0, 16, 2, 0), (4, 640, 'full', 0, 8, 2, 0)])
-def test_attn_oproj_one_launch(ops, nq_tok, kv_len, mode, first, nq, nkv, valid):
-    """vlaser_attn_oproj (r04 rewrite: attention + o_proj of a <= 16-row layer-step in ONE launch; every workgroup recomputes its kv group's attention from
-    K / V^T tiles staged in LDS by coalesced LDS-DMA, two-step softmax, P V split by head-dim tile): the per-kv-head slabs sum to o_proj(attention) of an
-    fp32 reference for the expert's geometry (4 action rows; the proprio row riding with its own key limit), prompts of every tile count around the
-    one-pass limit (19 tiles) and beyond (online rescale between passes), a single decode row, GQA groups 2 / 4 / 6 / 8, 16 tokens; the result is
-    bit-reproducible.  Group 7 (Vlaser-8B) is refused (the engine keeps the two launches there)."""
-    from vlaser_amd import _lib as L
-    smax, H = 1536, 768
-    G = nq // nkv
-    q = rnd(nq_tok, nq * 128, seed=1)
-    k = rnd(1, nkv, smax, 128, seed=2); v = rnd(1, nkv, smax, 128, seed=3)
-    k[:, :, 5] *= 4.0                                        # a dominant key early in the prompt: the second pass must rescale against it
-    vt = v.transpose(-1, -2).contiguous()
-    sc = 128 ** -0.5
-    vl = torch.tensor([valid], dtype=torch.int32, device='cuda')
-    blk = 384
-    kw = dict(valid_len=vl, blk_start=blk) if mode == 'prefix' else {}
-    parts = ops.attn_partial_buffers(1, nkv, 'cuda')
-    a = ops.attn_skinny_args(q, k, vt, parts, 1, nq_tok, kv_len, nq, nkv, 128, (nq_tok * nq * 128, 128, nq * 128), (nkv * smax * 128, smax * 128),
-                             (nkv * 128 * smax, 128 * smax), smax, sc, L.ATTN_PREFIX if mode == 'prefix' else L.ATTN_FULL, 1, first_tok_kv_len=first, **kw)
-    wo = rnd(H, nq * 128, std=0.03, seed=9)
-    wp = ops.pack_skinny(wo, nkv, 1)
-    out = torch.full((nkv, nq_tok, H), 5.0, dtype=torch.float32, device='cuda')
-    ops.launch_attn_oproj(a, wp, out, H)
-    torch.cuda.synchronize()
-    j = torch.arange(kv_len, device='cuda')[None, None]
-    if mode == 'prefix':
-        vis = ((j < valid) | (j >= blk)).expand(1, nq_tok, kv_len).clone()
-        if first:
-            vis[0, 0] = (j[0, 0] < valid) | ((j[0, 0] >= blk) & (j[0, 0] < first))      # the riding proprio row sees the block only up to itself
-    else:
-        vis = torch.ones(1, nq_tok, kv_len, dtype=torch.bool, device='cuda')
-    qq = q.view(1, nq_tok, nq, 128).permute(0, 2, 1, 3)
-    att = _attn_ref(qq, k[:, :, :kv_len], v[:, :, :kv_len], sc, vis)[0]          # [tok, nq*128]
-    ref = att.to(BF).float() @ wo.float().t()
-    close(out.sum(0), ref, rtol=2e-2, name='sum of the kv-head slabs')
-    # each slab is its own group's contribution
-    for kvh in range(nkv):
-        sl = slice(kvh * G * 128, (kvh + 1) * G * 128)
-        close(out[kvh], att[:, sl].to(BF).float() @ wo[:, sl].float().t(), rtol=2e-2, name=f'slab {kvh}')
-    out2 = torch.zeros_like(out)
-    ops.launch_attn_oproj(a, wp, out2, H)
-    assert torch.equal(out, out2)
-
-
-@pytest.mark.parametrize('nq_tok,B,kv_len,first,valid,H', [(4, 1, 389, 0, [277], 768), (5, 1, 389, 385, [277], 768), (4, 2, 389, 0, [277, 31], 768), (4, 1, 389, 0, [384], 768),
-                                                       (4, 1, 389, 0, [1], 768), (1, 1, 389, 0, [200], 1536), (4, 2, 389, 0, [384, 100], 768)])
-def test_chain_attn_oproj_vs_fp32(ops, nq_tok, B, kv_len, first, valid, H):
+@pytest.mark.parametrize('nq_tok,B,kv_len,first,valid,H,blk', [
+    (4, 1, 389, 0, [277], 768, 384), (5, 1, 389, 385, [277], 768, 384), (4, 2, 389, 0, [277, 31], 768, 384), (4, 1, 389, 0, [384], 768, 384),
+    (4, 1, 389, 0, [1], 768, 384), (1, 1, 389, 0, [200], 1536, 384), (4, 2, 389, 0, [384, 100], 768, 384),
+    # the greedy decode step's form (one token per sequence, key schedule sized for kvmax, the visible count on the device, empty trailing block): 10 / 9 / 16 / 8 / 1 splits
+    (1, 1, 640, 0, [571], 1536, 640), (1, 8, 640, 0, [561, 562, 600, 640, 1, 33, 577, 592], 1536, 640), (1, 1, 576, 0, [570], 1536, 576), (1, 2, 1024, 0, [1000, 3], 1536, 1024),
+    (1, 1, 512, 0, [512], 1536, 512), (1, 1, 64, 0, [40], 1536, 64), (4, 1, 600, 0, [500], 768, 596)])
+def test_chain_attn_oproj_vs_fp32(ops, nq_tok, B, kv_len, first, valid, H, blk):
     """r05: one wave per (kv head, key split) attention leaving (m, l) + normalised bf16 rows, merged by the o_proj launch's prologue: the sum of the split-K slabs ==
     o_proj(attention) of an fp32 reference under the VLA block mask (valid prefix + trailing block, the riding proprio row's own key limit, batches with ragged
     prefixes, a prefix of one key), and the pair agrees with vlaser_attn_skinny + vlaser_skinny(ATTN, PARTIAL) to bf16 noise; deterministic."""
     from vlaser_amd import _lib as L
-    nq, nkv, smax, blk = 12, 2, 448, 384
+    nq, nkv, smax = 12, 2, max(448, (kv_len + 63) // 64 * 64)
     G, M = nq // nkv, B * nq_tok
     ks_o = 3 if H == 768 else 2
     nsp = ops.chain_attn_splits(kv_len)
-    assert nsp == 7 and ops.chain_oproj_supported(M, H, nq * 128, ks_o, nsp, G)
+    assert nsp == ((kv_len + 31) // 32 + 1) // 2 <= 16
+    if M * (nq * 128 // ks_o // 8) > 512:            # the merge prologue has one thread per 16-byte piece of the activation tile: batch 8 x K 768 stays on the r01-r04 pair
+        assert not ops.chain_oproj_supported(M, H, nq * 128, ks_o, nsp, G)
+        with pytest.raises(L.VlaserHipError):
+            ops.launch_chain_oproj(ops.skinny_args(None, ops.pack_skinny(rnd(H, nq * 128, seed=9), ks_o, 1), M, out_f32=torch.zeros(ks_o, M, H, dtype=torch.float32, device='cuda'),
+                                                   attn_m=torch.zeros(4, device='cuda'), attn_o=torch.zeros(4, device='cuda', dtype=BF), attn_splits=nsp, attn_group=G, attn_nq=nq_tok)[0])
+        return
+    assert ops.chain_oproj_supported(M, H, nq * 128, ks_o, nsp, G)
     q = rnd(M, nq * 128, seed=1)
     k = rnd(B, nkv, smax, 128, seed=2); v = rnd(B, nkv, smax, 128, seed=3)
     k[:, :, 5] *= 4.0
@@ -391,18 +352,6 @@ def test_chain_attn_oproj_vs_fp32(ops, nq_tok, B, kv_len, first, valid, H):
     old = torch.zeros(ks_o, M, H, dtype=torch.float32, device='cuda')
     ops.skinny(L.PRO_ATTN, L.SK_PARTIAL, None, wp, M, out_f32=old, attn_m=parts[0], attn_l=parts[1], attn_o=parts[2], attn_splits=n_old, attn_group=G, attn_nq=nq_tok)
     assert (outs[0].sum(0) - old.sum(0)).abs().max().item() <= 2e-2 * max(1.0, old.sum(0).abs().max().item())
-
-
-def test_attn_oproj_refuses_odd_groups(ops):
-    from vlaser_amd import _lib as L
-    nq, nkv, smax = 28, 4, 512
-    q = rnd(2, nq * 128); k = rnd(1, nkv, smax, 128); vt = rnd(1, nkv, 128, smax)
-    a = ops.attn_skinny_args(q, k, vt, ops.attn_partial_buffers(1, nkv, 'cuda'), 1, 2, 33, nq, nkv, 128, (2 * nq * 128, 128, nq * 128), (nkv * smax * 128, smax * 128),
-                             (nkv * 128 * smax, 128 * smax), smax, 0.1, L.ATTN_FULL, 1)
-    assert not ops.attn_oproj_supported(nq, nkv, 2, 1, 128, 768)
-    wp = ops.pack_skinny(rnd(768, 1024), 4, 1); wp.K = nq * 128       # (geometry only: the launch must be refused before anything is read)
-    with pytest.raises(L.VlaserHipError):
-        ops.launch_attn_oproj(a, wp, torch.zeros(nkv, 2, 768, device='cuda'), 768)
 
 
 def _rms_ref(h, w, eps=1e-6):
@@ -610,6 +559,56 @@ def test_chain_down_vs_fp32(ops, M, N):
     ops.chain_down(xs, w4, res, out2, M, N, K)
     assert torch.equal(out2, first[:M])
     assert not ops.chain_down_supported(M, N, 18944) and not ops.chain_down_supported(17, N, K)
+
+
+@pytest.mark.parametrize('M,N', [(4, 768), (5, 768), (1, 1536), (4, 1536), (8, 768), (3, 776)])
+def test_chain_down2_and_qkv_slabs(ops, M, N):
+    """r05: the down projection as two K halves on six-column workgroups (vlaser_chain_down2: fp32 slabs, no residual) -- the slabs sum to x @ W^T, deterministic --
+    and its consumer: vlaser_chain_qkv with n_partials = 2 == the same launch on the pre-reduced stream h = bf16(res + slab 0 + slab 1) bit for bit, h stored by unit 0."""
+    from vlaser_amd import _lib as L
+    K = 8960
+    assert bool(L.lib().vlaser_chain_down2_supported(M, N, K))
+    x, w = rnd(M, K, std=0.7), rnd(N, K, std=0.03, seed=1)
+    w42 = ops.pack_down4(w, k_splits=2)
+    slabs = torch.full((2, M + 1, N), 9.0, device='cuda')[:, :M].contiguous()
+    side = torch.cuda.Stream(); junk = torch.randn(4096, 4096, device='cuda')
+    first = None
+    for rep in range(6):
+        out = torch.full((2 * M * N + 8,), 9.0, device='cuda')
+        with torch.cuda.stream(side):
+            junk @ junk
+        ops.chain_down2(x, w42, out, M, N, K)
+        first = out.clone() if first is None else first
+        assert torch.equal(out, first), rep
+    torch.cuda.synchronize()
+    assert float((first[2 * M * N:] - 9).abs().max()) == 0
+    sl = first[:2 * M * N].view(2, M, N)
+    ref = x.float() @ w.float().t()
+    close(sl.sum(0), ref, rtol=4e-3, atol=4e-3 * ref.abs().max().item(), name='sum of the two K halves')
+    close(sl[0], x[:, :K // 2].float() @ w[:, :K // 2].float().t(), rtol=4e-3, atol=4e-3 * ref.abs().max().item(), name='first half')
+    if N not in (768, 1536) or not bool(L.lib().vlaser_chain_qkv2_supported(M, 2048, N)):
+        return
+    # the consumer: q/k/v from (res, slabs) == q/k/v from h = bf16(res + s0 + s1)
+    H, nq, nkv, smax, tok = N, 12, 2, 448, M
+    res, nw = rnd(M, H, std=1.5, seed=2), (1 + 0.1 * rnd(H, seed=5).float()).to(BF)
+    h = (sl[0] + sl[1] + res.float()).to(BF)
+    W16, B16 = ops.pack_qkv16(rnd(nq * 128, H, std=0.03, seed=1), rnd(nkv * 128, H, std=0.03, seed=2), rnd(nkv * 128, H, std=0.03, seed=3), rnd(nq * 128, std=0.3, seed=4),
+                              rnd(nkv * 128, std=0.3, seed=5), rnd(nkv * 128, std=0.3, seed=6))
+    pw = ops.pack_skinny(W16, 1, 1)
+    cos, sin = ops.rope_table(64)
+    pos = (torch.arange(tok) + 2).int().cuda()
+    outs = []
+    for x_in, parts, npart in ((h, None, 0), (res, sl.contiguous(), 2)):
+        q_out = torch.zeros(M, nq * 128, dtype=BF, device='cuda')
+        kc = torch.zeros(1, nkv, smax, 128, dtype=BF, device='cuda'); vtc = torch.zeros(1, nkv, 128, smax, dtype=BF, device='cuda')
+        hA = torch.full((M, H), 7.0, dtype=BF, device='cuda')
+        a, keep = ops.skinny_args(x_in, pw, M, partials=parts, n_partials=npart, norm_w=nw, h_out=hA, bias=B16, q_out=q_out, k_cache=kc, vt_cache=vtc, rope_cos=cos, rope_sin=sin,
+                                  pos_ids=pos, n_q_heads=nq, n_kv_heads=nkv, s_max=smax, tok_per_batch=tok, slot_base=385)
+        ops.launch_chain_qkv(a)
+        outs.append((q_out, kc, vtc, hA))
+    for a_, b_ in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a_, b_)
+    assert torch.equal(outs[1][3], h) and float((outs[0][3].float() - 7).abs().max()) == 0
 
 
 def test_norms(ops):
@@ -1109,42 +1108,6 @@ def test_avg_update_ema_swa(ops):
             else:
                 assert ma.avg is None and ma.state_dict() == {}
         assert ma.n_averaged == 4
-
-
-@pytest.mark.parametrize('M', [4, 5])
-def test_fused_ogu_equals_the_two_launches_bit_for_bit(ops, M):
-    """csrc/euler.hip (r03): o_proj -> gate/up as ONE launch with an in-launch hand-off == vlaser_skinny(ATTN, PARTIAL) + vlaser_skinny(NORM, SWIGLU)
-    on 16-row units, bit for bit (same arithmetic, same order), on fresh data every iteration (the hand-off buffers keep their addresses, so a
-    stale line in any cache would show), with the arrival counters checked and the error word clear."""
-    from vlaser_amd import _lib as L
-    H, I, nq, nkv, S = 768, 8960, 12, 2, 7
-    G = nq // nkv
-    wo, gw, uw = rnd(H, nq * 128, std=0.03, seed=1), rnd(I, H, std=0.03, seed=2), rnd(I, H, std=0.03, seed=3)
-    pwo, pgu = ops.pack_skinny(wo, 3, 1), ops.pack_skinny(ops.pack_gate_up8(gw, uw), 1, 1)
-    nw = (1 + 0.1 * rnd(H, seed=5).float()).to(BF)
-    parts = ops.attn_partial_buffers(1, nkv, 'cuda')
-    part_a = torch.zeros(3, M, H, dtype=torch.float32, device='cuda'); part_b = torch.zeros_like(part_a)
-    act_a = torch.zeros(M, I, dtype=BF, device='cuda'); act_b = torch.zeros_like(act_a)
-    h_a = torch.zeros(M, H, dtype=BF, device='cuda'); h_b = torch.zeros_like(h_a)
-    sync = torch.zeros(L.FUSED_SYNC_WORDS, dtype=torch.int32, device='cuda')
-    gen = torch.Generator(device='cuda').manual_seed(11)
-    for it in range(60):
-        parts[0][:, :, :S].copy_(torch.randn(1, nkv, S, 32, generator=gen, device='cuda') * 3)
-        parts[1][:, :, :S].copy_(torch.rand(1, nkv, S, 32, generator=gen, device='cuda') * 50 + 1)
-        parts[2][:, :, :S].copy_(torch.randn(1, nkv, S, 32, 128, generator=gen, device='cuda') * 20)
-        h = (torch.randn(M, H, generator=gen, device='cuda')).to(BF)
-        ops.skinny(L.PRO_ATTN, L.SK_PARTIAL, None, pwo, M, out_f32=part_a, attn_m=parts[0], attn_l=parts[1], attn_o=parts[2], attn_splits=S, attn_group=G, attn_nq=M)
-        ops.skinny(L.PRO_NORM, L.SK_SWIGLU, h, pgu, M, partials=part_a, n_partials=3, norm_w=nw, h_out=h_a, out=act_a, ldo=I)
-        sync.zero_()
-        a = ops.fused_ogu_args(parts, pwo, part_b, h, nw, 1e-6, h_b, pgu, M, act_b, sync, S, G, M)
-        ops.launch_fused_ogu(a)
-        torch.cuda.synchronize()
-        assert int(sync[L.FUSED_SYNC_ERR]) == 0, 'bounded wait expired'
-        assert sync[[0, 32, 64, 96]].tolist() == [36, 36, 36, 36]
-        assert torch.equal(part_a, part_b), it
-        assert torch.equal(h_a, h_b), it
-        assert torch.equal(act_a, act_b), (it, int((act_a != act_b).sum()))
-    assert act_a.float().abs().max() > 0
 
 
 @pytest.mark.parametrize('M,W,ad,npart,row_off', [(4, 768, 7, 7, 0), (4, 768, 7, 7, 1), (1, 256, 7, 0, 0), (5, 512, 14, 3, 0), (16, 1024, 7, 8, 0), (9, 768, 16, 5, 2)])

@@ -38,8 +38,7 @@ def main():
         torch.cuda.synchronize()
         models.append((m, call))
         outs.append(o.float().cpu())
-        err = getattr(m, 'sync_errors', lambda: 0)()
-        print(f'variant {v!r}: ready, max|action - variant0| = {(outs[-1] - outs[0]).abs().max().item():.3e}, sync errors {err}', flush=True)
+        print(f'variant {v!r}: ready, max|action - variant0| = {(outs[-1] - outs[0]).abs().max().item():.3e}', flush=True)
     times = [[] for _ in variants]
     n = 20
     for r in range(rounds):

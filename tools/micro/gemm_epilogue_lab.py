@@ -10,7 +10,7 @@ src = os.path.join(ROOT, 'vlaser_amd', 'csrc')
 if os.environ.get('GEMM_LAB_CHILD') != '1':
     os.makedirs(LAB, exist_ok=True)
     flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-mllvm', '-amdgpu-mfma-vgpr-form']
-    objs = [os.path.join(src, f) for f in ('attn.o', 'skinny.o', 'euler.o', 'misc.o', 'train.o', 'attn_bwd.o', 'attn_o.o', 'api.o')]
+    objs = [os.path.join(src, f) for f in ('attn.o', 'skinny.o', 'chain.o', 'misc.o', 'train.o', 'attn_bwd.o', 'api.o')]
     variants = [('product', None), ('fragments', ['-DGEMM_STORE_MODE=0']), ('via LDS', ['-DGEMM_STORE_MODE=1']), ('lane swap', ['-DGEMM_STORE_MODE=2']),
                 ('no stores', ['-DGEMM_LAB_NOSTORE']), ('issue 1st', ['-DGLDS_ISSUE_FIRST=1'])]
     if os.environ.get('GEMM_LAB_ONLY'):

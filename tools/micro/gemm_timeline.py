@@ -13,7 +13,7 @@ so = os.path.join(LAB, 'libvlaser_gemmtl.so')
 src = os.path.join(ROOT, 'vlaser_amd', 'csrc')
 flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-mllvm', '-amdgpu-mfma-vgpr-form']
 subprocess.check_call(['/opt/rocm/bin/hipcc'] + flags + ['-DGEMM_TIMELINE', '-c', os.path.join(src, 'gemm.hip'), '-o', os.path.join(LAB, 'gemm_tl.o')])
-objs = [os.path.join(src, f) for f in ('attn.o', 'skinny.o', 'euler.o', 'misc.o', 'train.o', 'attn_bwd.o', 'attn_o.o', 'api.o')]
+objs = [os.path.join(src, f) for f in ('attn.o', 'skinny.o', 'chain.o', 'misc.o', 'train.o', 'attn_bwd.o', 'api.o')]
 subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + [os.path.join(LAB, 'gemm_tl.o'), '-o', so])
 os.environ['VLASER_HIP_LIB'] = so
 

@@ -2,7 +2,7 @@
 // Launches the action expert's gate/up GEMV, N = 17920, K = 768, M = 4 -- since r05 vlaser_chain_gu (csrc/chain.hip: chain_gu_kernel, every unit of a workgroup
 // requested up front), with `skinny` as second argument the r01-r04 vlaser_skinny(NORM, SWIGLU) -- through the
 // C ABI, cycling over 28 distinct 27.5 MB weight buffers (770 MB > the 256 MiB Infinity Cache, so every launch
-// streams from HBM exactly as in the real layer sequence).  Usage: skinny_pmc [rounds] [chain|chain16|skinny]
+// streams from HBM exactly as in the real layer sequence).  Usage: skinny_pmc [rounds] [chain16|chain|skinny]  (chain16 = 16-row lane-local units, the default path)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -16,7 +16,7 @@ static unsigned short bf16(float f) { unsigned u; memcpy(&u, &f, 4); return (uns
 
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 4;
-  const char* which = argc > 2 ? argv[2] : "chain";
+  const char* which = argc > 2 ? argv[2] : "chain16";      // the default path of PiZeroInference (EULER_DEFAULT: gu16 + chain)
   const bool old_kernel = !strcmp(which, "skinny"), units16 = !strcmp(which, "chain16");
   const int M = 4, K = 768, N = 17920, NL = 28, NP = 3;
   const size_t wbytes = (size_t)N * K * 2;

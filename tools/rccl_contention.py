@@ -46,7 +46,7 @@ def analyze(d):
     for r in rows:
         ev.append(dict(name=r['Kernel_Name'], s=int(r['Start_Timestamp']), e=int(r['End_Timestamp']), grid=int(r.get('Grid_Size', 0) or 0), wg=int(r.get('Workgroup_Size', 0) or 0),
                        q=r.get('Queue_Id', '')))
-    is_rccl = lambda n: any(t in n.lower() for t in ('nccl', 'rccl'))
+    is_rccl = lambda n: any(t in n.lower() for t in ('nccl', 'rccl', 'comm_shadow'))     # (comm_shadow: tools/micro/rccl_shadow_lab.py's stand-in)
     rc = [x for x in ev if is_rccl(x['name'])]
     co = [x for x in ev if not is_rccl(x['name'])]
     print(f'## RCCL kernels in the trace ({len(rc)} launches, {len(co)} compute launches)\n')

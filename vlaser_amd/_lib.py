@@ -37,12 +37,6 @@ class SkinnyArgs(C.Structure):
                 ('attn_splits', i32), ('attn_group', i32), ('attn_nq', i32), ('dbg', vp)]
 
 
-class FusedOguArgs(C.Structure):
-    _fields_ = [('attn_m', vp), ('attn_l', vp), ('attn_o', vp), ('attn_splits', i32), ('attn_group', i32), ('attn_nq', i32), ('Wo', vp), ('K_o', i32),
-                ('ks_o', i32), ('part_o', vp), ('h_in', vp), ('norm_w', vp), ('eps', f32), ('h_out', vp), ('Wgu', vp), ('M', i32), ('H', i32),
-                ('N_gu', i32), ('n_valid_gu', i32), ('act', vp), ('ld_act', i32), ('sync', vp), ('cons_delay', i32), ('dbg', vp)]
-
-
 class VlaStageArgs(C.Structure):
     _fields_ = [('ids', vp), ('ids_out', vp), ('B', i32), ('T', i32), ('pad_id', i64), ('valid_in', vp), ('valid_is_i64', i32), ('valid_out', vp),
                 ('proprio', vp), ('proprio_out', vp), ('n_proprio', i32), ('noise', vp), ('noise_out', vp), ('n_noise', i32),
@@ -50,8 +44,6 @@ class VlaStageArgs(C.Structure):
                 ('call_no', i32), ('itp_mask', vp), ('action_mask', vp), ('mask_dtype', i32), ('n_act', i32), ('pos_vlm', vp), ('pos_pro', vp), ('pos_act', vp),
                 ('pos_vlm_out', vp), ('pos_pro_out', vp), ('pos_act_out', vp), ('pos_ride_out', vp), ('itp_bs', i64), ('itp_rs', i64), ('act_bs', i64), ('act_rs', i64)]
 
-
-FUSED_SYNC_WORDS, FUSED_SYNC_ERR = 160, 128
 
 # enums (include/vlaser_hip.h)
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_LS_RES, EPI_RES, EPI_SWIGLU, EPI_QKV_ROPE, EPI_VIT_QKV, EPI_F32, EPI_PARTIAL, EPI_SWIGLU_BWD = range(11)
@@ -62,11 +54,11 @@ SK_PARTIAL, SK_QKV_ROPE, SK_SWIGLU, SK_F32, SK_BIAS, SK_BIAS_SILU = range(6)
 _SIGS = {
     'vlaser_gemm': [i32, C.POINTER(GemmArgs), vp],
     'vlaser_gemm_nn': [i32, C.POINTER(GemmArgs), vp],
+    'vlaser_set_cu_budget': [i32],
     'vlaser_attn_prefill': [C.POINTER(AttnArgs), vp],
     'vlaser_attn_skinny': [C.POINTER(AttnArgs), vp],
     'vlaser_attn_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, i32, vp],
     'vlaser_skinny': [i32, i32, C.POINTER(SkinnyArgs), vp],
-    'vlaser_fused_ogu': [C.POINTER(FusedOguArgs), vp],
     'vlaser_chain_qkv_supported': [i32, i32, i32],
     'vlaser_chain_gu_supported': [i32, i32, i32, i32, i32],
     'vlaser_chain_down_supported': [i32, i32, i32],
@@ -78,6 +70,9 @@ _SIGS = {
     'vlaser_chain_oproj': [C.POINTER(SkinnyArgs), vp],
     'vlaser_chain_gu': [C.POINTER(SkinnyArgs), vp],
     'vlaser_chain_down': [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp],
+    'vlaser_chain_down2_supported': [i32, i32, i32],
+    'vlaser_chain_qkv2_supported': [i32, i32, i32],
+    'vlaser_chain_down2': [vp, i32, vp, vp, i32, i32, i32, vp, vp],
     'vlaser_layernorm': [vp, vp, vp, vp, i32, i32, f32, vp],
     'vlaser_rmsnorm': [vp, vp, vp, i32, i32, f32, vp],
     'vlaser_im2col': [vp, vp, i32, i32, i32, vp],
@@ -88,7 +83,6 @@ _SIGS = {
     'vlaser_argmax': [vp, i32, i32, vp, vp, vp, i32, vp],
     'vlaser_vla_prep': [vp, vp, vp, vp, i32, i32, i32, f32, f32, vp],
     'vlaser_small_linear': [vp, vp, vp, vp, i32, i32, i32, vp],
-    'vlaser_attn_oproj': [C.POINTER(AttnArgs), vp, vp, i32, vp],
     'vlaser_vla_step': [vp, vp, i32, i32, i32, vp, f32, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     'vlaser_vla_euler': [vp, vp, i32, i32, vp, f32, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, vp, i32, i32, vp],
     'vlaser_vla_stage': [C.POINTER(VlaStageArgs), vp],

@@ -86,8 +86,7 @@ struct DirectChunk {
         s[t][r] = key0 + g * 8 + t * 4 + r < kv_len ? s[t][r] * sc : NEG_BIG;
         mx = fmaxf(mx, s[t][r]);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = vl_xor32_max(vl_xor16_max(mx));          // (r05) permlane swaps instead of two ds_bpermute round trips in the softmax chain of every tile: same operands
     const float m_new = fmaxf(m_run, mx);
     const float alpha = fast_exp2(m_run - m_new);
     m_run = m_new;
@@ -297,8 +296,7 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
             mx = fmaxf(mx, s[c][t][r]);
           }
         }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = vl_xor32_max(vl_xor16_max(mx));          // (r05) permlane swaps instead of two ds_bpermute round trips in the softmax chain of every tile: same operands
     const float m_new = fmaxf(m_run, mx * sc);
     const float alpha = fast_exp2(m_run - m_new);
     m_run = m_new;
@@ -375,8 +373,7 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
     __syncthreads();                                           // every wave is done with the staged tiles: the area becomes the merge buffer
     float* wm = reinterpret_cast<float*>(smem) + wave * WS;
     {
-      float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-      l_tot += __shfl_xor(l_tot, 32, 64);
+      float l_tot = vl_xor32_sum(vl_xor16_sum(l_run));
       if (g == 0) { wm[fr] = m_run; wm[16 + fr] = l_tot; }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(wm + 32 + fr * HD + dt * 16 + g * 4) = o[dt];
@@ -440,8 +437,7 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
         for (int r = 0; r < 4; ++r) o[dt][r] = o[dt][r] * fa + rw[(dt * 4 + r) * 64] * fb;
     }
   }
-  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-  l_tot += __shfl_xor(l_tot, 32, 64);
+  float l_tot = vl_xor32_sum(vl_xor16_sum(l_run));
   if (q_row < a.sq) {
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     // base-2 log-sum-exp of the scaled scores, for the fused backward (vlaser_attn_bwd): P = exp2(s * scale * log2 e - lse)
@@ -564,8 +560,7 @@ __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
           s[t][r] *= sc;
           if (vis[t][r]) mx = fmaxf(mx, s[t][r]);
         }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = vl_xor32_max(vl_xor16_max(mx));
       const float m_new = fmaxf(m_run[qt], mx);
       const float alpha = fast_exp2(m_run[qt] - m_new);
       m_run[qt] = m_new;
@@ -608,8 +603,7 @@ __global__ __launch_bounds__(256) void attn_skinny_kernel(AttnP p) {
   if (wave < nwa) {
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    float l_tot = l_run[qt] + __shfl_xor(l_run[qt], 16, 64);
-    l_tot += __shfl_xor(l_tot, 32, 64);
+    float l_tot = vl_xor32_sum(vl_xor16_sum(l_run[qt]));
     if (g == 0) { wm[qt * 16 + fr] = m_run[qt]; wm[32 + qt * 16 + fr] = l_tot; }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(wm + 64 + (qt * 16 + fr) * 128 + dt * 16 + g * 4) = o[qt][dt];

@@ -99,8 +99,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnBwdP& p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) dsum += (float)dof[dc][e] * (float)of[e];
   }
-  dsum += __shfl_xor(dsum, 16, 64);
-  dsum += __shfl_xor(dsum, 32, 64);
+  dsum = vl_xor32_sum(vl_xor16_sum(dsum));
   const float D = dsum;
   const float lse = p.lse[(size_t)h * p.S + qc];
   if (WRITE_D && g == 0 && grp == 0 && qi < p.S) p.delta[(size_t)h * p.S + qi] = D;      // (the one-launch form gets D from attn_bwd_delta_kernel: same bits)
@@ -384,8 +383,7 @@ __global__ __launch_bounds__(256) void attn_bwd_delta_kernel(AttnBwdP p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) dsum += (float)dof[e] * (float)of[e];
   }
-  dsum += __shfl_xor(dsum, 16, 64);
-  dsum += __shfl_xor(dsum, 32, 64);
+  dsum = vl_xor32_sum(vl_xor16_sum(dsum));
   if (g == 0 && qi < p.S) p.delta[(size_t)h * p.S + qi] = dsum;
 }
 template <int TK, int KS>

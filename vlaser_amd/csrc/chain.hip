@@ -259,7 +259,7 @@ extern "C" int vlaser_chain_gu(const VlaserSkinnyArgs* a, vl_stream_t s) {
 
 // ------------------------------------------------------------------------------------------------------------------ q / k / v
 struct ChainQkvP {
-  const bf16_t* h_in; const bf16_t* norm_w; const u32x4* W; const bf16_t* bias;
+  const bf16_t* h_in; const float* partials; bf16_t* h_out; const bf16_t* norm_w; const u32x4* W; const bf16_t* bias;
   bf16_t* q_out; bf16_t* k_cache; bf16_t* vt_cache; const float* rope_cos; const float* rope_sin; const int32_t* pos_ids;
   int M, n_q_heads, n_kv_heads, s_max, tok_per_batch, slot_base;
   float eps;
@@ -268,7 +268,9 @@ struct ChainQkvP {
 
 // KS = K / 32 K-steps (24: hidden 768, 48: hidden 1536), RG = ceil(M / 4) row groups of the norm prologue.  One wave = one 16-row unit of the fused q/k/v
 // matrix (head_perm16 packing: lane group g of a unit holds [d, d+1, d+64, d+65], d = 8 (unit % 8) + 2 g -- the RoPE partner of every value in the same lane).
-template <int KS, int RG, bool DBG>
+// SP = 0: h_in is the residual stream itself; SP = 2: h = bf16(h_in + slab 0 + slab 1), the two K halves of vlaser_chain_down2 (slabs first, residual last: the
+// order of every other seam here), and unit 0's wave stores h for the o_proj -> gate/up seam.
+template <int KS, int RG, int SP, bool DBG>
 __global__ __launch_bounds__(64) void chain_qkv_kernel(ChainQkvP p) {
   constexpr int K = KS * 32, NCH = KS / 4, XS = K * 2 + 16;        // NCH: 16-byte chunks of a row per lane of its 16-lane group
   extern __shared__ __attribute__((aligned(16))) char xs[];        // [4 RG][XS] normalised activations (bf16)
@@ -279,13 +281,23 @@ __global__ __launch_bounds__(64) void chain_qkv_kernel(ChainQkvP p) {
   // ---- requests, in issue order: position id of the lane's row (cos / sin hang off it), norm weight + residual stream (L2), epilogue bias, weights (HBM)
   const int pos = p.pos_ids[min(fr, M - 1)];
   u32x4 wn[NCH], hc[RG][NCH];
+  f32x4 q[RG][NCH][SP > 0 ? 2 * SP : 1];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) wn[i] = ld_global_16(p.norm_w + (j16 + 16 * i) * 8);
 #pragma unroll
   for (int rg = 0; rg < RG; ++rg) {
     const int row = min(rg * 4 + r4, M - 1);
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) hc[rg][i] = ld_global_16(p.h_in + (size_t)row * K + (j16 + 16 * i) * 8);
+    for (int i = 0; i < NCH; ++i) {
+      const int off = row * K + (j16 + 16 * i) * 8;
+      hc[rg][i] = ld_global_16(p.h_in + off);
+#pragma unroll
+      for (int u = 0; u < SP; ++u) {
+        const float* pp = p.partials + (off + u * (M * K));
+        q[rg][i][2 * u] = *reinterpret_cast<const f32x4*>(pp);
+        q[rg][i][2 * u + 1] = *reinterpret_cast<const f32x4*>(pp + 4);
+      }
+    }
   }
   const u32x2 bias = *reinterpret_cast<const u32x2*>(p.bias + unit * 16 + g * 4);
   __builtin_amdgcn_sched_barrier(0);           // pin the issue order: vmcnt retires in order, the scheduler does not know
@@ -307,6 +319,19 @@ __global__ __launch_bounds__(64) void chain_qkv_kernel(ChainQkvP p) {
   // ---- RMSNorm: xn = bf16(w * bf16(h * rsqrt(mean(h^2) + eps))), one row per 16-lane group and row group; wave-local (no barrier)
 #pragma unroll
   for (int rg = 0; rg < RG; ++rg) {
+    if constexpr (SP > 0) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        float sl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < SP; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sl[e] += q[rg][i][2 * u][e]; sl[4 + e] += q[rg][i][2 * u + 1][e]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hc[rg][i][e] = pack_bf16x2(sl[2 * e] + bf16lo_to_f32(hc[rg][i][e]), sl[2 * e + 1] + bf16hi_to_f32(hc[rg][i][e]));
+        if (blockIdx.x == 0 && rg * 4 + r4 < M) st_global_16(p.h_out + (size_t)(rg * 4 + r4) * K + (j16 + 16 * i) * 8, hc[rg][i]);
+      }
+    }
     float ssq = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
@@ -377,30 +402,33 @@ __global__ __launch_bounds__(64) void chain_qkv_kernel(ChainQkvP p) {
 }
 
 extern "C" int vlaser_chain_qkv_supported(int M, int N, int K) { return M >= 1 && ((K == 768 && M <= 16) || (K == 1536 && M <= 8)) && N % 128 == 0; }      // (hidden 1536 x 16 rows would spill)
+/* with the two fp32 slabs of vlaser_chain_down2 as input (n_partials = 2) */
+extern "C" int vlaser_chain_qkv2_supported(int M, int N, int K) { return M >= 1 && ((K == 768 && M <= 8) || (K == 1536 && M <= 4)) && N % 128 == 0; }
 
 extern "C" int vlaser_chain_qkv(const VlaserSkinnyArgs* a, vl_stream_t s) {
   VL_CHECK(a && a->x && a->W && a->norm_w && a->bias && a->q_out && a->k_cache && a->vt_cache && a->rope_cos && a->rope_sin && a->pos_ids, "vlaser_chain_qkv: null operand");
   VL_CHECK(a->tiles_per_unit == 1 && a->k_splits == 1, "vlaser_chain_qkv: weights packed in 16-row lane-local units (pack_qkv16 + pack_skinny(..., 1, 1))");
-  VL_CHECK(a->n_partials == 0, "vlaser_chain_qkv: reads the residual stream as published by vlaser_chain_down (no split-K slabs)");
-  VL_CHECK(vlaser_chain_qkv_supported(a->M, a->N, a->K), "vlaser_chain_qkv: built for hidden 768 / 1536, M <= 16, whole heads (got M %d N %d K %d)", a->M, a->N, a->K);
+  VL_CHECK(a->n_partials == 0 || (a->n_partials == 2 && a->partials && a->h_out), "vlaser_chain_qkv: reads the residual stream as published by vlaser_chain_down (no slabs) or x + the two slabs of vlaser_chain_down2 (then h_out receives the rounded sum)");
+  VL_CHECK(a->n_partials == 0 ? vlaser_chain_qkv_supported(a->M, a->N, a->K) : vlaser_chain_qkv2_supported(a->M, a->N, a->K),
+           "vlaser_chain_qkv: built for hidden 768 / 1536, M <= 16 (8 / 4 with slabs), whole heads (got M %d N %d K %d slabs %d)", a->M, a->N, a->K, a->n_partials);
   VL_CHECK(((uintptr_t)a->W & 15) == 0 && ((uintptr_t)a->x & 15) == 0 && ((uintptr_t)a->norm_w & 15) == 0 && ((uintptr_t)a->bias & 7) == 0, "vlaser_chain_qkv: alignment");
   ChainQkvP p;
-  p.h_in = (const bf16_t*)a->x; p.norm_w = (const bf16_t*)a->norm_w; p.W = (const u32x4*)a->W; p.bias = (const bf16_t*)a->bias;
+  p.h_in = (const bf16_t*)a->x; p.partials = a->partials; p.h_out = (bf16_t*)a->h_out; p.norm_w = (const bf16_t*)a->norm_w; p.W = (const u32x4*)a->W; p.bias = (const bf16_t*)a->bias;
   p.q_out = (bf16_t*)a->q_out; p.k_cache = (bf16_t*)a->k_cache; p.vt_cache = (bf16_t*)a->vt_cache; p.rope_cos = a->rope_cos; p.rope_sin = a->rope_sin;
   p.pos_ids = a->pos_ids; p.M = a->M; p.n_q_heads = a->n_q_heads; p.n_kv_heads = a->n_kv_heads; p.s_max = a->s_max; p.tok_per_batch = a->tok_per_batch;
   p.slot_base = a->slot_base; p.eps = a->eps; p.dbg = a->dbg;
   const int units = a->N / 16, rg = (a->M + 3) / 4, ks = a->K / 32;
   const int lds = 4 * rg * (a->K * 2 + 16);
   hipStream_t stream = (hipStream_t)s;
-#define CQ_LAUNCH(KS_, RG_, DBG_)                                                                       \
-  do {                                                                                                  \
-    if (int rc = set_max_lds_once(chain_qkv_kernel<KS_, RG_, DBG_>, lds)) return rc;                     \
-    hipLaunchKernelGGL((chain_qkv_kernel<KS_, RG_, DBG_>), dim3(units), dim3(64), lds, stream, p);       \
-    VL_LAUNCH_CHECK();                                                                                  \
-    return 0;                                                                                           \
+#define CQ_LAUNCH(KS_, RG_, SP_, DBG_)                                                                      \
+  do {                                                                                                      \
+    if (int rc = set_max_lds_once(chain_qkv_kernel<KS_, RG_, SP_, DBG_>, lds)) return rc;                    \
+    hipLaunchKernelGGL((chain_qkv_kernel<KS_, RG_, SP_, DBG_>), dim3(units), dim3(64), lds, stream, p);      \
+    VL_LAUNCH_CHECK();                                                                                      \
+    return 0;                                                                                               \
   } while (0)
-#define CQ_CASE(KS_, RG_) if (ks == KS_ && rg == RG_) { if (p.dbg) CQ_LAUNCH(KS_, RG_, true); else CQ_LAUNCH(KS_, RG_, false); }
-  CQ_CASE(24, 1) CQ_CASE(24, 2) CQ_CASE(24, 3) CQ_CASE(24, 4) CQ_CASE(48, 1) CQ_CASE(48, 2)
+#define CQ_CASE(KS_, RG_, SP_) if (ks == KS_ && rg == RG_ && a->n_partials == SP_) { if (p.dbg) CQ_LAUNCH(KS_, RG_, SP_, true); else CQ_LAUNCH(KS_, RG_, SP_, false); }
+  CQ_CASE(24, 1, 0) CQ_CASE(24, 2, 0) CQ_CASE(24, 3, 0) CQ_CASE(24, 4, 0) CQ_CASE(48, 1, 0) CQ_CASE(48, 2, 0) CQ_CASE(24, 1, 2) CQ_CASE(24, 2, 2) CQ_CASE(48, 1, 2)
 #undef CQ_CASE
 #undef CQ_LAUNCH
   vlaser_set_error("vlaser_chain_qkv: no variant");
@@ -409,7 +437,7 @@ extern "C" int vlaser_chain_qkv(const VlaserSkinnyArgs* a, vl_stream_t s) {
 
 // ------------------------------------------------------------------------------------------------------------------ down projection
 struct ChainDownP {
-  const bf16_t* x; const u32x4* W; const bf16_t* res; bf16_t* h_out;
+  const bf16_t* x; const u32x4* W; const bf16_t* res; bf16_t* h_out; float* out_f32;
   int M, N, ldx;
   unsigned long long* dbg;
 };
@@ -422,17 +450,21 @@ struct ChainDownP {
 // COLS = 3 puts N = 768 on 256 workgroups: a CU sustains ~35 GB/s of requests, so the launch lasts as long as the bytes of its busiest CU -- 54 KB of weights + the
 // whole [M, K] activation (every workgroup contracts over all of K: the price of publishing the result once) instead of 72 + 71 KB on 192 CUs.
 // RG = ceil(M / 4) row groups.
-template <int NW, int NL, int RG, int COLS, int CG, bool DBG>
+// KS = 2 (vlaser_chain_down2, grid.y = K half): every byte a CU pulls costs the same ~17 ns / KB whether it comes from HBM or from L2 (r05d timeline: 71 -> 125 ->
+// 143 KB per CU = 2.7 -> 3.75 -> 3.95 us), and at KS = 1 more than half of a CU's bytes are the activation.  Two K halves x 128 six-column workgroups = 256
+// workgroups of 54 KB weights + HALF the activation; the halves leave two fp32 slabs [2][M][N] that the q/k/v launch (one wave per unit: 24 more L2 loads per lane,
+// inside the shadow of its weight round trip) and the next gate/up's residual path reduce -- no bf16 rounding here, the consumer rounds h = bf16(res + s0 + s1).
+template <int NW, int NL, int RG, int COLS, int CG, int KS, bool DBG>
 __global__ __launch_bounds__(NW * 64) void chain_down_kernel(ChainDownP p) {
   __shared__ __attribute__((aligned(16))) float part[NW][CG][RG][4][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = lane >> 2, i = lane & 3;
-  const int M = p.M, n0 = blockIdx.x * (COLS * CG);
-  unsigned long long* dbg = DBG ? p.dbg + (size_t)blockIdx.x * 8 : nullptr;
+  const int M = p.M, n0 = blockIdx.x * (COLS * CG), kh = KS > 1 ? blockIdx.y : 0;
+  unsigned long long* dbg = DBG ? p.dbg + ((size_t)kh * gridDim.x + blockIdx.x) * 8 : nullptr;
   CH_STAMP(0);
   // ---- requests: residual (final phase: thread t -> row t / CG... see below), activations (L2), weights (HBM)
   const int fr_row = min(tid / CG, M - 1), fr_cg = tid % CG;            // final phase: thread t < M * CG finishes row t / CG of column group t % CG
   float rres[COLS];
-  {
+  if constexpr (KS == 1) {
     const bf16_t* rp = p.res + (size_t)fr_row * p.N + n0 + fr_cg * COLS;
 #pragma unroll
     for (int c = 0; c < COLS; ++c) rres[c] = bf16_to_f32(rp[c]);          // unconditional (clamped): no branch in front of the load burst
@@ -440,13 +472,13 @@ __global__ __launch_bounds__(NW * 64) void chain_down_kernel(ChainDownP p) {
   u32x4 xv[RG][NL], wv[CG][NL];
 #pragma unroll
   for (int rg = 0; rg < RG; ++rg) {
-    const bf16_t* xr = p.x + (size_t)min(rg * 4 + i, M - 1) * p.ldx + (wave * NL) * 128 + b * 8;
+    const bf16_t* xr = p.x + (size_t)min(rg * 4 + i, M - 1) * p.ldx + ((kh * NW + wave) * NL) * 128 + b * 8;
 #pragma unroll
     for (int l = 0; l < NL; ++l) xv[rg][l] = ld_global_16(xr + l * 128);
   }
   __builtin_amdgcn_sched_barrier(0);           // activations (L2) strictly in front of the weights (HBM) in the queue
   {
-    const u32x4* src = p.W + (((size_t)blockIdx.x * NW + wave) * NL) * (CG * 16 * COLS) + b * COLS + min(i, COLS - 1);
+    const u32x4* src = p.W + ((((size_t)kh * gridDim.x + blockIdx.x) * NW + wave) * NL) * (CG * 16 * COLS) + b * COLS + min(i, COLS - 1);
 #pragma unroll
     for (int l = 0; l < NL; ++l)
 #pragma unroll
@@ -493,9 +525,15 @@ __global__ __launch_bounds__(NW * 64) void chain_down_kernel(ChainDownP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) s4[r] += t[r];
     }
-    bf16_t* op = p.h_out + (size_t)fr_row * p.N + n0 + fr_cg * COLS;
+    if constexpr (KS == 1) {
+      bf16_t* op = p.h_out + (size_t)fr_row * p.N + n0 + fr_cg * COLS;
 #pragma unroll
-    for (int c = 0; c < COLS; ++c) op[c] = f32_to_bf16(s4[c] + rres[c]);
+      for (int c = 0; c < COLS; ++c) op[c] = f32_to_bf16(s4[c] + rres[c]);
+    } else {
+      float* op = p.out_f32 + ((size_t)kh * M + fr_row) * p.N + n0 + fr_cg * COLS;
+#pragma unroll
+      for (int c = 0; c < COLS; ++c) op[c] = s4[c];
+    }
   }
   CH_STAMP(5);
 }
@@ -522,15 +560,15 @@ extern "C" int vlaser_chain_down(const void* x, int ldx, const void* W, const vo
   VL_CHECK(vlaser_chain_down_supported(M, N, K) && ldx >= K && ldx % 8 == 0, "vlaser_chain_down: built for K = 8960 (7 waves x 10 loads x 128), N %% 3 == 0 or N %% 4 == 0, M <= 16 (got M %d N %d K %d)", M, N, K);
   VL_CHECK(((uintptr_t)W & 15) == 0 && ((uintptr_t)x & 15) == 0, "vlaser_chain_down: alignment");
   ChainDownP p;
-  p.x = (const bf16_t*)x; p.W = (const u32x4*)W; p.res = (const bf16_t*)res; p.h_out = (bf16_t*)h_out; p.M = M; p.N = N; p.ldx = ldx; p.dbg = dbg;
+  p.x = (const bf16_t*)x; p.W = (const u32x4*)W; p.res = (const bf16_t*)res; p.h_out = (bf16_t*)h_out; p.out_f32 = nullptr; p.M = M; p.N = N; p.ldx = ldx; p.dbg = dbg;
   int cols, groups;
   const int wgs = vlaser_chain_down_geometry(N, &cols, &groups);
   const int rg = (M + 3) / 4;
   hipStream_t stream = (hipStream_t)s;
 #define CD_LAUNCH(RG_, COLS_, CG_)                                                                                                       \
   do {                                                                                                                                   \
-    if (dbg) hipLaunchKernelGGL((chain_down_kernel<7, 10, RG_, COLS_, CG_, true>), dim3(wgs), dim3(7 * 64), 0, stream, p);                 \
-    else hipLaunchKernelGGL((chain_down_kernel<7, 10, RG_, COLS_, CG_, false>), dim3(wgs), dim3(7 * 64), 0, stream, p);                    \
+    if (dbg) hipLaunchKernelGGL((chain_down_kernel<7, 10, RG_, COLS_, CG_, 1, true>), dim3(wgs), dim3(7 * 64), 0, stream, p);              \
+    else hipLaunchKernelGGL((chain_down_kernel<7, 10, RG_, COLS_, CG_, 1, false>), dim3(wgs), dim3(7 * 64), 0, stream, p);                 \
     VL_LAUNCH_CHECK();                                                                                                                   \
     return 0;                                                                                                                            \
   } while (0)
@@ -541,6 +579,31 @@ extern "C" int vlaser_chain_down(const void* x, int ldx, const void* W, const vo
 #undef CD_CASE2
 #undef CD_LAUNCH
   vlaser_set_error("vlaser_chain_down: no variant");
+  return -1;
+}
+
+/* The same contraction split into two K halves (grid.y): out_f32 [2][M][N] fp32 slabs, no residual, no rounding.  W = ops.pack_down4(W, k_splits=2):
+ * [K half][workgroup][7 waves][5 loads][2 groups][16 blocks][cols][8]; a workgroup owns 2 x cols output columns (cols = 3 when N % 6 == 0, else 4 with N % 8 == 0). */
+extern "C" int vlaser_chain_down2_supported(int M, int N, int K) { return M >= 1 && M <= 8 && K == 8960 && (N % 6 == 0 || N % 8 == 0); }
+extern "C" int vlaser_chain_down2(const void* x, int ldx, const void* W, float* out_f32, int M, int N, int K, unsigned long long* dbg, vl_stream_t s) {
+  VL_CHECK(x && W && out_f32, "vlaser_chain_down2: null operand");
+  VL_CHECK(vlaser_chain_down2_supported(M, N, K) && ldx >= K && ldx % 8 == 0, "vlaser_chain_down2: built for K = 8960 (2 halves x 7 waves x 5 loads x 128), N %% 6 == 0 or N %% 8 == 0, M <= 8 (got M %d N %d K %d)", M, N, K);
+  VL_CHECK(((uintptr_t)W & 15) == 0 && ((uintptr_t)x & 15) == 0, "vlaser_chain_down2: alignment");
+  ChainDownP p;
+  p.x = (const bf16_t*)x; p.W = (const u32x4*)W; p.res = nullptr; p.h_out = nullptr; p.out_f32 = out_f32; p.M = M; p.N = N; p.ldx = ldx; p.dbg = dbg;
+  const int cols = (N % 6 == 0) ? 3 : 4, wgs = N / (cols * 2), rg = (M + 3) / 4;
+  hipStream_t stream = (hipStream_t)s;
+#define CD2_LAUNCH(RG_, COLS_)                                                                                                           \
+  do {                                                                                                                                   \
+    if (dbg) hipLaunchKernelGGL((chain_down_kernel<7, 5, RG_, COLS_, 2, 2, true>), dim3(wgs, 2), dim3(7 * 64), 0, stream, p);               \
+    else hipLaunchKernelGGL((chain_down_kernel<7, 5, RG_, COLS_, 2, 2, false>), dim3(wgs, 2), dim3(7 * 64), 0, stream, p);                  \
+    VL_LAUNCH_CHECK();                                                                                                                   \
+    return 0;                                                                                                                            \
+  } while (0)
+  if (rg == 1) { if (cols == 3) CD2_LAUNCH(1, 3); else CD2_LAUNCH(1, 4); }
+  if (rg == 2) { if (cols == 3) CD2_LAUNCH(2, 3); else CD2_LAUNCH(2, 4); }
+#undef CD2_LAUNCH
+  vlaser_set_error("vlaser_chain_down2: no variant");
   return -1;
 }
 
@@ -710,12 +773,13 @@ extern "C" int vlaser_chain_attn(const VlaserAttnArgs* a, vl_stream_t s) {
 // ------------------------------------------------------------------------------------------------------------------ o_proj: merge of the attention splits -> GEMV -> split-K slabs
 struct ChainOprojP {
   const float* pml; const bf16_t* po; const u32x4* W; float* out;
-  int M, N, n_units, G, nq, nkv;
+  int M, N, n_units, G, nq, nkv, n_splits;
   float inv_cpr;
   unsigned long long* dbg;
 };
 
-// grid (N / 16 units, ks K-splits); NS = K / (ks * 256) K-steps per wave; S = attention splits (exact); the K range of a workgroup = whole heads
+// grid (N / 16 units, ks K-splits); NS = K / (ks * 256) K-steps per wave; the K range of a workgroup = whole heads.  S = attention splits REQUESTED (all up front): the
+// launch has p.n_splits <= S of them (the Euler phase exactly 7 = its S; a decode step over kvmax keys 8..16) -- the requests beyond re-read the last split and get weight 0
 template <int NS, int S, bool DBG>
 __global__ __launch_bounds__(512) void chain_oproj_kernel(ChainOprojP p) {
   constexpr int KB = NS * 256, cpr = KB / 8, XS = KB * 2 + 16;
@@ -733,13 +797,15 @@ __global__ __launch_bounds__(512) void chain_oproj_kernel(ChainOprojP p) {
   const int k = ks * KB + j * 8, h = k >> 7, d = k & 127;
   const int b = ch_fdiv(mm, __builtin_amdgcn_rcpf((float)p.nq)), tok = mm - b * p.nq, kvh = ch_fdiv(h, __builtin_amdgcn_rcpf((float)p.G)), hg = h - kvh * p.G,
             r = hg * p.nq + tok;
-  const size_t pbase = ((size_t)b * p.nkv + kvh) * S;
+  const int nsp = (S == 7) ? 7 : p.n_splits;
+  const size_t pbase = ((size_t)b * p.nkv + kvh) * nsp;
   f32x2_t ml[S];
   u32x4 ov[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    ml[s] = *reinterpret_cast<const f32x2_t*>(p.pml + ((pbase + s) * 32 + r) * 2);
-    ov[s] = ld_global_16(p.po + ((pbase + s) * 32 + r) * 128 + d);
+    const int sc = (S == 7) ? s : min(s, nsp - 1);
+    ml[s] = *reinterpret_cast<const f32x2_t*>(p.pml + ((pbase + sc) * 32 + r) * 2);
+    ov[s] = ld_global_16(p.po + ((pbase + sc) * 32 + r) * 128 + d);
   }
   __builtin_amdgcn_sched_barrier(0);
   u32x4 w[NS];
@@ -756,7 +822,8 @@ __global__ __launch_bounds__(512) void chain_oproj_kernel(ChainOprojP p) {
   float Ls = 0.f, v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    const float f = ml[s][1] * __builtin_amdgcn_exp2f(ml[s][0] - Mx);
+    float f = ml[s][1] * __builtin_amdgcn_exp2f(ml[s][0] - Mx);
+    if (S != 7) f = s < nsp ? f : 0.f;
     Ls += f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[2 * e] += f * bf16lo_to_f32(ov[s][e]); v[2 * e + 1] += f * bf16hi_to_f32(ov[s][e]); }
@@ -786,7 +853,7 @@ __global__ __launch_bounds__(512) void chain_oproj_kernel(ChainOprojP p) {
 extern "C" int vlaser_chain_oproj_supported(int M, int N, int K, int k_splits, int attn_splits, int group) {
   if (M < 1 || M > 16 || N % 16 || K % (k_splits * 256) || K % (128 * group) || (K / k_splits) % (128) ) return 0;
   const int ns = K / (k_splits * 256);
-  if (!((ns == 2 || ns == 3) && attn_splits == 7)) return 0;
+  if (!((ns == 2 || ns == 3) && attn_splits >= 1 && attn_splits <= 16)) return 0;
   return M * (K / k_splits / 8) <= 512;
 }
 
@@ -794,26 +861,28 @@ extern "C" int vlaser_chain_oproj_supported(int M, int N, int K, int k_splits, i
 extern "C" int vlaser_chain_oproj(const VlaserSkinnyArgs* a, vl_stream_t s) {
   VL_CHECK(a && a->W && a->attn_m && a->attn_o && a->out_f32, "vlaser_chain_oproj: null operand");
   VL_CHECK(a->tiles_per_unit == 1 && vlaser_chain_oproj_supported(a->M, a->N, a->K, a->k_splits, a->attn_splits, a->attn_group),
-           "vlaser_chain_oproj: built for 16-row units, 2 / 3 K-steps per wave, 7 attention splits, M * K / k_splits / 8 <= 512 (got M %d N %d K %d ks %d splits %d)", a->M, a->N, a->K,
+           "vlaser_chain_oproj: built for 16-row units, 2 / 3 K-steps per wave, <= 16 attention splits, M * K / k_splits / 8 <= 512 (got M %d N %d K %d ks %d splits %d)", a->M, a->N, a->K,
            a->k_splits, a->attn_splits);
   ChainOprojP p;
   p.pml = a->attn_m; p.po = (const bf16_t*)a->attn_o; p.W = (const u32x4*)a->W; p.out = a->out_f32;
-  p.M = a->M; p.N = a->n_valid > 0 ? a->n_valid : a->N; p.n_units = a->N / 16; p.G = a->attn_group; p.nq = a->attn_nq; p.nkv = a->K / (128 * a->attn_group);
+  p.M = a->M; p.N = a->n_valid > 0 ? a->n_valid : a->N; p.n_units = a->N / 16; p.G = a->attn_group; p.nq = a->attn_nq; p.nkv = a->K / (128 * a->attn_group); p.n_splits = a->attn_splits;
   const int kb = a->K / a->k_splits, ns = kb / 256;
   p.inv_cpr = 8.0f / (float)kb; p.dbg = a->dbg;
   VL_CHECK(p.N % 16 == 0, "vlaser_chain_oproj: N must be a whole number of 16-column units");
   const int lds = ((a->M * (kb * 2 + 16) + 15) & ~15) + 7 * 64 * 16;
   const dim3 grid(a->N / 16, a->k_splits);
   hipStream_t stream = (hipStream_t)s;
-#define CO_LAUNCH(NS_, DBG_)                                                                              \
+#define CO_LAUNCH(NS_, S_, DBG_)                                                                          \
   do {                                                                                                    \
-    if (int rc = set_max_lds_once(chain_oproj_kernel<NS_, 7, DBG_>, lds)) return rc;                       \
-    hipLaunchKernelGGL((chain_oproj_kernel<NS_, 7, DBG_>), grid, dim3(512), lds, stream, p);               \
+    if (int rc = set_max_lds_once(chain_oproj_kernel<NS_, S_, DBG_>, lds)) return rc;                      \
+    hipLaunchKernelGGL((chain_oproj_kernel<NS_, S_, DBG_>), grid, dim3(512), lds, stream, p);              \
     VL_LAUNCH_CHECK();                                                                                    \
     return 0;                                                                                             \
   } while (0)
-  if (ns == 2) { if (p.dbg) CO_LAUNCH(2, true); else CO_LAUNCH(2, false); }
-  if (ns == 3) { if (p.dbg) CO_LAUNCH(3, true); else CO_LAUNCH(3, false); }
+#define CO_CASE(NS_, S_) if (ns == NS_ && sreq == S_) { if (p.dbg) CO_LAUNCH(NS_, S_, true); else CO_LAUNCH(NS_, S_, false); }
+  const int sreq = p.n_splits == 7 ? 7 : (p.n_splits <= 10 ? 10 : 16);
+  CO_CASE(2, 7) CO_CASE(3, 7) CO_CASE(2, 10) CO_CASE(3, 10) CO_CASE(2, 16) CO_CASE(3, 16)
+#undef CO_CASE
 #undef CO_LAUNCH
   vlaser_set_error("vlaser_chain_oproj: no variant");
   return -1;

@@ -135,7 +135,7 @@ __device__ __forceinline__ int vl_sload_i32(const int32_t* p) { return *reinterp
 
 // ---- kernel arguments in ONE scalar-memory round trip.  hipcc issues the s_load of a by-value argument struct piecemeal, where each field is first
 // needed, with an `s_waitcnt lgkmcnt(0)` in front of every first use: the <= 16-row kernels started with 3-6 SERIALISED round trips to the kernarg segment
-// (scalar cache cold at every kernel start) before their first global load went out (r04, read in the ISA: skinny_kernel 4 rounds, attn_oproj 6).
+// (scalar cache cold at every kernel start) before their first global load went out (r04, read in the ISA: skinny_kernel 4 rounds, the since-removed attention + o_proj kernel 6).
 // Touching every 16-byte piece of the struct in one empty asm statement at the top of the kernel makes the compiler fetch all of it up front, back to back,
 // behind a single wait.  MEASURED (r04f, same-box A/B of the whole chunk): SLOWER, 13.75 vs 12.99 ms -- inside a replayed HIP graph a kernarg line costs only
 // 40-80 ns (tools/micro/kernarg_lab.hip: the graph keeps its arguments in device memory; eager launches with host-resident kernargs pay 1.2 us per

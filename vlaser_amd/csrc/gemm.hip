@@ -1150,6 +1150,16 @@ static int launch_bm(const VlaserGemmArgs* args, hipStream_t stream, int splits)
   return 0;
 }
 
+// CUs the tile / split heuristics may count on.  256 on an MI355X of its own; a data-parallel rank lowers it by the CUs RCCL's channel workgroups hold during the
+// backward (tools/micro/rccl_shadow_lab.py: with 8 resident streaming workgroups beside it a forward + backward whose grids were sized for 256 CUs takes x1.54 -- every
+// 250-workgroup grid grows a second round).  Process-wide, set between steps (not while launches of another thread are being queued).
+static int g_cu_budget = 256;
+extern "C" int vlaser_set_cu_budget(int cus) {
+  const int prev = g_cu_budget;
+  if (cus >= 64 && cus <= 256) g_cu_budget = cus;
+  return prev;
+}
+
 // Tile configuration.  Measured on the path's shapes (tools/micro/gemm_lab.cpp, profiles/r02b_gemm_lab.md): the LDS-DMA
 // pipelines beat the register-staged kernels whenever the grid is a single round of workgroups (<= one per CU), largest tile
 // first losing to smallest: 64x128 (8 waves, 4 stages) for the smallest problems, then 128x128 (4 stages), 128x256 (3 stages),
@@ -1163,35 +1173,36 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
   auto blocks = [&](int bm, int bn = BN) { return ((args->M + bm - 1) / bm) * ((args->N + bn - 1) / bn) * splits * nb; };
   (void)tn;
   int bm = args->force_bm;
+  const int cus = g_cu_budget;         // CUs this launch may count on (vlaser_set_cu_budget): the single-round rule is only as good as this number
   if (bm == 0) {
     if constexpr (AKM) {                 // TN form: 128- and 256-row tiles only (>= 16 slots per staged k-row on both operands)
       // measured at K = 576 (tools/micro/tn_lab.py): qkv / o (192 / 144 tiles of 128x128) 10.2 / 10.0 us; down 1100 / 1200 / 1300 = 33.7 / 29.5 / 26.2 us,
       // gate/up 67.2 / 59.9 / 50.5 us -- multi-round grids want the largest tile
       // r04: grids of more than one round take the staggered two-group kernel (gate/up 46.0 -> 43.8 us; single-round shapes tie: tools/micro/gemm_epilogue_lab.py)
-      if (blocks(128, 128) <= 256) bm = 1100;
-      else if (blocks(128, 256) <= 256) bm = 1200;
-      else bm = (EPI == VL_EPI_NONE && nb == 1 && blocks(256, 256) > 256) ? 1340 : 1300;
+      if (blocks(128, 128) <= cus) bm = 1100;
+      else if (blocks(128, 256) <= cus) bm = 1200;
+      else bm = (EPI == VL_EPI_NONE && nb == 1 && blocks(256, 256) > cus) ? 1340 : 1300;
     } else if (args->M <= 32 && !WKM) {
       bm = 32;
-    } else if (!WKM && blocks(64, 64) <= 256) {      // (the NN form's transposing reads need >= 16 slots per staged k-row: BNT >= 128)
+    } else if (!WKM && blocks(64, 64) <= cus) {      // (the NN form's transposing reads need >= 16 slots per staged k-row: BNT >= 128)
       bm = 1564;                       // r03: a K-step costs the same ~0.4 us whatever the tile, so the smallest problems want the most workgroups (profiles/r03e_gemm_lab.md)
-    } else if (blocks(64, 128) <= 256) {
+    } else if (blocks(64, 128) <= cus) {
       bm = 1500;
-    } else if (blocks(128, 128) <= 256) {
+    } else if (blocks(128, 128) <= cus) {
       bm = 1100;
-    } else if (blocks(144, 128) <= 256) {
+    } else if (blocks(144, 128) <= cus) {
       bm = 1440;                       // M = 8 x 128 + a few rows (the ViT's 1025 tokens): 144-row tiles cover it in 8 instead of 9 tile rows
-    } else if (blocks(128, 256) <= 256) {
+    } else if (blocks(128, 256) <= cus) {
       bm = 1200;
-    } else if (blocks(192, 256) <= 256 && (args->M + 191) / 192 * 192 < (args->M + 255) / 256 * 256) {
+    } else if (blocks(192, 256) <= cus && (args->M + 191) / 192 * 192 < (args->M + 255) / 256 * 256) {
       bm = 1900;                       // r03: the SFT step's 560 rows = 3 x 192 (256-row tiles pad 27 %): gate/up forward 53.8 -> 50.5 us (tools/micro/sft_gemm_lab.py)
-    } else if (blocks(256, 256) <= 256) {
+    } else if (blocks(256, 256) <= cus) {
       bm = 1300;
     } else {
       const struct { int code, bm, bn; float rate; } cand[4] = {{1500, 64, 128, 701.f}, {1100, 128, 128, 850.f}, {1200, 128, 256, 1040.f}, {1300, 256, 256, 1208.f}};
       float best = 1e30f;
       for (const auto& c : cand) {
-        const float t = (float)((blocks(c.bm, c.bn) + 255) / 256) * (float)(c.bm * c.bn) / c.rate;
+        const float t = (float)((blocks(c.bm, c.bn) + cus - 1) / cus) * (float)(c.bm * c.bn) / c.rate;
         if (t < best) { best = t; bm = c.code; }
       }
     }

@@ -579,9 +579,7 @@ __global__ __launch_bounds__(256) void vla_step_kernel(const bf16_t* __restrict_
         }
       }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int k = 0; k < ADIM; ++k) acc[k] += __shfl_xor(acc[k], o, 64);
+      for (int k = 0; k < ADIM; ++k) acc[k] = wave_sum(acc[k]);
       if (lane < adim) {
         float vel = 0.f;
 #pragma unroll
@@ -638,11 +636,9 @@ __global__ __launch_bounds__(256) void vla_step_kernel(const bf16_t* __restrict_
       }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int i = 0; i < CPW; ++i) acc[r][i] += __shfl_xor(acc[r][i], o, 64);
+      for (int i = 0; i < CPW; ++i) acc[r][i] = wave_sum(acc[r][i]);
     if (lane < 4 * CPW) {
       const int r = lane >> 2, i = lane & 3;
       float v = 0.f;

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyP p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { const float lo = bf16lo_to_f32(hr[j]), hi = bf16hi_to_f32(hr[j]); ssq += lo * lo + hi * hi; }
           if (tid >= nch) ssq = 0.f;               // clamped duplicate chunk
-          ssq += __shfl_xor(ssq, 1, 64); ssq += __shfl_xor(ssq, 2, 64); ssq += __shfl_xor(ssq, 4, 64); ssq += __shfl_xor(ssq, 8, 64);
+          ssq = group16_sum(ssq);
           if ((lane & 15) == 0 && tid < nch) gs[mm * gstride + ((tid - mm * cpr) >> 4)] = ssq;
           if (tid < nch && write_h) st_global_16(reinterpret_cast<bf16_t*>(a.h_out) + off, hr);
           // pin the norm-weight chunk's vmcnt wait HERE: its first real use is after the (conditional) early weight requests below, where

@@ -49,9 +49,6 @@ class QwenLayerWeights:
             else:
                 self.sk_qkv = ops.pack_skinny(wqkv, 1)
             self.sk_o = ops.pack_skinny(wo, ks_o, tpu_o)
-            # 'fuse_ao' (r04): attention + o_proj in one launch takes W_o fragment-major with one K split per kv head (the consumer sums n_kv slabs)
-            nkv_ = llm.num_key_value_heads
-            self.sk_ao = ops.pack_skinny(wo, nkv_, 1) if ('fuse_ao' in opts and (llm.num_attention_heads // nkv_) in (2, 4, 6, 8)) else None
             # wide output + short K (action expert: 17920 x 768): 96-row units (tpu = 6) measured slower on MI355X (12.3 vs 11.2 us): kept in
             # the kernel, not used; 16-row lane-local units ('gu16', r03) balance 1120 units over 256 workgroups (80 vs 96 rows on the longest)
             if 'gu16' in opts:
@@ -61,8 +58,10 @@ class QwenLayerWeights:
             self.sk_down = ops.pack_skinny(wdown, ks_down, tpu_down, k_pad=i_pad)
             # 'chain' (r05, csrc/chain.hip): the down projection without cross-workgroup split-K (4 output columns per workgroup over the whole K) publishes the next
             # layer's residual stream as bf16; needs the 16-row q/k/v packing and the MLP width the kernel is built for
-            self.sk_down4 = (ops.pack_down4(wdown) if ('chain' in opts and 'qkv16' in opts and wdown.shape[1] == ops.DOWN4_WAVES * ops.DOWN4_LOADS * 128
-                                                       and wdown.shape[0] % 4 == 0) else None)
+            ok4 = 'chain' in opts and 'qkv16' in opts and wdown.shape[1] == ops.DOWN4_WAVES * ops.DOWN4_LOADS * 128
+            self.sk_down4 = ops.pack_down4(wdown) if (ok4 and (wdown.shape[0] % 3 == 0 or wdown.shape[0] % 4 == 0)) else None
+            # 'down2' (with 'chain'): the down projection as two K halves on 256 six-column workgroups leaving two fp32 slabs (vlaser_chain_down2) that the q/k/v launch reduces
+            self.sk_down42 = ops.pack_down4(wdown, k_splits=2) if (ok4 and 'down2' in opts and (wdown.shape[0] % 6 == 0 or wdown.shape[0] % 8 == 0)) else None
 
 
 class QwenStack:
@@ -283,12 +282,11 @@ class SkinnyBuffers:
         self.part_o = torch.zeros(stack.ks_o, max_rows, H, dtype=torch.float32, device=device)
         self.part_d = torch.zeros(stack.ks_down, max_rows, H, dtype=torch.float32, device=device)
         self.plans = {}      # cached launch argument structs of skinny_layer
-        self.sync = None     # [slots, VL_FUSED_SYNC_WORDS] int32: arrival counters of the fused launches (set + zeroed by the caller)
 
 
 def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in, partials, n_partials, cache: KVCache, layer, rope,
                  pos_ids, batch, tok_per_batch, slot_base, kv_len, attn_mode, valid_len=None, blk_start=0, skip_post_attn=False,
-                 first_tok_kv_len=0, skip=(), sync=None):
+                 first_tok_kv_len=0, skip=()):
     """One decoder layer over M = batch*tok_per_batch <= 16 rows with the weight-streaming kernels (5 launches).
     Input residual = h_in + sum(partials) (partials = down_proj slabs of the previous layer).  Returns
     (h, partials, n_partials) describing this layer's output residual the same way."""
@@ -297,31 +295,25 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
     nq, nkv, hd = stack.nq, stack.nkv, llm.head_dim
     # the five argument structs of this (layer, input buffers, geometry) are built once and re-launched: only the cache slot,
     # the key count and its split factor change from step to step (greedy decode is otherwise host-bound on struct building)
-    # 'fuse_ogu' (r03): o_proj -> gate/up as ONE launch with an in-launch hand-off (csrc/euler.hip); needs its arrival-counter slot `sync`
-    # (zeroed by the caller before the launch) and the geometry the fused kernel is built for -- anything else takes the two launches
+    # (the two fused launches of r03 / r04 -- o_proj -> gate/up with an in-launch hand-off, attention + o_proj in one launch -- lost to the r05 chain kernels below and were
+    # removed from the library: DESIGN.md section 3)
     nsp = ops.attn_splits(kv_len)
-    fuse = (sync is not None and 'fuse_ogu' in stack.opts and 'gu16' in stack.opts and not skip_post_attn and stack.tpu_o == 1 and stack.ks_o == 3
-            and llm.hidden_size == 768 and nq * hd == 1536 and nsp == 7 and M * (llm.hidden_size // 8) <= 512)
-    # 'fuse_ao' (r04 rewrite): attention + o_proj as ONE launch without any hand-off (csrc/attn_o.hip: every workgroup recomputes its kv group's attention
-    # from K / V^T staged in LDS by coalesced LDS-DMA);
-    # batch 1, <= 32 (head, token) rows per kv head; the consumer then sums n_kv_heads slabs instead of ks_o
-    G_ = nq // nkv
-    fuse_ao = ('fuse_ao' in stack.opts and not fuse and not skip_post_attn and getattr(lw, 'sk_ao', None) is not None
-               and ops.attn_oproj_supported(nq, nkv, tok_per_batch, batch, hd, llm.hidden_size) and nkv <= sb.part_o.shape[0]
-               and attn_mode in (L.ATTN_FULL, L.ATTN_PREFIX) and (attn_mode == L.ATTN_FULL or blk_start % 16 == 0))
     # 'chain' (r05): qkv / gate-up / down on the latency-built kernels of csrc/chain.hip -- the layer takes a residual stream that is already reduced (n_partials == 0:
     # the action encoder's output, or what the previous layer's vlaser_chain_down published) and hands on (hC, None, 0)
     H_, I_ = llm.hidden_size, llm.intermediate_size
-    chain = ('chain' in stack.opts and not fuse and not fuse_ao and n_partials == 0 and getattr(lw, 'sk_down4', None) is not None and lw.sk_qkv.tpu == 1
+    down2 = getattr(lw, 'sk_down42', None) is not None and ops.chain_down2_supported(M, H_, I_)
+    from_down2 = n_partials == 2 and partials is not None and partials.data_ptr() == sb.part_d.data_ptr() and down2
+    chain = ('chain' in stack.opts and getattr(lw, 'sk_down4', None) is not None and lw.sk_qkv.tpu == 1
+             and ((n_partials == 0 and h_in.data_ptr() != sb.hB.data_ptr()) or from_down2)
              and ops.chain_qkv_supported(M, lw.sk_qkv.N, H_) and ops.chain_gu_supported(M, lw.sk_gu.N, H_, stack.ks_o, lw.sk_gu.tpu)
-             and ops.chain_down_supported(M, H_, I_) and sb.act.shape[1] == I_ and h_in.data_ptr() != sb.hB.data_ptr())
+             and ops.chain_down_supported(M, H_, I_) and sb.act.shape[1] == I_)
     # ... and attention + o_proj on the one-wave-per-split attention / bf16-partial merge pair when the key count gives the split count they are built for
     nsp2 = ops.chain_attn_splits(kv_len)
     chain_ao = (chain and not skip_post_attn and lw.sk_o.tpu == 1 and tok_per_batch * (nq // nkv) <= 32
                 and ops.chain_oproj_supported(M, lw.sk_o.N, nq * hd, stack.ks_o, nsp2, nq // nkv) and 'chain_noao' not in stack.opts)
     key = (layer, M, tok_per_batch, attn_mode, h_in.data_ptr(), 0 if partials is None else partials.data_ptr(), n_partials,
            0 if valid_len is None else valid_len.data_ptr(), pos_ids.data_ptr(), cache.k.data_ptr(), skip_post_attn, first_tok_kv_len,
-           sync.data_ptr() if fuse else 0, fuse_ao, chain, chain_ao)
+           chain, chain_ao, down2)
     plan = sb.plans.get(key)
     if plan is None:
         ks, vs = cache.strides()
@@ -343,12 +335,9 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
                 plan.o = ops.skinny_args(None, lw.sk_o, M, out_f32=sb.part_o, attn_m=sb.chain_parts[0], attn_o=sb.chain_parts[1], attn_splits=nsp2,
                                          attn_group=nq // nkv, attn_nq=tok_per_batch)
             # (chain: vlaser_chain_qkv leaves no rounded copy of the residual stream behind -- its input already IS the rounded stream)
-            plan.gu = ops.skinny_args(h_in if chain else sb.hA, lw.sk_gu, M, partials=sb.part_o, n_partials=nkv if fuse_ao else stack.ks_o, norm_w=lw.ln_post,
+            plan.gu = ops.skinny_args(h_in if (chain and n_partials == 0) else sb.hA, lw.sk_gu, M, partials=sb.part_o, n_partials=stack.ks_o, norm_w=lw.ln_post,
                                       eps=llm.rms_norm_eps, h_out=sb.hB, out=sb.act, ldo=sb.act.shape[1])
             plan.down = SimpleNamespace(dbg=None) if chain else ops.skinny_args(sb.act, lw.sk_down, M, out_f32=sb.part_d)
-            if fuse:
-                plan.ogu = ops.fused_ogu_args(sb.attn_parts, lw.sk_o, sb.part_o, sb.hA, lw.ln_post, llm.rms_norm_eps, sb.hB, lw.sk_gu, M, sb.act, sync,
-                                              nsp, nq // nkv, tok_per_batch)
         if len(sb.plans) > 4096:         # keys hold buffer addresses of per-call tensors (ragged lengths): bound the cache
             sb.plans.clear()
         sb.plans[key] = plan
@@ -367,6 +356,7 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
         if chain_ao:
             if 'attn' not in skip:
                 ops.launch_chain_attn(a, stream)
+            plan.o[0].attn_splits = nsp2          # (the key count, hence the split count, moves from step to step in an eager decode)
             if 'o' not in skip:
                 ops.launch_chain_oproj(plan.o[0], stream)
         else:
@@ -377,31 +367,23 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
                 ops.launch_skinny(L.PRO_ATTN, L.SK_PARTIAL, plan.o[0], stream)
         if 'gu' not in skip:
             ops.launch_chain_gu(plan.gu[0], stream)
+        if down2:
+            if 'down' not in skip:
+                ops.chain_down2(sb.act, lw.sk_down42, sb.part_d, M, H_, I_, dbg=plan.down.dbg, stream=stream)
+            return sb.hB, sb.part_d, 2
         if 'down' not in skip:
             ops.chain_down(sb.act, lw.sk_down4, sb.hB, sb.hC, M, H_, I_, dbg=plan.down.dbg, stream=stream)
         return sb.hC, None, 0
-    if fuse_ao:
-        if 'attn' not in skip and 'o' not in skip:
-            ops.launch_attn_oproj(a, lw.sk_ao, sb.part_o, llm.hidden_size, stream)
-        if 'gu' not in skip:
-            ops.launch_skinny(L.PRO_NORM, L.SK_SWIGLU, plan.gu[0], stream)
-        if 'down' not in skip:
-            ops.launch_skinny(L.PRO_PLAIN, L.SK_PARTIAL, plan.down[0], stream)
-        return sb.hB, sb.part_d, stack.ks_down
     if skip_post_attn:          # only this layer's K / V are needed (written by the qkv launch above)
         return sb.hA, None, 0
     if 'attn' not in skip:
         ops.launch_attn_skinny(a, stream)
     # o_proj: the prologue merges the attention split partials (flash-decoding) straight into its activation tile
-    if fuse:
-        if 'gu' not in skip and 'o' not in skip:
-            ops.launch_fused_ogu(plan.ogu, stream)
-    else:
-        plan.o[0].attn_splits = nsp
-        if 'o' not in skip:
-            ops.launch_skinny(L.PRO_ATTN, L.SK_PARTIAL, plan.o[0], stream)
-        if 'gu' not in skip:
-            ops.launch_skinny(L.PRO_NORM, L.SK_SWIGLU, plan.gu[0], stream)
+    plan.o[0].attn_splits = nsp
+    if 'o' not in skip:
+        ops.launch_skinny(L.PRO_ATTN, L.SK_PARTIAL, plan.o[0], stream)
+    if 'gu' not in skip:
+        ops.launch_skinny(L.PRO_NORM, L.SK_SWIGLU, plan.gu[0], stream)
     if 'down' not in skip:
         ops.launch_skinny(L.PRO_PLAIN, L.SK_PARTIAL, plan.down[0], stream)
     return sb.hB, sb.part_d, stack.ks_down

@@ -214,19 +214,6 @@ def attn_bwd(q, k, vt, o, d_o, lse, delta_ws, dq, dk, dv, S, n_q, n_kv, s_max, s
                                     dk.data_ptr(), dv.data_ptr(), S, n_q, n_kv, s_max, scale, int(causal), S if kv_valid is None else kv_valid, head_dim, _stream()), 'vlaser_attn_bwd')
 
 
-def launch_attn_oproj(args, wo_packed: 'PackedW', out_f32, N, stream=None):
-    """Attention + o_proj of a <= 16-row layer-step in one launch (csrc/attn_o.hip): `args` = an attn_skinny argument struct (batch 1), `wo_packed` =
-    pack_skinny(o_proj.weight, k_splits = n_kv_heads, tpu = 1), out_f32 >= n_kv_heads * sq * N fp32 (one partial slab per kv head)."""
-    assert wo_packed.tpu == 1 and wo_packed.k_splits == args.n_kv_heads and wo_packed.N == N and wo_packed.K == args.n_q_heads * 128
-    L.check(L.lib().vlaser_attn_oproj(C.byref(args), wo_packed.t.data_ptr(), out_f32.data_ptr(), N, _stream() if stream is None else stream), 'vlaser_attn_oproj')
-
-
-def attn_oproj_supported(n_q, n_kv, tok_per_batch, batch, head_dim, hidden):
-    """Geometry the one-launch attention + o_proj kernel is built for (engine.skinny_layer falls back to the two launches otherwise)."""
-    G = n_q // n_kv
-    return batch == 1 and head_dim == 128 and G in (2, 4, 6, 8) and G * tok_per_batch <= 32 and hidden % 16 == 0
-
-
 def attn_splits(kv_len):
     """Key splits of the skinny attention: about 2 chunks (of 32 keys) per block, at most 8 splits (measured: 389 keys,
     1/2/4/7 splits -> 13.5/9.5/7.7/6.3 us per launch)."""
@@ -323,15 +310,32 @@ def chain_down_geometry(N):
     return wgs, c.value, g.value
 
 
-def pack_down4(W, nw=DOWN4_WAVES, nl=DOWN4_LOADS):
-    """down_proj.weight [N, K] -> [workgroup][nw waves][nl loads][groups][16 blocks][cols][8] bf16 for vlaser_chain_down: block b, column i of group c of wave w,
-    load l holds W[(wg groups + c) cols + i, (w nl + l) 128 + 8 b : + 8] -- one contiguous 16 x cols x 16 bytes per wave-level load, one contiguous stream per
-    workgroup (groups x cols output columns over the whole K)."""
+def pack_down4(W, nw=DOWN4_WAVES, nl=DOWN4_LOADS, k_splits=1):
+    """down_proj.weight [N, K] -> [K split][workgroup][nw waves][loads][groups][16 blocks][cols][8] bf16 for vlaser_chain_down (k_splits = 1) / vlaser_chain_down2
+    (k_splits = 2: two K halves, always 2 column groups per workgroup): block b, column i of group c of wave w, load l holds
+    W[(wg groups + c) cols + i, kh K/k_splits + (w loads + l) 128 + 8 b : + 8] -- one contiguous 16 x cols x 16 bytes per wave-level load, one contiguous stream per workgroup."""
     N, K = W.shape
-    wgs, cols, groups = chain_down_geometry(N)
+    if k_splits == 1:
+        wgs, cols, groups = chain_down_geometry(N)
+    else:
+        assert k_splits == 2 and nl % 2 == 0 and (N % 6 == 0 or N % 8 == 0), (N, K, k_splits)
+        cols, groups = (3 if N % 6 == 0 else 4), 2
+        wgs = N // (cols * groups)
+    nlk = nl // k_splits
     assert N == wgs * cols * groups and K == nw * nl * 128, (N, K)
-    v = W.view(wgs, groups, cols, nw, nl, 16, 8)                # [wg, c, i, w, l, b, e]
-    return v.permute(0, 3, 4, 1, 5, 2, 6).contiguous().reshape(-1)      # [wg, w, l, c, b, i, e]
+    v = W.view(wgs, groups, cols, k_splits, nw, nlk, 16, 8)                # [wg, c, i, kh, w, l, b, e]
+    return v.permute(3, 0, 4, 5, 1, 6, 2, 7).contiguous().reshape(-1)      # [kh, wg, w, l, c, b, i, e]
+
+
+def chain_down2(x, W42, out_f32, M, N, K, dbg=None, stream=None):
+    """out_f32[2, M, N] = the two K halves of x[M, :K] @ W^T (fp32, no residual), W42 = pack_down4(W, k_splits=2)."""
+    assert x.dtype == BF16 and out_f32.dtype == torch.float32 and x.stride(-1) == 1 and out_f32.numel() >= 2 * M * N
+    L.check(L.lib().vlaser_chain_down2(x.data_ptr(), x.stride(0), W42.data_ptr(), out_f32.data_ptr(), M, N, K, dbg if isinstance(dbg, int) else _p(dbg),
+                                       _stream() if stream is None else stream), 'vlaser_chain_down2')
+
+
+def chain_down2_supported(M, N, K):
+    return bool(L.lib().vlaser_chain_down2_supported(M, N, K)) and bool(L.lib().vlaser_chain_qkv2_supported(M, 128, 768 if N == 768 else N))
 
 
 def chain_qkv_supported(M, N, K):
@@ -380,26 +384,6 @@ def chain_down(x, W4, res, h_out, M, N, K, dbg=None, stream=None):
     assert x.dtype == BF16 and res.dtype == BF16 and h_out.dtype == BF16 and x.stride(-1) == 1 and res.data_ptr() != h_out.data_ptr()
     L.check(L.lib().vlaser_chain_down(x.data_ptr(), x.stride(0), W4.data_ptr(), res.data_ptr(), h_out.data_ptr(), M, N, K, dbg if isinstance(dbg, int) else _p(dbg),
                                       _stream() if stream is None else stream), 'vlaser_chain_down')
-
-
-def fused_ogu_args(attn_parts, Wo: PackedW, part_o, h_in, norm_w, eps, h_out, Wgu: PackedW, M, act, sync, attn_splits, attn_group, attn_nq, cons_delay=None, dbg=None):
-    """Filled VlaserFusedOguArgs: o_proj (attention-split merge + split-K partial tiles) handed to gate/up (+ residual, RMSNorm, SwiGLU) inside ONE
-    launch (csrc/euler.hip).  `sync`: int32 view of VL_FUSED_SYNC_WORDS words, zeroed by the caller on the stream before every launch."""
-    assert Wo.tpu == 1 and Wgu.tpu == 1 and Wgu.k_splits == 1 and sync.numel() >= L.FUSED_SYNC_WORDS and sync.dtype == torch.int32
-    a = L.FusedOguArgs()
-    a.attn_m, a.attn_l, a.attn_o = attn_parts[0].data_ptr(), attn_parts[1].data_ptr(), attn_parts[2].data_ptr()
-    a.attn_splits, a.attn_group, a.attn_nq = attn_splits, attn_group, attn_nq
-    a.Wo, a.K_o, a.ks_o, a.part_o = Wo.t.data_ptr(), Wo.K, Wo.k_splits, part_o.data_ptr()
-    a.h_in, a.norm_w, a.eps, a.h_out = h_in.data_ptr(), norm_w.data_ptr(), eps, _p(h_out)
-    a.Wgu, a.M, a.H, a.N_gu, a.n_valid_gu = Wgu.t.data_ptr(), M, Wgu.K, Wgu.N, Wgu.n_valid
-    a.act, a.ld_act, a.sync = act.data_ptr(), act.stride(0), sync.data_ptr()
-    a.cons_delay = int(os.environ.get('VLASER_OGU_DELAY', '0')) if cons_delay is None else cons_delay
-    a.dbg = _p(dbg)
-    return a
-
-
-def launch_fused_ogu(a, stream=None):
-    L.check(L.lib().vlaser_fused_ogu(C.byref(a), _stream() if stream is None else stream), 'vlaser_fused_ogu')
 
 
 # measured on the action-expert chunk: 72 / 100 / 130 / 160 target blocks -> 16.63 / 16.52 / 16.48 / 16.50 ms
@@ -623,6 +607,18 @@ def reduce_norm(h_in, partials, n_partials, M, C, h_out, x_out=None, bias=None, 
 _GEMM_CFGS = ((1564, 64, 64, 420.0), (1500, 64, 128, 701.0), (1100, 128, 128, 850.0), (1440, 144, 128, 900.0), (1200, 128, 256, 1040.0), (1300, 256, 256, 1208.0))
 
 
+_CU_BUDGET = 256
+
+
+def set_cu_budget(cus):
+    """CUs the GEMM tile / split heuristics (here and in csrc/gemm.hip) may count on; returns the previous value.  A data-parallel rank passes 256 minus the CUs
+    RCCL's channel workgroups hold beside its backward (sft.py), everything else leaves the default."""
+    global _CU_BUDGET
+    prev = L.lib().vlaser_set_cu_budget(int(cus))
+    _CU_BUDGET = L.lib().vlaser_set_cu_budget(-1)          # (out of range: a read)
+    return prev
+
+
 def gemm_tile_config(M, N, splits=1, batch=1, nn=False):
     """Mirror of the tile choice in csrc/gemm.hip `launch<EPI, WKM>` (single-round rule, then least modelled time): (code, BM, BN, rate);
     nn: the NN form (vlaser_gemm_nn), which has no 64x64 and no 32-row configuration."""
@@ -630,11 +626,11 @@ def gemm_tile_config(M, N, splits=1, batch=1, nn=False):
     if M <= 32 and not nn:
         return (32, 32, 128, 500.0)
     for c in _GEMM_CFGS:
-        if c[0] == 1300 and blocks(192, 256) <= 256 and -(-M // 192) * 192 < -(-M // 256) * 256:
+        if c[0] == 1300 and blocks(192, 256) <= _CU_BUDGET and -(-M // 192) * 192 < -(-M // _CU_BUDGET) * 256:
             return (1900, 192, 256, 1208.0)
-        if blocks(c[1], c[2]) <= 256 and not (nn and c[0] == 1564):
+        if blocks(c[1], c[2]) <= _CU_BUDGET and not (nn and c[0] == 1564):
             return c
-    return min((c for c in _GEMM_CFGS if c[0] not in (1440, 1564)), key=lambda c: -(-blocks(c[1], c[2]) // 256) * c[1] * c[2] / c[3])
+    return min((c for c in _GEMM_CFGS if c[0] not in (1440, 1564)), key=lambda c: -(-blocks(c[1], c[2]) // _CU_BUDGET) * c[1] * c[2] / c[3])
 
 
 def split_slab_elems(max_rows, N):
@@ -665,7 +661,7 @@ def gemm_splits(M, N, K, max_elems=None, max_splits=8, nn=False):
         fixed, step = _GEMM_STEP_US[code]
         # + what the extra fp32 slabs cost their consumer: the seam kernel takes 5.3 / 5.3 / 5.4 us with 1 / 3 / 7 slabs of 2.4 MB, 5.3 / 5.9 with 1 / 4 slabs
         # of 4.2 MB (profiles/r03l_chunk_kernel_stats.md) -- about 0.04 us per MB of slab
-        t = -(-blocks // 256) * (fixed + (K // s // 64) * step) + (s > 1) * 0.04 * s * M * N * 4.0 / 1e6
+        t = -(-blocks // _CU_BUDGET) * (fixed + (K // s // 64) * step) + (s > 1) * 0.04 * s * M * N * 4.0 / 1e6
         if best[0] is None or t < best[0] - 1e-9:
             best = (t, s)
     return best[1]

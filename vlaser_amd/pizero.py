@@ -113,7 +113,6 @@ class PiZero:
     #   qkv16: 16-row lane-local units for the q/k/v weight-streaming GEMV (128 instead of 64 workgroups): -0.88 us per layer-step in-chain
     #   gu16: the same for gate/up (1120 units): +0.6 us in-chain with the r03 kernel (its five units streamed one after the other, see csrc/chain.hip) -- on again
     #         with 'chain' (r05), whose gate/up requests all five up front
-    #   fuse_ogu (needs gu16): o_proj -> gate/up as one launch with an in-launch hand-off (csrc/euler.hip): +2.0 us in-chain -- off
     #   glue1: ONE launch between two passes through the layers (vlaser_vla_step: tail of Euler step s-1 + action encoder of step s) instead of four:
     #          10.9 vs 16.3 us in isolation, -0.085 ms per chunk in-chain (tools/micro/vla_step_lab.py, ab_chunk.py) -- ON.  Not bit-identical to the
     #          4-launch path (linear_1 / time embedding folded into linear_2 in fp32): same tolerance against oracle and goldens
@@ -202,8 +201,6 @@ class PiZero:
         self.sb_pro = SkinnyBuffers(self.expert, 16, dev)
         self.sb_act = SkinnyBuffers(self.expert, 16, dev)
         self.rope = ops.rope_table(T + 16, llm.head_dim, llm.rope_theta, dev)
-        # arrival counters of the fused Euler launches: one slot per (Euler step, layer), zeroed once per chunk at the start of the Euler phase
-        self.euler_sync = torch.zeros(cfg.num_inference_steps * llm.num_hidden_layers, L.FUSED_SYNC_WORDS, dtype=torch.int32, device=dev)
         W = cfg.action_hidden_size
         z = lambda *s, dt=BF: torch.zeros(*s, dtype=dt, device=dev)
         self.h_vlm = z(B * T, llm.hidden_size)
@@ -331,10 +328,6 @@ class PiZero:
             self.action5[1:1 + M].copy_(self.in_noise[:M])
         else:
             self.action[:M].copy_(self.in_noise[:M])
-        fused = any(o.startswith('fuse_') for o in self.euler_opts)
-        if fused:
-            self.euler_sync.zero_()               # ONE memset node per chunk: every fused launch below owns its own counter slot
-        sync = lambda s_, i_: self.euler_sync[s_ * nL + i_] if fused else None
         for s in range(n):
             t = s * dt
             first = ride and s == 0
@@ -346,7 +339,7 @@ class PiZero:
                 for i in range(nL):
                     h, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_pro, h, parts, npart, self.cache, i, self.rope,
                                                    self.pos5, B, na + 1, T, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len, blk_start=T,
-                                                   first_tok_kv_len=T + 1, skip=skip, sync=sync(s, i))
+                                                   first_tok_kv_len=T + 1, skip=skip)
                 ops.vla_euler(h, parts, npart, M + 1, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action5, W, cfg.action_dim, dt,
                               clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel5)
                 self.action[:M].copy_(self.action5[1:1 + M])          # row 0 of action5 (the proprio row's "velocity") is scratch
@@ -356,7 +349,7 @@ class PiZero:
             for i in range(nL):
                 h, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_act, h, parts, npart, self.cache, i, self.rope,
                                                self.pos_act, B, na, T + 1, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len,
-                                               blk_start=T, skip=skip, sync=sync(s, i))
+                                               blk_start=T, skip=skip)
             ring = (self.out_ring, self.call_ctr) if s == n - 1 else (None, None)
             ops.vla_euler(h, parts, npart, M, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action, W, cfg.action_dim, dt,
                           clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel_trace[s], ring=ring[0], ring_ctr=ring[1])
@@ -377,10 +370,6 @@ class PiZero:
         acts = [self.action, self.action_b]
         p = (n - 1) % 2                           # n - 1 ping-pongs later the actions sit in self.action, where the last step finishes in place
         assert acts[p] is self.noise_dst          # the staging launch wrote this call's noise here
-        fused = any(o.startswith('fuse_') for o in self.euler_opts)
-        if fused:
-            self.euler_sync.zero_()
-        sync = lambda s_, i_: self.euler_sync[s_ * nL + i_] if fused else None
         fin = None
         for s in range(n):
             first = ride and s == 0
@@ -396,14 +385,14 @@ class PiZero:
                 for i in range(nL):
                     h, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_pro, h, parts, npart, self.cache, i, self.rope,
                                                    self.pos5, B, na + 1, T, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len, blk_start=T,
-                                                   first_tok_kv_len=T + 1, skip=skip, sync=sync(s, i))
+                                                   first_tok_kv_len=T + 1, skip=skip)
                 fin = (h, parts, npart, M + 1, 1, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b)       # row 0 = the proprio row: skipped
             else:
                 h, parts, npart = self.h_act, None, 0
                 for i in range(nL):
                     h, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_act, h, parts, npart, self.cache, i, self.rope,
                                                    self.pos_act, B, na, T + 1, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len,
-                                                   blk_start=T, skip=skip, sync=sync(s, i))
+                                                   blk_start=T, skip=skip)
                 fin = (h, parts, npart, M, 0, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b)
         assert acts[p] is self.action
         ring = (self.out_ring, self.call_ctr)     # always: the caller's copy (a 1-slot ring when output_ring == 0) is where an unsupported mask turns into NaN
@@ -548,11 +537,6 @@ class PiZero:
                       prep.VLA_MEAN, prep.VLA_STD, call_ctr=self.call_ctr, call_no=k, masks=masks, n_act=na, positions=positions,
                       pos_out=(self.pos_vlm, self.pos_pro, self.pos_act, self.pos5 if B == 1 else None))
         self._calls = k                           # only after the launch was accepted: the host's ring index cannot run ahead of the device's call number
-
-    def sync_errors(self):
-        """Number of fused-launch slots whose bounded in-launch wait expired during the last chunk (0 on a healthy run; the result is
-        invalid otherwise -- csrc/euler.hip never hangs, it flags)."""
-        return int((self.euler_sync[:, L.FUSED_SYNC_ERR] != 0).sum())
 
     def last_velocities(self, B=1):
         """Decoder output (velocity) of every Euler step of the last infer_action call: fp32 [n_steps, B, horizon, action_dim]
