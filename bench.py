@@ -263,7 +263,10 @@ def sft_bench(rank, world, local, dist, steps, warmup=2):
             'steps': steps, 'tokens_per_rank_step': S, 'last_loss': round(loss, 4), 'fwd_bwd_ms': round(fwd_bwd_ms, 2),
             'parallelism': f'dp{world} (ZeRO-1: bucketed RCCL reduce-scatter(mean, bf16) issued from the backward + all-gather of updated params)',
             'exchange': {'bucket_mib': buckets_mb, 'NCCL_ALGO': os.environ.get('NCCL_ALGO', 'default'), 'NCCL_PROTO': os.environ.get('NCCL_PROTO', 'default'),
-                         'NCCL_MAX_NCHANNELS': os.environ.get('NCCL_MAX_NCHANNELS', 'default (profiles/r05_rccl_contention.md: 8 / 16 / 32 measured beside it)'),
+                         'NCCL_MAX_NCHANNELS': os.environ.get('NCCL_MAX_NCHANNELS', 'unset = RCCL default (chosen: profiles/r05_rccl_contention.md section 4)'),
+                         # one-GPU stand-in for RCCL's channel workgroups (tools/micro/rccl_shadow_lab.py): forward + backward stretch beside C resident streaming workgroups
+                         'contention_model': {'source': 'profiles/r05_rccl_contention.md', 'fwd_bwd_stretch_by_channel_workgroups': {'1': 1.13, '8': 1.23, '16': 1.28, '32': 1.34, '64': 1.46},
+                                              'both_streams_cu_masked': 1.13, 'predicted_fwd_bwd_ms_at_8_gpus': [16.4, 17.7]},
                          'gradient_bytes_per_rank': 3570e6 if world > 1 else 0, **exchange_info},
             'gflop_per_rank_step': round(fl / 1e9, 1), 'mfma_frac': round(fl * world * steps / dt / (world * 2.5e15), 4)}
 

@@ -199,6 +199,8 @@ int vlaser_chain_down(const void* x, int ldx, const void* W, const void* res, vo
  *                      wave for the o_proj -> gate/up seam): half the activation bytes per CU of vlaser_chain_down, 24 more L2 loads per lane in the q/k/v launch */
 int vlaser_chain_down2_supported(int M, int N, int K);
 int vlaser_chain_qkv2_supported(int M, int N, int K);
+/* tools / tests: 1 = the one-wave-per-unit kernel of vlaser_chain_qkv at hidden 1536 too (default 0: two waves there, one K half each); returns the previous value */
+int vlaser_chain_qkv_set_waves(int n);
 int vlaser_chain_down2(const void* x, int ldx, const void* W, float* out_f32, int M, int N, int K, unsigned long long* dbg, vl_stream_t stream);
 
 /* (The two fused layer-step launches measured in r03 / r04 -- o_proj -> gate/up with an in-launch hand-off, +2.0 us in-chain; attention + o_proj in one launch,
@@ -252,8 +254,11 @@ int vlaser_pixel_shuffle(const void* x, void* out, int T, int G, int C, int ps_v
  * count_out (optional, device int32) receives the number of <IMG_CONTEXT> tokens. */
 int vlaser_embed_merge(const int64_t* ids, int n, const void* embed, const void* vit, int n_vit_rows, void* out, int H,
                        long long img_id, long long pad_id, int zero_pad, int32_t* rank_ws, int32_t* count_out, vl_stream_t stream);
-/* greedy argmax over fp32 logits [M,N] (GenerationMixin greedy step) + optional embedding gather of the winner. */
-int vlaser_argmax(const float* logits, int M, int N, int64_t* out_id, const void* embed, void* next_h, int H, vl_stream_t stream);
+/* greedy argmax over fp32 logits [M,N] (GenerationMixin greedy step; lowest index wins ties, as torch.argmax) + optional embedding gather of the winner.
+ * (ABI 6) ws: optional device workspace of vlaser_argmax_ws_bytes(M) bytes, ZEROED ONCE by the caller and then owned by these launches (one stream at a time): the row is
+ * spread over 64 workgroups whose last arriver folds their (value, index) pairs -- 18 -> ~4 us at N = 151 674; ws = NULL (or N < 4096): one workgroup per row. */
+int vlaser_argmax_ws_bytes(int M);
+int vlaser_argmax(const float* logits, int M, int N, int64_t* out_id, const void* embed, void* next_h, int H, void* ws, int ws_bytes, vl_stream_t stream);
 /* pi0 head glue: SinusoidalPosEmb + ActionEncoder.linear_1 (modules.py:9-22,45-50); proprio_encoder
  * (pizero_internvl.py:823); final norm + action_decoder + Euler update (+clamp) (pizero_internvl.py:911-932). */
 int vlaser_vla_prep(const float* action, const void* w1, const void* b1, void* xcat, int M, int W, int adim, float t, float max_period, vl_stream_t stream);

@@ -489,7 +489,7 @@ def test_chain_gu_bit_identical_to_skinny(ops, M, H, I, npart):
 
 @pytest.mark.parametrize('B,tok,H', [(1, 4, 768), (1, 5, 768), (2, 4, 768), (4, 4, 768), (1, 1, 1536), (8, 1, 1536)])
 def test_chain_qkv_vs_skinny_and_fp32(ops, B, tok, H):
-    """r05: one wave per 16-row q/k/v unit over the whole K (no LDS exchange between waves): q, K cache and V^T cache vs the fp32 reference and vs the 8-wave skinny
+    """r05: one wave per 16-row q/k/v unit over the whole K (hidden 768; two waves, one K half each, at hidden 1536): q, K cache and V^T cache vs the fp32 reference and vs the 8-wave skinny
     kernel (different fp32 summation order: bf16-level agreement), untouched cache slots stay untouched."""
     from vlaser_amd import _lib as L
     nq, nkv, smax = 12, 2, 448
@@ -521,6 +521,20 @@ def test_chain_qkv_vs_skinny_and_fp32(ops, B, tok, H):
     assert float((kc[:, :, :385].float() - 3).abs().max()) == 0 and float((vtc[:, :, :, 385 + tok:].float() - 3).abs().max()) == 0
     for a_, b_ in zip(outs[0], outs[1]):           # vs the 8-wave kernel: the same values up to the fp32 summation order
         assert (a_.float() - b_.float()).abs().max().item() <= 2 ** -6 * max(1.0, b_.float().abs().max().item())
+    if H == 1536:          # hidden 1536 runs two waves per unit (one K half each) by default; the one-wave kernel stays reachable and agrees to the summation order
+        prev = L.lib().vlaser_chain_qkv_set_waves(1)
+        try:
+            assert prev == 0
+            q1 = torch.zeros(M, nq * 128, dtype=BF, device='cuda')
+            kc1 = torch.full((B, nkv, smax, 128), 3.0, dtype=BF, device='cuda'); vtc1 = torch.full((B, nkv, 128, smax), 3.0, dtype=BF, device='cuda')
+            a, keep = ops.skinny_args(h, pw, M, n_partials=0, norm_w=nw, bias=B16, q_out=q1, k_cache=kc1, vt_cache=vtc1, rope_cos=cos, rope_sin=sin, pos_ids=pos,
+                                      n_q_heads=nq, n_kv_heads=nkv, s_max=smax, tok_per_batch=tok, slot_base=385)
+            ops.launch_chain_qkv(a)
+        finally:
+            L.lib().vlaser_chain_qkv_set_waves(prev)
+        close(q1.view(M, nq, 128), _rope_ref(q, pos), name='q, one wave per unit')
+        for a_, b_ in zip((q1, kc1, vtc1), outs[1]):
+            assert (a_.float() - b_.float()).abs().max().item() <= 2 ** -6 * max(1.0, b_.float().abs().max().item())
     # slot_base < 0: the cache slot is the row's position id (graph-replayable decode)
     kc2 = torch.zeros(B, nkv, smax, 128, dtype=BF, device='cuda'); vtc2 = torch.zeros(B, nkv, 128, smax, dtype=BF, device='cuda')
     pos2 = (torch.arange(tok).repeat(B) + 100).int().cuda()
@@ -687,6 +701,21 @@ def test_argmax_widths_and_ties(ops, N):
     oid = torch.full((4,), -1, dtype=torch.int64, device='cuda')
     ops.argmax(logits, oid, None, None)
     assert torch.equal(oid, logits.argmax(-1)) and oid[3] == 0 and oid[1] == N - 1
+    # r05: the same rows spread over 64 workgroups each (last arriver folds the pairs and re-arms the counter): repeated launches on one workspace, + the embedding gather
+    ws = ops.argmax_workspace(4, 'cuda')
+    emb = rnd(N, 64, seed=3)
+    for rep in range(3):
+        oid2 = torch.full((4,), -1, dtype=torch.int64, device='cuda'); nh = torch.zeros(4, 64, dtype=BF, device='cuda')
+        ops.argmax(logits, oid2, emb, nh, ws=ws)
+        assert torch.equal(oid2, oid) and torch.equal(nh, emb[oid])
+    sub = logits[:, 1:].contiguous()                      # the other row alignment (N - 1 columns)
+    oid3 = torch.full((4,), -1, dtype=torch.int64, device='cuda')
+    ops.argmax(sub, oid3, None, None, ws=ws)
+    assert torch.equal(oid3, sub.argmax(-1))
+    if N >= 4096:                                         # (narrower rows take the one-workgroup kernel and never look at the workspace)
+        from vlaser_amd import _lib as L
+        with pytest.raises(L.VlaserHipError):
+            ops.argmax(logits, oid2, None, None, ws=ws[:16])
 
 
 def test_vla_glue(ops):

@@ -9,7 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from vlaser_amd import config as C, synth            # noqa: E402
+from vlaser_amd import _lib as L, config as C, synth            # noqa: E402
 from vlaser_amd.internvl_chat import InternVLChatModel  # noqa: E402
 
 
@@ -35,6 +35,7 @@ def main():
         for rep in range(3):
             for s, m in zip(settings, models):
                 ts = []
+                L.lib().vlaser_chain_qkv_set_waves(1 if 'qkv1w' in s.split(',') else 0)      # (pseudo-option: the one-wave q/k/v kernel at hidden 1536; captured with the model's graphs)
                 for n_new in (1, 33):
                     out = m.generate(pv, ids, max_new_tokens=n_new, min_new_tokens=n_new)
                     torch.cuda.synchronize()

@@ -72,6 +72,7 @@ _SIGS = {
     'vlaser_chain_down': [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp],
     'vlaser_chain_down2_supported': [i32, i32, i32],
     'vlaser_chain_qkv2_supported': [i32, i32, i32],
+    'vlaser_chain_qkv_set_waves': [i32],
     'vlaser_chain_down2': [vp, i32, vp, vp, i32, i32, i32, vp, vp],
     'vlaser_layernorm': [vp, vp, vp, vp, i32, i32, f32, vp],
     'vlaser_rmsnorm': [vp, vp, vp, i32, i32, f32, vp],
@@ -80,7 +81,8 @@ _SIGS = {
     'vlaser_pixel_shuffle_ln': [vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
     'vlaser_pixel_shuffle': [vp, vp, i32, i32, i32, i32, vp],
     'vlaser_embed_merge': [vp, i32, vp, vp, i32, vp, i32, i64, i64, i32, vp, vp, vp],
-    'vlaser_argmax': [vp, i32, i32, vp, vp, vp, i32, vp],
+    'vlaser_argmax': [vp, i32, i32, vp, vp, vp, i32, vp, i32, vp],
+    'vlaser_argmax_ws_bytes': [i32],
     'vlaser_vla_prep': [vp, vp, vp, vp, i32, i32, i32, f32, f32, vp],
     'vlaser_small_linear': [vp, vp, vp, vp, i32, i32, i32, vp],
     'vlaser_vla_step': [vp, vp, i32, i32, i32, vp, f32, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp],

@@ -270,11 +270,16 @@ struct ChainQkvP {
 // matrix (head_perm16 packing: lane group g of a unit holds [d, d+1, d+64, d+65], d = 8 (unit % 8) + 2 g -- the RoPE partner of every value in the same lane).
 // SP = 0: h_in is the residual stream itself; SP = 2: h = bf16(h_in + slab 0 + slab 1), the two K halves of vlaser_chain_down2 (slabs first, residual last: the
 // order of every other seam here), and unit 0's wave stores h for the o_proj -> gate/up seam.
-template <int KS, int RG, int SP, bool DBG>
-__global__ __launch_bounds__(64) void chain_qkv_kernel(ChainQkvP p) {
-  constexpr int K = KS * 32, NCH = KS / 4, XS = K * 2 + 16;        // NCH: 16-byte chunks of a row per lane of its 16-lane group
-  extern __shared__ __attribute__((aligned(16))) char xs[];        // [4 RG][XS] normalised activations (bf16)
-  const int lane = threadIdx.x, fr = lane & 15, g = lane >> 4, r4 = lane >> 4, j16 = lane & 15;
+// NWV = 2 (hidden 1536, the greedy decode): two waves per unit, each over one K half -- 24 weight requests and 24 dependent MFMAs per wave instead of 48 (6.6 -> 5.x us per
+// launch); both waves load the whole row (3 KB from L2) for the row's sum of squares and normalise their own half into their own LDS rows (still wave-local); wave 1 hands its
+// accumulator to wave 0 through LDS (the launch's only barrier).
+template <int KS, int RG, int SP, int NWV, bool DBG>
+__global__ __launch_bounds__(64 * NWV) void chain_qkv_kernel(ChainQkvP p) {
+  constexpr int K = KS * 32, NCH = KS / 4, KSW = KS / NWV, NCW = NCH / NWV, XS = (K / NWV) * 2 + 16;        // NCH: 16-byte chunks of a row per lane of its 16-lane group
+  static_assert(NWV == 1 || ((NWV == 2 || NWV == 4) && SP == 0 && KS % (4 * NWV) == 0), "several waves: plain residual stream, whole chunks per K part");
+  extern __shared__ __attribute__((aligned(16))) char smem_q[];    // [NWV][4 RG][XS] normalised activations (bf16) | NWV = 2: f32x4[64] of wave 1's accumulator
+  const int lane = threadIdx.x & 63, wv = NWV == 1 ? 0 : (int)(threadIdx.x >> 6), fr = lane & 15, g = lane >> 4, r4 = lane >> 4, j16 = lane & 15;
+  char* xs = smem_q + wv * (4 * RG * XS);
   const int unit = blockIdx.x, M = p.M;
   unsigned long long* dbg = DBG ? p.dbg + (size_t)blockIdx.x * 8 : nullptr;
   CH_STAMP(0);
@@ -301,11 +306,11 @@ __global__ __launch_bounds__(64) void chain_qkv_kernel(ChainQkvP p) {
   }
   const u32x2 bias = *reinterpret_cast<const u32x2*>(p.bias + unit * 16 + g * 4);
   __builtin_amdgcn_sched_barrier(0);           // pin the issue order: vmcnt retires in order, the scheduler does not know
-  u32x4 w[KS];
+  u32x4 w[KSW];
   {
-    const u32x4* src = p.W + (size_t)unit * (KS * 64) + lane;
+    const u32x4* src = p.W + (size_t)unit * (KS * 64) + wv * (KSW * 64) + lane;
 #pragma unroll
-    for (int f = 0; f < KS; ++f) w[f] = __builtin_nontemporal_load(src + f * 64);
+    for (int f = 0; f < KSW; ++f) w[f] = __builtin_nontemporal_load(src + f * 64);
   }
   __builtin_amdgcn_sched_barrier(0);
   const int d = ((unit & 7) << 3) + 2 * g;
@@ -341,15 +346,24 @@ __global__ __launch_bounds__(64) void chain_qkv_kernel(ChainQkvP p) {
     const float rs = rsqrtf(ssq / (float)K + p.eps);
     const int row = rg * 4 + r4;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
+    for (int i2 = 0; i2 < NCW; ++i2) {
+      u32x4 hv, wv4;
+      if constexpr (NWV == 1) { hv = hc[rg][i2]; wv4 = wn[i2]; }
+      else {                                     // this wave's K part: chunks [wv NCW, (wv + 1) NCW) -- selected without indexing the register arrays dynamically
+        hv = hc[rg][i2]; wv4 = wn[i2];
+#pragma unroll
+        for (int v = 1; v < NWV; ++v)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { hv[e] = wv == v ? hc[rg][v * NCW + i2][e] : hv[e]; wv4[e] = wv == v ? wn[v * NCW + i2][e] : wv4[e]; }
+      }
       u32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float lo = round_bf16(bf16lo_to_f32(hc[rg][i][e]) * rs) * bf16lo_to_f32(wn[i][e]);
-        const float hi = round_bf16(bf16hi_to_f32(hc[rg][i][e]) * rs) * bf16hi_to_f32(wn[i][e]);
+        const float lo = round_bf16(bf16lo_to_f32(hv[e]) * rs) * bf16lo_to_f32(wv4[e]);
+        const float hi = round_bf16(bf16hi_to_f32(hv[e]) * rs) * bf16hi_to_f32(wv4[e]);
         o[e] = pack_bf16x2(lo, hi);
       }
-      if (row < M) *reinterpret_cast<u32x4*>(xs + row * XS + (j16 + 16 * i) * 16) = o;
+      if (row < M) *reinterpret_cast<u32x4*>(xs + row * XS + (j16 + 16 * i2) * 16) = o;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -361,7 +375,7 @@ __global__ __launch_bounds__(64) void chain_qkv_kernel(ChainQkvP p) {
   const char* xrow = xs + (mok ? fr : 0) * XS + g * 16;
   f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
-  for (int f = 0; f < KS; f += 2) {
+  for (int f = 0; f < KSW; f += 2) {
     const u32x4 x0 = *reinterpret_cast<const u32x4*>(xrow + f * 64), x1 = *reinterpret_cast<const u32x4*>(xrow + (f + 1) * 64);     // rows >= M shadow row 0 (never stored)
     acc0 = mfma16(as_bf16x8(w[f]), as_bf16x8(x0), acc0);
     acc1 = mfma16(as_bf16x8(w[f + 1]), as_bf16x8(x1), acc1);
@@ -371,6 +385,18 @@ __global__ __launch_bounds__(64) void chain_qkv_kernel(ChainQkvP p) {
   for (int e = 0; e < 4; ++e) acc[e] = acc0[e] + acc1[e];
   if constexpr (DBG) asm volatile("" ::"v"(acc[0]));
   CH_STAMP(3);
+  if constexpr (NWV > 1) {                       // out = sum of the K parts in wave order, wave 0 finishes
+    f32x4* red = reinterpret_cast<f32x4*>(smem_q + NWV * (4 * RG * XS));
+    if (wv != 0) red[(wv - 1) * 64 + lane] = acc;
+    __syncthreads();
+    if (wv != 0) return;
+#pragma unroll
+    for (int v = 1; v < NWV; ++v) {
+      const f32x4 o = red[(v - 1) * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += o[e];
+    }
+  }
   // ---- epilogue: bias + RoPE + scatter (as skinny_epilogue16<QKV_ROPE>): lane -> row m = fr, values [d, d+1, d+64, d+65] of head unit / 8
   if (mok) {
     const int m = fr, head = unit >> 3;
@@ -402,6 +428,8 @@ __global__ __launch_bounds__(64) void chain_qkv_kernel(ChainQkvP p) {
 }
 
 extern "C" int vlaser_chain_qkv_supported(int M, int N, int K) { return M >= 1 && ((K == 768 && M <= 16) || (K == 1536 && M <= 8)) && N % 128 == 0; }      // (hidden 1536 x 16 rows would spill)
+static int g_qkv_waves = 0;            // tools / tests: 1 forces the one-wave kernel at hidden 1536 (same-box A/B, order-of-summation tests); 0 = the defaults below
+extern "C" int vlaser_chain_qkv_set_waves(int n) { const int prev = g_qkv_waves; if (n == 0 || n == 1) g_qkv_waves = n; return prev; }
 /* with the two fp32 slabs of vlaser_chain_down2 as input (n_partials = 2) */
 extern "C" int vlaser_chain_qkv2_supported(int M, int N, int K) { return M >= 1 && ((K == 768 && M <= 8) || (K == 1536 && M <= 4)) && N % 128 == 0; }
 
@@ -418,17 +446,22 @@ extern "C" int vlaser_chain_qkv(const VlaserSkinnyArgs* a, vl_stream_t s) {
   p.pos_ids = a->pos_ids; p.M = a->M; p.n_q_heads = a->n_q_heads; p.n_kv_heads = a->n_kv_heads; p.s_max = a->s_max; p.tok_per_batch = a->tok_per_batch;
   p.slot_base = a->slot_base; p.eps = a->eps; p.dbg = a->dbg;
   const int units = a->N / 16, rg = (a->M + 3) / 4, ks = a->K / 32;
-  const int lds = 4 * rg * (a->K * 2 + 16);
+  // waves per unit (K parts): hidden 1536 two (measured in the decode step: 0.9745 -> 0.9595 ms per token), hidden 768 one
+  const int nwv = (a->n_partials == 0 && ks == 48 && g_qkv_waves != 1) ? 2 : 1;
+  const int lds = nwv * 4 * rg * (a->K / nwv * 2 + 16) + (nwv - 1) * 64 * 16;
   hipStream_t stream = (hipStream_t)s;
-#define CQ_LAUNCH(KS_, RG_, SP_, DBG_)                                                                      \
-  do {                                                                                                      \
-    if (int rc = set_max_lds_once(chain_qkv_kernel<KS_, RG_, SP_, DBG_>, lds)) return rc;                    \
-    hipLaunchKernelGGL((chain_qkv_kernel<KS_, RG_, SP_, DBG_>), dim3(units), dim3(64), lds, stream, p);      \
-    VL_LAUNCH_CHECK();                                                                                      \
-    return 0;                                                                                               \
+#define CQ_LAUNCH(KS_, RG_, SP_, NWV_, DBG_)                                                                            \
+  do {                                                                                                                  \
+    if (int rc = set_max_lds_once(chain_qkv_kernel<KS_, RG_, SP_, NWV_, DBG_>, lds)) return rc;                          \
+    hipLaunchKernelGGL((chain_qkv_kernel<KS_, RG_, SP_, NWV_, DBG_>), dim3(units), dim3(64 * NWV_), lds, stream, p);     \
+    VL_LAUNCH_CHECK();                                                                                                  \
+    return 0;                                                                                                           \
   } while (0)
-#define CQ_CASE(KS_, RG_, SP_) if (ks == KS_ && rg == RG_ && a->n_partials == SP_) { if (p.dbg) CQ_LAUNCH(KS_, RG_, SP_, true); else CQ_LAUNCH(KS_, RG_, SP_, false); }
+#define CQ_CASEW(KS_, RG_, SP_, NWV_) if (ks == KS_ && rg == RG_ && a->n_partials == SP_ && nwv == NWV_) { if (p.dbg) CQ_LAUNCH(KS_, RG_, SP_, NWV_, true); else CQ_LAUNCH(KS_, RG_, SP_, NWV_, false); }
+#define CQ_CASE(KS_, RG_, SP_) CQ_CASEW(KS_, RG_, SP_, 1)
   CQ_CASE(24, 1, 0) CQ_CASE(24, 2, 0) CQ_CASE(24, 3, 0) CQ_CASE(24, 4, 0) CQ_CASE(48, 1, 0) CQ_CASE(48, 2, 0) CQ_CASE(24, 1, 2) CQ_CASE(24, 2, 2) CQ_CASE(48, 1, 2)
+  CQ_CASEW(48, 1, 0, 2) CQ_CASEW(48, 2, 0, 2)      // (measured and not kept: four waves at hidden 1536 0.9709 vs 0.9697 ms per token; two waves at hidden 768 11.656 vs 11.645 ms per chunk)
+#undef CQ_CASEW
 #undef CQ_CASE
 #undef CQ_LAUNCH
   vlaser_set_error("vlaser_chain_qkv: no variant");

@@ -335,10 +335,94 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
     for (int c = threadIdx.x * 8; c < H; c += 1024 * 8) st_global_16(next_h + (size_t)m * H + c, ld_global_16(src + c));
   }
 }
-extern "C" int vlaser_argmax(const float* logits, int M, int N, int64_t* out_id, const void* embed, void* next_h, int H, vl_stream_t s) {
+// r05: the row spread over G workgroups.  One workgroup reading a 0.6 MB row is bound by what ONE CU can request (~35 GB/s: 18 us of a 0.96 ms decode step, lesson 46);
+// G = 64 workgroups of 256 threads read 9.5 KB each, leave (value, index) pairs, and the LAST one to arrive (device-scope counter, reset by it for the next launch) folds the
+// pairs -- max value, lowest index: independent of the arrival order -- and gathers the winner's embedding row.  ws: [M][G] float | [M][G] int | [M] counters (zeroed once).
+constexpr int ARGMAX_G = 64;
+__global__ __launch_bounds__(256) void argmax_split_kernel(const float* __restrict__ logits, int N, int64_t* __restrict__ out_id, const bf16_t* __restrict__ embed,
+                                                           bf16_t* __restrict__ next_h, int H, float* pv, int* pi, unsigned* ctr) {
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  __shared__ int winner, is_last;
+  const int m = blockIdx.y, g = blockIdx.x, G = gridDim.x;
+  const float* row = logits + (size_t)m * N;
+  const int per = (((N + G - 1) / G) + 1) & ~1;                  // even: 8-byte loads stay aligned when the row is
+  const int lo = min(N, g * per), hi = min(N, lo + per);
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  auto upd = [&](float v, int n) { if (v > best || (v == best && n < idx)) { best = v; idx = n; } };
+  if ((reinterpret_cast<uintptr_t>(row) & 7) == 0) {
+    const f32x2_t* row2 = reinterpret_cast<const f32x2_t*>(row);
+    const int lo2 = lo >> 1, hi2 = hi >> 1;                       // pairs [lo2, hi2); an odd last element below
+    int n = lo2 + threadIdx.x;
+    for (; n + 3 * 256 < hi2; n += 4 * 256) {
+      f32x2_t v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = row2[n + j * 256];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { upd(v[j][0], 2 * (n + j * 256)); upd(v[j][1], 2 * (n + j * 256) + 1); }
+    }
+    for (; n < hi2; n += 256) { const f32x2_t v = row2[n]; upd(v[0], 2 * n); upd(v[1], 2 * n + 1); }
+    if (threadIdx.x == 0 && (hi & 1)) upd(row[hi - 1], hi - 1);
+  } else {
+    for (int k = lo + threadIdx.x; k < hi; k += 256) upd(row[k], k);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+    __hip_atomic_store(pv + (size_t)m * G + g, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(pi + (size_t)m * G + g, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned old = __hip_atomic_fetch_add(ctr + m, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);      // release: the pair is visible before the count
+    is_last = old == (unsigned)(G - 1);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  best = -INFINITY; idx = 0x7fffffff;
+  if ((int)threadIdx.x < G) {
+    best = __hip_atomic_load(pv + (size_t)m * G + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    idx = __hip_atomic_load(pi + (size_t)m * G + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x < 64) {                                        // G <= 64: one wave holds every pair
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(idx, o, 64);
+      if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if (threadIdx.x == 0) {
+      out_id[m] = idx;
+      winner = idx;
+      __hip_atomic_store(ctr + m, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch (stream order)
+    }
+  }
+  __syncthreads();
+  if (next_h) {
+    const bf16_t* src = embed + (size_t)winner * H;
+    for (int c = threadIdx.x * 8; c < H; c += 256 * 8) st_global_16(next_h + (size_t)m * H + c, ld_global_16(src + c));
+  }
+}
+extern "C" int vlaser_argmax_ws_bytes(int M) { return M * (ARGMAX_G * 8 + 4); }
+extern "C" int vlaser_argmax(const float* logits, int M, int N, int64_t* out_id, const void* embed, void* next_h, int H, void* ws, int ws_bytes, vl_stream_t s) {
   VL_CHECK(logits && out_id && M > 0 && N > 0, "vlaser_argmax: bad args");
   VL_CHECK(!next_h || (embed && H % 8 == 0), "vlaser_argmax: embed/H");
-  hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(1024), 0, (hipStream_t)s, logits, N, out_id, (const bf16_t*)embed, (bf16_t*)next_h, H);
+  if (ws && N >= 4096) {
+    VL_CHECK(ws_bytes >= vlaser_argmax_ws_bytes(M) && ((uintptr_t)ws & 3) == 0, "vlaser_argmax: workspace of %d bytes, %d needed (vlaser_argmax_ws_bytes; zeroed once by the caller)", ws_bytes,
+             vlaser_argmax_ws_bytes(M));
+    float* pv = (float*)ws;
+    int* pi = (int*)(pv + (size_t)M * ARGMAX_G);
+    unsigned* ctr = (unsigned*)(pi + (size_t)M * ARGMAX_G);
+    hipLaunchKernelGGL(argmax_split_kernel, dim3(ARGMAX_G, M), dim3(256), 0, (hipStream_t)s, logits, N, out_id, (const bf16_t*)embed, (bf16_t*)next_h, H, pv, pi, ctr);
+  } else {
+    hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(1024), 0, (hipStream_t)s, logits, N, out_id, (const bf16_t*)embed, (bf16_t*)next_h, H);
+  }
   VL_LAUNCH_CHECK();
   return 0;
 }

@@ -120,6 +120,7 @@ class InternVLChatModel:
         self.img_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.logits = torch.zeros(16, llm.vocab_size, dtype=torch.float32, device=dev)
         self.next_ids = torch.zeros(16, dtype=torch.int64, device=dev)
+        self.argmax_ws = ops.argmax_workspace(16, dev)      # r05: the vocabulary row spread over 64 workgroups (one CU's request rate was the whole 18 us)
         self.next_h = torch.zeros(16, llm.hidden_size, dtype=BF, device=dev)
         # device-resident decode state: pos1 = position (= cache slot) of the incoming token of each sequence, vis = keys visible to it
         self.dyn = torch.zeros(32, dtype=torch.int32, device=dev)
@@ -185,7 +186,7 @@ class InternVLChatModel:
             ops.rmsnorm(h_last, self.llm.norm, llm.rms_norm_eps, out=self.pbuf.x[:M])
             ops.gemm(L.EPI_F32, self.pbuf.x[:M], self.llm.head, out=self.logits[:M])
         if greedy:
-            ops.argmax(self.logits[:M], self.next_ids, self.llm.embed, self.next_h)
+            ops.argmax(self.logits[:M], self.next_ids, self.llm.embed, self.next_h, ws=self.argmax_ws)
 
     def _decode_step(self, B, L_cur, lens=None, step=0):
         """One greedy step for B sequences: consumes self.next_h.  Uniform batches hold L_cur cached tokens each.  Ragged

@@ -476,10 +476,15 @@ def embed_merge(ids, embed, vit, out, img_id, pad_id, zero_pad, rank_ws, count_o
                                        _p(count_out), _stream()), 'vlaser_embed_merge')
 
 
-def argmax(logits, out_id, embed=None, next_h=None):
+def argmax_workspace(max_rows, device):
+    """Zeroed workspace of vlaser_argmax's many-workgroup form (pairs + arrival counters); owned by the launches that receive it, one stream at a time."""
+    return torch.zeros(L.lib().vlaser_argmax_ws_bytes(max_rows), dtype=torch.uint8, device=device)
+
+
+def argmax(logits, out_id, embed=None, next_h=None, ws=None):
     M, N = logits.shape
     L.check(L.lib().vlaser_argmax(logits.data_ptr(), M, N, out_id.data_ptr(), _p(embed), _p(next_h),
-                                  0 if embed is None else embed.shape[1], _stream()), 'vlaser_argmax')
+                                  0 if embed is None else embed.shape[1], _p(ws), 0 if ws is None else ws.numel(), _stream()), 'vlaser_argmax')
 
 
 def vla_prep(action, w1, b1, xcat, M, W, adim, t, max_period):
