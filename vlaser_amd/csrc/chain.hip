@@ -863,6 +863,36 @@ __global__ __launch_bounds__(512) void chain_oproj_kernel(ChainOprojP p) {
   }
   const float inv = Ls > 0.f ? 1.0f / Ls : 0.f;
   if (tid < nch) *reinterpret_cast<u32x4*>(xs + mm * XS + j * 16) = u32x4{pack_bf16x2(v[0] * inv, v[1] * inv), pack_bf16x2(v[2] * inv, v[3] * inv), pack_bf16x2(v[4] * inv, v[5] * inv), pack_bf16x2(v[6] * inv, v[7] * inv)};
+  // more than 512 pieces (decode batches of 6 .. 16 rows): the remaining ones in further passes of the same arithmetic, their requests no longer up front (one exposed L2 round
+  // trip per pass; never taken by the Euler phase or the batch-1 decode)
+  for (int c2 = tid + 512; c2 < nch; c2 += 512) {
+    const int mm2 = ch_fdiv(c2, p.inv_cpr), j2 = c2 - mm2 * cpr;
+    const int k2 = ks * KB + j2 * 8, h2 = k2 >> 7, d2 = k2 & 127;
+    const int b2 = ch_fdiv(mm2, __builtin_amdgcn_rcpf((float)p.nq)), tok2 = mm2 - b2 * p.nq, kvh2 = ch_fdiv(h2, __builtin_amdgcn_rcpf((float)p.G)), r2 = (h2 - kvh2 * p.G) * p.nq + tok2;
+    const size_t pb2 = ((size_t)b2 * p.nkv + kvh2) * nsp;
+    f32x2_t ml2[S];
+    u32x4 ov2[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int sc = (S == 7) ? s : min(s, nsp - 1);
+      ml2[s] = *reinterpret_cast<const f32x2_t*>(p.pml + ((pb2 + sc) * 32 + r2) * 2);
+      ov2[s] = ld_global_16(p.po + ((pb2 + sc) * 32 + r2) * 128 + d2);
+    }
+    float Mx2 = -1.0e30f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) Mx2 = fmaxf(Mx2, ml2[s][0]);
+    float Ls2 = 0.f, v2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      float f = ml2[s][1] * __builtin_amdgcn_exp2f(ml2[s][0] - Mx2);
+      if (S != 7) f = s < nsp ? f : 0.f;
+      Ls2 += f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v2[2 * e] += f * bf16lo_to_f32(ov2[s][e]); v2[2 * e + 1] += f * bf16hi_to_f32(ov2[s][e]); }
+    }
+    const float inv2 = Ls2 > 0.f ? 1.0f / Ls2 : 0.f;
+    *reinterpret_cast<u32x4*>(xs + mm2 * XS + j2 * 16) = u32x4{pack_bf16x2(v2[0] * inv2, v2[1] * inv2), pack_bf16x2(v2[2] * inv2, v2[3] * inv2), pack_bf16x2(v2[4] * inv2, v2[5] * inv2), pack_bf16x2(v2[6] * inv2, v2[7] * inv2)};
+  }
   __syncthreads();
   CH_STAMP(2);
   const bool mok = fr < M;
@@ -887,14 +917,14 @@ extern "C" int vlaser_chain_oproj_supported(int M, int N, int K, int k_splits, i
   if (M < 1 || M > 16 || N % 16 || K % (k_splits * 256) || K % (128 * group) || (K / k_splits) % (128) ) return 0;
   const int ns = K / (k_splits * 256);
   if (!((ns == 2 || ns == 3) && attn_splits >= 1 && attn_splits <= 16)) return 0;
-  return M * (K / k_splits / 8) <= 512;
+  return 1;            // (M (K / k_splits / 8) > 512 pieces of the activation tile: further passes of the merge prologue)
 }
 
 /* args as vlaser_skinny(VL_PRO_ATTN, VL_SK_PARTIAL) with tiles_per_unit = 1, attn_m = the (m, l) pairs and attn_o = the bf16 rows written by vlaser_chain_attn */
 extern "C" int vlaser_chain_oproj(const VlaserSkinnyArgs* a, vl_stream_t s) {
   VL_CHECK(a && a->W && a->attn_m && a->attn_o && a->out_f32, "vlaser_chain_oproj: null operand");
   VL_CHECK(a->tiles_per_unit == 1 && vlaser_chain_oproj_supported(a->M, a->N, a->K, a->k_splits, a->attn_splits, a->attn_group),
-           "vlaser_chain_oproj: built for 16-row units, 2 / 3 K-steps per wave, <= 16 attention splits, M * K / k_splits / 8 <= 512 (got M %d N %d K %d ks %d splits %d)", a->M, a->N, a->K,
+           "vlaser_chain_oproj: built for 16-row units, 2 / 3 K-steps per wave, <= 16 attention splits (got M %d N %d K %d ks %d splits %d)", a->M, a->N, a->K,
            a->k_splits, a->attn_splits);
   ChainOprojP p;
   p.pml = a->attn_m; p.po = (const bf16_t*)a->attn_o; p.W = (const u32x4*)a->W; p.out = a->out_f32;

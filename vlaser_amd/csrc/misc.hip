@@ -337,7 +337,7 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
 }
 // r05: the row spread over G workgroups.  One workgroup reading a 0.6 MB row is bound by what ONE CU can request (~35 GB/s: 18 us of a 0.96 ms decode step, lesson 46);
 // G = 64 workgroups of 256 threads read 9.5 KB each, leave (value, index) pairs, and the LAST one to arrive (device-scope counter, reset by it for the next launch) folds the
-// pairs -- max value, lowest index: independent of the arrival order -- and gathers the winner's embedding row.  ws: [M][G] float | [M][G] int | [M] counters (zeroed once).
+// pairs -- max value, lowest index: independent of the arrival order -- and gathers the winner's embedding row.  ws (capacity R rows): [R] counters (zeroed once, re-armed by the last arriver) | [R][G] float | [R][G] int.
 constexpr int ARGMAX_G = 64;
 __global__ __launch_bounds__(256) void argmax_split_kernel(const float* __restrict__ logits, int N, int64_t* __restrict__ out_id, const bf16_t* __restrict__ embed,
                                                            bf16_t* __restrict__ next_h, int H, float* pv, int* pi, unsigned* ctr) {
@@ -416,9 +416,11 @@ extern "C" int vlaser_argmax(const float* logits, int M, int N, int64_t* out_id,
   if (ws && N >= 4096) {
     VL_CHECK(ws_bytes >= vlaser_argmax_ws_bytes(M) && ((uintptr_t)ws & 3) == 0, "vlaser_argmax: workspace of %d bytes, %d needed (vlaser_argmax_ws_bytes; zeroed once by the caller)", ws_bytes,
              vlaser_argmax_ws_bytes(M));
-    float* pv = (float*)ws;
-    int* pi = (int*)(pv + (size_t)M * ARGMAX_G);
-    unsigned* ctr = (unsigned*)(pi + (size_t)M * ARGMAX_G);
+    // layout by the workspace's CAPACITY, not by this launch's M: the counters must sit where the zeroing (and every earlier launch, whatever its M) left them at 0
+    const int cap = ws_bytes / (ARGMAX_G * 8 + 4);
+    unsigned* ctr = (unsigned*)ws;
+    float* pv = (float*)(ctr + cap);
+    int* pi = (int*)(pv + (size_t)cap * ARGMAX_G);
     hipLaunchKernelGGL(argmax_split_kernel, dim3(ARGMAX_G, M), dim3(256), 0, (hipStream_t)s, logits, N, out_id, (const bf16_t*)embed, (bf16_t*)next_h, H, pv, pi, ctr);
   } else {
     hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(1024), 0, (hipStream_t)s, logits, N, out_id, (const bf16_t*)embed, (bf16_t*)next_h, H);
