@@ -11,6 +11,7 @@
 // ds_read_b128.  Global->register prefetch of tile k+1 overlaps the MFMAs of tile k; one barrier per K-step.
 // blockIdx is remapped so each XCD owns a contiguous run of tiles that share the same weight panel (guide T1).
 
+#include <cstdlib>
 #include "common.h"
 #include "../../include/vlaser_hip.h"
 
@@ -763,9 +764,20 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // IFIRST: the refill of the stage read in the previous step is requested right behind the barrier, in FRONT of this step's fragment reads (r02 order) instead
 // of behind the first half's (r03).  With only two stages and HBM-cold weights (192x256, the training forward's gate/up) the extra half step of lead is
 // worth more than the reads it delays: 43.7 -> 38.7 us; every ring of three or more stages loses 5-13 % with it (tools/micro/gemm_epilogue_lab.py).
-template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false, bool IFIRST = GLDS_ISSUE_FIRST != 0>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
+// PRD (r05, LAB ONLY -- measured slower, see launch<>'s case 2100): PRD extra PRODUCER waves (one per SIMD) issue every LDS-DMA piece; the WM x WN compute waves only pass
+// the barrier, read fragments and issue MFMAs.  The idea: with no DMA at all the loop's compute side (fragment reads -> MFMAs, one barrier per K-step, 192x256 tile) runs at
+// 0.90 us per K-step = 1.8 PFLOP/s whatever the MFMA shape (tools/micro/mfma_shape_lab.hip, profiles/r05r_mfma_shape_lab.md), the product loop at 1.6.  A producer wave's
+// K-step: vmcnt for ITS pieces of tile kt -> barrier -> refill of the stage read in step kt-1.  What it showed: issuing pieces is serial PER WAVE, so fewer issuing waves
+// lengthen the step -- the 8 compute waves issuing 6 pieces each in parallel are the better arrangement.
+// ASYM (r05): the W operand's ring is ONE STAGE DEEPER than the A operand's (NST + 1 against NST).  A two-stage ring has one tile in flight -- requested at step kt, needed at
+// kt + 1 -- and its step lasts as long as that round trip (192x256: 1.6 us against 0.9 us of fragment reads + MFMAs, profiles/r05r_mfma_shape_lab.md); a third full stage does
+// not fit 160 KB at these tile sizes, a third stage of the HBM-cold operand alone does (192x256: 2 x 24 + 3 x 32 = 144 KB): the weights get two steps of lead, the activations
+// (L2-resident) one.  Issue order per step: A(kt + NST - 1), then W(kt + NST); everything that must have landed at step kt is older than everything that may still fly.
+template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false, bool IFIRST = GLDS_ISSUE_FIRST != 0, int PRD = 0, bool ASYM = false>
+__global__ __launch_bounds__((WM * WN + PRD) * 64) void gemm_glds_kernel(GemmP p) {
+  static_assert(!(ASYM && PRD), "one lab at a time");
   constexpr int NW = WM * WN;
+  constexpr int NWI = PRD ? PRD : NW;                    // waves that issue LDS-DMA pieces
   constexpr int WTM = BM / WM, WTN = BNT / WN;
   constexpr int MT = WTM / 16, NT = WTN / 16;
   constexpr int STAGE = (BM + BNT) * 128;               // bytes: A tile | W tile (row-major, 128 B = 64 k per row)
@@ -773,7 +785,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
   constexpr int WROWB = BNT * 2, WRPP = 1024 / WROWB, WSPR = BNT / 8;      // WKM: bytes per k-row, k-rows per piece, 16-byte slots per k-row
   constexpr int AROWB = BM * 2, ARPP = 1024 / AROWB, ASPR = BM / 8;        // AKM: the same for the A tile
   static_assert(!AKM || (WKM && (BM == 128 || BM == 256)), "AKM needs WKM and a power-of-two tile of >= 16 slots per k-row");
-  constexpr int PA = (NPA + NW - 1) / NW, PW = (NPW + NW - 1) / NW;     // pieces per wave per K-tile; an uneven split re-issues the last piece
+  constexpr int PA = (NPA + NWI - 1) / NWI, PW = (NPW + NWI - 1) / NWI; // pieces per issuing wave per K-tile; an uneven split re-issues the last piece
   constexpr int PIECES = PA + PW;                        // (same bytes to the same LDS address: benign) so every wave's vmcnt arithmetic is identical
   static_assert(NPA * 8 == BM && NPW * 8 == BNT, "tile rows must be multiples of 8");
   static_assert(NT % 2 == 0, "fused pair epilogues need an even number of 16-column tiles per wave");
@@ -781,6 +793,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
   const VlaserGemmArgs& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
+  const bool producer = PRD && wave >= NW;               // (wave-uniform)
+  const int iw = PRD ? wave - NW : wave;                 // index among the issuing waves (compute waves of a PRD kernel never use it)
   const int nwg = gridDim.x;
   GEMM_STAMP(0)
   int bid = blockIdx.x;
@@ -804,34 +818,40 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     if constexpr (AKM) {
-      const int krow = min(wave * PA + i, NPA - 1) * ARPP + lane / ASPR;
+      const int krow = min(iw * PA + i, NPA - 1) * ARPP + lane / ASPR;
       const int slot = (lane % ASPR) ^ (2 * ((krow & 3) | (((krow >> 3) & 1) << 2)));
       srcA[i] = A + (size_t)(kbase + krow) * a.lda + min(m0 + slot * 8, ((a.M + 7) & ~7) - 8);
     } else {
-      const int row = min(wave * PA + i, NPA - 1) * 8 + prow;
+      const int row = min(iw * PA + i, NPA - 1) * 8 + prow;
       srcA[i] = A + (size_t)min(m0 + row, a.M - 1) * a.lda + kbase + ((pslot ^ (row & 7)) << 3);
     }
   }
 #pragma unroll
   for (int i = 0; i < PW; ++i) {
     if constexpr (WKM) {
-      const int krow = min(wave * PW + i, NPW - 1) * WRPP + lane / WSPR;              // k-row of this lane inside the tile
+      const int krow = min(iw * PW + i, NPW - 1) * WRPP + lane / WSPR;              // k-row of this lane inside the tile
       const int slot = (lane % WSPR) ^ (2 * ((krow & 3) | (((krow >> 3) & 1) << 2)));    // logical 16-byte slot fetched into physical slot lane % WSPR
       srcW[i] = W + (size_t)(kbase + krow) * a.ldw + min(n0 + slot * 8, ((a.N + 7) & ~7) - 8);   // columns past N (chunk-aligned clamp) only feed dropped outputs
     } else {
-      const int row = min(wave * PW + i, NPW - 1) * 8 + prow;
+      const int row = min(iw * PW + i, NPW - 1) * 8 + prow;
       srcW[i] = W + (size_t)min(n0 + row, a.N - 1) * a.ldw + kbase + ((pslot ^ (row & 7)) << 3);
     }
   }
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;      // LDS byte address of the stage ring (low 32 bits of the generic pointer)
-  auto issue_tile = [&](int kt, int st) {
+  constexpr int WRING = ASYM ? NST * BM * 128 : 0;      // ASYM: [NST A stages][NST + 1 W stages]; else [NST (A | W) stages]
+  auto issue_a = [&](int kt, int sa) {
     const int ko = min(kt, nk - 1) * BK;                 // tiles past the end re-fetch the last one (never read)
-    const uint32_t base = lds0 + st * STAGE;
+    const uint32_t base = lds0 + sa * (ASYM ? BM * 128 : STAGE);
 #pragma unroll
-    for (int i = 0; i < PA; ++i) glds16(srcA[i] + (AKM ? (size_t)ko * a.lda : (size_t)ko), __builtin_amdgcn_readfirstlane(base + min(wave * PA + i, NPA - 1) * 1024));
-#pragma unroll
-    for (int i = 0; i < PW; ++i) glds16(srcW[i] + (WKM ? (size_t)ko * a.ldw : (size_t)ko), __builtin_amdgcn_readfirstlane(base + BM * 128 + min(wave * PW + i, NPW - 1) * 1024));
+    for (int i = 0; i < PA; ++i) glds16(srcA[i] + (AKM ? (size_t)ko * a.lda : (size_t)ko), __builtin_amdgcn_readfirstlane(base + min(iw * PA + i, NPA - 1) * 1024));
   };
+  auto issue_w = [&](int kt, int sw) {
+    const int ko = min(kt, nk - 1) * BK;
+    const uint32_t base = ASYM ? lds0 + WRING + sw * (BNT * 128) : lds0 + sw * STAGE + BM * 128;
+#pragma unroll
+    for (int i = 0; i < PW; ++i) glds16(srcW[i] + (WKM ? (size_t)ko * a.ldw : (size_t)ko), __builtin_amdgcn_readfirstlane(base + min(iw * PW + i, NPW - 1) * 1024));
+  };
+  auto issue_tile = [&](int kt, int st) { issue_a(kt, st); issue_w(kt, st); };
 
   f32x4 acc[NT][MT];
 #pragma unroll
@@ -839,25 +859,44 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
+  if (!PRD || producer) {
 #pragma unroll
-  for (int st = 0; st < NST - 1; ++st) issue_tile(st, st);
+    for (int st = 0; st < NST - 1; ++st) issue_tile(st, st);
+    if constexpr (ASYM) issue_w(NST - 1, NST - 1);
+  }
   GEMM_STAMP(1)
   const int fr = lane & 15, fq = lane >> 4;
-  int st = 0;                                            // stage of tile kt
+  int st = 0;                                            // stage of tile kt (ASYM: of its A tile)
+  [[maybe_unused]] int sw = 0;                           // ASYM: stage of tile kt's W tile (ring of NST + 1)
   for (int kt = 0; kt < nk; ++kt) {
-    wait_vmcnt<PIECES * (NST - 2)>();                    // this wave's pieces of tile kt have landed (younger tiles may fly)
+    if constexpr (ASYM) wait_vmcnt<PA * (NST - 2) + PW * (NST - 1)>();
+    else if (!PRD || producer) wait_vmcnt<PIECES * (NST - 2)>();      // this wave's pieces of tile kt have landed (younger tiles may fly)
     __builtin_amdgcn_s_barrier();                        // ... and everyone else's; also: all waves are done reading stage kt-1
     GEMM_STAMP(2 + kt)
     int stn = st + NST - 1; if (stn >= NST) stn -= NST;  // = (kt-1) % NST: the stage read in the previous step
-    const char* As = smem + st * STAGE;
-    const char* Ws = As + BM * 128;
+    if constexpr (PRD > 0) {
+      if (producer) {
+        issue_tile(kt + NST - 1, stn);
+        if (++st == NST) st = 0;
+        continue;
+      }
+    }
+    const char* As = smem + st * (ASYM ? BM * 128 : STAGE);
+    const char* Ws = ASYM ? smem + WRING + sw * (BNT * 128) : As + BM * 128;
+    [[maybe_unused]] int swn = sw + NST; if (swn >= NST + 1) swn -= NST + 1;      // ASYM: = (kt - 1) % (NST + 1): the W stage read in the previous step
+    auto refill = [&]() {
+      if constexpr (ASYM) { issue_a(kt + NST - 1, stn); issue_w(kt + NST, swn); }
+      else issue_tile(kt + NST - 1, stn);
+    };
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 fa[MT], fw[NT];
       // (r03) the refill of stage kt-1 is issued BEHIND the first half's fragment reads: an LDS-DMA piece costs ~100-185 issue cycles
       // (MI355X_MICROARCH.md), and in front of the reads the whole K-step sat behind PIECES of them before its first ds_read went out
-      if (ks == 1 && !IFIRST) issue_tile(kt + NST - 1, stn);
-      if (ks == 0 && IFIRST) issue_tile(kt + NST - 1, stn);
+      if constexpr (PRD == 0) {
+        if (ks == 1 && !IFIRST) refill();
+        if (ks == 0 && IFIRST) refill();
+      }
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         if constexpr (AKM) {
@@ -898,9 +937,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
         for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(fw[nt], fa[mt], acc[nt][mt]);
     }
     if (++st == NST) st = 0;
+    if constexpr (ASYM) { if (++sw == NST + 1) sw = 0; }
   }
   GEMM_STAMP(36)
   wait_vmcnt<0>();                                       // drain the clamped look-ahead tiles before the block retires
+  if constexpr (PRD > 0) { if (producer) return; }       // (a terminated wave leaves the barrier's count: the epilogue's barrier below completes once every producer has drained and left)
 
   VlaserGemmArgs ea = a;
   if (bz > 0) {
@@ -910,7 +951,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmP p) {
   }
   [[maybe_unused]] char* scr = nullptr;                // this wave's scratch for the row-contiguous stores: the stage ring, once every wave is out of the K loop
   if constexpr (EPI == VL_EPI_NONE || EPI == VL_EPI_BIAS || EPI == VL_EPI_BIAS_GELU || EPI == VL_EPI_BIAS_LS_RES || EPI == VL_EPI_RES) {
-    static_assert(NW * EpiScratch<MT, NT>::BYTES <= NST * STAGE, "epilogue scratch exceeds the stage ring");
+    static_assert(NW * EpiScratch<MT, NT>::BYTES <= NST * STAGE + (ASYM ? BNT * 128 : 0), "epilogue scratch exceeds the stage ring");
     __builtin_amdgcn_s_barrier();                        // (each wave drained its own LDS-DMA pieces above: nothing lands in the ring any more)
     scr = smem + wave * EpiScratch<MT, NT>::BYTES;
   }
@@ -1117,22 +1158,22 @@ static int launch_tn_stag(const VlaserGemmArgs* args, hipStream_t stream) {
   return 0;
 }
 
-template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false, bool IFIRST = GLDS_ISSUE_FIRST != 0>
+template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false, bool IFIRST = GLDS_ISSUE_FIRST != 0, int PRD = 0, bool ASYM = false>
 static int launch_glds(const VlaserGemmArgs* args, hipStream_t stream, int splits) {
   GemmP p;
   p.a = *args;
   p.tiles_m = (args->M + BM - 1) / BM;
   p.tiles_n = (args->N + BNT - 1) / BNT;
-  constexpr int lds = NST * (BM + BNT) * 128;
+  constexpr int lds = NST * (BM + BNT) * 128 + (ASYM ? BNT * 128 : 0);
   static_assert(lds <= 160 * 1024, "stage ring exceeds the 160 KiB LDS of a CU");
   if (args->sumsq_part) {
     VL_CHECK(EPI == VL_EPI_NONE && AKM && splits == 1, "sumsq_part: only the TN weight-gradient form (vlaser_gemm_tn_lds) sums its output's squares");
     const long long need = (long long)p.tiles_m * p.tiles_n * (args->batch > 1 ? args->batch : 1) * WM * WN;
     VL_CHECK(args->sumsq_cap >= need, "sumsq_part: %d slots given, this launch writes %lld (workgroups x waves)", args->sumsq_cap, need);
   }
-  if (int rc = set_max_lds_once(gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM, IFIRST>, lds)) return rc;
-  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM, IFIRST>), dim3(p.tiles_m * p.tiles_n, splits, args->batch > 1 ? args->batch : 1),
-                     dim3(WM * WN * 64), lds, stream, p);
+  if (int rc = set_max_lds_once(gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM, IFIRST, PRD, ASYM>, lds)) return rc;
+  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM, IFIRST, PRD, ASYM>), dim3(p.tiles_m * p.tiles_n, splits, args->batch > 1 ? args->batch : 1),
+                     dim3((WM * WN + PRD) * 64), lds, stream, p);
   VL_LAUNCH_CHECK();
   return 0;
 }
@@ -1208,26 +1249,34 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
     }
   }
   // LDS-DMA pipeline configurations: 1100 = 128x128 / 4 stages, 1200 = 128x256 / 3, 1300 = 256x256 / 2, 1500 = 64x128 / 4 (8 waves each), 1440 = 144x128 / 4 (6 waves)
+  if constexpr (!AKM) {
+    static const bool no_asym = getenv("VLASER_GEMM_NO_ASYM") != nullptr;      // diagnostics / same-box A/B: the r03-r04 two-stage rings instead of the asymmetric ones
+    if (no_asym) bm = bm == 1900 ? 1901 : bm == 1300 ? 1302 : bm;
+  }
   if constexpr (AKM) {
     switch (bm) {
       case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4, true, true>(args, stream, splits);
       case 1105: return launch_glds<EPI, 128, 128, 2, 4, 5, true, true>(args, stream, splits);
       case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3, true, true>(args, stream, splits);
       case 1300: return launch_glds<EPI, 256, 256, 2, 4, 2, true, true>(args, stream, splits);
+      case 1303: return launch_glds<EPI, 256, 256, 2, 4, 2, true, true, GLDS_ISSUE_FIRST != 0, 0, true>(args, stream, splits);      // r05 lab: + a third stage for the N-side operand
       // r04: two staggered wave groups over a ring of four 32-deep buffers (gemm_tn_stag_kernel)
       case 1340: if constexpr (EPI == VL_EPI_NONE) return launch_tn_stag<256, 256>(args, stream); break;
       case 1240: if constexpr (EPI == VL_EPI_NONE) return launch_tn_stag<128, 256>(args, stream); break;
       case 1140: if constexpr (EPI == VL_EPI_NONE) return launch_tn_stag<128, 128>(args, stream); break;
       default: break;
     }
-    vlaser_set_error("vlaser_gemm_tn_lds: force_cfg must be 0 or 1100 / 1105 / 1200 / 1300 / 1140 / 1240 / 1340 (got %d)", bm);
+    vlaser_set_error("vlaser_gemm_tn_lds: force_cfg must be 0 or 1100 / 1105 / 1200 / 1300 / 1303 / 1140 / 1240 / 1340 (got %d)", bm);
     return -1;
   }
   switch (bm) {
     case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM>(args, stream, splits);
     case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3, WKM>(args, stream, splits);
-    case 1300: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM>(args, stream, splits);
+    // r05: the two-stage rings carry a THIRD stage for the W operand alone (ASYM: weights two steps ahead, activations one; 256x256: 2 x 32 + 3 x 32 = 160 KB, 192x256: 144 KB):
+    // bit-identical, 3408 x 8192 x 3584 193.9 -> 168.6 us, the SFT forward's gate/up 42.7 -> 37.2 us (tools/micro/asym_ring_lab.py, profiles/r05t_asym_ring_lab.md)
+    case 1300: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM, false, false, 0, true>(args, stream, splits);
     case 1301: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM, false, true>(args, stream, splits);      // lab: the two-stage 256x256 ring with the refill requested first
+    case 1302: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM>(args, stream, splits);                   // lab: the r02-r04 two-stage ring
     case 1500: return launch_glds<EPI, 64, 128, 2, 4, 4, WKM>(args, stream, splits);
     case 1440: return launch_glds<EPI, 144, 128, 3, 2, 4, WKM>(args, stream, splits);
     // r03: deeper rings / smaller tiles for the latency-bound single-round shapes (a K-step of the 64x128 tile takes ~0.38 us with 3 tiles in flight:
@@ -1236,7 +1285,12 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
     case 1105: return launch_glds<EPI, 128, 128, 2, 4, 5, WKM>(args, stream, splits);
     case 1564: if constexpr (!WKM) return launch_glds<EPI, 64, 64, 2, 2, 8, false>(args, stream, splits); break;
     case 1532: return launch_glds<EPI, 32, 128, 1, 4, 7, WKM>(args, stream, splits);
-    case 1900: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, true>(args, stream, splits);      // r03: 3 tile rows for the SFT step's 560 rows (256-row tiles pad 27 %)
+    case 1900: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, false, 0, true>(args, stream, splits);      // r03: 3 tile rows for the SFT step's 560 rows (256-row tiles pad 27 %); r05: ASYM ring
+    case 1901: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, true>(args, stream, splits);      // lab: the r03-r04 two-stage ring, refill requested first
+    // r05 lab (tools/micro/producer_lab.py, profiles/r05s_producer_waves.md): the 128x128 ring with 4 producer waves (one per SIMD) issuing every LDS-DMA piece: bit-identical,
+    // 12-16 % SLOWER (piece issue is serial per wave: 4 waves x 12 pieces take longer than 8 x 6); the 128x256 / 192x256 tiles do not fit 12 waves' 168 registers.  Not used.
+    case 2100: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM, false, GLDS_ISSUE_FIRST != 0, 4>(args, stream, splits);
+    case 1903: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, true, 0, true>(args, stream, splits);      // lab: ASYM with the refill requested first (41.9 us against 37.2)
     default: break;
   }
   if constexpr (WKM) {
@@ -1475,8 +1529,8 @@ extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   VL_CHECK(a->K % BK == 0, "vlaser_gemm: K=%d must be a multiple of %d", a->K, BK);
   VL_CHECK(a->batch <= 1 || (epi == VL_EPI_NONE || epi == VL_EPI_F32 || epi == VL_EPI_BIAS), "vlaser_gemm: batched mode supports NONE / F32 / BIAS epilogues");
   VL_CHECK(!a->sumsq_part, "vlaser_gemm: sumsq_part is honoured by vlaser_gemm_tn_lds only");
-  VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1301 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 || a->force_bm == 1564 || a->force_bm == 1532 || a->force_bm == 1900,
-           "vlaser_gemm: force_bm must be 0/32/64/128 or an LDS-DMA configuration code 1100/1105/1200/1300/1301/1440/1500/1506/1532/1564/1900");
+  VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128 || a->force_bm == 2100 || a->force_bm == 1903 || a->force_bm == 1901 || a->force_bm == 1302 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1301 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 || a->force_bm == 1564 || a->force_bm == 1532 || a->force_bm == 1900,
+           "vlaser_gemm: force_bm must be 0/32/64/128 or an LDS-DMA configuration code 1100/1105/1200/1300/1301/1440/1500/1506/1532/1564/1900, 2100 (lab: producer waves)");
   VL_CHECK(a->lda % 8 == 0 && a->ldw % 8 == 0, "vlaser_gemm: lda/ldw must be multiples of 8 (16-byte rows)");
   VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm: operands must be 16-byte aligned");
   switch (epi) {
@@ -1516,9 +1570,9 @@ extern "C" int vlaser_gemm_nn(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   VL_CHECK(a->M > 0 && a->N > 0 && a->K > 0 && a->K % BK == 0, "vlaser_gemm_nn: bad shape M=%d N=%d K=%d (K must be a multiple of %d)", a->M, a->N, a->K, BK);
   VL_CHECK(a->N % 8 == 0 && a->lda % 8 == 0 && a->ldw % 8 == 0 && a->ldw >= a->N, "vlaser_gemm_nn: N, lda, ldw must be multiples of 8 and ldw >= N");
   VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm_nn: operands must be 16-byte aligned");
-  VL_CHECK(a->force_bm == 0 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1301 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 ||
+  VL_CHECK(a->force_bm == 0 || a->force_bm == 2100 || a->force_bm == 1903 || a->force_bm == 1901 || a->force_bm == 1302 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1301 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 ||
                a->force_bm == 1532 || a->force_bm == 1900,
-           "vlaser_gemm_nn: force_bm must be 0 or an LDS-DMA configuration code 1100/1105/1200/1300/1440/1500/1506/1532/1900");
+           "vlaser_gemm_nn: force_bm must be 0 or an LDS-DMA configuration code 1100/1105/1200/1300/1440/1500/1506/1532/1900, 2100 (lab: producer waves)");
   VL_CHECK(a->batch <= 1 || epi == VL_EPI_NONE || epi == VL_EPI_F32, "vlaser_gemm_nn: batched mode supports the NONE / F32 epilogues");
   VL_CHECK(!a->sumsq_part, "vlaser_gemm_nn: sumsq_part is honoured by vlaser_gemm_tn_lds only");
   switch (epi) {

@@ -631,7 +631,7 @@ def gemm_tile_config(M, N, splits=1, batch=1, nn=False):
     if M <= 32 and not nn:
         return (32, 32, 128, 500.0)
     for c in _GEMM_CFGS:
-        if c[0] == 1300 and blocks(192, 256) <= _CU_BUDGET and -(-M // 192) * 192 < -(-M // _CU_BUDGET) * 256:
+        if c[0] == 1300 and blocks(192, 256) <= _CU_BUDGET and -(-M // 192) * 192 < -(-M // 256) * 256:
             return (1900, 192, 256, 1208.0)
         if blocks(c[1], c[2]) <= _CU_BUDGET and not (nn and c[0] == 1564):
             return c
