@@ -833,6 +833,31 @@ def test_gemm_glds_ragged_and_splitk(ops, bm):
     close(part.sum(0), x.float() @ w.float().t(), rtol=2e-3, atol=2e-3, name=f'split-K cfg{bm}')
 
 
+@pytest.mark.parametrize('asym,two_stage', [(1900, 1901), (1300, 1302), (1903, 1901)])
+def test_gemm_asymmetric_ring_is_bit_identical_to_the_two_stage_ring(ops, asym, two_stage):
+    """r05: the 192x256 / 256x256 tiles carry a third stage for the W operand alone (weights two K-steps ahead, activations one).  Same arithmetic in the same order as the
+    r03-r04 two-stage rings: bit-identical outputs -- NT and NN forms, K of 1 .. 24 tiles (shorter than, equal to and longer than both rings), ragged M / N, split-K slabs."""
+    from vlaser_amd import _lib as L
+    for (M, N, K) in [(560, 1792, 1536), (200, 520, 64), (257, 300, 128), (385, 1024, 192), (70, 777, 256), (3408 // 8, 2048, 3584)]:
+        x, w = rnd(M, K), rnd(N, K, std=0.05, seed=M)
+        o1, o2 = torch.zeros(M, N, dtype=BF, device='cuda'), torch.zeros(M, N, dtype=BF, device='cuda')
+        ops.gemm(L.EPI_NONE, x, w, out=o1, force_bm=asym)
+        ops.gemm(L.EPI_NONE, x, w, out=o2, force_bm=two_stage)
+        assert torch.equal(o1, o2), (M, N, K)
+        close(o1, x.float() @ w.float().t(), rtol=1e-2, atol=1e-2, name=f'nt {M}x{N}x{K} cfg{asym}')
+        if N % 8 == 0:
+            wk = w.t().contiguous()
+            ops.gemm_nn(L.EPI_NONE, x, wk, out=o1, force_bm=asym)
+            ops.gemm_nn(L.EPI_NONE, x, wk, out=o2, force_bm=two_stage)
+            assert torch.equal(o1, o2), ('nn', M, N, K)
+    M, N, K, S = 385, 1024, 2048, 4
+    x, w = rnd(M, K), rnd(N, K, std=0.05, seed=9)
+    p1, p2 = torch.zeros(S, M, N, dtype=torch.float32, device='cuda'), torch.zeros(S, M, N, dtype=torch.float32, device='cuda')
+    ops.gemm(L.EPI_PARTIAL, x, w, out_f32=p1, k_splits=S, force_bm=asym)
+    ops.gemm(L.EPI_PARTIAL, x, w, out_f32=p2, k_splits=S, force_bm=two_stage)
+    assert torch.equal(p1, p2)
+
+
 def test_gemm_lds_attribute_is_set_per_kernel_in_any_order():
     """The dynamic-LDS limit is raised once per (kernel instantiation, device).  In a fresh process, run the LDS-DMA configurations
     from the largest stage ring to the smallest: every one must launch (a table shared by all instantiations let the first, largest

@@ -773,9 +773,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // kt + 1 -- and its step lasts as long as that round trip (192x256: 1.6 us against 0.9 us of fragment reads + MFMAs, profiles/r05r_mfma_shape_lab.md); a third full stage does
 // not fit 160 KB at these tile sizes, a third stage of the HBM-cold operand alone does (192x256: 2 x 24 + 3 x 32 = 144 KB): the weights get two steps of lead, the activations
 // (L2-resident) one.  Issue order per step: A(kt + NST - 1), then W(kt + NST); everything that must have landed at step kt is older than everything that may still fly.
-template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false, bool IFIRST = GLDS_ISSUE_FIRST != 0, int PRD = 0, bool ASYM = false>
+// SPREAD (r05 lab): the refill's pieces are not issued as one burst (behind the barrier or behind the first half's reads -- both waves of a SIMD are in that burst together and
+// the MFMA pipe idles for its 6-7 x ~100 issue cycles) but ONE AT A TIME between groups of MFMAs, evenly over the K-step's 2 x MT x NT of them.
+template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false, bool IFIRST = GLDS_ISSUE_FIRST != 0, int PRD = 0, bool ASYM = false, bool SPREAD = false>
 __global__ __launch_bounds__((WM * WN + PRD) * 64) void gemm_glds_kernel(GemmP p) {
-  static_assert(!(ASYM && PRD), "one lab at a time");
+  static_assert(!(ASYM && PRD) && !(SPREAD && PRD), "one lab at a time");
   constexpr int NW = WM * WN;
   constexpr int NWI = PRD ? PRD : NW;                    // waves that issue LDS-DMA pieces
   constexpr int WTM = BM / WM, WTN = BNT / WN;
@@ -852,6 +854,18 @@ __global__ __launch_bounds__((WM * WN + PRD) * 64) void gemm_glds_kernel(GemmP p
     for (int i = 0; i < PW; ++i) glds16(srcW[i] + (WKM ? (size_t)ko * a.ldw : (size_t)ko), __builtin_amdgcn_readfirstlane(base + min(iw * PW + i, NPW - 1) * 1024));
   };
   auto issue_tile = [&](int kt, int st) { issue_a(kt, st); issue_w(kt, st); };
+  // piece j of a refill (A pieces first, then W: the order the vmcnt arithmetic assumes); kta / ktw and sa / sw as issue_a / issue_w take them
+  auto issue_piece = [&](int j, int kta, int sa, int ktw, int sw2) {
+    if (j < PA) {
+      const int ko = min(kta, nk - 1) * BK;
+      const uint32_t base = lds0 + sa * (ASYM ? BM * 128 : STAGE);
+      glds16(srcA[j] + (AKM ? (size_t)ko * a.lda : (size_t)ko), __builtin_amdgcn_readfirstlane(base + min(iw * PA + j, NPA - 1) * 1024));
+    } else {
+      const int i = j - PA, ko = min(ktw, nk - 1) * BK;
+      const uint32_t base = ASYM ? lds0 + WRING + sw2 * (BNT * 128) : lds0 + sw2 * STAGE + BM * 128;
+      glds16(srcW[i] + (WKM ? (size_t)ko * a.ldw : (size_t)ko), __builtin_amdgcn_readfirstlane(base + min(iw * PW + i, NPW - 1) * 1024));
+    }
+  };
 
   f32x4 acc[NT][MT];
 #pragma unroll
@@ -893,7 +907,7 @@ __global__ __launch_bounds__((WM * WN + PRD) * 64) void gemm_glds_kernel(GemmP p
       bf16x8 fa[MT], fw[NT];
       // (r03) the refill of stage kt-1 is issued BEHIND the first half's fragment reads: an LDS-DMA piece costs ~100-185 issue cycles
       // (MI355X_MICROARCH.md), and in front of the reads the whole K-step sat behind PIECES of them before its first ds_read went out
-      if constexpr (PRD == 0) {
+      if constexpr (PRD == 0 && !SPREAD) {
         if (ks == 1 && !IFIRST) refill();
         if (ks == 0 && IFIRST) refill();
       }
@@ -934,7 +948,18 @@ __global__ __launch_bounds__((WM * WN + PRD) * 64) void gemm_glds_kernel(GemmP p
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(fw[nt], fa[mt], acc[nt][mt]);
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[nt][mt] = mfma16(fw[nt], fa[mt], acc[nt][mt]);
+          if constexpr (SPREAD) {
+            constexpr int GAP = (2 * MT * NT) / (PIECES + 1) > 0 ? (2 * MT * NT) / (PIECES + 1) : 1;
+            const int g = ks * (MT * NT) + nt * MT + mt + 1;          // MFMAs of this K-step issued so far (a compile-time value after unrolling)
+            if (g % GAP == 0 && g / GAP - 1 < PIECES) {
+              __builtin_amdgcn_sched_barrier(0);
+              issue_piece(g / GAP - 1, kt + NST - 1, stn, ASYM ? kt + NST : kt + NST - 1, ASYM ? swn : stn);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
     }
     if (++st == NST) st = 0;
     if constexpr (ASYM) { if (++sw == NST + 1) sw = 0; }
@@ -1158,7 +1183,7 @@ static int launch_tn_stag(const VlaserGemmArgs* args, hipStream_t stream) {
   return 0;
 }
 
-template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false, bool IFIRST = GLDS_ISSUE_FIRST != 0, int PRD = 0, bool ASYM = false>
+template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false, bool IFIRST = GLDS_ISSUE_FIRST != 0, int PRD = 0, bool ASYM = false, bool SPREAD = false>
 static int launch_glds(const VlaserGemmArgs* args, hipStream_t stream, int splits) {
   GemmP p;
   p.a = *args;
@@ -1171,8 +1196,8 @@ static int launch_glds(const VlaserGemmArgs* args, hipStream_t stream, int split
     const long long need = (long long)p.tiles_m * p.tiles_n * (args->batch > 1 ? args->batch : 1) * WM * WN;
     VL_CHECK(args->sumsq_cap >= need, "sumsq_part: %d slots given, this launch writes %lld (workgroups x waves)", args->sumsq_cap, need);
   }
-  if (int rc = set_max_lds_once(gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM, IFIRST, PRD, ASYM>, lds)) return rc;
-  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM, IFIRST, PRD, ASYM>), dim3(p.tiles_m * p.tiles_n, splits, args->batch > 1 ? args->batch : 1),
+  if (int rc = set_max_lds_once(gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM, IFIRST, PRD, ASYM, SPREAD>, lds)) return rc;
+  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM, IFIRST, PRD, ASYM, SPREAD>), dim3(p.tiles_m * p.tiles_n, splits, args->batch > 1 ? args->batch : 1),
                      dim3((WM * WN + PRD) * 64), lds, stream, p);
   VL_LAUNCH_CHECK();
   return 0;
@@ -1291,6 +1316,12 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
     // 12-16 % SLOWER (piece issue is serial per wave: 4 waves x 12 pieces take longer than 8 x 6); the 128x256 / 192x256 tiles do not fit 12 waves' 168 registers.  Not used.
     case 2100: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM, false, GLDS_ISSUE_FIRST != 0, 4>(args, stream, splits);
     case 1903: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, true, 0, true>(args, stream, splits);      // lab: ASYM with the refill requested first (41.9 us against 37.2)
+    // r05 lab: the refill's pieces spread between the K-step's MFMAs (SPREAD)
+    case 1905: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, false, 0, true, true>(args, stream, splits);
+    case 1305: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM, false, false, 0, true, true>(args, stream, splits);
+    case 1205: return launch_glds<EPI, 128, 256, 2, 4, 3, WKM, false, false, 0, false, true>(args, stream, splits);
+    case 1106: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM, false, false, 0, false, true>(args, stream, splits);
+    case 1445: return launch_glds<EPI, 144, 128, 3, 2, 4, WKM, false, false, 0, false, true>(args, stream, splits);
     default: break;
   }
   if constexpr (WKM) {
@@ -1529,7 +1560,7 @@ extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   VL_CHECK(a->K % BK == 0, "vlaser_gemm: K=%d must be a multiple of %d", a->K, BK);
   VL_CHECK(a->batch <= 1 || (epi == VL_EPI_NONE || epi == VL_EPI_F32 || epi == VL_EPI_BIAS), "vlaser_gemm: batched mode supports NONE / F32 / BIAS epilogues");
   VL_CHECK(!a->sumsq_part, "vlaser_gemm: sumsq_part is honoured by vlaser_gemm_tn_lds only");
-  VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128 || a->force_bm == 2100 || a->force_bm == 1903 || a->force_bm == 1901 || a->force_bm == 1302 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1301 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 || a->force_bm == 1564 || a->force_bm == 1532 || a->force_bm == 1900,
+  VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128 || a->force_bm == 2100 || a->force_bm == 1905 || a->force_bm == 1305 || a->force_bm == 1205 || a->force_bm == 1106 || a->force_bm == 1445 || a->force_bm == 1903 || a->force_bm == 1901 || a->force_bm == 1302 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1301 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 || a->force_bm == 1564 || a->force_bm == 1532 || a->force_bm == 1900,
            "vlaser_gemm: force_bm must be 0/32/64/128 or an LDS-DMA configuration code 1100/1105/1200/1300/1301/1440/1500/1506/1532/1564/1900, 2100 (lab: producer waves)");
   VL_CHECK(a->lda % 8 == 0 && a->ldw % 8 == 0, "vlaser_gemm: lda/ldw must be multiples of 8 (16-byte rows)");
   VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm: operands must be 16-byte aligned");
@@ -1570,7 +1601,7 @@ extern "C" int vlaser_gemm_nn(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   VL_CHECK(a->M > 0 && a->N > 0 && a->K > 0 && a->K % BK == 0, "vlaser_gemm_nn: bad shape M=%d N=%d K=%d (K must be a multiple of %d)", a->M, a->N, a->K, BK);
   VL_CHECK(a->N % 8 == 0 && a->lda % 8 == 0 && a->ldw % 8 == 0 && a->ldw >= a->N, "vlaser_gemm_nn: N, lda, ldw must be multiples of 8 and ldw >= N");
   VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm_nn: operands must be 16-byte aligned");
-  VL_CHECK(a->force_bm == 0 || a->force_bm == 2100 || a->force_bm == 1903 || a->force_bm == 1901 || a->force_bm == 1302 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1301 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 ||
+  VL_CHECK(a->force_bm == 0 || a->force_bm == 2100 || a->force_bm == 1905 || a->force_bm == 1305 || a->force_bm == 1205 || a->force_bm == 1106 || a->force_bm == 1445 || a->force_bm == 1903 || a->force_bm == 1901 || a->force_bm == 1302 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1301 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 ||
                a->force_bm == 1532 || a->force_bm == 1900,
            "vlaser_gemm_nn: force_bm must be 0 or an LDS-DMA configuration code 1100/1105/1200/1300/1440/1500/1506/1532/1900, 2100 (lab: producer waves)");
   VL_CHECK(a->batch <= 1 || epi == VL_EPI_NONE || epi == VL_EPI_F32, "vlaser_gemm_nn: batched mode supports the NONE / F32 epilogues");
