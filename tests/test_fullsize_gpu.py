@@ -254,7 +254,7 @@ def test_full_depth_qa_logits_and_greedy_ids_vs_fp32_oracle(full):
     parity('full-depth 2B QA last-position logits vs fp32 oracle relative L2', l2, 5e-2)
     parity('full-depth 2B QA last-position logits vs fp32 oracle cosine', cos0, 0.999, lower=True)
     top = rlg[0, 0].topk(8)
-    parity('full-depth 2B QA top-8 logit VALUES vs fp32 oracle, elementwise (rtol 2e-2, atol 5e-2)', elementwise(lg[0, 0][top.indices], top.values, 2e-2, 5e-2), 0.6)
+    parity('full-depth 2B QA top-8 logit VALUES vs fp32 oracle, elementwise (rtol 2e-2, atol 5e-2)', elementwise(lg[0, 0][top.indices], top.values, 2e-2, 5e-2), 0.52)
     for t in range(4):
         t2 = rlg[0, t].topk(2).values
         if (t2[0] - t2[1]).item() > 4 * e0 * rlg[0, t].abs().max().item():          # clear margin: the ids must agree
@@ -316,7 +316,7 @@ def test_full_depth_sft_loss_and_grads_vs_fp32_oracle():
     for k, rel, cos, nrel in worst:
         parity(f'full-depth SFT gradient {k}: relative Frobenius error', rel, GRAD_REL.get(k, GRAD_REL['default']))
         parity(f'full-depth SFT gradient {k}: cosine', cos, GRAD_COS.get(k, GRAD_COS['default']), lower=True)
-        parity(f'full-depth SFT gradient {k}: relative norm error', nrel, 5e-3)
+        parity(f'full-depth SFT gradient {k}: relative norm error', nrel, 4.6e-3)        # worst measured 2.3e-3 (layers.14 q_proj)
 
 
 def test_full_depth_8b_one_tile_logits_vs_fp32_oracle():

@@ -833,10 +833,11 @@ def test_gemm_glds_ragged_and_splitk(ops, bm):
     close(part.sum(0), x.float() @ w.float().t(), rtol=2e-3, atol=2e-3, name=f'split-K cfg{bm}')
 
 
-@pytest.mark.parametrize('asym,two_stage', [(1900, 1901), (1300, 1302), (1903, 1901)])
+@pytest.mark.parametrize('asym,two_stage', [(1900, 1901), (1300, 1302), (1903, 1901), (1100, 1101), (1200, 1201), (1440, 1441), (1500, 1501), (1904, 1901), (1304, 1302)])
 def test_gemm_asymmetric_ring_is_bit_identical_to_the_two_stage_ring(ops, asym, two_stage):
-    """r05: the 192x256 / 256x256 tiles carry a third stage for the W operand alone (weights two K-steps ahead, activations one).  Same arithmetic in the same order as the
-    r03-r04 two-stage rings: bit-identical outputs -- NT and NN forms, K of 1 .. 24 tiles (shorter than, equal to and longer than both rings), ragged M / N, split-K slabs."""
+    """r05: the 192x256 / 256x256 tiles carry a third stage for the W operand alone (weights two K-steps ahead, activations one), and every ring issues its refill one piece
+    at a time between the K-step's MFMAs instead of as one burst (x01 / 1304 / 1904 = the burst forms).  Same arithmetic in the same order as the
+    r03-r04 rings: bit-identical outputs -- NT and NN forms, K of 1 .. 24 tiles (shorter than, equal to and longer than both rings), ragged M / N, split-K slabs."""
     from vlaser_amd import _lib as L
     for (M, N, K) in [(560, 1792, 1536), (200, 520, 64), (257, 300, 128), (385, 1024, 192), (70, 777, 256), (3408 // 8, 2048, 3584)]:
         x, w = rnd(M, K), rnd(N, K, std=0.05, seed=M)

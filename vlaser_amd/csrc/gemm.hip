@@ -1278,50 +1278,57 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
     static const bool no_asym = getenv("VLASER_GEMM_NO_ASYM") != nullptr;      // diagnostics / same-box A/B: the r03-r04 two-stage rings instead of the asymmetric ones
     if (no_asym) bm = bm == 1900 ? 1901 : bm == 1300 ? 1302 : bm;
   }
+  if constexpr (!AKM) {
+    static const bool no_spread = getenv("VLASER_GEMM_NO_SPREAD") != nullptr;  // diagnostics / same-box A/B: the refill as one burst per K-step (r02-r04)
+    if (no_spread) bm = bm == 1100 ? 1101 : bm == 1200 ? 1201 : bm == 1300 ? 1304 : bm == 1440 ? 1441 : bm == 1500 ? 1501 : bm == 1900 ? 1904 : bm;
+  }
   if constexpr (AKM) {
     switch (bm) {
+      // (r05: neither the asymmetric ring nor the spread refill helps the TN form -- both operands are activations / gradients out of L2, and its 256x256 tile lost 3-6 % with
+      // the pieces between the MFMAs: profiles/r05z_spread_lab.md -- so it keeps the r04 rings)
       case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4, true, true>(args, stream, splits);
       case 1105: return launch_glds<EPI, 128, 128, 2, 4, 5, true, true>(args, stream, splits);
       case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3, true, true>(args, stream, splits);
       case 1300: return launch_glds<EPI, 256, 256, 2, 4, 2, true, true>(args, stream, splits);
-      case 1303: return launch_glds<EPI, 256, 256, 2, 4, 2, true, true, GLDS_ISSUE_FIRST != 0, 0, true>(args, stream, splits);      // r05 lab: + a third stage for the N-side operand
       // r04: two staggered wave groups over a ring of four 32-deep buffers (gemm_tn_stag_kernel)
       case 1340: if constexpr (EPI == VL_EPI_NONE) return launch_tn_stag<256, 256>(args, stream); break;
       case 1240: if constexpr (EPI == VL_EPI_NONE) return launch_tn_stag<128, 256>(args, stream); break;
       case 1140: if constexpr (EPI == VL_EPI_NONE) return launch_tn_stag<128, 128>(args, stream); break;
       default: break;
     }
-    vlaser_set_error("vlaser_gemm_tn_lds: force_cfg must be 0 or 1100 / 1105 / 1200 / 1300 / 1303 / 1140 / 1240 / 1340 (got %d)", bm);
+    vlaser_set_error("vlaser_gemm_tn_lds: force_cfg must be 0 or 1100 / 1105 / 1200 / 1300 / 1140 / 1240 / 1340 (got %d)", bm);
     return -1;
   }
   switch (bm) {
-    case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM>(args, stream, splits);
-    case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3, WKM>(args, stream, splits);
+    // r05: the refill's pieces go out one at a time between the K-step's MFMAs (SPREAD: bit-identical, -1 ... -9 % per launch, tools/micro/spread_lab.py); 1101 / 1201 / 1304 / 1441 /
+    // 1501 / 1904 = the burst forms of r02-r04 (lab, VLASER_GEMM_NO_SPREAD=1)
+    case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM, false, false, 0, false, true>(args, stream, splits);
+    case 1101: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM>(args, stream, splits);
+    case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3, WKM, false, false, 0, false, true>(args, stream, splits);
+    case 1201: return launch_glds<EPI, 128, 256, 2, 4, 3, WKM>(args, stream, splits);
     // r05: the two-stage rings carry a THIRD stage for the W operand alone (ASYM: weights two steps ahead, activations one; 256x256: 2 x 32 + 3 x 32 = 160 KB, 192x256: 144 KB):
     // bit-identical, 3408 x 8192 x 3584 193.9 -> 168.6 us, the SFT forward's gate/up 42.7 -> 37.2 us (tools/micro/asym_ring_lab.py, profiles/r05t_asym_ring_lab.md)
-    case 1300: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM, false, false, 0, true>(args, stream, splits);
+    case 1300: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM, false, false, 0, true, true>(args, stream, splits);
+    case 1304: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM, false, false, 0, true>(args, stream, splits);      // lab: asymmetric ring, refill as one burst
     case 1301: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM, false, true>(args, stream, splits);      // lab: the two-stage 256x256 ring with the refill requested first
     case 1302: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM>(args, stream, splits);                   // lab: the r02-r04 two-stage ring
-    case 1500: return launch_glds<EPI, 64, 128, 2, 4, 4, WKM>(args, stream, splits);
-    case 1440: return launch_glds<EPI, 144, 128, 3, 2, 4, WKM>(args, stream, splits);
+    case 1500: return launch_glds<EPI, 64, 128, 2, 4, 4, WKM, false, false, 0, false, true>(args, stream, splits);
+    case 1501: return launch_glds<EPI, 64, 128, 2, 4, 4, WKM>(args, stream, splits);
+    case 1440: return launch_glds<EPI, 144, 128, 3, 2, 4, WKM, false, false, 0, false, true>(args, stream, splits);
+    case 1441: return launch_glds<EPI, 144, 128, 3, 2, 4, WKM>(args, stream, splits);
     // r03: deeper rings / smaller tiles for the latency-bound single-round shapes (a K-step of the 64x128 tile takes ~0.38 us with 3 tiles in flight:
     // the LDS-DMA round trip under load is ~1.1 us, so the bytes in flight per CU, not the MFMA pipe, set the rate)
     case 1506: return launch_glds<EPI, 64, 128, 2, 4, 6, WKM>(args, stream, splits);
     case 1105: return launch_glds<EPI, 128, 128, 2, 4, 5, WKM>(args, stream, splits);
-    case 1564: if constexpr (!WKM) return launch_glds<EPI, 64, 64, 2, 2, 8, false>(args, stream, splits); break;
+    case 1564: if constexpr (!WKM) return launch_glds<EPI, 64, 64, 2, 2, 8, false>(args, stream, splits); break;      // (burst: the 4-wave 64x64 tile lost 3.5 % with the spread refill)
     case 1532: return launch_glds<EPI, 32, 128, 1, 4, 7, WKM>(args, stream, splits);
-    case 1900: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, false, 0, true>(args, stream, splits);      // r03: 3 tile rows for the SFT step's 560 rows (256-row tiles pad 27 %); r05: ASYM ring
+    case 1900: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, false, 0, true, true>(args, stream, splits);      // r03: 3 tile rows for the SFT step's 560 rows (256-row tiles pad 27 %); r05: ASYM ring
     case 1901: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, true>(args, stream, splits);      // lab: the r03-r04 two-stage ring, refill requested first
     // r05 lab (tools/micro/producer_lab.py, profiles/r05s_producer_waves.md): the 128x128 ring with 4 producer waves (one per SIMD) issuing every LDS-DMA piece: bit-identical,
     // 12-16 % SLOWER (piece issue is serial per wave: 4 waves x 12 pieces take longer than 8 x 6); the 128x256 / 192x256 tiles do not fit 12 waves' 168 registers.  Not used.
     case 2100: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM, false, GLDS_ISSUE_FIRST != 0, 4>(args, stream, splits);
     case 1903: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, true, 0, true>(args, stream, splits);      // lab: ASYM with the refill requested first (41.9 us against 37.2)
-    // r05 lab: the refill's pieces spread between the K-step's MFMAs (SPREAD)
-    case 1905: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, false, 0, true, true>(args, stream, splits);
-    case 1305: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM, false, false, 0, true, true>(args, stream, splits);
-    case 1205: return launch_glds<EPI, 128, 256, 2, 4, 3, WKM, false, false, 0, false, true>(args, stream, splits);
-    case 1106: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM, false, false, 0, false, true>(args, stream, splits);
-    case 1445: return launch_glds<EPI, 144, 128, 3, 2, 4, WKM, false, false, 0, false, true>(args, stream, splits);
+    case 1904: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, false, 0, true>(args, stream, splits);      // lab: asymmetric ring, refill as one burst
     default: break;
   }
   if constexpr (WKM) {
@@ -1560,7 +1567,7 @@ extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   VL_CHECK(a->K % BK == 0, "vlaser_gemm: K=%d must be a multiple of %d", a->K, BK);
   VL_CHECK(a->batch <= 1 || (epi == VL_EPI_NONE || epi == VL_EPI_F32 || epi == VL_EPI_BIAS), "vlaser_gemm: batched mode supports NONE / F32 / BIAS epilogues");
   VL_CHECK(!a->sumsq_part, "vlaser_gemm: sumsq_part is honoured by vlaser_gemm_tn_lds only");
-  VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128 || a->force_bm == 2100 || a->force_bm == 1905 || a->force_bm == 1305 || a->force_bm == 1205 || a->force_bm == 1106 || a->force_bm == 1445 || a->force_bm == 1903 || a->force_bm == 1901 || a->force_bm == 1302 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1301 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 || a->force_bm == 1564 || a->force_bm == 1532 || a->force_bm == 1900,
+  VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128 || a->force_bm == 2100 || a->force_bm == 1101 || a->force_bm == 1201 || a->force_bm == 1304 || a->force_bm == 1441 || a->force_bm == 1501 || a->force_bm == 1904 || a->force_bm == 1903 || a->force_bm == 1901 || a->force_bm == 1302 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1301 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 || a->force_bm == 1564 || a->force_bm == 1532 || a->force_bm == 1900,
            "vlaser_gemm: force_bm must be 0/32/64/128 or an LDS-DMA configuration code 1100/1105/1200/1300/1301/1440/1500/1506/1532/1564/1900, 2100 (lab: producer waves)");
   VL_CHECK(a->lda % 8 == 0 && a->ldw % 8 == 0, "vlaser_gemm: lda/ldw must be multiples of 8 (16-byte rows)");
   VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm: operands must be 16-byte aligned");
@@ -1601,7 +1608,7 @@ extern "C" int vlaser_gemm_nn(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   VL_CHECK(a->M > 0 && a->N > 0 && a->K > 0 && a->K % BK == 0, "vlaser_gemm_nn: bad shape M=%d N=%d K=%d (K must be a multiple of %d)", a->M, a->N, a->K, BK);
   VL_CHECK(a->N % 8 == 0 && a->lda % 8 == 0 && a->ldw % 8 == 0 && a->ldw >= a->N, "vlaser_gemm_nn: N, lda, ldw must be multiples of 8 and ldw >= N");
   VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm_nn: operands must be 16-byte aligned");
-  VL_CHECK(a->force_bm == 0 || a->force_bm == 2100 || a->force_bm == 1905 || a->force_bm == 1305 || a->force_bm == 1205 || a->force_bm == 1106 || a->force_bm == 1445 || a->force_bm == 1903 || a->force_bm == 1901 || a->force_bm == 1302 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1301 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 ||
+  VL_CHECK(a->force_bm == 0 || a->force_bm == 2100 || a->force_bm == 1101 || a->force_bm == 1201 || a->force_bm == 1304 || a->force_bm == 1441 || a->force_bm == 1501 || a->force_bm == 1904 || a->force_bm == 1903 || a->force_bm == 1901 || a->force_bm == 1302 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1301 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 ||
                a->force_bm == 1532 || a->force_bm == 1900,
            "vlaser_gemm_nn: force_bm must be 0 or an LDS-DMA configuration code 1100/1105/1200/1300/1440/1500/1506/1532/1900, 2100 (lab: producer waves)");
   VL_CHECK(a->batch <= 1 || epi == VL_EPI_NONE || epi == VL_EPI_F32, "vlaser_gemm_nn: batched mode supports the NONE / F32 epilogues");
