@@ -305,11 +305,11 @@ def test_golden_manifest_matches_directory():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """The bench line committed with the round (profiles/r04w_bench_line.json, produced by `python bench.py` on the GPU box) carries what the contract asks of it:
+    """The bench line committed with the round (profiles/r05*_bench_line.json, produced by `python bench.py` on the GPU box) carries what the contract asks of it:
     the headline metric of BASELINE.json with `roofline` (measured traffic) and `cpu_baseline`, the SFT side line with its own CPU baseline, a consistent value."""
     import glob
     import json
-    lines = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r04*_bench_line.json')))
+    lines = sorted(p for p in glob.glob(os.path.join(ROOT, 'profiles', 'r05*_bench_line.json')) if 'chunk' not in os.path.basename(p) and 'sft' not in os.path.basename(p))
     assert lines
     d = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
@@ -324,3 +324,23 @@ def test_committed_bench_line_keeps_the_contract():
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
     s = d['sft']
     assert s['metric'] == 'sft_tokens_per_sec' and s['fwd_bwd_ms'] < s['ms_per_step'] and 'cpu_baseline' in s
+    # r05: the headline is the reference's own eight-tensor call, the phases are also timed behind their real predecessors, the forced-DP step is on the line
+    assert d['reference_signature']['is_headline'] is True and abs(d['reference_signature']['ms_per_chunk'] - d['ms_per_step']) < 1e-6
+    ic = d['phases']['in_chain']
+    assert abs(ic['sum_ms'] - d['phases']['chunk_graph_ms']) < 0.1 and s['forced_dp_world1_ms']['ms_per_step'] > s['ms_per_step']
+    assert 'NCCL_MAX_NCHANNELS' in s['exchange']
+
+
+def test_cu_budget_moves_the_tile_choice_on_both_sides():
+    """vlaser_set_cu_budget (ABI 6): the C heuristics and their Python mirror count single-round grids against the same number; out-of-range values only read it."""
+    from vlaser_amd import ops, _lib
+    assert ops.set_cu_budget(256) == 256
+    try:
+        full = ops.gemm_tile_config(560, 17920)              # 3 x 70 = 210 tiles of 192x256: one round on 256 CUs
+        assert full[0] == 1900
+        assert ops.set_cu_budget(200) == 256 and ops._CU_BUDGET == 200
+        assert ops.gemm_tile_config(560, 17920)[0] != 1900   # 210 > 200: no longer a single round
+        assert _lib.lib().vlaser_set_cu_budget(7) == 200 and _lib.lib().vlaser_set_cu_budget(1000) == 200      # refused, unchanged
+    finally:
+        ops.set_cu_budget(256)
+    assert ops._CU_BUDGET == 256 and ops.gemm_tile_config(560, 17920) == full
