@@ -1247,7 +1247,10 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
       // r04: grids of more than one round take the staggered two-group kernel (gate/up 46.0 -> 43.8 us; single-round shapes tie: tools/micro/gemm_epilogue_lab.py)
       if (blocks(128, 128) <= cus) bm = 1100;
       else if (blocks(128, 256) <= cus) bm = 1200;
-      else bm = (EPI == VL_EPI_NONE && nb == 1 && blocks(256, 256) > cus) ? 1340 : 1300;
+      else {
+        static const bool no_stag = getenv("VLASER_TN_NO_STAG") != nullptr;      // diagnostics / same-box A/B: the plain two-stage 256x256 ring for multi-round grids too
+        bm = (EPI == VL_EPI_NONE && nb == 1 && blocks(256, 256) > cus && !no_stag) ? 1340 : 1300;
+      }
     } else if (args->M <= 32 && !WKM) {
       bm = 32;
     } else if (!WKM && blocks(64, 64) <= cus) {      // (the NN form's transposing reads need >= 16 slots per staged k-row: BNT >= 128)
