@@ -76,9 +76,11 @@ typedef struct {
 } VlaserGemmArgs;
 
 int vlaser_gemm(int epi, const VlaserGemmArgs* args, vl_stream_t stream);
-/* (ABI 6) CUs the GEMM tile heuristics may count on (64..256, default 256; returns the previous value): a ZeRO-1 rank whose RCCL reduce-scatter runs beside the
- * backward (zero_stage1_config.json: overlap_comm) sets 256 - the CUs of RCCL's channel workgroups, so that its single-round grids stay single-round. */
+/* (ABI 6) CUs the GEMM tile heuristics may count on (64..256, default 256; set returns the previous value, out-of-range values are refused): for a host that runs these
+ * launches on a CU-masked stream beside another kernel's resident workgroups (RCCL's channels during zero_stage1_config.json's overlap_comm) -- the grids are then sized for
+ * the CUs the mask leaves.  Without a mask a lower budget measured no gain (profiles/r05_rccl_contention.md). */
 int vlaser_set_cu_budget(int cus);
+int vlaser_get_cu_budget(void);
 
 /* NN form: out[M,N] = A[M,K] @ B[K,N], B = args->W row-major with row stride args->ldw ("k-major").  The dgrad of an nn.Linear
  * (dX = dY @ W, autograd of modeling_internvl_chat.py:194-203 / joint_model.py:410-696) reads the forward weight [N_out, K_in] as it

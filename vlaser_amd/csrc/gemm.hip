@@ -1216,15 +1216,17 @@ static int launch_bm(const VlaserGemmArgs* args, hipStream_t stream, int splits)
   return 0;
 }
 
-// CUs the tile / split heuristics may count on.  256 on an MI355X of its own; a data-parallel rank lowers it by the CUs RCCL's channel workgroups hold during the
-// backward (tools/micro/rccl_shadow_lab.py: with 8 resident streaming workgroups beside it a forward + backward whose grids were sized for 256 CUs takes x1.54 -- every
-// 250-workgroup grid grows a second round).  Process-wide, set between steps (not while launches of another thread are being queued).
+// CUs the tile / split heuristics may count on: 256 on an MI355X of its own.  For a host that runs this library's launches on a CU-MASKED stream (hipExtStreamCreateWithCUMask:
+// the only arrangement in which streaming workgroups of another kernel -- RCCL's channels -- did not stretch the single-round GEMM grids, tools/micro/rccl_shadow_lab.py,
+// profiles/r05_rccl_contention.md): the grids must be sized for the CUs the mask leaves.  Without a mask a lower budget does not help (measured).  Process-wide, set between
+// steps (not while launches of another thread are being queued).
 static int g_cu_budget = 256;
 extern "C" int vlaser_set_cu_budget(int cus) {
   const int prev = g_cu_budget;
   if (cus >= 64 && cus <= 256) g_cu_budget = cus;
   return prev;
 }
+extern "C" int vlaser_get_cu_budget(void) { return g_cu_budget; }
 
 // Tile configuration.  Measured on the path's shapes (tools/micro/gemm_lab.cpp, profiles/r02b_gemm_lab.md): the LDS-DMA
 // pipelines beat the register-staged kernels whenever the grid is a single round of workgroups (<= one per CU), largest tile

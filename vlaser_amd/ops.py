@@ -616,11 +616,11 @@ _CU_BUDGET = 256
 
 
 def set_cu_budget(cus):
-    """CUs the GEMM tile / split heuristics (here and in csrc/gemm.hip) may count on; returns the previous value.  A data-parallel rank passes 256 minus the CUs
-    RCCL's channel workgroups hold beside its backward (sft.py), everything else leaves the default."""
+    """CUs the GEMM tile / split heuristics (here and in csrc/gemm.hip) may count on; returns the previous value.  For launches on a CU-masked stream (the grids are then
+    sized for the CUs the mask leaves: tools/micro/rccl_shadow_lab.py); everything else leaves the default of 256."""
     global _CU_BUDGET
     prev = L.lib().vlaser_set_cu_budget(int(cus))
-    _CU_BUDGET = L.lib().vlaser_set_cu_budget(-1)          # (out of range: a read)
+    _CU_BUDGET = L.lib().vlaser_get_cu_budget()            # (an out-of-range request is refused: mirror what the library holds)
     return prev
 
 
