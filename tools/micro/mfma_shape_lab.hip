@@ -16,10 +16,15 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }      // conflict-free for 16 consecutive rows at one k-slot
 
-template <int SHAPE, bool READS, bool MFMAS, bool BARRIER>
-__global__ __launch_bounds__(512) void lab_kernel(int steps, float* sink) {
-  __shared__ __attribute__((aligned(16))) char smem[(192 + 256) * 128];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3;
+// DMA (second table): on top of the 16x16 loop every wave also issues the 7 LDS-DMA pieces of a refill per K-step (1 KiB each, from an L2-resident buffer into a spare LDS region,
+// waited for at the top of the next step like the product's two-stage ring), as one burst in front of the second half's reads:
+//   1 = the product's form: per piece a 64-bit per-lane pointer + the K offset (2 VALU), s_mov m0 + s_nop, global_load_lds_dwordx4 v[ptr], off
+//   2 = scalar base + 32-bit per-lane offset, ONE m0 write per 4 pieces, the piece's LDS / global displacement in the instruction's immediate offset
+//       (global_load_lds_dwordx4 v_off, s[base:base+1] offset:1024 i; the immediate moves BOTH addresses -- probed below -- so v_off carries -1024 i)
+template <int SHAPE, bool READS, bool MFMAS, bool BARRIER, int DMA = 0, int FLY = 0>      // FLY: refills (of 7 pieces) that may still be in flight at the top of a step
+__global__ __launch_bounds__(512) void lab_kernel(int steps, float* sink, const char* gsrc = nullptr) {
+  __shared__ __attribute__((aligned(16))) char smem[(192 + 256) * 128 + (DMA ? 8 * 7 * 1024 : 0)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 2, wc = wave & 3;
   for (int i = tid; i < (192 + 256) * 8; i += 512) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0x3c003c00u + i, 0x3c003c00u, 0x3c013c00u, 0x3c003c02u};
   __syncthreads();
   const char* As = smem;
@@ -37,10 +42,33 @@ __global__ __launch_bounds__(512) void lab_kernel(int steps, float* sink) {
     for (int t = 0; t < 6; ++t) fa[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + lds_off(wr * 96 + t * 16 + fr, fq)));
 #pragma unroll
     for (int t = 0; t < 4; ++t) fw[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ws + lds_off(wc * 64 + t * 16 + fr, fq)));
+    [[maybe_unused]] const uint32_t dma_lds = (uint32_t)(uintptr_t)smem + (192 + 256) * 128 + wave * 7 * 1024;
+    [[maybe_unused]] const char* wsrc = gsrc + ((size_t)blockIdx.x * 8 + wave) * (7 * 8 * 4096);          // this wave's 7 x 8 "rows" of 4 KB
+    [[maybe_unused]] const char* pp[7];
+    [[maybe_unused]] uint32_t voff[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { pp[i] = wsrc + (size_t)(i * 8 + (lane >> 3)) * 4096 + (lane & 7) * 16; voff[i] = (uint32_t)((i * 8 + (lane >> 3)) * 4096 + (lane & 7) * 16) - (uint32_t)(i & 3) * 1024u; }
     for (int s = 0; s < steps; ++s) {
+      if constexpr (DMA != 0) { if constexpr (FLY == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else if constexpr (FLY == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
       if constexpr (BARRIER) __builtin_amdgcn_s_barrier();
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
+        if constexpr (DMA == 1) {
+          if (ks == 1) {
+            const size_t ko = (size_t)(s & 7) * 128;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(pp[i] + ko), "s"(__builtin_amdgcn_readfirstlane(dma_lds + i * 1024)) : "memory");
+          }
+        }
+        if constexpr (DMA == 2) {
+          if (ks == 1) {
+            const char* sb = wsrc + (size_t)(s & 7) * 128;
+            asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %5\n\tglobal_load_lds_dwordx4 %1, %5 offset:1024\n\tglobal_load_lds_dwordx4 %2, %5 offset:2048\n\tglobal_load_lds_dwordx4 %3, %5 offset:3072"
+                         : : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(__builtin_amdgcn_readfirstlane(dma_lds)), "s"(sb) : "memory");
+            asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %4\n\tglobal_load_lds_dwordx4 %1, %4 offset:1024\n\tglobal_load_lds_dwordx4 %2, %4 offset:2048"
+                         : : "v"(voff[4]), "v"(voff[5]), "v"(voff[6]), "s"(__builtin_amdgcn_readfirstlane(dma_lds + 4096)), "s"(sb) : "memory");
+          }
+        }
         if constexpr (READS) {
 #pragma unroll
           for (int t = 0; t < 6; ++t) fa[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const volatile u32x4*>(As + lds_off(wr * 96 + t * 16 + fr, ks * 4 + fq)));
@@ -106,18 +134,30 @@ __global__ __launch_bounds__(512) void lab_kernel(int steps, float* sink) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc_sum += acc[i][j][0] + acc[i][j][15];
   }
+  if constexpr (DMA != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (acc_sum == 12345.678f) sink[blockIdx.x] = acc_sum;
 }
 
-template <int SHAPE, bool READS, bool MFMAS, bool BARRIER>
-static void run(const char* what, float* sink) {
+// probe: does the immediate offset of global_load_lds move the LDS address, the global address, or both?  src[i] = i (dwords); one wave
+__global__ void probe_kernel(const uint32_t* src, uint32_t* out) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2048];
+  for (int i = threadIdx.x; i < 2048; i += 64) lds[i] = 0xdeadbeefu;
+  __syncthreads();
+  const uint32_t voff = threadIdx.x * 16, base = (uint32_t)(uintptr_t)lds;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\ts_waitcnt vmcnt(0)" : : "v"(voff), "s"(src), "s"(base) : "memory");
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2048; i += 64) out[i] = lds[i];
+}
+
+template <int SHAPE, bool READS, bool MFMAS, bool BARRIER, int DMA = 0, int FLY = 0>
+static void run(const char* what, float* sink, const char* gsrc = nullptr) {
   const int steps = 4800;       // = 200 launches' worth of the 24-step K loop
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((lab_kernel<SHAPE, READS, MFMAS, BARRIER>), dim3(256), dim3(512), 0, 0, 240, sink);
+  hipLaunchKernelGGL((lab_kernel<SHAPE, READS, MFMAS, BARRIER, DMA, FLY>), dim3(256), dim3(512), 0, 0, 240, sink, gsrc);
   hipDeviceSynchronize();
   hipEventRecord(e0, 0);
-  hipLaunchKernelGGL((lab_kernel<SHAPE, READS, MFMAS, BARRIER>), dim3(256), dim3(512), 0, 0, steps, sink);
+  hipLaunchKernelGGL((lab_kernel<SHAPE, READS, MFMAS, BARRIER, DMA, FLY>), dim3(256), dim3(512), 0, 0, steps, sink, gsrc);
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -138,5 +178,25 @@ int main() {
   run<32, false, true, false>("MFMAs only", sink);
   run<16, true, false, false>("fragment reads only", sink);
   run<32, true, false, false>("fragment reads only", sink);
+  // the immediate offset's meaning
+  uint32_t *psrc, *pout;
+  hipMalloc((void**)&psrc, 8192 * 4); hipMalloc((void**)&pout, 2048 * 4);
+  { uint32_t h[8192]; for (int i = 0; i < 8192; ++i) h[i] = i; hipMemcpy(psrc, h, sizeof(h), hipMemcpyHostToDevice); }
+  hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, 0, psrc, pout);
+  { uint32_t h[2048]; hipMemcpy(h, pout, sizeof(h), hipMemcpyDeviceToHost);
+    int first = -1; for (int i = 0; i < 2048; ++i) if (h[i] != 0xdeadbeefu) { first = i; break; }
+    printf("\nprobe: global_load_lds_dwordx4 v_off, s[src] offset:1024 with m0 = LDS base: first written LDS dword %d (256 = the offset moves the LDS address), its value %u (256 = it moves the global address too)\n", first, first >= 0 ? h[first] : 0u); }
+  // piece issue inside the loop
+  char* gsrc;
+  hipMalloc((void**)&gsrc, (size_t)256 * 8 * 7 * 8 * 4096 + 4096);
+  hipMemset(gsrc, 1, (size_t)256 * 8 * 7 * 8 * 4096 + 4096);
+  printf("\n| 16x16 loop with its barrier + 7 LDS-DMA pieces per wave and K-step | us per K-step |\n|---|---|\n");
+  run<16, true, true, true, 0>("no pieces", sink, gsrc);
+  run<16, true, true, true, 1>("form 1: 64-bit per-lane pointers, m0 per piece (the product's)", sink, gsrc);
+  run<16, true, true, true, 2>("form 2: scalar base + 32-bit offsets, m0 per 4 pieces, immediate offsets", sink, gsrc);
+  run<16, true, true, true, 1, 1>("form 1, one refill may fly over the barrier (1.5 steps to land)", sink, gsrc);
+  run<16, true, true, true, 2, 1>("form 2, one refill may fly", sink, gsrc);
+  run<16, true, true, true, 1, 2>("form 1, two refills may fly (2.5 steps to land)", sink, gsrc);
+  run<16, true, true, true, 2, 2>("form 2, two refills may fly", sink, gsrc);
   return 0;
 }
