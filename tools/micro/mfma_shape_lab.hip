@@ -21,7 +21,7 @@ __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + (
 //   1 = the product's form: per piece a 64-bit per-lane pointer + the K offset (2 VALU), s_mov m0 + s_nop, global_load_lds_dwordx4 v[ptr], off
 //   2 = scalar base + 32-bit per-lane offset, ONE m0 write per 4 pieces, the piece's LDS / global displacement in the instruction's immediate offset
 //       (global_load_lds_dwordx4 v_off, s[base:base+1] offset:1024 i; the immediate moves BOTH addresses -- probed below -- so v_off carries -1024 i)
-template <int SHAPE, bool READS, bool MFMAS, bool BARRIER, int DMA = 0, int FLY = 0>      // FLY: refills (of 7 pieces) that may still be in flight at the top of a step
+template <int SHAPE, bool READS, bool MFMAS, bool BARRIER, int DMA = 0, int FLY = 0, bool CONTIG = false, bool SHARED = false>      // FLY: refills (of 7 pieces) that may still be in flight at the top of a step; CONTIG: a piece = 1 KiB contiguous in memory (pre-tiled operand) instead of 8 rows x 128 B
 __global__ __launch_bounds__(512) void lab_kernel(int steps, float* sink, const char* gsrc = nullptr) {
   __shared__ __attribute__((aligned(16))) char smem[(192 + 256) * 128 + (DMA ? 8 * 7 * 1024 : 0)];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 2, wc = wave & 3;
@@ -43,11 +43,13 @@ __global__ __launch_bounds__(512) void lab_kernel(int steps, float* sink, const 
 #pragma unroll
     for (int t = 0; t < 4; ++t) fw[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ws + lds_off(wc * 64 + t * 16 + fr, fq)));
     [[maybe_unused]] const uint32_t dma_lds = (uint32_t)(uintptr_t)smem + (192 + 256) * 128 + wave * 7 * 1024;
-    [[maybe_unused]] const char* wsrc = gsrc + ((size_t)blockIdx.x * 8 + wave) * (7 * 8 * 4096);          // this wave's 7 x 8 "rows" of 4 KB
+    // this wave's 7 x 8 "rows" of 4 KB.  SHARED = 1: the same 1.8 MB for every workgroup (L2-resident in every XCD, as the product's operand tiles are: a W tile is read by
+    // the 3-5 workgroups of its tile column, an A tile by up to 70); SHARED = 0: 448 KB of its own per workgroup (115 MB touched: out of the Infinity Cache / HBM, 7 TB/s over the chip)
+    [[maybe_unused]] const char* wsrc = gsrc + ((size_t)(SHARED ? 0 : blockIdx.x) * 8 + wave) * (7 * 8 * 4096);
     [[maybe_unused]] const char* pp[7];
     [[maybe_unused]] uint32_t voff[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) { pp[i] = wsrc + (size_t)(i * 8 + (lane >> 3)) * 4096 + (lane & 7) * 16; voff[i] = (uint32_t)((i * 8 + (lane >> 3)) * 4096 + (lane & 7) * 16) - (uint32_t)(i & 3) * 1024u; }
+    for (int i = 0; i < 7; ++i) { pp[i] = CONTIG ? wsrc + (size_t)i * 8 * 4096 + lane * 16 : wsrc + (size_t)(i * 8 + (lane >> 3)) * 4096 + (lane & 7) * 16; voff[i] = (uint32_t)((i * 8 + (lane >> 3)) * 4096 + (lane & 7) * 16) - (uint32_t)(i & 3) * 1024u; }
     for (int s = 0; s < steps; ++s) {
       if constexpr (DMA != 0) { if constexpr (FLY == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else if constexpr (FLY == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
       if constexpr (BARRIER) __builtin_amdgcn_s_barrier();
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(512) void lab_kernel(int steps, float* sink, const 
       for (int ks = 0; ks < 2; ++ks) {
         if constexpr (DMA == 1) {
           if (ks == 1) {
-            const size_t ko = (size_t)(s & 7) * 128;
+            const size_t ko = (size_t)(s & 7) * (CONTIG ? 1024 : 128);
 #pragma unroll
             for (int i = 0; i < 7; ++i) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(pp[i] + ko), "s"(__builtin_amdgcn_readfirstlane(dma_lds + i * 1024)) : "memory");
           }
@@ -149,15 +151,15 @@ __global__ void probe_kernel(const uint32_t* src, uint32_t* out) {
   for (int i = threadIdx.x; i < 2048; i += 64) out[i] = lds[i];
 }
 
-template <int SHAPE, bool READS, bool MFMAS, bool BARRIER, int DMA = 0, int FLY = 0>
+template <int SHAPE, bool READS, bool MFMAS, bool BARRIER, int DMA = 0, int FLY = 0, bool CONTIG = false, bool SHARED = false>
 static void run(const char* what, float* sink, const char* gsrc = nullptr) {
   const int steps = 4800;       // = 200 launches' worth of the 24-step K loop
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((lab_kernel<SHAPE, READS, MFMAS, BARRIER, DMA, FLY>), dim3(256), dim3(512), 0, 0, 240, sink, gsrc);
+  hipLaunchKernelGGL((lab_kernel<SHAPE, READS, MFMAS, BARRIER, DMA, FLY, CONTIG, SHARED>), dim3(256), dim3(512), 0, 0, 240, sink, gsrc);
   hipDeviceSynchronize();
   hipEventRecord(e0, 0);
-  hipLaunchKernelGGL((lab_kernel<SHAPE, READS, MFMAS, BARRIER, DMA, FLY>), dim3(256), dim3(512), 0, 0, steps, sink, gsrc);
+  hipLaunchKernelGGL((lab_kernel<SHAPE, READS, MFMAS, BARRIER, DMA, FLY, CONTIG, SHARED>), dim3(256), dim3(512), 0, 0, steps, sink, gsrc);
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -198,5 +200,18 @@ int main() {
   run<16, true, true, true, 2, 1>("form 2, one refill may fly", sink, gsrc);
   run<16, true, true, true, 1, 2>("form 1, two refills may fly (2.5 steps to land)", sink, gsrc);
   run<16, true, true, true, 2, 2>("form 2, two refills may fly", sink, gsrc);
+  run<16, true, true, true, 1, 0, true>("form 1, every piece 1 KiB CONTIGUOUS in memory (pre-tiled operand)", sink, gsrc);
+  run<16, true, true, true, 1, 1, true>("form 1, contiguous pieces, one refill may fly", sink, gsrc);
+  run<16, false, false, true, 1, 0, false>("pieces only (no reads, no MFMAs), 8 rows x 128 B", sink, gsrc);
+  run<16, false, false, true, 1, 0, true>("pieces only, contiguous", sink, gsrc);
+  run<16, false, false, true, 1, 2, false>("pieces only, 8 rows x 128 B, two refills may fly", sink, gsrc);
+  printf("\n| the same with an L2-RESIDENT source (every workgroup reads the same 1.8 MB) | | | us per K-step | |\n|---|---|---|---|---|\n");
+  run<16, false, false, true, 1, 0, false, true>("pieces only, 8 rows x 128 B", sink, gsrc);
+  run<16, false, false, true, 1, 2, false, true>("pieces only, two refills may fly", sink, gsrc);
+  run<16, false, false, true, 1, 0, true, true>("pieces only, contiguous", sink, gsrc);
+  run<16, true, true, true, 1, 0, false, true>("loop + pieces (form 1)", sink, gsrc);
+  run<16, true, true, true, 1, 1, false, true>("loop + pieces, one refill may fly", sink, gsrc);
+  run<16, true, true, true, 1, 2, false, true>("loop + pieces, two refills may fly", sink, gsrc);
+  run<16, true, true, true, 2, 2, false, true>("loop + pieces (form 2), two refills may fly", sink, gsrc);
   return 0;
 }
