@@ -12,6 +12,8 @@
 // blockIdx is remapped so each XCD owns a contiguous run of tiles that share the same weight panel (guide T1).
 
 #include <cstdlib>
+#include <cstring>
+#include <cstdio>
 #include "common.h"
 #include "../../include/vlaser_hip.h"
 
@@ -1284,8 +1286,14 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
     if (no_asym) bm = bm == 1900 ? 1901 : bm == 1300 ? 1302 : bm;
   }
   if constexpr (!AKM) {
-    static const bool no_spread = getenv("VLASER_GEMM_NO_SPREAD") != nullptr;  // diagnostics / same-box A/B: the refill as one burst per K-step (r02-r04)
-    if (no_spread) bm = bm == 1100 ? 1101 : bm == 1200 ? 1201 : bm == 1300 ? 1304 : bm == 1440 ? 1441 : bm == 1500 ? 1501 : bm == 1900 ? 1904 : bm;
+    // diagnostics / same-box A/B: the refill as one burst per K-step (r02-r04) -- "1" for every configuration, or a list of configuration codes ("1200,1500")
+    static const char* no_spread = getenv("VLASER_GEMM_NO_SPREAD");
+    if (no_spread) {
+      char code[8];
+      snprintf(code, sizeof(code), "%d", bm);
+      if (!strcmp(no_spread, "1") || strstr(no_spread, code))
+        bm = bm == 1100 ? 1101 : bm == 1200 ? 1201 : bm == 1300 ? 1304 : bm == 1440 ? 1441 : bm == 1500 ? 1501 : bm == 1900 ? 1904 : bm;
+    }
   }
   if constexpr (AKM) {
     switch (bm) {
