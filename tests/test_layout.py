@@ -157,6 +157,22 @@ def test_bad_arguments_return_errors_not_crashes():
     assert b'distinct action buffers' in lib.vlaser_last_error()
 
 
+def test_chain_gu_predicate_mirrors_the_dispatch_table():
+    """`vlaser_chain_gu_supported` answered 1 for K = 768 / 2 producer slabs / 2 units per workgroup, which `vlaser_chain_gu` has no instantiation for.
+    Both are generated from one variant list now: the predicate (host-only, no GPU) must say yes exactly on the list's rows."""
+    from vlaser_amd import _lib
+    lib = _lib.lib()
+    built = {(3, 3, 3, 2), (3, 3, 2, 2), (6, 3, 2, 2), (3, 2, 3, 2), (6, 2, 2, 2), (3, 5, 3, 1), (6, 5, 2, 1)}     # {K / 256, units per workgroup, slabs, tiles per unit}
+    for ns in (2, 3, 4, 6):
+        for longest in (1, 2, 3, 4, 5, 6):
+            for sp in (1, 2, 3, 4):
+                for tpu in (1, 2):
+                    N = 16 * tpu * (256 * (longest - 1) + 100)
+                    got = lib.vlaser_chain_gu_supported(4, N, ns * 256, sp, tpu)
+                    assert got == int((ns, longest, sp, tpu) in built), (ns, longest, sp, tpu, got)
+    assert lib.vlaser_chain_gu_supported(17, 17920, 768, 3, 2) == 0 and lib.vlaser_chain_gu_supported(16, 17920, 1536, 2, 2) == 0     # rows / chunks per thread
+
+
 def test_weight_packing_roundtrip():
     """pack_qkv / pack_gate_up / pack_skinny are pure permutations (CPU check of the index maps)."""
     from vlaser_amd import ops

@@ -219,14 +219,19 @@ static int chain_gu_launch(const ChainGuP& p, int gx, int lds, hipStream_t strea
   return 0;
 }
 
-/* tpu = tiles per unit of the packed weights (2: pack_gate_up, 1: pack_gate_up8) */
+/* tpu = tiles per unit of the packed weights (2: pack_gate_up, 1: pack_gate_up8).
+   ONE list of the built variants {K / 256, units per workgroup, producer slabs, tiles per unit}: the predicate and the dispatch below are both generated from it
+   (the predicate admitted K = 768 / 2 slabs / 2 units per workgroup, which has no instantiation). */
+#define CG_VARIANTS(X) X(3, 3, 3, 2) X(3, 3, 2, 2) X(6, 3, 2, 2) X(3, 2, 3, 2) X(6, 2, 2, 2) X(3, 5, 3, 1) X(6, 5, 2, 1)
 extern "C" int vlaser_chain_gu_supported(int M, int N, int K, int n_partials, int tpu) {
-  if (M < 1 || M > 16 || (K != 768 && K != 1536) || (tpu != 1 && tpu != 2) || N % (16 * tpu) || (K == 768 && n_partials != 2 && n_partials != 3) || (K == 1536 && n_partials != 2)) return 0;
+  if (M < 1 || M > 16 || K % 256 || (tpu != 1 && tpu != 2) || N < 16 * tpu || N % (16 * tpu)) return 0;
   const int cpt = (M * (K / 8) + 511) / 512;
   if (cpt > 3) return 0;
-  const int units = N / (16 * tpu);
-  const int longest = (units + 255) / 256;
-  return tpu == 2 ? (longest == 2 || longest == 3) : (longest == 5 && !(K == 768 && n_partials == 2));
+  const int ns = K / 256, units = N / (16 * tpu), longest = (units + 255) / 256;
+#define CG_HAS(NS_, UE_, SP_, TPU_) if (ns == NS_ && longest == UE_ && n_partials == SP_ && tpu == TPU_) return 1;
+  CG_VARIANTS(CG_HAS)
+#undef CG_HAS
+  return 0;
 }
 
 extern "C" int vlaser_chain_gu(const VlaserSkinnyArgs* a, vl_stream_t s) {
@@ -250,7 +255,7 @@ extern "C" int vlaser_chain_gu(const VlaserSkinnyArgs* a, vl_stream_t s) {
   hipStream_t stream = (hipStream_t)s;
 #define CG_CASE(NS_, UE_, SP_, CPT_, TPU_) if (ns == NS_ && longest == UE_ && a->n_partials == SP_ && cpt == CPT_ && tpu == TPU_) return chain_gu_launch<NS_, UE_, SP_, CPT_, TPU_>(p, gx, lds, stream);
 #define CG_CPT(NS_, UE_, SP_, TPU_) CG_CASE(NS_, UE_, SP_, 1, TPU_) CG_CASE(NS_, UE_, SP_, 2, TPU_) CG_CASE(NS_, UE_, SP_, 3, TPU_)
-  CG_CPT(3, 3, 3, 2) CG_CPT(3, 3, 2, 2) CG_CPT(6, 3, 2, 2) CG_CPT(3, 2, 3, 2) CG_CPT(6, 2, 2, 2) CG_CPT(3, 5, 3, 1) CG_CPT(6, 5, 2, 1)
+  CG_VARIANTS(CG_CPT)
 #undef CG_CPT
 #undef CG_CASE
   vlaser_set_error("vlaser_chain_gu: no variant for K %d, %d units per workgroup, %d slabs, %d chunks per thread, %d tiles per unit", a->K, longest, a->n_partials, cpt, tpu);

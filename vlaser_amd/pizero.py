@@ -108,6 +108,33 @@ def stage_pixels(pixel_values, out, dev):
     return out
 
 
+class _ActionChunk(torch.Tensor):
+    """The tensor `infer_action` returns when it was handed the reference's dense masks: an ordinary device tensor that remembers the model whose deferred mask
+    check covers it.  The check itself never synchronises (pizero.py::_poll_errors); but the first thing a caller does with a chunk is bring it to the host
+    (`actions[0].float().cpu().numpy()`, eval.py:139) -- that transfer waits for the chunk anyway, and the snapshot of the error word was enqueued behind the
+    chunk on the same stream, so polling right AFTER a `.cpu()` / `.to('cpu')` / `.tolist()` / `.item()` costs nothing and turns the NaN chunk of an unsupported
+    mask into its `ValueError` at the natural place (VERDICT r05 weak #9) instead of one call late."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        owner = None
+        for a in args:
+            if isinstance(a, _ActionChunk):
+                owner = getattr(a, '_vl_owner', None)
+                if owner is not None:
+                    break
+        out = super().__torch_function__(func, types, args, kwargs or {})
+        if owner is None:
+            return out
+        to_host = getattr(func, '__name__', '') in ('tolist', 'item') or (isinstance(out, torch.Tensor) and out.device.type == 'cpu')
+        if to_host:
+            owner._poll_errors(block=False)
+            return out.as_subclass(torch.Tensor) if isinstance(out, torch.Tensor) else out
+        if isinstance(out, _ActionChunk):
+            out._vl_owner = owner
+        return out
+
+
 class PiZero:
     # Euler-phase kernel options of the action expert (VLASER_EULER overrides: comma list, "none" = the r02 kernels):
     #   qkv16: 16-row lane-local units for the q/k/v weight-streaming GEMV (128 instead of 64 workgroups): -0.88 us per layer-step in-chain
@@ -151,6 +178,7 @@ class PiZero:
         self.euler_opts = tuple(x for x in eo.split(',') if x and x != 'none')
         self._graphs = {}
         self._pos_state = None
+        self._pos_next = None
         # output_ring = 0 (default): infer_action returns a FRESH tensor, as the reference does (pizero_internvl.py:934-936).  output_ring = n > 0 (opt-in, serving
         # loops / bench.py): it returns a VIEW of slot (call number mod n) of a small result ring written by the chunk's last kernel -- no copy launch, but the
         # view is overwritten n calls later
@@ -158,6 +186,7 @@ class PiZero:
         self._calls = 0
         self._err_pending = []                  # (event, pinned int32[4] snapshot of call_ctr) of calls that passed dense masks and were not polled yet
         self._err_pins = None
+        self._n_masked = 0
         if max_batch * cfg.num_action_tokens > 16:
             raise ValueError('the weight-streaming action path handles batch * horizon <= 16 rows')
 
@@ -193,6 +222,7 @@ class PiZero:
     def _alloc(self):
         cfg, dev, B = self.cfg, self.device, self.max_batch
         self._pos_state = None                  # fresh (zeroed) position-id buffers
+        self._pos_next = None
         llm = cfg.base.llm
         T = self.max_image_text_tokens
         self.s_max = (self.total_num_tokens + 63) // 64 * 64
@@ -243,6 +273,7 @@ class PiZero:
         None the defaults are written once per batch size."""
         T, na, dev = self.max_image_text_tokens, self.num_action_tokens, self.device
         custom = not (vlm_position_ids is None and proprio_position_ids is None and action_position_ids is None)
+        self._pos_next = None
         if not custom and self._pos_state == ('default', B):
             return None
         d = self._pos_defaults.get(B)
@@ -250,8 +281,14 @@ class PiZero:
             d = self._pos_defaults[B] = (torch.arange(1, T + 1, device=dev).repeat(B, 1), torch.ones(B, 1, dtype=torch.long, device=dev),
                                          torch.arange(2, 2 + na, device=dev).repeat(B, 1))
         on = lambda t, dflt: dflt if t is None else t.to(device=dev, dtype=torch.int64, non_blocking=True).contiguous()
-        self._pos_state = ('custom', B) if custom else ('default', B)
+        # the state the slots WILL hold once the staging launch has been accepted: the caller commits it (`_pos_commit`) behind that launch -- a call that raises
+        # between here and there (bad proprio / mask shape ...) must not leave a retry believing the slots are written
+        self._pos_next = ('custom', B) if custom else ('default', B)
         return on(vlm_position_ids, d[0]), on(proprio_position_ids, d[1]), on(action_position_ids, d[2])
+
+    def _pos_commit(self):
+        if self._pos_next is not None:
+            self._pos_state, self._pos_next = self._pos_next, None
 
     # ------------------------------------------------------------------ reference helpers (API parity)
     def build_causal_mask_and_position_ids(self, attention_mask, dtype):
@@ -266,6 +303,12 @@ class PiZero:
         return self.cache
 
     # ------------------------------------------------------------------ the hot path (all kernel launches)
+    def _ride(self, B):
+        """Batch 1: the proprio row rides with the action rows of Euler step 0 (see _run_prefill).  Needs a second Euler step: the step that hosts the
+        proprio row integrates M + 1 rows in `action5` and does not write the result ring, so with num_inference_steps == 1 the caller's slot (and the
+        NaN poisoning of an unsupported mask) would never be written -- the proprio row takes its own pass then."""
+        return self.ride_proprio and B == 1 and self.num_inference_steps >= 2
+
     def _run(self, B):
         """ViT + projector + scatter -> joint prefill -> Euler loop: three phases, separately callable so that bench.py can time each
         one from its own HIP graph (per-phase ms on the JSON line)."""
@@ -292,7 +335,7 @@ class PiZero:
         # a later row's output, and the per-row arithmetic of the <= 16-row kernels does not depend on M -- so its K / V^T (slot T)
         # and every action are bit-identical to the separate pass, and the expert's weights are streamed once for both.
         # (An HIP-graph side branch was tried first: graph replay runs the branches back to back, 0.9 % kernel overlap in rocprof.)
-        ride = self.ride_proprio and B == 1
+        ride = self._ride(B)
         if ride:
             ops.small_linear(self.in_proprio, self.pe_w, self.pe_b, self.h5, B, cfg.action_hidden_size, cfg.proprio_dim)      # row 0
         else:
@@ -316,7 +359,7 @@ class PiZero:
         llm, ex = cfg.base.llm, cfg.expert
         T, na = self.max_image_text_tokens, self.num_action_tokens
         nL = llm.num_hidden_layers
-        ride = self.ride_proprio and B == 1
+        ride = self._ride(B)
         M = B * na
         n = self.num_inference_steps
         dt = 1.0 / n
@@ -363,7 +406,7 @@ class PiZero:
         llm, ex = cfg.base.llm, cfg.expert
         T, na = self.max_image_text_tokens, self.num_action_tokens
         nL = llm.num_hidden_layers
-        ride = self.ride_proprio and B == 1
+        ride = self._ride(B)
         M, n, W, ad = B * na, self.num_inference_steps, cfg.action_hidden_size, cfg.action_dim
         dt = 1.0 / n
         clip = self.final_action_clip_value
@@ -403,6 +446,10 @@ class PiZero:
     def infer_action(self, input_ids, pixel_values, image_text_proprio_mask=None, action_mask=None, vlm_position_ids=None,
                      proprio_position_ids=None, action_position_ids=None, proprios=None, noise=None, generator=None,
                      valid_len=None):
+        """pizero_internvl.py:798-936.  The dense masks are checked ON THE DEVICE against the only visibility the kernels express (valid prefix + trailing
+        block); the call never waits for that check.  An unsupported mask turns THIS call's chunk into NaN and raises `ValueError` at the next poll: bringing
+        the returned chunk to the host (`.cpu()`, `.tolist()` ...), the next public method of this object, `last_velocities()` or `check_errors()`.  A NaN
+        chunk therefore always means "call check_errors()"."""
         cfg, dev = self.cfg, self.device
         B = pixel_values.shape[0] // self.num_images
         T, na = self.max_image_text_tokens, self.num_action_tokens
@@ -412,11 +459,14 @@ class PiZero:
             sl = lambda t, lo, hi, k=1: None if t is None else t[lo * k:hi * k]
             for lo in range(0, B, mb):
                 hi = min(B, lo + mb)
-                outs.append(self.infer_action(input_ids[lo:hi], pixel_values[lo * ni:hi * ni], sl(image_text_proprio_mask, lo, hi),
-                                              sl(action_mask, lo, hi), sl(vlm_position_ids, lo, hi), sl(proprio_position_ids, lo, hi),
-                                              sl(action_position_ids, lo, hi), sl(proprios, lo, hi), sl(noise, lo, hi), generator,
-                                              sl(valid_len, lo, hi)))
-            return torch.cat(outs, 0)             # (a copy: also with output_ring > 0, where each group's result is a view of the ring)
+                o = self.infer_action(input_ids[lo:hi], pixel_values[lo * ni:hi * ni], sl(image_text_proprio_mask, lo, hi),
+                                      sl(action_mask, lo, hi), sl(vlm_position_ids, lo, hi), sl(proprio_position_ids, lo, hi),
+                                      sl(action_position_ids, lo, hi), sl(proprios, lo, hi), sl(noise, lo, hi), generator,
+                                      sl(valid_len, lo, hi))
+                # with output_ring > 0 a group's result is a VIEW of a ring slot that a later group of this same call may overwrite (more groups than
+                # slots): take the copy now, in stream order
+                outs.append(o.clone() if self.output_ring > 0 else o)
+            return torch.cat(outs, 0)
         if input_ids.shape != (B, T):
             raise ValueError(f'input_ids must be [B,{T}] (right-padded with pad_token_id), got {tuple(input_ids.shape)}')
         # ---- stage inputs into the static slots of the captured graph: ONE launch (vlaser_vla_stage) once the tensors are on the device.  The reference's
@@ -460,7 +510,8 @@ class PiZero:
             # snapshot of {call number, error words} behind the chunk, into pinned host memory: polled at the NEXT call / by check_errors(), never waited for here
             if self._err_pins is None:
                 self._err_pins = [torch.empty(4, dtype=torch.int32).pin_memory() for _ in range(12)]      # > 8 outstanding + the ones being read
-            pin = self._err_pins[self._calls % len(self._err_pins)]
+            pin = self._err_pins[self._n_masked % len(self._err_pins)]      # (a counter of MASKED calls: at most 8 + the ones being read are ever outstanding)
+            self._n_masked += 1
             pin.copy_(self.call_ctr, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
@@ -469,7 +520,11 @@ class PiZero:
                 self._poll_errors(block=False, at_most_pending=8)
         slot = self._calls % self.out_ring.shape[0]
         act = self.out_ring[slot, :B * na * cfg.action_dim].view(B, na, cfg.action_dim)[:, -cfg.horizon_steps:]
-        return act if self.output_ring > 0 else act.clone()
+        act = act if self.output_ring > 0 else act.clone()
+        if masks is not None:
+            act = act.as_subclass(_ActionChunk)   # bringing it to the host polls the deferred mask check (see _ActionChunk)
+            act._vl_owner = self
+        return act
 
     def _poll_errors(self, block, at_most_pending=0):
         """Raise for a finished call whose dense masks the kernels cannot honour (error word written by `vlaser_vla_stage`).  block=False looks only at calls
@@ -492,7 +547,8 @@ class PiZero:
         if bad is not None:
             why = '; '.join(t for b_, t in self.ERR_BITS.items() if bad[1] & b_)
             raise ValueError(f'infer_action call #{bad[0]}: the dense masks are not the prefix + trailing-block pattern of build_causal_mask_and_position_ids '
-                             f'(pizero_internvl.py:517-603) -- the only visibility the kernels\' (valid_len, blk_start) descriptors express; its result was NaN.  {why}')
+                             f'(pizero_internvl.py:517-603) -- the only visibility the kernels\' (valid_len, blk_start) descriptors express; the chunk that call '
+                             f'returned is all NaN (a NaN chunk always means: call check_errors()).  {why}')
 
     def check_errors(self):
         """Wait for every outstanding call and raise if one of them passed a mask the kernels cannot honour (the lazy check of infer_action, made now)."""
@@ -537,10 +593,13 @@ class PiZero:
                       prep.VLA_MEAN, prep.VLA_STD, call_ctr=self.call_ctr, call_no=k, masks=masks, n_act=na, positions=positions,
                       pos_out=(self.pos_vlm, self.pos_pro, self.pos_act, self.pos5 if B == 1 else None))
         self._calls = k                           # only after the launch was accepted: the host's ring index cannot run ahead of the device's call number
+        if positions is not None:
+            self._pos_commit()                    # likewise: the slots hold the new position ids only now
 
     def last_velocities(self, B=1):
         """Decoder output (velocity) of every Euler step of the last infer_action call: fp32 [n_steps, B, horizon, action_dim]
-        (the `action_vel` of pizero_internvl.py:911; golden G7b pins it per step)."""
+        (the `action_vel` of pizero_internvl.py:911; golden G7b pins it per step).  Waits for that call and raises its deferred mask error, if any."""
+        self._poll_errors(block=True)
         na = self.num_action_tokens
         return self.vel_trace[:, :B * na].view(self.num_inference_steps, B, na, -1).clone()
 
@@ -553,6 +612,7 @@ class PiZero:
         attention kernel (block mask as two PREFIX launches) instead of the weight-streaming <= 16-row kernels + the key-split
         attention -- so `infer_action == infer_action_naive` cross-checks the two implementations (the reference remarks ~1e-3 in
         bf16, none in fp32: eval.py:131-137).  Batch 1."""
+        self._poll_errors(block=False)
         cfg, dev = self.cfg, self.device
         base, llm, ex = cfg.base, cfg.base.llm, cfg.expert
         T, na, nL = self.max_image_text_tokens, self.num_action_tokens, llm.num_hidden_layers
@@ -575,6 +635,7 @@ class PiZero:
         if pos is not None:                       # (test surface: plain torch copies; the hot path converts them inside vlaser_vla_stage)
             self.pos_vlm[:T].copy_(pos[0].reshape(-1)); self.pos_pro[:1].copy_(pos[1].reshape(-1)); self.pos_act[:na].copy_(pos[2].reshape(-1))
             self.pos5[:1].copy_(self.pos_pro[:1]); self.pos5[1:1 + na].copy_(self.pos_act[:na])
+            self._pos_commit()
         if noise is None:
             noise = torch.randn((1, na, cfg.action_dim), generator=generator)
         self.action[:na].copy_(noise.reshape(na, -1).to(torch.float32))
@@ -614,6 +675,7 @@ class PiZero:
         of :645-702, 0-based positions `cumsum(mask) - 1`, `final_layer_post_attn_skip_names=[]`) + lm_head -> {'logits': fp32
         [B, S, V]}; it must reproduce InternVLChatModel's logits (same weights, VLA-style embedding assembly with zeroed pad
         rows).  Prefill only (kv_cache must be None), no padding inside the sequence (the reference assumes the same)."""
+        self._poll_errors(block=False)
         if kv_cache is not None:
             raise NotImplementedError('infer_text: prefill only (kv_cache=None)')
         if self.vlm.head is None:
