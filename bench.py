@@ -227,6 +227,7 @@ def sft_bench(rank, world, local, dist, steps, warmup=2):
         except Exception as e:          # noqa: BLE001 -- a missing version query must not cost the run
             ver = f'unavailable ({type(e).__name__})'
         exchange_info = {'rccl_version': ver, 'first_collective_ms': round(first_ms, 2), 'second_collective_ms': round((time.perf_counter() - t0) * 1e3, 3)}
+    exchange_info.update(model.exchange_info())            # mode (none | pg | capi), CU-mask widths of the capi mode
     for _ in range(warmup):
         out = model.step(pv, ids, labels)
     torch.cuda.synchronize()
@@ -256,8 +257,66 @@ def sft_bench(rank, world, local, dist, steps, warmup=2):
     torch.cuda.synchronize()
     fwd_bwd_ms = (time.perf_counter() - t0) / steps * 1e3
     buckets_mb = [round((hi - lo) * 2 / 2 ** 20) for lo, hi in model.buckets]
+    side = {}
+    if world == 1 and dist is None and os.environ.get('VLASER_BENCH_NO_SFT_SIDE') != '1':
+        # (a) per-device batch 4, the reference launcher's PER_DEVICE_BATCH_SIZE (internvl3_2b_dynamic_res_2nd_finetune_full.sh:47-67): one optimizer step over four samples.
+        #     The kernels run one sample at a time (M = 560 rows each, fp32 gradient accumulation); AdamW and the norm are paid once per 2 240 tokens
+        try:
+            g4 = torch.Generator().manual_seed(2000)
+            ids4 = torch.stack([torch.cat([torch.randint(1, 151643, (41,), generator=g4), torch.full((256,), cfg.img_context_token_id),
+                                           torch.randint(1, 151643, (S - 41 - 256,), generator=g4)]) for _ in range(4)])
+            lab4 = torch.full_like(ids4, -100)
+            lab4[:, -R:] = ids4[:, -R:]
+            pv4 = torch.randn(4, 3, 448, 448, generator=g4).to(dev).to(torch.bfloat16)
+            model.wait_optimizer()
+            for _ in range(2):
+                o4 = model.train_step([(pv4, ids4, lab4)])
+            torch.cuda.synchronize()
+            n4 = max(steps // 2, 3)
+            t0 = time.perf_counter()
+            for _ in range(n4):
+                o4 = model.train_step([(pv4, ids4, lab4)])
+            torch.cuda.synchronize()
+            d4 = (time.perf_counter() - t0) / n4
+            assert float(o4.loss) == float(o4.loss)
+            side['micro_batch4'] = {'ms_per_step': round(d4 * 1e3, 2), 'tokens_per_s': round(4 * S / d4, 1), 'tokens_per_step': 4 * S,
+                                    'note': 'per-device batch 4 (…2nd_finetune_full.sh:47-67), one optimizer step; samples run one at a time (M = 560 rows per GEMM, not 2 240), '
+                                            'weighted fp32 gradient accumulation, AdamW once per step'}
+        except Exception as e:          # noqa: BLE001 -- a side number
+            side['micro_batch4'] = {'error': f'{type(e).__name__}: {e}'[:200]}
     del model
     torch.cuda.empty_cache()
+    if world == 1 and dist is None and os.environ.get('VLASER_BENCH_NO_SFT_SIDE') != '1':
+        # (b) the reference's activation policy: grad_checkpoint on (BASELINE configs[4], SURVEY 8d, …2nd_finetune_full.sh:46) -- every layer's forward re-run inside the
+        #     backward instead of 1.1 GB of kept activations; same values bit for bit (tests/test_sft_gpu.py)
+        try:
+            sd = synth.vlm_state_dict(cfg, device=dev, dtype=torch.bfloat16)
+            mr = SFTModel(cfg, device=dev, max_seq_len=576, recompute=True)
+            mr.load_state_dict(sd)
+            del sd
+            for _ in range(warmup):
+                mr.step(pv, ids, labels)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                orc = mr.step(pv, ids, labels)
+            torch.cuda.synchronize()
+            dr = (time.perf_counter() - t0) / steps
+            mr.wait_optimizer()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                mr.forward_backward(pv, ids, labels)
+            torch.cuda.synchronize()
+            side['recompute_ms_per_step'] = round(dr * 1e3, 2)
+            side['recompute_fwd_bwd_ms'] = round((time.perf_counter() - t0) / steps * 1e3, 2)
+            side['recompute_note'] = 'SFTModel(recompute=True): per-layer activation recompute as the reference\'s grad_checkpoint; the headline sft line keeps activations (1.1 GB of 288 GB)'
+            assert float(orc.loss) == float(orc.loss)
+            del mr
+            torch.cuda.empty_cache()
+        except Exception as e:          # noqa: BLE001
+            side['recompute_ms_per_step'] = None
+            side['recompute_error'] = f'{type(e).__name__}: {e}'[:200]
     fl = sft_flops(cfg, S, R - 1 + 1, 1)
     return {'metric': 'sft_tokens_per_sec', 'value': round(world * steps * S / dt, 1), 'unit': 'tokens/s', 'ms_per_step': round(dt / steps * 1e3, 2),
             'steps': steps, 'tokens_per_rank_step': S, 'last_loss': round(loss, 4), 'fwd_bwd_ms': round(fwd_bwd_ms, 2),
@@ -268,7 +327,8 @@ def sft_bench(rank, world, local, dist, steps, warmup=2):
                          'contention_model': {'source': 'profiles/r05_rccl_contention.md', 'fwd_bwd_stretch_by_channel_workgroups': {'1': 1.13, '8': 1.23, '16': 1.28, '32': 1.34, '64': 1.46},
                                               'both_streams_cu_masked': 1.13, 'predicted_fwd_bwd_ms_at_8_gpus': [16.4, 17.7]},
                          'gradient_bytes_per_rank': 3570e6 if world > 1 else 0, **exchange_info},
-            'gflop_per_rank_step': round(fl / 1e9, 1), 'mfma_frac': round(fl * world * steps / dt / (world * 2.5e15), 4)}
+            'gflop_per_rank_step': round(fl / 1e9, 1), 'mfma_frac': round(fl * world * steps / dt / (world * 2.5e15), 4),
+            'fwd_bwd_mfma_frac': round(fl / (fwd_bwd_ms * 1e-3) / 2.5e15, 4), **side}
 
 
 def main():
@@ -401,13 +461,22 @@ def main():
                                       'note': 'MFMA-bound part at 2.5 PFLOP/s + HBM-bound Euler part at 8 TB/s; the Euler phase is a chain of 1 400 dependent launches '
                                               '(5 per layer-step), see DESIGN.md section 3'}
             traffic, traffic_src = _pmc_traffic()
+            # two clocks for the same launch: the IN-CHAIN figure measured live (graph with the kernel - graph without it: what the chunk pays for it,
+            # its boundary included) and the kernel's own duration as rocprofv3 reports it in the committed kernel trace of this tree.  Neither bounds the other (the
+            # in-chain difference can come out BELOW the rocprof duration: removing the kernel also removes the cache state it leaves its successor); `frac` is quoted
+            # on the LARGER of the two, i.e. the lower fraction
+            rp_us, rp_src = _rocprof_duration()
+            us_used = max(avg_ms * 1e3, rp_us or 0.0)
+            ach = byts / (us_used * 1e-6) / 1e9
             line['roofline'] = {'bound': 'hbm', 'kernel': 'chain_gu_kernel (csrc/chain.hip: action-expert gate/up GEMV, residual + split-K reduce + RMSNorm -> SwiGLU, N=17920 K=768, M=4; '
                                                           '280 launches per chunk)',
                                 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
                                 'traffic': traffic, 'traffic_source': traffic_src,
-                                'bytes_per_launch': byts, 'us_per_launch': round(avg_ms * 1e3, 3), 'launches_timed': n,
-                                'timing': 'IN-CHAIN: (Euler-phase graph with the kernel - the same graph without it) / launches, HIP events on the launch stream; '
-                                          'includes the kernel boundary, so it is an upper bound of the rocprof duration in profiles/',
+                                'bytes_per_launch': byts, 'us_per_launch': round(us_used, 3), 'launches_timed': n,
+                                'us_per_launch_in_chain': round(avg_ms * 1e3, 3), 'us_per_launch_rocprof': rp_us, 'rocprof_source': rp_src,
+                                'timing': 'us_per_launch = max(in-chain, rocprof).  IN-CHAIN: (Euler-phase graph with the kernel - the same graph without it) / launches, HIP events '
+                                          'on the launch stream, measured in this run.  ROCPROF: average duration of the kernel in the committed `rocprofv3 --kernel-trace --stats` '
+                                          'summary of this tree (profiles/).  The two differ by a few per cent in either direction',
                                 'us_per_launch_isolated': round(iso_ms * 1e3, 3), 'achieved_isolated': round(byts / (iso_ms * 1e-3) / 1e9, 1)}
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(vla)
@@ -438,7 +507,8 @@ def main():
     if rank == 0:
         if sft_line is not None:
             if world == 1 and dist is None and 'error' not in sft_line and os.environ.get('VLASER_BENCH_NO_FORCED_DP') != '1':
-                sft_line['forced_dp_world1_ms'] = _forced_dp_world1(a.sft_steps)
+                # both exchange modes: torch's ProcessGroupNCCL, and RCCL's C API on a CU-masked stream with the compute streams on the complement
+                sft_line['forced_dp_world1_ms'] = {m: _forced_dp_world1(a.sft_steps, m) for m in ('pg', 'capi')}
             if world == 1 and not a.no_cpu_baseline and 'error' not in sft_line:
                 sft_line['cpu_baseline'] = sft_cpu_baseline(vla.base)
             line['sft'] = sft_line
@@ -453,11 +523,11 @@ def main():
         sys.exit(3)                                              # the headline line is out; a failed SFT sub-bench is still a failed run
 
 
-def _forced_dp_world1(steps):
+def _forced_dp_world1(steps, mode='pg'):
     """ms per SFT step with the ZeRO-1 exchange forced on at world size 1 (`VLASER_FORCE_DP=1`: every bucket goes through RCCL's reduce_scatter / all_gather with
     itself, the optimizer runs on the comm stream in front of each all-gather -- what an N-GPU rank executes, with N = 1): a CHILD bench process (the process group
     cannot be added to this one after the fact), its own line parsed; None (with the reason) when the child fails."""
-    env = dict(os.environ, VLASER_FORCE_DP='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    env = dict(os.environ, VLASER_FORCE_DP='1', VLASER_DP_EXCHANGE=mode, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), '--workload', 'sft', '--sft-steps', str(steps), '--no-cpu-baseline'], env=env, capture_output=True,
                            text=True, timeout=600)
@@ -466,6 +536,7 @@ def _forced_dp_world1(steps):
             return {'error': f'child rc {r.returncode}: ' + (r.stderr.strip().splitlines()[-1][:160] if r.stderr.strip() else 'no line')}
         d = json.loads(ln)
         return {'ms_per_step': d['ms_per_step'], 'fwd_bwd_ms': d['fwd_bwd_ms'], 'rccl_version': d['exchange'].get('rccl_version'),
+                'exchange': {k: d['exchange'].get(k) for k in ('mode', 'comm_cus', 'compute_cus', 'cu_masks') if k in d['exchange']},
                 'note': 'the whole model is this rank\'s "shard": all of AdamW sits in front of the all-gathers (1/N of it at N ranks)'}
     except Exception as e:          # noqa: BLE001 -- a side number, never a reason to lose the line
         return {'error': f'{type(e).__name__}: {e}'[:200]}
@@ -715,6 +786,21 @@ def _pmc_traffic():
         return json.load(open(path))['traffic_bytes_per_launch'], {'file': 'profiles/r05g_pmc_dominant_kernel.json', 'measured_in_run': False, 'live_attempt': err, 'how': how}
     except (OSError, KeyError, ValueError):
         return None, {'measured_in_run': False, 'live_attempt': err}
+
+
+def _rocprof_duration():
+    """Average rocprofv3 duration (us) of the dominant kernel from the newest committed record profiles/*_dominant_kernel_rocprof.json (written by
+    tools/rocprof_dominant.py from a `rocprofv3 --kernel-trace --stats` run of the chunk workload) -> (us or None, source)."""
+    import glob
+    root = os.path.dirname(os.path.abspath(__file__))
+    recs = sorted(glob.glob(os.path.join(root, 'profiles', '*_dominant_kernel_rocprof.json')))
+    if not recs:
+        return None, 'no profiles/*_dominant_kernel_rocprof.json'
+    try:
+        d = json.load(open(recs[-1]))
+        return float(d['avg_us']), {'file': 'profiles/' + os.path.basename(recs[-1]), 'calls': d.get('calls'), 'from': d.get('from')}
+    except (OSError, KeyError, ValueError) as e:
+        return None, f'{type(e).__name__}: {e}'[:120]
 
 
 def _finish(dist, line):

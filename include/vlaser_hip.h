@@ -81,6 +81,14 @@ int vlaser_gemm(int epi, const VlaserGemmArgs* args, vl_stream_t stream);
  * the CUs the mask leaves.  Without a mask a lower budget measured no gain (profiles/r05_rccl_contention.md). */
 int vlaser_set_cu_budget(int cus);
 int vlaser_get_cu_budget(void);
+/* (ABI 7) A HIP stream whose kernels may only run on CUs [first_cu, first_cu + n_cus) (hipExtStreamCreateWithCUMask).  The data-parallel SFT step's switchable
+ * exchange (`VLASER_DP_EXCHANGE=capi`, vlaser_amd/rccl_capi.py) puts RCCL's reduce-scatter / all-gather on such a stream and the forward + backward on streams masked to
+ * the complement, so that RCCL's channel workgroups never share a CU with a GEMM workgroup -- what DeepSpeed's `overlap_comm: true` comm stream
+ * (Vlaser_VLM/internvl_chat/zero_stage1_config.json, the engine behind internvl_chat_finetune.py:1041-1057) leaves to the hardware scheduler: measured x1.13 instead of
+ * x1.23-1.34 on the forward + backward beside 8-32 resident streaming workgroups (profiles/r05j_rccl_shadow_masks.md).  The caller owns the stream (wrap it with
+ * torch.cuda.ExternalStream) and destroys it with vlaser_stream_destroy. */
+int vlaser_stream_create_cumask(int first_cu, int n_cus, vl_stream_t* out);
+int vlaser_stream_destroy(vl_stream_t stream);
 
 /* NN form: out[M,N] = A[M,K] @ B[K,N], B = args->W row-major with row stride args->ldw ("k-major").  The dgrad of an nn.Linear
  * (dX = dY @ W, autograd of modeling_internvl_chat.py:194-203 / joint_model.py:410-696) reads the forward weight [N_out, K_in] as it

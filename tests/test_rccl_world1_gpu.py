@@ -48,10 +48,16 @@ def _vla(pg):
     return m, [float(o.loss) for o in outs], [float(o.grad_norm) for o in outs]
 
 
-def _worker(rank, port, out_dir):
+def _worker(rank, port, out_dir, exchange):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), VLASER_FORCE_DP='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    # the same steps with the exchange on RCCL's C API (own communicator + own stream), with and without the CU masks
+    mode, comm_cus = {'pg': ('pg', 0), 'capi': ('capi', 32), 'capi_nomask': ('capi', 0)}[exchange]
+    os.environ.update(VLASER_DP_EXCHANGE=mode, VLASER_DP_COMM_CUS=str(comm_cus))
+    if comm_cus:
+        from vlaser_amd import ops
+        ops.set_cu_budget(256 - comm_cus)          # the masked step sizes its GEMM grids (and split-K) for the CUs the mask leaves: the no-DP reference must do the same
     torch.set_grad_enabled(False)
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1)
@@ -64,6 +70,12 @@ def _worker(rank, port, out_dir):
         a, la, na = _sft(None, clip)
         b, lb, nb = _sft(dist.group.WORLD, clip)
         assert not a.dp_active and b.dp_active and b.comm_stream is not None and len(b.buckets) >= 3
+        info = b.exchange_info()
+        assert info['mode'] == mode and (b.capi is not None) == (mode == 'capi') and (b.main_stream is not None) == bool(comm_cus), info
+        if mode == 'capi':
+            assert info['comm_cus'] == comm_cus and info['compute_cus'] == 256 - comm_cus and b.comm_stream is b.capi.stream, info
+            if comm_cus:
+                assert b.opt_stream.cuda_stream not in (0, b.main_stream.cuda_stream) and b.wgrad_stream.cuda_stream != b.main_stream.cuda_stream
         res[f'sft{clip}'] = dict(same_p=torch.equal(a.fp.p, b.fp.p), same_m=torch.equal(a.m, b.m), same_v=torch.equal(a.v, b.v),
                                  same_master=torch.equal(a.master, b.master), la=la, lb=lb, na=na, nb=nb)
         if clip > 0:
@@ -77,33 +89,52 @@ def _worker(rank, port, out_dir):
             del c
         del a, b
         torch.cuda.empty_cache()
-    a, la, na = _vla(None)
-    b, lb, nb = _vla(dist.group.WORLD)
-    assert not a.dp_active and b.dp_active
-    res['vla'] = dict(same_p=torch.equal(a.fp.p, b.fp.p), same_m=torch.equal(a.m, b.m), same_v=torch.equal(a.v, b.v), same_master=torch.equal(a.master, b.master),
-                      la=la, lb=lb, na=na, nb=nb)
-    # the collectives themselves, on a ragged bucket (the padded path of dp.reduce_scatter_mean / all_gather_params)
+    if exchange == 'pg':                           # (the VLA trainer's exchange stays on the process group: the switch is the SFT step's)
+        a, la, na = _vla(None)
+        b, lb, nb = _vla(dist.group.WORLD)
+        assert not a.dp_active and b.dp_active
+        res['vla'] = dict(same_p=torch.equal(a.fp.p, b.fp.p), same_m=torch.equal(a.m, b.m), same_v=torch.equal(a.v, b.v), same_master=torch.equal(a.master, b.master),
+                          la=la, lb=lb, na=na, nb=nb)
+    # the collectives themselves, on a ragged bucket (the padded path of dp.reduce_scatter_mean / all_gather_params) and on an even one (in place)
     from vlaser_amd import dp
-    g = torch.randn(1000, device='cuda').to(torch.bfloat16)
-    g0 = g.clone()
-    shard = dp.plan_shards([(0, 1000)], 1, 0)[0]
-    dp.reduce_scatter_mean(g, (0, 1000), shard, dist.group.WORLD)
-    dp.all_gather_params(g, (0, 1000), shard, dist.group.WORLD)
-    torch.cuda.synchronize()
-    res['ragged_identity'] = torch.equal(g, g0)
+    capi = None
+    if mode == 'capi':
+        from vlaser_amd import rccl_capi
+        capi = rccl_capi.CapiExchange(dist.group.WORLD, 'cuda:0', comm_cus=comm_cus)
+        assert capi.version >= 20000
+    ok = True
+    for n in (1000, 1024):
+        g = torch.randn(n, device='cuda').to(torch.bfloat16)
+        g0 = g.clone()
+        shard = dp.plan_shards([(0, n)], 1, 0)[0]
+        if capi is not None:
+            capi.stream.wait_stream(torch.cuda.current_stream())
+        dp.reduce_scatter_mean(g, (0, n), shard, dist.group.WORLD, capi=capi)
+        dp.all_gather_params(g, (0, n), shard, dist.group.WORLD, capi=capi)
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(g, g0)
+    if capi is not None:
+        t = torch.tensor([3.5], device='cuda')
+        capi.stream.wait_stream(torch.cuda.current_stream())
+        capi.all_reduce_sum(t)
+        torch.cuda.synchronize()
+        ok = ok and t.item() == 3.5
+        capi.destroy()
+    res['ragged_identity'] = ok
     torch.save(res, os.path.join(out_dir, 'res.pt'))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(900)
-def test_rccl_world1_steps_are_bit_identical_to_no_dp(tmp_path):
+@pytest.mark.parametrize('exchange', ['pg', 'capi', 'capi_nomask'])
+def test_rccl_world1_steps_are_bit_identical_to_no_dp(tmp_path, exchange):
     import torch.multiprocessing as mp
-    port = 29900 + (os.getpid() % 50)
-    mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    port = 29900 + (os.getpid() % 50) + {'pg': 0, 'capi': 50, 'capi_nomask': 100}[exchange]
+    mp.spawn(_worker, args=(port, str(tmp_path), exchange), nprocs=1, join=True)
     res = torch.load(tmp_path / 'res.pt')
     assert res['ragged_identity']
-    for k in ('sft0.0', 'sft1.0', 'sft_serial_adamw', 'vla'):
+    for k in ('sft0.0', 'sft1.0', 'sft_serial_adamw') + (('vla',) if exchange == 'pg' else ()):
         r = res[k]
         assert r['la'] == r['lb'], (k, r)                                     # losses bit-equal
         assert r['na'] == r['nb'], (k, r)                                     # gradient norms: same shard order, all-reduce over one rank

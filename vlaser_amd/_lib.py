@@ -56,6 +56,8 @@ _SIGS = {
     'vlaser_gemm_nn': [i32, C.POINTER(GemmArgs), vp],
     'vlaser_set_cu_budget': [i32],
     'vlaser_get_cu_budget': [],
+    'vlaser_stream_create_cumask': [i32, i32, C.POINTER(vp)],
+    'vlaser_stream_destroy': [vp],
     'vlaser_attn_prefill': [C.POINTER(AttnArgs), vp],
     'vlaser_attn_skinny': [C.POINTER(AttnArgs), vp],
     'vlaser_attn_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, i32, vp],

@@ -17,6 +17,7 @@ Parameters live in ONE flat bf16 buffer in kernel layout (q/k/v fused+permuted, 
 [lm_head, final norm, layer L-1 ... layer 0, embed_tokens, mlp1] so gradient buckets complete front to back.
 """
 import math
+import contextlib
 import os
 from types import SimpleNamespace
 
@@ -274,14 +275,54 @@ class SFTModel:
         self.pos_all = torch.arange(S, dtype=torch.int32, device=dev)
         self.gacc = None                                            # fp32 gradient accumulator (allocated by the first multi-sample step)
         self._alloc_projector_ws()
-        self.comm_stream = torch.cuda.Stream(device=dev) if self.dp_active else None
+        # The exchange (data parallel only).  VLASER_DP_EXCHANGE=pg (default): torch's ProcessGroupNCCL from a comm stream.  =capi: RCCL's C API on a communicator and a
+        # stream of this package's own (rccl_capi.py), that stream CU-masked to the last VLASER_DP_COMM_CUS CUs (default 32; 0 = no masks) and EVERY compute stream of the
+        # step (main, weight gradients, optimizer) masked to the rest -- RCCL's channel workgroups then never share a CU with a GEMM workgroup (x1.13 instead of
+        # x1.23-1.34 on the forward + backward in the one-GPU stand-in, profiles/r05j_rccl_shadow_masks.md).  The GEMM tile heuristics count on the CUs the mask leaves.
+        self.exchange_mode = os.environ.get('VLASER_DP_EXCHANGE', 'pg') if self.dp_active else 'none'
+        if self.exchange_mode not in ('pg', 'capi', 'none'):
+            raise ValueError(f'VLASER_DP_EXCHANGE={self.exchange_mode!r}: pg | capi')
+        self.capi, self.main_stream, mask = None, None, None
+        if self.exchange_mode == 'capi':
+            from . import rccl_capi
+            self.capi = rccl_capi.CapiExchange(self.pg, dev, comm_cus=int(os.environ.get('VLASER_DP_COMM_CUS', '32')))
+            self.comm_stream = self.capi.stream
+            mask = self.capi.compute_mask()
+            if mask is not None:
+                self.main_stream = rccl_capi.masked_stream(*mask)
+                ops.set_cu_budget(mask[1])
+        else:
+            self.comm_stream = torch.cuda.Stream(device=dev) if self.dp_active else None
+        mk = (lambda **kw: rccl_capi.masked_stream(*mask)) if mask is not None else (lambda **kw: torch.cuda.Stream(device=dev, **kw))
         # single rank: AdamW (HBM-bound, a third of a step) runs on its own stream bucket by bucket in the order the next forward
         # consumes the parameters, so the next step's frozen-ViT / early-layer GEMMs (MFMA-bound) overlap it
-        self.opt_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get('VLASER_SFT_OPT_PRIORITY', '0')))
+        self.opt_stream = mk(priority=int(os.environ.get('VLASER_SFT_OPT_PRIORITY', '0')))
         # r04: the layer weight gradients run on a stream of their own.  dW = dY^T X depends on dY only, nothing in the backward chain depends on it, and most
         # of the chain's launches are single-round grids of 108-252 workgroups on 256 CUs (tools/micro/sft_timeline.py): the weight-gradient GEMMs fill the gaps
         self._slab_norm = os.environ.get('VLASER_SFT_NO_SLAB_NORM') != '1'      # A/B: reduce the gate/up dgrad's slabs in their own launch again
-        self.wgrad_stream = None if os.environ.get('VLASER_SFT_NO_WGRAD_STREAM') == '1' else torch.cuda.Stream(device=dev)
+        self.wgrad_stream = None if os.environ.get('VLASER_SFT_NO_WGRAD_STREAM') == '1' else mk()
+
+    def exchange_info(self):
+        """What the step's exchange runs on (bench.py puts it on the line as `sft.exchange.mode` ...)."""
+        info = {'mode': self.exchange_mode}
+        if self.capi is not None:
+            m = self.capi.compute_mask()
+            info.update({'comm_cus': self.capi.comm_cus, 'compute_cus': m[1] if m else self.capi.total_cus, 'rccl_version_capi': self.capi.version,
+                         'cu_masks': m is not None})
+        return info
+
+    @contextlib.contextmanager
+    def _on_main(self):
+        """capi mode with CU masks: the step's launches go to the masked main stream, ordered behind the caller's stream at entry and in front of it at exit."""
+        ms = self.main_stream
+        cur = torch.cuda.current_stream()
+        if ms is None or cur == ms:
+            yield
+            return
+        ms.wait_stream(cur)
+        with torch.cuda.stream(ms):
+            yield
+        cur.wait_stream(ms)
 
     def _alloc_projector_ws(self):
         """Projector (mlp1) workspaces, sized for `max_tiles` tiles x 256 visual tokens."""
@@ -490,20 +531,21 @@ class SFTModel:
         """Loss + gradients of ONE sample.  The ~850 launches of the call all go to the stream that is current at entry: its handle is looked up once and
         pinned for the C-ABI launches (`torch.cuda.current_stream()` per launch was 30 % of the call's host time: tools/micro/sft_host_profile.py); the
         bucket callbacks, which switch streams themselves, run with the pin lifted."""
-        main = torch.cuda.current_stream().cuda_stream
-        prev = ops.pin_stream(main)
-        cb = on_bucket_ready
-        if cb is not None:
-            def on_bucket_ready(b, _cb=cb):
+        with self._on_main():
+            main = torch.cuda.current_stream().cuda_stream
+            prev = ops.pin_stream(main)
+            cb = on_bucket_ready
+            if cb is not None:
+                def on_bucket_ready(b, _cb=cb):
+                    ops.pin_stream(prev)
+                    try:
+                        _cb(b)
+                    finally:
+                        ops.pin_stream(main)
+            try:
+                return self._forward_backward(pixel_values, input_ids, labels, image_flags, on_bucket_ready)
+            finally:
                 ops.pin_stream(prev)
-                try:
-                    _cb(b)
-                finally:
-                    ops.pin_stream(main)
-        try:
-            return self._forward_backward(pixel_values, input_ids, labels, image_flags, on_bucket_ready)
-        finally:
-            ops.pin_stream(prev)
 
     def _forward_backward(self, pixel_values, input_ids, labels, image_flags=None, on_bucket_ready=None):
         cfg, llm, dev = self.cfg, self.llm, self.device
@@ -802,9 +844,13 @@ class SFTModel:
         ev.record()
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(ev)
-            dp.reduce_scatter_mean(self.fp.g, self.buckets[b], self.shards[b], self.pg)
+            dp.reduce_scatter_mean(self.fp.g, self.buckets[b], self.shards[b], self.pg, capi=self.capi)
 
     def optimizer_step(self, lr=None):
+        with self._on_main():
+            return self._optimizer_step(lr)
+
+    def _optimizer_step(self, lr=None):
         lr = self.lr if lr is None else lr
         self.step_count += 1
         if self.dp_active:
@@ -818,7 +864,11 @@ class SFTModel:
             for (s_lo, s_hi, _) in self.shards:
                 if s_hi > s_lo:
                     ops.sumsq(self.fp.g[s_lo:s_hi], self.gnorm2, self.sumsq_ws)
-        if self.dp_active:
+        if self.capi is not None:                                  # the 4-byte sum on the package's own communicator / stream too
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            self.capi.all_reduce_sum(self.gnorm2)
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        elif self.dp_active:
             torch.distributed.all_reduce(self.gnorm2, group=self.pg)
         gnorm = self.gnorm2.sqrt()                                  # device tensor: reading it is the caller's (only) sync
 
@@ -854,7 +904,7 @@ class SFTModel:
                 self.comm_stream.wait_event(ev)
                 for b in reversed(range(len(self.buckets))):
                     adamw_bucket(b)
-                    dp.all_gather_params(self.fp.p, self.buckets[b], self.shards[b], self.pg)
+                    dp.all_gather_params(self.fp.p, self.buckets[b], self.shards[b], self.pg, capi=self.capi)
                     self.ag_events[b] = torch.cuda.Event()
                     self.ag_events[b].record()
             return gnorm
@@ -867,7 +917,7 @@ class SFTModel:
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
                 for b in reversed(range(len(self.buckets))):
-                    dp.all_gather_params(self.fp.p, self.buckets[b], self.shards[b], self.pg)
+                    dp.all_gather_params(self.fp.p, self.buckets[b], self.shards[b], self.pg, capi=self.capi)
                     self.ag_events[b] = torch.cuda.Event()
                     self.ag_events[b].record()
             if not self.overlap_allgather:
@@ -947,6 +997,10 @@ class SFTModel:
         return self._run_weighted(work, lr)
 
     def _run_weighted(self, work, lr):
+        with self._on_main():
+            return self._run_weighted_main(work, lr)
+
+    def _run_weighted_main(self, work, lr):
         """Samples (pixel_values, ids, labels, image_flags, weight) -> accumulated weighted gradients -> exchange -> optimizer step."""
         self._norm_early = False                   # only trusted when THIS step's backward queued every bucket's partial norm (below)
         if len(work) == 1 and work[0][4] == 1.0:
