@@ -8,6 +8,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form tools/micro/mfma_shape_lab.hip -o tools/micro/mfma_shape_lab && tools/micro/mfma_shape_lab
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <cstdint>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -21,11 +22,22 @@ __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + (
 //   1 = the product's form: per piece a 64-bit per-lane pointer + the K offset (2 VALU), s_mov m0 + s_nop, global_load_lds_dwordx4 v[ptr], off
 //   2 = scalar base + 32-bit per-lane offset, ONE m0 write per 4 pieces, the piece's LDS / global displacement in the instruction's immediate offset
 //       (global_load_lds_dwordx4 v_off, s[base:base+1] offset:1024 i; the immediate moves BOTH addresses -- probed below -- so v_off carries -1024 i)
-template <int SHAPE, bool READS, bool MFMAS, bool BARRIER, int DMA = 0, int FLY = 0, bool CONTIG = false, bool SHARED = false>      // FLY: refills (of 7 pieces) that may still be in flight at the top of a step; CONTIG: a piece = 1 KiB contiguous in memory (pre-tiled operand) instead of 8 rows x 128 B
+// FLY: refills (of 7 pieces) that may still be in flight at the top of a step; CONTIG: a piece = 1 KiB contiguous in memory (pre-tiled operand) instead of 8 rows x 128 B
+__device__ int g_random_fill = 0;      // r06: 1 = full-range random bf16 operands in [-1, 1) instead of the near-constant pattern (DVFS: guide 5.4 rule 25)
+__device__ __forceinline__ uint32_t lab_rnd_pair(uint32_t i) {
+  uint32_t h = i * 2654435761u ^ 0x9e3779b9u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+  const float a = ((h & 0xffff) / 32768.0f - 1.0f), b = ((h >> 16) / 32768.0f - 1.0f);
+  return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u);
+}
+template <int SHAPE, bool READS, bool MFMAS, bool BARRIER, int DMA, int FLY, bool CONTIG, bool SHARED>
 __global__ __launch_bounds__(512) void lab_kernel(int steps, float* sink, const char* gsrc = nullptr) {
   __shared__ __attribute__((aligned(16))) char smem[(192 + 256) * 128 + (DMA ? 8 * 7 * 1024 : 0)];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 2, wc = wave & 3;
-  for (int i = tid; i < (192 + 256) * 8; i += 512) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0x3c003c00u + i, 0x3c003c00u, 0x3c013c00u, 0x3c003c02u};
+  if (g_random_fill) {
+    for (int i = tid; i < (192 + 256) * 8; i += 512) reinterpret_cast<u32x4*>(smem)[i] = u32x4{lab_rnd_pair(4 * i), lab_rnd_pair(4 * i + 1), lab_rnd_pair(4 * i + 2), lab_rnd_pair(4 * i + 3)};
+  } else {
+    for (int i = tid; i < (192 + 256) * 8; i += 512) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0x3c003c00u + i, 0x3c003c00u, 0x3c013c00u, 0x3c003c02u};
+  }
   __syncthreads();
   const char* As = smem;
   const char* Ws = smem + 192 * 128;
@@ -168,9 +180,15 @@ static void run(const char* what, float* sink, const char* gsrc = nullptr) {
   printf("| %dx%d | %s | %s | %.3f | %s |\n", SHAPE, SHAPE, what, BARRIER ? "yes" : "no", us_step, MFMAS ? (char*)([&] { static char b[32]; snprintf(b, 32, "%.0f", tflops); return b; }()) : "");
 }
 
-int main() {
+int main(int argc, char** argv) {
   float* sink;
   hipMalloc((void**)&sink, 256 * 4);
+  const bool random_fill = argc > 1 && !strcmp(argv[1], "random");
+  if (random_fill) {
+    int one = 1;
+    hipMemcpyToSymbol(HIP_SYMBOL(g_random_fill), &one, sizeof(int));
+    printf("operands: full-range random bf16 in [-1, 1) (accumulators grow like a random walk: no overflow in 4 800 steps)\n\n");
+  } else printf("operands: the near-constant pattern of r05 (1.0 +- a few ulp)\n\n");
   printf("| MFMA shape | per K-step (192x256x64 tile, 8 waves) | barrier per K-step | us per K-step | TFLOP/s (256 CUs) |\n|---|---|---|---|---|\n");
   run<16, true, true, true>("fragment reads + MFMAs (the product loop's structure)", sink);
   run<32, true, true, true>("fragment reads + MFMAs", sink);
@@ -180,6 +198,7 @@ int main() {
   run<32, false, true, false>("MFMAs only", sink);
   run<16, true, false, false>("fragment reads only", sink);
   run<32, true, false, false>("fragment reads only", sink);
+  if (random_fill) return 0;
   // the immediate offset's meaning
   uint32_t *psrc, *pout;
   hipMalloc((void**)&psrc, 8192 * 4); hipMalloc((void**)&pout, 2048 * 4);

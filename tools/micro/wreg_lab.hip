@@ -45,10 +45,13 @@ struct LabP {
   int M, N, K, tiles_m, tiles_n;
 };
 
-// BM x 256 tile, WM x 4 waves, NSTA A stages in LDS, W ring of D K-steps in registers (D <= NSTA - 1).  Fragment-major W: [N / 16][K / 64][2 halves][64 lanes][16 B].
-template <int BM, int WM, int NSTA, int D, bool SPREAD>
-__global__ __launch_bounds__(WM * 4 * 64) void wreg_kernel(LabP p) {
-  constexpr int BNT = 256, WN = 4, NW = WM * WN, WTM = BM / WM, MT = WTM / 16, NT = 4, NPA = BM / 8, PA = (NPA + NW - 1) / NW, GRP = PA + 2 * NT;
+// BM x 256 tile, WM x WN waves, NSTA A stages in LDS, W ring of D K-steps in registers (D <= NSTA - 1).  Fragment-major W: [N / 16][K / 64][2 halves][64 lanes][16 B].
+// WM = 2, WN = 4 (the product's wave grid): the two M-waves of a tile column both fetch the column's W fragments -- 64 KB of W requests per K-step and CU for 32 KB of data.
+// WM = 1, WN = 8 (second table): every wave owns ALL BM rows of 32 columns -- each W fragment is fetched by exactly one wave (32 KB per step), a wave's ring is 16 registers
+// per K-step of depth, and every wave reads the whole A tile out of LDS (the same LDS read volume as 2 x 4: 8 waves x BM x 128 B).
+template <int BM, int WM, int NSTA, int D, bool SPREAD, int WN = 4>
+__global__ __launch_bounds__(WM * WN * 64) void wreg_kernel(LabP p) {
+  constexpr int BNT = 256, NW = WM * WN, WTM = BM / WM, MT = WTM / 16, WTN = BNT / WN, NT = WTN / 16, NPA = BM / 8, PA = (NPA + NW - 1) / NW, GRP = PA + 2 * NT;
   static_assert(D <= NSTA - 1 && (D - 1) * GRP <= 63, "ring depths");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave / WN, wc = wave % WN, fr = lane & 15, fq = lane >> 4;
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(WM * 4 * 64) void wreg_kernel(LabP p) {
   uint32_t voff[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) voff[t] = (uint32_t)(min(n0 / 16 + wc * NT + t, p.N / 16 - 1)) * (uint32_t)(nk * 2048) + lane * 16;
+  static_assert(PA <= 2 * NT, "the spread form hangs one A piece behind each MFMA group");
   bf16x8 w[D][2 * NT];
   f32x4 acc[NT][MT];
 #pragma unroll
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(WM * 4 * 64) void wreg_kernel(LabP p) {
     if (m < p.M) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
+        const int n = n0 + wc * WTN + nt * 16 + fq * 4;
         if (n < p.N) *reinterpret_cast<u32x2*>(p.out + (size_t)m * p.N + n) = u32x2{pack_bf16x2(acc[nt][mt][0], acc[nt][mt][1]), pack_bf16x2(acc[nt][mt][2], acc[nt][mt][3])};
       }
     }
@@ -170,14 +174,14 @@ __global__ void count_diff(const bf16_t* a, const bf16_t* b, size_t n, unsigned*
   if (c) atomicAdd(out, c);
 }
 
-template <int BM, int WM, int NSTA, int D, bool SPREAD>
+template <int BM, int WM, int NSTA, int D, bool SPREAD, int WN = 4>
 static void launch_lab(const LabP& p0, hipStream_t s) {
   LabP p = p0;
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + 255) / 256;
   constexpr int lds = NSTA * BM * 128;
   static bool once = false;
-  if (!once) { CK(hipFuncSetAttribute((const void*)wreg_kernel<BM, WM, NSTA, D, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); once = true; }
-  hipLaunchKernelGGL((wreg_kernel<BM, WM, NSTA, D, SPREAD>), dim3(p.tiles_m * p.tiles_n), dim3(WM * 4 * 64), lds, s, p);
+  if (!once) { CK(hipFuncSetAttribute((const void*)wreg_kernel<BM, WM, NSTA, D, SPREAD, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); once = true; }
+  hipLaunchKernelGGL((wreg_kernel<BM, WM, NSTA, D, SPREAD, WN>), dim3(p.tiles_m * p.tiles_n), dim3(WM * WN * 64), lds, s, p);
 }
 
 int main(int argc, char** argv) {
@@ -187,16 +191,22 @@ int main(int argc, char** argv) {
   const Shape shapes[] = {{3408, 8192, 3584, "8B-sized (VERDICT r05 #1)", 0}, {3408, 8192, 3456, "the same, K = 54 steps (D = 3 divides)", 0}, {560, 17920, 1536, "SFT forward gate/up", 0},
                           {384, 17920, 1536, "chunk prefill gate/up", 0}, {1025, 4096, 1024, "ViT fc1", 0}};
   const int NL = 8;
+  // `wreg_lab zero`: zero-filled operands (the DVFS uplift of guide 5.4 rule 25 on the same kernels: clock, not work); `wreg_lab <n>`: only the first n shapes
+  const bool zero_fill = argc > 1 && !strcmp(argv[1], "zero");
+  const float fs = zero_fill ? 0.f : 1.f;
+  printf("operands: %s\n\n", zero_fill ? "ZERO-filled" : "full-range random bf16");
   unsigned* dcnt; CK(hipMalloc(&dcnt, 4));
   printf("| shape (M x N x K) | kernel | us per launch | TFLOP/s | us per K-step of the busiest CU | differs from the product in |\n|---|---|---|---|---|---|\n");
+  int n_shapes = zero_fill ? 1 : 100;
   for (const Shape& sh : shapes) {
+    if (n_shapes-- <= 0) break;
     const int M = sh.M, N = sh.N, K = sh.K;
     bf16_t *x, *w[NL], *wp[NL], *out, *ref;
     CK(hipMalloc(&x, (size_t)M * K * 2)); CK(hipMalloc(&out, (size_t)M * N * 2)); CK(hipMalloc(&ref, (size_t)M * N * 2));
-    fill_bf16<<<1024, 256, 0, s>>>(x, (size_t)M * K, 1, 1.0f);
+    fill_bf16<<<1024, 256, 0, s>>>(x, (size_t)M * K, 1, 1.0f * fs);
     for (int i = 0; i < NL; ++i) {
       CK(hipMalloc(&w[i], (size_t)N * K * 2)); CK(hipMalloc(&wp[i], (size_t)N * K * 2));
-      fill_bf16<<<1024, 256, 0, s>>>(w[i], (size_t)N * K, 100 + i, 0.03f);
+      fill_bf16<<<1024, 256, 0, s>>>(w[i], (size_t)N * K, 100 + i, 0.03f * fs);
       pack_w<<<2048, 256, 0, s>>>(w[i], wp[i], N, K);
     }
     const double fl = 2.0 * M * N * K;
@@ -250,6 +260,14 @@ int main(int argc, char** argv) {
     lab("W in VGPRs: 128x256, A 5 stages, W ring 4, spread", 128, [](const LabP& q, hipStream_t st) { launch_lab<128, 2, 5, 4, true>(q, st); }, nk % 4 == 0);
     lab("W in VGPRs: 128x256, A 8 stages, W ring 3, spread", 128, [](const LabP& q, hipStream_t st) { launch_lab<128, 2, 8, 3, true>(q, st); }, nk % 3 == 0);
     lab("W in VGPRs: 128x256, A 8 stages, W ring 2, spread", 128, [](const LabP& q, hipStream_t st) { launch_lab<128, 2, 8, 2, true>(q, st); }, nk % 2 == 0);
+    // one wave per 32 columns over ALL rows: no duplicate W fetch
+    lab("W in VGPRs, 1 x 8 waves: 128x256, A 9 stages, W ring 4", 128, [](const LabP& q, hipStream_t st) { launch_lab<128, 1, 9, 4, true, 8>(q, st); }, nk % 4 == 0);
+    lab("W in VGPRs, 1 x 8 waves: 128x256, A 9 stages, W ring 2", 128, [](const LabP& q, hipStream_t st) { launch_lab<128, 1, 9, 2, true, 8>(q, st); }, nk % 2 == 0);
+    lab("W in VGPRs, 1 x 8 waves: 128x256, A 5 stages, W ring 4", 128, [](const LabP& q, hipStream_t st) { launch_lab<128, 1, 5, 4, true, 8>(q, st); }, nk % 4 == 0);
+    lab("W in VGPRs, 1 x 8 waves: 128x256, A 9 stages, W ring 6", 128, [](const LabP& q, hipStream_t st) { launch_lab<128, 1, 9, 6, true, 8>(q, st); }, nk % 6 == 0);
+    lab("W in VGPRs, 1 x 8 waves: 192x256, A 6 stages, W ring 4", 192, [](const LabP& q, hipStream_t st) { launch_lab<192, 1, 6, 4, true, 8>(q, st); }, nk % 4 == 0);
+    lab("W in VGPRs, 1 x 8 waves: 192x256, A 6 stages, W ring 2", 192, [](const LabP& q, hipStream_t st) { launch_lab<192, 1, 6, 2, true, 8>(q, st); }, nk % 2 == 0);
+    lab("W in VGPRs, 1 x 8 waves: 64x256, A 9 stages, W ring 4", 64, [](const LabP& q, hipStream_t st) { launch_lab<64, 1, 9, 4, true, 8>(q, st); }, nk % 4 == 0);
     CK(hipFree(x)); CK(hipFree(out)); CK(hipFree(ref));
     for (int i = 0; i < NL; ++i) { CK(hipFree(w[i])); CK(hipFree(wp[i])); }
   }

@@ -43,7 +43,7 @@ def _find_rccl():
 
 
 class _UniqueId(C.Structure):
-    _fields_ = [('internal', C.c_char * UNIQUE_ID_BYTES)]
+    _fields_ = [('internal', C.c_ubyte * UNIQUE_ID_BYTES)]       # (c_ubyte, not c_char: a c_char array field reads back truncated at its first NUL)
 
 
 def rccl():
@@ -93,9 +93,10 @@ class CapiExchange:
         uid = _UniqueId()
         if self.rank == 0:
             _ck(lib.ncclGetUniqueId(C.byref(uid)), 'ncclGetUniqueId')
-        box = [bytes(uid.internal) if self.rank == 0 else None]
+        box = [C.string_at(C.byref(uid), UNIQUE_ID_BYTES) if self.rank == 0 else None]
         # the id travels over the group that already exists (rank 0 of the GROUP is the source)
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group, device=self.device if dist.get_backend(group) == 'nccl' else None)
+        assert len(box[0]) == UNIQUE_ID_BYTES
         C.memmove(C.byref(uid), box[0], UNIQUE_ID_BYTES)
         self.comm = C.c_void_p()
         with torch.cuda.device(self.device):
