@@ -276,10 +276,13 @@ int vlaser_small_linear(const float* x, const void* w, const void* b, void* out,
 /* (ABI 5) ring (nullable): the updated actions are ALSO written to slot (ring_ctr[0] mod ring_n) of `ring` (ring_stride floats per slot), so that the host
  * surface can hand out a view of the result instead of launching a copy (the reference returns a fresh tensor: pizero_internvl.py:934-936).
  * (ABI 6) ring_ctr = int32[3] = VlaserVlaStageArgs.call_ctr: {call number k, error word of even calls, error word of odd calls}; when this call's error word
- * (ring_ctr[1 + (k & 1)]) is non-zero the ring copy is NaN: a dense mask the kernels cannot honour is never served silently. */
+ * (ring_ctr[1 + (k & 1)]) is non-zero the ring copy is NaN: a dense mask the kernels cannot honour is never served silently.
+ * (ABI 7) method: the reference's `integration_method` (pizero_internvl.py:164,910-922, `integration_step` :1309-1331): 0 euler a + dt v, 1 heun a + (0.5 dt)(v + v),
+ * 2 rk4 a + (dt / 6)(((v + 2 v) + 2 v) + v) -- the reference's model_step returns this step's decoder output whatever it is handed, so the higher-order methods re-combine
+ * ONE velocity (golden G7c).  `dt` is then the method's coefficient (dt | 0.5 dt | dt / 6), rounded from double by the caller. */
 int vlaser_vla_euler(const void* h_in, const float* partials, int n_partials, int M, const void* norm_w, float eps, const void* wd,
                      const void* bd, float* action, int W, int adim, float dt, float clip, int do_clip, float* vel_out, float* ring, const int* ring_ctr,
-                     int ring_n, int ring_stride, vl_stream_t stream);
+                     int ring_n, int ring_stride, int method, vl_stream_t stream);
 /* (ABI 5) Every per-call input of PiZero.infer_action (pizero_internvl.py:798-808: input_ids, pixel_values, proprios; :879-881 the noise the reference
  * draws inside) into the static input slots of the captured chunk graph in ONE launch: ids int64 [B, T] copied; valid_out[b] = valid_in[b] (int32, or int64
  * when valid_is_i64) or, with valid_in null, the number of ids != pad_id in row b; proprio / noise fp32 copied; pixels -> bf16 (pix_dtype 0: bf16 copy,
@@ -315,7 +318,7 @@ int vlaser_vla_stage(const VlaserVlaStageArgs* args, vl_stream_t stream);
  * (fp32 [W], this step's row).  h_out [M, W] bf16 = linear_3's output.  a_in / a_out must differ when finish != 0.  W multiple of 256, <= 1024. */
 int vlaser_vla_step(const void* h_in, const float* partials, int n_partials, int rows_in, int row_off, const void* norm_w, float eps, const void* wd,
                     const void* bd, const float* a_in, float* a_out, float* vel_out, float dt, int finish, const float* w21, const float* cs, const void* w3,
-                    const void* b3, void* h_out, int M, int W, int adim, vl_stream_t stream);
+                    const void* b3, void* h_out, int M, int W, int adim, int method /* (ABI 7) as vlaser_vla_euler's; dt = the method's coefficient */, vl_stream_t stream);
 int vlaser_cast_f32_bf16(const float* x, void* y, long long n, vl_stream_t stream);
 /* uint8 image -> normalised bf16 pixel_values [n_img, 3, H, W] (ABI 4).  Replaces the host-side fp32 normalisation of
  * InternVLAProcessor.__call__ (Vlaser_VLA/Simpler/src/model/vla/processing.py:51-63,303-311; mode 0: (u8 * (1/255) - mean) / std) and of

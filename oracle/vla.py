@@ -138,6 +138,18 @@ def joint_forward(sd, vla, hs, pos, mask, caches, final_skip=('vlm', 'proprio'),
     return (out, per_layer) if return_layers else out
 
 
+def integration_step(action, delta_t, vel, method='euler'):
+    """pizero_internvl.py:910-922 + `integration_step` :1309-1331.  The reference hands integration_step a `model_step(x, tt)` that ignores both arguments and returns the
+    decoder output of THIS step's joint pass (:914-917): k1 = k2 = k3 = k4 = vel, so heun and rk4 re-combine one velocity with their own rounding."""
+    if method == 'euler':
+        return action + delta_t * vel
+    if method == 'heun':
+        return action + 0.5 * delta_t * (vel + vel)
+    if method == 'rk4':
+        return action + (delta_t / 6.0) * (vel + 2 * vel + 2 * vel + vel)
+    raise ValueError(f'Unknown integration method: {method}')
+
+
 def infer_action(sd, vla, input_ids, pixel_values, image_text_proprio_mask, action_mask, vlm_position_ids,
                  proprio_position_ids, action_position_ids, proprios, noise, return_trace=False):
     """PiZero.infer_action (pizero_internvl.py:798-936) with the noise as an explicit input."""
@@ -159,7 +171,7 @@ def infer_action(sd, vla, input_ids, pixel_values, image_text_proprio_mask, acti
         out = joint_forward(sd, vla, {'action': ae}, {'action': action_position_ids}, action_mask, caches,
                             final_skip=())['action']
         vel = F.linear(out, sd['action_decoder.weight'], sd['action_decoder.bias'])
-        action = action + dt_step * vel
+        action = integration_step(action, dt_step, vel, getattr(vla, 'integration_method', 'euler'))
         t = t + dt_step
         if return_trace:
             trace.append((action.clone(), vel.clone()))

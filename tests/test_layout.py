@@ -151,10 +151,12 @@ def test_bad_arguments_return_errors_not_crashes():
     assert lib.vlaser_attn_bwd(P, P, P, P, P, P, P, P, P, P, 64, 12, 2, 128, 0.1, 1, 64, 64, None) != 0           # head_dim other than 128 is refused
     assert b'head_dim 64' in lib.vlaser_last_error()
     # one launch between two passes through the expert: width not a multiple of 256; finishing in place
-    assert lib.vlaser_vla_step(None, None, 0, 4, 0, None, 1e-6, None, None, P, P, None, 0.1, 0, P, P, P, P, P, 4, 700, 7, None) != 0
+    assert lib.vlaser_vla_step(None, None, 0, 4, 0, None, 1e-6, None, None, P, P, None, 0.1, 0, P, P, P, P, P, 4, 700, 7, 0, None) != 0
     assert b'multiple of 256' in lib.vlaser_last_error()
-    assert lib.vlaser_vla_step(P, None, 0, 4, 0, P, 1e-6, P, P, P, P, None, 0.1, 1, P, P, P, P, P, 4, 768, 7, None) != 0
+    assert lib.vlaser_vla_step(P, None, 0, 4, 0, P, 1e-6, P, P, P, P, None, 0.1, 1, P, P, P, P, P, 4, 768, 7, 0, None) != 0
     assert b'distinct action buffers' in lib.vlaser_last_error()
+    assert lib.vlaser_vla_step(None, None, 0, 4, 0, None, 1e-6, None, None, P, P, None, 0.1, 0, P, P, P, P, P, 4, 768, 7, 3, None) != 0      # (ABI 7) integration method 0 | 1 | 2
+    assert b'method' in lib.vlaser_last_error()
 
 
 def test_chain_gu_predicate_mirrors_the_dispatch_table():
@@ -315,7 +317,7 @@ def test_golden_manifest_matches_directory():
     src = open(os.path.join(ROOT, 'tools', 'gen_golden.py')).read()
     main = src[src.index('def main():'):]
     default_path = main[main.index("t_start = time.time()"):]
-    for fn in ('g1_prompts(', 'g2_tiling(', 'g3_g4(', 'g5_g6(', 'g6b_ragged(', 'g7_vla(', 'g7b_trace(', 'g10_flow_matching(', 'g10b_flow_matching_vlm(',
+    for fn in ('g1_prompts(', 'g2_tiling(', 'g3_g4(', 'g5_g6(', 'g6b_ragged(', 'g7_vla(', 'g7b_trace(', 'g7c_integrators(', 'g10_flow_matching(', 'g10b_flow_matching_vlm(',
                'g8_sft_grads(', 'g11_packed('):
         assert fn in default_path, f'{fn} missing from the default path of tools/gen_golden.py'
 

@@ -290,6 +290,31 @@ def test_infer_action_vs_golden(pz, golden_dir):
         assert torch.equal(act, act2)
 
 
+def test_infer_action_integration_methods_vs_golden(golden_model, golden_dir):
+    """VERDICT r05 missing #6: `integration_method` heun / rk4 (pizero_internvl.py:164,910-922,1309-1331) against the reference's own chunks (golden G7c) at the Euler
+    tolerance, and against this path's own Euler chunk: heun bit-identical (the reference's is too), rk4 within a few fp32 ulp (the reference: 2.4e-7)."""
+    import dataclasses
+    from vlaser_amd.pizero import PiZeroInference
+    cfg, vla, sd = golden_model
+    d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))
+    c = np.load(os.path.join(golden_dir, 'g7c_integrators.npz'))
+    got = {}
+    for method in ('euler', 'heun', 'rk4'):
+        m = PiZeroInference(dataclasses.replace(vla, integration_method=method), max_batch=1)
+        m.load_state_dict(sd)
+        for case in ('a', 'b'):
+            ids, pv, m1, m2, vp, pp, ap, pro, noise = _vla_inputs(d, case, m)
+            act = m.infer_action(ids, pv, m1, m2, vp, pp, ap, pro, noise=noise).cpu()
+            got[method, case] = act
+            parity(f'action chunk {case}, integration_method={method} vs golden G7c max|err|', (act - torch.from_numpy(c[f'{case}_{method}_action'])).abs().max().item(), TOL['action'])
+        del m
+    for case in ('a', 'b'):
+        assert torch.equal(got['heun', case], got['euler', case])
+        assert (got['rk4', case] - got['euler', case]).abs().max().item() < 2e-6
+    with pytest.raises(ValueError, match='Unknown integration method'):
+        dataclasses.replace(vla, integration_method='midpoint')
+
+
 def test_infer_action_internals_vs_reference_trace(pz, golden_dir):
     """VERDICT r01 #3a/b: the action chunk within 1e-2 (and relative to the model-dependent part of the signal, action - clip(noise)),
     the decoder velocity of EVERY Euler step, and the cached K / V of the first and last layer (VLM positions + proprio token)

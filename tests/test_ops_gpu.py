@@ -745,6 +745,15 @@ def test_vla_glue(ops):
     vref = (y @ wd.float().t() + bd.float())
     close(vel, vref, rtol=1e-2, atol=5e-3, name='vel')
     close(act, a0 + 0.1 * vel, rtol=1e-5, atol=1e-6, name='euler')
+    # r06: the reference's other integration methods (pizero_internvl.py:1309-1331) re-combine ONE velocity per step: the update is torch's arithmetic BIT FOR BIT
+    # (every product and sum rounded separately), from the same decoder output
+    from oracle.vla import integration_step
+    for method in ('heun', 'rk4'):
+        a1 = a0.clone(); v1 = torch.zeros(M, adim, device='cuda')
+        ops.vla_euler(h, parts, 3, M, nw, 1e-6, wd, bd, a1, W, adim, 0.1, 1.0, False, v1, method=method)
+        assert torch.equal(v1, vel), method
+        assert torch.equal(a1.cpu(), integration_step(a0.cpu(), 0.1, vel.cpu(), method)), method
+    assert torch.equal(integration_step(a0.cpu(), 0.1, vel.cpu(), 'heun'), a0.cpu() + 0.1 * vel.cpu())        # heun == euler exactly (a power-of-two rescaling)
 
 
 @pytest.mark.parametrize('bm', [32, 64, 128, 1100, 1200, 1300, 1440, 1500, 0])

@@ -121,6 +121,31 @@ def test_sft_gradients_vs_reference_autograd(golden_dir, golden_model, g56):
         np.testing.assert_allclose(g[torch.from_numpy(d[f'idx::{n}'])].numpy(), d[f'val::{n}'], rtol=2e-3, atol=1e-6 * float(d[f'norm::{n}']) + 1e-9, err_msg=n)
 
 
+def test_infer_action_integration_methods(golden_dir, golden_model):
+    """G7c: the reference's chunks under integration_method = euler / heun / rk4 (its model_step closure returns one velocity per step: heun == euler bit for bit)."""
+    import dataclasses
+    _, vla, sd = golden_model
+    d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))
+    c = np.load(os.path.join(golden_dir, 'g7c_integrators.npz'))
+    np.testing.assert_array_equal(c['a_heun_action'], c['a_euler_action'])
+    np.testing.assert_array_equal(c['a_euler_action'], d['a_action'])
+    case = 'a'
+    g = torch.Generator().manual_seed(int(d[f'{case}_seed']))
+    pv = torch.randn(1, 3, 448, 448, generator=g)
+    ids = torch.from_numpy(d[f'{case}_input_ids'])
+    am = (ids != vla.base.pad_token_id).long()
+    m, vp, pp, ap = ovla.build_causal_mask_and_position_ids(am, torch.float32, vla)
+    m1, m2 = ovla.split_full_mask_into_submasks(m, vla)
+    acts = {}
+    for method in ('heun', 'rk4'):
+        v2 = dataclasses.replace(vla, integration_method=method)
+        acts[method] = ovla.infer_action(sd, v2, ids, pv, m1, m2, vp, pp, ap, torch.from_numpy(d[f'{case}_proprio']), torch.from_numpy(d[f'{case}_noise']))
+        np.testing.assert_allclose(acts[method].numpy(), c[f'{case}_{method}_action'], rtol=0, atol=2e-5)
+    assert (acts['rk4'] - acts['heun']).abs().max().item() < 1e-6
+    with pytest.raises(ValueError, match='Unknown integration method'):
+        ovla.integration_step(torch.zeros(1), 0.1, torch.zeros(1), 'midpoint')
+
+
 def test_infer_action(golden_dir, golden_model):
     _, vla, sd = golden_model
     d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))

@@ -365,6 +365,25 @@ def g7_vla(vla, sd, ref_vlm):
     return fake
 
 
+def g7c_integrators(fake, vla):
+    """G7c: `integration_method` other than "euler" (pizero_internvl.py:164,910-922,1309-1331).  The reference's `model_step` closure ignores its arguments and returns
+    the decoder output of THIS step's joint pass, so "heun" and "rk4" re-combine one velocity: heun == euler bit for bit, rk4 == euler up to the rounding of
+    (dt / 6) * (k1 + 2 k2 + 2 k3 + k4).  The fixture pins exactly that: the reference's own chunks for the two G7 cases under each method."""
+    d = {}
+    for case, (seed, n_valid) in {'a': (0, 277), 'b': (1, 300)}.items():
+        pv, ids, am, proprio, mask, vp, pp, ap = _g7_case(fake, seed, n_valid)
+        m1, m2 = RP.PiZero.split_full_mask_into_submasks(fake, mask)
+        for method in ('euler', 'heun', 'rk4'):
+            fake.integration_method = method
+            torch.manual_seed(1234 + seed)
+            act = RP.PiZero.infer_action(fake, ids, pv, m1, m2, vp, pp, ap, proprio)
+            d[f'{case}_{method}_action'] = act.numpy()
+        fake.integration_method = 'euler'
+        print('G7c', case, 'heun == euler:', bool((d[f'{case}_heun_action'] == d[f'{case}_euler_action']).all()), ' max|rk4 - euler|',
+              float(np.abs(d[f'{case}_rk4_action'] - d[f'{case}_euler_action']).max()))
+    np.savez_compressed(os.path.join(OUT, 'g7c_integrators.npz'), **d)
+
+
 def _g7_case(fake, seed, n_valid):
     g = torch.Generator().manual_seed(seed)
     pv = torch.randn(1, 3, 448, 448, generator=g)
@@ -653,8 +672,11 @@ def main():
         fake = g7_vla(vla, sd, build_ref_vlm(cfg, vlm_sd))
         if '--only-g10b' in sys.argv:
             return g10b_flow_matching_vlm(fake, vla, fake._ref_vlm)
+        if '--only-g7c' in sys.argv:
+            return g7c_integrators(fake, vla)
         if '--skip-g7b' not in sys.argv:
             g7b_trace(fake, vla)
+        g7c_integrators(fake, vla)
         g10_flow_matching(fake, vla)
         return g10b_flow_matching_vlm(fake, vla, fake._ref_vlm)
     import subprocess
@@ -677,6 +699,7 @@ def main():
     g5_g6(cfg, sd, ref_vlm)
     fake = g7_vla(vla, sd, ref_vlm)
     g7b_trace(fake, vla)
+    g7c_integrators(fake, vla)
     g10_flow_matching(fake, vla)
     g10b_flow_matching_vlm(fake, vla, fake._ref_vlm)
     g8_sft_grads(cfg, build_ref_vlm(cfg, vlm_sd))

@@ -88,8 +88,8 @@ _SIGS = {
     'vlaser_argmax_ws_bytes': [i32],
     'vlaser_vla_prep': [vp, vp, vp, vp, i32, i32, i32, f32, f32, vp],
     'vlaser_small_linear': [vp, vp, vp, vp, i32, i32, i32, vp],
-    'vlaser_vla_step': [vp, vp, i32, i32, i32, vp, f32, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp],
-    'vlaser_vla_euler': [vp, vp, i32, i32, vp, f32, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, vp, i32, i32, vp],
+    'vlaser_vla_step': [vp, vp, i32, i32, i32, vp, f32, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    'vlaser_vla_euler': [vp, vp, i32, i32, vp, f32, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, vp, i32, i32, i32, vp],
     'vlaser_vla_stage': [C.POINTER(VlaStageArgs), vp],
     'vlaser_cast_f32_bf16': [vp, vp, i64, vp],
     'vlaser_normalize_u8': [vp, vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp],

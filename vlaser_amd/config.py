@@ -84,10 +84,11 @@ class VLAConfig:
     integration_method: str = 'euler'        # pizero_internvl.py:164 (`cfg.get("integration_method", "euler")`); the eval YAML does not set it
 
     def __post_init__(self):
-        # the reference also offers midpoint / rk4-style steps through integration_step (pizero_internvl.py:910-922,1309-1331); the captured chunk graph
-        # implements the forward-Euler update only -- refuse anything else instead of silently integrating differently
-        if self.integration_method != 'euler':
-            raise ValueError(f"integration_method={self.integration_method!r}: only 'euler' (the reference's default, pizero_internvl.py:164,910-912) is built")
+        # the reference's `integration_step` (pizero_internvl.py:910-922,1309-1331): euler | heun | rk4.  Its `model_step` closure returns THIS step's decoder output
+        # whatever (x, t) it is handed, so heun and rk4 re-combine one velocity per step (no extra passes through the expert): served by the same kernels with the
+        # method's arithmetic (r06, golden G7c); anything else raises exactly where the reference does
+        if self.integration_method not in ('euler', 'heun', 'rk4'):
+            raise ValueError(f'Unknown integration method: {self.integration_method}')
 
     @property
     def expert(self) -> LLMConfig:

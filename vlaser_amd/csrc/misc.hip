@@ -473,6 +473,21 @@ extern "C" int vlaser_small_linear(const float* x, const void* w, const void* b,
   return 0;
 }
 
+// The update of one integration step (pizero_internvl.py:910-922, `integration_step` :1309-1331).  The reference's `model_step` closure returns the decoder output of THIS
+// step's joint pass whatever (x, t) it is handed (:914-917), so heun and rk4 re-combine ONE velocity: method 0 euler a + dt v; 1 heun a + (0.5 dt) (v + v);
+// 2 rk4 a + (dt / 6) (((v + 2 v) + 2 v) + v), each product and sum rounded as torch rounds them (no contraction).  `coef` = dt | 0.5 dt | dt / 6, rounded from double by
+// the host as torch rounds a Python scalar.  Golden G7c: heun == euler bit for bit, rk4 within 2.4e-7.
+__device__ __forceinline__ float vl_integrate(float a, float vel, float coef, int method) {
+  if (method == 2) {
+    float w = __fadd_rn(vel, __fmul_rn(2.f, vel));
+    w = __fadd_rn(w, __fmul_rn(2.f, vel));
+    w = __fadd_rn(w, vel);
+    return __fadd_rn(a, __fmul_rn(coef, w));
+  }
+  if (method == 1) return __fadd_rn(a, __fmul_rn(coef, __fadd_rn(vel, vel)));
+  return a + coef * vel;                                   // euler: the arithmetic of r01-r05 unchanged
+}
+
 // vla_euler: h = bf16(h_in + sum partials); y = rmsnorm(h) (expert final norm, joint_model.py:804-808);
 // vel = Wd y + bd (pizero_internvl.py:911); action += dt * vel (:912); optional clamp on the last step (:927-932).
 // One block per row m (<=16 rows); 256 threads.
@@ -485,7 +500,7 @@ __global__ __launch_bounds__(256) void vla_euler_kernel(const bf16_t* __restrict
                                                         int M, const bf16_t* __restrict__ norm_w, float eps, const bf16_t* __restrict__ wd,
                                                         const bf16_t* __restrict__ bd, float* __restrict__ action, int Wd, int adim, float dt,
                                                         float clip, int do_clip, float* __restrict__ vel_out, float* __restrict__ ring,
-                                                        const int* __restrict__ ring_ctr, int ring_n, int ring_stride) {
+                                                        const int* __restrict__ ring_ctr, int ring_n, int ring_stride, int method) {
   __shared__ float red[4][ADIM + 1];
   const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool on = (int)threadIdx.x * 8 < Wd;
@@ -542,7 +557,7 @@ __global__ __launch_bounds__(256) void vla_euler_kernel(const bf16_t* __restrict
   if ((int)threadIdx.x < adim) {
     const int j = threadIdx.x;
     const float vel = round_bf16(red[0][j] + red[1][j] + red[2][j] + red[3][j] + bf16_to_f32(bd[j]));
-    float av = action[m * adim + j] + dt * vel;
+    float av = vl_integrate(action[m * adim + j], vel, dt, method);
     if (do_clip) av = fminf(fmaxf(av, -clip), clip);
     action[m * adim + j] = av;
     if (vel_out) vel_out[m * adim + j] = vel;
@@ -558,14 +573,15 @@ __global__ __launch_bounds__(256) void vla_euler_kernel(const bf16_t* __restrict
 }
 extern "C" int vlaser_vla_euler(const void* h_in, const float* partials, int n_partials, int M, const void* norm_w, float eps,
                                 const void* wd, const void* bd, float* action, int Wd, int adim, float dt, float clip, int do_clip,
-                                float* vel_out, float* ring, const int* ring_ctr, int ring_n, int ring_stride, vl_stream_t s) {
+                                float* vel_out, float* ring, const int* ring_ctr, int ring_n, int ring_stride, int method, vl_stream_t s) {
   VL_CHECK(h_in && norm_w && wd && bd && action && M > 0 && Wd <= 2048 && Wd % 8 == 0, "vlaser_vla_euler: bad args");
+  VL_CHECK(method >= 0 && method <= 2, "vlaser_vla_euler: method 0 (euler) | 1 (heun) | 2 (rk4), got %d", method);
   VL_CHECK(!ring || (ring_ctr && ring_n >= 1 && ring_stride >= M * adim), "vlaser_vla_euler: the output ring needs its counter, >= 1 slots of >= M * adim floats");
   VL_CHECK(n_partials >= 0 && n_partials <= 8 && (n_partials == 0 || partials) && adim >= 1 && adim <= 16,
            "vlaser_vla_euler: 0..8 partial slabs, action_dim <= 16 (got %d, %d)", n_partials, adim);
 #define VL_EULER(AD_, HP_)                                                                                                          \
   hipLaunchKernelGGL((vla_euler_kernel<AD_, HP_>), dim3(M), dim3(256), 0, (hipStream_t)s, (const bf16_t*)h_in, partials, n_partials, M, \
-                     (const bf16_t*)norm_w, eps, (const bf16_t*)wd, (const bf16_t*)bd, action, Wd, adim, dt, clip, do_clip, vel_out, ring, ring_ctr, ring_n, ring_stride)
+                     (const bf16_t*)norm_w, eps, (const bf16_t*)wd, (const bf16_t*)bd, action, Wd, adim, dt, clip, do_clip, vel_out, ring, ring_ctr, ring_n, ring_stride, method)
   if (adim <= 8) { if (n_partials > 0) VL_EULER(8, true); else VL_EULER(8, false); }
   else { if (n_partials > 0) VL_EULER(16, true); else VL_EULER(16, false); }
 #undef VL_EULER
@@ -586,7 +602,7 @@ __global__ __launch_bounds__(256) void vla_step_kernel(const bf16_t* __restrict_
                                                        const bf16_t* __restrict__ norm_w, float eps, const bf16_t* __restrict__ wd, const bf16_t* __restrict__ bd,
                                                        const float* __restrict__ a_in, float* __restrict__ a_out, float* __restrict__ vel_out, float dt, int finish,
                                                        const float* __restrict__ w21, const float* __restrict__ cs, const bf16_t* __restrict__ w3,
-                                                       const bf16_t* __restrict__ b3, bf16_t* __restrict__ h_out, int M, int Wd, int adim) {
+                                                       const bf16_t* __restrict__ b3, bf16_t* __restrict__ h_out, int M, int Wd, int adim, int method) {
   constexpr int MAXM = 16, MAXW = 1024;
   __shared__ float a_s[MAXM * ADIM];
   __shared__ __attribute__((aligned(16))) bf16_t e2_s[MAXM * MAXW];
@@ -671,7 +687,7 @@ __global__ __launch_bounds__(256) void vla_step_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int k = 0; k < ADIM; ++k) vel = lane == k ? acc[k] : vel;
         vel = round_bf16(vel + bf16_to_f32(bd[lane]));
-        const float av = a_in[m * adim + lane] + dt * vel;
+        const float av = vl_integrate(a_in[m * adim + lane], vel, dt, method);
         a_s[m * ADIM + lane] = av;
         if (blockIdx.x == 0) {
           a_out[m * adim + lane] = av;
@@ -738,8 +754,9 @@ __global__ __launch_bounds__(256) void vla_step_kernel(const bf16_t* __restrict_
 }
 extern "C" int vlaser_vla_step(const void* h_in, const float* partials, int n_partials, int rows_in, int row_off, const void* norm_w, float eps, const void* wd,
                                const void* bd, const float* a_in, float* a_out, float* vel_out, float dt, int finish, const float* w21, const float* cs,
-                               const void* w3, const void* b3, void* h_out, int M, int Wd, int adim, vl_stream_t s) {
+                               const void* w3, const void* b3, void* h_out, int M, int Wd, int adim, int method, vl_stream_t s) {
   VL_CHECK(a_in && a_out && w21 && cs && w3 && b3 && h_out && M >= 1 && M <= 16, "vlaser_vla_step: bad args (1..16 rows)");
+  VL_CHECK(method >= 0 && method <= 2, "vlaser_vla_step: method 0 (euler) | 1 (heun) | 2 (rk4), got %d", method);
   VL_CHECK(Wd % 256 == 0 && Wd <= 1024 && adim >= 1 && adim <= 16, "vlaser_vla_step: Wd must be a multiple of 256 and <= 1024, action_dim <= 16 (wider experts keep the separate launches)");
   VL_CHECK(adim <= 8 || Wd <= 768, "vlaser_vla_step: action_dim > 8 is built for Wd <= 768 (the 16 x 1024 variant needs scratch: such heads keep the separate launches)");
   VL_CHECK(!finish || (h_in && norm_w && wd && bd && n_partials >= 0 && n_partials <= 8 && (n_partials == 0 || partials) && rows_in >= M + row_off && row_off >= 0 && a_in != a_out),
@@ -748,7 +765,7 @@ extern "C" int vlaser_vla_step(const void* h_in, const float* partials, int n_pa
 #define VL_STEP(AD_, KJ_)                                                                                                                          \
   hipLaunchKernelGGL((vla_step_kernel<AD_, KJ_>), dim3(blocks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)h_in, partials, n_partials, rows_in, row_off, \
                      (const bf16_t*)norm_w, eps, (const bf16_t*)wd, (const bf16_t*)bd, a_in, a_out, vel_out, dt, finish, w21, cs, (const bf16_t*)w3,   \
-                     (const bf16_t*)b3, (bf16_t*)h_out, M, Wd, adim)
+                     (const bf16_t*)b3, (bf16_t*)h_out, M, Wd, adim, method)
 #define VL_STEP_KJ(AD_) { switch (Wd / 256) { case 1: VL_STEP(AD_, 1); break; case 2: VL_STEP(AD_, 2); break; case 3: VL_STEP(AD_, 3); break; default: if constexpr (AD_ <= 8) VL_STEP(AD_, 4); } }
   if (adim <= 8) VL_STEP_KJ(8) else VL_STEP_KJ(16)
 #undef VL_STEP_KJ

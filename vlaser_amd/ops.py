@@ -497,11 +497,21 @@ def small_linear(x, w, b, out, M, N, K):
             'vlaser_small_linear')
 
 
-def vla_euler(h_in, partials, n_partials, M, norm_w, eps, wd, bd, action, W, adim, dt, clip, do_clip, vel_out=None, ring=None, ring_ctr=None):
-    """ring (fp32 [slots, stride]) + ring_ctr (device int32): the result also goes to slot (*ring_ctr mod slots) -- infer_action returns that view."""
+INTEGRATION_METHODS = {'euler': 0, 'heun': 1, 'rk4': 2}
+
+
+def integration_coef(dt, method='euler'):
+    """The scalar the reference's `integration_step` multiplies the (re-combined) velocity with (pizero_internvl.py:1309-1331): dt | 0.5 dt | dt / 6, evaluated in
+    Python double exactly as the reference evaluates it; ctypes rounds it to fp32 the way torch rounds a Python scalar."""
+    return {'euler': dt, 'heun': 0.5 * dt, 'rk4': dt / 6.0}[method]
+
+
+def vla_euler(h_in, partials, n_partials, M, norm_w, eps, wd, bd, action, W, adim, dt, clip, do_clip, vel_out=None, ring=None, ring_ctr=None, method='euler'):
+    """ring (fp32 [slots, stride]) + ring_ctr (device int32): the result also goes to slot (*ring_ctr mod slots) -- infer_action returns that view.
+    method: the reference's `integration_method` (euler | heun | rk4); dt is the STEP (1 / num_inference_steps), the method's coefficient is derived here."""
     L.check(L.lib().vlaser_vla_euler(h_in.data_ptr(), _p(partials), n_partials, M, norm_w.data_ptr(), eps, wd.data_ptr(),
-                                     bd.data_ptr(), action.data_ptr(), W, adim, dt, clip, int(do_clip), _p(vel_out), _p(ring), _p(ring_ctr),
-                                     0 if ring is None else ring.shape[0], 0 if ring is None else ring.stride(0), _stream()),
+                                     bd.data_ptr(), action.data_ptr(), W, adim, integration_coef(dt, method), clip, int(do_clip), _p(vel_out), _p(ring), _p(ring_ctr),
+                                     0 if ring is None else ring.shape[0], 0 if ring is None else ring.stride(0), INTEGRATION_METHODS[method], _stream()),
             'vlaser_vla_euler')
 
 
@@ -576,15 +586,16 @@ def vla_stage(ids, ids_out, valid_in, valid_out, proprio, proprio_out, noise, no
     L.check(L.lib().vlaser_vla_stage(C.byref(a), _stream()), 'vlaser_vla_stage')
 
 
-def vla_step(a_in, a_out, w21, cs, w3, b3, h_out, M, W, adim, finish=None, vel_out=None, dt=0.0):
+def vla_step(a_in, a_out, w21, cs, w3, b3, h_out, M, W, adim, finish=None, vel_out=None, dt=0.0, method='euler'):
     """One launch between two passes through the expert: `finish` = (h_in, partials, n_partials, rows_in, row_off, norm_w, eps, wd, bd) completes the
     previous Euler step (a_out = a_in + dt * vel), then the action encoder (folded linear_1 / time embedding: w21, cs) writes h_out."""
     if finish is None:
         f = (None, None, 0, M, 0, None, 0.0, None, None)
     else:
         f = finish
-    L.check(L.lib().vlaser_vla_step(_p(f[0]), _p(f[1]), f[2], f[3], f[4], _p(f[5]), f[6], _p(f[7]), _p(f[8]), a_in.data_ptr(), a_out.data_ptr(), _p(vel_out), dt,
-                                    0 if finish is None else 1, w21.data_ptr(), cs.data_ptr(), w3.data_ptr(), b3.data_ptr(), h_out.data_ptr(), M, W, adim, _stream()),
+    L.check(L.lib().vlaser_vla_step(_p(f[0]), _p(f[1]), f[2], f[3], f[4], _p(f[5]), f[6], _p(f[7]), _p(f[8]), a_in.data_ptr(), a_out.data_ptr(), _p(vel_out),
+                                    integration_coef(dt, method), 0 if finish is None else 1, w21.data_ptr(), cs.data_ptr(), w3.data_ptr(), b3.data_ptr(), h_out.data_ptr(), M, W,
+                                    adim, INTEGRATION_METHODS[method], _stream()),
             'vlaser_vla_step')
 
 
@@ -622,6 +633,10 @@ def set_cu_budget(cus):
     prev = L.lib().vlaser_set_cu_budget(int(cus))
     _CU_BUDGET = L.lib().vlaser_get_cu_budget()            # (an out-of-range request is refused: mirror what the library holds)
     return prev
+
+
+def get_cu_budget():
+    return L.lib().vlaser_get_cu_budget()
 
 
 def gemm_tile_config(M, N, splits=1, batch=1, nn=False):

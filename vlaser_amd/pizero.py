@@ -384,7 +384,7 @@ class PiZero:
                                                    self.pos5, B, na + 1, T, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len, blk_start=T,
                                                    first_tok_kv_len=T + 1, skip=skip)
                 ops.vla_euler(h, parts, npart, M + 1, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action5, W, cfg.action_dim, dt,
-                              clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel5)
+                              clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel5, method=cfg.integration_method)
                 self.action[:M].copy_(self.action5[1:1 + M])          # row 0 of action5 (the proprio row's "velocity") is scratch
                 self.vel_trace[s, :M].copy_(self.vel5[1:1 + M])
                 continue
@@ -395,7 +395,7 @@ class PiZero:
                                                blk_start=T, skip=skip)
             ring = (self.out_ring, self.call_ctr) if s == n - 1 else (None, None)
             ops.vla_euler(h, parts, npart, M, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action, W, cfg.action_dim, dt,
-                          clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel_trace[s], ring=ring[0], ring_ctr=ring[1])
+                          clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel_trace[s], ring=ring[0], ring_ctr=ring[1], method=cfg.integration_method)
 
     def _run_euler_glue1(self, B, skip=()):
         """The same integration with ONE launch between two passes through the expert's layers (`vlaser_vla_step`: tail of step s-1 + action
@@ -421,7 +421,7 @@ class PiZero:
                 ops.vla_step(acts[p], acts[p], self.ae_w21, self.ae_cs[s], self.ae_w3_raw, self.ae_b3, h_enc, M, W, ad)
             else:
                 ops.vla_step(acts[p], acts[1 - p], self.ae_w21, self.ae_cs[s], self.ae_w3_raw, self.ae_b3, h_enc, M, W, ad, finish=fin,
-                             vel_out=self.vel_trace[s - 1], dt=dt)
+                             vel_out=self.vel_trace[s - 1], dt=dt, method=cfg.integration_method)
                 p = 1 - p
             if first:
                 h, parts, npart = self.h5, None, 0
@@ -440,7 +440,7 @@ class PiZero:
         assert acts[p] is self.action
         ring = (self.out_ring, self.call_ctr)     # always: the caller's copy (a 1-slot ring when output_ring == 0) is where an unsupported mask turns into NaN
         ops.vla_euler(fin[0], fin[1], fin[2], M, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action, W, ad, dt,
-                      clip if clip is not None else 0.0, clip is not None, vel_out=self.vel_trace[n - 1], ring=ring[0], ring_ctr=ring[1])
+                      clip if clip is not None else 0.0, clip is not None, vel_out=self.vel_trace[n - 1], ring=ring[0], ring_ctr=ring[1], method=cfg.integration_method)
 
     @torch.no_grad()
     def infer_action(self, input_ids, pixel_values, image_text_proprio_mask=None, action_mask=None, vlm_position_ids=None,
@@ -666,7 +666,7 @@ class PiZero:
                 prefill_layer(eg, lw, eb, h_act, self.cache, i, self.rope, self.pos_act, 1, na, L.ATTN_PREFIX, valid_len=self.valid_len, blk_start=T,
                               kv_len=T + 1 + na, slot_base=T + 1)
             ops.vla_euler(h_act, None, 0, na, eg.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action, W, cfg.action_dim, dt,
-                          clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel_trace[s])
+                          clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel_trace[s], method=cfg.integration_method)
         return self.action[:na].view(1, na, cfg.action_dim).clone()
 
     @torch.no_grad()

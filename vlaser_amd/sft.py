@@ -900,6 +900,21 @@ class SFTModel:
             # (world 1 with the exchange forced on: 31.0 -> 28.9 ms per step, profiles/r03dp_force_dp_world1.md)
             ev = torch.cuda.Event()
             ev.record()
+            if self.main_stream is not None:
+                # capi mode with CU masks: the comm stream owns only RCCL's share of the CUs -- the shard AdamW (HBM-bound) runs on the compute-masked optimizer stream,
+                # bucket by bucket, and each bucket's all-gather follows it on the comm stream behind an event
+                self.opt_stream.wait_event(ev)
+                for b in reversed(range(len(self.buckets))):
+                    with torch.cuda.stream(self.opt_stream):
+                        adamw_bucket(b)
+                        eb = torch.cuda.Event()
+                        eb.record()
+                    with torch.cuda.stream(self.comm_stream):
+                        self.comm_stream.wait_event(eb)
+                        dp.all_gather_params(self.fp.p, self.buckets[b], self.shards[b], self.pg, capi=self.capi)
+                        self.ag_events[b] = torch.cuda.Event()
+                        self.ag_events[b].record()
+                return gnorm
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
                 for b in reversed(range(len(self.buckets))):
