@@ -748,6 +748,7 @@ def test_vla_glue(ops):
     # r06: the reference's other integration methods (pizero_internvl.py:1309-1331) re-combine ONE velocity per step: the update is torch's arithmetic BIT FOR BIT
     # (every product and sum rounded separately), from the same decoder output
     from oracle.vla import integration_step
+    assert torch.equal(act.cpu(), integration_step(a0.cpu(), 0.1, vel.cpu(), 'euler'))
     for method in ('heun', 'rk4'):
         a1 = a0.clone(); v1 = torch.zeros(M, adim, device='cuda')
         ops.vla_euler(h, parts, 3, M, nw, 1e-6, wd, bd, a1, W, adim, 0.1, 1.0, False, v1, method=method)

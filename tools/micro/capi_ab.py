@@ -27,6 +27,7 @@ print('| exchange | comm CUs | compute CUs (budget) | forward + backward ms | st
 for mode, cus in (('pg', 0), ('capi', 0), ('capi', 8), ('capi', 16), ('capi', 32), ('pg', 0)):
     os.environ.update(VLASER_DP_EXCHANGE=mode, VLASER_DP_COMM_CUS=str(cus))
     ops.set_cu_budget(256)
+    torch.cuda.set_stream(torch.cuda.default_stream())      # (a CU-masked model makes its main stream the thread's current stream: undo it between configurations)
     sd = synth.vlm_state_dict(cfg, device='cuda', dtype=torch.bfloat16)
     m = SFTModel(cfg, max_seq_len=576, process_group=dist.group.WORLD)
     m.load_state_dict(sd)

@@ -476,16 +476,22 @@ extern "C" int vlaser_small_linear(const float* x, const void* w, const void* b,
 // The update of one integration step (pizero_internvl.py:910-922, `integration_step` :1309-1331).  The reference's `model_step` closure returns the decoder output of THIS
 // step's joint pass whatever (x, t) it is handed (:914-917), so heun and rk4 re-combine ONE velocity: method 0 euler a + dt v; 1 heun a + (0.5 dt) (v + v);
 // 2 rk4 a + (dt / 6) (((v + 2 v) + 2 v) + v), each product and sum rounded as torch rounds them (no contraction).  `coef` = dt | 0.5 dt | dt / 6, rounded from double by
-// the host as torch rounds a Python scalar.  Golden G7c: heun == euler bit for bit, rk4 within 2.4e-7.
+// the host as torch rounds a Python scalar.  Golden G7c: heun == euler bit for bit, rk4 within 2.4e-7; tests/test_ops_gpu.py::test_vla_glue checks the update against torch bit for bit.
+__device__ __forceinline__ float vl_unfused(float x) {       // an opaque copy: keeps hipcc (-ffp-contract=fast) from contracting `a + c * w` into one fma -- torch rounds the product
+  asm volatile("" : "+v"(x));
+  return x;
+}
 __device__ __forceinline__ float vl_integrate(float a, float vel, float coef, int method) {
+  float w = vel;
   if (method == 2) {
-    float w = __fadd_rn(vel, __fmul_rn(2.f, vel));
-    w = __fadd_rn(w, __fmul_rn(2.f, vel));
-    w = __fadd_rn(w, vel);
-    return __fadd_rn(a, __fmul_rn(coef, w));
+    w = vl_unfused(vel + vl_unfused(2.f * vel));
+    w = vl_unfused(w + vl_unfused(2.f * vel));
+    w = vl_unfused(w + vel);
+  } else if (method == 1) {
+    w = vl_unfused(vel + vel);
   }
-  if (method == 1) return __fadd_rn(a, __fmul_rn(coef, __fadd_rn(vel, vel)));
-  return a + coef * vel;                                   // euler: the arithmetic of r01-r05 unchanged
+  // (r06: euler too -- r01-r05 let the compiler fuse `a + dt * vel`; the reference's `action += delta_t * action_vel` rounds twice, and heun must equal euler bit for bit)
+  return a + vl_unfused(coef * w);
 }
 
 // vla_euler: h = bf16(h_in + sum partials); y = rmsnorm(h) (expert final norm, joint_model.py:804-808);

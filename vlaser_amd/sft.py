@@ -289,7 +289,12 @@ class SFTModel:
             self.comm_stream = self.capi.stream
             mask = self.capi.compute_mask()
             if mask is not None:
+                # The masked main stream becomes the calling thread's CURRENT stream, once, here.  hipExtStreamCreateWithCUMask only makes BLOCKING streams (implicitly
+                # ordered against the legacy default stream), and a step that hops default -> masked -> default on every call measured 19.1 ms of forward + backward
+                # against 13.8 ms inside one stream context (profiles/r06j_capi_masks.md): a trainer in this mode is a dedicated process, so the switch is global
                 self.main_stream = rccl_capi.masked_stream(*mask)
+                self.main_stream.wait_stream(torch.cuda.current_stream())
+                torch.cuda.set_stream(self.main_stream)
                 ops.set_cu_budget(mask[1])
         else:
             self.comm_stream = torch.cuda.Stream(device=dev) if self.dp_active else None
@@ -316,7 +321,7 @@ class SFTModel:
         """capi mode with CU masks: the step's launches go to the masked main stream, ordered behind the caller's stream at entry and in front of it at exit."""
         ms = self.main_stream
         cur = torch.cuda.current_stream()
-        if ms is None or cur == ms:
+        if ms is None or cur.cuda_stream == ms.cuda_stream:
             yield
             return
         ms.wait_stream(cur)
