@@ -723,7 +723,10 @@ static int adamw_grid_cap() {
     int n = 0;
     cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
   }
-  return cus[dev];
+  // r06: on a CU-masked stream (VLASER_DP_EXCHANGE=capi: the step's streams own vlaser_get_cu_budget() CUs) one workgroup per CU THE MASK LEAVES -- 256 workgroups on 248 CUs
+  // ran a second round of 8 (step 36.6 ms against 30.2 with 224 CUs, tools/micro/capi_ab.py)
+  const int budget = vlaser_get_cu_budget();
+  return budget < cus[dev] ? budget : cus[dev];
 }
 extern "C" int vlaser_adamw(void* p, float* master, float* m, float* v, const void* g, long long n, float lr, float b1, float b2, float eps, float wd,
                             float gscale, int step, vl_stream_t s) {
