@@ -323,11 +323,11 @@ def test_golden_manifest_matches_directory():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """The bench line committed with the round (profiles/r05*_bench_line.json, produced by `python bench.py` on the GPU box) carries what the contract asks of it:
+    """The bench line committed with the round (profiles/r06*_bench_line.json, produced by `python bench.py` on the GPU box) carries what the contract asks of it:
     the headline metric of BASELINE.json with `roofline` (measured traffic) and `cpu_baseline`, the SFT side line with its own CPU baseline, a consistent value."""
     import glob
     import json
-    lines = sorted(p for p in glob.glob(os.path.join(ROOT, 'profiles', 'r05*_bench_line.json')) if 'chunk' not in os.path.basename(p) and 'sft' not in os.path.basename(p))
+    lines = sorted(p for p in glob.glob(os.path.join(ROOT, 'profiles', 'r06*_bench_line.json')) if 'chunk' not in os.path.basename(p) and 'sft' not in os.path.basename(p))
     assert lines
     d = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
@@ -345,8 +345,14 @@ def test_committed_bench_line_keeps_the_contract():
     # r05: the headline is the reference's own eight-tensor call, the phases are also timed behind their real predecessors, the forced-DP step is on the line
     assert d['reference_signature']['is_headline'] is True and abs(d['reference_signature']['ms_per_chunk'] - d['ms_per_step']) < 1e-6
     ic = d['phases']['in_chain']
-    assert abs(ic['sum_ms'] - d['phases']['chunk_graph_ms']) < 0.1 and s['forced_dp_world1_ms']['ms_per_step'] > s['ms_per_step']
+    assert abs(ic['sum_ms'] - d['phases']['chunk_graph_ms']) < 0.1
     assert 'NCCL_MAX_NCHANNELS' in s['exchange']
+    # r06: both clocks of the dominant kernel with `frac` on the larger one; the SFT side numbers; the forced-DP step in BOTH exchange modes
+    assert r['us_per_launch'] >= max(r['us_per_launch_in_chain'], r['us_per_launch_rocprof'] or 0.0) - 1e-9 and 'rocprof_source' in r
+    assert s['recompute_ms_per_step'] > s['ms_per_step'] and s['micro_batch4']['tokens_per_step'] == 4 * s['tokens_per_rank_step'] and s['exchange']['mode'] == 'none'
+    f = s['forced_dp_world1_ms']
+    assert f['pg']['exchange']['mode'] == 'pg' and f['capi']['exchange'] == {'mode': 'capi', 'comm_cus': 32, 'compute_cus': 224, 'cu_masks': True}
+    assert f['pg']['ms_per_step'] > s['ms_per_step'] and f['capi']['ms_per_step'] > s['ms_per_step']
 
 
 def test_cu_budget_moves_the_tile_choice_on_both_sides():

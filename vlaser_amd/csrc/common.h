@@ -138,7 +138,7 @@ __device__ __forceinline__ int vl_sload_i32(const int32_t* p) { return *reinterp
 // (scalar cache cold at every kernel start) before their first global load went out (r04, read in the ISA: skinny_kernel 4 rounds, the since-removed attention + o_proj kernel 6).
 // Touching every 16-byte piece of the struct in one empty asm statement at the top of the kernel makes the compiler fetch all of it up front, back to back,
 // behind a single wait.  MEASURED (r04f, same-box A/B of the whole chunk): SLOWER, 13.75 vs 12.99 ms -- inside a replayed HIP graph a kernarg line costs only
-// 40-80 ns (tools/micro/kernarg_lab.hip: the graph keeps its arguments in device memory; eager launches with host-resident kernargs pay 1.2 us per
+// 40-80 ns (r04 lab, profiles/r04i_attn_oproj_timeline.md: the graph keeps its arguments in device memory; eager launches with host-resident kernargs pay 1.2 us per
 // line), the burst fetches all 5 lines of a 264-byte struct where the piecemeal code touches what the variant needs and overlaps the rest with address
 // arithmetic.  Kept behind -DVL_KERNARG_UP_FRONT for the record; OFF.
 template <int NQ, class P>

@@ -1337,7 +1337,7 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
     case 1532: return launch_glds<EPI, 32, 128, 1, 4, 7, WKM>(args, stream, splits);
     case 1900: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, false, 0, true, true>(args, stream, splits);      // r03: 3 tile rows for the SFT step's 560 rows (256-row tiles pad 27 %); r05: ASYM ring
     case 1901: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, true>(args, stream, splits);      // lab: the r03-r04 two-stage ring, refill requested first
-    // r05 lab (tools/micro/producer_lab.py, profiles/r05s_producer_waves.md): the 128x128 ring with 4 producer waves (one per SIMD) issuing every LDS-DMA piece: bit-identical,
+    // r05 lab (profiles/r05s_producer_waves.md; its driver left the tree in r06): the 128x128 ring with 4 producer waves (one per SIMD) issuing every LDS-DMA piece: bit-identical,
     // 12-16 % SLOWER (piece issue is serial per wave: 4 waves x 12 pieces take longer than 8 x 6); the 128x256 / 192x256 tiles do not fit 12 waves' 168 registers.  Not used.
     case 2100: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM, false, GLDS_ISSUE_FIRST != 0, 4>(args, stream, splits);
     case 1903: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, true, 0, true>(args, stream, splits);      // lab: ASYM with the refill requested first (41.9 us against 37.2)
