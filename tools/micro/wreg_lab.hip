@@ -188,6 +188,9 @@ int main(int argc, char** argv) {
   hipStream_t s; CK(hipStreamCreate(&s));
   struct Shape { int M, N, K; const char* name; int cfg; };
   // cfg = the product's tile for the shape (force_bm): 1900 = 192x256 ASYM, 1300 = 256x256 ASYM, 1200 = 128x256 / 3 stages
+  const bool warm_mode = argc > 1 && !strcmp(argv[1], "warm");
+  const Shape shapes_warm[] = {{1025, 3072, 1024, "ViT qkv", 0}, {1025, 1024, 1024, "ViT proj (whole K)", 0}, {1025, 4096, 1024, "ViT fc1", 0}, {1025, 1024, 4096, "ViT fc2 (whole K)", 0},
+                               {384, 2048, 1536, "LLM qkv", 0}, {384, 1536, 1536, "LLM o_proj (whole K)", 0}, {384, 17920, 1536, "LLM gate/up", 0}, {384, 1536, 8960, "LLM down (whole K)", 0}};
   const Shape shapes[] = {{3408, 8192, 3584, "8B-sized (VERDICT r05 #1)", 0}, {3408, 8192, 3456, "the same, K = 54 steps (D = 3 divides)", 0}, {560, 17920, 1536, "SFT forward gate/up", 0},
                           {384, 17920, 1536, "chunk prefill gate/up", 0}, {1025, 4096, 1024, "ViT fc1", 0}};
   const int NL = 8;
@@ -198,7 +201,10 @@ int main(int argc, char** argv) {
   unsigned* dcnt; CK(hipMalloc(&dcnt, 4));
   printf("| shape (M x N x K) | kernel | us per launch | TFLOP/s | us per K-step of the busiest CU | differs from the product in |\n|---|---|---|---|---|---|\n");
   int n_shapes = zero_fill ? 1 : 100;
-  for (const Shape& sh : shapes) {
+  std::vector<Shape> run_shapes;
+  if (warm_mode) run_shapes.assign(std::begin(shapes_warm), std::end(shapes_warm)); else run_shapes.assign(std::begin(shapes), std::end(shapes));
+  if (warm_mode) printf("product launches with HBM-cold weights (8 buffers cycled) vs the SAME weight buffer every launch (L2 / Infinity-Cache warm)\n\n");
+  for (const Shape& sh : run_shapes) {
     if (n_shapes-- <= 0) break;
     const int M = sh.M, N = sh.N, K = sh.K;
     bf16_t *x, *w[NL], *wp[NL], *out, *ref;
@@ -230,6 +236,18 @@ int main(int argc, char** argv) {
       printf("| %d x %d x %d %s | %s | %.1f | %.0f | %.3f | %s |\n", M, N, K, sh.name, what, us, fl / (us * 1e-6) / 1e12, us / (rounds * (K / 64)), diff);
       fflush(stdout);
     };
+    if (warm_mode) {
+      VlaserGemmArgs a; memset(&a, 0, sizeof a);
+      a.A = x; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = N; a.force_bm = 0;
+      auto cold = [&](int i) { a.W = w[i % NL]; a.out = out; if (vlaser_gemm(VL_EPI_NONE, &a, s)) { printf("vlaser_gemm: %s\n", vlaser_last_error()); exit(1); } };
+      auto warm = [&](int i) { a.W = w[0]; a.out = out; if (vlaser_gemm(VL_EPI_NONE, &a, s)) { printf("vlaser_gemm: %s\n", vlaser_last_error()); exit(1); } };
+      const double uc = time_graph(cold), uw = time_graph(warm);
+      printf("| %d x %d x %d %s | cold %.2f us | warm %.2f us | -%.2f us (%.0f %%) |\n", M, N, K, sh.name, uc, uw, uc - uw, 100.0 * (uc - uw) / uc);
+      fflush(stdout);
+      CK(hipFree(x)); CK(hipFree(out)); CK(hipFree(ref));
+      for (int i = 0; i < NL; ++i) { CK(hipFree(w[i])); CK(hipFree(wp[i])); }
+      continue;
+    }
     // the product (vlaser_gemm, its own tile choice and the forced 192x256 / 256x256 / 128x256 rings)
     for (int cfg : {0, 1900, 1300, 1200}) {
       VlaserGemmArgs a; memset(&a, 0, sizeof a);
