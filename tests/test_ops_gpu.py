@@ -843,7 +843,8 @@ def test_gemm_glds_ragged_and_splitk(ops, bm):
     close(part.sum(0), x.float() @ w.float().t(), rtol=2e-3, atol=2e-3, name=f'split-K cfg{bm}')
 
 
-@pytest.mark.parametrize('asym,two_stage', [(1900, 1901), (1300, 1302), (1903, 1901), (1100, 1101), (1200, 1201), (1440, 1441), (1500, 1501), (1904, 1901), (1304, 1302)])
+@pytest.mark.parametrize('asym,two_stage', [(1900, 1901), (1300, 1302), (1903, 1901), (1100, 1101), (1200, 1201), (1440, 1441), (1500, 1501), (1904, 1901), (1304, 1302),
+                                            (1102, 1101), (1202, 1201), (1442, 1441), (1502, 1501), (1902, 1901), (1564, 1566)])      # r06: 1100 / 1200 / 1440 / 1500 / 1564 / 1900 pipeline their fragment reads across the barrier (x02 / 1442 / 1566 = the plain loops)
 def test_gemm_asymmetric_ring_is_bit_identical_to_the_two_stage_ring(ops, asym, two_stage):
     """r05: the 192x256 / 256x256 tiles carry a third stage for the W operand alone (weights two K-steps ahead, activations one), and every ring issues its refill one piece
     at a time between the K-step's MFMAs instead of as one burst (x01 / 1304 / 1904 = the burst forms).  Same arithmetic in the same order as the
@@ -856,7 +857,7 @@ def test_gemm_asymmetric_ring_is_bit_identical_to_the_two_stage_ring(ops, asym, 
         ops.gemm(L.EPI_NONE, x, w, out=o2, force_bm=two_stage)
         assert torch.equal(o1, o2), (M, N, K)
         close(o1, x.float() @ w.float().t(), rtol=1e-2, atol=1e-2, name=f'nt {M}x{N}x{K} cfg{asym}')
-        if N % 8 == 0:
+        if N % 8 == 0 and asym != 1564:
             wk = w.t().contiguous()
             ops.gemm_nn(L.EPI_NONE, x, wk, out=o1, force_bm=asym)
             ops.gemm_nn(L.EPI_NONE, x, wk, out=o2, force_bm=two_stage)

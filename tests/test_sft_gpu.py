@@ -228,7 +228,7 @@ def test_gemm_tn_weight_gradient(K, M, N):
 
 @pytest.mark.parametrize('K,M,N,cfg', [(560, 1536, 2048, 0), (560, 17920, 1536, 0), (560, 1536, 8960, 0), (313, 256, 1536, 1100), (64, 136, 264, 1105),
                                        (130, 2048, 1536, 1200), (200, 1000, 520, 1300), (560, 17920, 1536, 1340), (200, 1000, 520, 1340), (313, 264, 1536, 1240), (64, 136, 264, 1140),
-                                       (96, 1536, 2048, 1140), (32, 304, 264, 1340)])
+                                       (96, 1536, 2048, 1140), (32, 304, 264, 1340), (313, 256, 1536, 1102), (130, 2048, 1536, 1202)])
 def test_gemm_tn_lds_padded_contraction(K, M, N, cfg):
     """vlaser_gemm_tn_lds (the TN weight-gradient product on the LDS-DMA pipeline, both operands k-major): contraction axis padded to 64-row
     tiles with ZERO pad rows in At and arbitrary finite pad rows in Wt; edge tiles in M and N; every tile configuration.  Against fp32 and
@@ -457,6 +457,20 @@ def test_step_norm_from_producers_matches_buffer_norm(setup, monkeypatch):
         d = (pa[k].float() - pb[k].float()).abs().max().item()
         # steps 2 and 3 of the two trajectories may move an element with a near-zero gradient in opposite directions: <= 2 lr per step
         assert d <= 2 * 2 * 1e-3 + 2e-2 * pb[k].float().abs().max().item(), (k, d)
+
+
+@pytest.mark.parametrize('pipe,plain', [(1100, 1102), (1200, 1202)])
+def test_gemm_tn_lds_pipelined_reads_bit_identical(pipe, plain):
+    """r06: the TN weight-gradient tiles pipeline their fragment reads across the K-step's barrier (csrc/gemm.hip PIPE; x02 = the r03-r05 plain loop): same accumulation order,
+    bit-identical outputs -- contraction of 1 .. 9 tiles, ragged M / N."""
+    from vlaser_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for (K, M, N) in [(64, 136, 264), (128, 1000, 520), (576, 2048 + 24, 1536 + 8), (320, 17920 // 8, 1536)]:
+        At = torch.randn(K, M, generator=g).to(BF).cuda(); Wt = torch.randn(K, N, generator=g).to(BF).cuda()
+        o1, o2 = torch.zeros(M, N, dtype=BF, device='cuda'), torch.zeros(M, N, dtype=BF, device='cuda')
+        ops.gemm_tn_lds(At, Wt, o1, K, force_cfg=pipe)
+        ops.gemm_tn_lds(At, Wt, o2, K, force_cfg=plain)
+        assert torch.equal(o1, o2), (K, M, N)
 
 
 def test_gemm_tn_lds_ragged_output_rows():

@@ -189,6 +189,53 @@ int main(int argc, char** argv) {
   struct Shape { int M, N, K; const char* name; int cfg; };
   // cfg = the product's tile for the shape (force_bm): 1900 = 192x256 ASYM, 1300 = 256x256 ASYM, 1200 = 128x256 / 3 stages
   const bool warm_mode = argc > 1 && !strcmp(argv[1], "warm");
+  // `wreg_lab pipe`: the product's tile against its PIPE variant (fragment reads pipelined across the K-step's barrier, csrc/gemm.hip) on the shapes that use the tile
+  if (argc > 1 && !strcmp(argv[1], "pipe")) {
+    struct PS { int M, N, K; const char* name; int base, pipe; };
+    const PS ps[] = {{1025, 3072, 1024, "ViT qkv (128x128)", 1102, 1100}, {1025, 4096, 1024, "ViT fc1 (144x128)", 1442, 1440}, {384, 17920, 1536, "LLM prefill gate/up (128x256)", 1202, 1200},
+                     {384, 2048, 1536, "LLM prefill qkv-sized (64x128)", 1502, 1500}, {384, 2048, 1536, "LLM prefill qkv-sized (64x64, 4 waves)", 1566, 1564},
+                     {560, 17920, 1536, "SFT forward gate/up (192x256)", 1902, 1900}, {560, 2048, 1536, "SFT qkv (64x128)", 1502, 1500},
+                     {560, 8960, 1536, "SFT 128x256", 1202, 1200}, {3408, 8192, 3584, "8B-sized (192x256)", 1902, 1900}, {3408, 8192, 3584, "8B-sized (128x256)", 1202, 1200},
+                     {13 * 1025, 4096, 1024, "ViT fc1 x 13 tiles (128x256)", 1202, 1200}};
+    printf("| shape | base us (code) | PIPE us (code) | delta | bit-identical |\n|---|---|---|---|---|\n");
+    hipStream_t s; CK(hipStreamCreate(&s));
+    unsigned* dcnt; CK(hipMalloc(&dcnt, 4));
+    for (const PS& q : ps) {
+      const int NL = 8;
+      bf16_t *x, *w[NL], *o1, *o2;
+      CK(hipMalloc(&x, (size_t)q.M * q.K * 2)); CK(hipMalloc(&o1, (size_t)q.M * q.N * 2)); CK(hipMalloc(&o2, (size_t)q.M * q.N * 2));
+      fill_bf16<<<1024, 256, 0, s>>>(x, (size_t)q.M * q.K, 1, 1.0f);
+      for (int i = 0; i < NL; ++i) { CK(hipMalloc(&w[i], (size_t)q.N * q.K * 2)); fill_bf16<<<1024, 256, 0, s>>>(w[i], (size_t)q.N * q.K, 100 + i, 0.03f); }
+      double us[2][3];
+      for (int rep = 0; rep < 3; ++rep)
+        for (int v = 0; v < 2; ++v) {                          // interleaved: base, pipe, base, pipe, ...
+          VlaserGemmArgs a; memset(&a, 0, sizeof a);
+          a.A = x; a.M = q.M; a.N = q.N; a.K = q.K; a.lda = q.K; a.ldw = q.K; a.ldo = q.N; a.force_bm = v ? q.pipe : q.base; a.out = v ? o2 : o1;
+          hipGraph_t g; hipGraphExec_t ge;
+          CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+          for (int i = 0; i < NL; ++i) { a.W = w[i]; if (vlaser_gemm(VL_EPI_NONE, &a, s)) { printf("vlaser_gemm: %s\n", vlaser_last_error()); return 1; } }
+          CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+          hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+          CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
+          CK(hipEventRecord(e0, s));
+          for (int r = 0; r < 10; ++r) CK(hipGraphLaunch(ge, s));
+          CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+          us[v][rep] = ms * 1e3 / (10 * NL);
+          CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+        }
+      CK(hipMemsetAsync(dcnt, 0, 4, s));
+      count_diff<<<1024, 256, 0, s>>>(o1, o2, (size_t)q.M * q.N, dcnt);
+      unsigned c; CK(hipMemcpyAsync(&c, dcnt, 4, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s));
+      auto med = [](double* v) { double a = v[0], b = v[1], c3 = v[2]; return a + b + c3 - (a < b ? (a < c3 ? a : c3) : (b < c3 ? b : c3)) - (a > b ? (a > c3 ? a : c3) : (b > c3 ? b : c3)); };
+      const double b = med(us[0]), pp = med(us[1]);
+      printf("| %d x %d x %d %s | %.2f (%d) | %.2f (%d) | %+.1f %% | %s |\n", q.M, q.N, q.K, q.name, b, q.base, pp, q.pipe, 100.0 * (pp - b) / b, c ? "NO" : "yes");
+      fflush(stdout);
+      CK(hipFree(x)); CK(hipFree(o1)); CK(hipFree(o2));
+      for (int i = 0; i < NL; ++i) CK(hipFree(w[i]));
+    }
+    return 0;
+  }
   const Shape shapes_warm[] = {{1025, 3072, 1024, "ViT qkv", 0}, {1025, 1024, 1024, "ViT proj (whole K)", 0}, {1025, 4096, 1024, "ViT fc1", 0}, {1025, 1024, 4096, "ViT fc2 (whole K)", 0},
                                {384, 2048, 1536, "LLM qkv", 0}, {384, 1536, 1536, "LLM o_proj (whole K)", 0}, {384, 17920, 1536, "LLM gate/up", 0}, {384, 1536, 8960, "LLM down (whole K)", 0}};
   const Shape shapes[] = {{3408, 8192, 3584, "8B-sized (VERDICT r05 #1)", 0}, {3408, 8192, 3456, "the same, K = 54 steps (D = 3 divides)", 0}, {560, 17920, 1536, "SFT forward gate/up", 0},
@@ -249,13 +296,13 @@ int main(int argc, char** argv) {
       continue;
     }
     // the product (vlaser_gemm, its own tile choice and the forced 192x256 / 256x256 / 128x256 rings)
-    for (int cfg : {0, 1900, 1300, 1200}) {
+    for (int cfg : {0, 1902, 1300, 1202}) {
       VlaserGemmArgs a; memset(&a, 0, sizeof a);
       a.A = x; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = N; a.force_bm = cfg;
-      auto launch = [&](int i) { a.W = w[i % NL]; a.out = cfg == 1900 ? ref : out; if (vlaser_gemm(VL_EPI_NONE, &a, s)) { printf("vlaser_gemm: %s\n", vlaser_last_error()); exit(1); } };
+      auto launch = [&](int i) { a.W = w[i % NL]; a.out = cfg == 1902 ? ref : out; if (vlaser_gemm(VL_EPI_NONE, &a, s)) { printf("vlaser_gemm: %s\n", vlaser_last_error()); exit(1); } };
       const double us = time_graph(launch);
       char nm[64]; snprintf(nm, sizeof nm, "product force_bm=%d", cfg);
-      report(nm, us, cfg == 1300 ? 256 : cfg == 1200 ? 128 : 192, cfg == 1900 ? "(reference)" : "");
+      report(nm, us, cfg == 1300 ? 256 : cfg == 1202 ? 128 : 192, cfg == 1902 ? "(reference)" : "");
     }
     LabP p{x, nullptr, out, M, N, K, 0, 0};
     auto lab = [&](const char* what, int bm, auto&& fn, bool divides) {

@@ -777,9 +777,16 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // (L2-resident) one.  Issue order per step: A(kt + NST - 1), then W(kt + NST); everything that must have landed at step kt is older than everything that may still fly.
 // SPREAD (r05 lab): the refill's pieces are not issued as one burst (behind the barrier or behind the first half's reads -- both waves of a SIMD are in that burst together and
 // the MFMA pipe idles for its 6-7 x ~100 issue cycles) but ONE AT A TIME between groups of MFMAs, evenly over the K-step's 2 x MT x NT of them.
-template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false, bool IFIRST = GLDS_ISSUE_FIRST != 0, int PRD = 0, bool ASYM = false, bool SPREAD = false>
+// PIPE (r06, tools/micro/kstep_pipe_lab.hip, profiles/r06d_kstep_pipe_lab.md): the fragment reads are software-pipelined across the K-step's barrier.  In the plain loop both waves
+// of a SIMD read their fragments together and issue their MFMAs together, so the LDS reads (0.28 us of a 1.08 us resident 192x256 K-step on random data) ADD to the MFMAs.  Here a
+// step is [barrier | reads(kt, h0) -> set A | MFMAs(kt-1, h1) from set B | reads(kt, h1) -> set B | MFMAs(kt, h0) from set A]: every read block is issued in front of an MFMA block
+// that does not depend on it.  Same accumulation order per accumulator (bit-identical).  The stage read in step kt-1 is still refilled in step kt: its pending reads (set B) are
+// retired by an explicit lgkmcnt(0) in front of the barrier -- long complete by then -- so no prefetch depth is lost (r02's version of the idea moved the barrier and lost a stage).
+template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false, bool IFIRST = GLDS_ISSUE_FIRST != 0, int PRD = 0, bool ASYM = false, bool SPREAD = false,
+          bool PIPE = false>
 __global__ __launch_bounds__((WM * WN + PRD) * 64) void gemm_glds_kernel(GemmP p) {
   static_assert(!(ASYM && PRD) && !(SPREAD && PRD), "one lab at a time");
+  static_assert(!PIPE || (PRD == 0 && !IFIRST), "PIPE: compute waves issue the pieces; the refill is spread or issued behind the first read block");
   constexpr int NW = WM * WN;
   constexpr int NWI = PRD ? PRD : NW;                    // waves that issue LDS-DMA pieces
   constexpr int WTM = BM / WM, WTN = BNT / WN;
@@ -884,6 +891,89 @@ __global__ __launch_bounds__((WM * WN + PRD) * 64) void gemm_glds_kernel(GemmP p
   const int fr = lane & 15, fq = lane >> 4;
   int st = 0;                                            // stage of tile kt (ASYM: of its A tile)
   [[maybe_unused]] int sw = 0;                           // ASYM: stage of tile kt's W tile (ring of NST + 1)
+  if constexpr (PIPE) {
+    auto read_frags = [&](int ks, const char* As, const char* Ws, bf16x8 (&fa)[MT], bf16x8 (&fw)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        if constexpr (AKM) {
+          const int kr = ks * 32 + 8 * fq + (fr >> 2), c0 = wr * WTM + t * 16;
+          const int sl = (c0 >> 3) + ((fr & 3) >> 1), hb = (fr & 1) * 8;
+          const int key_lo = 2 * ((kr & 3) | (((kr >> 3) & 1) << 2)), key_hi = 2 * (((kr + 4) & 3) | ((((kr + 4) >> 3) & 1) << 2));
+          typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+          const char* plo = As + kr * AROWB + (((sl & ~15) | ((sl & 15) ^ key_lo)) << 4) + hb;
+          const char* phi = As + (kr + 4) * AROWB + (((sl & ~15) | ((sl & 15) ^ key_hi)) << 4) + hb;
+          union { s16x4_t h[2]; bf16x8 b; } u;
+          u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(uint32_t)(uintptr_t)plo);
+          u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(uint32_t)(uintptr_t)phi);
+          fa[t] = u.b;
+        } else {
+          fa[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + lds_off(wr * WTM + t * 16 + fr, ks * 4 + fq)));
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if constexpr (WKM) {
+          const int kr = ks * 32 + 8 * fq + (fr >> 2), c0 = wc * WTN + t * 16;
+          const int sl = (c0 >> 3) + ((fr & 3) >> 1), hb = (fr & 1) * 8;
+          const int key_lo = 2 * ((kr & 3) | (((kr >> 3) & 1) << 2)), key_hi = 2 * (((kr + 4) & 3) | ((((kr + 4) >> 3) & 1) << 2));
+          typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+          const char* plo = Ws + kr * WROWB + (((sl & ~15) | ((sl & 15) ^ key_lo)) << 4) + hb;
+          const char* phi = Ws + (kr + 4) * WROWB + (((sl & ~15) | ((sl & 15) ^ key_hi)) << 4) + hb;
+          union { s16x4_t h[2]; bf16x8 b; } u;
+          u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(uint32_t)(uintptr_t)plo);
+          u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(uint32_t)(uintptr_t)phi);
+          fw[t] = u.b;
+        } else {
+          fw[t] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ws + lds_off(wc * WTN + t * 16 + fr, ks * 4 + fq)));
+        }
+      }
+    };
+    // one block of MT x NT MFMAs; `blk` = 0 / 1: first / second block of the step (the spread refill counts MFMAs over both); kt / stn / swn: the step whose refill rides here
+    auto mfma_block = [&](const bf16x8 (&fa)[MT], const bf16x8 (&fw)[NT], int blk, bool refill, int kt, int stn, int swn) __attribute__((always_inline)) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[nt][mt] = mfma16(fw[nt], fa[mt], acc[nt][mt]);
+          if constexpr (SPREAD) {
+            constexpr int GAP = (2 * MT * NT) / (PIECES + 1) > 0 ? (2 * MT * NT) / (PIECES + 1) : 1;
+            const int g = blk * (MT * NT) + nt * MT + mt + 1;
+            if (refill && g % GAP == 0 && g / GAP - 1 < PIECES) {
+              __builtin_amdgcn_sched_barrier(0);
+              issue_piece(g / GAP - 1, kt + NST - 1, stn, ASYM ? kt + NST : kt + NST - 1, ASYM ? swn : stn);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+    };
+    auto refill_burst = [&](int kt, int stn, int swn) __attribute__((always_inline)) {
+      if constexpr (ASYM) { issue_a(kt + NST - 1, stn); issue_w(kt + NST, swn); }
+      else issue_tile(kt + NST - 1, stn);
+    };
+    bf16x8 faA[MT], fwA[NT], faB[MT], fwB[NT];
+    for (int kt = 0; kt < nk; ++kt) {
+      if constexpr (ASYM) wait_vmcnt<PA * (NST - 2) + PW * (NST - 1)>();
+      else wait_vmcnt<PIECES * (NST - 2)>();               // this wave's pieces of tile kt have landed (younger tiles may fly)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // set B's reads of tile kt-1 (issued a whole MFMA block ago) are retired: stage kt-1 may be refilled behind the barrier
+      __builtin_amdgcn_s_barrier();
+      GEMM_STAMP(2 + kt)
+      int stn = st + NST - 1; if (stn >= NST) stn -= NST;
+      [[maybe_unused]] int swn = sw + NST; if (swn >= NST + 1) swn -= NST + 1;
+      const char* As = smem + st * (ASYM ? BM * 128 : STAGE);
+      const char* Ws = ASYM ? smem + WRING + sw * (BNT * 128) : As + BM * 128;
+      read_frags(0, As, Ws, faA, fwA);
+      // the refill of this step: spread over the step's two MFMA blocks, or -- burst form, and ALWAYS in step 0, which has no first block -- in one piece behind the first read
+      // block, in the order the vmcnt arithmetic assumes (A pieces, then W pieces)
+      if (!SPREAD || kt == 0) refill_burst(kt, stn, swn);
+      if (kt > 0) mfma_block(faB, fwB, 0, SPREAD, kt, stn, swn);
+      read_frags(1, As, Ws, faB, fwB);
+      mfma_block(faA, fwA, 1, SPREAD && kt > 0, kt, stn, swn);
+      if (++st == NST) st = 0;
+      if constexpr (ASYM) { if (++sw == NST + 1) sw = 0; }
+    }
+    mfma_block(faB, fwB, 0, false, 0, 0, 0);               // (nk - 1, h1)
+  } else
+  {
   for (int kt = 0; kt < nk; ++kt) {
     if constexpr (ASYM) wait_vmcnt<PA * (NST - 2) + PW * (NST - 1)>();
     else if (!PRD || producer) wait_vmcnt<PIECES * (NST - 2)>();      // this wave's pieces of tile kt have landed (younger tiles may fly)
@@ -965,6 +1055,7 @@ __global__ __launch_bounds__((WM * WN + PRD) * 64) void gemm_glds_kernel(GemmP p
     }
     if (++st == NST) st = 0;
     if constexpr (ASYM) { if (++sw == NST + 1) sw = 0; }
+  }
   }
   GEMM_STAMP(36)
   wait_vmcnt<0>();                                       // drain the clamped look-ahead tiles before the block retires
@@ -1185,7 +1276,8 @@ static int launch_tn_stag(const VlaserGemmArgs* args, hipStream_t stream) {
   return 0;
 }
 
-template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false, bool IFIRST = GLDS_ISSUE_FIRST != 0, int PRD = 0, bool ASYM = false, bool SPREAD = false>
+template <int EPI, int BM, int BNT, int WM, int WN, int NST, bool WKM = false, bool AKM = false, bool IFIRST = GLDS_ISSUE_FIRST != 0, int PRD = 0, bool ASYM = false, bool SPREAD = false,
+          bool PIPE = false>
 static int launch_glds(const VlaserGemmArgs* args, hipStream_t stream, int splits) {
   GemmP p;
   p.a = *args;
@@ -1198,8 +1290,8 @@ static int launch_glds(const VlaserGemmArgs* args, hipStream_t stream, int split
     const long long need = (long long)p.tiles_m * p.tiles_n * (args->batch > 1 ? args->batch : 1) * WM * WN;
     VL_CHECK(args->sumsq_cap >= need, "sumsq_part: %d slots given, this launch writes %lld (workgroups x waves)", args->sumsq_cap, need);
   }
-  if (int rc = set_max_lds_once(gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM, IFIRST, PRD, ASYM, SPREAD>, lds)) return rc;
-  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM, IFIRST, PRD, ASYM, SPREAD>), dim3(p.tiles_m * p.tiles_n, splits, args->batch > 1 ? args->batch : 1),
+  if (int rc = set_max_lds_once(gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM, IFIRST, PRD, ASYM, SPREAD, PIPE>, lds)) return rc;
+  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BM, BNT, WM, WN, NST, WKM, AKM, IFIRST, PRD, ASYM, SPREAD, PIPE>), dim3(p.tiles_m * p.tiles_n, splits, args->batch > 1 ? args->batch : 1),
                      dim3((WM * WN + PRD) * 64), lds, stream, p);
   VL_LAUNCH_CHECK();
   return 0;
@@ -1292,16 +1384,22 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
       char code[8];
       snprintf(code, sizeof(code), "%d", bm);
       if (!strcmp(no_spread, "1") || strstr(no_spread, code))
-        bm = bm == 1100 ? 1101 : bm == 1200 ? 1201 : bm == 1300 ? 1304 : bm == 1440 ? 1441 : bm == 1500 ? 1501 : bm == 1900 ? 1904 : bm;
+        bm = bm == 1100 ? 1101 : bm == 1200 ? 1201 : bm == 1300 ? 1304 : bm == 1440 ? 1441 : bm == 1500 ? 1501 : bm == 1900 ? 1904 : bm;      // (burst forms: plain loops)
     }
+  }
+  {
+    static const bool no_pipe = getenv("VLASER_GEMM_NO_PIPE") != nullptr;      // diagnostics / same-box A/B: the r05 plain K loop on the tiles that pipeline their fragment reads
+    if (no_pipe) bm = bm == 1100 ? 1102 : bm == 1200 ? 1202 : bm == 1440 ? 1442 : bm == 1500 ? 1502 : bm == 1564 ? 1566 : bm == 1900 ? 1902 : bm;
   }
   if constexpr (AKM) {
     switch (bm) {
       // (r05: neither the asymmetric ring nor the spread refill helps the TN form -- both operands are activations / gradients out of L2, and its 256x256 tile lost 3-6 % with
       // the pieces between the MFMAs: profiles/r05z_spread_lab.md -- so it keeps the r04 rings)
-      case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4, true, true>(args, stream, splits);
+      case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4, true, true, false, 0, false, false, true>(args, stream, splits);      // (r06: + PIPE; 1102 / 1202 = the r03-r05 plain loops)
+      case 1102: return launch_glds<EPI, 128, 128, 2, 4, 4, true, true>(args, stream, splits);
       case 1105: return launch_glds<EPI, 128, 128, 2, 4, 5, true, true>(args, stream, splits);
-      case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3, true, true>(args, stream, splits);
+      case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3, true, true, false, 0, false, false, true>(args, stream, splits);
+      case 1202: return launch_glds<EPI, 128, 256, 2, 4, 3, true, true>(args, stream, splits);
       case 1300: return launch_glds<EPI, 256, 256, 2, 4, 2, true, true>(args, stream, splits);
       // r04: two staggered wave groups over a ring of four 32-deep buffers (gemm_tn_stag_kernel)
       case 1340: if constexpr (EPI == VL_EPI_NONE) return launch_tn_stag<256, 256>(args, stream); break;
@@ -1309,15 +1407,19 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
       case 1140: if constexpr (EPI == VL_EPI_NONE) return launch_tn_stag<128, 128>(args, stream); break;
       default: break;
     }
-    vlaser_set_error("vlaser_gemm_tn_lds: force_cfg must be 0 or 1100 / 1105 / 1200 / 1300 / 1140 / 1240 / 1340 (got %d)", bm);
+    vlaser_set_error("vlaser_gemm_tn_lds: force_cfg must be 0 or 1100 / 1102 / 1105 / 1200 / 1202 / 1300 / 1140 / 1240 / 1340 (got %d)", bm);
     return -1;
   }
   switch (bm) {
     // r05: the refill's pieces go out one at a time between the K-step's MFMAs (SPREAD: bit-identical, -1 ... -9 % per launch, tools/micro/spread_lab.py); 1101 / 1201 / 1304 / 1441 /
     // 1501 / 1904 = the burst forms of r02-r04 (lab, VLASER_GEMM_NO_SPREAD=1)
-    case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM, false, false, 0, false, true>(args, stream, splits);
+    // r06: fragment reads pipelined across the K-step's barrier (PIPE: bit-identical; whole launches -1.4 % on 128x128, -5.0 % on 144x128, -3.5 ... -4.0 % on 64x128, -4.6 ... -5.6 % on
+    // 192x256, neutral on 128x256 -- profiles/r06o_pipe_ab.md); x02 / 1442 = the r05 defaults (spread refill, plain loop) for same-box A/B (VLASER_GEMM_NO_PIPE=1)
+    case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM, false, false, 0, false, true, true>(args, stream, splits);
+    case 1102: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM, false, false, 0, false, true>(args, stream, splits);
     case 1101: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM>(args, stream, splits);
-    case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3, WKM, false, false, 0, false, true>(args, stream, splits);
+    case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3, WKM, false, false, 0, false, true, true>(args, stream, splits);      // (r06: + PIPE: +0.3 ... -2.2 % per launch)
+    case 1202: return launch_glds<EPI, 128, 256, 2, 4, 3, WKM, false, false, 0, false, true>(args, stream, splits);
     case 1201: return launch_glds<EPI, 128, 256, 2, 4, 3, WKM>(args, stream, splits);
     // r05: the two-stage rings carry a THIRD stage for the W operand alone (ASYM: weights two steps ahead, activations one; 256x256: 2 x 32 + 3 x 32 = 160 KB, 192x256: 144 KB):
     // bit-identical, 3408 x 8192 x 3584 193.9 -> 168.6 us, the SFT forward's gate/up 42.7 -> 37.2 us (tools/micro/asym_ring_lab.py, profiles/r05t_asym_ring_lab.md)
@@ -1325,17 +1427,21 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
     case 1304: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM, false, false, 0, true>(args, stream, splits);      // lab: asymmetric ring, refill as one burst
     case 1301: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM, false, true>(args, stream, splits);      // lab: the two-stage 256x256 ring with the refill requested first
     case 1302: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM>(args, stream, splits);                   // lab: the r02-r04 two-stage ring
-    case 1500: return launch_glds<EPI, 64, 128, 2, 4, 4, WKM, false, false, 0, false, true>(args, stream, splits);
+    case 1500: return launch_glds<EPI, 64, 128, 2, 4, 4, WKM, false, false, 0, false, true, true>(args, stream, splits);
+    case 1502: return launch_glds<EPI, 64, 128, 2, 4, 4, WKM, false, false, 0, false, true>(args, stream, splits);
     case 1501: return launch_glds<EPI, 64, 128, 2, 4, 4, WKM>(args, stream, splits);
-    case 1440: return launch_glds<EPI, 144, 128, 3, 2, 4, WKM, false, false, 0, false, true>(args, stream, splits);
+    case 1440: return launch_glds<EPI, 144, 128, 3, 2, 4, WKM, false, false, 0, false, true, true>(args, stream, splits);
+    case 1442: return launch_glds<EPI, 144, 128, 3, 2, 4, WKM, false, false, 0, false, true>(args, stream, splits);
     case 1441: return launch_glds<EPI, 144, 128, 3, 2, 4, WKM>(args, stream, splits);
     // r03: deeper rings / smaller tiles for the latency-bound single-round shapes (a K-step of the 64x128 tile takes ~0.38 us with 3 tiles in flight:
     // the LDS-DMA round trip under load is ~1.1 us, so the bytes in flight per CU, not the MFMA pipe, set the rate)
     case 1506: return launch_glds<EPI, 64, 128, 2, 4, 6, WKM>(args, stream, splits);
     case 1105: return launch_glds<EPI, 128, 128, 2, 4, 5, WKM>(args, stream, splits);
-    case 1564: if constexpr (!WKM) return launch_glds<EPI, 64, 64, 2, 2, 8, false>(args, stream, splits); break;      // (burst: the 4-wave 64x64 tile lost 3.5 % with the spread refill)
+    case 1564: if constexpr (!WKM) return launch_glds<EPI, 64, 64, 2, 2, 8, false, false, false, 0, false, false, true>(args, stream, splits); break;      // (burst: the 4-wave 64x64 tile lost 3.5 % with the spread refill; r06: + PIPE, -6.1 %)
+    case 1566: if constexpr (!WKM) return launch_glds<EPI, 64, 64, 2, 2, 8, false>(args, stream, splits); break;      // the r03-r05 default (burst, plain loop)
     case 1532: return launch_glds<EPI, 32, 128, 1, 4, 7, WKM>(args, stream, splits);
-    case 1900: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, false, 0, true, true>(args, stream, splits);      // r03: 3 tile rows for the SFT step's 560 rows (256-row tiles pad 27 %); r05: ASYM ring
+    case 1900: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, false, 0, true, true, true>(args, stream, splits);      // (r06: + PIPE) r03: 3 tile rows for the SFT step's 560 rows (256-row tiles pad 27 %); r05: ASYM ring
+    case 1902: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, false, 0, true, true>(args, stream, splits);      // the r05 default (ASYM + spread, plain loop)
     case 1901: return launch_glds<EPI, 192, 256, 2, 4, 2, WKM, false, true>(args, stream, splits);      // lab: the r03-r04 two-stage ring, refill requested first
     // r05 lab (profiles/r05s_producer_waves.md; its driver left the tree in r06): the 128x128 ring with 4 producer waves (one per SIMD) issuing every LDS-DMA piece: bit-identical,
     // 12-16 % SLOWER (piece issue is serial per wave: 4 waves x 12 pieces take longer than 8 x 6); the 128x256 / 192x256 tiles do not fit 12 waves' 168 registers.  Not used.
@@ -1573,6 +1679,12 @@ extern "C" int vlaser_gemm_tn_lds(const void* At, const void* Wt, void* out, int
   return launch<VL_EPI_NONE, true, true>(&a, reinterpret_cast<hipStream_t>(s));
 }
 
+static bool glds_code(int bm) {      // every LDS-DMA configuration code launch<> knows (defaults + lab variants)
+  static const int codes[] = {1100, 1101, 1102, 1105, 1200, 1201, 1202, 1300, 1301, 1302, 1304, 1440, 1441, 1442, 1500, 1501, 1502, 1506, 1532, 1564, 1566, 1900, 1901, 1902, 1903, 1904, 2100};
+  for (int c : codes) if (c == bm) return true;
+  return false;
+}
+
 extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(s);
   VL_CHECK(a && a->A && a->W, "vlaser_gemm: null operand");
@@ -1580,7 +1692,7 @@ extern "C" int vlaser_gemm(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   VL_CHECK(a->K % BK == 0, "vlaser_gemm: K=%d must be a multiple of %d", a->K, BK);
   VL_CHECK(a->batch <= 1 || (epi == VL_EPI_NONE || epi == VL_EPI_F32 || epi == VL_EPI_BIAS), "vlaser_gemm: batched mode supports NONE / F32 / BIAS epilogues");
   VL_CHECK(!a->sumsq_part, "vlaser_gemm: sumsq_part is honoured by vlaser_gemm_tn_lds only");
-  VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128 || a->force_bm == 2100 || a->force_bm == 1101 || a->force_bm == 1201 || a->force_bm == 1304 || a->force_bm == 1441 || a->force_bm == 1501 || a->force_bm == 1904 || a->force_bm == 1903 || a->force_bm == 1901 || a->force_bm == 1302 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1301 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 || a->force_bm == 1564 || a->force_bm == 1532 || a->force_bm == 1900,
+  VL_CHECK(a->force_bm == 0 || a->force_bm == 32 || a->force_bm == 64 || a->force_bm == 128 || glds_code(a->force_bm),
            "vlaser_gemm: force_bm must be 0/32/64/128 or an LDS-DMA configuration code 1100/1105/1200/1300/1301/1440/1500/1506/1532/1564/1900, 2100 (lab: producer waves)");
   VL_CHECK(a->lda % 8 == 0 && a->ldw % 8 == 0, "vlaser_gemm: lda/ldw must be multiples of 8 (16-byte rows)");
   VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm: operands must be 16-byte aligned");
@@ -1621,8 +1733,7 @@ extern "C" int vlaser_gemm_nn(int epi, const VlaserGemmArgs* a, vl_stream_t s) {
   VL_CHECK(a->M > 0 && a->N > 0 && a->K > 0 && a->K % BK == 0, "vlaser_gemm_nn: bad shape M=%d N=%d K=%d (K must be a multiple of %d)", a->M, a->N, a->K, BK);
   VL_CHECK(a->N % 8 == 0 && a->lda % 8 == 0 && a->ldw % 8 == 0 && a->ldw >= a->N, "vlaser_gemm_nn: N, lda, ldw must be multiples of 8 and ldw >= N");
   VL_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "vlaser_gemm_nn: operands must be 16-byte aligned");
-  VL_CHECK(a->force_bm == 0 || a->force_bm == 2100 || a->force_bm == 1101 || a->force_bm == 1201 || a->force_bm == 1304 || a->force_bm == 1441 || a->force_bm == 1501 || a->force_bm == 1904 || a->force_bm == 1903 || a->force_bm == 1901 || a->force_bm == 1302 || a->force_bm == 1100 || a->force_bm == 1200 || a->force_bm == 1300 || a->force_bm == 1301 || a->force_bm == 1440 || a->force_bm == 1500 || a->force_bm == 1506 || a->force_bm == 1105 ||
-               a->force_bm == 1532 || a->force_bm == 1900,
+  VL_CHECK(a->force_bm == 0 || (glds_code(a->force_bm) && a->force_bm != 1564 && a->force_bm != 1566),
            "vlaser_gemm_nn: force_bm must be 0 or an LDS-DMA configuration code 1100/1105/1200/1300/1440/1500/1506/1532/1900, 2100 (lab: producer waves)");
   VL_CHECK(a->batch <= 1 || epi == VL_EPI_NONE || epi == VL_EPI_F32, "vlaser_gemm_nn: batched mode supports the NONE / F32 epilogues");
   VL_CHECK(!a->sumsq_part, "vlaser_gemm_nn: sumsq_part is honoured by vlaser_gemm_tn_lds only");
