@@ -844,7 +844,7 @@ def test_gemm_glds_ragged_and_splitk(ops, bm):
 
 
 @pytest.mark.parametrize('asym,two_stage', [(1900, 1901), (1300, 1302), (1903, 1901), (1100, 1101), (1200, 1201), (1440, 1441), (1500, 1501), (1904, 1901), (1304, 1302),
-                                            (1102, 1101), (1202, 1201), (1442, 1441), (1502, 1501), (1902, 1901), (1564, 1566)])      # r06: 1100 / 1200 / 1440 / 1500 / 1564 / 1900 pipeline their fragment reads across the barrier (x02 / 1442 / 1566 = the plain loops)
+                                            (1110, 1101), (1210, 1201), (1442, 1441), (1502, 1501), (1902, 1901), (1564, 1566)])      # r06: 1440 / 1500 / 1564 / 1900 pipeline their fragment reads across the barrier (1442 / 1502 / 1566 / 1902 = the plain loops; 1110 / 1210 = lab)
 def test_gemm_asymmetric_ring_is_bit_identical_to_the_two_stage_ring(ops, asym, two_stage):
     """r05: the 192x256 / 256x256 tiles carry a third stage for the W operand alone (weights two K-steps ahead, activations one), and every ring issues its refill one piece
     at a time between the K-step's MFMAs instead of as one burst (x01 / 1304 / 1904 = the burst forms).  Same arithmetic in the same order as the

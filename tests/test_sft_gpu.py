@@ -228,7 +228,7 @@ def test_gemm_tn_weight_gradient(K, M, N):
 
 @pytest.mark.parametrize('K,M,N,cfg', [(560, 1536, 2048, 0), (560, 17920, 1536, 0), (560, 1536, 8960, 0), (313, 256, 1536, 1100), (64, 136, 264, 1105),
                                        (130, 2048, 1536, 1200), (200, 1000, 520, 1300), (560, 17920, 1536, 1340), (200, 1000, 520, 1340), (313, 264, 1536, 1240), (64, 136, 264, 1140),
-                                       (96, 1536, 2048, 1140), (32, 304, 264, 1340), (313, 256, 1536, 1102), (130, 2048, 1536, 1202)])
+                                       (96, 1536, 2048, 1140), (32, 304, 264, 1340), (313, 256, 1536, 1110), (130, 2048, 1536, 1210)])
 def test_gemm_tn_lds_padded_contraction(K, M, N, cfg):
     """vlaser_gemm_tn_lds (the TN weight-gradient product on the LDS-DMA pipeline, both operands k-major): contraction axis padded to 64-row
     tiles with ZERO pad rows in At and arbitrary finite pad rows in Wt; edge tiles in M and N; every tile configuration.  Against fp32 and
@@ -459,9 +459,9 @@ def test_step_norm_from_producers_matches_buffer_norm(setup, monkeypatch):
         assert d <= 2 * 2 * 1e-3 + 2e-2 * pb[k].float().abs().max().item(), (k, d)
 
 
-@pytest.mark.parametrize('pipe,plain', [(1100, 1102), (1200, 1202)])
+@pytest.mark.parametrize('pipe,plain', [(1110, 1100), (1210, 1200)])
 def test_gemm_tn_lds_pipelined_reads_bit_identical(pipe, plain):
-    """r06: the TN weight-gradient tiles pipeline their fragment reads across the K-step's barrier (csrc/gemm.hip PIPE; x02 = the r03-r05 plain loop): same accumulation order,
+    """r06 lab: TN weight-gradient tiles with their fragment reads pipelined across the K-step's barrier (csrc/gemm.hip PIPE, codes 1110 / 1210; not the default): same accumulation order,
     bit-identical outputs -- contraction of 1 .. 9 tiles, ragged M / N."""
     from vlaser_amd import ops
     g = torch.Generator().manual_seed(5)

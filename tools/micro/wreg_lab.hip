@@ -192,11 +192,11 @@ int main(int argc, char** argv) {
   // `wreg_lab pipe`: the product's tile against its PIPE variant (fragment reads pipelined across the K-step's barrier, csrc/gemm.hip) on the shapes that use the tile
   if (argc > 1 && !strcmp(argv[1], "pipe")) {
     struct PS { int M, N, K; const char* name; int base, pipe; };
-    const PS ps[] = {{1025, 3072, 1024, "ViT qkv (128x128)", 1102, 1100}, {1025, 4096, 1024, "ViT fc1 (144x128)", 1442, 1440}, {384, 17920, 1536, "LLM prefill gate/up (128x256)", 1202, 1200},
+    const PS ps[] = {{1025, 3072, 1024, "ViT qkv (128x128)", 1100, 1110}, {1025, 4096, 1024, "ViT fc1 (144x128)", 1442, 1440}, {384, 17920, 1536, "LLM prefill gate/up (128x256)", 1200, 1210},
                      {384, 2048, 1536, "LLM prefill qkv-sized (64x128)", 1502, 1500}, {384, 2048, 1536, "LLM prefill qkv-sized (64x64, 4 waves)", 1566, 1564},
                      {560, 17920, 1536, "SFT forward gate/up (192x256)", 1902, 1900}, {560, 2048, 1536, "SFT qkv (64x128)", 1502, 1500},
-                     {560, 8960, 1536, "SFT 128x256", 1202, 1200}, {3408, 8192, 3584, "8B-sized (192x256)", 1902, 1900}, {3408, 8192, 3584, "8B-sized (128x256)", 1202, 1200},
-                     {13 * 1025, 4096, 1024, "ViT fc1 x 13 tiles (128x256)", 1202, 1200}};
+                     {560, 8960, 1536, "SFT 128x256", 1200, 1210}, {3408, 8192, 3584, "8B-sized (192x256)", 1902, 1900}, {3408, 8192, 3584, "8B-sized (128x256)", 1200, 1210},
+                     {13 * 1025, 4096, 1024, "ViT fc1 x 13 tiles (128x256)", 1200, 1210}};
     printf("| shape | base us (code) | PIPE us (code) | delta | bit-identical |\n|---|---|---|---|---|\n");
     hipStream_t s; CK(hipStreamCreate(&s));
     unsigned* dcnt; CK(hipMalloc(&dcnt, 4));
@@ -296,13 +296,13 @@ int main(int argc, char** argv) {
       continue;
     }
     // the product (vlaser_gemm, its own tile choice and the forced 192x256 / 256x256 / 128x256 rings)
-    for (int cfg : {0, 1902, 1300, 1202}) {
+    for (int cfg : {0, 1902, 1300, 1200}) {
       VlaserGemmArgs a; memset(&a, 0, sizeof a);
       a.A = x; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldo = N; a.force_bm = cfg;
       auto launch = [&](int i) { a.W = w[i % NL]; a.out = cfg == 1902 ? ref : out; if (vlaser_gemm(VL_EPI_NONE, &a, s)) { printf("vlaser_gemm: %s\n", vlaser_last_error()); exit(1); } };
       const double us = time_graph(launch);
       char nm[64]; snprintf(nm, sizeof nm, "product force_bm=%d", cfg);
-      report(nm, us, cfg == 1300 ? 256 : cfg == 1202 ? 128 : 192, cfg == 1902 ? "(reference)" : "");
+      report(nm, us, cfg == 1300 ? 256 : cfg == 1200 ? 128 : 192, cfg == 1902 ? "(reference)" : "");
     }
     LabP p{x, nullptr, out, M, N, K, 0, 0};
     auto lab = [&](const char* what, int bm, auto&& fn, bool divides) {

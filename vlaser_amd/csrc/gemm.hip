@@ -1389,17 +1389,17 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
   }
   {
     static const bool no_pipe = getenv("VLASER_GEMM_NO_PIPE") != nullptr;      // diagnostics / same-box A/B: the r05 plain K loop on the tiles that pipeline their fragment reads
-    if (no_pipe) bm = bm == 1100 ? 1102 : bm == 1200 ? 1202 : bm == 1440 ? 1442 : bm == 1500 ? 1502 : bm == 1564 ? 1566 : bm == 1900 ? 1902 : bm;
+    if (no_pipe) bm = bm == 1440 ? 1442 : bm == 1500 ? 1502 : bm == 1564 ? 1566 : bm == 1900 ? 1902 : bm;
   }
   if constexpr (AKM) {
     switch (bm) {
       // (r05: neither the asymmetric ring nor the spread refill helps the TN form -- both operands are activations / gradients out of L2, and its 256x256 tile lost 3-6 % with
       // the pieces between the MFMAs: profiles/r05z_spread_lab.md -- so it keeps the r04 rings)
-      case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4, true, true, false, 0, false, false, true>(args, stream, splits);      // (r06: + PIPE; 1102 / 1202 = the r03-r05 plain loops)
-      case 1102: return launch_glds<EPI, 128, 128, 2, 4, 4, true, true>(args, stream, splits);
+      case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4, true, true>(args, stream, splits);
+      case 1110: return launch_glds<EPI, 128, 128, 2, 4, 4, true, true, false, 0, false, false, true>(args, stream, splits);      // lab (r06): PIPE on the TN tiles -- the step moved by 0.05 ms: not the default
       case 1105: return launch_glds<EPI, 128, 128, 2, 4, 5, true, true>(args, stream, splits);
-      case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3, true, true, false, 0, false, false, true>(args, stream, splits);
-      case 1202: return launch_glds<EPI, 128, 256, 2, 4, 3, true, true>(args, stream, splits);
+      case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3, true, true>(args, stream, splits);
+      case 1210: return launch_glds<EPI, 128, 256, 2, 4, 3, true, true, false, 0, false, false, true>(args, stream, splits);
       case 1300: return launch_glds<EPI, 256, 256, 2, 4, 2, true, true>(args, stream, splits);
       // r04: two staggered wave groups over a ring of four 32-deep buffers (gemm_tn_stag_kernel)
       case 1340: if constexpr (EPI == VL_EPI_NONE) return launch_tn_stag<256, 256>(args, stream); break;
@@ -1407,19 +1407,20 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
       case 1140: if constexpr (EPI == VL_EPI_NONE) return launch_tn_stag<128, 128>(args, stream); break;
       default: break;
     }
-    vlaser_set_error("vlaser_gemm_tn_lds: force_cfg must be 0 or 1100 / 1102 / 1105 / 1200 / 1202 / 1300 / 1140 / 1240 / 1340 (got %d)", bm);
+    vlaser_set_error("vlaser_gemm_tn_lds: force_cfg must be 0 or 1100 / 1110 / 1105 / 1200 / 1210 / 1300 / 1140 / 1240 / 1340 (got %d)", bm);
     return -1;
   }
   switch (bm) {
     // r05: the refill's pieces go out one at a time between the K-step's MFMAs (SPREAD: bit-identical, -1 ... -9 % per launch, tools/micro/spread_lab.py); 1101 / 1201 / 1304 / 1441 /
     // 1501 / 1904 = the burst forms of r02-r04 (lab, VLASER_GEMM_NO_SPREAD=1)
-    // r06: fragment reads pipelined across the K-step's barrier (PIPE: bit-identical; whole launches -1.4 % on 128x128, -5.0 % on 144x128, -3.5 ... -4.0 % on 64x128, -4.6 ... -5.6 % on
-    // 192x256, neutral on 128x256 -- profiles/r06o_pipe_ab.md); x02 / 1442 = the r05 defaults (spread refill, plain loop) for same-box A/B (VLASER_GEMM_NO_PIPE=1)
-    case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM, false, false, 0, false, true, true>(args, stream, splits);
-    case 1102: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM, false, false, 0, false, true>(args, stream, splits);
+    // r06: fragment reads pipelined across the K-step's barrier (PIPE: bit-identical; whole launches -4.1 ... -5.0 % on 144x128, -2.5 ... -5.3 % on 64x128, -6.1 ... -6.3 % on 64x64,
+    // -4.3 ... -6.6 % on 192x256, noise on 128x128 / 128x256 which keep the plain loop -- profiles/r06o_pipe_ab.md); 1442 / 1502 / 1566 / 1902 = the r05 defaults for same-box A/B
+    // (VLASER_GEMM_NO_PIPE=1)
+    case 1100: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM, false, false, 0, false, true>(args, stream, splits);
+    case 1110: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM, false, false, 0, false, true, true>(args, stream, splits);      // lab: PIPE on 128x128 (-2.4 ... +3.6 %: noise; not the default)
     case 1101: return launch_glds<EPI, 128, 128, 2, 4, 4, WKM>(args, stream, splits);
-    case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3, WKM, false, false, 0, false, true, true>(args, stream, splits);      // (r06: + PIPE: +0.3 ... -2.2 % per launch)
-    case 1202: return launch_glds<EPI, 128, 256, 2, 4, 3, WKM, false, false, 0, false, true>(args, stream, splits);
+    case 1200: return launch_glds<EPI, 128, 256, 2, 4, 3, WKM, false, false, 0, false, true>(args, stream, splits);
+    case 1210: return launch_glds<EPI, 128, 256, 2, 4, 3, WKM, false, false, 0, false, true, true>(args, stream, splits);      // lab: PIPE on 128x256 (-2.2 ... +2.0 %: noise; not the default)
     case 1201: return launch_glds<EPI, 128, 256, 2, 4, 3, WKM>(args, stream, splits);
     // r05: the two-stage rings carry a THIRD stage for the W operand alone (ASYM: weights two steps ahead, activations one; 256x256: 2 x 32 + 3 x 32 = 160 KB, 192x256: 144 KB):
     // bit-identical, 3408 x 8192 x 3584 193.9 -> 168.6 us, the SFT forward's gate/up 42.7 -> 37.2 us (tools/micro/asym_ring_lab.py, profiles/r05t_asym_ring_lab.md)
@@ -1680,7 +1681,7 @@ extern "C" int vlaser_gemm_tn_lds(const void* At, const void* Wt, void* out, int
 }
 
 static bool glds_code(int bm) {      // every LDS-DMA configuration code launch<> knows (defaults + lab variants)
-  static const int codes[] = {1100, 1101, 1102, 1105, 1200, 1201, 1202, 1300, 1301, 1302, 1304, 1440, 1441, 1442, 1500, 1501, 1502, 1506, 1532, 1564, 1566, 1900, 1901, 1902, 1903, 1904, 2100};
+  static const int codes[] = {1100, 1101, 1110, 1105, 1200, 1201, 1210, 1300, 1301, 1302, 1304, 1440, 1441, 1442, 1500, 1501, 1502, 1506, 1532, 1564, 1566, 1900, 1901, 1902, 1903, 1904, 2100};
   for (int c : codes) if (c == bm) return true;
   return false;
 }
