@@ -844,7 +844,7 @@ def test_gemm_glds_ragged_and_splitk(ops, bm):
 
 
 @pytest.mark.parametrize('asym,two_stage', [(1900, 1901), (1300, 1302), (1903, 1901), (1100, 1101), (1200, 1201), (1440, 1441), (1500, 1501), (1904, 1901), (1304, 1302),
-                                            (1110, 1101), (1210, 1201), (1442, 1441), (1502, 1501), (1902, 1901), (1564, 1566)])      # r06: 1440 / 1500 / 1564 / 1900 pipeline their fragment reads across the barrier (1442 / 1502 / 1566 / 1902 = the plain loops; 1110 / 1210 = lab)
+                                            (1110, 1101), (1210, 1201), (1442, 1441), (1502, 1501), (1902, 1901), (1564, 1566), (1310, 1302)])      # r06: 1440 / 1500 / 1564 / 1900 pipeline their fragment reads across the barrier (1442 / 1502 / 1566 / 1902 = the plain loops; 1110 / 1210 = lab)
 def test_gemm_asymmetric_ring_is_bit_identical_to_the_two_stage_ring(ops, asym, two_stage):
     """r05: the 192x256 / 256x256 tiles carry a third stage for the W operand alone (weights two K-steps ahead, activations one), and every ring issues its refill one piece
     at a time between the K-step's MFMAs instead of as one burst (x01 / 1304 / 1904 = the burst forms).  Same arithmetic in the same order as the
@@ -857,7 +857,7 @@ def test_gemm_asymmetric_ring_is_bit_identical_to_the_two_stage_ring(ops, asym, 
         ops.gemm(L.EPI_NONE, x, w, out=o2, force_bm=two_stage)
         assert torch.equal(o1, o2), (M, N, K)
         close(o1, x.float() @ w.float().t(), rtol=1e-2, atol=1e-2, name=f'nt {M}x{N}x{K} cfg{asym}')
-        if N % 8 == 0 and asym != 1564:
+        if N % 8 == 0 and asym not in (1564, 1310):
             wk = w.t().contiguous()
             ops.gemm_nn(L.EPI_NONE, x, wk, out=o1, force_bm=asym)
             ops.gemm_nn(L.EPI_NONE, x, wk, out=o2, force_bm=two_stage)

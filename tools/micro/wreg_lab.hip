@@ -196,7 +196,9 @@ int main(int argc, char** argv) {
                      {384, 2048, 1536, "LLM prefill qkv-sized (64x128)", 1502, 1500}, {384, 2048, 1536, "LLM prefill qkv-sized (64x64, 4 waves)", 1566, 1564},
                      {560, 17920, 1536, "SFT forward gate/up (192x256)", 1902, 1900}, {560, 2048, 1536, "SFT qkv (64x128)", 1502, 1500},
                      {560, 8960, 1536, "SFT 128x256", 1200, 1210}, {3408, 8192, 3584, "8B-sized (192x256)", 1902, 1900}, {3408, 8192, 3584, "8B-sized (128x256)", 1200, 1210},
-                     {13 * 1025, 4096, 1024, "ViT fc1 x 13 tiles (128x256)", 1200, 1210}};
+                     {13 * 1025, 4096, 1024, "ViT fc1 x 13 tiles (128x256)", 1200, 1210},
+                     {3408, 8192, 3584, "8B-sized (256x256 ASYM)", 1300, 1310}, {3408, 37888, 3584, "8B gate/up (256x256 ASYM)", 1300, 1310}, {3408, 3584, 18944, "8B down (256x256 ASYM)", 1300, 1310},
+                     {13 * 1025, 4096, 1024, "ViT fc1 x 13 tiles (256x256 ASYM)", 1300, 1310}};
     printf("| shape | base us (code) | PIPE us (code) | delta | bit-identical |\n|---|---|---|---|---|\n");
     hipStream_t s; CK(hipStreamCreate(&s));
     unsigned* dcnt; CK(hipMalloc(&dcnt, 4));

@@ -1426,6 +1426,7 @@ static int launch(const VlaserGemmArgs* args, hipStream_t stream) {
     // bit-identical, 3408 x 8192 x 3584 193.9 -> 168.6 us, the SFT forward's gate/up 42.7 -> 37.2 us (tools/micro/asym_ring_lab.py, profiles/r05t_asym_ring_lab.md)
     case 1300: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM, false, false, 0, true, true>(args, stream, splits);
     case 1304: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM, false, false, 0, true>(args, stream, splits);      // lab: asymmetric ring, refill as one burst
+    case 1310: if constexpr (!WKM) return launch_glds<EPI, 256, 256, 2, 4, 2, false, false, false, 0, true, true, true>(args, stream, splits); break;      // lab (r06): PIPE on 256x256, NT only (the NN form's transposing reads spill at 256 registers)
     case 1301: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM, false, true>(args, stream, splits);      // lab: the two-stage 256x256 ring with the refill requested first
     case 1302: return launch_glds<EPI, 256, 256, 2, 4, 2, WKM>(args, stream, splits);                   // lab: the r02-r04 two-stage ring
     case 1500: return launch_glds<EPI, 64, 128, 2, 4, 4, WKM, false, false, 0, false, true, true>(args, stream, splits);
@@ -1681,7 +1682,7 @@ extern "C" int vlaser_gemm_tn_lds(const void* At, const void* Wt, void* out, int
 }
 
 static bool glds_code(int bm) {      // every LDS-DMA configuration code launch<> knows (defaults + lab variants)
-  static const int codes[] = {1100, 1101, 1110, 1105, 1200, 1201, 1210, 1300, 1301, 1302, 1304, 1440, 1441, 1442, 1500, 1501, 1502, 1506, 1532, 1564, 1566, 1900, 1901, 1902, 1903, 1904, 2100};
+  static const int codes[] = {1100, 1101, 1110, 1105, 1200, 1201, 1210, 1310, 1300, 1301, 1302, 1304, 1440, 1441, 1442, 1500, 1501, 1502, 1506, 1532, 1564, 1566, 1900, 1901, 1902, 1903, 1904, 2100};
   for (int c : codes) if (c == bm) return true;
   return false;
 }
