@@ -334,6 +334,9 @@ int main(int argc, char** argv) {
     lab("W in VGPRs, 1 x 8 waves: 128x256, A 9 stages, W ring 6", 128, [](const LabP& q, hipStream_t st) { launch_lab<128, 1, 9, 6, true, 8>(q, st); }, nk % 6 == 0);
     lab("W in VGPRs, 1 x 8 waves: 192x256, A 6 stages, W ring 4", 192, [](const LabP& q, hipStream_t st) { launch_lab<192, 1, 6, 4, true, 8>(q, st); }, nk % 4 == 0);
     lab("W in VGPRs, 1 x 8 waves: 192x256, A 6 stages, W ring 2", 192, [](const LabP& q, hipStream_t st) { launch_lab<192, 1, 6, 2, true, 8>(q, st); }, nk % 2 == 0);
+    lab("W in VGPRs, 1 x 8 waves: 256x256, A 5 stages, W ring 2", 256, [](const LabP& q, hipStream_t st) { launch_lab<256, 1, 5, 2, true, 8>(q, st); }, nk % 2 == 0);
+    lab("W in VGPRs, 1 x 8 waves: 256x256, A 4 stages, W ring 2", 256, [](const LabP& q, hipStream_t st) { launch_lab<256, 1, 4, 2, true, 8>(q, st); }, nk % 2 == 0);
+    lab("W in VGPRs, 1 x 8 waves: 256x256, A 5 stages, W ring 3", 256, [](const LabP& q, hipStream_t st) { launch_lab<256, 1, 5, 3, true, 8>(q, st); }, nk % 3 == 0);
     lab("W in VGPRs, 1 x 8 waves: 64x256, A 9 stages, W ring 4", 64, [](const LabP& q, hipStream_t st) { launch_lab<64, 1, 9, 4, true, 8>(q, st); }, nk % 4 == 0);
     CK(hipFree(x)); CK(hipFree(out)); CK(hipFree(ref));
     for (int i = 0; i < NL; ++i) { CK(hipFree(w[i])); CK(hipFree(wp[i])); }
