@@ -83,6 +83,17 @@ __global__ __launch_bounds__(512) void lab_kernel(int steps, float* sink, int ra
   if (acc_sum == 12345.678f) sink[blockIdx.x] = acc_sum;
 }
 
+// `kstep_pipe_lab power`: the resident loop (no memory traffic of its own) beside a second stream that streams HBM -- does the K-step stretch although the two share no unit?
+__global__ __launch_bounds__(256) void stream_kernel(const u32x4* __restrict__ src, size_t n16, int rounds, float* sink) {
+  u32x4 acc = {0, 0, 0, 0};
+  for (int r = 0; r < rounds; ++r)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+      const u32x4 v = __builtin_nontemporal_load(src + i);
+      acc[0] ^= v[0]; acc[1] ^= v[1]; acc[2] ^= v[2]; acc[3] ^= v[3];
+    }
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[blockIdx.x] = 1.f;
+}
+
 template <int BM, int VAR>
 static void run(const char* what, float* sink, int random) {
   const int steps = 4800, lds = (BM + 256) * 128;
@@ -102,9 +113,33 @@ static void run(const char* what, float* sink, int random) {
   fflush(stdout);
 }
 
-int main() {
+int main(int argc, char** argv) {
   float* sink;
   hipMalloc((void**)&sink, 256 * 4);
+  if (argc > 1 && !strcmp(argv[1], "power")) {
+    const size_t bytes = (size_t)2 << 30;
+    u32x4* buf; hipMalloc((void**)&buf, bytes); hipMemset(buf, 1, bytes);
+    hipStream_t s1, s2; hipStreamCreate(&s1); hipStreamCreate(&s2);
+    const int steps = 4800, lds = (192 + 256) * 128;
+    hipFuncSetAttribute((const void*)lab_kernel<192, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    printf("| 192x256 resident K loop (product order, random operands, no memory traffic of its own) beside ... | us per K-step | background GB/s |\n|---|---|---|\n");
+    for (int wgs : {0, 32, 64, 128, 256, 512, 0}) {
+      hipEvent_t e0, e1, b0, b1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&b0); hipEventCreate(&b1);
+      hipLaunchKernelGGL((lab_kernel<192, 0>), dim3(256), dim3(512), lds, s1, 240, sink, 1);
+      hipDeviceSynchronize();
+      const int rounds = 12;
+      if (wgs) { hipEventRecord(b0, s2); hipLaunchKernelGGL(stream_kernel, dim3(wgs), dim3(256), 0, s2, buf, bytes / 16, rounds, sink); hipEventRecord(b1, s2); }
+      hipEventRecord(e0, s1);
+      hipLaunchKernelGGL((lab_kernel<192, 0>), dim3(256), dim3(512), lds, s1, steps, sink, 1);
+      hipEventRecord(e1, s1);
+      hipDeviceSynchronize();
+      float ms = 0, bms = 0; hipEventElapsedTime(&ms, e0, e1); if (wgs) hipEventElapsedTime(&bms, b0, b1);
+      char w[96]; snprintf(w, sizeof w, wgs ? "%d streaming workgroups (nt loads over 2 GiB)" : "nothing", wgs);
+      printf("| %s | %.3f | %s |\n", w, ms * 1e3 / steps, wgs ? ([&] { static char b[32]; snprintf(b, 32, "%.0f (stream ran %.1f ms, loop %.1f ms)", (double)bytes * rounds / (bms * 1e-3) / 1e9, bms, ms); return b; }()) : "");
+      fflush(stdout);
+    }
+    return 0;
+  }
   printf("| tile | operands | K-step structure (one barrier per step, operands resident in LDS) | us per K-step | TFLOP/s (256 CUs) |\n|---|---|---|---|---|\n");
   for (int random = 1; random >= 0; --random) {
     run<192, 0>("product order: reads h0, MFMAs h0, reads h1, MFMAs h1", sink, random);
