@@ -326,6 +326,27 @@ int vlaser_cast_f32_bf16(const float* x, void* y, long long n, vl_stream_t strea
  * operation order, one bf16 rounding.  layout 0: planar [n,3,H,W]; 1: interleaved [n,H,W,3].  hw = H*W (multiple of 4); mean3 / std3: HOST float[3]. */
 int vlaser_normalize_u8(const void* in_u8, void* out_bf16, int n_img, int hw, int layout, int mode, const float* mean3, const float* std3,
                         vl_stream_t stream);
+/* ---- (ABI 8, r06) image preparation on the device: the bicubic resize + tile cut of `load_image` (eval_example.py:38-82: `dynamic_preprocess` =
+ * dataset.py:830-866 `image.resize((target_width, target_height))` :849, the crop loop :851-862, the thumbnail :864; `build_transform` dataset.py:276-310).  The
+ * reference resizes on the host through Pillow (pillow==11.2.1, Vlaser_VLA/Simpler/requirements.txt:165; `Image.resize`, default filter BICUBIC ->
+ * libImaging/Resample.c): 8-bit fixed-point separable resampling, horizontal pass then vertical pass, the intermediate image rounded to 8 bits.  Bit-exact with
+ * Pillow (tests/test_resize.py, tests/test_image_gpu.py).
+ *
+ * vlaser_resample_ksize / vlaser_resample_coeffs: HOST functions, no GPU work -- Pillow's precompute_coeffs + normalize_coeffs_8bpc for one axis (whole-image box):
+ * bounds[2 * out_size] = (first input index, tap count) per output index, kk_t[ksize * out_size] = the 22-bit fixed-point weights TRANSPOSED (kk_t[k * out_size + i]:
+ * tap k of output i; taps beyond the count are 0).  Returns ksize = 2 ceil(2 max(in / out, 1)) + 1, or -1.  The caller copies both tables to the device.
+ *
+ * vlaser_resize_u8: src [H, W, 3] uint8 (row stride ld_src bytes) -> dst [h, w, 3] (ld_dst); tmp [H, w, 3] (ld_tmp) is the intermediate image, needed only when
+ * both axes change.  bounds_* / kk_* are DEVICE copies of the tables for (W -> w) and (H -> h); an axis that keeps its size takes NULL tables and is skipped, equal
+ * sizes on both axes are a copy (as Pillow).  Row strides that are multiples of 4 on dword-aligned images take the dword paths. */
+int vlaser_resample_ksize(int in_size, int out_size);
+int vlaser_resample_coeffs(int in_size, int out_size, int* bounds, int* kk_t);
+int vlaser_resize_u8(const void* src, int H, int W, long long ld_src, void* tmp, long long ld_tmp, void* dst, int h, int w, long long ld_dst, const int* bounds_x,
+                     const int* kk_x, int ksize_x, const int* bounds_y, const int* kk_y, int ksize_y, vl_stream_t stream);
+/* [rows * tile, cols * tile, 3] uint8 (row stride ld, multiple of 4) -> bf16 pixel_values [cols * rows, 3, tile, tile]: tile i = box ((i % cols) tile, (i / cols) tile, ...)
+ * of dynamic_preprocess's crop loop (dataset.py:851-862), normalised as vlaser_normalize_u8 (mode 1 = ToTensor + Normalize, dataset.py:297-299).  tile % 4 == 0. */
+int vlaser_tiles_normalize_u8(const void* src_u8, long long ld, int cols, int rows, int tile, void* out_bf16, int mode, const float* mean3, const float* std3,
+                              vl_stream_t stream);
 /* CrossEntropyLoss rows (modeling_internvl_chat.py:231-243): loss_row[r] = lse(logits[r]) - logits[r,label], 0 for
  * ignore_index; lse_row optional. */
 int vlaser_ce_rows(const float* logits, const int64_t* labels, int R, int N, long long ld, float* loss_row, float* lse_row,

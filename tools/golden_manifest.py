@@ -18,4 +18,5 @@ FIXTURES = {
     'META.json': 'tools/gen_golden.py',
     'g8_adapter.npz': 'tools/gen_golden_adapter.py',
     'g9_vla_state_keys.json': 'tools/gen_golden_vla_keys.py',
+    'g12_resize.npz': 'tools/gen_golden_resize.py',          # Pillow's outputs (the resampler is a third-party dependency of the reference: no reference import)
 }

@@ -93,6 +93,10 @@ _SIGS = {
     'vlaser_vla_stage': [C.POINTER(VlaStageArgs), vp],
     'vlaser_cast_f32_bf16': [vp, vp, i64, vp],
     'vlaser_normalize_u8': [vp, vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp],
+    'vlaser_resample_ksize': [i32, i32],
+    'vlaser_resample_coeffs': [i32, i32, vp, vp],
+    'vlaser_resize_u8': [vp, i32, i32, i64, vp, i64, vp, i32, i32, i64, vp, vp, i32, vp, vp, i32, vp],
+    'vlaser_tiles_normalize_u8': [vp, i64, i32, i32, i32, vp, i32, C.POINTER(f32), C.POINTER(f32), vp],
     'vlaser_avg_update': [vp, vp, i64, f32, i32, vp],
     'vlaser_ce_rows': [vp, vp, i32, i32, i64, vp, vp, i64, vp],
     'vlaser_reduce_norm': [vp, vp, i32, vp, vp, i32, vp, vp, f32, vp, vp, i32, i32, vp],

@@ -14,7 +14,7 @@ void vlaser_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* vlaser_last_error(void) { return g_err; }
-extern "C" int vlaser_abi_version(void) { return 7; }
+extern "C" int vlaser_abi_version(void) { return 8; }
 
 // ---- CU-masked streams (ABI 7) -- see include/vlaser_hip.h
 #include <hip/hip_runtime.h>
