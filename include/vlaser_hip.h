@@ -106,7 +106,8 @@ int vlaser_gemm_nn(int epi, const VlaserGemmArgs* args, vl_stream_t stream);
  * prefill, the 4 action tokens of every Euler step (pizero_internvl.py:896-908) and single-token greedy decode.
  * Masks are passed as descriptors instead of dense [B,1,Sq,Skv] additive tensors (pizero_internvl.py:517-603):
  * key j is visible to query row i iff  j < lim1(i)  ||  blk_start <= j < kv_len (rows >= blk_start only). */
-enum { VL_ATTN_FULL = 0, VL_ATTN_CAUSAL = 1, VL_ATTN_PREFIX = 2 };
+enum { VL_ATTN_FULL = 0, VL_ATTN_CAUSAL = 1, VL_ATTN_PREFIX = 2,
+       VL_ATTN_DENSE = 3 /* (ABI 8) a dense ADDITIVE mask as the reference hands it to eager_attention_forward (joint_model.py:636-656): see `mask` below */ };
 
 typedef struct {
   const void* q;   /* bf16, element (b,h,s,d) at q + b*q_bs + h*q_hs + s*q_ss + d */
@@ -130,6 +131,12 @@ typedef struct {
                                    proprio row riding in front of the action rows (pizero_internvl.py:517-587: proprio sees prefix + self) */
   float* lse_out;               /* vlaser_attn_prefill, optional (ABI 4): fp32 [B, n_q_heads, sq] base-2 log-sum-exp of the scaled scores, kept for vlaser_attn_bwd */
   unsigned long long* dbg;      /* vlaser_attn_skinny, optional (ABI 6): per-workgroup timestamps [grid][8] (wall_clock64, 100 MHz) for kernel tuning */
+  /* (ABI 8) VL_ATTN_DENSE (vlaser_attn_prefill at head_dim 128, vlaser_chain_attn): fp32 additive mask, element (b, query token i, key j) at
+   * mask[b * mask_bs + i * mask_rs + j] -- the same value for every head, as the reference's [B,1,Sq,Skv] tensors.  score = q.k * scale + mask; a value below -1e30
+   * (the reference writes finfo(dtype).min) hides the key outright; a query row with no visible key returns 0 (the reference: the mean of V -- nobody reads such
+   * rows).  mask_rs must be a multiple of 4 floats >= kv_len rounded up to 64 (prefill) / 32 (chain) keys, the base 16-byte aligned: values past kv_len are read and ignored. */
+  const float* mask;
+  long long mask_bs, mask_rs;
 } VlaserAttnArgs;
 
 int vlaser_attn_prefill(const VlaserAttnArgs* args, vl_stream_t stream);
@@ -309,6 +316,11 @@ typedef struct {
   const int64_t* pos_vlm; const int64_t* pos_pro; const int64_t* pos_act;
   int32_t* pos_vlm_out; int32_t* pos_pro_out; int32_t* pos_act_out; int32_t* pos_ride_out;
   long long itp_bs, itp_rs, act_bs, act_rs;   /* element strides of the masks' batch / row axes (0 = dense): split_full_mask_into_submasks (:589-603) returns slices of the full mask */
+  /* (ABI 8) mask_slot != NULL: GENERAL masks -- instead of being checked against the prefix + trailing-block pattern, both masks are COPIED as fp32 into
+   * mask_slot [B, T + 1 + n_act, mask_ld] (rows 0..T = image_text_proprio_mask, rows T+1.. = action_mask; columns past a row's width filled with -FLT_MAX) for the
+   * VL_ATTN_DENSE attention launches of the graph.  The one thing still refused (error bit 8): an image / text row that sees the proprio key -- the cached-prefix
+   * schedule computes the prefix rows' attention before the proprio token's K / V exist.  Both masks must be given; mask_ld % 32 == 0, >= T + 1 + n_act. */
+  float* mask_slot; int mask_ld;
 } VlaserVlaStageArgs;
 int vlaser_vla_stage(const VlaserVlaStageArgs* args, vl_stream_t stream);
 /* (ABI 4) Everything between two passes through the expert's layers in ONE launch: [finish != 0: the tail of the previous Euler step exactly as

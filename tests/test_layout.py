@@ -317,7 +317,7 @@ def test_golden_manifest_matches_directory():
     src = open(os.path.join(ROOT, 'tools', 'gen_golden.py')).read()
     main = src[src.index('def main():'):]
     default_path = main[main.index("t_start = time.time()"):]
-    for fn in ('g1_prompts(', 'g2_tiling(', 'g3_g4(', 'g5_g6(', 'g6b_ragged(', 'g7_vla(', 'g7b_trace(', 'g7c_integrators(', 'g10_flow_matching(', 'g10b_flow_matching_vlm(',
+    for fn in ('g1_prompts(', 'g2_tiling(', 'g3_g4(', 'g5_g6(', 'g6b_ragged(', 'g7_vla(', 'g7b_trace(', 'g7c_integrators(', 'g7d_general_masks(', 'g10_flow_matching(', 'g10b_flow_matching_vlm(',
                'g8_sft_grads(', 'g11_packed('):
         assert fn in default_path, f'{fn} missing from the default path of tools/gen_golden.py'
 

@@ -146,6 +146,32 @@ def test_infer_action_integration_methods(golden_dir, golden_model):
         ovla.integration_step(torch.zeros(1), 0.1, torch.zeros(1), 'midpoint')
 
 
+def g7d_case(d, case, vla):
+    """Inputs of one G7d case rebuilt from the fixture: (ids, pixel_values, image_text_proprio_mask, action_mask, position ids x 3, proprio, noise)."""
+    T, na = vla.max_image_text_tokens, vla.num_action_tokens
+    Lt = T + 1 + na
+    pv = torch.randn(1, 3, 448, 448, generator=torch.Generator().manual_seed(int(d[f'{case}_pixel_seed'])))
+    ids = torch.from_numpy(d[f'{case}_input_ids'])
+    vis = torch.from_numpy(np.unpackbits(d[f'{case}_mask_bits'])[:Lt * Lt].reshape(Lt, Lt).astype(bool))
+    bias = torch.from_numpy(d[f'{case}_mask_bias']).float() if d[f'{case}_mask_bias'].size else torch.zeros(Lt, Lt)
+    mask = torch.where(vis, bias, torch.full((), torch.finfo(torch.float32).min))[None, None]
+    m1, m2 = ovla.split_full_mask_into_submasks(mask, vla)
+    _, vp, pp, ap = ovla.build_causal_mask_and_position_ids((ids != vla.base.pad_token_id).long(), torch.float32, vla)
+    return ids, pv, m1, m2, vp, pp, ap, torch.from_numpy(d[f'{case}_proprio']), torch.from_numpy(d[f'{case}_noise'])
+
+
+def test_infer_action_general_masks(golden_dir, golden_model):
+    """G7d: the reference's own chunks under masks its builder never produces (left-padded prompt, causal text, finite biases + a hole in an action row): the additive
+    tensors go straight into eager attention (joint_model.py:636-656), and the oracle adds them the same way."""
+    _, vla, sd = golden_model
+    d = np.load(os.path.join(golden_dir, 'g7d_general_masks.npz'))
+    for case in ('a', 'b', 'c'):
+        ids, pv, m1, m2, vp, pp, ap, pro, noise = g7d_case(d, case, vla)
+        act = ovla.infer_action(sd, vla, ids, pv, m1, m2, vp, pp, ap, pro, noise)
+        np.testing.assert_allclose(act.numpy(), d[f'{case}_action'], rtol=0, atol=2e-5)
+    assert int((torch.from_numpy(d['a_input_ids'])[0, :50] == vla.base.pad_token_id).sum()) == 50          # case a really is left-padded
+
+
 def test_infer_action(golden_dir, golden_model):
     _, vla, sd = golden_model
     d = np.load(os.path.join(golden_dir, 'g7_vla.npz'))

@@ -384,6 +384,63 @@ def g7c_integrators(fake, vla):
     np.savez_compressed(os.path.join(OUT, 'g7c_integrators.npz'), **d)
 
 
+def g7d_general_masks(fake, vla):
+    """G7d: the reference's `infer_action` under masks its own builder never produces -- the additive [B,1,Sq,Skv] tensors go straight into `eager_attention_forward`
+    (joint_model.py:636-656), so any pattern / finite bias is legal input.  Three cases: the prompt LEFT-padded by 50 positions (the valid tokens are not a prefix; position ids
+    as the builder returns them), the same with the text after the image attending causally, and the right-padded prompt with finite biases on every visible entry + a hole in
+    one action row.  Inputs that cannot be rebuilt from a seed (the masks) are stored."""
+    FMIN = torch.finfo(torch.float32).min
+    T, na = 384, vla.num_action_tokens
+    Lt = T + 1 + na
+    d = {}
+    for case, (seed, left, kind) in {'a': (0, 50, 'plain'), 'b': (1, 50, 'causal_text'), 'c': (2, 0, 'bias')}.items():
+        g = torch.Generator().manual_seed(100 + seed)
+        pv = torch.randn(1, 3, 448, 448, generator=g)
+        ids = torch.full((1, T), 151643)
+        ids[0, left:left + 10] = torch.randint(0, 151643, (10,), generator=g)
+        ids[0, left + 10:left + 266] = 151667
+        ids[0, left + 266:left + 277] = torch.randint(0, 151643, (11,), generator=g)
+        am = (ids != 151643).long()
+        proprio = torch.rand(1, 1, 7, generator=g) * 2 - 1
+        noise = torch.randn(1, na, 7, generator=g)
+        _, vp, pp, ap = RP.PiZero.build_causal_mask_and_position_ids(fake, am, torch.float32)
+        m = torch.full((1, Lt, Lt), FMIN)
+        vis = am[0].bool()
+        m[0, :T, :T][vis[:, None] & vis[None, :]] = 0.0
+        m[0, T:, :T][:, vis] = 0.0
+        m[:, T, T] = 0.0
+        m[:, T + 1:, T:] = 0.0
+        if kind == 'causal_text':
+            idx = am[0].nonzero().flatten()[-11:]
+            for a_, i in enumerate(idx):
+                m[0, i, idx[a_ + 1:]] = FMIN
+        if kind == 'bias':
+            m = torch.where(m < -1e30, m, torch.randn(1, Lt, Lt, generator=g))
+            m[:, T + 2, 20:60] = FMIN
+        mask = m[:, None]
+        m1, m2 = RP.PiZero.split_full_mask_into_submasks(fake, mask)
+        real_randn = torch.randn
+        torch.randn = lambda *a, **k: noise.clone()          # the reference draws its noise inside infer_action (:879-881): hand it this case's
+        try:
+            act = RP.PiZero.infer_action(fake, ids, pv, m1, m2, vp, pp, ap, proprio)
+        finally:
+            torch.randn = real_randn
+        d[f'{case}_input_ids'], d[f'{case}_pixel_seed'], d[f'{case}_proprio'], d[f'{case}_noise'] = ids.numpy(), np.array(100 + seed), proprio.numpy(), noise.numpy()
+        d[f'{case}_mask_bits'] = np.packbits((mask[0, 0] > -1e30).numpy())                      # visibility as bits ...
+        d[f'{case}_mask_bias'] = (torch.where(mask[0, 0] < -1e30, torch.zeros(()), mask[0, 0]).to(torch.float16).numpy() if kind == 'bias' else np.zeros(0, np.float16))
+        if kind == 'bias':       # (... and the biases as the fp16 values the mask is REBUILT from: the reference ran on exactly those)
+            mask_r = torch.where(mask[0, 0] < -1e30, mask[0, 0], torch.from_numpy(d[f'{case}_mask_bias']).float())[None, None]
+            m1, m2 = RP.PiZero.split_full_mask_into_submasks(fake, mask_r)
+            torch.randn = lambda *a, **k: noise.clone()
+            try:
+                act = RP.PiZero.infer_action(fake, ids, pv, m1, m2, vp, pp, ap, proprio)
+            finally:
+                torch.randn = real_randn
+        d[f'{case}_action'] = act.numpy()
+        print('G7d', case, kind, 'left pad', left, 'action', act.flatten()[:4].tolist())
+    np.savez_compressed(os.path.join(OUT, 'g7d_general_masks.npz'), **d)
+
+
 def _g7_case(fake, seed, n_valid):
     g = torch.Generator().manual_seed(seed)
     pv = torch.randn(1, 3, 448, 448, generator=g)
@@ -674,9 +731,12 @@ def main():
             return g10b_flow_matching_vlm(fake, vla, fake._ref_vlm)
         if '--only-g7c' in sys.argv:
             return g7c_integrators(fake, vla)
+        if '--only-g7d' in sys.argv:
+            return g7d_general_masks(fake, vla)
         if '--skip-g7b' not in sys.argv:
             g7b_trace(fake, vla)
         g7c_integrators(fake, vla)
+        g7d_general_masks(fake, vla)
         g10_flow_matching(fake, vla)
         return g10b_flow_matching_vlm(fake, vla, fake._ref_vlm)
     import subprocess
@@ -700,6 +760,7 @@ def main():
     fake = g7_vla(vla, sd, ref_vlm)
     g7b_trace(fake, vla)
     g7c_integrators(fake, vla)
+    g7d_general_masks(fake, vla)
     g10_flow_matching(fake, vla)
     g10b_flow_matching_vlm(fake, vla, fake._ref_vlm)
     g8_sft_grads(cfg, build_ref_vlm(cfg, vlm_sd))

@@ -11,6 +11,7 @@ FIXTURES = {
     'g7_vla.npz': 'tools/gen_golden.py',
     'g7b_vla_trace.npz': 'tools/gen_golden.py',
     'g7c_integrators.npz': 'tools/gen_golden.py',
+    'g7d_general_masks.npz': 'tools/gen_golden.py',
     'g8_sft_grads.npz': 'tools/gen_golden.py',
     'g10_flow_matching.npz': 'tools/gen_golden.py',
     'g10b_flow_matching_vlm.npz': 'tools/gen_golden.py',

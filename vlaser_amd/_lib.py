@@ -25,7 +25,7 @@ class AttnArgs(C.Structure):
                 ('k_bs', i64), ('k_hs', i64), ('vt_bs', i64), ('vt_hs', i64), ('o_bs', i64), ('o_ss', i64),
                 ('ld_vt', i32), ('scale', f32), ('mode', i32), ('causal_off', i32), ('valid_len', vp),
                 ('blk_start', i32), ('q_row_off', i32), ('part_m', vp), ('part_l', vp), ('part_o', vp), ('n_splits', i32),
-                ('first_tok_kv_len', i32), ('lse_out', vp), ('dbg', vp)]
+                ('first_tok_kv_len', i32), ('lse_out', vp), ('dbg', vp), ('mask', vp), ('mask_bs', i64), ('mask_rs', i64)]
 
 
 class SkinnyArgs(C.Structure):
@@ -42,12 +42,13 @@ class VlaStageArgs(C.Structure):
                 ('proprio', vp), ('proprio_out', vp), ('n_proprio', i32), ('noise', vp), ('noise_out', vp), ('n_noise', i32),
                 ('pix', vp), ('pix_out', vp), ('n_pix', i64), ('pix_dtype', i32), ('hw', i32), ('mean', f32 * 3), ('std', f32 * 3), ('call_ctr', vp),
                 ('call_no', i32), ('itp_mask', vp), ('action_mask', vp), ('mask_dtype', i32), ('n_act', i32), ('pos_vlm', vp), ('pos_pro', vp), ('pos_act', vp),
-                ('pos_vlm_out', vp), ('pos_pro_out', vp), ('pos_act_out', vp), ('pos_ride_out', vp), ('itp_bs', i64), ('itp_rs', i64), ('act_bs', i64), ('act_rs', i64)]
+                ('pos_vlm_out', vp), ('pos_pro_out', vp), ('pos_act_out', vp), ('pos_ride_out', vp), ('itp_bs', i64), ('itp_rs', i64), ('act_bs', i64), ('act_rs', i64),
+                ('mask_slot', vp), ('mask_ld', i32)]
 
 
 # enums (include/vlaser_hip.h)
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_LS_RES, EPI_RES, EPI_SWIGLU, EPI_QKV_ROPE, EPI_VIT_QKV, EPI_F32, EPI_PARTIAL, EPI_SWIGLU_BWD = range(11)
-ATTN_FULL, ATTN_CAUSAL, ATTN_PREFIX = range(3)
+ATTN_FULL, ATTN_CAUSAL, ATTN_PREFIX, ATTN_DENSE = range(4)
 PRO_PLAIN, PRO_NORM, PRO_ATTN = range(3)
 SK_PARTIAL, SK_QKV_ROPE, SK_SWIGLU, SK_F32, SK_BIAS, SK_BIAS_SILU = range(6)
 

@@ -120,7 +120,9 @@ struct DirectChunk {
 // TK = keys per tile (64 / 128): with about one workgroup per CU a wave is alone on its SIMD and every tile is a serial chain
 // barrier -> LDS store -> barrier -> S^T -> max (two cross-lane hops) -> exp -> P V; 128-key tiles halve the number of chains
 // per key and give each one twice the independent MFMA / exp work to overlap.
-template <int HD, int KS, int TK, bool TAIL = false, bool HOST = false>      // HOST: TAIL with the tail rows hosted by the last full workgroup (p.tail_host; its own instantiation: +2 x 16 registers); TAIL: the FULL-mode tail handling (p.tail_key0 / p.tail_qb); its own instantiation, so the other shapes do not carry its registers
+// DENSE (ABI 8): VL_ATTN_DENSE -- every key tile is walked and the visibility comes from a.mask (fp32, additive): the mask values of a tile ride in registers with the tile's
+// K / V^T (requested one tile ahead, 4 consecutive keys = 16 bytes per score quad); its own instantiation, so the descriptor modes do not carry its registers
+template <int HD, int KS, int TK, bool TAIL = false, bool HOST = false, bool DENSE = false>      // HOST: TAIL with the tail rows hosted by the last full workgroup (p.tail_host; its own instantiation: +2 x 16 registers); TAIL: the FULL-mode tail handling (p.tail_key0 / p.tail_qb); its own instantiation, so the other shapes do not carry its registers
 __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
   constexpr int DC = HD / 32;   // d-chunks of 32 for S^T
   constexpr int DT = HD / 16;   // d-tiles of 16 for O^T
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
   int blk_lim1, blk_has2 = 0;
   {
     const int q_last = min(a.sq, qb * 64 + 64) - 1;
-    if (a.mode == VL_ATTN_FULL) {
+    if (a.mode == VL_ATTN_FULL || DENSE) {
       lim1 = blk_lim1 = a.kv_len;
     } else if (a.mode == VL_ATTN_CAUSAL) {
       lim1 = min(a.kv_len, q_row + 1 + a.causal_off);
@@ -227,9 +229,20 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
   const int n_tiles = n1 + max(0, t2_hi - t2_lo);
 
   u32x4 rk[KCH], rv[VCH];
+  // DENSE: this lane's mask values of the tile in flight (rmk) and of the tile being computed (cmk): row = its query row, 4 consecutive keys per (chunk, t)
+  f32x4 rmk[DENSE ? NC : 1][2], cmk[DENSE ? NC : 1][2];
+  const float* mrow = nullptr;
+  const float inv_scale = DENSE ? 1.0f / a.scale : 0.f;
+  if constexpr (DENSE) mrow = a.mask + (size_t)b * a.mask_bs + (size_t)min(q_row, a.sq - 1) * a.mask_rs;
   auto tile_key0 = [&](int it) { return (it < n1 ? it : t2_lo + (it - n1)) * TK; };
   auto load_tile = [&](int it) {
     const int key0 = tile_key0(it);
+    if constexpr (DENSE) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) rmk[c][t] = *reinterpret_cast<const f32x4*>(mrow + min(key0 + c * 32 + g * 8 + t * 4, (int)a.mask_rs - 4));
+    }
 #pragma unroll
     for (int i = 0; i < KCH; ++i) {
       const int c = tid + i * 256;              // chunk id: row = c / (HD/8), slot = c % (HD/8)
@@ -245,6 +258,10 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
     }
   };
   auto store_tile = [&]() {
+    if constexpr (DENSE) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { cmk[c][0] = rmk[c][0]; cmk[c][1] = rmk[c][1]; }
+    }
 #pragma unroll
     for (int i = 0; i < KCH; ++i) {
       const int c = tid + i * 256;
@@ -286,7 +303,15 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if constexpr (MASKED) {
+          if constexpr (MASKED && DENSE) {
+            // score * scale + mask == (score + mask / scale) * scale: the mask enters before the scale that the exponent's FMA applies
+            const int key = key0 + (cb + c) * 32 + g * 8 + t * 4 + r;
+            const float mv = cmk[cb + c][t][r];
+            const bool v = (key < lim1) && (mv > -1.0e30f);
+            vis[c][t][r] = v;
+            s[c][t][r] = v ? __builtin_fmaf(mv, inv_scale, s[c][t][r]) : s[c][t][r];
+            if (v) mx = fmaxf(mx, s[c][t][r]);
+          } else if constexpr (MASKED) {
             const int key = key0 + (cb + c) * 32 + g * 8 + t * 4 + r;
             const bool v = (key < lim1) || (key >= lo2 && key < hi2);
             vis[c][t][r] = v;
@@ -331,7 +356,7 @@ __global__ __launch_bounds__(256 * KS) void attn_prefill_kernel(AttnP p) {
     }
   };
   // smallest prefix limit among this wave's 16 rows (wave-uniform): a tile ending at or below it needs no masks
-  const int wave_lim1 = a.mode == VL_ATTN_CAUSAL ? min(a.kv_len, qb * 64 + wave * 16 + 1 + a.causal_off) : blk_lim1;
+  const int wave_lim1 = DENSE ? 0 : (a.mode == VL_ATTN_CAUSAL ? min(a.kv_len, qb * 64 + wave * 16 + 1 + a.causal_off) : blk_lim1);      // (DENSE: every tile takes the masked body)
 
   const int n_it = (n_tiles + KS - 1) / KS;                   // block-uniform trip count; a group past its last tile idles at the barriers
   if (n_tiles > 0) load_tile(min(grp, n_tiles - 1));
@@ -657,6 +682,15 @@ extern "C" int vlaser_attn_prefill(const VlaserAttnArgs* a, vl_stream_t s) {
   VL_CHECK(a->sq > 0 && a->batch > 0, "vlaser_attn_prefill: empty");
   AttnP p; p.a = *a; p.tail_key0 = -1; p.tail_qb = -1; p.tail_host = 0;
   dim3 grid((a->sq + 63) / 64, a->n_q_heads, a->batch);
+  if (a->mode == VL_ATTN_DENSE) {
+    VL_CHECK(a->head_dim == 128 && a->mask && a->mask_rs % 4 == 0 && a->mask_rs >= ((a->kv_len + 63) & ~63) && (((uintptr_t)a->mask) & 15) == 0 && a->mask_bs % 4 == 0,
+             "vlaser_attn_prefill: VL_ATTN_DENSE needs head_dim 128 and a 16-byte aligned fp32 mask whose row stride is a multiple of 4 >= kv_len rounded up to 64");
+    constexpr int lds = 2 * 64 * 128 * 2;
+    if (int rc = set_max_lds_once(attn_prefill_kernel<128, 1, 64, false, false, true>, lds)) return rc;
+    hipLaunchKernelGGL((attn_prefill_kernel<128, 1, 64, false, false, true>), grid, dim3(256), lds, stream, p);
+    VL_LAUNCH_CHECK();
+    return 0;
+  }
   // tile / split choice, measured (tools/micro/attn_lab.py, profiles/r02k_attn.md): a 2-way in-workgroup key split pays only when
   // the grid does not even reach one workgroup per CU (joint prefill: 72 workgroups, 11.4 -> 10.8 us); 128-key tiles only for the
   // unmasked head_dim-64 case around one workgroup per CU (ViT, 1 tile: 23.9 -> 22.8 us); more registers per wave (a forced

@@ -659,9 +659,11 @@ struct ChainAttnP {
   int sq, kv_len, G, ld_vt, mode, blk_start, first_tok_kv_len, n_splits, n_kv;
   float scale;
   unsigned long long* dbg;
+  const float* mask; long long mask_bs, mask_rs;      // VL_ATTN_DENSE (ABI 8): fp32 additive mask, row = query TOKEN (the same for every head)
 };
 
-template <int NC, bool DBG>
+// DENSE: the visibility and a bias per (token, key) come from p.mask instead of the (valid_len, blk_start) descriptors; requested with the K / V^T of the chunks
+template <int NC, bool DBG, bool DENSE = false>
 __global__ __launch_bounds__(64) void chain_attn_kernel(ChainAttnP p) {
   constexpr int HD = 128, DC = 4, DT = 8;
   const int lane = threadIdx.x, fr = lane & 15, g = lane >> 4;
@@ -697,10 +699,25 @@ __global__ __launch_bounds__(64) void chain_attn_kernel(ChainAttnP p) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) vf[c][dt] = ld_global_16(VT + (size_t)(dt * 16 + fr) * p.ld_vt + key0 + g * 8);
   }
+  f32x4 mk[DENSE ? 2 : 1][DENSE ? NC : 1][2];
+  if constexpr (DENSE) {
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int r = min(qt * 16 + fr, nrows - 1);
+      const int hg = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)nq)), tok = r - hg * nq;
+      const float* mrow = p.mask + (size_t)b * p.mask_bs + (size_t)tok * p.mask_rs;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int key0 = min(split * NC + c, n_chunks - 1) << 5;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) mk[qt][c][t] = *reinterpret_cast<const f32x4*>(mrow + key0 + g * 8 + t * 4);
+      }
+    }
+  }
   __builtin_amdgcn_sched_barrier(0);
   // (behind the requests: the two scalar round trips -- pointer, value -- of the valid length run while the vector loads are in flight)
   int lim1 = p.kv_len, lo2 = 0x7fffffff, hi2 = 0;
-  if (p.mode == VL_ATTN_PREFIX) {
+  if (p.mode == VL_ATTN_PREFIX && !DENSE) {
     lim1 = min(p.valid_len ? vl_sload_i32(p.valid_len + b) : p.kv_len, p.kv_len);      // scalar cache: not in the vmcnt queue
     lo2 = p.blk_start; hi2 = p.kv_len;
   }
@@ -743,6 +760,11 @@ __global__ __launch_bounds__(64) void chain_attn_kernel(ChainAttnP p) {
           const int key = key0 + g * 8 + t * 4 + r;
           vis[t][r] = visk[t][r] & ((key < lim1) | (key < row_hi2[qt]));
           s[t][r] *= sc;
+          if constexpr (DENSE) {
+            const float mv = mk[qt][c][t][r];
+            vis[t][r] = vis[t][r] & (mv > -1.0e30f);
+            s[t][r] = vis[t][r] ? __builtin_fmaf(mv, 1.4426950408889634f, s[t][r]) : s[t][r];
+          }
           mx = vis[t][r] ? fmaxf(mx, s[t][r]) : mx;
         }
       mx = vl_xor32_max(vl_xor16_max(mx));
@@ -794,15 +816,19 @@ extern "C" int vlaser_chain_attn_splits(int kv_len) { return (((kv_len + 31) >> 
 extern "C" int vlaser_chain_attn(const VlaserAttnArgs* a, vl_stream_t s) {
   VL_CHECK(a && a->q && a->k && a->vt && a->part_m && a->part_o, "vlaser_chain_attn: null pointer");
   VL_CHECK(a->head_dim == 128 && a->n_q_heads % a->n_kv_heads == 0 && a->sq >= 1 && a->sq * (a->n_q_heads / a->n_kv_heads) <= 32, "vlaser_chain_attn: head_dim 128, group * tokens <= 32");
-  VL_CHECK(a->ld_vt % 32 == 0 && a->kv_len >= 1 && a->kv_len <= a->ld_vt && (a->mode == VL_ATTN_FULL || a->mode == VL_ATTN_PREFIX), "vlaser_chain_attn: bad cache geometry / mode");
+  VL_CHECK(a->ld_vt % 32 == 0 && a->kv_len >= 1 && a->kv_len <= a->ld_vt && (a->mode == VL_ATTN_FULL || a->mode == VL_ATTN_PREFIX || a->mode == VL_ATTN_DENSE), "vlaser_chain_attn: bad cache geometry / mode");
+  VL_CHECK(a->mode != VL_ATTN_DENSE || (a->mask && a->mask_rs % 4 == 0 && a->mask_rs >= ((a->kv_len + 31) & ~31) && (((uintptr_t)a->mask) & 15) == 0 && a->mask_bs % 4 == 0 && a->first_tok_kv_len == 0),
+           "vlaser_chain_attn: VL_ATTN_DENSE needs a 16-byte aligned fp32 mask whose row stride is a multiple of 4 >= kv_len rounded up to 32 (and no riding first token)");
   VL_CHECK(a->n_splits == vlaser_chain_attn_splits(a->kv_len) && a->n_splits <= 16, "vlaser_chain_attn: n_splits must be ceil(chunks / 2) <= 16 (kv_len <= 1024)");
   ChainAttnP p;
   p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.vt = (const bf16_t*)a->vt; p.pml = a->part_m; p.po = (bf16_t*)a->part_o; p.valid_len = a->valid_len;
   p.q_bs = a->q_bs; p.q_hs = a->q_hs; p.q_ss = a->q_ss; p.k_bs = a->k_bs; p.k_hs = a->k_hs; p.vt_bs = a->vt_bs; p.vt_hs = a->vt_hs;
   p.sq = a->sq; p.kv_len = a->kv_len; p.G = a->n_q_heads / a->n_kv_heads; p.ld_vt = a->ld_vt; p.mode = a->mode; p.blk_start = a->blk_start;
   p.first_tok_kv_len = a->first_tok_kv_len; p.n_splits = a->n_splits; p.n_kv = a->n_kv_heads; p.scale = a->scale; p.dbg = a->dbg;
+  p.mask = a->mask; p.mask_bs = a->mask_bs; p.mask_rs = a->mask_rs;
   const dim3 grid(a->n_kv_heads, a->n_splits, a->batch);
-  if (p.dbg) hipLaunchKernelGGL((chain_attn_kernel<2, true>), grid, dim3(64), 0, (hipStream_t)s, p);
+  if (a->mode == VL_ATTN_DENSE) hipLaunchKernelGGL((chain_attn_kernel<2, false, true>), grid, dim3(64), 0, (hipStream_t)s, p);
+  else if (p.dbg) hipLaunchKernelGGL((chain_attn_kernel<2, true>), grid, dim3(64), 0, (hipStream_t)s, p);
   else hipLaunchKernelGGL((chain_attn_kernel<2, false>), grid, dim3(64), 0, (hipStream_t)s, p);
   VL_LAUNCH_CHECK();
   return 0;

@@ -863,12 +863,18 @@ struct VlaStageP {
   long long itp_bs, itp_rs, act_bs, act_rs;       // element strides of the masks' batch / row axes (the reference hands out SLICES of the full mask, :589-603)
   const int64_t* pos_vlm; const int64_t* pos_pro; const int64_t* pos_act;
   int32_t* pos_vlm_out; int32_t* pos_pro_out; int32_t* pos_act_out; int32_t* pos_ride_out;
+  float* mask_slot; int mask_ld;                  // (ABI 8) general masks: copy instead of check
 };
 #define VLS_ROWS_PER_BLOCK 8
 // element e of an additive mask "lets the key through" iff it is +-0 (the reference writes exactly 0 or finfo(dtype).min)
 __device__ __forceinline__ bool vls_mask_open(const void* m, int dt, size_t e) {
   if (dt == 1) return (reinterpret_cast<const uint32_t*>(m)[e] & 0x7fffffffu) == 0;
   return (reinterpret_cast<const uint16_t*>(m)[e] & 0x7fffu) == 0;      // bf16 / fp16
+}
+__device__ __forceinline__ float vls_mask_f32(const void* m, int dt, size_t e) {
+  if (dt == 1) return reinterpret_cast<const float*>(m)[e];
+  if (dt == 0) return bf16_to_f32(reinterpret_cast<const bf16_t*>(m)[e]);
+  return (float)reinterpret_cast<const _Float16*>(m)[e];
 }
 __global__ __launch_bounds__(256) void vla_stage_kernel(VlaStageP p) {
   const int tid = threadIdx.x;
@@ -924,6 +930,21 @@ __global__ __launch_bounds__(256) void vla_stage_kernel(VlaStageP p) {
       c = (int)wave_sum((float)n);
     }
     int bad = 0;
+    if (p.mask_slot) {
+      // general masks: rows as fp32 into the slot the VL_ATTN_DENSE launches read; the only pattern still refused is a prefix row that sees the proprio key
+      for (int rr = wave; rr < VLS_ROWS_PER_BLOCK; rr += 4) {
+        const int r = r0 + rr;
+        if (r >= rpb) break;
+        float* dst = p.mask_slot + ((size_t)b * rpb + r) * p.mask_ld;
+        const bool itp = r < W1;
+        const int wd = itp ? W1 : W2;
+        const size_t base = itp ? (size_t)(b * p.itp_bs + r * p.itp_rs) : (size_t)(b * p.act_bs + (r - W1) * p.act_rs);
+        for (int j = lane; j < p.mask_ld; j += 64) dst[j] = j < wd ? vls_mask_f32(itp ? p.itp_mask : p.action_mask, p.mask_dtype, base + j) : -3.402823466e38f;
+        if (r < T && lane == 0 && vls_mask_f32(p.itp_mask, p.mask_dtype, base + T) > -1.0e30f) bad |= 8;
+      }
+      if (bad && p.ctr) atomicOr(&p.ctr[1 + (p.call_no & 1)], bad);
+      return;
+    }
     for (int rr = wave; rr < VLS_ROWS_PER_BLOCK; rr += 4) {
       const int r = r0 + rr;
       if (r >= rpb) break;
@@ -979,6 +1000,8 @@ extern "C" int vlaser_vla_stage(const VlaserVlaStageArgs* a, vl_stream_t s) {
            "vlaser_vla_stage: dense masks need the call-counter / error words, mask_dtype 0 bf16 / 1 f32 / 2 f16 and 1..64 action tokens");
   VL_CHECK((!a->pos_vlm || a->pos_vlm_out) && (!a->pos_pro || a->pos_pro_out) && (!a->pos_act || (a->pos_act_out && a->n_act >= 1)), "vlaser_vla_stage: position-id slots missing");
   VL_CHECK(!a->pos_ride_out || (a->B == 1 && a->n_act >= 1 && a->n_act < 256), "vlaser_vla_stage: pos_ride_out is the batch-1 [proprio | action] position row");
+  VL_CHECK(!a->mask_slot || (a->itp_mask && a->action_mask && a->mask_ld % 32 == 0 && a->mask_ld >= a->T + 1 + a->n_act && (((uintptr_t)a->mask_slot) & 15) == 0),
+           "vlaser_vla_stage: general masks need BOTH dense masks and a 16-byte aligned slot with mask_ld a multiple of 32 >= T + 1 + n_act");
   VlaStageP p;
   p.ids = a->ids; p.ids_out = a->ids_out; p.B = a->B; p.T = a->T; p.pad_id = a->pad_id;
   p.valid_in = a->valid_in; p.valid_is_i64 = a->valid_is_i64; p.valid_out = a->valid_out;
@@ -993,6 +1016,7 @@ extern "C" int vlaser_vla_stage(const VlaserVlaStageArgs* a, vl_stream_t s) {
   p.n_mask_blocks = masks ? a->B * ((a->T + 1 + a->n_act + VLS_ROWS_PER_BLOCK - 1) / VLS_ROWS_PER_BLOCK) : 0;
   p.pos_vlm = a->pos_vlm; p.pos_pro = a->pos_pro; p.pos_act = a->pos_act;
   p.pos_vlm_out = a->pos_vlm_out; p.pos_pro_out = a->pos_pro_out; p.pos_act_out = a->pos_act_out; p.pos_ride_out = a->pos_ride_out;
+  p.mask_slot = a->mask_slot; p.mask_ld = a->mask_ld;
   long long pb = (p.n_pix8 + 255) / 256;
   if (pb > 1024) pb = 1024;
   hipLaunchKernelGGL(vla_stage_kernel, dim3(1 + p.n_mask_blocks + (int)pb), dim3(256), 0, (hipStream_t)s, p);

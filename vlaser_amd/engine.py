@@ -236,7 +236,7 @@ def prefill_begin(stack: QwenStack, buf: PrefillBuffers, h, M):
 
 def prefill_layer(stack: QwenStack, lw: QwenLayerWeights, buf: PrefillBuffers, h, cache: KVCache, layer, rope, pos_ids, batch,
                   tok_per_batch, attn_mode, valid_len=None, blk_start=0, causal_off=0, kv_len=None, skip_post_attn=False,
-                  next_norm_w=None, slot_base=0):
+                  next_norm_w=None, slot_base=0, dense_mask=None):
     """One Qwen2DecoderLayer over M = batch*tok_per_batch rows with the big-GEMM kernels; K/V written to slots
     [slot_base, slot_base + tok_per_batch) of the cache (slot_base > 0: decode steps of models too wide for the
     weight-streaming kernels).  Expects buf.x = input_layernorm(h); leaves buf.x = next_norm(h_out) when
@@ -255,7 +255,8 @@ def prefill_layer(stack: QwenStack, lw: QwenLayerWeights, buf: PrefillBuffers, h
     ks, vs = cache.strides()
     ops.attn_prefill(q, cache.k[layer], cache.vt[layer], ao, batch, tok_per_batch, tok_per_batch if kv_len is None else kv_len, nq, nkv, hd,
                      (tok_per_batch * nq * hd, hd, nq * hd), ks, vs, (tok_per_batch * nq * hd, nq * hd), cache.s_max, hd ** -0.5,
-                     attn_mode, causal_off=causal_off, valid_len=valid_len, blk_start=blk_start, q_row_off=slot_base)
+                     L.ATTN_DENSE if dense_mask is not None else attn_mode, causal_off=causal_off, valid_len=valid_len, blk_start=blk_start, q_row_off=slot_base,
+                     dense_mask=dense_mask)        # dense_mask: fp32 view [B, tok_per_batch, >= kv_len] of the reference's additive mask (general masks, ABI 8)
     part = buf.part
     sp_o, sp_d = ops.gemm_splits(M, H, nq * hd, part.numel()), ops.gemm_splits(M, H, I, part.numel())
     ops.gemm(L.EPI_PARTIAL, ao, lw.wo, out_f32=part, k_splits=sp_o)
@@ -286,7 +287,7 @@ class SkinnyBuffers:
 
 def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in, partials, n_partials, cache: KVCache, layer, rope,
                  pos_ids, batch, tok_per_batch, slot_base, kv_len, attn_mode, valid_len=None, blk_start=0, skip_post_attn=False,
-                 first_tok_kv_len=0, skip=()):
+                 first_tok_kv_len=0, skip=(), dense_mask=None):
     """One decoder layer over M = batch*tok_per_batch <= 16 rows with the weight-streaming kernels (5 launches).
     Input residual = h_in + sum(partials) (partials = down_proj slabs of the previous layer).  Returns
     (h, partials, n_partials) describing this layer's output residual the same way."""
@@ -311,9 +312,14 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
     nsp2 = ops.chain_attn_splits(kv_len)
     chain_ao = (chain and not skip_post_attn and lw.sk_o.tpu == 1 and tok_per_batch * (nq // nkv) <= 32
                 and ops.chain_oproj_supported(M, lw.sk_o.N, nq * hd, stack.ks_o, nsp2, nq // nkv) and 'chain_noao' not in stack.opts)
+    if dense_mask is not None:
+        # general additive masks (ABI 8) are served by the chain attention only (every <= 16-row launch of the VLA at its shipped widths)
+        if not (chain_ao or (chain and skip_post_attn)):
+            raise NotImplementedError('dense additive masks need the chain attention (hidden 768 / 1536, <= 16 rows, group * tokens <= 32)')
+        attn_mode = L.ATTN_DENSE
     key = (layer, M, tok_per_batch, attn_mode, h_in.data_ptr(), 0 if partials is None else partials.data_ptr(), n_partials,
            0 if valid_len is None else valid_len.data_ptr(), pos_ids.data_ptr(), cache.k.data_ptr(), skip_post_attn, first_tok_kv_len,
-           chain, chain_ao, down2)
+           chain, chain_ao, down2, 0 if dense_mask is None else dense_mask.data_ptr())
     plan = sb.plans.get(key)
     if plan is None:
         ks, vs = cache.strides()
@@ -331,7 +337,7 @@ def skinny_layer(stack: QwenStack, lw: QwenLayerWeights, sb: SkinnyBuffers, h_in
             if chain_ao:
                 plan.attn = ops.attn_skinny_args(sb.q, cache.k[layer], cache.vt[layer], (sb.chain_parts[0], sb.chain_parts[0], sb.chain_parts[1]), batch, tok_per_batch,
                                                  kv_len, nq, nkv, hd, (tok_per_batch * nq * hd, hd, nq * hd), ks, vs, cache.s_max, hd ** -0.5, attn_mode, nsp2,
-                                                 valid_len=valid_len, blk_start=blk_start, first_tok_kv_len=first_tok_kv_len)
+                                                 valid_len=valid_len, blk_start=blk_start, first_tok_kv_len=first_tok_kv_len, dense_mask=dense_mask)
                 plan.o = ops.skinny_args(None, lw.sk_o, M, out_f32=sb.part_o, attn_m=sb.chain_parts[0], attn_o=sb.chain_parts[1], attn_splits=nsp2,
                                          attn_group=nq // nkv, attn_nq=tok_per_batch)
             # (chain: vlaser_chain_qkv leaves no rounded copy of the residual stream behind -- its input already IS the rounded stream)

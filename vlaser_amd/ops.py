@@ -184,7 +184,7 @@ def linear(x, W, bias=None, epi=None, res=None, ls=None, out=None, out_dtype=BF1
 
 # ------------------------------------------------------------------------------------------------ attention
 def _attn_args(q, k, vt, out, batch, sq, kv_len, n_q, n_kv, hd, q_str, k_str, vt_str, o_str, ld_vt, scale, mode,
-               causal_off=0, valid_len=None, blk_start=0, q_row_off=0, parts=None, n_splits=1, first_tok_kv_len=0, lse_out=None):
+               causal_off=0, valid_len=None, blk_start=0, q_row_off=0, parts=None, n_splits=1, first_tok_kv_len=0, lse_out=None, dense_mask=None):
     a = L.AttnArgs()
     a.q, a.k, a.vt, a.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), _p(out)
     a.batch, a.sq, a.kv_len, a.n_q_heads, a.n_kv_heads, a.head_dim = batch, sq, kv_len, n_q, n_kv, hd
@@ -200,6 +200,10 @@ def _attn_args(q, k, vt, out, batch, sq, kv_len, n_q, n_kv, hd, q_str, k_str, vt
     a.n_splits = n_splits
     a.first_tok_kv_len = first_tok_kv_len
     a.lse_out = _p(lse_out)
+    if dense_mask is not None:
+        # (ABI 8) VL_ATTN_DENSE: fp32 additive mask VIEW [B, sq, >= kv_len] (row 0 = query token 0, column 0 = key 0) of a buffer with padded rows
+        assert dense_mask.dtype == torch.float32 and dense_mask.dim() == 3 and dense_mask.stride(2) == 1 and dense_mask.shape[1] >= sq
+        a.mask, a.mask_bs, a.mask_rs = dense_mask.data_ptr(), dense_mask.stride(0), dense_mask.stride(1)
     return a
 
 
@@ -522,13 +526,14 @@ _MASK_DTYPES = {torch.bfloat16: 0, torch.float32: 1, torch.float16: 2}
 
 
 def vla_stage(ids, ids_out, valid_in, valid_out, proprio, proprio_out, noise, noise_out, pix, pix_out, pad_id, mean, std, call_ctr=None, call_no=0,
-              masks=None, n_act=0, positions=None, pos_out=None):
+              masks=None, n_act=0, positions=None, pos_out=None, mask_slot=None):
     """All per-call inputs of infer_action into the chunk graph's static slots in ONE launch (device tensors, contiguous).  pix: bf16 / fp32
     (already normalised) or uint8 [n,3,H,W] (normalised here, InternVLAProcessor arithmetic); valid_in: int32 / int64 [B] or None (= zero count of the dense
     mask's proprio row when `masks` is given, else the count of ids != pad_id).  masks = (image_text_proprio_mask | None, action_mask | None): the
     reference's dense additive masks, checked on the device against the prefix + trailing-block pattern (error word in call_ctr, see the header).
     positions = (vlm | None, proprio | None, action | None) int64 device tensors -> pos_out = (vlm, proprio, action, ride | None) int32 slots.
-    call_ctr: int32[3] {call number, error word of even calls, of odd calls}; call_no: this call's number (host-owned)."""
+    call_ctr: int32[3] {call number, error word of even calls, of odd calls}; call_no: this call's number (host-owned).
+    mask_slot (ABI 8): fp32 [B, T + 1 + n_act, ld] -- GENERAL masks: both masks are copied there for the VL_ATTN_DENSE launches instead of being checked."""
     a = L.VlaStageArgs()
     B, T = ids.shape
     assert ids.dtype == torch.int64 and ids.is_cuda and ids.is_contiguous()
@@ -570,6 +575,11 @@ def vla_stage(ids, ids_out, valid_in, valid_out, proprio, proprio_out, noise, no
                 raise ValueError(f'action_mask must be [{B},1,{n_act},{T + 1 + n_act}], got {tuple(m2.shape)}')
             assert m2.is_cuda and m2.stride(-1) == 1, 'action_mask: rows must be contiguous (any batch / row stride)'
             a.action_mask, a.act_bs, a.act_rs = m2.data_ptr(), m2.stride(0), m2.stride(2)
+    if mask_slot is not None:
+        if masks is None or masks[0] is None or masks[1] is None:
+            raise ValueError('general masks: image_text_proprio_mask AND action_mask are required')
+        assert mask_slot.dtype == torch.float32 and mask_slot.is_contiguous() and mask_slot.dim() == 3 and mask_slot.shape[0] >= B and mask_slot.shape[1] == T + 1 + n_act
+        a.mask_slot, a.mask_ld = mask_slot.data_ptr(), mask_slot.shape[2]
     if positions is not None:
         want = ((B, T), (B, 1), (B, n_act))
         for name, t, o, shp in zip(('pos_vlm', 'pos_pro', 'pos_act'), positions, pos_out[:3], want):

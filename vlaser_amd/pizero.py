@@ -151,9 +151,12 @@ class PiZero:
 
     ERR_BITS = {1: 'image_text_proprio_mask: the keys the proprio row sees are not a contiguous valid prefix',
                 2: 'image_text_proprio_mask: a valid-prefix row (or the proprio row\'s own key) does not have the prefix pattern of build_causal_mask_and_position_ids',
-                4: 'action_mask: an action row does not see exactly {valid prefix, proprio, every action token}'}
+                4: 'action_mask: an action row does not see exactly {valid prefix, proprio, every action token}',
+                8: 'image_text_proprio_mask (general_masks=True): an image / text row sees the proprio key -- the cached-prefix schedule computes the prefix rows before '
+                   'the proprio token\'s K / V exist'}
 
-    def __init__(self, cfg: VLAConfig, device='cuda', max_batch=1, use_graph=True, ride_proprio=True, naive_support=False, euler_opts=None, output_ring=0):
+    def __init__(self, cfg: VLAConfig, device='cuda', max_batch=1, use_graph=True, ride_proprio=True, naive_support=False, euler_opts=None, output_ring=0,
+                 general_masks=False):
         L.lib()
         if not torch.cuda.is_available():
             raise L.VlaserHipError('vlaser_amd needs an MI355X (gfx950) GPU: there is no CPU fallback')
@@ -174,6 +177,11 @@ class PiZero:
         self.use_graph = use_graph
         self.naive_support = naive_support      # keep the expert's un-packed weights for infer_action_naive (tests)
         self.ride_proprio = ride_proprio        # batch 1: proprio row processed with the action rows of Euler step 0 (see _run)
+        # general_masks=True (ABI 8, opt-in): the two dense additive masks of the call are SERVED as given -- any visibility pattern (left padding, holes, causal text)
+        # and any finite bias -- by the VL_ATTN_DENSE variants of the attention kernels, as the reference's eager attention would (joint_model.py:636-656), instead of
+        # being checked against the prefix + trailing-block pattern.  Slower (every key tile is walked with its mask values, the proprio row takes its own pass);
+        # the default path and its timings are untouched.  Still refused: an image / text row that sees the proprio key (ERR_BITS[8]).
+        self.general_masks = bool(general_masks)
         eo = os.environ.get('VLASER_EULER', self.EULER_DEFAULT) if euler_opts is None else euler_opts
         self.euler_opts = tuple(x for x in eo.split(',') if x and x != 'none')
         self._graphs = {}
@@ -257,6 +265,9 @@ class PiZero:
         self.pos5 = z(16, dt=torch.int32)
         self.call_ctr = z(4, dt=torch.int32)    # {call number, error word of even calls, error word of odd calls, pad}: vlaser_vla_stage / vlaser_vla_euler
         self.out_ring = z(max(self.output_ring, 4), 16 * cfg.action_dim, dt=torch.float32)      # >= 4 slots: `output_ring` may be switched on later without re-capturing the graph
+        # general masks: fp32 [B, T + 1 + na, ld] -- rows 0..T image_text_proprio_mask, rows T+1.. action_mask (written by the staging launch, read by the dense-mask attention)
+        self.mask_slot = (torch.full((B, self.total_num_tokens, (self.total_num_tokens + 63) // 64 * 64), -3.0e38, dtype=torch.float32, device=dev)
+                          if self.general_masks else None)
         self._calls = 0
         self._err_pending = []
         self._pos_defaults = {}
@@ -307,7 +318,7 @@ class PiZero:
         """Batch 1: the proprio row rides with the action rows of Euler step 0 (see _run_prefill).  Needs a second Euler step: the step that hosts the
         proprio row integrates M + 1 rows in `action5` and does not write the result ring, so with num_inference_steps == 1 the caller's slot (and the
         NaN poisoning of an unsupported mask) would never be written -- the proprio row takes its own pass then."""
-        return self.ride_proprio and B == 1 and self.num_inference_steps >= 2
+        return self.ride_proprio and B == 1 and self.num_inference_steps >= 2 and not self.general_masks      # (general masks: the proprio row has its own mask row -> its own pass)
 
     def _run(self, B):
         """ViT + projector + scatter -> joint prefill -> Euler loop: three phases, separately callable so that bench.py can time each
@@ -341,16 +352,19 @@ class PiZero:
         else:
             ops.small_linear(self.in_proprio, self.pe_w, self.pe_b, self.h_pro, B, cfg.action_hidden_size, cfg.proprio_dim)
         h_pro, parts, npart = self.h_pro, None, 0
+        # general masks: rows 0..T-1 of the slot for the image / text rows (keys 0..T-1), row T for the proprio token (keys 0..T)
+        dm_vlm = self.mask_slot[:B, :T] if self.general_masks else None
+        dm_pro = self.mask_slot[:B, T:T + 1] if self.general_masks else None
         prefill_begin(self.vlm, self.pbuf, h_vlm, B * T)
         for i in range(nL):
             last = i == nL - 1
             prefill_layer(self.vlm, self.vlm.layers[i], self.pbuf, h_vlm, self.cache, i, self.rope, self.pos_vlm, B, T,
                           L.ATTN_PREFIX, valid_len=self.valid_len, blk_start=T, skip_post_attn=last,
-                          next_norm_w=None if last else self.vlm.layers[i + 1].ln_in)
+                          next_norm_w=None if last else self.vlm.layers[i + 1].ln_in, dense_mask=dm_vlm)
             if not ride:
                 h_pro, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_pro, h_pro, parts, npart, self.cache, i,
                                                    self.rope, self.pos_pro, B, 1, T, T + 1, L.ATTN_PREFIX, valid_len=self.valid_len,
-                                                   blk_start=T, skip_post_attn=last)
+                                                   blk_start=T, skip_post_attn=last, dense_mask=dm_pro)
 
     def _run_euler(self, B, skip=()):
         """a14: flow-matching Euler integration over the cached prefix.  `skip`: names of per-layer launches left out (bench.py's in-chain
@@ -392,7 +406,7 @@ class PiZero:
             for i in range(nL):
                 h, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_act, h, parts, npart, self.cache, i, self.rope,
                                                self.pos_act, B, na, T + 1, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len,
-                                               blk_start=T, skip=skip)
+                                               blk_start=T, skip=skip, dense_mask=self.mask_slot[:B, T + 1:] if self.general_masks else None)
             ring = (self.out_ring, self.call_ctr) if s == n - 1 else (None, None)
             ops.vla_euler(h, parts, npart, M, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action, W, cfg.action_dim, dt,
                           clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel_trace[s], ring=ring[0], ring_ctr=ring[1], method=cfg.integration_method)
@@ -435,7 +449,7 @@ class PiZero:
                 for i in range(nL):
                     h, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_act, h, parts, npart, self.cache, i, self.rope,
                                                    self.pos_act, B, na, T + 1, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len,
-                                                   blk_start=T, skip=skip)
+                                                   blk_start=T, skip=skip, dense_mask=self.mask_slot[:B, T + 1:] if self.general_masks else None)
                 fin = (h, parts, npart, M, 0, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b)
         assert acts[p] is self.action
         ring = (self.out_ring, self.call_ctr)     # always: the caller's copy (a 1-slot ring when output_ring == 0) is where an unsupported mask turns into NaN
@@ -477,6 +491,8 @@ class PiZero:
         if noise is None:
             noise = torch.randn((B, na, cfg.action_dim), generator=generator)      # reference: torch.randn inside (:879-881)
         masks = None if (image_text_proprio_mask is None and action_mask is None) else (image_text_proprio_mask, action_mask)
+        if self.general_masks and (image_text_proprio_mask is None or action_mask is None):
+            raise ValueError('PiZero(general_masks=True): infer_action needs image_text_proprio_mask AND action_mask (they ARE the visibility in this mode)')
         positions = self._positions_for_stage(B, vlm_position_ids, proprio_position_ids, action_position_ids)
         self._stage_inputs(B, input_ids, pixel_values, proprios, noise, valid_len, masks, positions)
         # ---- run (HIP graph replay after the first call per batch size)
@@ -546,9 +562,11 @@ class PiZero:
         self._err_pending = keep
         if bad is not None:
             why = '; '.join(t for b_, t in self.ERR_BITS.items() if bad[1] & b_)
+            if self.general_masks:
+                raise ValueError(f'infer_action call #{bad[0]}: {why}; the chunk that call returned is all NaN (a NaN chunk always means: call check_errors())')
             raise ValueError(f'infer_action call #{bad[0]}: the dense masks are not the prefix + trailing-block pattern of build_causal_mask_and_position_ids '
                              f'(pizero_internvl.py:517-603) -- the only visibility the kernels\' (valid_len, blk_start) descriptors express; the chunk that call '
-                             f'returned is all NaN (a NaN chunk always means: call check_errors()).  {why}')
+                             f'returned is all NaN (a NaN chunk always means: call check_errors()).  PiZero(general_masks=True) serves arbitrary additive masks.  {why}')
 
     def check_errors(self):
         """Wait for every outstanding call and raise if one of them passed a mask the kernels cannot honour (the lazy check of infer_action, made now)."""
@@ -591,7 +609,8 @@ class PiZero:
         k = self._calls + 1
         ops.vla_stage(ids, self.in_ids[:B], valid_len, self.valid_len, pro, self.in_proprio, nz, self.noise_dst, pv, self.in_pix, self.pad_token_id,
                       prep.VLA_MEAN, prep.VLA_STD, call_ctr=self.call_ctr, call_no=k, masks=masks, n_act=na, positions=positions,
-                      pos_out=(self.pos_vlm, self.pos_pro, self.pos_act, self.pos5 if B == 1 else None))
+                      pos_out=(self.pos_vlm, self.pos_pro, self.pos_act, self.pos5 if B == 1 else None),
+                      mask_slot=self.mask_slot[:B] if (self.general_masks and masks is not None) else None)
         self._calls = k                           # only after the launch was accepted: the host's ring index cannot run ahead of the device's call number
         if positions is not None:
             self._pos_commit()                    # likewise: the slots hold the new position ids only now
