@@ -98,6 +98,19 @@ def test_load_image_vs_host_path_and_fixture(ip):
     assert torch.equal(out.cpu(), want)
 
 
+def test_load_image_from_file_like_the_reference(tmp_path):
+    """`vlaser_amd.image.load_image(path)` == the reference-style host path (`prep.load_image(Image.open(path))`) in bf16, from a PNG on disk."""
+    from PIL import Image
+    from vlaser_amd import prep
+    from vlaser_amd.image import load_image
+    img = np.random.default_rng(23).integers(0, 256, (333, 777, 3), dtype=np.uint8)
+    f = tmp_path / 'obs.png'
+    Image.fromarray(img).save(f)
+    got = load_image(str(f), 448, 12)
+    want = prep.load_image(Image.open(f).convert('RGB'), 448, 12).to(torch.bfloat16)
+    assert got.is_cuda and got.dtype == torch.bfloat16 and torch.equal(got.cpu(), want)
+
+
 def test_resize_argument_errors(ip):
     from vlaser_amd import _lib as L
     d = torch.zeros(8, 8, 3, dtype=torch.uint8, device='cuda')

@@ -94,3 +94,20 @@ class ImagePrep:
         if thumb:
             self.tiles_normalize(self.resize(img, S, S), 1, 1, out[n:])
         return out
+
+
+_PREPS = {}
+
+
+def load_image(image_file, input_size=448, max_num=12, device='cuda'):
+    """Drop-in for the reference's `load_image(image_file, input_size=448, max_num=12)` (eval_example.py:76-82): a path / file object / PIL image -> bf16 pixel_values
+    [n_tiles, 3, input_size, input_size] ON THE DEVICE (the reference returns fp32 on the host and the caller does `.to(torch.bfloat16).cuda()`, eval_example.py:96).  Only the
+    file decoding runs on the host."""
+    from PIL import Image
+    im = image_file if isinstance(image_file, Image.Image) else Image.open(image_file)
+    arr = np.asarray(im.convert('RGB'), dtype=np.uint8)
+    key = (str(device), input_size)
+    ip = _PREPS.get(key)
+    if ip is None:
+        ip = _PREPS[key] = ImagePrep(device, input_size)
+    return ip.load_image(arr, max_num=max_num)
