@@ -10,6 +10,8 @@ Weights are stored in HBM in the layouts the kernels want (packed once at load):
   * K cache [L][B,n_kv,S_max,128], V cache TRANSPOSED [L][B,n_kv,128,S_max] (MFMA A-fragment = one 16-byte load).
 """
 
+import os
+
 import torch
 from types import SimpleNamespace
 
@@ -191,15 +193,13 @@ class VitEngine:
             ops.attn_prefill(self.q, self.k, self.vt, ao, T, S, S, Hn, Hn, hd, (Hn * sp * hd, sp * hd, hd), (Hn * sp * hd, sp * hd),
                              (Hn * hd * sp, hd * sp), (S * C, C), sp, 1.0, L.ATTN_FULL)
             # h += ls1 * (proj(ao) + b); x = LN2(h)      (modeling_intern_vit.py:291)
-            ops.gemm(L.EPI_PARTIAL, ao, lw['wproj'], out_f32=self.part, k_splits=sp_proj)
-            ops.reduce_norm(h, self.part, sp_proj, M, C, h, x, bias=lw['bproj'], ls=lw['ls1'], norm=2, norm_w=lw['n2w'],
-                            norm_b=lw['n2b'], eps=v.layer_norm_eps)
+            residual_seam(ao, lw['wproj'], h, self.part, M, C, C, x, bias=lw['bproj'], ls=lw['ls1'], norm=2, norm_w=lw['n2w'], norm_b=lw['n2b'],
+                          eps=v.layer_norm_eps, splits=sp_proj)
             ops.gemm(L.EPI_BIAS_GELU, x, lw['wfc1'], out=f, bias=lw['bfc1'])
             # h += ls2 * (fc2(f) + b); x = LN1 of the NEXT layer (:293)
-            ops.gemm(L.EPI_PARTIAL, f, lw['wfc2'], out_f32=self.part, k_splits=sp_fc2)
             nxt = self.layers[li + 1] if li + 1 < nl else None
-            ops.reduce_norm(h, self.part, sp_fc2, M, C, h, x if nxt else None, bias=lw['bfc2'], ls=lw['ls2'], norm=2 if nxt else 0,
-                            norm_w=nxt['n1w'] if nxt else None, norm_b=nxt['n1b'] if nxt else None, eps=v.layer_norm_eps)
+            residual_seam(f, lw['wfc2'], h, self.part, M, C, v.intermediate_size, x if nxt else None, bias=lw['bfc2'], ls=lw['ls2'], norm=2 if nxt else 0,
+                          norm_w=nxt['n1w'] if nxt else None, norm_b=nxt['n1b'] if nxt else None, eps=v.layer_norm_eps, splits=sp_fc2)
             if return_layers:
                 layers_out.append(h.clone())
         if not project:
@@ -212,6 +212,31 @@ class VitEngine:
         if return_layers:
             return self.feat[:n_tok], layers_out
         return self.feat[:n_tok]
+
+
+def residual_seam(a, w, h, part, M, N, K, x_out=None, bias=None, ls=None, norm=0, norm_w=None, norm_b=None, eps=1e-6, splits=None):
+    """The seam behind an N = hidden GEMM: h += [ls *] (a @ w^T [+ bias]); x_out = norm(h) (norm: 0 none / 1 RMS / 2 LayerNorm).  Two compositions of the same arithmetic
+    and the same rounding points (h rounded to bf16 once, the norm taken of the rounded h):
+      * few row tiles, long K (the output tiles alone cannot fill 256 CUs): split-K GEMM -> fp32 slabs -> ONE fused reduce + residual + norm launch;
+      * ONE slab, or two slabs of >= 2048 rows: whole-K GEMM with the residual in its epilogue + a stand-alone norm launch.  Measured (r06, tools/micro/seam_ab.py,
+        profiles/r06x_seam_ab.md): 9-13 us less for the 13-tile ViT proj / fc2 (1 slab), 11 us for the 8B o_proj (1 slab), 96 us for the 8B down_proj at S = 3408 (2 slabs):
+        with one or two large slabs the fp32 slab round trip (2 x 49 MB at 3408 x 3584) costs more than the split buys.  One slab is bit-identical to the slab path; two differ in
+        the fp32 summation order.  (The one-tile ViT proj, 2 slabs of 1025 rows, is 3 us faster as a pair in isolation and EQUAL inside the chunk -- same-box A/B 11.775 vs
+        11.778 ms -- so the small shapes keep the slab path and their bit-exact history.)"""
+    sp = ops.gemm_splits(M, N, K, part.numel()) if splits is None else splits
+    if sp >= 3 or (sp == 2 and M < 2048) or os.environ.get('VLASER_SEAM_SPLITK') == '1':
+        ops.gemm(L.EPI_PARTIAL, a, w, out_f32=part, k_splits=sp)
+        ops.reduce_norm(h, part, sp, M, N, h, x_out, bias=bias, ls=ls, norm=norm if x_out is not None else 0, norm_w=norm_w, norm_b=norm_b, eps=eps)
+        return
+    if ls is not None:
+        ops.gemm(L.EPI_BIAS_LS_RES, a, w, out=h, bias=bias, res=h, ls=ls)
+    else:
+        assert bias is None
+        ops.gemm(L.EPI_RES, a, w, out=h, res=h)
+    if x_out is not None and norm == 2:
+        ops.layernorm(h, norm_w, norm_b, eps, out=x_out)
+    elif x_out is not None and norm == 1:
+        ops.rmsnorm(h, norm_w, eps, out=x_out)
 
 
 # ------------------------------------------------------------------------------------------------------ LLM
@@ -259,12 +284,10 @@ def prefill_layer(stack: QwenStack, lw: QwenLayerWeights, buf: PrefillBuffers, h
                      dense_mask=dense_mask)        # dense_mask: fp32 view [B, tok_per_batch, >= kv_len] of the reference's additive mask (general masks, ABI 8)
     part = buf.part
     sp_o, sp_d = ops.gemm_splits(M, H, nq * hd, part.numel()), ops.gemm_splits(M, H, I, part.numel())
-    ops.gemm(L.EPI_PARTIAL, ao, lw.wo, out_f32=part, k_splits=sp_o)
-    ops.reduce_norm(h, part, sp_o, M, H, h, x, norm=1, norm_w=lw.ln_post, eps=llm.rms_norm_eps)
+    residual_seam(ao, lw.wo, h, part, M, H, nq * hd, x, norm=1, norm_w=lw.ln_post, eps=llm.rms_norm_eps, splits=sp_o)
     ops.gemm(L.EPI_SWIGLU, x, lw.wgu, out=act)
-    ops.gemm(L.EPI_PARTIAL, act, lw.wdown, out_f32=part, k_splits=sp_d)
-    ops.reduce_norm(h, part, sp_d, M, H, h, x if next_norm_w is not None else None, norm=1 if next_norm_w is not None else 0,
-                    norm_w=next_norm_w, eps=llm.rms_norm_eps)
+    residual_seam(act, lw.wdown, h, part, M, H, I, x if next_norm_w is not None else None, norm=1 if next_norm_w is not None else 0, norm_w=next_norm_w,
+                  eps=llm.rms_norm_eps, splits=sp_d)
 
 
 class SkinnyBuffers:
