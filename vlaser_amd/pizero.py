@@ -179,7 +179,7 @@ class PiZero:
         self.ride_proprio = ride_proprio        # batch 1: proprio row processed with the action rows of Euler step 0 (see _run)
         # general_masks=True (ABI 8, opt-in): the two dense additive masks of the call are SERVED as given -- any visibility pattern (left padding, holes, causal text)
         # and any finite bias -- by the VL_ATTN_DENSE variants of the attention kernels, as the reference's eager attention would (joint_model.py:636-656), instead of
-        # being checked against the prefix + trailing-block pattern.  Slower (every key tile is walked with its mask values, the proprio row takes its own pass);
+        # being checked against the prefix + trailing-block pattern.  Slower (every key tile is walked with its mask values);
         # the default path and its timings are untouched.  Still refused: an image / text row that sees the proprio key (ERR_BITS[8]).
         self.general_masks = bool(general_masks)
         eo = os.environ.get('VLASER_EULER', self.EULER_DEFAULT) if euler_opts is None else euler_opts
@@ -318,7 +318,7 @@ class PiZero:
         """Batch 1: the proprio row rides with the action rows of Euler step 0 (see _run_prefill).  Needs a second Euler step: the step that hosts the
         proprio row integrates M + 1 rows in `action5` and does not write the result ring, so with num_inference_steps == 1 the caller's slot (and the
         NaN poisoning of an unsupported mask) would never be written -- the proprio row takes its own pass then."""
-        return self.ride_proprio and B == 1 and self.num_inference_steps >= 2 and not self.general_masks      # (general masks: the proprio row has its own mask row -> its own pass)
+        return self.ride_proprio and B == 1 and self.num_inference_steps >= 2      # (general masks too: rows T .. T + na of the mask slot ARE the riding launch's rows)
 
     def _run(self, B):
         """ViT + projector + scatter -> joint prefill -> Euler loop: three phases, separately callable so that bench.py can time each
@@ -396,7 +396,8 @@ class PiZero:
                 for i in range(nL):
                     h, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_pro, h, parts, npart, self.cache, i, self.rope,
                                                    self.pos5, B, na + 1, T, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len, blk_start=T,
-                                                   first_tok_kv_len=T + 1, skip=skip)
+                                                   first_tok_kv_len=0 if self.general_masks else T + 1, skip=skip,
+                                                   dense_mask=self.mask_slot[:B, T:] if self.general_masks else None)      # (dense: the proprio row's own mask row hides the action keys)
                 ops.vla_euler(h, parts, npart, M + 1, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b, self.action5, W, cfg.action_dim, dt,
                               clip if clip is not None else 0.0, clip is not None and s == n - 1, vel_out=self.vel5, method=cfg.integration_method)
                 self.action[:M].copy_(self.action5[1:1 + M])          # row 0 of action5 (the proprio row's "velocity") is scratch
@@ -442,7 +443,8 @@ class PiZero:
                 for i in range(nL):
                     h, parts, npart = skinny_layer(self.expert, self.expert.layers[i], self.sb_pro, h, parts, npart, self.cache, i, self.rope,
                                                    self.pos5, B, na + 1, T, T + 1 + na, L.ATTN_PREFIX, valid_len=self.valid_len, blk_start=T,
-                                                   first_tok_kv_len=T + 1, skip=skip)
+                                                   first_tok_kv_len=0 if self.general_masks else T + 1, skip=skip,
+                                                   dense_mask=self.mask_slot[:B, T:] if self.general_masks else None)      # (dense: the proprio row's own mask row hides the action keys)
                 fin = (h, parts, npart, M + 1, 1, self.expert.norm, ex.rms_norm_eps, self.ad_w, self.ad_b)       # row 0 = the proprio row: skipped
             else:
                 h, parts, npart = self.h_act, None, 0
