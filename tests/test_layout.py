@@ -28,6 +28,8 @@ def test_library_exports_every_declared_symbol():
     for n in sorted(names):
         assert hasattr(lib, n), f'{n} declared in include/vlaser_hip.h but not exported by libvlaser_hip.so'
     assert lib.vlaser_abi_version() == 8
+    # __graft_entry__.build() asserts the same number (the driver's build check): the two must move together
+    assert f'vlaser_abi_version() == {lib.vlaser_abi_version()}' in open(os.path.join(ROOT, '__graft_entry__.py')).read()
     # ONE public header (the experimental one and its two off-by-default kernels left in r05); every bound signature refers to a declared symbol, and the
     # library exports nothing that no header declares
     assert sorted(os.listdir(os.path.join(ROOT, 'include'))) == ['vlaser_hip.h']
