@@ -518,6 +518,11 @@ def main():
             line['qa'] = qa_bench(local)
             if not a.no_8b:
                 line['qa_8b'] = qa8b_bench(local)
+            if os.environ.get('VLASER_BENCH_NO_SFT_SIDE') != '1':
+                try:
+                    line['vla_train'] = vla_train_bench(local)
+                except Exception as e:      # a side number must not take the line down
+                    line['vla_train'] = {'error': str(e)[:200]}
     _finish(dist, line if rank == 0 else None)
     if isinstance(sft_line, dict) and 'error' in sft_line:
         sys.exit(3)                                              # the headline line is out; a failed SFT sub-bench is still a failed run
@@ -774,6 +779,37 @@ def qa8b_bench(local):
             'prefill_ms': round(ts[0] * 1e3, 2), 'decode_tokens_per_s': round(1.0 / step, 1), 'decode_ms_per_step': round(step * 1e3, 3), 'image_prep': prep_side,
             'roofline': {'prefill': {'bound': 'mfma', 'achieved': round(pre_flop / ts[0] / 1e12, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(pre_flop / ts[0] / 2.5e15, 4)},
                          'decode': {'bound': 'hbm', 'achieved': round(dec_bytes / step / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(dec_bytes / step / 1e9 / HBM_PEAK_GBS, 4)}}}
+
+
+def vla_train_bench(local, steps=6):
+    """SURVEY 8f-1 (the other half of "fine-tune" for the VLA): one flow-matching training step of Vlaser-2B-VLA at full depth, per-device batch 1 -- `PiZero.forward`
+    (pizero_internvl.py:1064-1197) + backward + the optimizer update of `TrainAgent.run` (train.py:345-636): the action-expert parameter group (the reference's default), and with
+    `train_vlm: True` the VLM group as well (ViT + projector + LLM, second optimizer, one clip).  Random-init weights, synthetic sample; fp32 AdamW moments (the reference: bnb 8-bit)."""
+    from vlaser_amd import config as C, synth
+    from vlaser_amd.vla_train import VLATrainer
+    dev = f'cuda:{local}'
+    vla = C.VLAConfig(base=C.vlaser_2b())
+    sd = synth.vla_state_dict(vla, device=dev, dtype=torch.bfloat16)
+    ids, pv, pro, _ = make_inputs(vla.base, 1, seed=5)
+    g = torch.Generator().manual_seed(6)
+    smp = dict(input_ids=ids, pixel_values=pv, proprios=pro, actions=torch.rand(1, vla.num_action_tokens, vla.action_dim, generator=g) * 2 - 1,
+               t=torch.rand(1, generator=g) * 0.999, x0=torch.randn(1, vla.num_action_tokens, vla.action_dim, generator=g))
+    out = {'config': 'Vlaser-2B-VLA flow-matching training step, full depth, per-device batch 1, 384-token prompt (277 valid), 4 action tokens; ms per optimizer step'}
+    for key, kw in (('action_expert_group_ms', {}), ('with_vlm_group_ms', {'train_vlm': True})):
+        m = VLATrainer(vla, device=dev, lr=5e-5, max_grad_norm=1.0, **kw)
+        m.load_state_dict(sd)
+        for _ in range(2):
+            r = m.step([smp])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = m.step([smp])
+        torch.cuda.synchronize()
+        out[key] = round((time.perf_counter() - t0) / steps * 1e3, 2)
+        out[key.replace('_ms', '_last_loss')] = round(float(r.loss), 4)
+        del m
+        torch.cuda.empty_cache()
+    return out
 
 
 def _pmc_traffic():

@@ -441,9 +441,12 @@ int vlaser_silu_bwd(const void* x, const void* dy, void* dx, long long n, vl_str
 /* Backward of the joint attention (joint_model.py:410-696) for the R <= 16 expert rows (proprio + action tokens, cache slots
  * [blk_start, blk_start + R)) over the frozen VLM prefix [0, valid_len) + their own block; first_tok_self: row 0 sees only itself in
  * the block (proprio row of the block mask, pizero_internvl.py:517-587).  q / dO / O / dq bf16 [R, n_q*128]; K [n_kv, s_max, 128]
- * (post-RoPE), VT [n_kv, 128, s_max]; dk / dv bf16 [R, n_kv*128] (gradients of the block keys; dk still needs the inverse RoPE). */
+ * (post-RoPE), VT [n_kv, 128, s_max]; dk / dv bf16 [R, n_kv*128] (gradients of the block keys; dk still needs the inverse RoPE).
+ * (ABI 8) ws: device workspace of vlaser_attn_rows_bwd_ws_floats(n_q) floats owned by the call (one workgroup per (query head, row) leaves the block keys' P / dS
+ * there; a second launch sums dK / dV from them in a fixed order: r03-r05 walked the (head, row) pairs of a kv head one after the other in ONE workgroup, 1.04 ms per layer). */
+int vlaser_attn_rows_bwd_ws_floats(int n_q);
 int vlaser_attn_rows_bwd(const void* q, const void* K, const void* VT, const void* dO, const void* O, void* dq, void* dk, void* dv, int R, int n_q,
-                         int n_kv, int s_max, int valid_len, int blk_start, int first_tok_self, float scale, vl_stream_t stream);
+                         int n_kv, int s_max, int valid_len, int blk_start, int first_tok_self, float scale, float* ws, vl_stream_t stream);
 
 /* ---- f1 with `train_vlm: True` (ABI 4, r03): the reference's second parameter group `trainable_vlm_parameters` (pizero_internvl.py:405-411 =
  * vision tower + projector + the VLM mixture's decoder layers; optimiser + schedule train.py:270-295, stepped :509-520).  The gradient reaches the
@@ -459,7 +462,7 @@ int vlaser_attn_bwd_pds_masked(const float* scores, const float* dP, const void*
 /* vlaser_attn_rows_bwd that also stores P and dS of EVERY key, bf16 [n_q][16][s_max] (row r of head h at (h*16 + r)*s_max): the prefix keys' dK / dV
  * then come from vlaser_gemm_tn_grouped (contraction over the R rows, summed over the q heads of a kv group) */
 int vlaser_attn_rows_bwd_ex(const void* q, const void* K, const void* VT, const void* dO, const void* O, void* dq, void* dk, void* dv, int R, int n_q,
-                            int n_kv, int s_max, int valid_len, int blk_start, int first_tok_self, float scale, void* p_out, void* ds_out, vl_stream_t stream);
+                            int n_kv, int s_max, int valid_len, int blk_start, int first_tok_self, float scale, void* p_out, void* ds_out, float* ws, vl_stream_t stream);
 /* vlaser_rope_bwd_pack with a second source of key / value gradients for the same rows (bf16 [S, n_kv*128], nullable), added in fp32 before the rotation */
 int vlaser_rope_bwd_pack_ex(const void* dq, const void* dk, const void* dv, const float* rope_cos, const float* rope_sin, const int32_t* pos_ids,
                             void* out_packed, int S, int n_q, int n_kv, int kv_per_q_head, const void* dk_extra, const void* dv_extra, vl_stream_t stream);

@@ -124,8 +124,9 @@ _SIGS = {
     'vlaser_grad_accumulate': [vp, vp, i64, f32, i32, i32, vp],
     'vlaser_silu': [vp, vp, i64, vp],
     'vlaser_silu_bwd': [vp, vp, vp, i64, vp],
-    'vlaser_attn_rows_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
-    'vlaser_attn_rows_bwd_ex': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp],
+    'vlaser_attn_rows_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp],
+    'vlaser_attn_rows_bwd_ex': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp],
+    'vlaser_attn_rows_bwd_ws_floats': [i32],
     'vlaser_attn_bwd_pds_masked': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, i32, vp],
     'vlaser_rope_bwd_pack_ex': [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],
     'vlaser_layernorm_bwd': [vp, vp, vp, vp, vp, i32, i32, f32, vp],

@@ -943,22 +943,25 @@ extern "C" int vlaser_silu_bwd(const void* x, const void* dy, void* dx, long lon
 // -> dQ = dS K; dK / dV are accumulated for the block keys only (the prefix keys belong to the frozen VLM: no gradient is needed).
 // K [n_kv, S_max, 128] (post-RoPE), V^T [n_kv, 128, S_max]; q / dO / O / dq bf16 [R, n_q*128]; dk / dv bf16 [R, n_kv*128].
 #define ARB_MAXKEYS 2048
+// r06: one workgroup per (query head, row) -- 60 workgroups for 12 heads x 5 rows -- instead of one per kv head walking its G x R (head, row) pairs one after the other
+// (2 workgroups, 30 sequential passes of ~35 us: 1.04 ms per layer, 29 of the 47 ms of the action-expert training step; profiles/r06aa_vla_train_kernel_stats.md).  The block
+// keys' P and dS (R x R per head) go to a small fp32 workspace; attn_rows_bwd_kv_kernel sums dK / dV of the block keys from them in the old fixed order (head group outer,
+// row inner): deterministic, no atomics.
 __global__ __launch_bounds__(256) void attn_rows_bwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ VT,
                                                             const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O, bf16_t* __restrict__ dq,
-                                                            bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int R, int n_q, int n_kv, int s_max,
+                                                            float* __restrict__ ws, int R, int n_q, int n_kv, int s_max,
                                                             int valid_len, int blk_start, int first_tok_self, float scale,
                                                             bf16_t* __restrict__ p_out, bf16_t* __restrict__ ds_out) {
   // p_out / ds_out (optional, bf16 [n_q][16][s_max]): softmax probabilities and dS of every key, for the dK / dV of the PREFIX keys when the VLM
   // is trained too (train_vlm: True): dK[kvh] = sum_{g, r} dS[kvh G + g][r]^T q[r, head], dV likewise from P and dO (vlaser_gemm_tn_grouped)
   __shared__ float sc[ARB_MAXKEYS];       // p, then dS
   __shared__ float qs[128], dos[128], red[8];
-  __shared__ float dk_acc[16 * 128], dv_acc[16 * 128];
-  const int kvh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int G = n_q / n_kv, kv_len = blk_start + R;
+  const int h = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = n_q / n_kv, kvh = h / G, kv_len = blk_start + R;
   const bf16_t* Kh = K + (size_t)kvh * s_max * 128;
   const bf16_t* Vh = VT + (size_t)kvh * 128 * s_max;
-  for (int i = tid; i < R * 128; i += 256) { dk_acc[i] = 0.f; dv_acc[i] = 0.f; }
-  __syncthreads();
+  float* p_blk = ws + ((size_t)h * 16 + r) * 16;                       // [n_q][16][16] P of the block keys, then the same for dS
+  float* ds_blk = ws + (size_t)n_q * 256 + ((size_t)h * 16 + r) * 16;
   auto block_sum = [&](float v) {
     v = wave_sum(v);
     if (lane == 0) red[wave] = v;
@@ -975,95 +978,104 @@ __global__ __launch_bounds__(256) void attn_rows_bwd_kernel(const bf16_t* __rest
     __syncthreads();
     return t;
   };
+  const size_t ro = (size_t)r * n_q * 128 + (size_t)h * 128;
+  if (tid < 128) { qs[tid] = bf16_to_f32(q[ro + tid]); dos[tid] = bf16_to_f32(dO[ro + tid]); }
+  __syncthreads();
+  const int hi2 = (r == 0 && first_tok_self) ? blk_start + 1 : kv_len;
+  float mx = -3.0e38f;
+  for (int j = tid; j < kv_len; j += 256) {
+    const bool vis = j < valid_len || (j >= blk_start && j < hi2);
+    float s = -3.0e38f;
+    if (vis) {
+      float a = 0.f;
+      const bf16_t* kr = Kh + (size_t)j * 128;
+#pragma unroll
+      for (int d8 = 0; d8 < 16; ++d8) {
+        const u32x4 kv = *reinterpret_cast<const u32x4*>(kr + d8 * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a += qs[d8 * 8 + 2 * e] * bf16lo_to_f32(kv[e]); a += qs[d8 * 8 + 2 * e + 1] * bf16hi_to_f32(kv[e]); }
+      }
+      s = a * scale;
+    }
+    sc[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = block_max(mx);
+  float sum = 0.f;
+  for (int j = tid; j < kv_len; j += 256) {
+    const float p = sc[j] > -1.0e38f ? __expf(sc[j] - mx) : 0.f;
+    sc[j] = p;
+    sum += p;
+  }
+  sum = block_sum(sum);
+  const float inv = 1.0f / sum;
+  // D = <dO, O>; dP_j = dO . V_j; dS_j = p_j (dP_j - D) * scale
+  float dd = 0.f;
+  if (tid < 128) dd = dos[tid] * bf16_to_f32(O[ro + tid]);
+  const float D = block_sum(dd);
+  for (int j = tid; j < kv_len; j += 256) {
+    const float p = sc[j] * inv;
+    float ds = 0.f;
+    if (p > 0.f) {
+      float dp = 0.f;
+#pragma unroll 8
+      for (int d = 0; d < 128; ++d) dp += dos[d] * bf16_to_f32(Vh[(size_t)d * s_max + j]);
+      ds = p * (dp - D) * scale;
+    }
+    if (j >= blk_start) { p_blk[j - blk_start] = p; ds_blk[j - blk_start] = ds; }      // block keys: dV_j += p dO, dK_j += dS q in attn_rows_bwd_kv_kernel
+    sc[j] = ds;
+    if (p_out) {
+      p_out[((size_t)h * 16 + r) * s_max + j] = f32_to_bf16(p);
+      ds_out[((size_t)h * 16 + r) * s_max + j] = f32_to_bf16(ds);
+    }
+  }
+  __syncthreads();
+  // dQ[d] = sum_j dS_j K_j[d]: two threads per d, each half of the keys
+  {
+    const int d = tid & 127, half = tid >> 7;
+    float a = 0.f;
+    for (int j = half; j < kv_len; j += 2) a += sc[j] * bf16_to_f32(Kh[(size_t)j * 128 + d]);
+    if (half == 1) qs[d] = a;                       // qs is free now
+    __syncthreads();
+    if (half == 0) dq[ro + d] = f32_to_bf16(a + qs[d]);
+  }
+}
+// dK / dV of the R block keys of one kv head: sum over its G query heads (outer) and the R query rows (inner) of dS q / P dO -- the order the r03-r05 kernel accumulated in
+__global__ __launch_bounds__(128) void attn_rows_bwd_kv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ dO, const float* __restrict__ ws, bf16_t* __restrict__ dk,
+                                                               bf16_t* __restrict__ dv, int R, int n_q, int n_kv) {
+  const int kvh = blockIdx.x, jb = blockIdx.y, d = threadIdx.x, G = n_q / n_kv;
+  float ak = 0.f, av = 0.f;
   for (int hg = 0; hg < G; ++hg) {
     const int h = kvh * G + hg;
     for (int r = 0; r < R; ++r) {
-      const size_t ro = (size_t)r * n_q * 128 + (size_t)h * 128;
-      if (tid < 128) { qs[tid] = bf16_to_f32(q[ro + tid]); dos[tid] = bf16_to_f32(dO[ro + tid]); }
-      __syncthreads();
-      const int hi2 = (r == 0 && first_tok_self) ? blk_start + 1 : kv_len;
-      float mx = -3.0e38f;
-      for (int j = tid; j < kv_len; j += 256) {
-        const bool vis = j < valid_len || (j >= blk_start && j < hi2);
-        float s = -3.0e38f;
-        if (vis) {
-          float a = 0.f;
-          const bf16_t* kr = Kh + (size_t)j * 128;
-#pragma unroll 8
-          for (int d = 0; d < 128; ++d) a += qs[d] * bf16_to_f32(kr[d]);
-          s = a * scale;
-        }
-        sc[j] = s;
-        mx = fmaxf(mx, s);
-      }
-      mx = block_max(mx);
-      float sum = 0.f;
-      for (int j = tid; j < kv_len; j += 256) {
-        const float p = sc[j] > -1.0e38f ? __expf(sc[j] - mx) : 0.f;
-        sc[j] = p;
-        sum += p;
-      }
-      sum = block_sum(sum);
-      const float inv = 1.0f / sum;
-      // D = <dO, O>; dP_j = dO . V_j; dS_j = p_j (dP_j - D) * scale
-      float dd = 0.f;
-      if (tid < 128) dd = dos[tid] * bf16_to_f32(O[ro + tid]);
-      const float D = block_sum(dd);
-      for (int j = tid; j < kv_len; j += 256) {
-        const float p = sc[j] * inv;
-        float ds = 0.f;
-        if (p > 0.f) {
-          float dp = 0.f;
-#pragma unroll 8
-          for (int d = 0; d < 128; ++d) dp += dos[d] * bf16_to_f32(Vh[(size_t)d * s_max + j]);
-          ds = p * (dp - D) * scale;
-          if (j >= blk_start) {                          // block keys: dV_j += p dO, dK_j += dS q  (threads own distinct j: no race)
-            float* dvr = dv_acc + (j - blk_start) * 128;
-            float* dkr = dk_acc + (j - blk_start) * 128;
-            for (int d = 0; d < 128; ++d) { dvr[d] += p * dos[d]; dkr[d] += ds * qs[d]; }
-          }
-        }
-        sc[j] = ds;
-        if (p_out) {
-          p_out[((size_t)h * 16 + r) * s_max + j] = f32_to_bf16(p);
-          ds_out[((size_t)h * 16 + r) * s_max + j] = f32_to_bf16(ds);
-        }
-      }
-      __syncthreads();
-      // dQ[d] = sum_j dS_j K_j[d]: two threads per d, each half of the keys
-      {
-        const int d = tid & 127, half = tid >> 7;
-        float a = 0.f;
-        for (int j = half; j < kv_len; j += 2) a += sc[j] * bf16_to_f32(Kh[(size_t)j * 128 + d]);
-        if (half == 1) qs[d] = a;                       // qs is free now
-        __syncthreads();
-        if (half == 0) dq[ro + d] = f32_to_bf16(a + qs[d]);
-      }
-      __syncthreads();
+      const size_t ro = (size_t)r * n_q * 128 + (size_t)h * 128 + d;
+      const float p = ws[((size_t)h * 16 + r) * 16 + jb], ds = ws[(size_t)n_q * 256 + ((size_t)h * 16 + r) * 16 + jb];
+      av += p * bf16_to_f32(dO[ro]);
+      ak += ds * bf16_to_f32(q[ro]);
     }
   }
-  for (int i = tid; i < R * 128; i += 256) {
-    const int r = i >> 7, d = i & 127;
-    dk[(size_t)r * n_kv * 128 + kvh * 128 + d] = f32_to_bf16(dk_acc[i]);
-    dv[(size_t)r * n_kv * 128 + kvh * 128 + d] = f32_to_bf16(dv_acc[i]);
-  }
+  dk[(size_t)jb * n_kv * 128 + kvh * 128 + d] = f32_to_bf16(ak);
+  dv[(size_t)jb * n_kv * 128 + kvh * 128 + d] = f32_to_bf16(av);
 }
+extern "C" int vlaser_attn_rows_bwd_ws_floats(int n_q) { return n_q > 0 ? 2 * n_q * 256 : -1; }
 extern "C" int vlaser_attn_rows_bwd_ex(const void* q, const void* K, const void* VT, const void* dO, const void* O, void* dq, void* dk, void* dv, int R, int n_q,
-                                       int n_kv, int s_max, int valid_len, int blk_start, int first_tok_self, float scale, void* p_out, void* ds_out,
+                                       int n_kv, int s_max, int valid_len, int blk_start, int first_tok_self, float scale, void* p_out, void* ds_out, float* ws,
                                        vl_stream_t s);
 extern "C" int vlaser_attn_rows_bwd(const void* q, const void* K, const void* VT, const void* dO, const void* O, void* dq, void* dk, void* dv, int R, int n_q,
-                                    int n_kv, int s_max, int valid_len, int blk_start, int first_tok_self, float scale, vl_stream_t s) {
-  return vlaser_attn_rows_bwd_ex(q, K, VT, dO, O, dq, dk, dv, R, n_q, n_kv, s_max, valid_len, blk_start, first_tok_self, scale, nullptr, nullptr, s);
+                                    int n_kv, int s_max, int valid_len, int blk_start, int first_tok_self, float scale, float* ws, vl_stream_t s) {
+  return vlaser_attn_rows_bwd_ex(q, K, VT, dO, O, dq, dk, dv, R, n_q, n_kv, s_max, valid_len, blk_start, first_tok_self, scale, nullptr, nullptr, ws, s);
 }
 extern "C" int vlaser_attn_rows_bwd_ex(const void* q, const void* K, const void* VT, const void* dO, const void* O, void* dq, void* dk, void* dv, int R, int n_q,
-                                       int n_kv, int s_max, int valid_len, int blk_start, int first_tok_self, float scale, void* p_out, void* ds_out,
+                                       int n_kv, int s_max, int valid_len, int blk_start, int first_tok_self, float scale, void* p_out, void* ds_out, float* ws,
                                        vl_stream_t s) {
-  VL_CHECK(q && K && VT && dO && O && dq && dk && dv && (!p_out == !ds_out), "vlaser_attn_rows_bwd: null pointer");
+  VL_CHECK(q && K && VT && dO && O && dq && dk && dv && ws && (!p_out == !ds_out), "vlaser_attn_rows_bwd: null pointer (ws = vlaser_attn_rows_bwd_ws_floats(n_q) floats)");
   VL_CHECK(R >= 1 && R <= 16 && n_q % n_kv == 0 && blk_start + R <= s_max && blk_start + R <= ARB_MAXKEYS && valid_len <= blk_start,
            "vlaser_attn_rows_bwd: bad geometry (R <= 16, kv_len <= %d)", ARB_MAXKEYS);
-  hipLaunchKernelGGL(attn_rows_bwd_kernel, dim3(n_kv), dim3(256), 0, (hipStream_t)s, (const bf16_t*)q, (const bf16_t*)K, (const bf16_t*)VT, (const bf16_t*)dO,
-                     (const bf16_t*)O, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, R, n_q, n_kv, s_max, valid_len, blk_start, first_tok_self, scale, (bf16_t*)p_out,
-                     (bf16_t*)ds_out);
+  VL_CHECK((((uintptr_t)K) & 15) == 0 && s_max % 8 == 0, "vlaser_attn_rows_bwd: the K cache must be 16-byte aligned");
+  hipLaunchKernelGGL(attn_rows_bwd_kernel, dim3(n_q, R), dim3(256), 0, (hipStream_t)s, (const bf16_t*)q, (const bf16_t*)K, (const bf16_t*)VT, (const bf16_t*)dO,
+                     (const bf16_t*)O, (bf16_t*)dq, ws, R, n_q, n_kv, s_max, valid_len, blk_start, first_tok_self, scale, (bf16_t*)p_out, (bf16_t*)ds_out);
+  VL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_rows_bwd_kv_kernel, dim3(n_kv, R), dim3(128), 0, (hipStream_t)s, (const bf16_t*)q, (const bf16_t*)dO, ws, (bf16_t*)dk, (bf16_t*)dv, R, n_q, n_kv);
   VL_LAUNCH_CHECK();
   return 0;
 }

@@ -884,10 +884,13 @@ def silu_bwd(x, dy, dx):
     L.check(L.lib().vlaser_silu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _stream()), 'vlaser_silu_bwd')
 
 
-def attn_rows_bwd(q, K, VT, dO, O, dq, dk, dv, R, n_q, n_kv, s_max, valid_len, blk_start, first_tok_self, scale, p_out=None, ds_out=None):
+def attn_rows_bwd(q, K, VT, dO, O, dq, dk, dv, R, n_q, n_kv, s_max, valid_len, blk_start, first_tok_self, scale, p_out=None, ds_out=None, ws=None):
+    if ws is None:         # (a trainer passes its own; stream-ordered scratch otherwise)
+        ws = torch.empty(L.lib().vlaser_attn_rows_bwd_ws_floats(n_q), dtype=torch.float32, device=q.device)
+    assert ws.dtype == torch.float32 and ws.numel() >= L.lib().vlaser_attn_rows_bwd_ws_floats(n_q)
     L.check(L.lib().vlaser_attn_rows_bwd_ex(q.data_ptr(), K.data_ptr(), VT.data_ptr(), dO.data_ptr(), O.data_ptr(), dq.data_ptr(), dk.data_ptr(),
                                             dv.data_ptr(), R, n_q, n_kv, s_max, valid_len, blk_start, int(first_tok_self), scale, _p(p_out), _p(ds_out),
-                                            _stream()), 'vlaser_attn_rows_bwd')
+                                            ws.data_ptr(), _stream()), 'vlaser_attn_rows_bwd')
 
 
 # ------------------------------------------------------------------------------------------------ f1 with train_vlm: VLM-side backward

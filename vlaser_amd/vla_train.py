@@ -241,6 +241,7 @@ class VLATrainer:
         self.dh, self.dh2, self.dx = z(16, H), z(16, H), z(16, H)
         self.dact, self.dgu = z(16, I), z(16, 2 * I)
         self.dao, self.dq = z(16, nq * hd), z(16, nq * hd)
+        self.arb_ws = torch.zeros(L.lib().vlaser_attn_rows_bwd_ws_floats(nq), dtype=F32, device=self.device)      # block-key P / dS of vlaser_attn_rows_bwd
         self.dk, self.dv = z(16, nkv * hd), z(16, nkv * hd)
         self.dqkv = z(16, NQ)
         self.dv64, self.decT = z(16, 64), z(H, 64)
@@ -381,7 +382,7 @@ class VLATrainer:
             self._wgrad(dh2, ao, gv[f'l{i}.wo'], R)
             vg = self.vg
             ops.attn_rows_bwd(q, self.cache.k[i, 0], self.cache.vt[i, 0], dao[:R], ao, self.dq[:R], self.dk[:R], self.dv[:R], R, nq, nkv, self.s_max,
-                              n_valid, T, True, scale, p_out=None if vg is None else vg.p_rows, ds_out=None if vg is None else vg.ds_rows)
+                              n_valid, T, True, scale, p_out=None if vg is None else vg.p_rows, ds_out=None if vg is None else vg.ds_rows, ws=self.arb_ws)
             if vg is not None:                          # train_vlm: the prefix keys' dK / dV of this layer, then the VLM rows' own layer backward
                 vg.prefix_kv_grads((q, dao[:R]), R, nq, nkv)
                 vg.backward_layer(i, n_valid)

@@ -17,6 +17,8 @@ Forward = the inference kernels with every intermediate kept (the image/text row
 (NN dgrad on the weights as stored, TN wgrad, RMSNorm / SwiGLU / RoPE backward) with a bidirectional mask, plus LayerNorm / GELU / layer-scale /
 full-attention backward for the vision tower.  All arithmetic is HIP through the C ABI; torch holds buffers and does index plumbing.
 """
+import os
+
 import torch
 
 from . import _lib as L
@@ -120,6 +122,10 @@ class VLMGroup:
         self.dqkv = z(T, NQ)
         self.dkx, self.dvx = z(T, nkv * hd), z(T, nkv * hd)                    # prefix-key gradients from the expert rows of ONE layer
         self.p_rows, self.ds_rows = z(nq, 16, tr.s_max), z(nq, 16, tr.s_max)    # P / dS of the expert rows over every key
+        # fused attention backward of the VLM rows (r06): the forward's base-2 log-sum-exp per layer + the kernel's delta scratch
+        self.lse = torch.zeros(llm.num_hidden_layers, nq * T, dtype=F32, device=dev)
+        self.delta_ws = torch.zeros(nq * T, dtype=F32, device=dev)
+        self.fused_attn_bwd = os.environ.get('VLASER_VLA_VLM_ATTN_BWD', 'fused') != 'materialised'
         # ---- vision tower: saved activations per block + projector intermediates
         S, C, Cm, Hn, hdv = vis.num_positions, vis.hidden_size, vis.intermediate_size, vis.num_attention_heads, vis.head_dim
         sp = self.sp = tr.vit.s_pad
@@ -217,7 +223,7 @@ class VLMGroup:
             ops.gemm(L.EPI_QKV_ROPE, self.x1[i], g('wqkv'), bias=g('bqkv'), q_out=self.q[i], k_cache=tr.cache.k[i], vt_cache=tr.cache.vt[i], rope_cos=tr.rope[0],
                      rope_sin=tr.rope[1], pos_ids=tr.pos_vlm, n_q_heads=nq, n_kv_heads=nkv, s_max=tr.s_max, tok_per_batch=T, slot_base=0)
             ops.attn_prefill(self.q[i], tr.cache.k[i], tr.cache.vt[i], self.ao[i], 1, T, T, nq, nkv, hd, (T * nq * hd, hd, nq * hd), ks, vs, (T * nq * hd, nq * hd),
-                             tr.s_max, hd ** -0.5, L.ATTN_PREFIX, valid_len=tr.valid_len, blk_start=T)
+                             tr.s_max, hd ** -0.5, L.ATTN_PREFIX, valid_len=tr.valid_len, blk_start=T, lse_out=self.lse[i])
             if i == Lyr - 1:
                 break                                      # the last layer's post-attention half feeds nothing (final_layer_post_attn_skip_names)
             sp_o = ops.gemm_splits(T, H, nq * hd, self.part.numel())
@@ -264,8 +270,20 @@ class VLMGroup:
             ops.rmsnorm_bwd(dx, self.h2[i], g('ln_post'), dh, dh2, T, H, llm.rms_norm_eps, dw_out=gg('ln_post'), dw_ws=self.normw_ws)
             self._dgrad(dh2, g('wo'), dao)
             self._wgrad(dh2, self.ao[i], gg('wo'))
-            # attention backward through materialised score matrices; key k visible iff k < n_valid (bidirectional inside the valid prefix)
+            # attention backward; key k visible iff k < n_valid (bidirectional inside the valid prefix)
             Kc, VTc = tr.cache.k[i, 0], tr.cache.vt[i, 0]
+            if self.fused_attn_bwd:
+                # r06: the SFT step's fused kernel (csrc/attn_bwd.hip; causal = 0, kv_valid = the prefix length) instead of six launches through materialised
+                # [heads, T, T] fp32 score matrices: ~200 -> ~40 us per layer (profiles/r06ab_vla_train_kernel_stats.md)
+                ops.attn_bwd(self.q[i], Kc, VTc, self.ao[i], dao, self.lse[i], self.delta_ws, self.dq, self.dk, self.dv, T, nq, nkv, sm, scale, causal=False,
+                             kv_valid=n_valid, head_dim=hd)
+                ops.rope_bwd_pack_ex(self.dq, self.dk, self.dv, tr.rope[0], tr.rope[1], tr.pos_vlm, dqkv, T, nq, nkv, kv_per_q_head=True, dk_extra=self.dkx,
+                                     dv_extra=self.dvx)
+                dres = dh2
+                self._dgrad(dqkv, g('wqkv'), dx)
+                self._wgrad(dqkv, self.x1[i], gg('wqkv'), bias_out=gg('bqkv'))
+                ops.rmsnorm_bwd(dx, self.h_in[i], g('ln_in'), dres, dh, T, H, llm.rms_norm_eps, dw_out=gg('ln_in'), dw_ws=self.normw_ws)
+                return
             n = nq * T * Tp
             sc, dP = self.sc[:n].view(nq, T, Tp), self.dP[:n].view(nq, T, Tp)
             P, dS = self.P[:n].view(nq, T, Tp), self.dS[:n].view(nq, T, Tp)
