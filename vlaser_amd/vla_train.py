@@ -241,6 +241,7 @@ class VLATrainer:
         self.dh, self.dh2, self.dx = z(16, H), z(16, H), z(16, H)
         self.dact, self.dgu = z(16, I), z(16, 2 * I)
         self.dao, self.dq = z(16, nq * hd), z(16, nq * hd)
+        self.dgrad_part = torch.zeros(40 * 16 * 1536, dtype=F32, device=self.device)      # split-K slabs of the long-contraction dgrads (_dgrad)
         self.arb_ws = torch.zeros(L.lib().vlaser_attn_rows_bwd_ws_floats(nq), dtype=F32, device=self.device)      # block-key P / dS of vlaser_attn_rows_bwd
         self.dk, self.dv = z(16, nkv * hd), z(16, nkv * hd)
         self.dqkv = z(16, NQ)
@@ -261,7 +262,17 @@ class VLATrainer:
 
     # ------------------------------------------------------------------ small helpers
     def _dgrad(self, dY, W, out, M):
-        """out[M,K] = dY[M,N] @ W[N,K], W as the forward stores it (NN GEMM)."""
+        """out[M,K] = dY[M,N] @ W[N,K], W as the forward stores it (NN GEMM).  A long contraction over M <= 16 rows is a weight STREAM: the gate/up dgrad
+        ([5, 17920] @ [17920, 768]) has six output tiles, i.e. six workgroups pulling 27.5 MB (~80 us, r06ab trace); as many split-K slices as divide the
+        contraction put 240 workgroups on it, the fp32 slabs (a few hundred KB) are summed in slab order by one launch -- the rule of the SFT step's head dgrad."""
+        Nin, Kout = W.shape
+        if Nin > 2048 and Kout <= 4096 and Kout % 8 == 0:
+            sp = max(d for d in range(1, 41) if Nin % (64 * d) == 0)
+            if sp > 8 and sp * M * Kout <= self.dgrad_part.numel():
+                part = self.dgrad_part[:sp * M * Kout]
+                ops.gemm_nn(L.EPI_PARTIAL, dY[:M], W, out_f32=part, k_splits=sp)
+                ops.reduce_norm(None, part, sp, M, Kout, out[:M])
+                return
         ops.gemm_nn(L.EPI_NONE, dY[:M], W, out=out[:M])
 
     def _wgrad(self, dY, X, out, M, bias_out=None):
