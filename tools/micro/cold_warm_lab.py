@@ -1,4 +1,6 @@
-"""Lab (r06): does the gate/up weight stream of the <= 16-row path care where its 27.5 MB come from -- 28 separately allocated buffers (the model), 28 slices of one\ncontiguous allocation, the same buffer every launch (Infinity-Cache / TLB warm), 4 or 12 buffers cycled (inside / beyond the 256 MB Infinity Cache)?  In-graph us per launch.\npython tools/micro/cold_warm_lab.py"""
+"""Lab (r06): does the gate/up weight stream of the <= 16-row path care where its 27.5 MB come from -- 28 separately allocated buffers (the model), 28 slices of one
+contiguous allocation, the same buffer every launch (Infinity-Cache / TLB warm), 4 or 12 buffers cycled (inside / beyond the 256 MB Infinity Cache)?  In-graph us per launch.
+python tools/micro/cold_warm_lab.py"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
